@@ -1,0 +1,197 @@
+/*
+ * slimt_hip.h -- C ABI of the MI355X (gfx950) backend for slimt's int8
+ * transformer-NMT hot path. Plain pointers and sizes only; every function
+ * returns 0 on success or a non-zero status (slimt_hip_last_error() gives the
+ * message). No exceptions cross this boundary; nothing here falls back to a
+ * CPU implementation -- without a HIP device the compute entry points fail.
+ *
+ * Citations are file:line in the reference checkout (jerinphilip/slimt).
+ * The op-level group is what a `Provider::Hip` in slimt/QMM.cc would forward
+ * to (INTEGRATION.md shows the .inl.cc); the engine-level group is what
+ * `Encoder::forward` / `Decoder::step` / `Model::forward` dispatch to under
+ * SLIMT_HAS_HIP.
+ *
+ * Weight layout at this boundary is slimt's canonical prepared layout: int8
+ * [N][K], K contiguous (== the Marian intgemm8 payload, slimt/Io.cc:225-239),
+ * i.e. what prepare_weight_quantized_transposed below emits.
+ */
+#ifndef SLIMT_HIP_H
+#define SLIMT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLIMT_HIP_ABI_VERSION 1
+
+/* ---- status -------------------------------------------------------------- */
+int slimt_hip_abi_version(void);
+const char *slimt_hip_last_error(void); /* thread-local, never NULL */
+int slimt_hip_device_count(int *count);
+
+/* ---- op level: slimt::qmm::* (slimt/QMM.hh:48-63) ------------------------ */
+/* Host pointers in, host pointers out (H2D, kernels, D2H on `device` 0
+ * unless slimt_hip_set_device was called on this thread). Stateless and
+ * re-entrant like the reference providers (slimt/QMM.cc:36-75). */
+int slimt_hip_set_device(int device);
+
+/* qmm::affine (QMM.hh:48; Intgemm.inl.cc:92-156). bias == NULL gives
+ * qmm::dot (QMM.hh:56; Intgemm.inl.cc:158-226). x f32 [M,K] row-major,
+ * W int8 [N][K], y f32 [M,N]. Requires K % 64 == 0 (intgemm's own tile
+ * constraint), K <= 4096. */
+int slimt_hip_affine(const float *x, size_t M, size_t K, const int8_t *W_nk,
+                     size_t N, const float *bias, float a_quant,
+                     float b_quant, float *y);
+/* qmm::affine_with_select (QMM.hh:51; Intgemm.inl.cc:7-90): y [M,n_idx],
+ * column c is vocabulary id idx[c]. */
+int slimt_hip_affine_select(const float *x, size_t M, size_t K,
+                            const int8_t *W_nk, size_t N, const float *bias,
+                            float a_quant, float b_quant, const uint32_t *idx,
+                            size_t n_idx, float *y);
+/* Debug/parity: the raw int32 accumulators of Int8Shift::Multiply,
+ * accS[i,j] = sum_k (q[i,k]+127) * W[k,j]  (Intgemm.inl.cc:149-153). */
+int slimt_hip_affine_acc_i32(const float *x, size_t M, size_t K,
+                             const int8_t *W_nk, size_t N, float a_quant,
+                             int32_t *accS);
+/* qmm::prepare_weight_transposed (QMM.hh:59; Intgemm.inl.cc:228-235):
+ * weights f32 B^T [rows][cols] -> int8 canonical [rows][cols]. Runs on the
+ * host (load-time only, slimt/Io.cc:215). */
+int slimt_hip_prepare_weight_transposed(const float *weights, int8_t *prepared,
+                                        float quantization_multiplier,
+                                        size_t cols, size_t rows);
+/* qmm::prepare_weight_quantized_transposed (QMM.hh:62;
+ * Intgemm.inl.cc:237-243): the canonical layout IS the file layout, so this
+ * is a copy (like the Ruy provider, Ruy.inl.cc:267-274). Host side. */
+int slimt_hip_prepare_weight_quantized_transposed(const int8_t *input,
+                                                  int8_t *output, size_t rows,
+                                                  size_t cols);
+
+/* ---- op level: slimt/TensorOps.hh float ops ------------------------------ */
+/* layer_norm (TensorOps.cc:542-580) */
+int slimt_hip_layer_norm(const float *x, const float *scale, const float *bias,
+                         float eps, size_t rows, size_t cols, float *y);
+/* softmax (TensorOps.cc:282-315) */
+int slimt_hip_softmax(const float *x, size_t rows, size_t cols, float *y);
+/* highway (TensorOps.cc:662-682): out = sigmoid(g)*x + (1-sigmoid(g))*y */
+int slimt_hip_highway(const float *x, const float *y, const float *g, size_t n,
+                      float *out);
+/* scaled_dot_product_attention (Modules.cc:24-86) on already split heads:
+ * q [B,H,Tq,dh], k,v [B,H,S,dh], mask [B,S] additive -> out [B,H,Tq,dh],
+ * attn [B,H,Tq,S] (nullable). */
+int slimt_hip_sdpa(const float *q, const float *k, const float *v,
+                   const float *mask, size_t B, size_t H, size_t Tq, size_t S,
+                   size_t dh, float *out, float *attn);
+
+/* ---- engine level -------------------------------------------------------- */
+typedef struct slimt_hip_model slimt_hip_model; /* weights on one device */
+typedef struct slimt_hip_ctx slimt_hip_ctx;     /* stream + workspace, one per
+                                                   worker thread (Frontend.cc:212-226) */
+
+/* One named tensor as held by slimt::Transformer::items_ after
+ * io::load_items, or straight from the Marian .bin (Io.cc:114-161). */
+typedef struct slimt_hip_param {
+  const char *name; /* Marian parameter name (Modules.cc:336-406) */
+  int32_t type;     /* 0 = f32 [rows,cols]; 1 = intgemm8: int8 payload in file
+                       order ([cols][rows]; Wemb: [rows][cols]) followed by one
+                       f32 quantisation multiplier (Io.cc:225-239) */
+  int32_t rows;     /* shape[-2] */
+  int32_t cols;     /* shape[-1] */
+  const void *data; /* host memory, borrowed for the duration of the call */
+} slimt_hip_param;
+
+typedef struct slimt_hip_dims { /* Model::Config (Model.hh:33-51) */
+  int32_t encoder_layers;
+  int32_t decoder_layers;
+  int32_t num_heads;
+} slimt_hip_dims;
+
+/* Transformer::Transformer (Transformer.cc:87-94) + load_parameters
+ * (:185-225) + the Wemb handling of Io.cc:182-224: uploads and re-tiles the
+ * int8 weights for the MFMA B operand, precomputes column sums and prepared
+ * biases. Unknown names are ignored, missing ones are an error. */
+int slimt_hip_model_create(const slimt_hip_param *params, size_t n_params,
+                           const slimt_hip_dims *dims, int device,
+                           slimt_hip_model **out);
+int slimt_hip_model_destroy(slimt_hip_model *model);
+int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
+                         int32_t *dim_ffn, int32_t *vocab, int32_t *heads);
+
+/* stream: a hipStream_t to run on (borrowed), or NULL to create one. */
+int slimt_hip_ctx_create(slimt_hip_model *model, size_t max_batch,
+                         size_t max_source_length, void *stream,
+                         slimt_hip_ctx **out);
+int slimt_hip_ctx_destroy(slimt_hip_ctx *ctx);
+int slimt_hip_ctx_stream(slimt_hip_ctx *ctx, void **stream);
+int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
+
+/* Model::forward (Model.cc:187-204) = embed + Encoder::forward + the greedy
+ * loop of Model::decode (Model.cc:111-185). Host buffers.
+ *  src_ids  [B,S] padded token ids, lengths [B]
+ *  shortlist sorted unique target ids (Shortlist.cc:115-175), n_shortlist == 0
+ *            => full vocabulary (Transformer.cc:181)
+ *  out_ids  [B,Tmax], Tmax = (size_t)(limit_factor * S)  (Model.cc:160)
+ *  out_len  [B] tokens recorded per sentence, EOS included (Model.cc:127-137)
+ *  align    nullable [B,Tmax,S]: row t = attention of head 0 of the LAST
+ *           decoder layer over the first lengths[b] keys (Model.cc:84-108) */
+int slimt_hip_translate(slimt_hip_ctx *ctx, const uint32_t *src_ids,
+                        const uint32_t *lengths, size_t B, size_t S,
+                        const uint32_t *shortlist, size_t n_shortlist,
+                        float limit_factor, uint32_t eos_id, uint32_t *out_ids,
+                        uint32_t *out_len, float *align);
+/* Same with every buffer already resident in device memory; asynchronous on
+ * the ctx stream when `steps_hint` > 0 (runs exactly that many decode steps,
+ * no early-exit read-back), otherwise syncs every few steps to stop as soon
+ * as every sentence has emitted EOS. */
+int slimt_hip_translate_device(slimt_hip_ctx *ctx, const uint32_t *d_src_ids,
+                               const uint32_t *d_lengths, size_t B, size_t S,
+                               const uint32_t *d_shortlist, size_t n_shortlist,
+                               float limit_factor, uint32_t eos_id,
+                               uint32_t *d_out_ids, uint32_t *d_out_len,
+                               float *d_align, int steps_hint);
+
+/* Step-wise mirrors for parity tests ------------------------------------- */
+/* Model.cc:195-201: embed + Encoder::forward (Transformer.cc:57-69). Keeps
+ * the encoder output in the ctx for slimt_hip_decode_*. enc_out nullable
+ * host [B,S,D]; layer_out nullable host [Le,B,S,D] (every layer's output);
+ * embed_out nullable host [B,S,D]. */
+int slimt_hip_encode(slimt_hip_ctx *ctx, const uint32_t *src_ids,
+                     const uint32_t *lengths, size_t B, size_t S,
+                     float *embed_out, float *layer_out, float *enc_out);
+/* Decoder::start_states (Transformer.cc:78-85) + per-batch setup (cross
+ * attention K/V, shortlist gather). */
+int slimt_hip_decode_begin(slimt_hip_ctx *ctx, const uint32_t *shortlist,
+                           size_t n_shortlist);
+/* Decoder::step (Transformer.cc:120-183). prev == NULL => first step.
+ * logits host [B,N] (N = n_shortlist or vocab), attn nullable host [B,H,S]
+ * (last decoder layer), states nullable host [Ld,B,D] (SSRU cells after the
+ * step). */
+int slimt_hip_decode_step(slimt_hip_ctx *ctx, const uint32_t *prev,
+                          float *logits, float *attn, float *states);
+
+/* ---- measurement --------------------------------------------------------- */
+/* When enabled, HIP events bracket every launch of kernel family `kernel_id`
+ * on the ctx stream; slimt_hip_profile_read returns the number of launches
+ * and their summed duration since the last reset. */
+enum {
+  SLIMT_HIP_K_NONE = 0,
+  SLIMT_HIP_K_GEMM_ENC = 1,    /* encoder projections (M = B*S rows)       */
+  SLIMT_HIP_K_GEMM_DEC = 2,    /* decoder projections (M = B rows)         */
+  SLIMT_HIP_K_LOGITS = 3,      /* output projection + fused argmax         */
+  SLIMT_HIP_K_ATTN_ENC = 4,
+  SLIMT_HIP_K_ATTN_DEC = 5,
+  SLIMT_HIP_K_SSRU = 6,
+  SLIMT_HIP_K_COUNT = 7
+};
+int slimt_hip_profile_enable(slimt_hip_ctx *ctx, int kernel_id);
+int slimt_hip_profile_read(slimt_hip_ctx *ctx, uint64_t *launches,
+                           double *total_ms, double *int8_macs,
+                           double *weight_bytes);
+int slimt_hip_profile_reset(slimt_hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLIMT_HIP_H */

@@ -377,7 +377,10 @@ void so_add(const float *a, const float *b, size_t n, float *out) {
 /* TensorOps.cc:245-265 */
 void so_sinusoidal_signal(int start, size_t seq, size_t dim, float *out) {
   float num_timescales = (float)dim / 2;
-  float log_timescale_increment = logf(10000.0f) / (num_timescales - 1.0f);
+  /* std::log(10000.0F) as its correctly rounded f32 value (what a constant-
+   * folding compiler emits); avoids libm/compiler disagreement in the last bit */
+  const float log_10000 = 9.210340371976184f;
+  float log_timescale_increment = log_10000 / (num_timescales - 1.0f);
   for (size_t p = (size_t)start; p < seq + (size_t)start; ++p) {
     for (int i = 0; i < num_timescales; ++i) {
       float v = p * expf(i * -log_timescale_increment);

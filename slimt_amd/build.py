@@ -1,0 +1,72 @@
+"""Build libslimt_hip.so (gfx950 only) in-tree with hipcc.
+
+The library is the product: HIP kernels + the extern "C" boundary declared in
+include/slimt_hip.h. It is built into slimt_amd/lib/ so that it travels with
+the source tree (no JIT cache, no site-packages install).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libslimt_hip.so")
+
+SOURCES = ["kernels.hip", "engine.cpp"]
+HEADERS = ["kernels.h", "engine.h", "device_common.h", os.path.join(ROOT, "include", "slimt_hip.h")]
+
+# -ffp-contract=off: the float epilogues are written operation by operation
+# (separate mul/add like intgemm's callbacks); fused ops are explicit fmaf.
+FLAGS = [
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-shared",
+    "--offload-arch=gfx950",
+    "-ffp-contract=off",
+    "-fno-fast-math",
+    "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fno-gpu-flush-denormals-to-zero",
+    "-Wall",
+    "-Wno-unused-result",
+    "-x", "hip",
+]
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [
+        h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS
+    ] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + [
+        "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH,
+    ]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,347 @@
+"""ctypes binding of include/slimt_hip.h (slimt_amd/lib/libslimt_hip.so).
+
+Thin: numpy arrays in/out, every call goes through the C ABI exactly as a
+cgo/JNI/C++ host would. There is no fallback: if the library is missing or a
+call fails, SlimtHipError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import build as _build
+
+SYMBOLS = [
+    "slimt_hip_abi_version", "slimt_hip_last_error", "slimt_hip_device_count",
+    "slimt_hip_set_device", "slimt_hip_affine", "slimt_hip_affine_select",
+    "slimt_hip_affine_acc_i32", "slimt_hip_prepare_weight_transposed",
+    "slimt_hip_prepare_weight_quantized_transposed", "slimt_hip_layer_norm",
+    "slimt_hip_softmax", "slimt_hip_highway", "slimt_hip_sdpa",
+    "slimt_hip_model_create", "slimt_hip_model_destroy", "slimt_hip_model_info",
+    "slimt_hip_ctx_create", "slimt_hip_ctx_destroy", "slimt_hip_ctx_stream",
+    "slimt_hip_ctx_synchronize", "slimt_hip_translate", "slimt_hip_translate_device",
+    "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
+    "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
+]
+
+K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU = range(7)
+KERNEL_NAMES = {K_GEMM_ENC: "gemm_enc", K_GEMM_DEC: "gemm_dec", K_LOGITS: "logits_argmax",
+                K_ATTN_ENC: "attn_enc", K_ATTN_DEC: "attn_dec", K_SSRU: "ssru"}
+
+
+class SlimtHipError(RuntimeError):
+    pass
+
+
+class _Param(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("type", C.c_int32), ("rows", C.c_int32),
+                ("cols", C.c_int32), ("data", C.c_void_p)]
+
+
+class _Dims(C.Structure):
+    _fields_ = [("encoder_layers", C.c_int32), ("decoder_layers", C.c_int32),
+                ("num_heads", C.c_int32)]
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def lib():
+    """Load libslimt_hip.so (must have been built: __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise SlimtHipError(
+            f"{path} is missing: build it with `python -m slimt_amd.build` "
+            "(there is no CPU fallback)")
+    L = C.CDLL(path)
+    vp, f32, sz, i32, u32 = C.c_void_p, C.c_float, C.c_size_t, C.c_int, C.c_uint32
+    L.slimt_hip_abi_version.restype = i32
+    L.slimt_hip_last_error.restype = C.c_char_p
+    L.slimt_hip_device_count.argtypes = [vp]
+    L.slimt_hip_set_device.argtypes = [i32]
+    L.slimt_hip_affine.argtypes = [vp, sz, sz, vp, sz, vp, f32, f32, vp]
+    L.slimt_hip_affine_select.argtypes = [vp, sz, sz, vp, sz, vp, f32, f32, vp, sz, vp]
+    L.slimt_hip_affine_acc_i32.argtypes = [vp, sz, sz, vp, sz, f32, vp]
+    L.slimt_hip_prepare_weight_transposed.argtypes = [vp, vp, f32, sz, sz]
+    L.slimt_hip_prepare_weight_quantized_transposed.argtypes = [vp, vp, sz, sz]
+    L.slimt_hip_layer_norm.argtypes = [vp, vp, vp, f32, sz, sz, vp]
+    L.slimt_hip_softmax.argtypes = [vp, sz, sz, vp]
+    L.slimt_hip_highway.argtypes = [vp, vp, vp, sz, vp]
+    L.slimt_hip_sdpa.argtypes = [vp, vp, vp, vp, sz, sz, sz, sz, sz, vp, vp]
+    L.slimt_hip_model_create.argtypes = [vp, sz, vp, i32, vp]
+    L.slimt_hip_model_destroy.argtypes = [vp]
+    L.slimt_hip_model_info.argtypes = [vp, vp, vp, vp, vp]
+    L.slimt_hip_ctx_create.argtypes = [vp, sz, sz, vp, vp]
+    L.slimt_hip_ctx_destroy.argtypes = [vp]
+    L.slimt_hip_ctx_stream.argtypes = [vp, vp]
+    L.slimt_hip_ctx_synchronize.argtypes = [vp]
+    L.slimt_hip_translate.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp]
+    L.slimt_hip_translate_device.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp, i32]
+    L.slimt_hip_encode.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp]
+    L.slimt_hip_decode_begin.argtypes = [vp, vp, sz]
+    L.slimt_hip_decode_step.argtypes = [vp, vp, vp, vp, vp]
+    L.slimt_hip_profile_enable.argtypes = [vp, i32]
+    L.slimt_hip_profile_read.argtypes = [vp, vp, vp, vp, vp]
+    L.slimt_hip_profile_reset.argtypes = [vp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("slimt_hip_abi_version",):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _chk(rc: int) -> None:
+    if rc != 0:
+        raise SlimtHipError(f"slimt_hip error {rc}: {lib().slimt_hip_last_error().decode()}")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().slimt_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+# ---- op level (slimt::qmm / TensorOps) ---------------------------------------
+
+def affine(x, W_nk, bias, a_quant: float, b_quant: float):
+    """qmm::affine; bias=None gives qmm::dot. W_nk: int8 [N][K]."""
+    x = _f32(x)
+    W = np.ascontiguousarray(W_nk, dtype=np.int8)
+    N, K = W.shape
+    M = x.size // K
+    b = None if bias is None else _f32(bias).reshape(-1)
+    y = np.empty(x.shape[:-1] + (N,), dtype=np.float32)
+    _chk(lib().slimt_hip_affine(_p(x), M, K, _p(W), N, _p(b), a_quant, b_quant, _p(y)))
+    return y
+
+
+def dot(x, W_nk, a_quant: float, b_quant: float):
+    return affine(x, W_nk, None, a_quant, b_quant)
+
+
+def affine_with_select(x, W_nk, bias, a_quant, b_quant, indices):
+    x = _f32(x)
+    W = np.ascontiguousarray(W_nk, dtype=np.int8)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    N, K = W.shape
+    M = x.size // K
+    b = _f32(bias).reshape(-1)
+    y = np.empty(x.shape[:-1] + (idx.size,), dtype=np.float32)
+    _chk(lib().slimt_hip_affine_select(_p(x), M, K, _p(W), N, _p(b), a_quant, b_quant, _p(idx),
+                                       idx.size, _p(y)))
+    return y
+
+
+def affine_acc_i32(x, W_nk, a_quant: float):
+    x = _f32(x)
+    W = np.ascontiguousarray(W_nk, dtype=np.int8)
+    N, K = W.shape
+    M = x.size // K
+    acc = np.empty((M, N), dtype=np.int32)
+    _chk(lib().slimt_hip_affine_acc_i32(_p(x), M, K, _p(W), N, a_quant, _p(acc)))
+    return acc
+
+
+def prepare_weight_transposed(weights, quant_mult: float):
+    w = _f32(weights)
+    rows, cols = w.shape
+    out = np.empty((rows, cols), dtype=np.int8)
+    _chk(lib().slimt_hip_prepare_weight_transposed(_p(w), _p(out), quant_mult, cols, rows))
+    return out
+
+
+def prepare_weight_quantized_transposed(w_nk, rows: int, cols: int):
+    w = np.ascontiguousarray(w_nk, dtype=np.int8)
+    out = np.empty_like(w)
+    _chk(lib().slimt_hip_prepare_weight_quantized_transposed(_p(w), _p(out), rows, cols))
+    return out
+
+
+def layer_norm(x, scale, bias, eps: float = 1e-6):
+    x = _f32(x)
+    s, b = _f32(scale).reshape(-1), _f32(bias).reshape(-1)
+    cols = x.shape[-1]
+    y = np.empty_like(x)
+    _chk(lib().slimt_hip_layer_norm(_p(x), _p(s), _p(b), eps, x.size // cols, cols, _p(y)))
+    return y
+
+
+def softmax(x):
+    x = _f32(x)
+    cols = x.shape[-1]
+    y = np.empty_like(x)
+    _chk(lib().slimt_hip_softmax(_p(x), x.size // cols, cols, _p(y)))
+    return y
+
+
+def highway(x, y, g):
+    x, y, g = _f32(x), _f32(y), _f32(g)
+    out = np.empty_like(x)
+    _chk(lib().slimt_hip_highway(_p(x), _p(y), _p(g), x.size, _p(out)))
+    return out
+
+
+def sdpa(q, k, v, mask, want_attn: bool = True):
+    q, k, v, mask = _f32(q), _f32(k), _f32(v), _f32(mask)
+    B, H, Tq, dh = q.shape
+    S = k.shape[2]
+    out = np.empty_like(q)
+    attn = np.empty((B, H, Tq, S), dtype=np.float32) if want_attn else None
+    _chk(lib().slimt_hip_sdpa(_p(q), _p(k), _p(v), _p(mask), B, H, Tq, S, dh, _p(out), _p(attn)))
+    return out, attn
+
+
+# ---- engine level --------------------------------------------------------------
+
+class Model:
+    """Device-resident slimt::Transformer (weights on one GPU)."""
+
+    def __init__(self, model, device: int = 0):
+        """model: slimt_amd.synth.Model (or anything with .params/.H/...)."""
+        keep = []
+        arr = (_Param * len(model.params))()
+        for i, p in enumerate(model.params.values()):
+            buf = np.frombuffer(p.payload(), dtype=np.uint8).copy()
+            name = p.name.encode()
+            keep += [buf, name]
+            arr[i] = _Param(name, 0 if p.kind == "f32" else 1, p.rows, p.cols,
+                            buf.ctypes.data_as(C.c_void_p))
+        dims = _Dims(model.enc_layers, model.dec_layers, model.H)
+        h = C.c_void_p()
+        _chk(lib().slimt_hip_model_create(C.cast(arr, C.c_void_p), len(model.params),
+                                          C.byref(dims), device, C.byref(h)))
+        self.h = h
+        self.device = device
+        self.D, self.F, self.H, self.V = model.D, model.F, model.H, model.V
+        self.Le, self.Ld = model.enc_layers, model.dec_layers
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().slimt_hip_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One worker's stream + workspace (mirrors one slimt Async worker)."""
+
+    def __init__(self, model: Model, max_batch: int, max_source_length: int, stream: int = 0):
+        self.model = model
+        h = C.c_void_p()
+        _chk(lib().slimt_hip_ctx_create(model.h, max_batch, max_source_length,
+                                        C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.B = self.S = 0
+        self.N = model.V
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().slimt_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        s = C.c_void_p()
+        _chk(lib().slimt_hip_ctx_stream(self.h, C.byref(s)))
+        return s.value or 0
+
+    def synchronize(self):
+        _chk(lib().slimt_hip_ctx_synchronize(self.h))
+
+    def translate(self, ids, lengths, shortlist=None, limit_factor: float = 1.5, eos_id: int = 0,
+                  want_align: bool = False):
+        """Model::forward. Returns out_ids [B,Tmax], out_len [B], align|None."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        B, S = ids.shape
+        Tmax = int(np.float32(limit_factor) * np.float32(S))
+        T = max(Tmax, 1)
+        sl = None if shortlist is None else np.ascontiguousarray(shortlist, dtype=np.uint32)
+        out_ids = np.zeros((B, T), dtype=np.uint32)
+        out_len = np.zeros(B, dtype=np.uint32)
+        align = np.zeros((B, T, S), dtype=np.float32) if want_align else None
+        _chk(lib().slimt_hip_translate(self.h, _p(ids), _p(lengths), B, S, _p(sl),
+                                       0 if sl is None else sl.size, limit_factor, eos_id,
+                                       _p(out_ids), _p(out_len), _p(align)))
+        return out_ids, out_len, align
+
+    def translate_device(self, d_ids: int, d_lengths: int, B: int, S: int, d_shortlist: int,
+                         n_shortlist: int, limit_factor: float, eos_id: int, d_out_ids: int,
+                         d_out_len: int, d_align: int = 0, steps_hint: int = 0):
+        """Device pointers (ints) in and out; asynchronous when steps_hint > 0."""
+        vp = C.c_void_p
+        _chk(lib().slimt_hip_translate_device(
+            self.h, vp(d_ids), vp(d_lengths), B, S, vp(d_shortlist) if n_shortlist else None,
+            n_shortlist, limit_factor, eos_id, vp(d_out_ids), vp(d_out_len),
+            vp(d_align) if d_align else None, steps_hint))
+
+    def encode(self, ids, lengths, want_embed=False, want_layers=False):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        B, S = ids.shape
+        D, Le = self.model.D, self.model.Le
+        emb = np.empty((B, S, D), dtype=np.float32) if want_embed else None
+        layers = np.empty((Le, B, S, D), dtype=np.float32) if want_layers else None
+        out = np.empty((B, S, D), dtype=np.float32)
+        _chk(lib().slimt_hip_encode(self.h, _p(ids), _p(lengths), B, S, _p(emb), _p(layers), _p(out)))
+        self.B, self.S = B, S
+        return out, emb, layers
+
+    def decode_begin(self, shortlist=None):
+        sl = None if shortlist is None else np.ascontiguousarray(shortlist, dtype=np.uint32)
+        _chk(lib().slimt_hip_decode_begin(self.h, _p(sl), 0 if sl is None else sl.size))
+        self.N = self.model.V if sl is None else sl.size
+
+    def decode_step(self, prev=None, want_attn=True, want_states=True):
+        """Decoder::step. Returns logits [B,N], attn [B,H,1,S], states [Ld,B,D]."""
+        B, S, m = self.B, self.S, self.model
+        pv = None if prev is None else np.ascontiguousarray(prev, dtype=np.uint32)
+        logits = np.empty((B, self.N), dtype=np.float32)
+        attn = np.empty((B, m.H, 1, S), dtype=np.float32) if want_attn else None
+        states = np.empty((m.Ld, B, m.D), dtype=np.float32) if want_states else None
+        _chk(lib().slimt_hip_decode_step(self.h, _p(pv), _p(logits), _p(attn), _p(states)))
+        return logits, attn, states
+
+    def profile_enable(self, kernel_id: int):
+        _chk(lib().slimt_hip_profile_enable(self.h, kernel_id))
+
+    def profile_reset(self):
+        _chk(lib().slimt_hip_profile_reset(self.h))
+
+    def profile_read(self):
+        n = C.c_uint64(0)
+        ms, macs, wbytes = C.c_double(0), C.c_double(0), C.c_double(0)
+        _chk(lib().slimt_hip_profile_read(self.h, C.byref(n), C.byref(ms), C.byref(macs),
+                                          C.byref(wbytes)))
+        return {"launches": n.value, "total_ms": ms.value, "int8_macs": macs.value,
+                "weight_bytes": wbytes.value}

@@ -1,0 +1,98 @@
+// Device-side numerics shared by every kernel (gfx950 only).
+//
+// The float contract ("portable order", stated in DESIGN.md; the test oracle
+// restates it independently on the CPU):
+//  * every float expression is evaluated literally (this TU is compiled with
+//    -ffp-contract=off; fused multiply-adds are written as __builtin_fmaf);
+//  * exp is the fixed fmaf polynomial below, never the ocml/libm one;
+//  * a row sum is "lane = i % 64 adds its elements in ascending i, then a xor
+//    butterfly with masks 1,2,4,8,16,32" -- the natural wave64 reduction;
+//  * division and sqrt are the correctly rounded IEEE ones
+//    (-fhip-fp32-correctly-rounded-divide-sqrt, hipcc's default).
+// With that the GPU reproduces the CPU restatement of the reference bit for
+// bit, and differs from the reference's own scalar libm path by float
+// rounding only (<= ~1e-6 relative, tests/test_oracle.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slimt_hip {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float exp_p(float x) {
+  if (x < -86.0f) return 0.0f;
+  if (x > 88.0f) x = 88.0f;
+  float n = __builtin_rintf(x * 1.44269504088896341f);
+  float r = __builtin_fmaf(n, -0.693359375f, x);
+  r = __builtin_fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  float r2 = r * r;
+  float y = __builtin_fmaf(p, r2, r) + 1.0f;
+  int ni = (int)n;
+  return y * __int_as_float((ni + 127) << 23);
+}
+
+// TensorOps.cc:33-36
+__device__ __forceinline__ float sigmoid_p(float x) {
+  if (x > 0) return 1.0f / (1.0f + exp_p(-x));
+  float e = exp_p(x);
+  return e / (1.0f + e);
+}
+
+// xor butterfly over the 64 lanes, masks ascending; all lanes end equal.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// intgemm PrepareA: round-to-nearest-even, clamp to [-127, 127]
+// (Intgemm.inl.cc:29-34).
+__device__ __forceinline__ int quantize1(float x, float a_quant) {
+  float v = __builtin_rintf(x * a_quant);
+  v = v < -127.0f ? -127.0f : v;
+  v = v > 127.0f ? 127.0f : v;
+  if (v != v) v = 0.0f;
+  return (int)v;
+}
+
+__device__ __forceinline__ int pack4(int a, int b, int c, int d) {
+  return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24);
+}
+
+// Canonical LayerNorm of one row by one wave (TensorOps.cc:542-580).
+// x, y may alias. All 64 lanes must call.
+__device__ __forceinline__ void wave_layer_norm_row(const float *x, const float *scale,
+                                                    const float *bias, float eps, int D,
+                                                    float *y, int lane) {
+  float s = 0.0f;
+  for (int i = lane; i < D; i += 64) s += x[i];
+  s = wave_sum(s);
+  float mean = s / (float)D;
+  float q = 0.0f;
+  for (int i = lane; i < D; i += 64) {
+    float v = x[i] - mean;
+    q += v * v;
+  }
+  q = wave_sum(q);
+  float sigma = __builtin_sqrtf(q / (float)D + eps);
+  for (int i = lane; i < D; i += 64) {
+    float t = (x[i] - mean) / sigma;
+    float sc = scale[i] * t;
+    y[i] = sc + bias[i];
+  }
+}
+
+}  // namespace slimt_hip

@@ -1,0 +1,1114 @@
+// C ABI (include/slimt_hip.h) + host-side engine of the MI355X slimt backend.
+#include "engine.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+
+using namespace slimt_hip;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code ? code : -1;
+}
+
+#define HIPCHK(expr)                                                                    \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail((int)e_, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+#define RCCHK(expr)        \
+  do {                     \
+    int rc_ = (expr);      \
+    if (rc_) return rc_;   \
+  } while (0)
+
+hipError_t DevBuf::reserve(size_t n) {
+  if (n <= bytes && p) return hipSuccess;
+  if (p) {
+    hipError_t e = hipFree(p);
+    if (e != hipSuccess) return e;
+    p = nullptr;
+    bytes = 0;
+  }
+  if (n == 0) n = 16;
+  hipError_t e = hipMalloc(&p, n);
+  if (e == hipSuccess) bytes = n;
+  return e;
+}
+
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  bytes = 0;
+}
+
+extern "C" int slimt_hip_abi_version(void) { return SLIMT_HIP_ABI_VERSION; }
+extern "C" const char *slimt_hip_last_error(void) { return g_err; }
+
+extern "C" int slimt_hip_device_count(int *count) {
+  if (!count) return fail(-1, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail((int)e, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return 0;
+}
+
+extern "C" int slimt_hip_set_device(int device) {
+  HIPCHK(hipSetDevice(device));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// host-side weight preparation (load time; slimt/Io.cc:215,234)
+// ---------------------------------------------------------------------------
+extern "C" int slimt_hip_prepare_weight_transposed(const float *weights, int8_t *prepared,
+                                                   float quantization_multiplier, size_t cols,
+                                                   size_t rows) {
+  if (!weights || !prepared) return fail(-1, "null argument");
+  const size_t n = rows * cols;
+  for (size_t i = 0; i < n; ++i) {
+    float v = rintf(weights[i] * quantization_multiplier);
+    v = v < -127.0f ? -127.0f : v;
+    v = v > 127.0f ? 127.0f : v;
+    if (v != v) v = 0.0f;
+    prepared[i] = (int8_t)v;
+  }
+  return 0;
+}
+
+extern "C" int slimt_hip_prepare_weight_quantized_transposed(const int8_t *input, int8_t *output,
+                                                             size_t rows, size_t cols) {
+  if (!input || !output) return fail(-1, "null argument");
+  if (input != output) memmove(output, input, rows * cols);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// op level
+// ---------------------------------------------------------------------------
+namespace {
+
+struct TmpAffine {  // device temporaries of one stateless qmm call
+  DevBuf x, W, bias, idx, y;
+  AffineW aw;
+  ~TmpAffine() {
+    x.release(); W.release(); bias.release(); idx.release(); y.release();
+    aw.Wp.release(); aw.colsum.release(); aw.pb.release();
+  }
+};
+
+int prepare_affine(AffineW &aw, const int8_t *dW, int K, int N, const uint32_t *d_idx,
+                   const float *d_bias, float a_quant, float b_quant, hipStream_t st) {
+  const int n_tiles = (N + 15) / 16;
+  HIPCHK(aw.Wp.reserve(packed_weight_bytes(K, N)));
+  HIPCHK(aw.colsum.reserve((size_t)n_tiles * 16 * sizeof(int)));
+  HIPCHK(aw.pb.reserve((size_t)n_tiles * 16 * sizeof(float)));
+  HIPCHK(launch_pack_weight(dW, K, N, d_idx, d_bias, a_quant, b_quant, aw.Wp.p,
+                            aw.colsum.as<int>(), aw.pb.as<float>(), st));
+  aw.w.Wp = aw.Wp.p;
+  aw.w.colsum = aw.colsum.as<int>();
+  aw.w.pb = aw.pb.as<float>();
+  aw.w.u = 1.0f / (a_quant * b_quant);  // Intgemm.inl.cc:146
+  aw.w.a_quant = a_quant;
+  aw.w.b_quant = b_quant;
+  aw.w.K = K;
+  aw.w.N = N;
+  aw.w.n_tiles = n_tiles;
+  return 0;
+}
+
+int affine_common(const float *x, size_t M, size_t K, const int8_t *W_nk, size_t N,
+                  const float *bias, float a_quant, float b_quant, const uint32_t *idx,
+                  size_t n_idx, float *y, int32_t *acc) {
+  if (!x || !W_nk || (!y && !acc)) return fail(-1, "null argument");
+  if (K == 0 || K % 64 != 0 || K > 4096) return fail(-1, "K=%zu must be a multiple of 64, <= 4096", K);
+  if (M == 0 || N == 0) return fail(-1, "empty operand");
+  if (idx && n_idx == 0) return fail(-1, "empty index list");
+  hipStream_t st = nullptr;
+  TmpAffine t;
+  const size_t Nout = idx ? n_idx : N;
+  HIPCHK(t.x.reserve(M * K * sizeof(float)));
+  HIPCHK(t.W.reserve(N * K));
+  HIPCHK(hipMemcpyAsync(t.x.p, x, M * K * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(t.W.p, W_nk, N * K, hipMemcpyHostToDevice, st));
+  if (bias) {
+    HIPCHK(t.bias.reserve(N * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(t.bias.p, bias, N * sizeof(float), hipMemcpyHostToDevice, st));
+  }
+  if (idx) {
+    for (size_t i = 0; i < n_idx; ++i)
+      if (idx[i] >= N) return fail(-1, "index %u out of range (N=%zu)", idx[i], N);
+    HIPCHK(t.idx.reserve(n_idx * sizeof(uint32_t)));
+    HIPCHK(hipMemcpyAsync(t.idx.p, idx, n_idx * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  }
+  RCCHK(prepare_affine(t.aw, t.W.as<int8_t>(), (int)K, (int)Nout, idx ? t.idx.as<uint32_t>() : nullptr,
+                       bias ? t.bias.as<float>() : nullptr, a_quant, b_quant, st));
+  GemmArgs g;
+  g.x_f32 = t.x.as<float>();
+  g.lda = (int)K;
+  g.M = (int)M;
+  g.w = t.aw.w;
+  if (acc) {
+    HIPCHK(t.y.reserve(M * Nout * sizeof(int32_t)));
+    g.acc_out = t.y.as<int32_t>();
+    HIPCHK(launch_gemm(g, EPI_ACC, M >= 64 ? 64 : 16, st));
+    HIPCHK(hipMemcpyAsync(acc, t.y.p, M * Nout * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  } else {
+    HIPCHK(t.y.reserve(M * Nout * sizeof(float)));
+    g.y = t.y.as<float>();
+    g.ldy = (int)Nout;
+    HIPCHK(launch_gemm(g, EPI_PLAIN, M >= 64 ? 64 : 16, st));
+    HIPCHK(hipMemcpyAsync(y, t.y.p, M * Nout * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int slimt_hip_affine(const float *x, size_t M, size_t K, const int8_t *W_nk, size_t N,
+                                const float *bias, float a_quant, float b_quant, float *y) {
+  return affine_common(x, M, K, W_nk, N, bias, a_quant, b_quant, nullptr, 0, y, nullptr);
+}
+
+extern "C" int slimt_hip_affine_select(const float *x, size_t M, size_t K, const int8_t *W_nk,
+                                       size_t N, const float *bias, float a_quant, float b_quant,
+                                       const uint32_t *idx, size_t n_idx, float *y) {
+  if (!idx) return fail(-1, "idx is NULL");
+  return affine_common(x, M, K, W_nk, N, bias, a_quant, b_quant, idx, n_idx, y, nullptr);
+}
+
+extern "C" int slimt_hip_affine_acc_i32(const float *x, size_t M, size_t K, const int8_t *W_nk,
+                                        size_t N, float a_quant, int32_t *accS) {
+  return affine_common(x, M, K, W_nk, N, nullptr, a_quant, 1.0f, nullptr, 0, nullptr, accS);
+}
+
+namespace {
+struct Tmp3 {
+  DevBuf a, b, c, d, e, f;
+  ~Tmp3() { a.release(); b.release(); c.release(); d.release(); e.release(); f.release(); }
+};
+}  // namespace
+
+extern "C" int slimt_hip_layer_norm(const float *x, const float *scale, const float *bias,
+                                    float eps, size_t rows, size_t cols, float *y) {
+  if (!x || !scale || !bias || !y || !rows || !cols) return fail(-1, "bad argument");
+  Tmp3 t;
+  hipStream_t st = nullptr;
+  HIPCHK(t.a.reserve(rows * cols * 4));
+  HIPCHK(t.b.reserve(cols * 4));
+  HIPCHK(t.c.reserve(cols * 4));
+  HIPCHK(t.d.reserve(rows * cols * 4));
+  HIPCHK(hipMemcpyAsync(t.a.p, x, rows * cols * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(t.b.p, scale, cols * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(t.c.p, bias, cols * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(launch_layer_norm(t.a.as<float>(), t.b.as<float>(), t.c.as<float>(), eps, (int)rows,
+                           (int)cols, t.d.as<float>(), st));
+  HIPCHK(hipMemcpyAsync(y, t.d.p, rows * cols * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int slimt_hip_softmax(const float *x, size_t rows, size_t cols, float *y) {
+  if (!x || !y || !rows || !cols) return fail(-1, "bad argument");
+  Tmp3 t;
+  hipStream_t st = nullptr;
+  HIPCHK(t.a.reserve(rows * cols * 4));
+  HIPCHK(t.b.reserve(rows * cols * 4));
+  HIPCHK(hipMemcpyAsync(t.a.p, x, rows * cols * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(launch_softmax(t.a.as<float>(), (int)rows, (int)cols, t.b.as<float>(), st));
+  HIPCHK(hipMemcpyAsync(y, t.b.p, rows * cols * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int slimt_hip_highway(const float *x, const float *y, const float *g, size_t n,
+                                 float *out) {
+  if (!x || !y || !g || !out || !n) return fail(-1, "bad argument");
+  Tmp3 t;
+  hipStream_t st = nullptr;
+  HIPCHK(t.a.reserve(n * 4));
+  HIPCHK(t.b.reserve(n * 4));
+  HIPCHK(t.c.reserve(n * 4));
+  HIPCHK(t.d.reserve(n * 4));
+  HIPCHK(hipMemcpyAsync(t.a.p, x, n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(t.b.p, y, n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(t.c.p, g, n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(launch_highway(t.a.as<float>(), t.b.as<float>(), t.c.as<float>(), n, t.d.as<float>(), st));
+  HIPCHK(hipMemcpyAsync(out, t.d.p, n * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int slimt_hip_sdpa(const float *q, const float *k, const float *v, const float *mask,
+                              size_t B, size_t H, size_t Tq, size_t S, size_t dh, float *out,
+                              float *attn) {
+  if (!q || !k || !v || !mask || !out) return fail(-1, "null argument");
+  if (S < 1 || S > 128 || dh < 1 || dh > 64) return fail(-1, "unsupported S=%zu dh=%zu", S, dh);
+  Tmp3 t;
+  DevBuf qj, kj, vj, oj, ob;
+  struct G { DevBuf *b[5]; ~G() { for (auto *x : b) x->release(); } } guard{{&qj, &kj, &vj, &oj, &ob}};
+  hipStream_t st = nullptr;
+  const size_t D = H * dh;
+  const size_t nq = B * Tq * D * 4, nk = B * S * D * 4;
+  HIPCHK(t.a.reserve(nq)); HIPCHK(t.b.reserve(nk)); HIPCHK(t.c.reserve(nk));
+  HIPCHK(t.d.reserve(B * S * 4));
+  HIPCHK(qj.reserve(nq)); HIPCHK(kj.reserve(nk)); HIPCHK(vj.reserve(nk));
+  HIPCHK(oj.reserve(nq)); HIPCHK(ob.reserve(nq));
+  HIPCHK(hipMemcpyAsync(t.a.p, q, nq, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(t.b.p, k, nk, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(t.c.p, v, nk, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(t.d.p, mask, B * S * 4, hipMemcpyHostToDevice, st));
+  // [B,H,T,dh] -> joined [B,T,H*dh] (the engine's native layout)
+  HIPCHK(launch_transpose_heads(t.a.as<float>(), (int)B, (int)H, (int)Tq, (int)dh, qj.as<float>(), st));
+  HIPCHK(launch_transpose_heads(t.b.as<float>(), (int)B, (int)H, (int)S, (int)dh, kj.as<float>(), st));
+  HIPCHK(launch_transpose_heads(t.c.as<float>(), (int)B, (int)H, (int)S, (int)dh, vj.as<float>(), st));
+  if (attn) HIPCHK(t.e.reserve(B * H * Tq * S * 4));
+  AttnArgs a;
+  a.q = qj.as<float>(); a.k = kj.as<float>(); a.v = vj.as<float>();
+  a.ldq = a.ldk = a.ldv = a.ldo = (int)D;
+  a.mask = t.d.as<float>();
+  a.B = (int)B; a.H = (int)H; a.Tq = (int)Tq; a.S = (int)S; a.dh = (int)dh;
+  a.alpha = 1.0f / std::sqrt((float)dh);  // Modules.cc:43
+  a.out = oj.as<float>();
+  a.attn = attn ? t.e.as<float>() : nullptr;
+  HIPCHK(launch_attention(a, st));
+  HIPCHK(launch_transpose_heads(oj.as<float>(), (int)B, (int)Tq, (int)H, (int)dh, ob.as<float>(), st));
+  HIPCHK(hipMemcpyAsync(out, ob.p, nq, hipMemcpyDeviceToHost, st));
+  if (attn) HIPCHK(hipMemcpyAsync(attn, t.e.p, B * H * Tq * S * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------
+namespace {
+
+struct ParamTable {
+  std::map<std::string, const slimt_hip_param *> by_name;
+  const slimt_hip_param *get(const std::string &n) const {
+    auto it = by_name.find(n);
+    return it == by_name.end() ? nullptr : it->second;
+  }
+};
+
+int upload_f32(DevBuf &dst, const ParamTable &t, const std::string &name, size_t expect) {
+  const slimt_hip_param *p = t.get(name);
+  if (!p) return fail(-1, "missing parameter %s", name.c_str());
+  if (p->type != 0 || (size_t)p->rows * p->cols != expect)
+    return fail(-1, "parameter %s: expected f32 with %zu elements", name.c_str(), expect);
+  HIPCHK(dst.reserve(expect * 4));
+  HIPCHK(hipMemcpy(dst.p, p->data, expect * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int scalar_f32(const ParamTable &t, const std::string &name, float *out) {
+  const slimt_hip_param *p = t.get(name);
+  if (!p) return fail(-1, "missing parameter %s", name.c_str());
+  if (p->type != 0) return fail(-1, "parameter %s must be f32", name.c_str());
+  *out = *reinterpret_cast<const float *>(p->data);
+  return 0;
+}
+
+// Affine{W,b,quant} / Linear{W,quant} binding (Modules.cc:145-180,361-400)
+int load_affine(AffineW &aw, const ParamTable &t, const std::string &wname,
+                const std::string &bname /* may be empty */, int K, int N, DevBuf &scratch) {
+  const slimt_hip_param *W = t.get(wname);
+  if (!W) return fail(-1, "missing parameter %s", wname.c_str());
+  if (W->type != 1 || W->rows != K || W->cols != N)
+    return fail(-1, "parameter %s: expected intgemm8 [%d,%d], got type %d [%d,%d]", wname.c_str(),
+                K, N, W->type, W->rows, W->cols);
+  float a_quant = 0.f, b_quant = 0.f;
+  RCCHK(scalar_f32(t, wname + "_QuantMultA", &a_quant));
+  // b_quant sits right after the int8 payload (Modules.cc:18-22)
+  memcpy(&b_quant, reinterpret_cast<const int8_t *>(W->data) + (size_t)K * N, sizeof(float));
+  DevBuf bias;
+  if (!bname.empty()) {
+    int rc = upload_f32(bias, t, bname, (size_t)N);
+    if (rc) return rc;
+  }
+  HIPCHK(scratch.reserve((size_t)K * N));
+  // qmm::prepare_weight_quantized_transposed (Io.cc:234) is the identity for
+  // this backend: the file layout [N][K] is the canonical layout.
+  HIPCHK(hipMemcpy(scratch.p, W->data, (size_t)K * N, hipMemcpyHostToDevice));
+  int rc = prepare_affine(aw, scratch.as<int8_t>(), K, N, nullptr,
+                          bname.empty() ? nullptr : bias.as<float>(), a_quant, b_quant, nullptr);
+  hipError_t e = hipDeviceSynchronize();
+  bias.release();
+  if (rc) return rc;
+  HIPCHK(e);
+  return 0;
+}
+
+int load_ln(LnW &ln, const ParamTable &t, const std::string &prefix, int D) {
+  RCCHK(upload_f32(ln.scale, t, prefix + "_ln_scale", (size_t)D));
+  RCCHK(upload_f32(ln.bias, t, prefix + "_ln_bias", (size_t)D));
+  return 0;
+}
+
+int load_attn(AttnW &a, const ParamTable &t, const std::string &prefix, int D, DevBuf &scratch) {
+  RCCHK(load_affine(a.q, t, prefix + "Wq", prefix + "bq", D, D, scratch));
+  RCCHK(load_affine(a.k, t, prefix + "Wk", prefix + "bk", D, D, scratch));
+  RCCHK(load_affine(a.v, t, prefix + "Wv", prefix + "bv", D, D, scratch));
+  RCCHK(load_affine(a.o, t, prefix + "Wo", prefix + "bo", D, D, scratch));
+  RCCHK(load_ln(a.ln, t, prefix + "Wo", D));
+  return 0;
+}
+
+void free_affine(AffineW &a) {
+  a.Wp.release();
+  a.colsum.release();
+  a.pb.release();
+}
+void free_ln(LnW &l) {
+  l.scale.release();
+  l.bias.release();
+}
+void free_attn(AttnW &a) {
+  free_affine(a.q); free_affine(a.k); free_affine(a.v); free_affine(a.o);
+  free_ln(a.ln);
+}
+
+void model_free(slimt_hip_model *m) {
+  for (auto &L : m->enc) {
+    free_attn(L.attn); free_affine(L.ffn1); free_affine(L.ffn2); free_ln(L.ffn_ln);
+  }
+  for (auto &L : m->dec) {
+    free_affine(L.rnn_f); free_affine(L.rnn_w); free_ln(L.rnn_ln);
+    free_attn(L.attn); free_affine(L.ffn1); free_affine(L.ffn2); free_ln(L.ffn_ln);
+  }
+  m->wemb.release(); m->out_raw.release(); m->out_bias.release();
+  free_affine(m->out_full);
+}
+
+int model_build(slimt_hip_model *m, const slimt_hip_param *params, size_t n,
+                const slimt_hip_dims *dims) {
+  ParamTable t;
+  for (size_t i = 0; i < n; ++i)
+    if (params[i].name && params[i].data) t.by_name[params[i].name] = &params[i];
+  const slimt_hip_param *wemb = t.get("Wemb");
+  if (!wemb) return fail(-1, "missing parameter Wemb");
+  if (wemb->type != 1) return fail(-1, "Wemb must be intgemm8");
+  m->V = wemb->rows;
+  m->D = wemb->cols;
+  m->H = dims->num_heads;
+  m->Le = dims->encoder_layers;
+  m->Ld = dims->decoder_layers;
+  const int D = m->D, V = m->V;
+  if (D % 64 != 0 || D > 512) return fail(-1, "unsupported embedding size %d", D);
+  if (m->H <= 0 || D % m->H != 0 || D / m->H > 64) return fail(-1, "unsupported head count %d", m->H);
+  const slimt_hip_param *w1 = t.get("encoder_l1_ffn_W1");
+  if (!w1) return fail(-1, "missing parameter encoder_l1_ffn_W1");
+  m->F = w1->cols;
+  if (m->F % 64 != 0 || m->F > 4096) return fail(-1, "unsupported ffn size %d", m->F);
+  const int F = m->F;
+  const size_t VD = (size_t)V * D;
+
+  // Wemb (Io.cc:182-224): keep the int8 table for lookups (E = q * (1/m)),
+  // and re-quantise the dequantised table for the tied output layer exactly
+  // as io::load_items does through qmm::prepare_weight_transposed.
+  const int8_t *wq = reinterpret_cast<const int8_t *>(wemb->data);
+  memcpy(&m->wemb_mult, wq + VD, sizeof(float));
+  HIPCHK(m->wemb.reserve(VD));
+  HIPCHK(hipMemcpy(m->wemb.p, wq, VD, hipMemcpyHostToDevice));
+  {
+    std::vector<float> E(VD);
+    const float inv = 1 / m->wemb_mult;  // Io.cc:280-281
+    for (size_t i = 0; i < VD; ++i) E[i] = static_cast<float>(wq[i]) * inv;
+    std::vector<int8_t> prepared(VD);
+    RCCHK(slimt_hip_prepare_weight_transposed(E.data(), prepared.data(), m->wemb_mult, (size_t)D,
+                                              (size_t)V));
+    HIPCHK(m->out_raw.reserve(VD));
+    HIPCHK(hipMemcpy(m->out_raw.p, prepared.data(), VD, hipMemcpyHostToDevice));
+  }
+  RCCHK(scalar_f32(t, "none_QuantMultA", &m->out_a_quant));
+  RCCHK(upload_f32(m->out_bias, t, "decoder_ff_logit_out_b", (size_t)V));
+  RCCHK(prepare_affine(m->out_full, m->out_raw.as<int8_t>(), D, V, nullptr,
+                       m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, nullptr));
+  HIPCHK(hipDeviceSynchronize());
+
+  DevBuf scratch;
+  struct G { DevBuf *b; ~G() { b->release(); } } guard{&scratch};
+  m->enc.resize((size_t)m->Le);
+  m->dec.resize((size_t)m->Ld);
+  for (int i = 0; i < m->Le; ++i) {
+    const std::string L = "encoder_l" + std::to_string(i + 1);
+    auto &E = m->enc[(size_t)i];
+    RCCHK(load_attn(E.attn, t, L + "_self_", D, scratch));
+    RCCHK(load_affine(E.ffn1, t, L + "_ffn_W1", L + "_ffn_b1", D, F, scratch));
+    RCCHK(load_affine(E.ffn2, t, L + "_ffn_W2", L + "_ffn_b2", F, D, scratch));
+    RCCHK(load_ln(E.ffn_ln, t, L + "_ffn_ffn", D));
+  }
+  for (int i = 0; i < m->Ld; ++i) {
+    const std::string L = "decoder_l" + std::to_string(i + 1);
+    auto &Dl = m->dec[(size_t)i];
+    RCCHK(load_affine(Dl.rnn_w, t, L + "_rnn_W", "", D, D, scratch));
+    RCCHK(load_affine(Dl.rnn_f, t, L + "_rnn_Wf", L + "_rnn_bf", D, D, scratch));
+    RCCHK(load_ln(Dl.rnn_ln, t, L + "_rnn_ffn", D));
+    RCCHK(load_attn(Dl.attn, t, L + "_context_", D, scratch));
+    RCCHK(load_affine(Dl.ffn1, t, L + "_ffn_W1", L + "_ffn_b1", D, F, scratch));
+    RCCHK(load_affine(Dl.ffn2, t, L + "_ffn_W2", L + "_ffn_b2", F, D, scratch));
+    RCCHK(load_ln(Dl.ffn_ln, t, L + "_ffn_ffn", D));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int slimt_hip_model_create(const slimt_hip_param *params, size_t n_params,
+                                      const slimt_hip_dims *dims, int device,
+                                      slimt_hip_model **out) {
+  if (!params || !dims || !out) return fail(-1, "null argument");
+  *out = nullptr;
+  int count = 0;
+  RCCHK(slimt_hip_device_count(&count));
+  if (count <= 0) return fail(-1, "no HIP device available (this backend has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(-1, "device %d out of range (%d devices)", device, count);
+  HIPCHK(hipSetDevice(device));
+  auto *m = new slimt_hip_model();
+  m->device = device;
+  int rc = model_build(m, params, n_params, dims);
+  if (rc) {
+    model_free(m);
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" int slimt_hip_model_destroy(slimt_hip_model *model) {
+  if (!model) return 0;
+  (void)hipSetDevice(model->device);
+  model_free(model);
+  delete model;
+  return 0;
+}
+
+extern "C" int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
+                                    int32_t *dim_ffn, int32_t *vocab, int32_t *heads) {
+  if (!model) return fail(-1, "model is NULL");
+  if (dim_emb) *dim_emb = model->D;
+  if (dim_ffn) *dim_ffn = model->F;
+  if (vocab) *vocab = model->V;
+  if (heads) *heads = model->H;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+namespace {
+
+// sinusoidal_signal (TensorOps.cc:245-265): host libm, like the reference.
+void sinusoid_table(int S, int D, std::vector<float> &out) {
+  out.assign((size_t)S * D, 0.f);
+  float num_timescales = static_cast<float>(D) / 2;
+  // std::log(10000.0F), written as its correctly rounded f32 value so that no
+  // compiler's constant folding can differ from another's.
+  const float log_10000 = 9.210340371976184f;
+  float log_timescale_increment = log_10000 / (num_timescales - 1.0F);
+  for (size_t p = 0; p < (size_t)S; ++p) {
+    for (int i = 0; i < num_timescales; ++i) {
+      float v = p * std::exp(i * -log_timescale_increment);
+      size_t offset = p * (size_t)D + (size_t)i;
+      out[offset] = std::sin(v);
+      out[offset + static_cast<int>(num_timescales)] = std::cos(v);
+    }
+  }
+}
+
+void ctx_free(slimt_hip_ctx *c) {
+  DevBuf *bufs[] = {&c->pos, &c->ids, &c->lengths, &c->x0, &c->x1, &c->q, &c->k, &c->v, &c->att,
+                    &c->h8, &c->kv, &c->dx, &c->dh, &c->dq, &c->datt, &c->dout, &c->df8,
+                    &c->state, &c->part_val, &c->part_idx, &c->prev, &c->out_ids, &c->out_len,
+                    &c->finished, &c->n_finished, &c->align, &c->shortlist, &c->logits,
+                    &c->attn_dbg};
+  for (auto *b : bufs) b->release();
+  free_affine(c->out_sl);
+  if (c->n_finished_host) (void)hipHostFree(c->n_finished_host);
+  for (auto &e : c->prof_events) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+int ctx_alloc(slimt_hip_ctx *c) {
+  const slimt_hip_model *m = c->model;
+  const size_t B = c->max_B, S = c->max_S, M = B * S;
+  const size_t D = (size_t)m->D, F = (size_t)m->F, V = (size_t)m->V;
+  std::vector<float> pos;
+  sinusoid_table((int)S, (int)D, pos);
+  HIPCHK(c->pos.reserve(pos.size() * 4));
+  HIPCHK(hipMemcpy(c->pos.p, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c->ids.reserve(M * 4));
+  HIPCHK(c->lengths.reserve(B * 4));
+  HIPCHK(c->x0.reserve(M * D * 4));
+  HIPCHK(c->x1.reserve(M * D * 4));
+  HIPCHK(c->q.reserve(M * D * 4));
+  HIPCHK(c->k.reserve(M * D * 4));
+  HIPCHK(c->v.reserve(M * D * 4));
+  HIPCHK(c->att.reserve(M * D * 4));
+  HIPCHK(c->h8.reserve(M * F));
+  HIPCHK(c->kv.reserve((size_t)m->Ld * 2 * M * D * 4));
+  HIPCHK(c->dx.reserve(B * D * 4));
+  HIPCHK(c->dh.reserve(B * D * 4));
+  HIPCHK(c->dq.reserve(B * D * 4));
+  HIPCHK(c->datt.reserve(B * D * 4));
+  HIPCHK(c->dout.reserve(B * D * 4));
+  HIPCHK(c->df8.reserve(B * F));
+  HIPCHK(c->state.reserve((size_t)m->Ld * B * D * 4));
+  const size_t max_parts = (V + 63) / 64;
+  HIPCHK(c->part_val.reserve(B * max_parts * 4));
+  HIPCHK(c->part_idx.reserve(B * max_parts * 4));
+  HIPCHK(c->prev.reserve(B * 4));
+  HIPCHK(c->out_len.reserve(B * 4));
+  HIPCHK(c->finished.reserve(B));
+  HIPCHK(c->n_finished.reserve(16));
+  HIPCHK(c->shortlist.reserve(V * 4));
+  HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->n_finished_host), 16, hipHostMallocDefault));
+  return 0;
+}
+
+struct ProfScope {  // HIP events around one launch of the selected kernel family
+  slimt_hip_ctx *c;
+  bool on;
+  ProfScope(slimt_hip_ctx *ctx, int family, double macs, double bytes)
+      : c(ctx), on(ctx->prof_kernel == family) {
+    if (!on) return;
+    if (c->prof_used == c->prof_events.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        on = false;
+        return;
+      }
+      c->prof_events.emplace_back(a, b);
+    }
+    c->prof_macs += macs;
+    c->prof_bytes += bytes;
+    (void)hipEventRecord(c->prof_events[c->prof_used].first, c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(c->prof_events[c->prof_used].second, c->stream);
+    c->prof_used++;
+  }
+};
+
+double gemm_macs(int M, const PreparedWeight &w) { return (double)M * w.K * w.N; }
+double gemm_bytes(const PreparedWeight &w) { return (double)w.K * w.n_tiles * 16; }
+
+}  // namespace
+
+extern "C" int slimt_hip_ctx_create(slimt_hip_model *model, size_t max_batch,
+                                    size_t max_source_length, void *stream, slimt_hip_ctx **out) {
+  if (!model || !out) return fail(-1, "null argument");
+  *out = nullptr;
+  if (max_batch == 0 || max_source_length == 0) return fail(-1, "empty workspace");
+  if (max_source_length > 128)
+    return fail(-1, "max_source_length %zu > 128 (slimt wraps at 128, Frontend.hh:27)", max_source_length);
+  HIPCHK(hipSetDevice(model->device));
+  auto *c = new slimt_hip_ctx();
+  c->model = model;
+  c->max_B = max_batch;
+  c->max_S = max_source_length;
+  if (stream) {
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      return fail((int)e, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->own_stream = true;
+  }
+  int rc = ctx_alloc(c);
+  if (rc) {
+    ctx_free(c);
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int slimt_hip_ctx_destroy(slimt_hip_ctx *ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->model->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx_free(ctx);
+  delete ctx;
+  return 0;
+}
+
+extern "C" int slimt_hip_ctx_stream(slimt_hip_ctx *ctx, void **stream) {
+  if (!ctx || !stream) return fail(-1, "null argument");
+  *stream = reinterpret_cast<void *>(ctx->stream);
+  return 0;
+}
+
+extern "C" int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx) {
+  if (!ctx) return fail(-1, "ctx is NULL");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+namespace {
+
+EmbedArgs embed_args(const slimt_hip_ctx *c) {
+  const slimt_hip_model *m = c->model;
+  EmbedArgs e;
+  e.wemb = m->wemb.as<int8_t>();
+  e.inv_mult = 1 / m->wemb_mult;             // Io.cc:280-281
+  e.sqrt_d = std::sqrt(static_cast<float>(m->D));  // Transformer.cc:34
+  e.pos = c->pos.as<float>();
+  e.D = m->D;
+  return e;
+}
+
+// affine on M rows, f32 in -> f32 out
+int run_affine_f32(slimt_hip_ctx *c, int family, const AffineW &w, const float *x, int M, float *y,
+                   int rows_per_block) {
+  GemmArgs g;
+  g.x_f32 = x;
+  g.lda = w.w.K;
+  g.M = M;
+  g.w = w.w;
+  g.y = y;
+  g.ldy = w.w.N;
+  ProfScope p(c, family, gemm_macs(M, w.w), gemm_bytes(w.w));
+  HIPCHK(launch_gemm(g, EPI_PLAIN, rows_per_block, c->stream));
+  return 0;
+}
+
+int run_affine_res_ln(slimt_hip_ctx *c, int family, const AffineW &w, const float *x_f32,
+                      const int8_t *x_i8, int M, const float *res, const LnW &ln, float *y,
+                      int rows_per_block) {
+  GemmArgs g;
+  g.x_f32 = x_f32;
+  g.x_i8 = x_i8;
+  g.lda = w.w.K;
+  g.M = M;
+  g.w = w.w;
+  g.y = y;
+  g.ldy = w.w.N;
+  g.res = res;
+  g.ldres = w.w.N;
+  g.ln_scale = ln.scale.as<float>();
+  g.ln_bias = ln.bias.as<float>();
+  g.eps = 1e-6f;  // TensorOps.hh:67-68
+  ProfScope p(c, family, gemm_macs(M, w.w), gemm_bytes(w.w));
+  HIPCHK(launch_gemm(g, EPI_RES_LN, rows_per_block, c->stream));
+  return 0;
+}
+
+int run_affine_relu_q(slimt_hip_ctx *c, int family, const AffineW &w, const float *x, int M,
+                      float a_quant_next, int8_t *y8, int rows_per_block) {
+  GemmArgs g;
+  g.x_f32 = x;
+  g.lda = w.w.K;
+  g.M = M;
+  g.w = w.w;
+  g.y_i8 = y8;
+  g.ldy8 = w.w.N;
+  g.a_quant_out = a_quant_next;
+  ProfScope p(c, family, gemm_macs(M, w.w), gemm_bytes(w.w));
+  HIPCHK(launch_gemm(g, EPI_RELU_Q, rows_per_block, c->stream));
+  return 0;
+}
+
+int check_batch(const slimt_hip_ctx *c, size_t B, size_t S) {
+  if (B == 0 || S == 0) return fail(-1, "empty batch");
+  if (B > c->max_B || S > c->max_S)
+    return fail(-1, "batch %zux%zu exceeds the context workspace %zux%zu", B, S, c->max_B, c->max_S);
+  return 0;
+}
+
+// Model.cc:195-201: embedding + Encoder::forward. d_ids/d_len already in
+// ctx->ids / ctx->lengths. Result in ctx->x0.
+int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layers) {
+  const slimt_hip_model *m = c->model;
+  hipStream_t st = c->stream;
+  const int M = B * S, D = m->D;
+  const size_t nbytes = (size_t)M * D * 4;
+  c->B = B;
+  c->S = S;
+  c->have_encoder_out = false;
+  c->decode_ready = false;
+  float *x = c->x0.as<float>(), *y = c->x1.as<float>();
+  HIPCHK(launch_embed_encoder(embed_args(c), c->ids.as<uint32_t>(), B, S, x, st));
+  if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, x, nbytes, hipMemcpyDeviceToHost, st));
+  const int rpb = M >= 2048 ? 64 : (M >= 512 ? 32 : 16);
+  const int rpb_ln = M >= 4096 ? 32 : 16;
+  for (int l = 0; l < m->Le; ++l) {
+    const EncLayerW &L = m->enc[(size_t)l];
+    // Attention::forward (Modules.cc:287-319)
+    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.q, x, M, c->q.as<float>(), rpb));
+    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.k, x, M, c->k.as<float>(), rpb));
+    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.v, x, M, c->v.as<float>(), rpb));
+    AttnArgs a;
+    a.q = c->q.as<float>(); a.k = c->k.as<float>(); a.v = c->v.as<float>();
+    a.ldq = a.ldk = a.ldv = a.ldo = D;
+    a.lengths = c->lengths.as<uint32_t>();
+    a.B = B; a.H = m->H; a.Tq = S; a.S = S; a.dh = D / m->H;
+    a.alpha = 1.0f / std::sqrt(static_cast<float>(a.dh));
+    a.out = c->att.as<float>();
+    {
+      ProfScope p(c, SLIMT_HIP_K_ATTN_ENC, 0, 0);
+      HIPCHK(launch_attention(a, st));
+    }
+    RCCHK(run_affine_res_ln(c, SLIMT_HIP_K_GEMM_ENC, L.attn.o, c->att.as<float>(), nullptr, M, x,
+                            L.attn.ln, y, rpb_ln));
+    // FFN (Modules.cc:326-331): y -> x
+    RCCHK(run_affine_relu_q(c, SLIMT_HIP_K_GEMM_ENC, L.ffn1, y, M, L.ffn2.w.a_quant,
+                            c->h8.as<int8_t>(), rpb));
+    RCCHK(run_affine_res_ln(c, SLIMT_HIP_K_GEMM_ENC, L.ffn2, nullptr, c->h8.as<int8_t>(), M, y,
+                            L.ffn_ln, x, rpb_ln));
+    if (h_layers)
+      HIPCHK(hipMemcpyAsync(h_layers + (size_t)l * M * D, x, nbytes, hipMemcpyDeviceToHost, st));
+  }
+  c->have_encoder_out = true;
+  return 0;
+}
+
+// per-batch decoder setup: cross-attention K/V of the encoder output (computed
+// ONCE instead of every step, Modules.cc:248), shortlist gather, start states
+// (Transformer.cc:78-85).
+int decode_setup(slimt_hip_ctx *c, size_t n_sl) {
+  const slimt_hip_model *m = c->model;
+  hipStream_t st = c->stream;
+  const int B = c->B, S = c->S, M = B * S, D = m->D;
+  if (!c->have_encoder_out) return fail(-1, "decode before encode");
+  const int rpb = M >= 2048 ? 64 : (M >= 512 ? 32 : 16);
+  float *kv = c->kv.as<float>();
+  for (int l = 0; l < m->Ld; ++l) {
+    const DecLayerW &L = m->dec[(size_t)l];
+    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.k, c->x0.as<float>(), M,
+                         kv + (size_t)(2 * l) * M * D, rpb));
+    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.v, c->x0.as<float>(), M,
+                         kv + (size_t)(2 * l + 1) * M * D, rpb));
+  }
+  c->n_sl = (int)n_sl;
+  if (n_sl) {
+    // affine_with_select's SelectColumnsB + bias gather (Intgemm.inl.cc:48-69),
+    // hoisted out of the step loop: the shortlist is fixed per batch (Model.cc:117-120)
+    RCCHK(prepare_affine(c->out_sl, m->out_raw.as<int8_t>(), D, (int)n_sl,
+                         c->shortlist.as<uint32_t>(), m->out_bias.as<float>(), m->out_a_quant,
+                         m->wemb_mult, st));
+  }
+  HIPCHK(hipMemsetAsync(c->state.p, 0, (size_t)m->Ld * B * D * 4, st));
+  c->decode_ready = true;
+  return 0;
+}
+
+const AffineW &output_layer(const slimt_hip_ctx *c) {
+  return c->n_sl ? c->out_sl : c->model->out_full;
+}
+
+// DecoderLayer::forward x2 (Modules.cc:237-259) on ctx->dx; result in ctx->dx.
+int decoder_layers(slimt_hip_ctx *c, float *d_align, int Tmax, const uint32_t *d_out_len,
+                   float *d_attn_dbg) {
+  const slimt_hip_model *m = c->model;
+  hipStream_t st = c->stream;
+  const int B = c->B, S = c->S, M = B * S, D = m->D;
+  float *x = c->dx.as<float>();
+  float *kv = c->kv.as<float>();
+  for (int l = 0; l < m->Ld; ++l) {
+    const DecLayerW &L = m->dec[(size_t)l];
+    SsruArgs s;
+    s.x = x; s.B = B; s.D = D;
+    s.wf = L.rnn_f.w; s.w = L.rnn_w.w;
+    s.state = c->state.as<float>() + (size_t)l * B * D;
+    s.ln_scale = L.rnn_ln.scale.as<float>();
+    s.ln_bias = L.rnn_ln.bias.as<float>();
+    s.h = c->dh.as<float>();
+    {
+      ProfScope p(c, SLIMT_HIP_K_SSRU, 2.0 * B * D * D, 2.0 * D * D);
+      HIPCHK(launch_ssru(s, st));
+    }
+    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_DEC, L.attn.q, c->dh.as<float>(), B, c->dq.as<float>(), 16));
+    AttnArgs a;
+    a.q = c->dq.as<float>();
+    a.k = kv + (size_t)(2 * l) * M * D;
+    a.v = kv + (size_t)(2 * l + 1) * M * D;
+    a.ldq = a.ldk = a.ldv = a.ldo = D;
+    a.lengths = c->lengths.as<uint32_t>();
+    a.B = B; a.H = m->H; a.Tq = 1; a.S = S; a.dh = D / m->H;
+    a.alpha = 1.0f / std::sqrt(static_cast<float>(a.dh));
+    a.out = c->datt.as<float>();
+    if (l + 1 == m->Ld) {  // alignment = last layer (Transformer.cc:165-174)
+      a.attn = d_attn_dbg;
+      if (d_align) {
+        a.align = d_align;
+        a.out_len = d_out_len;
+        a.finished = c->finished.as<uint8_t>();
+        a.Tmax = Tmax;
+      }
+    }
+    {
+      ProfScope p(c, SLIMT_HIP_K_ATTN_DEC, 0, 0);
+      HIPCHK(launch_attention(a, st));
+    }
+    RCCHK(run_affine_res_ln(c, SLIMT_HIP_K_GEMM_DEC, L.attn.o, c->datt.as<float>(), nullptr, B,
+                            c->dh.as<float>(), L.attn.ln, c->dout.as<float>(), 16));
+    RCCHK(run_affine_relu_q(c, SLIMT_HIP_K_GEMM_DEC, L.ffn1, c->dout.as<float>(), B,
+                            L.ffn2.w.a_quant, c->df8.as<int8_t>(), 16));
+    RCCHK(run_affine_res_ln(c, SLIMT_HIP_K_GEMM_DEC, L.ffn2, nullptr, c->df8.as<int8_t>(), B,
+                            c->dout.as<float>(), L.ffn_ln, x, 16));
+  }
+  return 0;
+}
+
+int translate_device(slimt_hip_ctx *c, size_t B, size_t S, size_t n_sl, float limit_factor,
+                     uint32_t eos_id, uint32_t *d_out_ids, uint32_t *d_out_len, float *d_align,
+                     int steps_hint) {
+  const slimt_hip_model *m = c->model;
+  hipStream_t st = c->stream;
+  RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr));
+  RCCHK(decode_setup(c, n_sl));
+  const size_t Tmax = (size_t)(limit_factor * (float)S);  // Model.cc:160
+  DecodeState ds;
+  ds.prev = c->prev.as<uint32_t>();
+  ds.out_ids = d_out_ids;
+  ds.out_len = d_out_len;
+  ds.finished = c->finished.as<uint8_t>();
+  ds.n_finished = c->n_finished.as<int>();
+  ds.shortlist = n_sl ? c->shortlist.as<uint32_t>() : nullptr;
+  ds.Tmax = (int)Tmax;
+  ds.eos = eos_id;
+  HIPCHK(hipMemsetAsync(d_out_len, 0, B * 4, st));
+  HIPCHK(hipMemsetAsync(c->finished.p, 0, B, st));
+  HIPCHK(hipMemsetAsync(c->n_finished.p, 0, 16, st));
+  if (d_align) HIPCHK(hipMemsetAsync(d_align, 0, B * Tmax * S * 4, st));
+  const AffineW &out = output_layer(c);
+  int nt;
+  const int n_parts = gemm_col_blocks(out.w.N, EPI_ARGMAX, &nt);
+  const EmbedArgs e = embed_args(c);
+  const size_t max_steps = steps_hint > 0 ? (size_t)steps_hint : (Tmax > 1 ? Tmax : 1);
+  int rc = 0;
+  size_t t = 0;
+  bool all_done = false;
+  for (; t < max_steps && !rc; ++t) {
+    hipError_t he = launch_decode_begin_step(e, ds, (int)B, t == 0, 1, c->part_val.as<float>(),
+                                             c->part_idx.as<int>(), n_parts, c->dx.as<float>(), st);
+    if (he != hipSuccess) { rc = fail((int)he, "decode_begin_step: %s", hipGetErrorString(he)); break; }
+    if (steps_hint <= 0 && t > 0 && (t % 8) == 0) {
+      // stop as soon as every sentence has emitted EOS (Model.cc:161)
+      he = hipMemcpyAsync(c->n_finished_host, c->n_finished.p, sizeof(int), hipMemcpyDeviceToHost, st);
+      if (he == hipSuccess) he = hipStreamSynchronize(st);
+      if (he != hipSuccess) { rc = fail((int)he, "early-exit readback: %s", hipGetErrorString(he)); break; }
+      if (*c->n_finished_host >= (int)B) { all_done = true; break; }
+    }
+    rc = decoder_layers(c, d_align, (int)Tmax, d_out_len, nullptr);
+    if (rc) break;
+    GemmArgs g;
+    g.x_f32 = c->dx.as<float>();
+    g.lda = m->D;
+    g.M = (int)B;
+    g.w = out.w;
+    g.part_val = c->part_val.as<float>();
+    g.part_idx = c->part_idx.as<int>();
+    g.n_parts = n_parts;
+    {
+      ProfScope p(c, SLIMT_HIP_K_LOGITS, gemm_macs((int)B, out.w), gemm_bytes(out.w));
+      he = launch_gemm(g, EPI_ARGMAX, 16, st);
+    }
+    if (he != hipSuccess) { rc = fail((int)he, "logits gemm: %s", hipGetErrorString(he)); break; }
+  }
+  if (!rc && !all_done) {
+    hipError_t he = launch_decode_begin_step(e, ds, (int)B, 0, 0, c->part_val.as<float>(),
+                                             c->part_idx.as<int>(), n_parts, c->dx.as<float>(), st);
+    if (he != hipSuccess) rc = fail((int)he, "final record: %s", hipGetErrorString(he));
+  }
+  return rc;
+}
+
+}  // namespace
+
+extern "C" int slimt_hip_translate_device(slimt_hip_ctx *ctx, const uint32_t *d_src_ids,
+                                          const uint32_t *d_lengths, size_t B, size_t S,
+                                          const uint32_t *d_shortlist, size_t n_shortlist,
+                                          float limit_factor, uint32_t eos_id,
+                                          uint32_t *d_out_ids, uint32_t *d_out_len,
+                                          float *d_align, int steps_hint) {
+  if (!ctx || !d_src_ids || !d_lengths || !d_out_ids || !d_out_len) return fail(-1, "null argument");
+  RCCHK(check_batch(ctx, B, S));
+  if (n_shortlist > (size_t)ctx->model->V) return fail(-1, "shortlist larger than the vocabulary");
+  if (n_shortlist && !d_shortlist) return fail(-1, "shortlist is NULL");
+  HIPCHK(hipSetDevice(ctx->model->device));
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(ctx->ids.p, d_src_ids, B * S * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->lengths.p, d_lengths, B * 4, hipMemcpyDeviceToDevice, st));
+  if (n_shortlist)
+    HIPCHK(hipMemcpyAsync(ctx->shortlist.p, d_shortlist, n_shortlist * 4, hipMemcpyDeviceToDevice, st));
+  return translate_device(ctx, B, S, n_shortlist, limit_factor, eos_id, d_out_ids, d_out_len,
+                          d_align, steps_hint);
+}
+
+extern "C" int slimt_hip_translate(slimt_hip_ctx *ctx, const uint32_t *src_ids,
+                                   const uint32_t *lengths, size_t B, size_t S,
+                                   const uint32_t *shortlist, size_t n_shortlist,
+                                   float limit_factor, uint32_t eos_id, uint32_t *out_ids,
+                                   uint32_t *out_len, float *align) {
+  if (!ctx || !src_ids || !lengths || !out_ids || !out_len) return fail(-1, "null argument");
+  RCCHK(check_batch(ctx, B, S));
+  const slimt_hip_model *m = ctx->model;
+  if (n_shortlist > (size_t)m->V) return fail(-1, "shortlist larger than the vocabulary");
+  if (n_shortlist && !shortlist) return fail(-1, "shortlist is NULL");
+  for (size_t i = 0; i < B * S; ++i)
+    if (src_ids[i] >= (uint32_t)m->V) return fail(-1, "token id %u out of range", src_ids[i]);
+  for (size_t i = 0; i < n_shortlist; ++i)
+    if (shortlist[i] >= (uint32_t)m->V) return fail(-1, "shortlist id %u out of range", shortlist[i]);
+  for (size_t i = 0; i < B; ++i)
+    if (lengths[i] > S) return fail(-1, "length %u > S", lengths[i]);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t st = ctx->stream;
+  const size_t Tmax = (size_t)(limit_factor * (float)S);
+  const size_t Talloc = Tmax ? Tmax : 1;
+  HIPCHK(ctx->out_ids.reserve(B * Talloc * 4));
+  if (align) HIPCHK(ctx->align.reserve(B * Talloc * S * 4));
+  HIPCHK(hipMemcpyAsync(ctx->ids.p, src_ids, B * S * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->lengths.p, lengths, B * 4, hipMemcpyHostToDevice, st));
+  if (n_shortlist)
+    HIPCHK(hipMemcpyAsync(ctx->shortlist.p, shortlist, n_shortlist * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(ctx->out_ids.p, 0, B * Talloc * 4, st));
+  RCCHK(translate_device(ctx, B, S, n_shortlist, limit_factor, eos_id, ctx->out_ids.as<uint32_t>(),
+                         ctx->out_len.as<uint32_t>(), align ? ctx->align.as<float>() : nullptr, 0));
+  HIPCHK(hipMemcpyAsync(out_ids, ctx->out_ids.p, B * Talloc * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(out_len, ctx->out_len.p, B * 4, hipMemcpyDeviceToHost, st));
+  if (align) HIPCHK(hipMemcpyAsync(align, ctx->align.p, B * Talloc * S * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int slimt_hip_encode(slimt_hip_ctx *ctx, const uint32_t *src_ids,
+                                const uint32_t *lengths, size_t B, size_t S, float *embed_out,
+                                float *layer_out, float *enc_out) {
+  if (!ctx || !src_ids || !lengths) return fail(-1, "null argument");
+  RCCHK(check_batch(ctx, B, S));
+  const slimt_hip_model *m = ctx->model;
+  for (size_t i = 0; i < B * S; ++i)
+    if (src_ids[i] >= (uint32_t)m->V) return fail(-1, "token id %u out of range", src_ids[i]);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(ctx->ids.p, src_ids, B * S * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->lengths.p, lengths, B * 4, hipMemcpyHostToDevice, st));
+  RCCHK(encode_device(ctx, (int)B, (int)S, embed_out, layer_out));
+  if (enc_out)
+    HIPCHK(hipMemcpyAsync(enc_out, ctx->x0.p, B * S * (size_t)m->D * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int slimt_hip_decode_begin(slimt_hip_ctx *ctx, const uint32_t *shortlist,
+                                      size_t n_shortlist) {
+  if (!ctx) return fail(-1, "ctx is NULL");
+  const slimt_hip_model *m = ctx->model;
+  if (n_shortlist > (size_t)m->V) return fail(-1, "shortlist larger than the vocabulary");
+  if (n_shortlist && !shortlist) return fail(-1, "shortlist is NULL");
+  for (size_t i = 0; i < n_shortlist; ++i)
+    if (shortlist[i] >= (uint32_t)m->V) return fail(-1, "shortlist id %u out of range", shortlist[i]);
+  HIPCHK(hipSetDevice(m->device));
+  if (n_shortlist)
+    HIPCHK(hipMemcpyAsync(ctx->shortlist.p, shortlist, n_shortlist * 4, hipMemcpyHostToDevice,
+                          ctx->stream));
+  RCCHK(decode_setup(ctx, n_shortlist));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int slimt_hip_decode_step(slimt_hip_ctx *ctx, const uint32_t *prev, float *logits,
+                                     float *attn, float *states) {
+  if (!ctx || !logits) return fail(-1, "null argument");
+  if (!ctx->decode_ready) return fail(-1, "decode_step before decode_begin");
+  const slimt_hip_model *m = ctx->model;
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t st = ctx->stream;
+  const size_t B = (size_t)ctx->B, S = (size_t)ctx->S, D = (size_t)m->D;
+  if (prev) {
+    for (size_t i = 0; i < B; ++i)
+      if (prev[i] >= (uint32_t)m->V) return fail(-1, "token id %u out of range", prev[i]);
+    HIPCHK(hipMemcpyAsync(ctx->prev.p, prev, B * 4, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(launch_embed_decoder(embed_args(ctx), ctx->prev.as<uint32_t>(), (int)B, prev == nullptr,
+                              ctx->dx.as<float>(), st));
+  if (attn) HIPCHK(ctx->attn_dbg.reserve(B * (size_t)m->H * S * 4));
+  RCCHK(decoder_layers(ctx, nullptr, 0, nullptr, attn ? ctx->attn_dbg.as<float>() : nullptr));
+  const AffineW &out = output_layer(ctx);
+  const size_t N = (size_t)out.w.N;
+  HIPCHK(ctx->logits.reserve(B * N * 4));
+  GemmArgs g;
+  g.x_f32 = ctx->dx.as<float>();
+  g.lda = m->D;
+  g.M = (int)B;
+  g.w = out.w;
+  g.y = ctx->logits.as<float>();
+  g.ldy = (int)N;
+  HIPCHK(launch_gemm(g, EPI_PLAIN, 16, st));
+  HIPCHK(hipMemcpyAsync(logits, ctx->logits.p, B * N * 4, hipMemcpyDeviceToHost, st));
+  if (attn)
+    HIPCHK(hipMemcpyAsync(attn, ctx->attn_dbg.p, B * (size_t)m->H * S * 4, hipMemcpyDeviceToHost, st));
+  if (states)
+    HIPCHK(hipMemcpyAsync(states, ctx->state.p, (size_t)m->Ld * B * D * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------
+extern "C" int slimt_hip_profile_enable(slimt_hip_ctx *ctx, int kernel_id) {
+  if (!ctx) return fail(-1, "ctx is NULL");
+  if (kernel_id < 0 || kernel_id >= SLIMT_HIP_K_COUNT) return fail(-1, "bad kernel id %d", kernel_id);
+  ctx->prof_kernel = kernel_id;
+  return slimt_hip_profile_reset(ctx);
+}
+
+extern "C" int slimt_hip_profile_reset(slimt_hip_ctx *ctx) {
+  if (!ctx) return fail(-1, "ctx is NULL");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->prof_used = 0;
+  ctx->prof_macs = 0;
+  ctx->prof_bytes = 0;
+  return 0;
+}
+
+extern "C" int slimt_hip_profile_read(slimt_hip_ctx *ctx, uint64_t *launches, double *total_ms,
+                                      double *int8_macs, double *weight_bytes) {
+  if (!ctx) return fail(-1, "ctx is NULL");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double ms = 0;
+  for (size_t i = 0; i < ctx->prof_used; ++i) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, ctx->prof_events[i].first, ctx->prof_events[i].second));
+    ms += t;
+  }
+  if (launches) *launches = ctx->prof_used;
+  if (total_ms) *total_ms = ms;
+  if (int8_macs) *int8_macs = ctx->prof_macs;
+  if (weight_bytes) *weight_bytes = ctx->prof_bytes;
+  return 0;
+}

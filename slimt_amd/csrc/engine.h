@@ -1,0 +1,97 @@
+// Device-resident model + per-worker context for the MI355X slimt backend.
+// Mirrors slimt::Transformer / Encoder / Decoder (slimt/Transformer.hh:15-72)
+// and the loop of slimt::Model::forward/decode (slimt/Model.cc:111-204).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/slimt_hip.h"
+#include "kernels.h"
+
+namespace slimt_hip {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t n);  // grows (never shrinks); contents undefined after growth
+  void release();
+  template <class T>
+  T *as() const {
+    return reinterpret_cast<T *>(p);
+  }
+};
+
+struct AffineW {  // slimt::Affine / slimt::Linear (Modules.hh:14-22), prepared
+  PreparedWeight w;
+  DevBuf Wp, colsum, pb;
+};
+
+struct LnW {
+  DevBuf scale, bias;
+};
+
+struct AttnW {
+  AffineW q, k, v, o;
+  LnW ln;
+};
+
+struct EncLayerW {
+  AttnW attn;
+  AffineW ffn1, ffn2;
+  LnW ffn_ln;
+};
+
+struct DecLayerW {
+  AffineW rnn_f, rnn_w;
+  LnW rnn_ln;
+  AttnW attn;
+  AffineW ffn1, ffn2;
+  LnW ffn_ln;
+};
+
+}  // namespace slimt_hip
+
+struct slimt_hip_model {
+  int device = 0;
+  int D = 0, F = 0, H = 0, V = 0, Le = 0, Ld = 0;
+  std::vector<slimt_hip::EncLayerW> enc;
+  std::vector<slimt_hip::DecLayerW> dec;
+  slimt_hip::DevBuf wemb;      // int8 [V][D] (embedding lookup, Io.cc:191-200)
+  float wemb_mult = 0.f;       // quantisation multiplier of Wemb
+  slimt_hip::DevBuf out_raw;   // Wemb_intgemm8: int8 [V][D] (Io.cc:206-224)
+  slimt_hip::DevBuf out_bias;  // decoder_ff_logit_out_b [V]
+  float out_a_quant = 0.f;     // none_QuantMultA (Transformer.cc:111-113)
+  slimt_hip::AffineW out_full; // full-vocabulary output layer
+};
+
+struct slimt_hip_ctx {
+  slimt_hip_model *model = nullptr;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  size_t max_B = 0, max_S = 0;
+  // current batch
+  int B = 0, S = 0;
+  int n_sl = 0;  // 0 => full vocabulary
+  bool have_encoder_out = false;
+  bool decode_ready = false;
+  // encoder workspace
+  slimt_hip::DevBuf pos;  // [max_S][D]
+  slimt_hip::DevBuf ids, lengths;
+  slimt_hip::DevBuf x0, x1, q, k, v, att, h8;
+  slimt_hip::DevBuf kv;  // [Ld][2][B*S][D]
+  // decoder workspace
+  slimt_hip::DevBuf dx, dh, dq, datt, dout, df8, state;
+  slimt_hip::DevBuf part_val, part_idx;
+  slimt_hip::DevBuf prev, out_ids, out_len, finished, n_finished, align;
+  slimt_hip::DevBuf shortlist;
+  slimt_hip::AffineW out_sl;  // shortlisted output layer (per batch)
+  slimt_hip::DevBuf logits, attn_dbg;
+  int *n_finished_host = nullptr;  // pinned
+  // profiling
+  int prof_kernel = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  double prof_macs = 0, prof_bytes = 0;
+};

@@ -1,0 +1,146 @@
+// Host-callable launchers for the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace slimt_hip {
+
+// A prepared (device-resident) int8 weight: MFMA-B-fragment tiling + the
+// constants of the intgemm epilogue.
+//   Wp     [(n_tile, k_step, lane)] x 16 B: lane l of k-step s of tile t holds
+//          W[n = 16 t + (l & 15)][k = 64 s + 16 (l >> 4) .. +15]
+//   colsum [n]  sum_k W[k, n]
+//   pb     [n]  float(colsum[n]) * (-127/(aq*bq)) + bias[n]   (PrepareBias)
+//   u           1 / (aq * bq)
+struct PreparedWeight {
+  const void *Wp = nullptr;
+  const int *colsum = nullptr;
+  const float *pb = nullptr;
+  float u = 0.f;
+  float a_quant = 0.f;
+  float b_quant = 0.f;
+  int K = 0;
+  int N = 0;        // logical columns
+  int n_tiles = 0;  // ceil(N / 16)
+};
+
+size_t packed_weight_bytes(int K, int N);
+
+// W: device int8 [N_src][K]; idx (device, nullable) selects/gathers rows;
+// bias (device, nullable) is indexed by SOURCE row. Writes Wp/colsum/pb.
+hipError_t launch_pack_weight(const int8_t *W, int K, int N, const uint32_t *idx,
+                              const float *bias, float a_quant, float b_quant, void *Wp,
+                              int *colsum, float *pb, hipStream_t st);
+
+enum GemmEpilogue {
+  EPI_PLAIN = 0,   // y = deq (+bias)                        -> f32 [M][ldy]
+  EPI_RELU_Q = 1,  // quant(relu(deq), a_quant_out)          -> int8 [M][ldy8]
+  EPI_RES_LN = 2,  // LN(deq + res) over the full row        -> f32 [M][ldy]
+  EPI_ARGMAX = 3,  // per-row first-max over this block's columns -> partials
+  EPI_ACC = 4,     // raw accS                               -> int32 [M][N]
+};
+
+struct GemmArgs {
+  // A operand: exactly one of x_f32 / x_i8
+  const float *x_f32 = nullptr;
+  const int8_t *x_i8 = nullptr;
+  int lda = 0;  // row stride in elements
+  int M = 0;
+  // B operand
+  PreparedWeight w;
+  // outputs
+  float *y = nullptr;
+  int ldy = 0;
+  int8_t *y_i8 = nullptr;
+  int ldy8 = 0;
+  float a_quant_out = 0.f;
+  int32_t *acc_out = nullptr;
+  // EPI_RES_LN
+  const float *res = nullptr;
+  int ldres = 0;
+  const float *ln_scale = nullptr;
+  const float *ln_bias = nullptr;
+  float eps = 1e-6f;
+  // EPI_ARGMAX: partials [M][n_parts]
+  float *part_val = nullptr;
+  int *part_idx = nullptr;
+  int n_parts = 0;
+};
+
+// rows_per_block: 16, 32 or 64 (RM = 1, 2, 4 MFMA row tiles sharing each B
+// fragment). Returns the number of column blocks used (EPI_ARGMAX: n_parts).
+int gemm_col_blocks(int N, int epilogue, int *nt_out);
+hipError_t launch_gemm(const GemmArgs &a, int epilogue, int rows_per_block, hipStream_t st);
+
+struct SsruArgs {
+  const float *x = nullptr;  // [B][D]
+  int B = 0, D = 0;
+  PreparedWeight wf, w;      // Wf (affine, bias in pb), W (dot)
+  float *state = nullptr;    // [B][D] in/out
+  const float *ln_scale = nullptr, *ln_bias = nullptr;
+  float eps = 1e-6f;
+  float *h = nullptr;        // [B][D]
+};
+hipError_t launch_ssru(const SsruArgs &a, hipStream_t st);
+
+struct EmbedArgs {
+  const int8_t *wemb = nullptr;  // int8 [V][D]
+  float inv_mult = 0.f, sqrt_d = 0.f;
+  const float *pos = nullptr;    // [max_S][D] sinusoid table
+  int D = 0;
+};
+hipError_t launch_embed_encoder(const EmbedArgs &e, const uint32_t *ids, int B, int S, float *x,
+                                hipStream_t st);
+
+struct DecodeState {
+  // all device pointers
+  uint32_t *prev = nullptr;       // [B] last sampled token
+  uint32_t *out_ids = nullptr;    // [B][Tmax]
+  uint32_t *out_len = nullptr;    // [B]
+  uint8_t *finished = nullptr;    // [B]
+  int *n_finished = nullptr;      // [1]
+  const uint32_t *shortlist = nullptr;  // nullable
+  int Tmax = 0;
+  uint32_t eos = 0;
+};
+// Reduce the argmax partials of the previous step (if first == 0), record the
+// tokens (Model.cc:127-137) and build the next decoder input embedding
+// (Transformer.cc:133-160). with_embed == 0: sample/record only (last step).
+hipError_t launch_decode_begin_step(const EmbedArgs &e, const DecodeState &s, int B, int first,
+                                    int with_embed, const float *part_val, const int *part_idx,
+                                    int n_parts, float *x, hipStream_t st);
+// set prev tokens explicitly (step-wise parity API) and embed
+hipError_t launch_embed_decoder(const EmbedArgs &e, const uint32_t *prev, int B, int first,
+                                float *x, hipStream_t st);
+
+struct AttnArgs {
+  const float *q = nullptr;  // [B*Tq][ldq]
+  const float *k = nullptr;  // [B*S][ldk]
+  const float *v = nullptr;  // [B*S][ldv]
+  int ldq = 0, ldk = 0, ldv = 0;
+  const uint32_t *lengths = nullptr;  // [B] -> additive mask 0 / -99999999 (Input.cc:49-63)
+  const float *mask = nullptr;        // optional explicit [B][S] mask (op-level API)
+  int B = 0, H = 0, Tq = 0, S = 0, dh = 0;
+  float alpha = 0.f;  // 1/sqrt(dh)
+  float *out = nullptr;  // [B*Tq][ldo] joined heads
+  int ldo = 0;
+  float *attn = nullptr;  // nullable [B][H][Tq][S]
+  // alignment export (decoder, head 0): align[b][out_len[b]][s<len] unless finished
+  float *align = nullptr;
+  const uint32_t *out_len = nullptr;
+  const uint8_t *finished = nullptr;
+  int Tmax = 0;
+};
+hipError_t launch_attention(const AttnArgs &a, hipStream_t st);
+
+hipError_t launch_layer_norm(const float *x, const float *scale, const float *bias, float eps,
+                             int rows, int cols, float *y, hipStream_t st);
+hipError_t launch_softmax(const float *x, int rows, int cols, float *y, hipStream_t st);
+hipError_t launch_highway(const float *x, const float *y, const float *g, size_t n, float *out,
+                          hipStream_t st);
+// [B,H,T,dh] <-> [B,T,H*dh] helpers for the op-level sdpa API
+hipError_t launch_transpose_heads(const float *in, int B, int d2, int d1, int d0, float *out,
+                                  hipStream_t st);
+
+}  // namespace slimt_hip

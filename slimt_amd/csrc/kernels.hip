@@ -1,0 +1,769 @@
+// gfx950 (MI355X / CDNA4) kernels for slimt's int8 transformer-NMT hot path.
+// Written for wave64 + v_mfma_i32_16x16x64_i8 only: no other target, no
+// portability layer.
+//
+// Reference semantics (file:line in jerinphilip/slimt):
+//   int8 affine / dot / select  slimt/qmm/Intgemm.inl.cc:7-226 (Int8Shift)
+//   layer_norm                  slimt/TensorOps.cc:542-580
+//   softmax                     slimt/TensorOps.cc:296-314
+//   highway / sigmoid           slimt/TensorOps.cc:33-36,662-682
+//   attention                   slimt/Modules.cc:24-86
+//   SSRU                        slimt/Modules.cc:190-235
+//   embedding transform         slimt/Transformer.cc:24-49,133-160
+//   greedy sample + record      slimt/Transformer.cc:279-339, Model.cc:127-137
+#include "kernels.h"
+
+#include "device_common.h"
+
+namespace slimt_hip {
+
+// ---------------------------------------------------------------------------
+// weight packing (load time / once per batch for the shortlist)
+// ---------------------------------------------------------------------------
+
+size_t packed_weight_bytes(int K, int N) {
+  size_t n_tiles = (size_t)(N + 15) / 16;
+  return n_tiles * (size_t)(K / 64) * 64 * 16;
+}
+
+struct PackArgs {
+  const int8_t *W;
+  int K, N;
+  const uint32_t *idx;
+  const float *bias;
+  float mult;  // (-1 * (127/aq * 127/bq)) / 127, Intgemm.inl.cc:123-126
+  v4i *Wp;
+  int *colsum;
+  float *pb;
+};
+
+__device__ __forceinline__ int sum_bytes(int w) {
+  return (int)(int8_t)(w & 0xff) + (int)(int8_t)((w >> 8) & 0xff) +
+         (int)(int8_t)((w >> 16) & 0xff) + (int)(int8_t)((w >> 24) & 0xff);
+}
+
+// one block per 16-column tile of the logical [K, N] matrix
+__global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs a) {
+  const int tid = threadIdx.x;
+  const int ntile = blockIdx.x;
+  const int KS = a.K / 64;
+  const int chunks = a.K / 16;  // 16-byte chunks per row
+  for (int c = tid; c < 16 * chunks; c += 256) {
+    const int r = c / chunks, ch = c % chunks;
+    const int n = ntile * 16 + r;
+    v4i v = {0, 0, 0, 0};
+    if (n < a.N) {
+      const size_t src = a.idx ? (size_t)a.idx[n] : (size_t)n;
+      v = *reinterpret_cast<const v4i *>(a.W + src * a.K + (size_t)ch * 16);
+    }
+    const int ks = ch >> 2, kg = ch & 3;
+    a.Wp[((size_t)ntile * KS + ks) * 64 + kg * 16 + r] = v;
+  }
+  // column sums: 16 threads per row
+  const int r = tid >> 4, sub = tid & 15;
+  const int n = ntile * 16 + r;
+  int s = 0;
+  size_t src = 0;
+  if (n < a.N) {
+    src = a.idx ? (size_t)a.idx[n] : (size_t)n;
+    for (int ch = sub; ch < chunks; ch += 16) {
+      v4i v = *reinterpret_cast<const v4i *>(a.W + src * a.K + (size_t)ch * 16);
+      s += sum_bytes(v.x) + sum_bytes(v.y) + sum_bytes(v.z) + sum_bytes(v.w);
+    }
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  s += __shfl_xor(s, 8, 64);
+  if (sub == 0) {
+    float pbv = 0.0f;
+    if (n < a.N) {
+      float v = (float)s * a.mult;  // PrepareBias callback: cvt, mul, add
+      pbv = v + (a.bias ? a.bias[src] : 0.0f);
+    } else {
+      s = 0;
+    }
+    a.colsum[n] = s;
+    a.pb[n] = pbv;
+  }
+}
+
+hipError_t launch_pack_weight(const int8_t *W, int K, int N, const uint32_t *idx,
+                              const float *bias, float a_quant, float b_quant, void *Wp,
+                              int *colsum, float *pb, hipStream_t st) {
+  PackArgs a;
+  a.W = W;
+  a.K = K;
+  a.N = N;
+  a.idx = idx;
+  a.bias = bias;
+  float a_alpha = 127.0f / a_quant;
+  float b_alpha = 127.0f / b_quant;
+  a.mult = (-1.0f * (a_alpha * b_alpha)) / 127.0f;
+  a.Wp = reinterpret_cast<v4i *>(Wp);
+  a.colsum = colsum;
+  a.pb = pb;
+  const int n_tiles = (N + 15) / 16;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(n_tiles), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// int8 GEMM on v_mfma_i32_16x16x64_i8 with fused quantise prologue and
+// dequant / activation / LayerNorm / argmax epilogues
+// ---------------------------------------------------------------------------
+//
+// Block = 4 waves. Block tile = (16*RM rows) x (4 waves * NT tiles * 16 cols).
+// A (activations) is quantised once per K-chunk into LDS as int8 and shared
+// by the 4 waves; each wave streams its own B fragments (pre-tiled weights,
+// one fully coalesced 1 KiB load per MFMA operand) straight into registers
+// and reuses each across the RM row tiles.
+//
+// MFMA operand maps (v_mfma_i32_16x16x64_i8, checked by tests/test_gpu_qmm):
+//   A: lane l holds A[row = l & 15][k = 16 (l >> 4) .. +15]   (16 int8 = v4i)
+//   B: lane l holds B[k = 16 (l >> 4) .. +15][col = l & 15]
+//   C: lane l, reg r holds C[row = 4 (l >> 4) + r][col = l & 15]
+
+constexpr int KCH = 256;       // K chunk staged in LDS
+constexpr int LDA = KCH + 16;  // padded LDS row stride (bytes): conflict-free b128 reads
+
+struct GemmKArgs {
+  GemmArgs g;
+  int KS;           // K / 64
+  float u;
+};
+
+template <int RM>
+__device__ __forceinline__ void stage_A_f32(char *A_lds, const float *x, int lda, int M, int m0,
+                                            int k0, int kc, float aq, int tid) {
+  constexpr int R = 16 * RM;
+  const int units_per_row = kc >> 2;  // float4 units
+  for (int u = tid; u < R * units_per_row; u += 256) {
+    const int r = u / units_per_row, c4 = u - r * units_per_row;
+    const int row = m0 + r;
+    int packed = 0;
+    if (row < M) {
+      const float4 f = *reinterpret_cast<const float4 *>(x + (size_t)row * lda + k0 + c4 * 4);
+      packed = pack4(quantize1(f.x, aq), quantize1(f.y, aq), quantize1(f.z, aq),
+                     quantize1(f.w, aq));
+    }
+    *reinterpret_cast<int *>(A_lds + r * LDA + c4 * 4) = packed;
+  }
+}
+
+template <int RM>
+__device__ __forceinline__ void stage_A_i8(char *A_lds, const int8_t *x, int lda, int M, int m0,
+                                           int k0, int kc, int tid) {
+  constexpr int R = 16 * RM;
+  const int units_per_row = kc >> 4;  // 16-byte units
+  for (int u = tid; u < R * units_per_row; u += 256) {
+    const int r = u / units_per_row, c = u - r * units_per_row;
+    const int row = m0 + r;
+    v4i v = {0, 0, 0, 0};
+    if (row < M) v = *reinterpret_cast<const v4i *>(x + (size_t)row * lda + k0 + c * 16);
+    *reinterpret_cast<v4i *>(A_lds + r * LDA + c * 16) = v;
+  }
+}
+
+template <int RM, int NT, int EPI>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmKArgs ka) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GemmArgs &a = ka.g;
+  constexpr int R = 16 * RM;
+  constexpr int BN = 64 * NT;  // columns per block
+  char *A_lds = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  const int nt0 = (blockIdx.y * 4 + wave) * NT;  // first 16-col tile of this wave
+  const int K = a.w.K, KS = ka.KS;
+  const int n_tiles = a.w.n_tiles;
+  const v4i *Wp = reinterpret_cast<const v4i *>(a.w.Wp);
+
+  v4i acc[RM][NT];
+#pragma unroll
+  for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = v4i{0, 0, 0, 0};
+
+  for (int k0 = 0; k0 < K; k0 += KCH) {
+    const int kc = (K - k0) < KCH ? (K - k0) : KCH;
+    if (k0) __syncthreads();
+    if (a.x_f32)
+      stage_A_f32<RM>(A_lds, a.x_f32, a.lda, a.M, m0, k0, kc, a.w.a_quant, tid);
+    else
+      stage_A_i8<RM>(A_lds, a.x_i8, a.lda, a.M, m0, k0, kc, tid);
+    __syncthreads();
+    const int ksteps = kc >> 6;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      v4i af[RM];
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+        af[rm] = *reinterpret_cast<const v4i *>(A_lds + (rm * 16 + lr) * LDA + ks * 64 + lg * 16);
+      const int kstep = (k0 >> 6) + ks;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ntile = nt0 + nt;
+        if (ntile < n_tiles) {
+          const v4i bf = Wp[((size_t)ntile * KS + kstep) * 64 + lane];
+#pragma unroll
+          for (int rm = 0; rm < RM; ++rm)
+            acc[rm][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rm], bf, acc[rm][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------
+  // y = float(acc + 127 colsum) * u + prepared_bias   (Intgemm.inl.cc:146-153)
+  const float u = ka.u;
+  if constexpr (EPI == EPI_PLAIN || EPI == EPI_RELU_Q || EPI == EPI_ACC) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ntile = nt0 + nt;
+      if (ntile >= n_tiles) continue;
+      const int col = ntile * 16 + lr;
+      const int cs = a.w.colsum[col];
+      const float pb = a.w.pb[col];
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + rm * 16 + lg * 4 + r;
+          if (row >= a.M || col >= a.w.N) continue;
+          const int accS = acc[rm][nt][r] + 127 * cs;
+          if constexpr (EPI == EPI_ACC) {
+            a.acc_out[(size_t)row * a.w.N + col] = accS;
+          } else {
+            float v = (float)accS * u;
+            v = v + pb;
+            if constexpr (EPI == EPI_PLAIN) {
+              a.y[(size_t)row * a.ldy + col] = v;
+            } else {
+              v = v > 0.0f ? v : 0.0f;  // relu, TensorOps.cc:163-181
+              a.y_i8[(size_t)row * a.ldy8 + col] = (int8_t)quantize1(v, a.a_quant_out);
+            }
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_RES_LN) {
+    // the block owns complete rows (gridDim.y == 1, N == BN)
+    float *rowbuf = reinterpret_cast<float *>(smem + R * LDA);
+    constexpr int LDR = BN + 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = (nt0 + nt) * 16 + lr;
+      const int cs = a.w.colsum[col];
+      const float pb = a.w.pb[col];
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = rm * 16 + lg * 4 + r;
+          const int row = m0 + rl;
+          float v = 0.0f;
+          if (row < a.M) {
+            v = (float)(acc[rm][nt][r] + 127 * cs) * u;
+            v = v + pb;
+            v = v + a.res[(size_t)row * a.ldres + col];
+          }
+          rowbuf[rl * LDR + col] = v;
+        }
+    }
+    __syncthreads();
+    for (int rl = wave; rl < R; rl += 4) {
+      const int row = m0 + rl;
+      if (row < a.M)
+        wave_layer_norm_row(rowbuf + rl * LDR, a.ln_scale, a.ln_bias, a.eps, BN,
+                            a.y + (size_t)row * a.ldy, lane);
+    }
+  } else if constexpr (EPI == EPI_ARGMAX) {
+    // first-max (strict >, lowest column wins ties): Transformer.cc:287-297
+    float *red_v = reinterpret_cast<float *>(smem + R * LDA);
+    int *red_i = reinterpret_cast<int *>(red_v + 4 * R);
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float bv = -3.402823466e+38f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int ntile = nt0 + nt;
+          const int col = ntile * 16 + lr;
+          if (ntile < n_tiles && col < a.w.N) {
+            float v = (float)(acc[rm][nt][r] + 127 * a.w.colsum[col]) * u;
+            v = v + a.w.pb[col];
+            if (v > bv || (v == bv && col < bi)) {
+              bv = v;
+              bi = col;
+            }
+          }
+        }
+        // across the 16 lanes that share these rows
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          const float ov = __shfl_xor(bv, m, 64);
+          const int oi = __shfl_xor(bi, m, 64);
+          if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+          }
+        }
+        if (lr == 0) {
+          const int rl = rm * 16 + lg * 4 + r;
+          red_v[wave * R + rl] = bv;
+          red_i[wave * R + rl] = bi;
+        }
+      }
+    __syncthreads();
+    if (tid < R) {
+      const int row = m0 + tid;
+      float bv = red_v[tid];
+      int bi = red_i[tid];
+      for (int w = 1; w < 4; ++w) {
+        const float ov = red_v[w * R + tid];
+        const int oi = red_i[w * R + tid];
+        if (ov > bv || (ov == bv && oi < bi)) {
+          bv = ov;
+          bi = oi;
+        }
+      }
+      if (row < a.M) {
+        a.part_val[(size_t)row * a.n_parts + blockIdx.y] = bv;
+        a.part_idx[(size_t)row * a.n_parts + blockIdx.y] = bi;
+      }
+    }
+  }
+}
+
+int gemm_col_blocks(int N, int epilogue, int *nt_out) {
+  int nt;
+  if (epilogue == EPI_RES_LN) {
+    nt = N / 64;  // block must own the whole row
+  } else {
+    nt = N >= 256 ? 4 : (N >= 128 ? 2 : 1);
+  }
+  if (nt_out) *nt_out = nt;
+  const int bn = 64 * nt;
+  return (N + bn - 1) / bn;
+}
+
+template <int RM, int NT>
+static hipError_t launch_gemm_t(const GemmKArgs &ka, int epi, dim3 grid, hipStream_t st) {
+  constexpr int R = 16 * RM;
+  size_t lds = (size_t)R * LDA;
+  switch (epi) {
+    case EPI_PLAIN:
+      hipLaunchKernelGGL((gemm_rows_kernel<RM, NT, EPI_PLAIN>), grid, dim3(256), lds, st, ka);
+      break;
+    case EPI_RELU_Q:
+      hipLaunchKernelGGL((gemm_rows_kernel<RM, NT, EPI_RELU_Q>), grid, dim3(256), lds, st, ka);
+      break;
+    case EPI_ACC:
+      hipLaunchKernelGGL((gemm_rows_kernel<RM, NT, EPI_ACC>), grid, dim3(256), lds, st, ka);
+      break;
+    case EPI_RES_LN:
+      lds += (size_t)R * (64 * NT + 4) * sizeof(float);
+      hipLaunchKernelGGL((gemm_rows_kernel<RM, NT, EPI_RES_LN>), grid, dim3(256), lds, st, ka);
+      break;
+    case EPI_ARGMAX:
+      lds += (size_t)R * 4 * (sizeof(float) + sizeof(int));
+      hipLaunchKernelGGL((gemm_rows_kernel<RM, NT, EPI_ARGMAX>), grid, dim3(256), lds, st, ka);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmArgs &a, int epilogue, int rows_per_block, hipStream_t st) {
+  if (a.w.K % 64 != 0 || a.w.K <= 0 || a.M <= 0 || a.w.N <= 0) return hipErrorInvalidValue;
+  if ((a.x_f32 == nullptr) == (a.x_i8 == nullptr)) return hipErrorInvalidValue;
+  if (a.x_f32 && (a.lda % 4 != 0)) return hipErrorInvalidValue;
+  if (a.x_i8 && (a.lda % 16 != 0)) return hipErrorInvalidValue;
+  int nt;
+  const int col_blocks = gemm_col_blocks(a.w.N, epilogue, &nt);
+  if (epilogue == EPI_RES_LN && (a.w.N % 64 != 0 || a.w.N > 512)) return hipErrorInvalidValue;
+  if (epilogue == EPI_ARGMAX && a.n_parts != col_blocks) return hipErrorInvalidValue;
+  GemmKArgs ka;
+  ka.g = a;
+  ka.KS = a.w.K / 64;
+  ka.u = a.w.u;
+  int rm = rows_per_block / 16;
+  if (nt == 8 && rm > 2) rm = 2;  // register budget
+  const dim3 grid((a.M + 16 * rm - 1) / (16 * rm), col_blocks);
+#define SLIMT_GEMM_CASE(RM_, NT_) \
+  if (rm == RM_ && nt == NT_) return launch_gemm_t<RM_, NT_>(ka, epilogue, grid, st);
+  SLIMT_GEMM_CASE(1, 1) SLIMT_GEMM_CASE(1, 2) SLIMT_GEMM_CASE(1, 4) SLIMT_GEMM_CASE(1, 8)
+  SLIMT_GEMM_CASE(2, 1) SLIMT_GEMM_CASE(2, 2) SLIMT_GEMM_CASE(2, 4) SLIMT_GEMM_CASE(2, 8)
+  SLIMT_GEMM_CASE(4, 1) SLIMT_GEMM_CASE(4, 2) SLIMT_GEMM_CASE(4, 4)
+#undef SLIMT_GEMM_CASE
+  return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// SSRU cell (Modules.cc:190-235): f = affine(Wf, bf)(x); Wx = dot(W)(x);
+// c' = sigmoid(f) c + (1 - sigmoid(f)) Wx; h = LN(x + relu(c')); state <- c'
+// One block = 16 sentences x the full D columns; both GEMMs share the block.
+// ---------------------------------------------------------------------------
+
+template <int NT>
+__global__ __launch_bounds__(256) void ssru_kernel(SsruArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BN = 64 * NT;
+  constexpr int LDR = BN + 4;
+  char *Af = smem;             // x quantised with Wf's multiplier
+  char *Aw = smem + 16 * LDA;  // x quantised with W's multiplier
+  float *rowbuf = reinterpret_cast<float *>(smem + 2 * 16 * LDA);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int nt0 = wave * NT;
+  const int D = a.D, KS = D / 64;
+  const v4i *Wpf = reinterpret_cast<const v4i *>(a.wf.Wp);
+  const v4i *Wpw = reinterpret_cast<const v4i *>(a.w.Wp);
+
+  v4i accf[NT], accw[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) accf[nt] = accw[nt] = v4i{0, 0, 0, 0};
+
+  for (int k0 = 0; k0 < D; k0 += KCH) {
+    const int kc = (D - k0) < KCH ? (D - k0) : KCH;
+    if (k0) __syncthreads();
+    stage_A_f32<1>(Af, a.x, D, a.B, m0, k0, kc, a.wf.a_quant, tid);
+    stage_A_f32<1>(Aw, a.x, D, a.B, m0, k0, kc, a.w.a_quant, tid);
+    __syncthreads();
+    const int ksteps = kc >> 6;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const v4i af = *reinterpret_cast<const v4i *>(Af + lr * LDA + ks * 64 + lg * 16);
+      const v4i aw = *reinterpret_cast<const v4i *>(Aw + lr * LDA + ks * 64 + lg * 16);
+      const int kstep = (k0 >> 6) + ks;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const size_t off = ((size_t)(nt0 + nt) * KS + kstep) * 64 + lane;
+        accf[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, Wpf[off], accf[nt], 0, 0, 0);
+        accw[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw, Wpw[off], accw[nt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = (nt0 + nt) * 16 + lr;
+    const int csf = a.wf.colsum[col], csw = a.w.colsum[col];
+    const float pbf = a.wf.pb[col], pbw = a.w.pb[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rl = lg * 4 + r;
+      const int row = m0 + rl;
+      float v = 0.0f;
+      if (row < a.B) {
+        float f = (float)(accf[nt][r] + 127 * csf) * a.wf.u;
+        f = f + pbf;
+        float wx = (float)(accw[nt][r] + 127 * csw) * a.w.u;
+        wx = wx + pbw;
+        const size_t o = (size_t)row * D + col;
+        const float c = a.state[o];
+        const float sg = sigmoid_p(f);  // highway(c, Wx, f), TensorOps.cc:674-678
+        const float t1 = sg * c;
+        const float t2 = (1.0f - sg) * wx;
+        const float cn = t1 + t2;
+        a.state[o] = cn;
+        const float y = cn > 0.0f ? cn : 0.0f;
+        v = a.x[o] + y;  // Modules.cc:230
+      }
+      rowbuf[rl * LDR + col] = v;
+    }
+  }
+  __syncthreads();
+  for (int rl = wave; rl < 16; rl += 4) {
+    const int row = m0 + rl;
+    if (row < a.B)
+      wave_layer_norm_row(rowbuf + rl * LDR, a.ln_scale, a.ln_bias, a.eps, D,
+                          a.h + (size_t)row * D, lane);
+  }
+}
+
+hipError_t launch_ssru(const SsruArgs &a, hipStream_t st) {
+  if (a.D % 64 != 0 || a.D > 512) return hipErrorInvalidValue;
+  const int nt = a.D / 64;
+  const dim3 grid((a.B + 15) / 16);
+  const size_t lds = 2 * 16 * LDA + 16 * (size_t)(a.D + 4) * sizeof(float);
+  switch (nt) {
+    case 1: hipLaunchKernelGGL(ssru_kernel<1>, grid, dim3(256), lds, st, a); break;
+    case 2: hipLaunchKernelGGL(ssru_kernel<2>, grid, dim3(256), lds, st, a); break;
+    case 4: hipLaunchKernelGGL(ssru_kernel<4>, grid, dim3(256), lds, st, a); break;
+    case 8: hipLaunchKernelGGL(ssru_kernel<8>, grid, dim3(256), lds, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// embeddings
+// ---------------------------------------------------------------------------
+
+// E[tok][d] = float(q) * (1/mult)   (Io.cc:275-283), then * sqrt(D), then
+// + pos[s][d]  (Transformer.cc:24-49). Separate roundings, as in the reference.
+__device__ __forceinline__ float embed1(const EmbedArgs &e, uint32_t tok, int d, const float *pos) {
+  const float v = (float)e.wemb[(size_t)tok * e.D + d] * e.inv_mult;
+  const float s = v * e.sqrt_d;
+  return s + pos[d];
+}
+
+__global__ void embed_encoder_kernel(EmbedArgs e, const uint32_t *ids, int S, float *x) {
+  const int row = blockIdx.x;  // b * S + s
+  const int s = row % S;
+  const uint32_t tok = ids[row];
+  for (int d = threadIdx.x; d < e.D; d += blockDim.x)
+    x[(size_t)row * e.D + d] = embed1(e, tok, d, e.pos + (size_t)s * e.D);
+}
+
+hipError_t launch_embed_encoder(const EmbedArgs &e, const uint32_t *ids, int B, int S, float *x,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(embed_encoder_kernel, dim3(B * S), dim3(e.D < 256 ? 64 : 256), 0, st, e, ids,
+                     S, x);
+  return hipGetLastError();
+}
+
+// One block (64 threads) per sentence. Position is ALWAYS 0 in the decoder
+// (Transformer.cc:160); step 0 embeds zeros (Transformer.cc:138-144).
+__global__ __launch_bounds__(64) void decode_begin_step_kernel(EmbedArgs e, DecodeState s,
+                                                               int first, int with_embed,
+                                                               const float *part_val,
+                                                               const int *part_idx, int n_parts,
+                                                               float *x) {
+  const int b = blockIdx.x;
+  __shared__ uint32_t tok_s;
+  if (!first && threadIdx.x == 0) {
+    // finish the argmax: partials are in ascending column order
+    float bv = part_val[(size_t)b * n_parts];
+    int bi = part_idx[(size_t)b * n_parts];
+    for (int p = 1; p < n_parts; ++p) {
+      const float v = part_val[(size_t)b * n_parts + p];
+      if (v > bv) {
+        bv = v;
+        bi = part_idx[(size_t)b * n_parts + p];
+      }
+    }
+    const uint32_t tok = s.shortlist ? s.shortlist[bi] : (uint32_t)bi;
+    s.prev[b] = tok;
+    if (!s.finished[b]) {  // record(), Model.cc:127-137
+      const uint32_t n = s.out_len[b];
+      if ((int)n < s.Tmax) s.out_ids[(size_t)b * s.Tmax + n] = tok;
+      s.out_len[b] = n + 1;
+      if (tok == s.eos) {
+        s.finished[b] = 1;
+        atomicAdd(s.n_finished, 1);
+      }
+    }
+    tok_s = tok;
+  }
+  __syncthreads();
+  if (!with_embed) return;
+  if (first) {
+    for (int d = threadIdx.x; d < e.D; d += 64) {
+      const float z = 0.0f * e.sqrt_d;
+      x[(size_t)b * e.D + d] = z + e.pos[d];
+    }
+  } else {
+    const uint32_t tok = tok_s;
+    for (int d = threadIdx.x; d < e.D; d += 64) x[(size_t)b * e.D + d] = embed1(e, tok, d, e.pos);
+  }
+}
+
+hipError_t launch_decode_begin_step(const EmbedArgs &e, const DecodeState &s, int B, int first,
+                                    int with_embed, const float *part_val, const int *part_idx,
+                                    int n_parts, float *x, hipStream_t st) {
+  hipLaunchKernelGGL(decode_begin_step_kernel, dim3(B), dim3(64), 0, st, e, s, first, with_embed,
+                     part_val, part_idx, n_parts, x);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void embed_decoder_kernel(EmbedArgs e, const uint32_t *prev,
+                                                           int first, float *x) {
+  const int b = blockIdx.x;
+  if (first) {
+    for (int d = threadIdx.x; d < e.D; d += 64) {
+      const float z = 0.0f * e.sqrt_d;
+      x[(size_t)b * e.D + d] = z + e.pos[d];
+    }
+  } else {
+    const uint32_t tok = prev[b];
+    for (int d = threadIdx.x; d < e.D; d += 64) x[(size_t)b * e.D + d] = embed1(e, tok, d, e.pos);
+  }
+}
+
+hipError_t launch_embed_decoder(const EmbedArgs &e, const uint32_t *prev, int B, int first,
+                                float *x, hipStream_t st) {
+  hipLaunchKernelGGL(embed_decoder_kernel, dim3(B), dim3(64), 0, st, e, prev, first, x);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// attention (Modules.cc:24-86): one block per (sentence, head); K and V tiles
+// of that head staged in LDS once, queries spread over the block's waves.
+// f32 throughout; score = alpha * (k-ascending fmaf chain); softmax in the
+// portable order; out = key-ascending fmaf chain.
+// ---------------------------------------------------------------------------
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int S = a.S, dh = a.dh, LDK = dh + 1;
+  float *Ks = reinterpret_cast<float *>(smem);
+  float *Vs = Ks + S * LDK;
+  for (int i = tid; i < S * dh; i += 64 * NW) {
+    const int j = i / dh, d = i - j * dh;
+    Ks[j * LDK + d] = a.k[(size_t)(b * S + j) * a.ldk + h * dh + d];
+    Vs[j * LDK + d] = a.v[(size_t)(b * S + j) * a.ldv + h * dh + d];
+  }
+  __syncthreads();
+  // additive mask of this sentence for this lane's keys (Input.cc:49-63)
+  float mask0, mask1;
+  {
+    const int j0 = lane, j1 = lane + 64;
+    if (a.mask) {
+      mask0 = j0 < S ? a.mask[(size_t)b * S + j0] : 0.0f;
+      mask1 = j1 < S ? a.mask[(size_t)b * S + j1] : 0.0f;
+    } else {
+      const int len = (int)a.lengths[b];
+      const float minus_inf = -99999999.0f;
+      mask0 = (1.0f - (j0 < len ? 1.0f : 0.0f)) * minus_inf;
+      mask1 = (1.0f - (j1 < len ? 1.0f : 0.0f)) * minus_inf;
+    }
+  }
+  const int j0c = lane < S ? lane : S - 1;
+  const int j1c = (lane + 64) < S ? (lane + 64) : S - 1;
+  const int dc = lane < dh ? lane : dh - 1;
+  for (int qi = wave; qi < a.Tq; qi += NW) {
+    const float qv = a.q[(size_t)(b * a.Tq + qi) * a.ldq + h * dh + dc];
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int k = 0; k < dh; ++k) {
+      const float qk = __shfl(qv, k, 64);
+      s0 = __builtin_fmaf(qk, Ks[j0c * LDK + k], s0);
+      s1 = __builtin_fmaf(qk, Ks[j1c * LDK + k], s1);
+    }
+    if (a.alpha != 1.0f) {
+      s0 = a.alpha * s0;
+      s1 = a.alpha * s1;
+    }
+    s0 = s0 + mask0;
+    s1 = s1 + mask1;
+    const float lowest = -3.402823466e+38f;
+    if (lane >= S) s0 = lowest;
+    if (lane + 64 >= S) s1 = lowest;
+    const float m = wave_max(fmaxf(s0, s1));
+    const float e0 = lane < S ? exp_p(s0 - m) : 0.0f;
+    const float e1 = (lane + 64) < S ? exp_p(s1 - m) : 0.0f;
+    const float sum = wave_sum(e0 + e1);
+    const float p0 = e0 / sum, p1 = e1 / sum;
+    if (a.attn) {
+      float *ap = a.attn + ((size_t)(b * a.H + h) * a.Tq + qi) * S;
+      if (lane < S) ap[lane] = p0;
+      if (lane + 64 < S) ap[lane + 64] = p1;
+    }
+    if (a.align && h == 0 && !a.finished[b]) {  // update_alignment, Model.cc:84-108
+      const int len = (int)a.lengths[b];
+      const uint32_t t = a.out_len[b];
+      if ((int)t < a.Tmax) {
+        float *al = a.align + ((size_t)b * a.Tmax + t) * S;
+        if (lane < len) al[lane] = p0;
+        if (lane + 64 < len) al[lane + 64] = p1;
+      }
+    }
+    float o = 0.0f;
+    for (int j = 0; j < S; ++j) {
+      const float pj = __shfl(j < 64 ? p0 : p1, j & 63, 64);
+      o = __builtin_fmaf(pj, Vs[j * LDK + dc], o);
+    }
+    if (lane < dh) a.out[(size_t)(b * a.Tq + qi) * a.ldo + h * dh + lane] = o;
+  }
+}
+
+hipError_t launch_attention(const AttnArgs &a, hipStream_t st) {
+  if (a.S < 1 || a.S > 128 || a.dh < 1 || a.dh > 64) return hipErrorInvalidValue;
+  const size_t lds = 2 * (size_t)a.S * (a.dh + 1) * sizeof(float);
+  const dim3 grid(a.B * a.H);
+  if (a.Tq == 1)
+    hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(64), lds, st, a);
+  else
+    hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// stand-alone float ops (op-level C ABI; the engine uses the fused forms)
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float *x, const float *scale,
+                                                         const float *bias, float eps, int rows,
+                                                         int cols, float *y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row < rows)
+    wave_layer_norm_row(x + (size_t)row * cols, scale, bias, eps, cols, y + (size_t)row * cols,
+                        threadIdx.x & 63);
+}
+
+hipError_t launch_layer_norm(const float *x, const float *scale, const float *bias, float eps,
+                             int rows, int cols, float *y, hipStream_t st) {
+  hipLaunchKernelGGL(layer_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, scale, bias,
+                     eps, rows, cols, y);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void softmax_kernel(const float *x, int rows, int cols,
+                                                      float *y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float *xr = x + (size_t)row * cols;
+  float *yr = y + (size_t)row * cols;
+  float m = -3.402823466e+38f;
+  for (int i = lane; i < cols; i += 64) m = fmaxf(m, xr[i]);
+  m = wave_max(m);
+  float s = 0.0f;
+  for (int i = lane; i < cols; i += 64) s += exp_p(xr[i] - m);
+  s = wave_sum(s);
+  for (int i = lane; i < cols; i += 64) yr[i] = exp_p(xr[i] - m) / s;
+}
+
+hipError_t launch_softmax(const float *x, int rows, int cols, float *y, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, rows, cols, y);
+  return hipGetLastError();
+}
+
+__global__ void highway_kernel(const float *x, const float *y, const float *g, size_t n,
+                               float *out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sg = sigmoid_p(g[i]);
+  const float t1 = sg * x[i];
+  const float t2 = (1.0f - sg) * y[i];
+  out[i] = t1 + t2;
+}
+
+hipError_t launch_highway(const float *x, const float *y, const float *g, size_t n, float *out,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(highway_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, g,
+                     n, out);
+  return hipGetLastError();
+}
+
+// transpose_3120 (TensorOps.cc:98-121): [B, d2, d1, d0] -> [B, d1, d2, d0]
+__global__ void transpose_heads_kernel(const float *in, int d2, int d1, int d0, float *out) {
+  const int b = blockIdx.z, i2 = blockIdx.y, i1 = blockIdx.x;
+  const float *src = in + (((size_t)b * d2 + i2) * d1 + i1) * d0;
+  float *dst = out + (((size_t)b * d1 + i1) * d2 + i2) * d0;
+  for (int i = threadIdx.x; i < d0; i += blockDim.x) dst[i] = src[i];
+}
+
+hipError_t launch_transpose_heads(const float *in, int B, int d2, int d1, int d0, float *out,
+                                  hipStream_t st) {
+  hipLaunchKernelGGL(transpose_heads_kernel, dim3(d1, d2, B), dim3(64), 0, st, in, d2, d1, d0, out);
+  return hipGetLastError();
+}
+
+}  // namespace slimt_hip

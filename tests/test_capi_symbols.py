@@ -1,0 +1,85 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads, exports
+every entry point include/slimt_hip.h declares, its host-side functions work,
+and its compute entry points FAIL LOUDLY without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "slimt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(slimt_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from slimt_amd import build, capi
+    path = build.build()
+    assert os.path.exists(path)
+    dll = ctypes.CDLL(path)
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(dll, n), f"{n} declared in slimt_hip.h but not exported"
+    assert sorted(capi.SYMBOLS) == names
+    assert capi.lib().slimt_hip_abi_version() == 1
+
+
+def test_no_oracle_in_product():
+    """The product path must never import/link the oracle or /root/reference."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "slimt_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hh", ".cc")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "slimt_oracle" not in src and "from oracle" not in src, f
+                assert "import oracle" not in src, f
+                assert "/root/reference" not in src, f
+
+
+def test_host_side_prepare_functions(oracle):
+    from slimt_amd import capi
+    r = np.random.Generator(np.random.PCG64(0))
+    w = r.normal(0, 0.2, size=(40, 64)).astype(np.float32)
+    w[0, :4] = [0.5 / 100, 1.5 / 100, -2.5 / 100, 3.0]  # ties + saturation
+    got = capi.prepare_weight_transposed(w, 100.0)
+    want = oracle.quantize(w, 100.0)
+    assert np.array_equal(got, want)
+    q = r.integers(-127, 128, size=(24, 128)).astype(np.int8)
+    assert np.array_equal(capi.prepare_weight_quantized_transposed(q, 128, 24), q)
+
+
+def test_compute_fails_loudly_without_gpu():
+    from slimt_amd import capi, synth
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    x = np.zeros((2, 64), dtype=np.float32)
+    W = np.zeros((16, 64), dtype=np.int8)
+    with pytest.raises(capi.SlimtHipError):
+        capi.affine(x, W, None, 1.0, 1.0)
+    m = synth.make_model("micro")
+    with pytest.raises(capi.SlimtHipError) as e:
+        capi.Model(m)
+    assert "no HIP device" in str(e.value) or "hip" in str(e.value).lower()
+
+
+def test_bin_roundtrip():
+    from slimt_amd import synth
+    m = synth.make_model("micro", eos_bias=2.0)
+    buf = synth.write_bin(m)
+    back = synth.model_from_bin(buf, enc_layers=m.enc_layers, dec_layers=m.dec_layers)
+    assert back.D == m.D and back.F == m.F and back.V == m.V
+    assert set(back.params) == set(m.params)
+    for k, p in m.params.items():
+        q = back.params[k]
+        assert (q.rows, q.cols, q.kind) == (p.rows, p.cols, p.kind)
+        assert np.array_equal(np.asarray(q.data).reshape(-1), np.asarray(p.data).reshape(-1))
+        assert np.float32(q.mult) == np.float32(p.mult)
+    # 256-byte aligned payload start (Io.cc:151-153)
+    import struct
+    n = struct.unpack_from("<Q", buf, 8)[0]
+    assert n == len(m.params) + 1

@@ -1,0 +1,150 @@
+"""GPU parity of the engine-level boundary (Encoder::forward, Decoder::step,
+Model::forward) through the C ABI, against the CPU oracle on the same seeded
+synthetic models. Everything is compared BIT-EXACT against the oracle's
+PORTABLE float order (so every int8 activation, every int32 accumulator and
+every token along the way is identical); the distance to the reference's own
+scalar float order (FAITHFUL) is a float-rounding effect bounded separately
+in tests/test_oracle.py and per op in tests/test_gpu_ops.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# (preset, eos_bias, B, S, shortlist size or None, ragged)
+CONFIGS = [
+    ("micro", 3.0, 8, 8, 128, True),
+    ("micro", 3.0, 5, 7, None, True),      # full vocab, B not a multiple of 16
+    ("mini", 1.0, 16, 12, 256, True),
+    ("mini", 1.0, 33, 9, 1000, False),
+    ("tiny11", 6.0, 16, 16, 1024, True),
+    ("base", 6.0, 4, 8, 512, True),
+]
+
+
+@pytest.fixture(scope="module")
+def engines(hip, oracle, synth_models):
+    cache = {}
+
+    def get(preset, eos_bias):
+        key = (preset, eos_bias)
+        if key not in cache:
+            m = synth_models(preset, eos_bias)
+            cache[key] = (m, hip.Model(m), oracle.OracleModel(m))
+        return cache[key]
+
+    yield get
+    for _, gm, _ in cache.values():
+        gm.close()
+
+
+@pytest.mark.parametrize("preset,eos_bias,B,S,n_sl,ragged", CONFIGS)
+def test_encoder_every_layer_bit_exact(hip, oracle, engines, preset, eos_bias, B, S, n_sl, ragged):
+    from slimt_amd import synth
+    m, gm, om = engines(preset, eos_bias)
+    ids, lens = synth.make_batch(m.V, B, S, seed=B * 100 + S, ragged=ragged)
+    ctx = hip.Context(gm, B, S)
+    enc, emb, layers = ctx.encode(ids, lens, want_embed=True, want_layers=True)
+    oracle.set_mode(oracle.PORTABLE)
+    mask = oracle.make_mask(lens, S)
+    x = om.embed(ids)
+    assert np.array_equal(emb, x)
+    for l in range(1, m.enc_layers + 1):
+        x = om.encoder_layer(l, x, mask)
+        assert np.array_equal(layers[l - 1], x), (l, np.abs(layers[l - 1] - x).max())
+    assert np.array_equal(enc, x)
+    oracle.set_mode(oracle.FAITHFUL)
+    ctx.close()
+
+
+@pytest.mark.parametrize("preset,eos_bias,B,S,n_sl,ragged", CONFIGS)
+def test_decoder_steps_teacher_forced_bit_exact(hip, oracle, engines, preset, eos_bias, B, S, n_sl,
+                                                ragged):
+    """Decoder::step with random previous tokens: logits, last-layer attention
+    and SSRU states after every step."""
+    from slimt_amd import synth
+    m, gm, om = engines(preset, eos_bias)
+    ids, lens = synth.make_batch(m.V, B, S, seed=B * 100 + S + 1, ragged=ragged)
+    sl = None if n_sl is None else synth.make_shortlist(m.V, n_sl)
+    ctx = hip.Context(gm, B, S)
+    enc, _, _ = ctx.encode(ids, lens)
+    ctx.decode_begin(sl)
+    oracle.set_mode(oracle.PORTABLE)
+    mask = oracle.make_mask(lens, S)
+    states = np.zeros((m.dec_layers, B, m.D), dtype=np.float32)
+    r = np.random.Generator(np.random.PCG64(5))
+    prev = None
+    for t in range(5):
+        want_logits, want_attn = om.decode_step(enc, mask, states, prev, sl)
+        logits, attn, st = ctx.decode_step(prev)
+        assert np.array_equal(st, states), (t, np.abs(st - states).max())
+        assert np.array_equal(attn, want_attn), t
+        assert np.array_equal(logits, want_logits), (t, np.abs(logits - want_logits).max())
+        pool = np.arange(m.V) if sl is None else sl
+        prev = r.choice(pool, size=B).astype(np.uint32)
+    oracle.set_mode(oracle.FAITHFUL)
+    ctx.close()
+
+
+@pytest.mark.parametrize("preset,eos_bias,B,S,n_sl,ragged", CONFIGS)
+def test_translate_tokens_lengths_alignments(hip, oracle, engines, preset, eos_bias, B, S, n_sl,
+                                             ragged):
+    """Model::forward: identical greedy tokens, lengths (EOS bookkeeping) and
+    alignment rows, including sentences that finish at staggered steps."""
+    from slimt_amd import synth
+    m, gm, om = engines(preset, eos_bias)
+    ids, lens = synth.make_batch(m.V, B, S, seed=B * 100 + S + 2, ragged=ragged)
+    sl = None if n_sl is None else synth.make_shortlist(m.V, n_sl)
+    ctx = hip.Context(gm, B, S)
+    out, ln, al = ctx.translate(ids, lens, sl, limit_factor=1.5, eos_id=0, want_align=True)
+    oracle.set_mode(oracle.PORTABLE)
+    w_out, w_ln, w_al, steps = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
+    oracle.set_mode(oracle.FAITHFUL)
+    assert np.array_equal(ln, w_ln), (ln, w_ln)
+    assert np.array_equal(out, w_out)
+    assert np.array_equal(al, w_al)
+    # a second call on the same context must not see stale state
+    out2, ln2, _ = ctx.translate(ids, lens, sl, limit_factor=1.5, eos_id=0)
+    assert np.array_equal(out2, out) and np.array_equal(ln2, ln)
+    ctx.close()
+
+
+def test_translate_limit_factor_and_reuse(hip, oracle, engines):
+    from slimt_amd import synth
+    m, gm, om = engines("micro", 3.0)
+    ctx = hip.Context(gm, 16, 16)
+    oracle.set_mode(oracle.PORTABLE)
+    for (B, S, lf) in [(1, 1, 1.5), (2, 3, 1.0), (16, 16, 0.5), (3, 5, 2.5)]:
+        ids, lens = synth.make_batch(m.V, B, S, seed=B + S, ragged=B > 2)
+        out, ln, _ = ctx.translate(ids, lens, None, limit_factor=lf)
+        w_out, w_ln, _, _ = om.translate(ids, lens, None, lf, 0)
+        assert np.array_equal(out, w_out) and np.array_equal(ln, w_ln), (B, S, lf)
+    oracle.set_mode(oracle.FAITHFUL)
+    with pytest.raises(hip.SlimtHipError):
+        ctx.translate(np.zeros((17, 4), np.uint32), np.full(17, 4, np.uint32))  # B > workspace
+    with pytest.raises(hip.SlimtHipError):
+        ctx.translate(np.full((2, 4), m.V, np.uint32), np.full(2, 4, np.uint32))  # bad token id
+    ctx.close()
+
+
+def test_decode_invariants_at_bench_size(hip, engines):
+    """Size-independent properties at BASELINE's headline size (tiny11, B=256,
+    S=32, shortlist 4096): sentences are independent (batch rows can be
+    permuted / split without changing any token), tokens come from the
+    shortlist, lengths are capped at floor(1.5*S), and two runs agree."""
+    from slimt_amd import synth
+    m, gm, _ = engines("tiny11", 6.0)
+    B, S = 256, 32
+    ids, lens = synth.make_batch(m.V, B, S, seed=77, ragged=True)
+    sl = synth.make_shortlist(m.V, 4096)
+    ctx = hip.Context(gm, B, S)
+    out, ln, _ = ctx.translate(ids, lens, sl)
+    assert out.shape == (B, 48) and ln.max() <= 48 and ln.min() >= 1
+    for b in range(B):
+        assert np.all(np.isin(out[b, : ln[b]], sl))
+    perm = np.random.Generator(np.random.PCG64(1)).permutation(B)
+    out_p, ln_p, _ = ctx.translate(ids[perm], lens[perm], sl)
+    assert np.array_equal(out_p, out[perm]) and np.array_equal(ln_p, ln[perm])
+    half = B // 2
+    out_h, ln_h, _ = ctx.translate(ids[:half], lens[:half], sl)
+    assert np.array_equal(out_h, out[:half]) and np.array_equal(ln_h, ln[:half])
+    ctx.close()
