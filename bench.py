@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: target tokens/s, en-de tiny11 int8 greedy decode at
+batch 256 (BASELINE.json), on N MI355X of one node.
+
+A "step" = one pass of the hot path (Model::forward: embed + 6-layer encoder +
+greedy decode loop) over one batch of 256 synthetic sentences, inputs already
+resident in HBM. N > 1: one process per GPU (torchrun), weights replicated,
+each rank translates its own batches, no data-path collective (sentences are
+independent); torch.distributed is used only for the barrier and the
+max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on
+the stream the kernel runs on, over the timed region) and `cpu_baseline` (the
+CPU port of the reference path, timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_INT8_TOPS = 5000.0  # dense int8 MFMA, 2x the ~2.5 PF bf16 (MI355X_MICROARCH.md, Matrix cores)
+PEAK_HBM_GBS = 8000.0    # HBM3E spec (MI355X_MICROARCH.md, Chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preset", default="tiny11")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--src-len", type=int, default=32)
+    ap.add_argument("--shortlist", type=int, default=4096, help="0 = full vocabulary")
+    ap.add_argument("--profile-kernel", default="auto",
+                    help="kernel family bracketed by HIP events in the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sentences", type=int, default=16)
+    ap.add_argument("--all-kernels", action="store_true",
+                    help="after the timed region, time every kernel family (untimed pass)")
+    return ap.parse_args()
+
+
+def algorithmic_macs_per_sentence(D, F, Le, Ld, S, T, N):
+    """int8 MACs, cross-attention K/V computed once."""
+    return S * (Le * (4 * D * D + 2 * D * F) + Ld * 2 * D * D) + T * (Ld * (4 * D * D + 2 * D * F) + D * N)
+
+
+def cpu_baseline(model, S, T, n_sl, n_sent):
+    """The CPU port of the reference's op sequence (per-step K/V recompute and
+    per-call PrepareBias included), FAITHFUL float order, on the host cores."""
+    from oracle import oracle as O
+    from slimt_amd import synth
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(threads, 64))
+    O.set_mode(O.FAITHFUL)
+    om = O.OracleModel(model, reference_cost=True, threads=threads)
+    ids, lens = synth.make_batch(model.V, n_sent, S, seed=4321)
+    sl = synth.make_shortlist(model.V, n_sl) if n_sl else None
+    t0 = time.perf_counter()
+    out, ln, _, steps = om.translate(ids, lens, sl, 1.5, 0)
+    dt = time.perf_counter() - t0
+    toks = int(ln.sum())
+    return {
+        "value": toks / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+        "sample": f"{n_sent} sentences x S={S}, {steps} decode steps, {toks} tokens in {dt:.2f}s; "
+                  "C port of slimt's intgemm op sequence (AVX512-VNNI vpdpbusd when available, "
+                  "per-step K/V recompute + PrepareBias as in the reference), OpenMP over rows",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    from slimt_amd import capi, synth
+
+    if not torch.cuda.is_available() or capi.device_count() <= 0:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    B, S = args.batch, args.src_len
+    T = int(np.float32(1.5) * np.float32(S))
+    model = synth.make_model(args.preset, seed=1234, eos_bias=-100.0)  # nobody emits EOS
+    n_sl = args.shortlist
+    sl = synth.make_shortlist(model.V, n_sl) if n_sl else None
+    N_out = n_sl if n_sl else model.V
+    gm = capi.Model(model, device=local_rank)
+    ctx = capi.Context(gm, B, S)
+    dev = torch.device("cuda", local_rank)
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+
+    # a few distinct batches, resident in HBM before the timed region
+    n_batches = 4
+    batches = []
+    for i in range(n_batches):
+        ids, lens = synth.make_batch(model.V, B, S, seed=4321 + 97 * rank + i)
+        batches.append((to_dev(ids), to_dev(lens)))
+    d_sl = to_dev(sl) if sl is not None else None
+    d_out = torch.zeros((B, T), dtype=torch.int32, device=dev)
+    d_len = torch.zeros((B,), dtype=torch.int32, device=dev)
+
+    def step(i):
+        d_ids, d_lens = batches[i % n_batches]
+        ctx.translate_device(d_ids.data_ptr(), d_lens.data_ptr(), B, S,
+                             d_sl.data_ptr() if d_sl is not None else 0, n_sl, 1.5, 0,
+                             d_out.data_ptr(), d_len.data_ptr(), 0, steps_hint=T)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    tokens_per_step = int(d_len.sum().item())
+
+    kmap = {"gemm_enc": capi.K_GEMM_ENC, "gemm_dec": capi.K_GEMM_DEC, "logits": capi.K_LOGITS,
+            "attn_enc": capi.K_ATTN_ENC, "attn_dec": capi.K_ATTN_DEC, "ssru": capi.K_SSRU}
+    prof_name = "gemm_dec" if args.profile_kernel == "auto" else args.profile_kernel
+    ctx.profile_enable(kmap[prof_name])
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(capi.K_NONE)
+
+    dt_max = dt
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_max = float(t.item())
+        tk = torch.tensor([tokens_per_step], dtype=torch.int64, device=dev)
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        total_tokens_per_step = int(tk.item())
+    else:
+        total_tokens_per_step = tokens_per_step
+
+    per_kernel = None
+    if args.all_kernels and rank == 0:
+        per_kernel = {}
+        for name, kid in kmap.items():
+            ctx.profile_enable(kid)
+            for i in range(2):
+                step(i)
+            r = ctx.profile_read()
+            per_kernel[name] = {"launches_per_step": r["launches"] / 2,
+                                "ms_per_step": r["total_ms"] / 2,
+                                "avg_us": 1e3 * r["total_ms"] / max(1, r["launches"])}
+        ctx.profile_enable(capi.K_NONE)
+
+    if rank == 0:
+        value = total_tokens_per_step * args.steps / dt_max
+        avg_ms = prof["total_ms"] / max(1, prof["launches"])
+        ops = 2.0 * prof["int8_macs"] / max(1, prof["launches"])       # algorithmic int8 OPs / launch
+        wbytes = prof["weight_bytes"] / max(1, prof["launches"])       # algorithmic weight bytes / launch
+        achieved = ops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        macs_sentence = algorithmic_macs_per_sentence(model.D, model.F, model.enc_layers,
+                                                      model.dec_layers, S, T, N_out)
+        out = {
+            "metric": "target tokens/sec, en-de tiny11 int8 greedy, batch=256",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8", "data": "synthetic",
+            "config": {
+                "workload": f"en-de {args.preset} int8 greedy decode, batch={B} sentences/GPU, "
+                            f"S={S} source tokens, T={T} decode steps, "
+                            f"{'shortlist ' + str(n_sl) if n_sl else 'full 32k vocabulary'}",
+                "preset": args.preset, "batch_per_gpu": B, "src_len": S, "decode_steps": T,
+                "shortlist": n_sl, "parallelism": f"dp{world} (replicated weights, no collective)",
+                "tokens_per_step_all_gpus": total_tokens_per_step,
+                "int8_ops_per_token": 2.0 * macs_sentence / T,
+                "whole_job_int8_tops": 2.0 * macs_sentence * B * world * args.steps / dt_max / 1e12,
+            },
+            "roofline": {
+                "kernel": prof_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_INT8_TOPS,
+                "unit": "TOP/s", "frac": achieved / PEAK_INT8_TOPS, "traffic": None,
+                "launches": prof["launches"], "avg_launch_us": 1e3 * avg_ms,
+                "algorithmic_ops_per_launch": ops, "algorithmic_weight_bytes_per_launch": wbytes,
+                "hbm_achieved_GBs": wbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                "hbm_frac": (wbytes / (avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if avg_ms > 0 else 0.0,
+            },
+        }
+        if per_kernel is not None:
+            out["per_kernel"] = per_kernel
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, S, T, n_sl, args.cpu_sentences)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    gm.close()
+
+
+if __name__ == "__main__":
+    main()
