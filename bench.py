@@ -136,7 +136,7 @@ def main():
     kmap = {"gemm_enc": capi.K_GEMM_ENC, "gemm_dec": capi.K_GEMM_DEC, "logits": capi.K_LOGITS,
             "attn_enc": capi.K_ATTN_ENC, "attn_dec": capi.K_ATTN_DEC, "ssru": capi.K_SSRU}
     prof_name = "gemm_dec" if args.profile_kernel == "auto" else args.profile_kernel
-    ctx.profile_enable(kmap[prof_name])
+    ctx.profile_enable(kmap.get(prof_name, capi.K_NONE))
 
     barrier()
     t0 = time.perf_counter()
