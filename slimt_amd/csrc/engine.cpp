@@ -539,7 +539,7 @@ void sinusoid_table(int S, int D, std::vector<float> &out) {
 
 void ctx_free(slimt_hip_ctx *c) {
   DevBuf *bufs[] = {&c->pos, &c->ids, &c->lengths, &c->x0, &c->x1, &c->q, &c->k, &c->v, &c->att,
-                    &c->h8, &c->kv, &c->dx, &c->dh, &c->dq, &c->datt, &c->dout, &c->df8,
+                    &c->h8, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
                     &c->state, &c->part_val, &c->part_idx, &c->prev, &c->out_ids, &c->out_len,
                     &c->finished, &c->n_finished, &c->align, &c->shortlist, &c->logits,
                     &c->attn_dbg};
@@ -572,9 +572,9 @@ int ctx_alloc(slimt_hip_ctx *c) {
   HIPCHK(c->h8.reserve(M * F));
   HIPCHK(c->kv.reserve((size_t)m->Ld * 2 * M * D * 4));
   HIPCHK(c->dx.reserve(B * D * 4));
+  HIPCHK(c->dx_pre.reserve(B * D * 4));
   HIPCHK(c->dh.reserve(B * D * 4));
-  HIPCHK(c->dq.reserve(B * D * 4));
-  HIPCHK(c->datt.reserve(B * D * 4));
+  HIPCHK(c->datt8.reserve(B * D));
   HIPCHK(c->dout.reserve(B * D * 4));
   HIPCHK(c->df8.reserve(B * F));
   HIPCHK(c->state.reserve((size_t)m->Ld * B * D * 4));
@@ -828,37 +828,63 @@ const AffineW &output_layer(const slimt_hip_ctx *c) {
   return c->n_sl ? c->out_sl : c->model->out_full;
 }
 
-// DecoderLayer::forward x2 (Modules.cc:237-259) on ctx->dx; result in ctx->dx.
+// The last decoder LayerNorm is applied by the consumer of ctx->dx_pre (the
+// logits GEMM, or the next layer's SSRU): rows of the final decoder state.
+RowSrc decoder_out_rows(const slimt_hip_ctx *c) {
+  const DecLayerW &L = c->model->dec.back();
+  RowSrc r;
+  r.x = c->dx_pre.as<float>();
+  r.ln_scale = L.ffn_ln.scale.as<float>();
+  r.ln_bias = L.ffn_ln.bias.as<float>();
+  return r;
+}
+
+// DecoderLayer::forward x Ld (Modules.cc:237-259). Input: the step's target
+// embedding in ctx->dx; output: pre-LayerNorm rows in ctx->dx_pre.
 int decoder_layers(slimt_hip_ctx *c, float *d_align, int Tmax, const uint32_t *d_out_len,
                    float *d_attn_dbg) {
   const slimt_hip_model *m = c->model;
   hipStream_t st = c->stream;
   const int B = c->B, S = c->S, M = B * S, D = m->D;
-  float *x = c->dx.as<float>();
   float *kv = c->kv.as<float>();
   for (int l = 0; l < m->Ld; ++l) {
     const DecLayerW &L = m->dec[(size_t)l];
-    SsruArgs s;
-    s.x = x; s.B = B; s.D = D;
+    // layer input rows: embedding (layer 0) or LN(previous layer's pre-LN rows)
+    RowSrc xin;
+    if (l == 0) {
+      xin.x = c->dx.as<float>();
+    } else {
+      const DecLayerW &P = m->dec[(size_t)l - 1];
+      xin.x = c->dx_pre.as<float>();
+      xin.ln_scale = P.ffn_ln.scale.as<float>();
+      xin.ln_bias = P.ffn_ln.bias.as<float>();
+    }
+    DSsruArgs s;
+    s.B = B; s.D = D;
+    s.x = xin;
     s.wf = L.rnn_f.w; s.w = L.rnn_w.w;
     s.state = c->state.as<float>() + (size_t)l * B * D;
-    s.ln_scale = L.rnn_ln.scale.as<float>();
-    s.ln_bias = L.rnn_ln.bias.as<float>();
-    s.h = c->dh.as<float>();
+    s.h_pre = c->dh.as<float>();
     {
       ProfScope p(c, SLIMT_HIP_K_SSRU, 2.0 * B * D * D, 2.0 * D * D);
-      HIPCHK(launch_ssru(s, st));
+      HIPCHK(launch_dssru(s, st));
     }
-    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_DEC, L.attn.q, c->dh.as<float>(), B, c->dq.as<float>(), 16));
-    AttnArgs a;
-    a.q = c->dq.as<float>();
+    RowSrc h;  // LN(x + relu(c')), Modules.cc:230
+    h.x = c->dh.as<float>();
+    h.ln_scale = L.rnn_ln.scale.as<float>();
+    h.ln_bias = L.rnn_ln.bias.as<float>();
+    // Attention::forward (Modules.cc:287-319): Q projection + SDPA over the cached K/V
+    DQAttnArgs a;
+    a.B = B; a.D = D; a.H = m->H; a.S = S;
+    a.x = h;
+    a.wq = L.attn.q.w;
     a.k = kv + (size_t)(2 * l) * M * D;
     a.v = kv + (size_t)(2 * l + 1) * M * D;
-    a.ldq = a.ldk = a.ldv = a.ldo = D;
+    a.ldk = a.ldv = D;
     a.lengths = c->lengths.as<uint32_t>();
-    a.B = B; a.H = m->H; a.Tq = 1; a.S = S; a.dh = D / m->H;
-    a.alpha = 1.0f / std::sqrt(static_cast<float>(a.dh));
-    a.out = c->datt.as<float>();
+    a.alpha = 1.0f / std::sqrt(static_cast<float>(D / m->H));
+    a.out_i8 = c->datt8.as<int8_t>();
+    a.a_quant_out = L.attn.o.w.a_quant;
     if (l + 1 == m->Ld) {  // alignment = last layer (Transformer.cc:165-174)
       a.attn = d_attn_dbg;
       if (d_align) {
@@ -869,15 +895,48 @@ int decoder_layers(slimt_hip_ctx *c, float *d_align, int Tmax, const uint32_t *d
       }
     }
     {
-      ProfScope p(c, SLIMT_HIP_K_ATTN_DEC, 0, 0);
-      HIPCHK(launch_attention(a, st));
+      ProfScope p(c, SLIMT_HIP_K_ATTN_DEC, (double)B * D * D, (double)D * D);
+      HIPCHK(launch_dqattn(a, st));
     }
-    RCCHK(run_affine_res_ln(c, SLIMT_HIP_K_GEMM_DEC, L.attn.o, c->datt.as<float>(), nullptr, B,
-                            c->dh.as<float>(), L.attn.ln, c->dout.as<float>(), 16));
-    RCCHK(run_affine_relu_q(c, SLIMT_HIP_K_GEMM_DEC, L.ffn1, c->dout.as<float>(), B,
-                            L.ffn2.w.a_quant, c->df8.as<int8_t>(), 16));
-    RCCHK(run_affine_res_ln(c, SLIMT_HIP_K_GEMM_DEC, L.ffn2, nullptr, c->df8.as<int8_t>(), B,
-                            c->dout.as<float>(), L.ffn_ln, x, 16));
+    // O projection + residual h (Modules.cc:308-314) -> pre-LN rows
+    DGemmArgs o;
+    o.B = B; o.D = D;
+    o.a_i8 = c->datt8.as<int8_t>();
+    o.w = L.attn.o.w;
+    o.res = h;
+    o.y = c->dout.as<float>();
+    o.ldy = D;
+    {
+      ProfScope p(c, SLIMT_HIP_K_GEMM_DEC, gemm_macs(B, o.w), gemm_bytes(o.w));
+      HIPCHK(launch_dgemm(o, EPI_PLAIN, st));
+    }
+    RowSrc ao;  // LN(h + O(...)), Modules.cc:316
+    ao.x = c->dout.as<float>();
+    ao.ln_scale = L.attn.ln.scale.as<float>();
+    ao.ln_bias = L.attn.ln.bias.as<float>();
+    // FFN (Modules.cc:251-257)
+    DGemmArgs f1;
+    f1.B = B; f1.D = D;
+    f1.a = ao;
+    f1.w = L.ffn1.w;
+    f1.y_i8 = c->df8.as<int8_t>();
+    f1.ldy8 = m->F;
+    f1.a_quant_out = L.ffn2.w.a_quant;
+    {
+      ProfScope p(c, SLIMT_HIP_K_GEMM_DEC, gemm_macs(B, f1.w), gemm_bytes(f1.w));
+      HIPCHK(launch_dgemm(f1, EPI_RELU_Q, st));
+    }
+    DGemmArgs f2;
+    f2.B = B; f2.D = D;
+    f2.a_i8 = c->df8.as<int8_t>();
+    f2.w = L.ffn2.w;
+    f2.res = ao;
+    f2.y = c->dx_pre.as<float>();
+    f2.ldy = D;
+    {
+      ProfScope p(c, SLIMT_HIP_K_GEMM_DEC, gemm_macs(B, f2.w), gemm_bytes(f2.w));
+      HIPCHK(launch_dgemm(f2, EPI_PLAIN, st));
+    }
   }
   return 0;
 }
@@ -904,8 +963,7 @@ int translate_device(slimt_hip_ctx *c, size_t B, size_t S, size_t n_sl, float li
   HIPCHK(hipMemsetAsync(c->n_finished.p, 0, 16, st));
   if (d_align) HIPCHK(hipMemsetAsync(d_align, 0, B * Tmax * S * 4, st));
   const AffineW &out = output_layer(c);
-  int nt;
-  const int n_parts = gemm_col_blocks(out.w.N, EPI_ARGMAX, &nt);
+  const int n_parts = dgemm_col_blocks(out.w.K, out.w.N, (int)B);
   const EmbedArgs e = embed_args(c);
   const size_t max_steps = steps_hint > 0 ? (size_t)steps_hint : (Tmax > 1 ? Tmax : 1);
   int rc = 0;
@@ -924,17 +982,17 @@ int translate_device(slimt_hip_ctx *c, size_t B, size_t S, size_t n_sl, float li
     }
     rc = decoder_layers(c, d_align, (int)Tmax, d_out_len, nullptr);
     if (rc) break;
-    GemmArgs g;
-    g.x_f32 = c->dx.as<float>();
-    g.lda = m->D;
-    g.M = (int)B;
+    DGemmArgs g;
+    g.B = (int)B;
+    g.D = m->D;
+    g.a = decoder_out_rows(c);
     g.w = out.w;
     g.part_val = c->part_val.as<float>();
     g.part_idx = c->part_idx.as<int>();
     g.n_parts = n_parts;
     {
       ProfScope p(c, SLIMT_HIP_K_LOGITS, gemm_macs((int)B, out.w), gemm_bytes(out.w));
-      he = launch_gemm(g, EPI_ARGMAX, 16, st);
+      he = launch_dgemm(g, EPI_ARGMAX, st);
     }
     if (he != hipSuccess) { rc = fail((int)he, "logits gemm: %s", hipGetErrorString(he)); break; }
   }
@@ -1060,14 +1118,14 @@ extern "C" int slimt_hip_decode_step(slimt_hip_ctx *ctx, const uint32_t *prev, f
   const AffineW &out = output_layer(ctx);
   const size_t N = (size_t)out.w.N;
   HIPCHK(ctx->logits.reserve(B * N * 4));
-  GemmArgs g;
-  g.x_f32 = ctx->dx.as<float>();
-  g.lda = m->D;
-  g.M = (int)B;
+  DGemmArgs g;
+  g.B = (int)B;
+  g.D = m->D;
+  g.a = decoder_out_rows(ctx);
   g.w = out.w;
   g.y = ctx->logits.as<float>();
   g.ldy = (int)N;
-  HIPCHK(launch_gemm(g, EPI_PLAIN, 16, st));
+  HIPCHK(launch_dgemm(g, EPI_PLAIN, st));
   HIPCHK(hipMemcpyAsync(logits, ctx->logits.p, B * N * 4, hipMemcpyDeviceToHost, st));
   if (attn)
     HIPCHK(hipMemcpyAsync(attn, ctx->attn_dbg.p, B * (size_t)m->H * S * 4, hipMemcpyDeviceToHost, st));

@@ -82,7 +82,7 @@ struct slimt_hip_ctx {
   slimt_hip::DevBuf x0, x1, q, k, v, att, h8;
   slimt_hip::DevBuf kv;  // [Ld][2][B*S][D]
   // decoder workspace
-  slimt_hip::DevBuf dx, dh, dq, datt, dout, df8, state;
+  slimt_hip::DevBuf dx, dx_pre, dh, datt8, dout, df8, state;
   slimt_hip::DevBuf part_val, part_idx;
   slimt_hip::DevBuf prev, out_ids, out_len, finished, n_finished, align;
   slimt_hip::DevBuf shortlist;

@@ -134,6 +134,63 @@ struct AttnArgs {
 };
 hipError_t launch_attention(const AttnArgs &a, hipStream_t st);
 
+// ---- decode-step kernels (decode_kernels.hip) --------------------------------
+// 16 f32 rows [B][D]; ln_scale != nullptr => LayerNorm them on load (the
+// producer stored the pre-LN sum, Modules.cc:230,254-257,314-316).
+struct RowSrc {
+  const float *x = nullptr;
+  const float *ln_scale = nullptr;
+  const float *ln_bias = nullptr;
+};
+
+struct DGemmArgs {
+  int B = 0, D = 0;
+  RowSrc a;                       // A operand from f32 rows (K == D) ...
+  const int8_t *a_i8 = nullptr;   // ... or already quantised int8 [B][K]
+  PreparedWeight w;
+  RowSrc res;                     // residual rows added in the epilogue (N == D)
+  float *y = nullptr;
+  int ldy = 0;
+  int8_t *y_i8 = nullptr;
+  int ldy8 = 0;
+  float a_quant_out = 0.f;
+  float *part_val = nullptr;
+  int *part_idx = nullptr;
+  int n_parts = 0;
+  float eps = 1e-6f;
+};
+int dgemm_col_blocks(int K, int N, int B);
+hipError_t launch_dgemm(const DGemmArgs &a, int epilogue, hipStream_t st);
+
+struct DSsruArgs {
+  int B = 0, D = 0;
+  RowSrc x;
+  PreparedWeight wf, w;
+  float *state = nullptr;  // [B][D] in/out
+  float *h_pre = nullptr;  // [B][D]: x + relu(c'), pre-LN
+  float eps = 1e-6f;
+};
+hipError_t launch_dssru(const DSsruArgs &a, hipStream_t st);
+
+struct DQAttnArgs {
+  int B = 0, D = 0, H = 0, S = 0;
+  RowSrc x;            // decoder state rows (pre-LN of the SSRU block)
+  PreparedWeight wq;
+  const float *k = nullptr, *v = nullptr;  // cached cross-attention K/V [B*S][ld]
+  int ldk = 0, ldv = 0;
+  const uint32_t *lengths = nullptr;
+  float alpha = 0.f, eps = 1e-6f;
+  int8_t *out_i8 = nullptr;  // joined heads, quantised for the O projection
+  float a_quant_out = 0.f;
+  float *out_f32 = nullptr;  // optional f32 copy
+  float *attn = nullptr;     // nullable [B][H][S]
+  float *align = nullptr;
+  const uint32_t *out_len = nullptr;
+  const uint8_t *finished = nullptr;
+  int Tmax = 0;
+};
+hipError_t launch_dqattn(const DQAttnArgs &a, hipStream_t st);
+
 hipError_t launch_layer_norm(const float *x, const float *scale, const float *bias, float eps,
                              int rows, int cols, float *y, hipStream_t st);
 hipError_t launch_softmax(const float *x, int rows, int cols, float *y, hipStream_t st);

@@ -26,7 +26,7 @@ PRESETS = {
     "tiny11": (256, 1536, 8, 6, 2, 32000),
     "base": (512, 2048, 8, 6, 2, 32000),
     # small shapes for fast CPU tests (same structure)
-    "micro": (64, 128, 8, 2, 2, 512),
+    "micro": (64, 128, 4, 2, 2, 512),
     "mini": (128, 256, 8, 2, 2, 2048),
 }
 
