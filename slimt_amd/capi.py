@@ -22,12 +22,12 @@ SYMBOLS = [
     "slimt_hip_softmax", "slimt_hip_highway", "slimt_hip_sdpa",
     "slimt_hip_model_create", "slimt_hip_model_destroy", "slimt_hip_model_info",
     "slimt_hip_ctx_create", "slimt_hip_ctx_destroy", "slimt_hip_ctx_stream",
-    "slimt_hip_ctx_synchronize", "slimt_hip_translate", "slimt_hip_translate_device",
+    "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_translate", "slimt_hip_translate_device",
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
 ]
 
-K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU = range(7)
+K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED = range(8)
 KERNEL_NAMES = {K_GEMM_ENC: "gemm_enc", K_GEMM_DEC: "gemm_dec", K_LOGITS: "logits_argmax",
                 K_ATTN_ENC: "attn_enc", K_ATTN_DEC: "attn_dec", K_SSRU: "ssru"}
 
@@ -85,6 +85,7 @@ def lib():
     L.slimt_hip_ctx_destroy.argtypes = [vp]
     L.slimt_hip_ctx_stream.argtypes = [vp, vp]
     L.slimt_hip_ctx_synchronize.argtypes = [vp]
+    L.slimt_hip_ctx_set_decode_mode.argtypes = [vp, i32]
     L.slimt_hip_translate.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp]
     L.slimt_hip_translate_device.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp, i32]
     L.slimt_hip_encode.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp]
@@ -277,6 +278,10 @@ class Context:
 
     def synchronize(self):
         _chk(lib().slimt_hip_ctx_synchronize(self.h))
+
+    def set_decode_mode(self, mode: int):
+        """0 = auto (persistent fused decoder when supported), 1 = step-wise launches."""
+        _chk(lib().slimt_hip_ctx_set_decode_mode(self.h, mode))
 
     def translate(self, ids, lengths, shortlist=None, limit_factor: float = 1.5, eos_id: int = 0,
                   want_align: bool = False):

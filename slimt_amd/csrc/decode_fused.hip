@@ -1,0 +1,554 @@
+// Persistent fused greedy decoder: ONE launch runs the whole decode loop of
+// Model::decode (slimt/Model.cc:111-185) for a batch.
+//
+// The decoder (SSRU + cross-attention + FFN, slimt/Modules.cc:190-259) never
+// mixes sentences, so a workgroup can own 16 sentences (one MFMA row tile)
+// for ALL steps with no inter-workgroup communication at all:
+//   * activations, the SSRU cell states and the int8 A operands live in LDS
+//     for the whole loop; nothing but tokens / alignments is written to HBM;
+//   * the ~3 MB of decoder + shortlist weights are streamed from L2 each step
+//     in MFMA-fragment order (1 KiB coalesced per operand), 16 waves keeping
+//     2 x 8 fragments in flight each;
+//   * one wave per sentence does LayerNorm, embedding lookup, cross-attention
+//     (two heads per wave64 pass when S <= 32, d_head == 32) and the greedy
+//     bookkeeping (EOS / lengths / alignments);
+//   * no launch, no host round trip and no grid-wide barrier per step, and a
+//     batch only occupies ceil(B/16) CUs, so independent batches (slimt's
+//     Async workers, Frontend.cc:212-226) overlap on one GPU.
+// Arithmetic is bit-identical to the step-wise kernels (decode_kernels.hip).
+#include "device_common.h"
+#include "kernels.h"
+
+namespace slimt_hip {
+
+namespace {
+
+constexpr int NW = 16;   // waves per workgroup
+constexpr int CH = 4;    // weight fragments per prefetch chunk (per wave)
+
+struct Frags {
+  v4i f[CH];
+};
+
+// y = float(acc + 127 colsum) * u + pb   (Intgemm.inl.cc:146-153)
+__device__ __forceinline__ float dequant(int acc, int colsum, float u, float pb) {
+  const float v = (float)(acc + 127 * colsum) * u;
+  return v + pb;
+}
+
+// Stream this wave's tiles (tile = wave + 16 i) of a [K = 64 KS] x N weight,
+// A operand (16 x K int8) in LDS. epi(tile, acc) once per finished tile.
+template <int KS, class Epi>
+__device__ __forceinline__ void stream_gemm(const char *A, int lda, const PreparedWeight &w,
+                                            int wave, int lane, Epi &&epi) {
+  const v4i *Wp = reinterpret_cast<const v4i *>(w.Wp);
+  const int n_tiles = w.n_tiles;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int ntw = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;  // my tiles
+  if constexpr (KS <= CH) {
+    constexpr int TPC = CH / KS;  // whole tiles per chunk
+    v4i af[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      af[ks] = *reinterpret_cast<const v4i *>(A + lr * lda + ks * 64 + lg * 16);
+    const int nch = (ntw + TPC - 1) / TPC;
+    auto load = [&](Frags &b, int c) {
+#pragma unroll
+      for (int j = 0; j < TPC; ++j) {
+        const int i = c * TPC + j;
+        const int tile = wave + NW * i;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          v4i t = {0, 0, 0, 0};
+          if (i < ntw) t = Wp[((size_t)tile * KS + ks) * 64 + lane];
+          b.f[j * KS + ks] = t;
+        }
+      }
+    };
+    auto compute = [&](const Frags &b, int c) {
+#pragma unroll
+      for (int j = 0; j < TPC; ++j) {
+        const int i = c * TPC + j;
+        if (i < ntw) {
+          v4i acc = {0, 0, 0, 0};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ks], b.f[j * KS + ks], acc, 0, 0, 0);
+          epi(wave + NW * i, acc);
+        }
+      }
+    };
+    Frags bA, bB;
+    if (nch > 0) load(bA, 0);
+    if (nch > 1) load(bB, 1);
+    for (int c = 0; c < nch; c += 2) {
+      compute(bA, c);
+      if (c + 2 < nch) load(bA, c + 2);
+      if (c + 1 < nch) {
+        compute(bB, c + 1);
+        if (c + 3 < nch) load(bB, c + 3);
+      }
+    }
+  } else {
+    constexpr int CPT = KS / CH;  // chunks per tile
+    static_assert(KS % CH == 0, "K/64 must be a multiple of CH here");
+    const int nch = ntw * CPT;
+    auto load = [&](Frags &b, int c) {
+      const int tile = wave + NW * (c / CPT);
+      const int ks0 = (c % CPT) * CH;
+#pragma unroll
+      for (int p = 0; p < CH; ++p) b.f[p] = Wp[((size_t)tile * KS + ks0 + p) * 64 + lane];
+    };
+    v4i acc = {0, 0, 0, 0};
+    auto compute = [&](const Frags &b, int c) {
+      const int ks0 = (c % CPT) * CH;
+#pragma unroll
+      for (int p = 0; p < CH; ++p) {
+        const v4i af = *reinterpret_cast<const v4i *>(A + lr * lda + (ks0 + p) * 64 + lg * 16);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, b.f[p], acc, 0, 0, 0);
+      }
+      if ((c % CPT) == CPT - 1) {
+        epi(wave + NW * (c / CPT), acc);
+        acc = v4i{0, 0, 0, 0};
+      }
+    };
+    Frags bA, bB;
+    if (nch > 0) load(bA, 0);
+    if (nch > 1) load(bB, 1);
+    for (int c = 0; c < nch; c += 2) {
+      compute(bA, c);
+      if (c + 2 < nch) load(bA, c + 2);
+      if (c + 1 < nch) {
+        compute(bB, c + 1);
+        if (c + 3 < nch) load(bB, c + 3);
+      }
+    }
+  }
+}
+
+// canonical LayerNorm of row `src` (LDS) by one wave -> dst (LDS f32) and,
+// if A != nullptr, its int8 quantisation with aq.
+template <int DPL>
+__device__ __forceinline__ void ln_row(const float *src, const float *scale, const float *bias,
+                                       float eps, float *dst, char *A, float aq, int lane) {
+  constexpr int D = 64 * DPL;
+  float v[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) v[i] = src[lane + 64 * i];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) s += v[i];
+  s = wave_sum(s);
+  const float mean = s / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float d = v[i] - mean;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  const float sigma = __builtin_sqrtf(q / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float t = (v[i] - mean) / sigma;
+    const float m = scale[lane + 64 * i] * t;
+    const float y = m + bias[lane + 64 * i];
+    dst[lane + 64 * i] = y;
+    if (A) A[lane + 64 * i] = (char)quantize1(y, aq);
+  }
+}
+
+struct AttnRow {
+  const float *kl, *vl;  // this sentence's cached K / V [S][D]
+  const float *qrow;     // LDS: q [D]
+  char *arow;            // LDS: int8 output row [D] (A operand of the O projection)
+  int S, len;
+  float alpha, aq_o;
+  float *attn;   // nullable [H][S]
+  float *align;  // nullable [S]: head 0 (update_alignment, Model.cc:84-108)
+};
+
+// scaled_dot_product_attention (Modules.cc:24-86) for ONE sentence, all heads,
+// by one wave. Kept out of line: its registers must not add to the GEMM phases'.
+template <int D, int DH>
+__device__ __noinline__ void attention_row(AttnRow r, int lane) {
+  constexpr int H = D / DH;
+  const int S = r.S, len = r.len;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  if (DH == 32 && S <= 32) {
+    // two heads per pass: lane = (head parity, key)
+    const int hh = lane >> 5, j = lane & 31;
+    const int jc = j < S ? j : S - 1;
+    const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+    for (int hp = 0; hp < H / 2; ++hp) {
+      const int h = 2 * hp + hh;
+      const float *kr = r.kl + (size_t)jc * D + h * DH;
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 k4 = *reinterpret_cast<const float4 *>(kr + 4 * i);
+        const float4 q4 = *reinterpret_cast<const float4 *>(r.qrow + h * DH + 4 * i);
+        s = __builtin_fmaf(q4.x, k4.x, s);
+        s = __builtin_fmaf(q4.y, k4.y, s);
+        s = __builtin_fmaf(q4.z, k4.z, s);
+        s = __builtin_fmaf(q4.w, k4.w, s);
+      }
+      if (r.alpha != 1.0f) s = r.alpha * s;
+      s = s + mask;
+      if (j >= S) s = lowest;
+      float m = s;
+#pragma unroll
+      for (int x = 1; x < 32; x <<= 1) m = fmaxf(m, __shfl_xor(m, x, 64));
+      const float e = j < S ? exp_p(s - m) : 0.0f;
+      float sum = e;  // canonical order: masks 1..16; the mask-32 step would add +0
+#pragma unroll
+      for (int x = 1; x < 32; x <<= 1) sum = sum + __shfl_xor(sum, x, 64);
+      const float p = e / sum;
+      if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
+      if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
+      // V column of this lane: (head parity, d = lane & 31)
+      const float *vc = r.vl + (2 * hp) * DH + lane;
+      float o = 0.0f;
+      for (int jj = 0; jj < S; ++jj) {
+        const float pj = __shfl(p, (lane & 32) | jj, 64);
+        o = __builtin_fmaf(pj, vc[(size_t)jj * D], o);
+      }
+      r.arow[2 * hp * DH + lane] = (char)quantize1(o, r.aq_o);
+    }
+  } else {
+    // generic: one head per pass, keys lane and lane + 64
+    const int j0 = lane < S ? lane : S - 1;
+    const int j1 = (lane + 64) < S ? (lane + 64) : S - 1;
+    const int dc = lane < DH ? lane : DH - 1;
+    const float mask0 = (1.0f - (lane < len ? 1.0f : 0.0f)) * minus_inf;
+    const float mask1 = (1.0f - ((lane + 64) < len ? 1.0f : 0.0f)) * minus_inf;
+    for (int h = 0; h < H; ++h) {
+      float s0 = 0.0f, s1 = 0.0f;
+      for (int k = 0; k < DH; ++k) {
+        const float qk = r.qrow[h * DH + k];
+        s0 = __builtin_fmaf(qk, r.kl[(size_t)j0 * D + h * DH + k], s0);
+        s1 = __builtin_fmaf(qk, r.kl[(size_t)j1 * D + h * DH + k], s1);
+      }
+      if (r.alpha != 1.0f) {
+        s0 = r.alpha * s0;
+        s1 = r.alpha * s1;
+      }
+      s0 = s0 + mask0;
+      s1 = s1 + mask1;
+      if (lane >= S) s0 = lowest;
+      if (lane + 64 >= S) s1 = lowest;
+      const float m = wave_max(fmaxf(s0, s1));
+      const float e0 = lane < S ? exp_p(s0 - m) : 0.0f;
+      const float e1 = (lane + 64) < S ? exp_p(s1 - m) : 0.0f;
+      const float sum = wave_sum(e0 + e1);
+      const float p0 = e0 / sum, p1 = e1 / sum;
+      if (r.attn) {
+        float *ap = r.attn + (size_t)h * S;
+        if (lane < S) ap[lane] = p0;
+        if (lane + 64 < S) ap[lane + 64] = p1;
+      }
+      if (r.align && h == 0) {
+        if (lane < len) r.align[lane] = p0;
+        if (lane + 64 < len) r.align[lane + 64] = p1;
+      }
+      float o = 0.0f;
+      for (int jj = 0; jj < S; ++jj) {
+        const float pj = __shfl(jj < 64 ? p0 : p1, jj & 63, 64);
+        o = __builtin_fmaf(pj, r.vl[(size_t)jj * D + h * DH + dc], o);
+      }
+      if (lane < DH) r.arow[h * DH + lane] = (char)quantize1(o, r.aq_o);
+    }
+  }
+}
+
+}  // namespace
+
+template <int KSD, int KSF, int DH>
+__global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = 64 * KSD, F = 64 * KSF;
+  constexpr int LDF = D + 4;    // f32 row stride
+  constexpr int LDA = D + 16;   // int8 row stride (K = D)
+  constexpr int LDA3 = F + 16;  // int8 row stride (K = F)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
+
+  float *xs = reinterpret_cast<float *>(smem);  // layer input rows (post-LN); reused for q
+  float *hs = xs + 16 * LDF;                    // h / o rows (post-LN residual source)
+  float *pre = hs + 16 * LDF;                   // pre-LN accumulation
+  float *cs = pre + 16 * LDF;                   // SSRU cells [Ld][16][D]
+  char *A1 = reinterpret_cast<char *>(cs + (size_t)Ld * 16 * D);
+  char *A2 = A1 + 16 * LDA;
+  char *A3 = A2 + 16 * LDA;
+  float *red_v = reinterpret_cast<float *>(A3 + 16 * LDA3);  // [NW][16]
+  int *red_i = reinterpret_cast<int *>(red_v + NW * 16);
+  int *flags = red_i + NW * 16;  // [0] = number of finished sentences of this tile
+
+  // per-sentence state, owned by wave `wave` (uniform within the wave)
+  const int b = m0 + wave;
+  const bool live = b < B;
+  const int len = live ? (int)a.lengths[b] : 0;
+  uint32_t n_out = 0;
+  bool finished = !live;
+  const int valid_rows = (B - m0) < 16 ? (B - m0) : 16;
+
+  for (int i = tid; i < Ld * 16 * D; i += 1024) cs[i] = 0.0f;  // start_states, Transformer.cc:78-85
+  if (tid == 0) flags[0] = 0;
+  // step-0 embedding: zeros * sqrt(D) + pos(0)  (Transformer.cc:138-144,160)
+#pragma unroll
+  for (int i = 0; i < KSD; ++i) {
+    const float z = 0.0f * a.emb.sqrt_d;
+    xs[wave * LDF + lane + 64 * i] = live ? z + a.emb.pos[lane + 64 * i] : 0.0f;
+  }
+  __syncthreads();
+
+  const int max_steps = a.max_steps;
+  for (int t = 0; t < max_steps; ++t) {
+    for (int l = 0; l < Ld; ++l) {
+      const FusedLayerW &L = a.L[l];
+      float *cl = cs + (size_t)l * 16 * D;
+      // ---- SSRU (Modules.cc:190-235) ------------------------------------
+      // quantise x twice (Wf / W have their own multipliers)
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) {
+        const float v = xs[wave * LDF + lane + 64 * i];
+        A1[wave * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_f.a_quant);
+        A2[wave * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
+      }
+      __syncthreads();
+      for (int tile = wave; tile < D / 16; tile += NW) {
+        const v4i *Wf = reinterpret_cast<const v4i *>(L.rnn_f.Wp);
+        const v4i *Ww = reinterpret_cast<const v4i *>(L.rnn_w.Wp);
+        v4i bf[KSD], bw[KSD];
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+          bf[ks] = Wf[((size_t)tile * KSD + ks) * 64 + lane];
+          bw[ks] = Ww[((size_t)tile * KSD + ks) * 64 + lane];
+        }
+        v4i accf = {0, 0, 0, 0}, accw = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+          const v4i af = *reinterpret_cast<const v4i *>(A1 + lr * LDA + ks * 64 + lg * 16);
+          const v4i aw = *reinterpret_cast<const v4i *>(A2 + lr * LDA + ks * 64 + lg * 16);
+          accf = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[ks], accf, 0, 0, 0);
+          accw = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw, bw[ks], accw, 0, 0, 0);
+        }
+        const int col = tile * 16 + lr;
+        const int csf = L.rnn_f.colsum[col], csw = L.rnn_w.colsum[col];
+        const float pbf = L.rnn_f.pb[col], pbw = L.rnn_w.pb[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = lg * 4 + r;
+          const float f = dequant(accf[r], csf, L.rnn_f.u, pbf);
+          const float wx = dequant(accw[r], csw, L.rnn_w.u, pbw);
+          const float c = cl[rl * D + col];
+          const float sg = sigmoid_p(f);  // highway(c, Wx, f), TensorOps.cc:674-678
+          const float t1 = sg * c;
+          const float t2 = (1.0f - sg) * wx;
+          const float cn = t1 + t2;
+          cl[rl * D + col] = cn;
+          const float y = cn > 0.0f ? cn : 0.0f;
+          pre[rl * LDF + col] = xs[rl * LDF + col] + y;  // Modules.cc:230
+        }
+      }
+      __syncthreads();
+      // h = LN(x + relu(c')), quantised for the Q projection
+      ln_row<KSD>(pre + wave * LDF, L.rnn_ln_s, L.rnn_ln_b, a.eps, hs + wave * LDF, A1 + wave * LDA,
+                  L.q.a_quant, lane);
+      __syncthreads();
+      // ---- cross-attention (Modules.cc:287-319) --------------------------
+      // Q projection -> xs (x is dead until the end of the layer)
+      stream_gemm<KSD>(A1, LDA, L.q, wave, lane, [&](int tile, const v4i &acc) {
+        const int col = tile * 16 + lr;
+        const int cq = L.q.colsum[col];
+        const float pb = L.q.pb[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xs[(lg * 4 + r) * LDF + col] = dequant(acc[r], cq, L.q.u, pb);
+      });
+      __syncthreads();
+      // SDPA over the cached K/V of sentence b; output quantised into A1
+      if (live) {
+        AttnRow ar;
+        ar.kl = a.kv + ((size_t)(2 * l) * B + b) * S * D;
+        ar.vl = a.kv + ((size_t)(2 * l + 1) * B + b) * S * D;
+        ar.qrow = xs + wave * LDF;
+        ar.arow = A1 + wave * LDA;
+        ar.S = S;
+        ar.len = len;
+        ar.alpha = a.alpha;
+        ar.aq_o = L.o.a_quant;
+        ar.attn = (a.attn && (l + 1 == Ld)) ? a.attn + (size_t)b * H * S : nullptr;
+        const bool want_align = a.align && (l + 1 == Ld) && !finished && ((int)n_out < a.Tmax);
+        ar.align = want_align ? a.align + ((size_t)b * a.Tmax + n_out) * S : nullptr;
+        attention_row<D, DH>(ar, lane);
+      } else {
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) A1[wave * LDA + lane + 64 * i] = 0;
+      }
+      __syncthreads();
+      // O projection + residual h (Modules.cc:308-314)
+      stream_gemm<KSD>(A1, LDA, L.o, wave, lane, [&](int tile, const v4i &acc) {
+        const int col = tile * 16 + lr;
+        const int co = L.o.colsum[col];
+        const float pb = L.o.pb[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = lg * 4 + r;
+          const float v = dequant(acc[r], co, L.o.u, pb);
+          pre[rl * LDF + col] = v + hs[rl * LDF + col];
+        }
+      });
+      __syncthreads();
+      ln_row<KSD>(pre + wave * LDF, L.attn_ln_s, L.attn_ln_b, a.eps, hs + wave * LDF,
+                  A1 + wave * LDA, L.ffn1.a_quant, lane);
+      __syncthreads();
+      // ---- FFN (Modules.cc:251-257) ----------------------------------------
+      stream_gemm<KSD>(A1, LDA, L.ffn1, wave, lane, [&](int tile, const v4i &acc) {
+        const int col = tile * 16 + lr;
+        const int c1 = L.ffn1.colsum[col];
+        const float pb = L.ffn1.pb[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = dequant(acc[r], c1, L.ffn1.u, pb);
+          v = v > 0.0f ? v : 0.0f;
+          A3[(lg * 4 + r) * LDA3 + col] = (char)quantize1(v, L.ffn2.a_quant);
+        }
+      });
+      __syncthreads();
+      stream_gemm<KSF>(A3, LDA3, L.ffn2, wave, lane, [&](int tile, const v4i &acc) {
+        const int col = tile * 16 + lr;
+        const int c2 = L.ffn2.colsum[col];
+        const float pb = L.ffn2.pb[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = lg * 4 + r;
+          const float v = dequant(acc[r], c2, L.ffn2.u, pb);
+          pre[rl * LDF + col] = v + hs[rl * LDF + col];
+        }
+      });
+      __syncthreads();
+      // next layer's input; after the last layer: quantised for the logits
+      ln_row<KSD>(pre + wave * LDF, L.ffn_ln_s, L.ffn_ln_b, a.eps, xs + wave * LDF,
+                  (l + 1 == Ld) ? A1 + wave * LDA : nullptr, a.out.a_quant, lane);
+      __syncthreads();
+    }
+    // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
+    float bv[4];
+    int bi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bv[r] = -3.402823466e+38f;
+      bi[r] = 0x7fffffff;
+    }
+    stream_gemm<KSD>(A1, LDA, a.out, wave, lane, [&](int tile, const v4i &acc) {
+      const int col = tile * 16 + lr;
+      if (col < a.out.N) {
+        const int co = a.out.colsum[col];
+        const float pb = a.out.pb[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = dequant(acc[r], co, a.out.u, pb);
+          if (v > bv[r] || (v == bv[r] && col < bi[r])) {  // first max wins
+            bv[r] = v;
+            bi[r] = col;
+          }
+        }
+      }
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) {
+        const float ov = __shfl_xor(bv[r], x, 64);
+        const int oi = __shfl_xor(bi[r], x, 64);
+        if (ov > bv[r] || (ov == bv[r] && oi < bi[r])) {
+          bv[r] = ov;
+          bi[r] = oi;
+        }
+      }
+      if (lr == 0) {
+        red_v[wave * 16 + lg * 4 + r] = bv[r];
+        red_i[wave * 16 + lg * 4 + r] = bi[r];
+      }
+    }
+    __syncthreads();
+    // wave w finishes sentence w: reduce over the 16 waves' candidates
+    uint32_t tok = 0;
+    {
+      float v = lane < NW ? red_v[lane * 16 + wave] : -3.402823466e+38f;
+      int ix = lane < NW ? red_i[lane * 16 + wave] : 0x7fffffff;
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) {
+        const float ov = __shfl_xor(v, x, 64);
+        const int oi = __shfl_xor(ix, x, 64);
+        if (ov > v || (ov == v && oi < ix)) {
+          v = ov;
+          ix = oi;
+        }
+      }
+      ix = __shfl(ix, 0, 64);
+      if (live) tok = a.shortlist ? a.shortlist[ix] : (uint32_t)ix;
+    }
+    if (live && !finished) {  // record(), Model.cc:127-137
+      if (lane == 0 && (int)n_out < a.Tmax) a.out_ids[(size_t)b * a.Tmax + n_out] = tok;
+      n_out += 1;
+      if (tok == a.eos) {
+        finished = true;
+        if (lane == 0) atomicAdd(&flags[0], 1);
+      }
+    }
+    __syncthreads();
+    if (flags[0] >= valid_rows) break;  // every sentence of this tile has emitted EOS
+    if (t + 1 < max_steps) {
+      // next target embedding (Transformer.cc:146-160): position is always 0
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) {
+        float v = 0.0f;
+        if (live) {
+          const float e = (float)a.emb.wemb[(size_t)tok * D + lane + 64 * i] * a.emb.inv_mult;
+          const float sc = e * a.emb.sqrt_d;
+          v = sc + a.emb.pos[lane + 64 * i];
+        }
+        xs[wave * LDF + lane + 64 * i] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (live && lane == 0) a.out_len[b] = n_out;
+}
+
+size_t fused_decode_lds_bytes(int D, int F, int Ld) {
+  return (size_t)3 * 16 * (D + 4) * 4 + (size_t)Ld * 16 * D * 4 + 2 * 16 * (size_t)(D + 16) +
+         16 * (size_t)(F + 16) + 2 * NW * 16 * 4 + 64;
+}
+
+bool fused_decode_supported(int D, int F, int H, int Ld) {
+  if (Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
+  const int dh = D / H;
+  const bool shape = (D == 64 && F == 128 && dh == 16) || (D == 128 && F == 256 && dh == 16) ||
+                     (D == 256 && F == 1536 && dh == 32);
+  return shape && fused_decode_lds_bytes(D, F, Ld) <= 160 * 1024;
+}
+
+hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st) {
+  if (!fused_decode_supported(D, F, H, a.Ld)) return hipErrorInvalidValue;
+  const dim3 grid((a.B + 15) / 16);
+  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld);
+#define SLIMT_FUSED_CASE(KSD_, KSF_, DH_)                                                   \
+  if (D == 64 * KSD_ && F == 64 * KSF_ && D / H == DH_) {                                    \
+    auto k = decode_fused_kernel<KSD_, KSF_, DH_>;                                           \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                           \
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);                                     \
+    return hipGetLastError();                                                                \
+  }
+  SLIMT_FUSED_CASE(1, 2, 16) SLIMT_FUSED_CASE(2, 4, 16) SLIMT_FUSED_CASE(4, 24, 32)
+#undef SLIMT_FUSED_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace slimt_hip

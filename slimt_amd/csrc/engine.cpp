@@ -667,6 +667,13 @@ extern "C" int slimt_hip_ctx_stream(slimt_hip_ctx *ctx, void **stream) {
   return 0;
 }
 
+extern "C" int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode) {
+  if (!ctx) return fail(-1, "ctx is NULL");
+  if (mode != 0 && mode != 1) return fail(-1, "bad decode mode %d", mode);
+  ctx->decode_mode = mode;
+  return 0;
+}
+
 extern "C" int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx) {
   if (!ctx) return fail(-1, "ctx is NULL");
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -963,6 +970,39 @@ int translate_device(slimt_hip_ctx *c, size_t B, size_t S, size_t n_sl, float li
   HIPCHK(hipMemsetAsync(c->n_finished.p, 0, 16, st));
   if (d_align) HIPCHK(hipMemsetAsync(d_align, 0, B * Tmax * S * 4, st));
   const AffineW &out = output_layer(c);
+  if (c->decode_mode == 0 && fused_decode_supported(m->D, m->F, m->H, m->Ld)) {
+    // the whole greedy loop in one persistent launch (decode_fused.hip)
+    FusedDecodeArgs f;
+    f.B = (int)B; f.S = (int)S; f.Ld = m->Ld;
+    f.max_steps = steps_hint > 0 ? steps_hint : (int)(Tmax > 1 ? Tmax : 1);
+    f.Tmax = (int)Tmax;
+    for (int l = 0; l < m->Ld; ++l) {
+      const DecLayerW &L = m->dec[(size_t)l];
+      FusedLayerW &fl = f.L[l];
+      fl.rnn_f = L.rnn_f.w; fl.rnn_w = L.rnn_w.w; fl.q = L.attn.q.w; fl.o = L.attn.o.w;
+      fl.ffn1 = L.ffn1.w; fl.ffn2 = L.ffn2.w;
+      fl.rnn_ln_s = L.rnn_ln.scale.as<float>(); fl.rnn_ln_b = L.rnn_ln.bias.as<float>();
+      fl.attn_ln_s = L.attn.ln.scale.as<float>(); fl.attn_ln_b = L.attn.ln.bias.as<float>();
+      fl.ffn_ln_s = L.ffn_ln.scale.as<float>(); fl.ffn_ln_b = L.ffn_ln.bias.as<float>();
+    }
+    f.out = out.w;
+    f.shortlist = ds.shortlist;
+    f.emb = embed_args(c);
+    f.kv = c->kv.as<float>();
+    f.lengths = c->lengths.as<uint32_t>();
+    f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
+    f.eos = eos_id;
+    f.out_ids = d_out_ids;
+    f.out_len = d_out_len;
+    f.align = d_align;
+    const double macs = (double)B * f.max_steps *
+                        (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.N);
+    const double wbytes = (double)f.max_steps * ((B + 15) / 16) *
+                          (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.n_tiles * 16);
+    ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);
+    HIPCHK(launch_decode_fused(f, m->D, m->F, m->H, st));
+    return 0;
+  }
   const int n_parts = dgemm_col_blocks(out.w.K, out.w.N, (int)B);
   const EmbedArgs e = embed_args(c);
   const size_t max_steps = steps_hint > 0 ? (size_t)steps_hint : (Tmax > 1 ? Tmax : 1);

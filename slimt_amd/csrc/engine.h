@@ -76,6 +76,7 @@ struct slimt_hip_ctx {
   int n_sl = 0;  // 0 => full vocabulary
   bool have_encoder_out = false;
   bool decode_ready = false;
+  int decode_mode = 0;  // 0 auto (fused when supported), 1 step-wise launches
   // encoder workspace
   slimt_hip::DevBuf pos;  // [max_S][D]
   slimt_hip::DevBuf ids, lengths;

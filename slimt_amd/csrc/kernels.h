@@ -191,6 +191,34 @@ struct DQAttnArgs {
 };
 hipError_t launch_dqattn(const DQAttnArgs &a, hipStream_t st);
 
+// ---- persistent fused decoder (decode_fused.hip) ------------------------------
+struct FusedLayerW {
+  PreparedWeight rnn_f, rnn_w, q, o, ffn1, ffn2;
+  const float *rnn_ln_s = nullptr, *rnn_ln_b = nullptr;
+  const float *attn_ln_s = nullptr, *attn_ln_b = nullptr;
+  const float *ffn_ln_s = nullptr, *ffn_ln_b = nullptr;
+};
+
+struct FusedDecodeArgs {
+  int B = 0, S = 0, Ld = 0;
+  int max_steps = 0;  // decode steps to run at most (Model.cc:160-161)
+  int Tmax = 0;       // row length of out_ids / align
+  FusedLayerW L[4];
+  PreparedWeight out;                   // (shortlisted) output layer
+  const uint32_t *shortlist = nullptr;  // nullable: column -> vocabulary id
+  EmbedArgs emb;
+  const float *kv = nullptr;            // [Ld][2][B*S][D]
+  const uint32_t *lengths = nullptr;
+  float alpha = 0.f, eps = 1e-6f;
+  uint32_t eos = 0;
+  uint32_t *out_ids = nullptr;  // [B][Tmax]
+  uint32_t *out_len = nullptr;  // [B]
+  float *align = nullptr;       // nullable [B][Tmax][S]
+  float *attn = nullptr;        // nullable debug [B][H][S]
+};
+bool fused_decode_supported(int D, int F, int H, int Ld);
+hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
+
 hipError_t launch_layer_norm(const float *x, const float *scale, const float *bias, float eps,
                              int rows, int cols, float *y, hipStream_t st);
 hipError_t launch_softmax(const float *x, int rows, int cols, float *y, hipStream_t st);

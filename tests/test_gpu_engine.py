@@ -95,16 +95,20 @@ def test_translate_tokens_lengths_alignments(hip, oracle, engines, preset, eos_b
     ids, lens = synth.make_batch(m.V, B, S, seed=B * 100 + S + 2, ragged=ragged)
     sl = None if n_sl is None else synth.make_shortlist(m.V, n_sl)
     ctx = hip.Context(gm, B, S)
-    out, ln, al = ctx.translate(ids, lens, sl, limit_factor=1.5, eos_id=0, want_align=True)
     oracle.set_mode(oracle.PORTABLE)
     w_out, w_ln, w_al, steps = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
     oracle.set_mode(oracle.FAITHFUL)
-    assert np.array_equal(ln, w_ln), (ln, w_ln)
-    assert np.array_equal(out, w_out)
-    assert np.array_equal(al, w_al)
-    # a second call on the same context must not see stale state
-    out2, ln2, _ = ctx.translate(ids, lens, sl, limit_factor=1.5, eos_id=0)
-    assert np.array_equal(out2, out) and np.array_equal(ln2, ln)
+    # mode 0: persistent fused decoder (when the shape supports it);
+    # mode 1: one launch per stage and step. Same tokens either way.
+    for mode in (0, 1):
+        ctx.set_decode_mode(mode)
+        out, ln, al = ctx.translate(ids, lens, sl, limit_factor=1.5, eos_id=0, want_align=True)
+        assert np.array_equal(ln, w_ln), (mode, ln, w_ln)
+        assert np.array_equal(out, w_out), mode
+        assert np.array_equal(al, w_al), mode
+        # a second call on the same context must not see stale state
+        out2, ln2, _ = ctx.translate(ids, lens, sl, limit_factor=1.5, eos_id=0)
+        assert np.array_equal(out2, out) and np.array_equal(ln2, ln)
     ctx.close()
 
 
