@@ -195,6 +195,12 @@ int slimt_hip_profile_read(slimt_hip_ctx *ctx, uint64_t *launches,
                            double *total_ms, double *int8_macs,
                            double *weight_bytes);
 int slimt_hip_profile_reset(slimt_hip_ctx *ctx);
+/* Diagnostic: returns (into out[0..n), n <= 64) the 100 MHz wall-clock stamps
+ * the persistent decoder's workgroup 0 wrote at its phase boundaries during
+ * the previously selected step, then selects `step` for the next translate
+ * call (step < 0 disables stamping). */
+int slimt_hip_debug_decode_stamps(slimt_hip_ctx *ctx, int step, uint64_t *out,
+                                  size_t n);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ SYMBOLS = [
     "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_translate", "slimt_hip_translate_device",
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
+    "slimt_hip_debug_decode_stamps",
 ]
 
 K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED = range(8)
@@ -94,6 +95,7 @@ def lib():
     L.slimt_hip_profile_enable.argtypes = [vp, i32]
     L.slimt_hip_profile_read.argtypes = [vp, vp, vp, vp, vp]
     L.slimt_hip_profile_reset.argtypes = [vp]
+    L.slimt_hip_debug_decode_stamps.argtypes = [vp, i32, vp, sz]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("slimt_hip_abi_version",):
@@ -336,6 +338,12 @@ class Context:
         states = np.empty((m.Ld, B, m.D), dtype=np.float32) if want_states else None
         _chk(lib().slimt_hip_decode_step(self.h, _p(pv), _p(logits), _p(attn), _p(states)))
         return logits, attn, states
+
+    def debug_decode_stamps(self, step: int):
+        """Read the previous run's phase stamps (ticks of 10 ns) and arm `step`."""
+        out = np.zeros(64, dtype=np.uint64)
+        _chk(lib().slimt_hip_debug_decode_stamps(self.h, step, _p(out), 64))
+        return out
 
     def profile_enable(self, kernel_id: int):
         _chk(lib().slimt_hip_profile_enable(self.h, kernel_id))

@@ -38,13 +38,15 @@ __device__ __forceinline__ float dequant(int acc, int colsum, float u, float pb)
 
 // Stream this wave's tiles (tile = wave + 16 i) of a [K = 64 KS] x N weight,
 // A operand (16 x K int8) in LDS. epi(tile, acc) once per finished tile.
-template <int KS, class Epi>
+// NB chunks of CH fragments (1 KiB each) are kept in flight per wave.
+template <int KS, int NB, class Epi>
 __device__ __forceinline__ void stream_gemm(const char *A, int lda, const PreparedWeight &w,
                                             int wave, int lane, Epi &&epi) {
   const v4i *Wp = reinterpret_cast<const v4i *>(w.Wp);
   const int n_tiles = w.n_tiles;
   const int lr = lane & 15, lg = lane >> 4;
   const int ntw = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;  // my tiles
+  Frags b[NB];
   if constexpr (KS <= CH) {
     constexpr int TPC = CH / KS;  // whole tiles per chunk
     v4i af[KS];
@@ -52,7 +54,7 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
     for (int ks = 0; ks < KS; ++ks)
       af[ks] = *reinterpret_cast<const v4i *>(A + lr * lda + ks * 64 + lg * 16);
     const int nch = (ntw + TPC - 1) / TPC;
-    auto load = [&](Frags &b, int c) {
+    auto load = [&](Frags &bb, int c) {
 #pragma unroll
       for (int j = 0; j < TPC; ++j) {
         const int i = c * TPC + j;
@@ -61,11 +63,11 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
         for (int ks = 0; ks < KS; ++ks) {
           v4i t = {0, 0, 0, 0};
           if (i < ntw) t = Wp[((size_t)tile * KS + ks) * 64 + lane];
-          b.f[j * KS + ks] = t;
+          bb.f[j * KS + ks] = t;
         }
       }
     };
-    auto compute = [&](const Frags &b, int c) {
+    auto compute = [&](const Frags &bb, int c) {
 #pragma unroll
       for (int j = 0; j < TPC; ++j) {
         const int i = c * TPC + j;
@@ -73,54 +75,56 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
           v4i acc = {0, 0, 0, 0};
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ks], b.f[j * KS + ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ks], bb.f[j * KS + ks], acc, 0, 0, 0);
           epi(wave + NW * i, acc);
         }
       }
     };
-    Frags bA, bB;
-    if (nch > 0) load(bA, 0);
-    if (nch > 1) load(bB, 1);
-    for (int c = 0; c < nch; c += 2) {
-      compute(bA, c);
-      if (c + 2 < nch) load(bA, c + 2);
-      if (c + 1 < nch) {
-        compute(bB, c + 1);
-        if (c + 3 < nch) load(bB, c + 3);
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (k < nch) load(b[k], k);
+    for (int c = 0; c < nch; c += NB) {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        if (c + k < nch) {
+          compute(b[k], c + k);
+          if (c + k + NB < nch) load(b[k], c + k + NB);
+        }
       }
     }
   } else {
     constexpr int CPT = KS / CH;  // chunks per tile
     static_assert(KS % CH == 0, "K/64 must be a multiple of CH here");
     const int nch = ntw * CPT;
-    auto load = [&](Frags &b, int c) {
+    auto load = [&](Frags &bb, int c) {
       const int tile = wave + NW * (c / CPT);
       const int ks0 = (c % CPT) * CH;
 #pragma unroll
-      for (int p = 0; p < CH; ++p) b.f[p] = Wp[((size_t)tile * KS + ks0 + p) * 64 + lane];
+      for (int p = 0; p < CH; ++p) bb.f[p] = Wp[((size_t)tile * KS + ks0 + p) * 64 + lane];
     };
     v4i acc = {0, 0, 0, 0};
-    auto compute = [&](const Frags &b, int c) {
+    auto compute = [&](const Frags &bb, int c) {
       const int ks0 = (c % CPT) * CH;
 #pragma unroll
       for (int p = 0; p < CH; ++p) {
         const v4i af = *reinterpret_cast<const v4i *>(A + lr * lda + (ks0 + p) * 64 + lg * 16);
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, b.f[p], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bb.f[p], acc, 0, 0, 0);
       }
       if ((c % CPT) == CPT - 1) {
         epi(wave + NW * (c / CPT), acc);
         acc = v4i{0, 0, 0, 0};
       }
     };
-    Frags bA, bB;
-    if (nch > 0) load(bA, 0);
-    if (nch > 1) load(bB, 1);
-    for (int c = 0; c < nch; c += 2) {
-      compute(bA, c);
-      if (c + 2 < nch) load(bA, c + 2);
-      if (c + 1 < nch) {
-        compute(bB, c + 1);
-        if (c + 3 < nch) load(bB, c + 3);
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (k < nch) load(b[k], k);
+    for (int c = 0; c < nch; c += NB) {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        if (c + k < nch) {
+          compute(b[k], c + k);
+          if (c + k + NB < nch) load(b[k], c + k + NB);
+        }
       }
     }
   }
@@ -158,14 +162,27 @@ __device__ __forceinline__ void ln_row(const float *src, const float *scale, con
   }
 }
 
+// Address spaces are spelled out: across a non-inlined call the compiler
+// would otherwise fall back to FLAT loads, which it serialises one by one.
+#define SLIMT_GLOBAL __attribute__((address_space(1)))
+#define SLIMT_LDS __attribute__((address_space(3)))
+typedef const SLIMT_GLOBAL float *gcf_ptr;
+typedef SLIMT_GLOBAL float *gf_ptr;
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const SLIMT_GLOBAL f4 *gcf4_ptr;
+typedef const SLIMT_LDS float *lcf_ptr;
+typedef const SLIMT_LDS f4 *lcf4_ptr;
+typedef SLIMT_LDS char *lc_ptr;
+
 struct AttnRow {
-  const float *kl, *vl;  // this sentence's cached K / V [S][D]
-  const float *qrow;     // LDS: q [D]
-  char *arow;            // LDS: int8 output row [D] (A operand of the O projection)
+  gcf_ptr kl, vl;  // this sentence's cached K / V [S][D]
+  lcf_ptr qrow;    // LDS: q [D]
+  lc_ptr arow;     // LDS: int8 output row [D] (A operand of the O projection)
+  SLIMT_LDS float *pbuf;  // LDS: 64 floats of per-wave scratch
   int S, len;
   float alpha, aq_o;
-  float *attn;   // nullable [H][S]
-  float *align;  // nullable [S]: head 0 (update_alignment, Model.cc:84-108)
+  gf_ptr attn;   // nullable [H][S]
+  gf_ptr align;  // nullable [S]: head 0 (update_alignment, Model.cc:84-108)
 };
 
 // scaled_dot_product_attention (Modules.cc:24-86) for ONE sentence, all heads,
@@ -183,17 +200,27 @@ __device__ __noinline__ void attention_row(AttnRow r, int lane) {
     const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
     for (int hp = 0; hp < H / 2; ++hp) {
       const int h = 2 * hp + hh;
-      const float *kr = r.kl + (size_t)jc * D + h * DH;
+      gcf_ptr kr = r.kl + ((size_t)h * (DH / 4) * S + jc) * 4;  // [head][dh/4][S][4]
+      // V column of this lane: (head parity, d = lane & 31). The loads of a
+      // pass are issued up front: one memory round trip per pass, not per key.
+      gcf_ptr vc = r.vl + (2 * hp) * DH + lane;
+      f4 k4[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) k4[i] = *(gcf4_ptr)(kr + (size_t)i * S * 4);
+      float va[16], vb[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) va[jj] = vc[(size_t)(jj < S ? jj : S - 1) * D];
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float4 k4 = *reinterpret_cast<const float4 *>(kr + 4 * i);
-        const float4 q4 = *reinterpret_cast<const float4 *>(r.qrow + h * DH + 4 * i);
-        s = __builtin_fmaf(q4.x, k4.x, s);
-        s = __builtin_fmaf(q4.y, k4.y, s);
-        s = __builtin_fmaf(q4.z, k4.z, s);
-        s = __builtin_fmaf(q4.w, k4.w, s);
+        const f4 q4 = *(lcf4_ptr)(r.qrow + h * DH + 4 * i);
+        s = __builtin_fmaf(q4.x, k4[i].x, s);
+        s = __builtin_fmaf(q4.y, k4[i].y, s);
+        s = __builtin_fmaf(q4.z, k4[i].z, s);
+        s = __builtin_fmaf(q4.w, k4[i].w, s);
       }
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) vb[jj] = vc[(size_t)((16 + jj) < S ? (16 + jj) : S - 1) * D];
       if (r.alpha != 1.0f) s = r.alpha * s;
       s = s + mask;
       if (j >= S) s = lowest;
@@ -204,15 +231,27 @@ __device__ __noinline__ void attention_row(AttnRow r, int lane) {
       float sum = e;  // canonical order: masks 1..16; the mask-32 step would add +0
 #pragma unroll
       for (int x = 1; x < 32; x <<= 1) sum = sum + __shfl_xor(sum, x, 64);
-      const float p = e / sum;
+      const float p = e / sum;  // keys >= S: exactly 0
       if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
       if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
-      // V column of this lane: (head parity, d = lane & 31)
-      const float *vc = r.vl + (2 * hp) * DH + lane;
+      // broadcast the probabilities of this lane's head through LDS
+      r.pbuf[lane] = p;
       float o = 0.0f;
-      for (int jj = 0; jj < S; ++jj) {
-        const float pj = __shfl(p, (lane & 32) | jj, 64);
-        o = __builtin_fmaf(pj, vc[(size_t)jj * D], o);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f4 p4 = *(lcf4_ptr)(r.pbuf + (lane & 32) + 4 * i);
+        o = __builtin_fmaf(p4.x, va[4 * i + 0], o);
+        o = __builtin_fmaf(p4.y, va[4 * i + 1], o);
+        o = __builtin_fmaf(p4.z, va[4 * i + 2], o);
+        o = __builtin_fmaf(p4.w, va[4 * i + 3], o);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // keys >= S contribute fma(0, v, o) == o
+        const f4 p4 = *(lcf4_ptr)(r.pbuf + (lane & 32) + 16 + 4 * i);
+        o = __builtin_fmaf(p4.x, vb[4 * i + 0], o);
+        o = __builtin_fmaf(p4.y, vb[4 * i + 1], o);
+        o = __builtin_fmaf(p4.z, vb[4 * i + 2], o);
+        o = __builtin_fmaf(p4.w, vb[4 * i + 3], o);
       }
       r.arow[2 * hp * DH + lane] = (char)quantize1(o, r.aq_o);
     }
@@ -227,8 +266,9 @@ __device__ __noinline__ void attention_row(AttnRow r, int lane) {
       float s0 = 0.0f, s1 = 0.0f;
       for (int k = 0; k < DH; ++k) {
         const float qk = r.qrow[h * DH + k];
-        s0 = __builtin_fmaf(qk, r.kl[(size_t)j0 * D + h * DH + k], s0);
-        s1 = __builtin_fmaf(qk, r.kl[(size_t)j1 * D + h * DH + k], s1);
+        gcf_ptr kc = r.kl + ((size_t)(h * (DH / 4) + (k >> 2)) * S) * 4 + (k & 3);
+        s0 = __builtin_fmaf(qk, kc[(size_t)j0 * 4], s0);
+        s1 = __builtin_fmaf(qk, kc[(size_t)j1 * 4], s1);
       }
       if (r.alpha != 1.0f) {
         s0 = r.alpha * s0;
@@ -244,7 +284,7 @@ __device__ __noinline__ void attention_row(AttnRow r, int lane) {
       const float sum = wave_sum(e0 + e1);
       const float p0 = e0 / sum, p1 = e1 / sum;
       if (r.attn) {
-        float *ap = r.attn + (size_t)h * S;
+        gf_ptr ap = r.attn + (size_t)h * S;
         if (lane < S) ap[lane] = p0;
         if (lane + 64 < S) ap[lane + 64] = p1;
       }
@@ -263,6 +303,14 @@ __device__ __noinline__ void attention_row(AttnRow r, int lane) {
 }
 
 }  // namespace
+
+// Diagnostic phase stamps (100 MHz wall clock) of workgroup 0 at one chosen
+// step; a.stamps == nullptr in normal runs (one uniform branch per phase).
+#define SLIMT_STAMP(id)                                                                  \
+  do {                                                                                   \
+    if (a.stamps && blockIdx.x == 0 && tid == 0 && t == a.stamp_step)                    \
+      a.stamps[(id)] = wall_clock64();                                                   \
+  } while (0)
 
 template <int KSD, int KSF, int DH>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
@@ -286,6 +334,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   float *red_v = reinterpret_cast<float *>(A3 + 16 * LDA3);  // [NW][16]
   int *red_i = reinterpret_cast<int *>(red_v + NW * 16);
   int *flags = red_i + NW * 16;  // [0] = number of finished sentences of this tile
+  float *pbufs = reinterpret_cast<float *>(flags + 16);  // [NW][64] attention scratch
 
   // per-sentence state, owned by wave `wave` (uniform within the wave)
   const int b = m0 + wave;
@@ -307,9 +356,11 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 
   const int max_steps = a.max_steps;
   for (int t = 0; t < max_steps; ++t) {
+    SLIMT_STAMP(0);
     for (int l = 0; l < Ld; ++l) {
       const FusedLayerW &L = a.L[l];
       float *cl = cs + (size_t)l * 16 * D;
+      const int sb = 1 + 10 * l;
       // ---- SSRU (Modules.cc:190-235) ------------------------------------
       // quantise x twice (Wf / W have their own multipliers)
 #pragma unroll
@@ -319,6 +370,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         A2[wave * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
       }
       __syncthreads();
+      SLIMT_STAMP(sb + 0);
       for (int tile = wave; tile < D / 16; tile += NW) {
         const v4i *Wf = reinterpret_cast<const v4i *>(L.rnn_f.Wp);
         const v4i *Ww = reinterpret_cast<const v4i *>(L.rnn_w.Wp);
@@ -355,13 +407,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         }
       }
       __syncthreads();
+      SLIMT_STAMP(sb + 1);
       // h = LN(x + relu(c')), quantised for the Q projection
       ln_row<KSD>(pre + wave * LDF, L.rnn_ln_s, L.rnn_ln_b, a.eps, hs + wave * LDF, A1 + wave * LDA,
                   L.q.a_quant, lane);
       __syncthreads();
+      SLIMT_STAMP(sb + 2);
       // ---- cross-attention (Modules.cc:287-319) --------------------------
       // Q projection -> xs (x is dead until the end of the layer)
-      stream_gemm<KSD>(A1, LDA, L.q, wave, lane, [&](int tile, const v4i &acc) {
+      stream_gemm<KSD, 1>(A1, LDA, L.q, wave, lane, [&](int tile, const v4i &acc) {
         const int col = tile * 16 + lr;
         const int cq = L.q.colsum[col];
         const float pb = L.q.pb[col];
@@ -369,28 +423,31 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         for (int r = 0; r < 4; ++r) xs[(lg * 4 + r) * LDF + col] = dequant(acc[r], cq, L.q.u, pb);
       });
       __syncthreads();
+      SLIMT_STAMP(sb + 3);
       // SDPA over the cached K/V of sentence b; output quantised into A1
       if (live) {
         AttnRow ar;
-        ar.kl = a.kv + ((size_t)(2 * l) * B + b) * S * D;
-        ar.vl = a.kv + ((size_t)(2 * l + 1) * B + b) * S * D;
-        ar.qrow = xs + wave * LDF;
-        ar.arow = A1 + wave * LDA;
+        ar.kl = (gcf_ptr)(a.kv + ((size_t)(2 * l) * B + b) * S * D);
+        ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + b) * S * D);
+        ar.qrow = (lcf_ptr)(xs + wave * LDF);
+        ar.arow = (lc_ptr)(A1 + wave * LDA);
+        ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * 64);
         ar.S = S;
         ar.len = len;
         ar.alpha = a.alpha;
         ar.aq_o = L.o.a_quant;
-        ar.attn = (a.attn && (l + 1 == Ld)) ? a.attn + (size_t)b * H * S : nullptr;
+        ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
         const bool want_align = a.align && (l + 1 == Ld) && !finished && ((int)n_out < a.Tmax);
-        ar.align = want_align ? a.align + ((size_t)b * a.Tmax + n_out) * S : nullptr;
+        ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + n_out) * S) : (gf_ptr) nullptr;
         attention_row<D, DH>(ar, lane);
       } else {
 #pragma unroll
         for (int i = 0; i < KSD; ++i) A1[wave * LDA + lane + 64 * i] = 0;
       }
       __syncthreads();
+      SLIMT_STAMP(sb + 4);
       // O projection + residual h (Modules.cc:308-314)
-      stream_gemm<KSD>(A1, LDA, L.o, wave, lane, [&](int tile, const v4i &acc) {
+      stream_gemm<KSD, 1>(A1, LDA, L.o, wave, lane, [&](int tile, const v4i &acc) {
         const int col = tile * 16 + lr;
         const int co = L.o.colsum[col];
         const float pb = L.o.pb[col];
@@ -402,11 +459,13 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         }
       });
       __syncthreads();
+      SLIMT_STAMP(sb + 5);
       ln_row<KSD>(pre + wave * LDF, L.attn_ln_s, L.attn_ln_b, a.eps, hs + wave * LDF,
                   A1 + wave * LDA, L.ffn1.a_quant, lane);
       __syncthreads();
+      SLIMT_STAMP(sb + 6);
       // ---- FFN (Modules.cc:251-257) ----------------------------------------
-      stream_gemm<KSD>(A1, LDA, L.ffn1, wave, lane, [&](int tile, const v4i &acc) {
+      stream_gemm<KSD, 2>(A1, LDA, L.ffn1, wave, lane, [&](int tile, const v4i &acc) {
         const int col = tile * 16 + lr;
         const int c1 = L.ffn1.colsum[col];
         const float pb = L.ffn1.pb[col];
@@ -418,7 +477,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         }
       });
       __syncthreads();
-      stream_gemm<KSF>(A3, LDA3, L.ffn2, wave, lane, [&](int tile, const v4i &acc) {
+      SLIMT_STAMP(sb + 7);
+      stream_gemm<KSF, 2>(A3, LDA3, L.ffn2, wave, lane, [&](int tile, const v4i &acc) {
         const int col = tile * 16 + lr;
         const int c2 = L.ffn2.colsum[col];
         const float pb = L.ffn2.pb[col];
@@ -430,10 +490,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         }
       });
       __syncthreads();
+      SLIMT_STAMP(sb + 8);
       // next layer's input; after the last layer: quantised for the logits
       ln_row<KSD>(pre + wave * LDF, L.ffn_ln_s, L.ffn_ln_b, a.eps, xs + wave * LDF,
                   (l + 1 == Ld) ? A1 + wave * LDA : nullptr, a.out.a_quant, lane);
       __syncthreads();
+      SLIMT_STAMP(sb + 9);
     }
     // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
     float bv[4];
@@ -443,7 +505,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       bv[r] = -3.402823466e+38f;
       bi[r] = 0x7fffffff;
     }
-    stream_gemm<KSD>(A1, LDA, a.out, wave, lane, [&](int tile, const v4i &acc) {
+    stream_gemm<KSD, 2>(A1, LDA, a.out, wave, lane, [&](int tile, const v4i &acc) {
       const int col = tile * 16 + lr;
       if (col < a.out.N) {
         const int co = a.out.colsum[col];
@@ -475,6 +537,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       }
     }
     __syncthreads();
+    SLIMT_STAMP(41);
     // wave w finishes sentence w: reduce over the 16 waves' candidates
     uint32_t tok = 0;
     {
@@ -516,13 +579,14 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       }
     }
     __syncthreads();
+    SLIMT_STAMP(42);
   }
   if (live && lane == 0) a.out_len[b] = n_out;
 }
 
 size_t fused_decode_lds_bytes(int D, int F, int Ld) {
   return (size_t)3 * 16 * (D + 4) * 4 + (size_t)Ld * 16 * D * 4 + 2 * 16 * (size_t)(D + 16) +
-         16 * (size_t)(F + 16) + 2 * NW * 16 * 4 + 64;
+         16 * (size_t)(F + 16) + 2 * NW * 16 * 4 + 64 + NW * 64 * 4;
 }
 
 bool fused_decode_supported(int D, int F, int H, int Ld) {

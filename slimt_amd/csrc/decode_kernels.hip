@@ -471,12 +471,12 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
   // 3. K rows of this lane's keys, independent of Q: issue now
   const int j0 = lane < S ? lane : S - 1;
   const int j1 = (lane + 64) < S ? (lane + 64) : S - 1;
-  const float *kb = a.k + (size_t)bc * S * a.ldk + h * DH;
+  const float *kb = a.k + ((size_t)bc * a.H + h) * (DH / 4) * S * 4;  // [dh/4][S][4]
   constexpr int KPF = (DH < 32 ? DH : 32) / 4;  // float4s prefetched before Q is known
   float4 k0[KPF];
 #pragma unroll
   for (int i = 0; i < KPF; ++i)
-    k0[i] = *reinterpret_cast<const float4 *>(kb + (size_t)j0 * a.ldk + 4 * i);
+    k0[i] = *reinterpret_cast<const float4 *>(kb + ((size_t)i * S + j0) * 4);
   // first 16 V rows for this lane's output column
   const int dc = lane < DH ? lane : DH - 1;
   const float *vb = a.v + (size_t)bc * S * a.ldv + h * DH + dc;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
     if (i < KPF)
       k4 = k0[i];
     else
-      k4 = *reinterpret_cast<const float4 *>(kb + (size_t)j0 * a.ldk + 4 * i);
+      k4 = *reinterpret_cast<const float4 *>(kb + ((size_t)i * S + j0) * 4);
     s0 = __builtin_fmaf(q4.x, k4.x, s0);
     s0 = __builtin_fmaf(q4.y, k4.y, s0);
     s0 = __builtin_fmaf(q4.z, k4.z, s0);
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
 #pragma unroll
     for (int i = 0; i < DH / 4; ++i) {
       const float4 q4 = *reinterpret_cast<const float4 *>(qrow + 4 * i);
-      const float4 k4 = *reinterpret_cast<const float4 *>(kb + (size_t)j1 * a.ldk + 4 * i);
+      const float4 k4 = *reinterpret_cast<const float4 *>(kb + ((size_t)i * S + j1) * 4);
       s1 = __builtin_fmaf(q4.x, k4.x, s1);
       s1 = __builtin_fmaf(q4.y, k4.y, s1);
       s1 = __builtin_fmaf(q4.z, k4.z, s1);

@@ -542,7 +542,7 @@ void ctx_free(slimt_hip_ctx *c) {
                     &c->h8, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
                     &c->state, &c->part_val, &c->part_idx, &c->prev, &c->out_ids, &c->out_len,
                     &c->finished, &c->n_finished, &c->align, &c->shortlist, &c->logits,
-                    &c->attn_dbg};
+                    &c->attn_dbg, &c->stamps};
   for (auto *b : bufs) b->release();
   free_affine(c->out_sl);
   if (c->n_finished_host) (void)hipHostFree(c->n_finished_host);
@@ -698,8 +698,10 @@ EmbedArgs embed_args(const slimt_hip_ctx *c) {
 
 // affine on M rows, f32 in -> f32 out
 int run_affine_f32(slimt_hip_ctx *c, int family, const AffineW &w, const float *x, int M, float *y,
-                   int rows_per_block) {
+                   int rows_per_block, int kc_S = 0, int kc_dh = 0) {
   GemmArgs g;
+  g.kc_S = kc_S;
+  g.kc_dh = kc_dh;
   g.x_f32 = x;
   g.lda = w.w.K;
   g.M = M;
@@ -813,8 +815,9 @@ int decode_setup(slimt_hip_ctx *c, size_t n_sl) {
   float *kv = c->kv.as<float>();
   for (int l = 0; l < m->Ld; ++l) {
     const DecLayerW &L = m->dec[(size_t)l];
+    // K in the coalescing-friendly cache layout [sentence][head][d/4][key][4]
     RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.k, c->x0.as<float>(), M,
-                         kv + (size_t)(2 * l) * M * D, rpb));
+                         kv + (size_t)(2 * l) * M * D, rpb, S, D / m->H));
     RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.v, c->x0.as<float>(), M,
                          kv + (size_t)(2 * l + 1) * M * D, rpb));
   }
@@ -887,7 +890,7 @@ int decoder_layers(slimt_hip_ctx *c, float *d_align, int Tmax, const uint32_t *d
     a.wq = L.attn.q.w;
     a.k = kv + (size_t)(2 * l) * M * D;
     a.v = kv + (size_t)(2 * l + 1) * M * D;
-    a.ldk = a.ldv = D;
+    a.ldv = D;
     a.lengths = c->lengths.as<uint32_t>();
     a.alpha = 1.0f / std::sqrt(static_cast<float>(D / m->H));
     a.out_i8 = c->datt8.as<int8_t>();
@@ -995,6 +998,10 @@ int translate_device(slimt_hip_ctx *c, size_t B, size_t S, size_t n_sl, float li
     f.out_ids = d_out_ids;
     f.out_len = d_out_len;
     f.align = d_align;
+    if (c->stamp_step >= 0 && c->stamps.p) {
+      f.stamps = c->stamps.as<unsigned long long>();
+      f.stamp_step = c->stamp_step;
+    }
     const double macs = (double)B * f.max_steps *
                         (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.N);
     const double wbytes = (double)f.max_steps * ((B + 15) / 16) *
@@ -1208,5 +1215,24 @@ extern "C" int slimt_hip_profile_read(slimt_hip_ctx *ctx, uint64_t *launches, do
   if (total_ms) *total_ms = ms;
   if (int8_macs) *int8_macs = ctx->prof_macs;
   if (weight_bytes) *weight_bytes = ctx->prof_bytes;
+  return 0;
+}
+
+// Diagnostic: wall-clock stamps (100 MHz ticks) at the phase boundaries of the
+// persistent decoder, workgroup 0, decode step `step`. step < 0 disables.
+extern "C" int slimt_hip_debug_decode_stamps(slimt_hip_ctx *ctx, int step, uint64_t *out,
+                                             size_t n) {
+  if (!ctx) return fail(-1, "ctx is NULL");
+  HIPCHK(hipSetDevice(ctx->model->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (out && n && ctx->stamps.p) {
+    if (n > 64) n = 64;
+    HIPCHK(hipMemcpy(out, ctx->stamps.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
+  ctx->stamp_step = step;
+  if (step >= 0) {
+    HIPCHK(ctx->stamps.reserve(64 * sizeof(uint64_t)));
+    HIPCHK(hipMemset(ctx->stamps.p, 0, 64 * sizeof(uint64_t)));
+  }
   return 0;
 }

@@ -77,6 +77,8 @@ struct slimt_hip_ctx {
   bool have_encoder_out = false;
   bool decode_ready = false;
   int decode_mode = 0;  // 0 auto (fused when supported), 1 step-wise launches
+  slimt_hip::DevBuf stamps;  // diagnostic phase stamps of the fused decoder
+  int stamp_step = -1;
   // encoder workspace
   slimt_hip::DevBuf pos;  // [max_S][D]
   slimt_hip::DevBuf ids, lengths;

@@ -56,6 +56,10 @@ struct GemmArgs {
   int ldy8 = 0;
   float a_quant_out = 0.f;
   int32_t *acc_out = nullptr;
+  // EPI_PLAIN only: kc_S > 0 stores y in the decoder's K-cache layout
+  //   [sentence][head][d/4][key][4]  (row = sentence*kc_S + key, col = head*kc_dh + d)
+  // so that a wave reading one head's keys issues fully coalesced 16-byte loads.
+  int kc_S = 0, kc_dh = 0;
   // EPI_RES_LN
   const float *res = nullptr;
   int ldres = 0;
@@ -176,8 +180,9 @@ struct DQAttnArgs {
   int B = 0, D = 0, H = 0, S = 0;
   RowSrc x;            // decoder state rows (pre-LN of the SSRU block)
   PreparedWeight wq;
-  const float *k = nullptr, *v = nullptr;  // cached cross-attention K/V [B*S][ld]
-  int ldk = 0, ldv = 0;
+  const float *k = nullptr;  // cached K, layout [B][H][dh/4][S][4]
+  const float *v = nullptr;  // cached V [B*S][ldv]
+  int ldv = 0;
   const uint32_t *lengths = nullptr;
   float alpha = 0.f, eps = 1e-6f;
   int8_t *out_i8 = nullptr;  // joined heads, quantised for the O projection
@@ -207,7 +212,7 @@ struct FusedDecodeArgs {
   PreparedWeight out;                   // (shortlisted) output layer
   const uint32_t *shortlist = nullptr;  // nullable: column -> vocabulary id
   EmbedArgs emb;
-  const float *kv = nullptr;            // [Ld][2][B*S][D]
+  const float *kv = nullptr;            // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]
   const uint32_t *lengths = nullptr;
   float alpha = 0.f, eps = 1e-6f;
   uint32_t eos = 0;
@@ -215,6 +220,8 @@ struct FusedDecodeArgs {
   uint32_t *out_len = nullptr;  // [B]
   float *align = nullptr;       // nullable [B][Tmax][S]
   float *attn = nullptr;        // nullable debug [B][H][S]
+  unsigned long long *stamps = nullptr;  // nullable diagnostic [64] phase stamps
+  int stamp_step = 0;
 };
 bool fused_decode_supported(int D, int F, int H, int Ld);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);

@@ -238,7 +238,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmKArgs ka) {
             float v = (float)accS * u;
             v = v + pb;
             if constexpr (EPI == EPI_PLAIN) {
-              a.y[(size_t)row * a.ldy + col] = v;
+              if (a.kc_S) {
+                const int sb = row / a.kc_S, j = row - sb * a.kc_S;
+                const int h = col / a.kc_dh, d = col - h * a.kc_dh;
+                const size_t chunk = ((size_t)sb * (a.w.N / a.kc_dh) + h) * (a.kc_dh >> 2) + (d >> 2);
+                a.y[(chunk * a.kc_S + j) * 4 + (d & 3)] = v;
+              } else {
+                a.y[(size_t)row * a.ldy + col] = v;
+              }
             } else {
               v = v > 0.0f ? v : 0.0f;  // relu, TensorOps.cc:163-181
               a.y_i8[(size_t)row * a.ldy8 + col] = (int8_t)quantize1(v, a.a_quant_out);

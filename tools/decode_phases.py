@@ -1,0 +1,25 @@
+"""GPU box: per-phase time of the persistent decoder (workgroup 0, one step)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from slimt_amd import capi, synth
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+S, n_sl = 32, 4096
+m = synth.make_model("tiny11", eos_bias=-100.0)
+gm = capi.Model(m); ctx = capi.Context(gm, B, S)
+ids, lens = synth.make_batch(m.V, B, S); sl = synth.make_shortlist(m.V, n_sl)
+ctx.translate(ids, lens, sl)
+names = ["step_start"]
+for l in range(2):
+    names += [f"L{l}.ssru_quant", f"L{l}.ssru_gemm", f"L{l}.ln_h", f"L{l}.q_gemm", f"L{l}.attention",
+              f"L{l}.o_gemm", f"L{l}.ln_o", f"L{l}.ffn1", f"L{l}.ffn2", f"L{l}.ln_x"]
+idx = list(range(21)) + [41, 42]
+names += ["logits+argmax", "sample/record/embed"]
+for step in (5, 20):
+    ctx.debug_decode_stamps(step)
+    ctx.translate(ids, lens, sl)
+    st = ctx.debug_decode_stamps(-1).astype(np.int64)
+    t = st[idx]
+    print(f"--- B={B} step {step}: total {(t[-1]-t[0])/100:.1f} us")
+    for i in range(1, len(idx)):
+        print(f"  {names[i]:22s} {(t[i]-t[i-1])/100:7.2f} us")
