@@ -41,6 +41,10 @@ def parse():
                     help="kernel family bracketed by HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sentences", type=int, default=16)
+    ap.add_argument("--workers", type=int, default=1,
+                    help="translate contexts (HIP streams) per GPU, like slimt::Async workers "
+                         "(Frontend.cc:212-226): independent batches in flight on one device")
+    ap.add_argument("--decode-mode", type=int, default=0, help="0 = fused persistent decoder, 1 = step-wise")
     ap.add_argument("--all-kernels", action="store_true",
                     help="after the timed region, time every kernel family (untimed pass)")
     return ap.parse_args()
@@ -100,7 +104,11 @@ def main():
     sl = synth.make_shortlist(model.V, n_sl) if n_sl else None
     N_out = n_sl if n_sl else model.V
     gm = capi.Model(model, device=local_rank)
-    ctx = capi.Context(gm, B, S)
+    W = max(1, args.workers)
+    ctxs = [capi.Context(gm, B, S) for _ in range(W)]
+    for c in ctxs:
+        c.set_decode_mode(args.decode_mode)
+    ctx = ctxs[0]
     dev = torch.device("cuda", local_rank)
 
     def to_dev(a):
@@ -113,14 +121,17 @@ def main():
         ids, lens = synth.make_batch(model.V, B, S, seed=4321 + 97 * rank + i)
         batches.append((to_dev(ids), to_dev(lens)))
     d_sl = to_dev(sl) if sl is not None else None
-    d_out = torch.zeros((B, T), dtype=torch.int32, device=dev)
-    d_len = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_outs = [torch.zeros((B, T), dtype=torch.int32, device=dev) for _ in range(W)]
+    d_lens_out = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(W)]
+    d_len = d_lens_out[0]
 
     def step(i):
+        # step i runs on worker i % W; calls are asynchronous (fixed step count)
+        w = i % W
         d_ids, d_lens = batches[i % n_batches]
-        ctx.translate_device(d_ids.data_ptr(), d_lens.data_ptr(), B, S,
-                             d_sl.data_ptr() if d_sl is not None else 0, n_sl, 1.5, 0,
-                             d_out.data_ptr(), d_len.data_ptr(), 0, steps_hint=T)
+        ctxs[w].translate_device(d_ids.data_ptr(), d_lens.data_ptr(), B, S,
+                                 d_sl.data_ptr() if d_sl is not None else 0, n_sl, 1.5, 0,
+                                 d_outs[w].data_ptr(), d_lens_out[w].data_ptr(), 0, steps_hint=T)
 
     def barrier():
         torch.cuda.synchronize()
@@ -128,14 +139,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, W)):
         step(i)
     torch.cuda.synchronize()
     tokens_per_step = int(d_len.sum().item())
 
     kmap = {"gemm_enc": capi.K_GEMM_ENC, "gemm_dec": capi.K_GEMM_DEC, "logits": capi.K_LOGITS,
-            "attn_enc": capi.K_ATTN_ENC, "attn_dec": capi.K_ATTN_DEC, "ssru": capi.K_SSRU}
-    prof_name = "gemm_dec" if args.profile_kernel == "auto" else args.profile_kernel
+            "attn_enc": capi.K_ATTN_ENC, "attn_dec": capi.K_ATTN_DEC, "ssru": capi.K_SSRU,
+            "decode_fused": capi.K_DECODE_FUSED, "encode_fused": capi.K_ENCODE_FUSED}
+    auto_kernel = "decode_fused" if args.decode_mode == 0 else "gemm_dec"
+    prof_name = auto_kernel if args.profile_kernel == "auto" else args.profile_kernel
     ctx.profile_enable(kmap.get(prof_name, capi.K_NONE))
 
     barrier()
@@ -191,6 +204,7 @@ def main():
                             f"{'shortlist ' + str(n_sl) if n_sl else 'full 32k vocabulary'}",
                 "preset": args.preset, "batch_per_gpu": B, "src_len": S, "decode_steps": T,
                 "shortlist": n_sl, "parallelism": f"dp{world} (replicated weights, no collective)",
+                "workers_per_gpu": W, "decode": "fused-persistent" if args.decode_mode == 0 else "step-wise",
                 "tokens_per_step_all_gpus": total_tokens_per_step,
                 "int8_ops_per_token": 2.0 * macs_sentence / T,
                 "whole_job_int8_tops": 2.0 * macs_sentence * B * world * args.steps / dt_max / 1e12,
@@ -212,7 +226,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
     gm.close()
 
 

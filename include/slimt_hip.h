@@ -126,9 +126,10 @@ int slimt_hip_ctx_create(slimt_hip_model *model, size_t max_batch,
 int slimt_hip_ctx_destroy(slimt_hip_ctx *ctx);
 int slimt_hip_ctx_stream(slimt_hip_ctx *ctx, void **stream);
 int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
-/* Decode strategy of slimt_hip_translate*: 0 = automatic (persistent fused
- * decoder when the model shape supports it), 1 = one launch per stage and step
- * (the kernels behind slimt_hip_decode_step). Same results either way. */
+/* Execution strategy of slimt_hip_translate* / slimt_hip_encode: 0 = automatic
+ * (persistent fused encoder / decoder kernels when the model shape supports
+ * them), 1 = one launch per stage (and per decode step; the kernels behind
+ * slimt_hip_decode_step). Same results either way. */
 int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode);
 
 /* Model::forward (Model.cc:187-204) = embed + Encoder::forward + the greedy
@@ -188,7 +189,8 @@ enum {
   SLIMT_HIP_K_ATTN_DEC = 5,
   SLIMT_HIP_K_SSRU = 6,
   SLIMT_HIP_K_DECODE_FUSED = 7, /* persistent whole-loop decoder           */
-  SLIMT_HIP_K_COUNT = 8
+  SLIMT_HIP_K_ENCODE_FUSED = 8, /* persistent whole-stack encoder          */
+  SLIMT_HIP_K_COUNT = 9
 };
 int slimt_hip_profile_enable(slimt_hip_ctx *ctx, int kernel_id);
 int slimt_hip_profile_read(slimt_hip_ctx *ctx, uint64_t *launches,

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libslimt_hip.so")
 
-SOURCES = ["kernels.hip", "decode_kernels.hip", "decode_fused.hip", "engine.cpp"]
+SOURCES = ["kernels.hip", "decode_kernels.hip", "decode_fused.hip", "encode_fused.hip", "engine.cpp"]
 HEADERS = ["kernels.h", "engine.h", "device_common.h", os.path.join(ROOT, "include", "slimt_hip.h")]
 
 # -ffp-contract=off: the float epilogues are written operation by operation

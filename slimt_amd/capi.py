@@ -28,7 +28,7 @@ SYMBOLS = [
     "slimt_hip_debug_decode_stamps",
 ]
 
-K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED = range(8)
+K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED, K_ENCODE_FUSED = range(9)
 KERNEL_NAMES = {K_GEMM_ENC: "gemm_enc", K_GEMM_DEC: "gemm_dec", K_LOGITS: "logits_argmax",
                 K_ATTN_ENC: "attn_enc", K_ATTN_DEC: "attn_dec", K_SSRU: "ssru"}
 

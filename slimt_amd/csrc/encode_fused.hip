@@ -1,0 +1,405 @@
+// Persistent fused encoder: embedding + all encoder layers + the decoder's
+// cross-attention K/V cache in ONE launch (Model.cc:195-201,
+// Transformer.cc:57-69, Modules.cc:287-334).
+//
+// Encoder rows only interact inside a sentence (self-attention), so one
+// workgroup owns 32 rows = floor(32 / S) whole sentences (S <= 32) for all
+// layers: the residual stream (f32), the three int8 A operands of Q/K/V and
+// the f32 q/k/v of all heads live in LDS (~155 KiB of the CU's 160 KiB);
+// weights stream from L2 in MFMA-fragment order. Arithmetic is bit-identical
+// to the layer-by-layer kernels (kernels.hip).
+#include "device_common.h"
+#include "kernels.h"
+
+namespace slimt_hip {
+
+namespace {
+
+constexpr int ENW = 16;  // waves per workgroup
+constexpr int ER = 32;   // rows per workgroup (2 MFMA row tiles)
+
+#define SLIMT_GLOBAL __attribute__((address_space(1)))
+#define SLIMT_LDS __attribute__((address_space(3)))
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float edequant(int acc, int colsum, float u, float pb) {
+  const float v = (float)(acc + 127 * colsum) * u;
+  return v + pb;
+}
+
+// one 16-column tile of a weight against both row tiles of A (32 x K int8 in LDS)
+template <int KS>
+__device__ __forceinline__ void tile_mma2(const char *A, int lda, const v4i (&bf)[KS], int lr, int lg,
+                                          v4i &acc0, v4i &acc1, int ks0 = 0) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const v4i a0 = *reinterpret_cast<const v4i *>(A + lr * lda + (ks0 + ks) * 64 + lg * 16);
+    const v4i a1 = *reinterpret_cast<const v4i *>(A + (16 + lr) * lda + (ks0 + ks) * 64 + lg * 16);
+    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bf[ks], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bf[ks], acc1, 0, 0, 0);
+  }
+}
+
+template <int KS>
+__device__ __forceinline__ void load_frags(v4i (&bf)[KS], const PreparedWeight &w, int tile, int ks0,
+                                           int lane) {
+  const v4i *Wp = reinterpret_cast<const v4i *>(w.Wp);
+  const int KST = w.K >> 6;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) bf[ks] = Wp[((size_t)tile * KST + ks0 + ks) * 64 + lane];
+}
+
+// canonical in-place LayerNorm of LDS row x[0..D) by one wave
+template <int DPL>
+__device__ __forceinline__ void eln_row(float *x, const float *scale, const float *bias, float eps,
+                                        int lane) {
+  constexpr int D = 64 * DPL;
+  float v[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) v[i] = x[lane + 64 * i];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) s += v[i];
+  s = wave_sum(s);
+  const float mean = s / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float d = v[i] - mean;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  const float sigma = __builtin_sqrtf(q / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float t = (v[i] - mean) / sigma;
+    const float m = scale[lane + 64 * i] * t;
+    x[lane + 64 * i] = m + bias[lane + 64 * i];
+  }
+}
+
+}  // namespace
+
+template <int KSD, int KSF, int DH>
+__global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = 64 * KSD, H = D / DH;
+  constexpr int LDX = D + 4;   // f32 residual rows
+  constexpr int LDA = D + 16;  // int8 A rows
+  constexpr int LDQ = D + 1;   // f32 q/k/v rows (odd stride: row-per-lane reads are conflict-free)
+  static_assert(D / 16 == ENW, "one 16-column tile of a D-wide GEMM per wave");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int S = a.S, B = a.B;
+  const int spw = ER / S;              // whole sentences per workgroup
+  const int s0 = blockIdx.x * spw;     // first sentence
+  const int rows_used = spw * S;
+
+  float *xs = reinterpret_cast<float *>(smem);
+  char *Aq = reinterpret_cast<char *>(xs + ER * LDX);
+  char *Ak = Aq + ER * LDA;
+  char *Av = Ak + ER * LDA;
+  float *qb = reinterpret_cast<float *>(Av + ER * LDA);
+  float *kb = qb + ER * LDQ;
+  float *vb = kb + ER * LDQ;
+
+  // row r of this workgroup: sentence s0 + r / S, position r % S
+  auto row_sentence = [&](int r) { return s0 + r / S; };
+  auto row_valid = [&](int r) { return r < rows_used && row_sentence(r) < B; };
+
+  // ---- embedding (Model.cc:195-197) ----------------------------------------
+  for (int r = wave; r < ER; r += ENW) {
+    const bool ok = row_valid(r);
+    const int sb = row_sentence(r), pos = r % S;
+    const uint32_t tok = ok ? a.ids[(size_t)sb * S + pos] : 0;
+#pragma unroll
+    for (int i = 0; i < KSD; ++i) {
+      float v = 0.0f;
+      if (ok) {
+        const float e = (float)a.emb.wemb[(size_t)tok * D + lane + 64 * i] * a.emb.inv_mult;
+        const float sc = e * a.emb.sqrt_d;
+        v = sc + a.emb.pos[(size_t)pos * D + lane + 64 * i];
+      }
+      xs[r * LDX + lane + 64 * i] = v;
+      if (ok && a.embed_out) a.embed_out[((size_t)sb * S + pos) * D + lane + 64 * i] = v;
+    }
+  }
+  __syncthreads();
+
+  for (int l = 0; l < a.Le; ++l) {
+    const FusedEncLayerW &L = a.L[l];
+    // ---- Attention::forward (Modules.cc:287-319) ---------------------------
+    for (int r = wave; r < ER; r += ENW) {
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) {
+        const float v = xs[r * LDX + lane + 64 * i];
+        Aq[r * LDA + lane + 64 * i] = (char)quantize1(v, L.q.a_quant);
+        Ak[r * LDA + lane + 64 * i] = (char)quantize1(v, L.k.a_quant);
+        Av[r * LDA + lane + 64 * i] = (char)quantize1(v, L.v.a_quant);
+      }
+    }
+    __syncthreads();
+    {  // Q, K, V projections: wave = column tile of each
+      v4i bq[KSD], bk[KSD], bv[KSD];
+      load_frags<KSD>(bq, L.q, wave, 0, lane);
+      load_frags<KSD>(bk, L.k, wave, 0, lane);
+      load_frags<KSD>(bv, L.v, wave, 0, lane);
+      const int col = wave * 16 + lr;
+      {
+        v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+        tile_mma2<KSD>(Aq, LDA, bq, lr, lg, c0, c1);
+        const int cs = L.q.colsum[col];
+        const float pb = L.q.pb[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          qb[(lg * 4 + r) * LDQ + col] = edequant(c0[r], cs, L.q.u, pb);
+          qb[(16 + lg * 4 + r) * LDQ + col] = edequant(c1[r], cs, L.q.u, pb);
+        }
+      }
+      {
+        v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+        tile_mma2<KSD>(Ak, LDA, bk, lr, lg, c0, c1);
+        const int cs = L.k.colsum[col];
+        const float pb = L.k.pb[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          kb[(lg * 4 + r) * LDQ + col] = edequant(c0[r], cs, L.k.u, pb);
+          kb[(16 + lg * 4 + r) * LDQ + col] = edequant(c1[r], cs, L.k.u, pb);
+        }
+      }
+      {
+        v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+        tile_mma2<KSD>(Av, LDA, bv, lr, lg, c0, c1);
+        const int cs = L.v.colsum[col];
+        const float pb = L.v.pb[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vb[(lg * 4 + r) * LDQ + col] = edequant(c0[r], cs, L.v.u, pb);
+          vb[(16 + lg * 4 + r) * LDQ + col] = edequant(c1[r], cs, L.v.u, pb);
+        }
+      }
+    }
+    __syncthreads();
+    // scaled_dot_product_attention (Modules.cc:24-86): wave = (head, query
+    // parity); two queries per pass (lane half = query), keys/values of the
+    // sentence held in registers. Output quantised for the O projection into
+    // Aq (dead since the projections).
+    {
+      const int h = wave % H, par = wave / H;  // ENW == 2 * H for the supported shapes
+      const int half = lane >> 5, j = lane & 31;
+      const float minus_inf = -99999999.0f;  // Input.cc:56-61
+      const float lowest = -3.402823466e+38f;
+      for (int sl = 0; sl < spw; ++sl) {
+        const int sb = s0 + sl;
+        if (sb >= B) break;
+        const int base = sl * S;
+        const int len = (int)a.lengths[sb];
+        const int jc = j < S ? j : S - 1;
+        float kreg[DH], vreg[32];
+#pragma unroll
+        for (int k = 0; k < DH; ++k) kreg[k] = kb[(base + jc) * LDQ + h * DH + k];
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj)
+          vreg[jj] = vb[(base + (jj < S ? jj : S - 1)) * LDQ + h * DH + (lane & (DH - 1))];
+        const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+        // queries of this wave: positions par*2 + half + 4*i
+        for (int i0 = par * 2; i0 < S; i0 += 4) {
+          const int qi = i0 + half;
+          const int qic = qi < S ? qi : S - 1;
+          const float *qrow = qb + (base + qic) * LDQ + h * DH;
+          float s = 0.0f;
+#pragma unroll
+          for (int k = 0; k < DH; ++k) s = __builtin_fmaf(qrow[k], kreg[k], s);
+          if (a.alpha != 1.0f) s = a.alpha * s;
+          s = s + mask;
+          if (j >= S) s = lowest;
+          float m = s;
+#pragma unroll
+          for (int x = 1; x < 32; x <<= 1) m = fmaxf(m, __shfl_xor(m, x, 64));
+          const float e = j < S ? exp_p(s - m) : 0.0f;
+          float sum = e;  // canonical order: masks 1..16; the mask-32 step would add +0
+#pragma unroll
+          for (int x = 1; x < 32; x <<= 1) sum = sum + __shfl_xor(sum, x, 64);
+          const float p = e / sum;  // keys >= S: exactly 0
+          float o = 0.0f;
+#pragma unroll
+          for (int jj = 0; jj < 32; ++jj) {  // keys >= S contribute fma(0, v, o) == o
+            const float pj = __shfl(p, (lane & 32) | jj, 64);
+            o = __builtin_fmaf(pj, vreg[jj], o);
+          }
+          if (qi < S && j < DH) Aq[(base + qi) * LDA + h * DH + j] = (char)quantize1(o, L.o.a_quant);
+        }
+      }
+    }
+    // rows that belong to no sentence keep a defined A operand
+    for (int r = rows_used + wave; r < ER; r += ENW)
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) Aq[r * LDA + lane + 64 * i] = 0;
+    __syncthreads();
+    {  // O projection + residual: x = x + yo (Modules.cc:308-314)
+      v4i bo[KSD];
+      load_frags<KSD>(bo, L.o, wave, 0, lane);
+      v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+      tile_mma2<KSD>(Aq, LDA, bo, lr, lg, c0, c1);
+      const int col = wave * 16 + lr;
+      const int cs = L.o.colsum[col];
+      const float pb = L.o.pb[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float *p0 = xs + (lg * 4 + r) * LDX + col;
+        float *p1 = xs + (16 + lg * 4 + r) * LDX + col;
+        *p0 = *p0 + edequant(c0[r], cs, L.o.u, pb);
+        *p1 = *p1 + edequant(c1[r], cs, L.o.u, pb);
+      }
+    }
+    __syncthreads();
+    for (int r = wave; r < ER; r += ENW) {
+      eln_row<KSD>(xs + r * LDX, L.attn_ln_s, L.attn_ln_b, a.eps, lane);
+#pragma unroll
+      for (int i = 0; i < KSD; ++i)
+        Aq[r * LDA + lane + 64 * i] = (char)quantize1(xs[r * LDX + lane + 64 * i], L.ffn1.a_quant);
+    }
+    __syncthreads();
+    // ---- FFN (Modules.cc:326-331): F is walked in chunks of 256 columns; the
+    // FFN2 accumulators of this wave's column tile stay in registers.
+    {
+      v4i f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
+      for (int fc = 0; fc < KSF / 4; ++fc) {
+        v4i b1[KSD], b2[4];
+        const int t1 = fc * 16 + wave;  // FFN1 column tile of this chunk
+        load_frags<KSD>(b1, L.ffn1, t1, 0, lane);
+        load_frags<4>(b2, L.ffn2, wave, fc * 4, lane);
+        v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+        tile_mma2<KSD>(Aq, LDA, b1, lr, lg, c0, c1);
+        const int col1 = t1 * 16 + lr;
+        const int cs = L.ffn1.colsum[col1];
+        const float pb = L.ffn1.pb[col1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v0 = edequant(c0[r], cs, L.ffn1.u, pb);
+          float v1 = edequant(c1[r], cs, L.ffn1.u, pb);
+          v0 = v0 > 0.0f ? v0 : 0.0f;
+          v1 = v1 > 0.0f ? v1 : 0.0f;
+          Ak[(lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v0, L.ffn2.a_quant);
+          Ak[(16 + lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v1, L.ffn2.a_quant);
+        }
+        __syncthreads();
+        tile_mma2<4>(Ak, LDA, b2, lr, lg, f0, f1);
+        __syncthreads();
+      }
+      const int col = wave * 16 + lr;
+      const int cs = L.ffn2.colsum[col];
+      const float pb = L.ffn2.pb[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float *p0 = xs + (lg * 4 + r) * LDX + col;
+        float *p1 = xs + (16 + lg * 4 + r) * LDX + col;
+        *p0 = edequant(f0[r], cs, L.ffn2.u, pb) + *p0;
+        *p1 = edequant(f1[r], cs, L.ffn2.u, pb) + *p1;
+      }
+    }
+    __syncthreads();
+    for (int r = wave; r < ER; r += ENW) {
+      eln_row<KSD>(xs + r * LDX, L.ffn_ln_s, L.ffn_ln_b, a.eps, lane);
+      if (a.layer_out && row_valid(r)) {
+        float *dst = a.layer_out + ((size_t)l * B * S + (size_t)row_sentence(r) * S + r % S) * D;
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) dst[lane + 64 * i] = xs[r * LDX + lane + 64 * i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- encoder output + decoder cross-attention K/V (Modules.cc:248-249,
+  // computed once per batch instead of every step) ----------------------------
+  for (int r = wave; r < ER; r += ENW) {
+    if (a.enc_out && row_valid(r)) {
+      float *dst = a.enc_out + ((size_t)row_sentence(r) * S + r % S) * D;
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) dst[lane + 64 * i] = xs[r * LDX + lane + 64 * i];
+    }
+  }
+  for (int l = 0; l < a.Ld; ++l) {
+    const PreparedWeight &wk = a.dec_k[l], &wv = a.dec_v[l];
+    for (int r = wave; r < ER; r += ENW) {
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) {
+        const float v = xs[r * LDX + lane + 64 * i];
+        Ak[r * LDA + lane + 64 * i] = (char)quantize1(v, wk.a_quant);
+        Av[r * LDA + lane + 64 * i] = (char)quantize1(v, wv.a_quant);
+      }
+    }
+    __syncthreads();
+    v4i bk[KSD], bv[KSD];
+    load_frags<KSD>(bk, wk, wave, 0, lane);
+    load_frags<KSD>(bv, wv, wave, 0, lane);
+    const int col = wave * 16 + lr;
+    float *kout = a.kv + (size_t)(2 * l) * B * S * D;
+    float *vout = a.kv + (size_t)(2 * l + 1) * B * S * D;
+    {
+      v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+      tile_mma2<KSD>(Ak, LDA, bk, lr, lg, c0, c1);
+      const int cs = wk.colsum[col];
+      const float pb = wk.pb[col];
+      const int hh = col / DH, d = col % DH;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = t * 16 + lg * 4 + r;
+          if (row_valid(rr)) {  // K cache layout [sentence][head][d/4][key][4]
+            const size_t chunk = ((size_t)row_sentence(rr) * H + hh) * (DH / 4) + (d >> 2);
+            kout[(chunk * S + rr % S) * 4 + (d & 3)] = edequant(t ? c1[r] : c0[r], cs, wk.u, pb);
+          }
+        }
+    }
+    {
+      v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+      tile_mma2<KSD>(Av, LDA, bv, lr, lg, c0, c1);
+      const int cs = wv.colsum[col];
+      const float pb = wv.pb[col];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = t * 16 + lg * 4 + r;
+          if (row_valid(rr))
+            vout[((size_t)row_sentence(rr) * S + rr % S) * D + col] =
+                edequant(t ? c1[r] : c0[r], cs, wv.u, pb);
+        }
+    }
+    __syncthreads();
+  }
+}
+
+size_t fused_encode_lds_bytes(int D) {
+  return (size_t)ER * (D + 4) * 4 + 3 * (size_t)ER * (D + 16) + 3 * (size_t)ER * (D + 1) * 4;
+}
+
+bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
+  if (S < 1 || S > ER || Le < 1 || Le > 6 || Ld < 1 || Ld > 4) return false;
+  if (H <= 0 || D % H || F % 256) return false;
+  return D == 256 && D / H == 32 && fused_encode_lds_bytes(D) <= 160 * 1024;
+}
+
+hipError_t launch_encode_fused(const FusedEncodeArgs &a, int D, int F, int H, hipStream_t st) {
+  if (!fused_encode_supported(D, F, H, a.Le, a.Ld, a.S)) return hipErrorInvalidValue;
+  const int spw = ER / a.S;
+  const dim3 grid((a.B + spw - 1) / spw);
+  const size_t lds = fused_encode_lds_bytes(D);
+  hipError_t e = hipSuccess;
+#define SLIMT_ENC_CASE(KSF_)                                                                   \
+  if (F == 64 * KSF_) {                                                                        \
+    auto k = encode_fused_kernel<4, KSF_, 32>;                                                 \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                                 \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    if (e != hipSuccess) return e;                                                             \
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);                                       \
+    return hipGetLastError();                                                                  \
+  }
+  SLIMT_ENC_CASE(24) SLIMT_ENC_CASE(16) SLIMT_ENC_CASE(32)
+#undef SLIMT_ENC_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace slimt_hip

@@ -542,7 +542,7 @@ void ctx_free(slimt_hip_ctx *c) {
                     &c->h8, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
                     &c->state, &c->part_val, &c->part_idx, &c->prev, &c->out_ids, &c->out_len,
                     &c->finished, &c->n_finished, &c->align, &c->shortlist, &c->logits,
-                    &c->attn_dbg, &c->stamps};
+                    &c->attn_dbg, &c->stamps, &c->dbg_embed, &c->dbg_layers};
   for (auto *b : bufs) b->release();
   free_affine(c->out_sl);
   if (c->n_finished_host) (void)hipHostFree(c->n_finished_host);
@@ -767,6 +767,49 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
   c->S = S;
   c->have_encoder_out = false;
   c->decode_ready = false;
+  c->kv_ready = false;
+  if (c->decode_mode == 0 && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
+    // embedding + every encoder layer + the decoder's K/V cache in one launch
+    FusedEncodeArgs f;
+    f.B = B; f.S = S; f.Le = m->Le; f.Ld = m->Ld;
+    for (int l = 0; l < m->Le; ++l) {
+      const EncLayerW &L = m->enc[(size_t)l];
+      FusedEncLayerW &fl = f.L[l];
+      fl.q = L.attn.q.w; fl.k = L.attn.k.w; fl.v = L.attn.v.w; fl.o = L.attn.o.w;
+      fl.ffn1 = L.ffn1.w; fl.ffn2 = L.ffn2.w;
+      fl.attn_ln_s = L.attn.ln.scale.as<float>(); fl.attn_ln_b = L.attn.ln.bias.as<float>();
+      fl.ffn_ln_s = L.ffn_ln.scale.as<float>(); fl.ffn_ln_b = L.ffn_ln.bias.as<float>();
+    }
+    for (int l = 0; l < m->Ld; ++l) {
+      f.dec_k[l] = m->dec[(size_t)l].attn.k.w;
+      f.dec_v[l] = m->dec[(size_t)l].attn.v.w;
+    }
+    f.emb = embed_args(c);
+    f.ids = c->ids.as<uint32_t>();
+    f.lengths = c->lengths.as<uint32_t>();
+    f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
+    f.kv = c->kv.as<float>();
+    f.enc_out = c->x0.as<float>();
+    if (h_embed) {
+      HIPCHK(c->dbg_embed.reserve(nbytes));
+      f.embed_out = c->dbg_embed.as<float>();
+    }
+    if (h_layers) {
+      HIPCHK(c->dbg_layers.reserve(nbytes * (size_t)m->Le));
+      f.layer_out = c->dbg_layers.as<float>();
+    }
+    {
+      const double macs = (double)M * (m->Le * (4.0 * D * D + 2.0 * D * m->F) + m->Ld * 2.0 * D * D);
+      ProfScope p(c, SLIMT_HIP_K_ENCODE_FUSED, macs, 0);
+      HIPCHK(launch_encode_fused(f, m->D, m->F, m->H, st));
+    }
+    if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, c->dbg_embed.p, nbytes, hipMemcpyDeviceToHost, st));
+    if (h_layers)
+      HIPCHK(hipMemcpyAsync(h_layers, c->dbg_layers.p, nbytes * (size_t)m->Le, hipMemcpyDeviceToHost, st));
+    c->have_encoder_out = true;
+    c->kv_ready = true;
+    return 0;
+  }
   float *x = c->x0.as<float>(), *y = c->x1.as<float>();
   HIPCHK(launch_embed_encoder(embed_args(c), c->ids.as<uint32_t>(), B, S, x, st));
   if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, x, nbytes, hipMemcpyDeviceToHost, st));
@@ -813,7 +856,7 @@ int decode_setup(slimt_hip_ctx *c, size_t n_sl) {
   if (!c->have_encoder_out) return fail(-1, "decode before encode");
   const int rpb = M >= 2048 ? 64 : (M >= 512 ? 32 : 16);
   float *kv = c->kv.as<float>();
-  for (int l = 0; l < m->Ld; ++l) {
+  for (int l = 0; l < m->Ld && !c->kv_ready; ++l) {
     const DecLayerW &L = m->dec[(size_t)l];
     // K in the coalescing-friendly cache layout [sentence][head][d/4][key][4]
     RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.k, c->x0.as<float>(), M,

@@ -76,6 +76,8 @@ struct slimt_hip_ctx {
   int n_sl = 0;  // 0 => full vocabulary
   bool have_encoder_out = false;
   bool decode_ready = false;
+  bool kv_ready = false;  // cross-attention K/V already produced by the fused encoder
+  slimt_hip::DevBuf dbg_embed, dbg_layers;
   int decode_mode = 0;  // 0 auto (fused when supported), 1 step-wise launches
   slimt_hip::DevBuf stamps;  // diagnostic phase stamps of the fused decoder
   int stamp_step = -1;

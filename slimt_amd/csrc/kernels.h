@@ -226,6 +226,29 @@ struct FusedDecodeArgs {
 bool fused_decode_supported(int D, int F, int H, int Ld);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
 
+// ---- persistent fused encoder (encode_fused.hip) ------------------------------
+struct FusedEncLayerW {
+  PreparedWeight q, k, v, o, ffn1, ffn2;
+  const float *attn_ln_s = nullptr, *attn_ln_b = nullptr;
+  const float *ffn_ln_s = nullptr, *ffn_ln_b = nullptr;
+};
+
+struct FusedEncodeArgs {
+  int B = 0, S = 0, Le = 0, Ld = 0;
+  FusedEncLayerW L[6];
+  PreparedWeight dec_k[4], dec_v[4];  // decoder cross-attention K / V projections
+  EmbedArgs emb;
+  const uint32_t *ids = nullptr;      // [B][S]
+  const uint32_t *lengths = nullptr;  // [B]
+  float alpha = 0.f, eps = 1e-6f;
+  float *kv = nullptr;         // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]
+  float *enc_out = nullptr;    // nullable [B*S][D]
+  float *layer_out = nullptr;  // nullable [Le][B*S][D]
+  float *embed_out = nullptr;  // nullable [B*S][D]
+};
+bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S);
+hipError_t launch_encode_fused(const FusedEncodeArgs &a, int D, int F, int H, hipStream_t st);
+
 hipError_t launch_layer_norm(const float *x, const float *scale, const float *bias, float eps,
                              int rows, int cols, float *y, hipStream_t st);
 hipError_t launch_softmax(const float *x, int rows, int cols, float *y, hipStream_t st);

@@ -17,6 +17,8 @@ CONFIGS = [
     ("mini", 1.0, 16, 12, 256, True),
     ("mini", 1.0, 33, 9, 1000, False),
     ("tiny11", 6.0, 16, 16, 1024, True),
+    ("tiny11", 6.0, 19, 32, 2048, True),
+    ("tiny11", 6.0, 7, 11, None, True),
     ("base", 6.0, 4, 8, 512, True),
 ]
 
@@ -43,16 +45,19 @@ def test_encoder_every_layer_bit_exact(hip, oracle, engines, preset, eos_bias, B
     m, gm, om = engines(preset, eos_bias)
     ids, lens = synth.make_batch(m.V, B, S, seed=B * 100 + S, ragged=ragged)
     ctx = hip.Context(gm, B, S)
-    enc, emb, layers = ctx.encode(ids, lens, want_embed=True, want_layers=True)
     oracle.set_mode(oracle.PORTABLE)
     mask = oracle.make_mask(lens, S)
-    x = om.embed(ids)
-    assert np.array_equal(emb, x)
+    want = [om.embed(ids)]
     for l in range(1, m.enc_layers + 1):
-        x = om.encoder_layer(l, x, mask)
-        assert np.array_equal(layers[l - 1], x), (l, np.abs(layers[l - 1] - x).max())
-    assert np.array_equal(enc, x)
+        want.append(om.encoder_layer(l, want[-1], mask))
     oracle.set_mode(oracle.FAITHFUL)
+    for mode in (0, 1):  # fused persistent encoder (when supported) / layer-by-layer kernels
+        ctx.set_decode_mode(mode)
+        enc, emb, layers = ctx.encode(ids, lens, want_embed=True, want_layers=True)
+        assert np.array_equal(emb, want[0]), mode
+        for l in range(1, m.enc_layers + 1):
+            assert np.array_equal(layers[l - 1], want[l]), (mode, l, np.abs(layers[l - 1] - want[l]).max())
+        assert np.array_equal(enc, want[-1]), mode
     ctx.close()
 
 
