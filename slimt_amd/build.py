@@ -68,5 +68,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_TEST = os.path.join(LIB_DIR, "slimt_hip_host_test")
+HOST_SOURCES = ["Io.cc", "QMM.cc", "Model.cc", "host_test.cc"]
+
+
+def build_host(force: bool = False) -> str:
+    """The C++ host mirror of the reference interface (slimt::qmm, Model/Worker)
+    + its test driver, linked against libslimt_hip.so like slimt itself would be."""
+    build()
+    srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST_DIR, h) for h in os.listdir(HOST_DIR)] + [LIB_PATH]
+    if not force and os.path.exists(HOST_TEST) and all(
+            os.path.getmtime(d) <= os.path.getmtime(HOST_TEST) for d in deps):
+        return HOST_TEST
+    rocm_lib = "/opt/rocm/lib"
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", HOST_DIR,
+           "-I", os.path.join(ROOT, "include")] + srcs + [
+        "-L", LIB_DIR, "-lslimt_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + rocm_lib,
+        "-Wl,-rpath," + rocm_lib, "-o", HOST_TEST]
+    subprocess.check_call(cmd)
+    return HOST_TEST
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv))

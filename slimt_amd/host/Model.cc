@@ -1,0 +1,87 @@
+#include "Model.hh"
+
+#include <cassert>
+#include <stdexcept>
+
+#include "Io.hh"
+
+namespace slimt {
+
+namespace {
+[[noreturn]] void raise(const char *what) {
+  throw std::runtime_error(std::string(what) + ": " + slimt_hip_last_error());
+}
+}  // namespace
+
+void Input::add(const Words &words) {
+  assert(words.size() <= sequence_length_);
+  assert(lengths_.size() < batch_size_);
+  const size_t row = lengths_.size();
+  for (size_t j = 0; j < words.size(); ++j) indices_[row * sequence_length_ + j] = words[j];
+  words_.insert(words_.end(), words.begin(), words.end());
+  lengths_.push_back(static_cast<uint32_t>(words.size()));
+}
+
+Model::Model(const Config &config, const void *model_bin, size_t size) : config_(config) {
+  std::vector<io::Item> items = io::load_items(model_bin, size);
+  std::vector<slimt_hip_param> params;
+  params.reserve(items.size());
+  for (const io::Item &it : items) {
+    if (it.type != io::ItemType::f32 && it.type != io::ItemType::ig8) continue;  // e.g. special:model.yml
+    slimt_hip_param p;
+    p.name = it.name.c_str();
+    p.type = it.type == io::ItemType::f32 ? 0 : 1;
+    p.rows = it.shape.size() >= 2 ? it.shape[it.shape.size() - 2] : 1;
+    p.cols = it.shape.empty() ? 1 : it.shape.back();
+    p.data = it.data;
+    params.push_back(p);
+  }
+  slimt_hip_dims dims;
+  dims.encoder_layers = static_cast<int32_t>(config.encoder_layers);
+  dims.decoder_layers = static_cast<int32_t>(config.decoder_layers);
+  dims.num_heads = static_cast<int32_t>(config.num_heads);
+  if (slimt_hip_model_create(params.data(), params.size(), &dims, config.device, &model_))
+    raise("slimt_hip_model_create");
+}
+
+Model::~Model() { slimt_hip_model_destroy(model_); }
+
+Worker::Worker(const Model &model, size_t max_batch, size_t max_length) : model_(model) {
+  if (slimt_hip_ctx_create(model.handle(), max_batch, max_length, nullptr, &ctx_))
+    raise("slimt_hip_ctx_create");
+}
+
+Worker::~Worker() { slimt_hip_ctx_destroy(ctx_); }
+
+Histories Worker::forward(const Input &input, const std::optional<Words> &shortlist,
+                          bool with_alignments) {
+  const size_t B = input.lengths().size(), S = input.sequence_length();
+  const size_t Tmax = static_cast<size_t>(input.limit_factor() * static_cast<float>(S));
+  const size_t T = Tmax ? Tmax : 1;
+  std::vector<uint32_t> out_ids(B * T), out_len(B);
+  std::vector<float> align(with_alignments ? B * T * S : 0);
+  const uint32_t *sl = shortlist ? shortlist->data() : nullptr;
+  const size_t n_sl = shortlist ? shortlist->size() : 0;
+  if (slimt_hip_translate(ctx_, input.indices().data(), input.lengths().data(), B, S, sl, n_sl,
+                          input.limit_factor(), model_.config().eos_id, out_ids.data(),
+                          out_len.data(), with_alignments ? align.data() : nullptr))
+    raise("slimt_hip_translate");
+  Histories histories;
+  histories.reserve(B);
+  for (size_t b = 0; b < B; ++b) {
+    auto hyp = std::make_shared<Hypothesis>();
+    const size_t n = out_len[b] < T ? out_len[b] : T;
+    hyp->target.assign(out_ids.begin() + b * T, out_ids.begin() + b * T + n);
+    if (with_alignments) {
+      const size_t len = input.lengths()[b];
+      for (size_t t = 0; t < n; ++t) {  // rows of `length` probabilities, slimt/Model.cc:95-106
+        const float *row = align.data() + (b * T + t) * S;
+        hyp->alignment.emplace_back(row, row + len);
+      }
+    }
+    histories.push_back(std::move(hyp));
+  }
+  return histories;
+}
+
+}  // namespace slimt

@@ -1,0 +1,93 @@
+// Host-side mirror of the reference's model driver for the HIP backend:
+// slimt::Input (slimt/Input.hh:10-36), slimt::Model::Config / forward
+// (slimt/Model.hh:33-56) and the Histories result types (slimt/Types.hh:34-62),
+// implemented on top of the C ABI (include/slimt_hip.h). One `Model` owns the
+// device weights; each worker thread owns one `Worker` (stream + workspace),
+// like one slimt::Async worker calling the const Model::forward
+// (slimt/Frontend.cc:212-226).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "slimt_hip.h"
+
+namespace slimt {
+
+using Word = uint32_t;
+using Words = std::vector<Word>;
+using Distribution = std::vector<float>;
+using Alignment = std::vector<Distribution>;
+
+struct Hypothesis {  // slimt/Types.hh:55-61
+  Words target;
+  Alignment alignment;
+};
+using History = std::shared_ptr<Hypothesis>;
+using Histories = std::vector<History>;
+
+// Padded batch (slimt/Input.cc:20-63): indices [B,S], lengths, limit factor.
+class Input {
+ public:
+  Input(size_t batch_size, size_t sequence_length, uint32_t pad_id, float limit_factor)
+      : batch_size_(batch_size), sequence_length_(sequence_length), pad_id_(pad_id),
+        limit_factor_(limit_factor), indices_(batch_size * sequence_length, pad_id) {}
+  void add(const Words &words);  // one sentence, EOS included
+  const std::vector<uint32_t> &indices() const { return indices_; }
+  const std::vector<uint32_t> &lengths() const { return lengths_; }
+  const Words &words() const { return words_; }
+  size_t batch_size() const { return batch_size_; }
+  size_t sequence_length() const { return sequence_length_; }
+  float limit_factor() const { return limit_factor_; }
+
+ private:
+  size_t batch_size_, sequence_length_;
+  uint32_t pad_id_;
+  float limit_factor_;
+  std::vector<uint32_t> indices_;
+  std::vector<uint32_t> lengths_;
+  Words words_;
+};
+
+class Model {
+ public:
+  struct Config {  // slimt/Model.hh:33-51 (tiny preset defaults, Model.cc:206-231)
+    size_t encoder_layers = 6;
+    size_t decoder_layers = 2;
+    size_t num_heads = 8;
+    uint32_t eos_id = 0;
+    int device = 0;
+  };
+  // `model_bin`: a Marian .bin held in memory for the duration of the call.
+  Model(const Config &config, const void *model_bin, size_t size);
+  ~Model();
+  Model(const Model &) = delete;
+  Model &operator=(const Model &) = delete;
+  slimt_hip_model *handle() const { return model_; }
+  const Config &config() const { return config_; }
+
+ private:
+  Config config_;
+  slimt_hip_model *model_ = nullptr;
+};
+
+class Worker {
+ public:
+  Worker(const Model &model, size_t max_batch, size_t max_length);
+  ~Worker();
+  Worker(const Worker &) = delete;
+  Worker &operator=(const Worker &) = delete;
+  // Model::forward (slimt/Model.cc:187-204): shortlist = sorted target ids of
+  // the batch (slimt/Model.cc:117-120) or nullopt for the full vocabulary.
+  Histories forward(const Input &input, const std::optional<Words> &shortlist = std::nullopt,
+                    bool with_alignments = true);
+
+ private:
+  const Model &model_;
+  slimt_hip_ctx *ctx_ = nullptr;
+};
+
+}  // namespace slimt
