@@ -170,16 +170,8 @@ def main():
             prof[k] += r[k]
         c.profile_enable(capi.K_NONE)
 
-    dt_max = dt
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_max = float(t.item())
-        tk = torch.tensor([tokens_per_step], dtype=torch.int64, device=dev)
-        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
-        total_tokens_per_step = int(tk.item())
-    else:
-        total_tokens_per_step = tokens_per_step
+    from slimt_amd.sharding import reduce_timing
+    dt_max, total_tokens_per_step = reduce_timing(dist, dev, dt, tokens_per_step)
 
     per_kernel = None
     if args.all_kernels and rank == 0:
