@@ -59,7 +59,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + [
+    extra = os.environ.get("SLIMT_HIPCC_EXTRA", "").split()  # experiments only
+    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + [
         "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH,
     ]
     if verbose:

@@ -45,16 +45,65 @@ __device__ __forceinline__ float sigmoid_p(float x) {
   return e / (1.0f + e);
 }
 
+// Value of lane (l ^ M). Pure data movement, so any mechanism gives the same
+// bits; the cheap ones are used: DPP quad permutes for M = 1, 2 (no LDS
+// crossbar trip), ds_swizzle bit-mask mode for M = 4, 8, 16 (no address VGPR),
+// ds_bpermute only for M = 32.
+template <int M>
+__device__ __forceinline__ float lane_xor(float v) {
+  const int i = __float_as_int(v);
+#ifdef SLIMT_REDUCE_BPERMUTE
+  (void)i;
+  return __shfl_xor(v, M, 64);
+#endif
+  if constexpr (M == 1) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, false));  // [1,0,3,2]
+  } else if constexpr (M == 2) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, false));  // [2,3,0,1]
+  } else if constexpr (M == 4 || M == 8 || M == 16) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(i, (M << 10) | 0x1f));
+  } else {
+    return __shfl_xor(v, M, 64);
+  }
+}
+
 // xor butterfly over the 64 lanes, masks ascending; all lanes end equal.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+  v = v + lane_xor<1>(v);
+  v = v + lane_xor<2>(v);
+  v = v + lane_xor<4>(v);
+  v = v + lane_xor<8>(v);
+  v = v + lane_xor<16>(v);
+  v = v + lane_xor<32>(v);
   return v;
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  v = fmaxf(v, lane_xor<1>(v));
+  v = fmaxf(v, lane_xor<2>(v));
+  v = fmaxf(v, lane_xor<4>(v));
+  v = fmaxf(v, lane_xor<8>(v));
+  v = fmaxf(v, lane_xor<16>(v));
+  v = fmaxf(v, lane_xor<32>(v));
+  return v;
+}
+
+// the same butterflies restricted to each 32-lane half (masks 1..16)
+__device__ __forceinline__ float half_sum(float v) {
+  v = v + lane_xor<1>(v);
+  v = v + lane_xor<2>(v);
+  v = v + lane_xor<4>(v);
+  v = v + lane_xor<8>(v);
+  v = v + lane_xor<16>(v);
+  return v;
+}
+
+__device__ __forceinline__ float half_max(float v) {
+  v = fmaxf(v, lane_xor<1>(v));
+  v = fmaxf(v, lane_xor<2>(v));
+  v = fmaxf(v, lane_xor<4>(v));
+  v = fmaxf(v, lane_xor<8>(v));
+  v = fmaxf(v, lane_xor<16>(v));
   return v;
 }
 

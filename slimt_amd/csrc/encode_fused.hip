@@ -80,6 +80,13 @@ __device__ __forceinline__ void eln_row(float *x, const float *scale, const floa
 
 }  // namespace
 
+// Diagnostic phase stamps (100 MHz wall clock) of workgroup 0 in one layer.
+#define SLIMT_ESTAMP(id)                                                              \
+  do {                                                                                \
+    if (a.stamps && blockIdx.x == 0 && tid == 0 && l == a.stamp_layer)                \
+      a.stamps[(id)] = wall_clock64();                                                \
+  } while (0)
+
 template <int KSD, int KSF, int DH>
 __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,6 +109,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   float *qb = reinterpret_cast<float *>(Av + ER * LDA);
   float *kb = qb + ER * LDQ;
   float *vb = kb + ER * LDQ;
+  float *pbufs = vb + ER * LDQ;  // [ENW][64] attention scratch (16-byte aligned: see lds bytes)
 
   // row r of this workgroup: sentence s0 + r / S, position r % S
   auto row_sentence = [&](int r) { return s0 + r / S; };
@@ -128,7 +136,14 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
 
   for (int l = 0; l < a.Le; ++l) {
     const FusedEncLayerW &L = a.L[l];
+    SLIMT_ESTAMP(0);
     // ---- Attention::forward (Modules.cc:287-319) ---------------------------
+    // the weight fragments of this wave's Q/K/V column tile do not depend on
+    // the activations: issue them first, quantise x underneath
+    v4i bq[KSD], bk[KSD], bv[KSD];
+    load_frags<KSD>(bq, L.q, wave, 0, lane);
+    load_frags<KSD>(bk, L.k, wave, 0, lane);
+    load_frags<KSD>(bv, L.v, wave, 0, lane);
     for (int r = wave; r < ER; r += ENW) {
 #pragma unroll
       for (int i = 0; i < KSD; ++i) {
@@ -139,11 +154,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       }
     }
     __syncthreads();
+    SLIMT_ESTAMP(1);
     {  // Q, K, V projections: wave = column tile of each
-      v4i bq[KSD], bk[KSD], bv[KSD];
-      load_frags<KSD>(bq, L.q, wave, 0, lane);
-      load_frags<KSD>(bk, L.k, wave, 0, lane);
-      load_frags<KSD>(bv, L.v, wave, 0, lane);
       const int col = wave * 16 + lr;
       {
         v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
@@ -180,12 +192,14 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       }
     }
     __syncthreads();
+    SLIMT_ESTAMP(2);
     // scaled_dot_product_attention (Modules.cc:24-86): wave = (head, query
     // parity); two queries per pass (lane half = query), keys/values of the
     // sentence held in registers. Output quantised for the O projection into
     // Aq (dead since the projections).
     {
       const int h = wave % H, par = wave / H;  // ENW == 2 * H for the supported shapes
+      float *pw = pbufs + wave * 64;
       const int half = lane >> 5, j = lane & 31;
       const float minus_inf = -99999999.0f;  // Input.cc:56-61
       const float lowest = -3.402823466e+38f;
@@ -213,19 +227,20 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
           if (a.alpha != 1.0f) s = a.alpha * s;
           s = s + mask;
           if (j >= S) s = lowest;
-          float m = s;
-#pragma unroll
-          for (int x = 1; x < 32; x <<= 1) m = fmaxf(m, __shfl_xor(m, x, 64));
+          const float m = half_max(s);
           const float e = j < S ? exp_p(s - m) : 0.0f;
-          float sum = e;  // canonical order: masks 1..16; the mask-32 step would add +0
-#pragma unroll
-          for (int x = 1; x < 32; x <<= 1) sum = sum + __shfl_xor(sum, x, 64);
+          const float sum = half_sum(e);  // canonical order: masks 1..16; the mask-32 step would add +0
           const float p = e / sum;  // keys >= S: exactly 0
+          // broadcast this half's probabilities through the wave's LDS scratch
+          pw[lane] = p;
           float o = 0.0f;
 #pragma unroll
-          for (int jj = 0; jj < 32; ++jj) {  // keys >= S contribute fma(0, v, o) == o
-            const float pj = __shfl(p, (lane & 32) | jj, 64);
-            o = __builtin_fmaf(pj, vreg[jj], o);
+          for (int i = 0; i < 8; ++i) {  // keys >= S contribute fma(0, v, o) == o
+            const f4 p4 = *reinterpret_cast<const f4 *>(pw + (lane & 32) + 4 * i);
+            o = __builtin_fmaf(p4.x, vreg[4 * i + 0], o);
+            o = __builtin_fmaf(p4.y, vreg[4 * i + 1], o);
+            o = __builtin_fmaf(p4.z, vreg[4 * i + 2], o);
+            o = __builtin_fmaf(p4.w, vreg[4 * i + 3], o);
           }
           if (qi < S && j < DH) Aq[(base + qi) * LDA + h * DH + j] = (char)quantize1(o, L.o.a_quant);
         }
@@ -236,6 +251,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
 #pragma unroll
       for (int i = 0; i < KSD; ++i) Aq[r * LDA + lane + 64 * i] = 0;
     __syncthreads();
+    SLIMT_ESTAMP(3);
     {  // O projection + residual: x = x + yo (Modules.cc:308-314)
       v4i bo[KSD];
       load_frags<KSD>(bo, L.o, wave, 0, lane);
@@ -253,6 +269,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       }
     }
     __syncthreads();
+    SLIMT_ESTAMP(4);
     for (int r = wave; r < ER; r += ENW) {
       eln_row<KSD>(xs + r * LDX, L.attn_ln_s, L.attn_ln_b, a.eps, lane);
 #pragma unroll
@@ -260,17 +277,20 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         Aq[r * LDA + lane + 64 * i] = (char)quantize1(xs[r * LDX + lane + 64 * i], L.ffn1.a_quant);
     }
     __syncthreads();
+    SLIMT_ESTAMP(5);
     // ---- FFN (Modules.cc:326-331): F is walked in chunks of 256 columns; the
     // FFN2 accumulators of this wave's column tile stay in registers.
     {
       v4i f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
+      v4i b1[KSD], b2[4];
+      load_frags<KSD>(b1, L.ffn1, wave, 0, lane);
+      load_frags<4>(b2, L.ffn2, wave, 0, lane);
       for (int fc = 0; fc < KSF / 4; ++fc) {
-        v4i b1[KSD], b2[4];
         const int t1 = fc * 16 + wave;  // FFN1 column tile of this chunk
-        load_frags<KSD>(b1, L.ffn1, t1, 0, lane);
-        load_frags<4>(b2, L.ffn2, wave, fc * 4, lane);
         v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
         tile_mma2<KSD>(Aq, LDA, b1, lr, lg, c0, c1);
+        // b1 is consumed: fetch the next chunk's fragments into the same registers
+        if (fc + 1 < KSF / 4) load_frags<KSD>(b1, L.ffn1, t1 + 16, 0, lane);
         const int col1 = t1 * 16 + lr;
         const int cs = L.ffn1.colsum[col1];
         const float pb = L.ffn1.pb[col1];
@@ -285,6 +305,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         }
         __syncthreads();
         tile_mma2<4>(Ak, LDA, b2, lr, lg, f0, f1);
+        if (fc + 1 < KSF / 4) load_frags<4>(b2, L.ffn2, wave, (fc + 1) * 4, lane);
         __syncthreads();
       }
       const int col = wave * 16 + lr;
@@ -299,6 +320,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       }
     }
     __syncthreads();
+    SLIMT_ESTAMP(6);
     for (int r = wave; r < ER; r += ENW) {
       eln_row<KSD>(xs + r * LDX, L.ffn_ln_s, L.ffn_ln_b, a.eps, lane);
       if (a.layer_out && row_valid(r)) {
@@ -308,6 +330,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       }
     }
     __syncthreads();
+    SLIMT_ESTAMP(7);
   }
 
   // ---- encoder output + decoder cross-attention K/V (Modules.cc:248-249,
@@ -373,7 +396,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
 }
 
 size_t fused_encode_lds_bytes(int D) {
-  return (size_t)ER * (D + 4) * 4 + 3 * (size_t)ER * (D + 16) + 3 * (size_t)ER * (D + 1) * 4;
+  return (size_t)ER * (D + 4) * 4 + 3 * (size_t)ER * (D + 16) + 3 * (size_t)ER * (D + 1) * 4 +
+         (size_t)ENW * 64 * 4;
 }
 
 bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S) {

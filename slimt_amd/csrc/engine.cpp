@@ -798,6 +798,10 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       HIPCHK(c->dbg_layers.reserve(nbytes * (size_t)m->Le));
       f.layer_out = c->dbg_layers.as<float>();
     }
+    if (c->stamp_step >= 0 && c->stamps.p) {  // encoder stamps live in slots 48..55
+      f.stamps = c->stamps.as<unsigned long long>() + 48;
+      f.stamp_layer = c->stamp_step < m->Le ? c->stamp_step : m->Le - 1;
+    }
     {
       const double macs = (double)M * (m->Le * (4.0 * D * D + 2.0 * D * m->F) + m->Ld * 2.0 * D * D);
       ProfScope p(c, SLIMT_HIP_K_ENCODE_FUSED, macs, 0);

@@ -245,6 +245,8 @@ struct FusedEncodeArgs {
   float *enc_out = nullptr;    // nullable [B*S][D]
   float *layer_out = nullptr;  // nullable [Le][B*S][D]
   float *embed_out = nullptr;  // nullable [B*S][D]
+  unsigned long long *stamps = nullptr;  // nullable diagnostic phase stamps
+  int stamp_layer = 0;
 };
 bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S);
 hipError_t launch_encode_fused(const FusedEncodeArgs &a, int D, int F, int H, hipStream_t st);

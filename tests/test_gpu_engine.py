@@ -162,33 +162,39 @@ def test_decode_invariants_at_bench_size(hip, engines):
 def test_concurrent_contexts_share_one_model(hip, oracle, engines):
     """slimt::Async semantics (Frontend.cc:212-226): several workers call the
     re-entrant forward concurrently on one shared model. Each worker = one
-    context (stream + workspace); results must be identical to serial runs."""
+    context (stream + workspace); every result must equal the oracle's."""
     import threading
     from slimt_amd import synth
     m, gm, om = engines("tiny11", 6.0)
     B, S, W = 48, 24, 6
     sl = synth.make_shortlist(m.V, 2048)
     jobs = [synth.make_batch(m.V, B, S, seed=1000 + i, ragged=True) for i in range(W)]
+    oracle.set_mode(oracle.PORTABLE)
+    want = [om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3] for ids, lens in jobs]
+    oracle.set_mode(oracle.FAITHFUL)
     ctxs = [hip.Context(gm, B, S) for _ in range(W)]
-    serial = [ctxs[0].translate(ids, lens, sl, want_align=True) for ids, lens in jobs]
-    results = [None] * W
+    problems = []
+
+    def check(tag, i, got):
+        out, ln, al = got
+        if not (np.array_equal(out, want[i][0]) and np.array_equal(ln, want[i][1])
+                and np.array_equal(al, want[i][2])):
+            rows = np.nonzero((out != want[i][0]).any(axis=1) | (ln != want[i][1]))[0]
+            first = [int(np.argmax(out[r] != want[i][0][r])) for r in rows]
+            problems.append((tag, i, rows.tolist(), first))
+
+    for i, (ids, lens) in enumerate(jobs):  # serial, all on context 0 (first calls)
+        check("serial", i, ctxs[0].translate(ids, lens, sl, want_align=True))
 
     def work(i):
-        for _ in range(3):
-            results[i] = ctxs[i].translate(jobs[i][0], jobs[i][1], sl, want_align=True)
+        for it in range(3):
+            check(f"concurrent#{it}", i, ctxs[i].translate(jobs[i][0], jobs[i][1], sl, want_align=True))
 
     threads = [threading.Thread(target=work, args=(i,)) for i in range(W)]
     for t in threads:
         t.start()
     for t in threads:
         t.join()
-    for i in range(W):
-        for a, b in zip(results[i], serial[i]):
-            assert np.array_equal(a, b), i
-    oracle.set_mode(oracle.PORTABLE)
-    w_out, w_ln, w_al, _ = om.translate(jobs[2][0], jobs[2][1], sl, 1.5, 0, want_align=True)
-    oracle.set_mode(oracle.FAITHFUL)
-    assert np.array_equal(results[2][0], w_out) and np.array_equal(results[2][1], w_ln)
-    assert np.array_equal(results[2][2], w_al)
     for c in ctxs:
         c.close()
+    assert not problems, problems

@@ -23,3 +23,11 @@ for step in (5, 20):
     print(f"--- B={B} step {step}: total {(t[-1]-t[0])/100:.1f} us")
     for i in range(1, len(idx)):
         print(f"  {names[i]:22s} {(t[i]-t[i-1])/100:7.2f} us")
+
+ctx.debug_decode_stamps(2)
+ctx.translate(ids, lens, sl)
+st = ctx.debug_decode_stamps(-1).astype(np.int64)[48:56]
+en = ["quantise", "qkv_gemm", "attention", "o_gemm", "ln+quant", "ffn", "ln"]
+print(f"--- encoder layer 2 (workgroup 0): total {(st[7]-st[0])/100:.1f} us")
+for i in range(7):
+    print(f"  {en[i]:22s} {(st[i+1]-st[i])/100:7.2f} us")
