@@ -549,6 +549,8 @@ struct so_model {
   float *kv_cache;
   size_t kv_B, kv_S;
   const float *kv_src;
+  float kv_probe[4]; /* first/last values of the cached encoder_out: a recycled
+                        pointer with different contents must not hit the cache */
 };
 
 static const so_param *find_param(const so_param *p, size_t n, const char *name) {
@@ -868,7 +870,10 @@ static const float *kv_for(const so_model *m_, int layer, int which,
   so_model *m = (so_model *)m_;
   size_t D = (size_t)m->D, H = (size_t)m->H, dh = D / H;
   size_t per = B * S * D;
-  if (m->kv_src != encoder_out || m->kv_B != B || m->kv_S != S || !m->kv_cache) {
+  const float probe[4] = {encoder_out[0], encoder_out[per / 2], encoder_out[per - 1],
+                          encoder_out[per / 3]};
+  if (m->kv_src != encoder_out || m->kv_B != B || m->kv_S != S || !m->kv_cache ||
+      memcmp(probe, m->kv_probe, sizeof probe) != 0) {
     free(m->kv_cache);
     m->kv_cache = (float *)malloc(per * 2 * (size_t)m->Ld * sizeof(float));
     float *tmp = (float *)malloc(per * sizeof(float));
@@ -882,6 +887,7 @@ static const float *kv_for(const so_model *m_, int layer, int which,
     m->kv_src = encoder_out;
     m->kv_B = B;
     m->kv_S = S;
+    memcpy(m->kv_probe, probe, sizeof probe);
   }
   return m->kv_cache + (size_t)(2 * layer + which) * per;
 }
@@ -952,6 +958,7 @@ size_t so_translate(const so_model *m, const uint32_t *src_ids,
                     uint32_t *out_len, float *align) {
   size_t D = (size_t)m->D, H = (size_t)m->H;
   size_t N = shortlist ? n_sl : (size_t)m->V;
+  ((so_model *)m)->kv_src = NULL; /* new batch: the cross-attention K/V cache is stale */
   float *mask = (float *)malloc(B * S * sizeof(float));
   so_make_mask(lengths, B, S, mask);
   float *emb = (float *)malloc(B * S * D * sizeof(float));

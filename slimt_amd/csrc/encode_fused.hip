@@ -93,7 +93,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   constexpr int D = 64 * KSD, H = D / DH;
   constexpr int LDX = D + 4;   // f32 residual rows
   constexpr int LDA = D + 16;  // int8 A rows
-  constexpr int LDQ = D + 1;   // f32 q/k/v rows (odd stride: row-per-lane reads are conflict-free)
+  constexpr int LDQ = D + 1;   // f32 k/v rows (odd stride: row-per-lane reads are conflict-free)
+  constexpr int LDQQ = D + 4;  // f32 q rows (16-byte aligned: read as b128 broadcasts)
   static_assert(D / 16 == ENW, "one 16-column tile of a D-wide GEMM per wave");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   char *Ak = Aq + ER * LDA;
   char *Av = Ak + ER * LDA;
   float *qb = reinterpret_cast<float *>(Av + ER * LDA);
-  float *kb = qb + ER * LDQ;
+  float *kb = qb + ER * LDQQ;
   float *vb = kb + ER * LDQ;
   float *pbufs = vb + ER * LDQ;  // [ENW][64] attention scratch (16-byte aligned: see lds bytes)
 
@@ -164,8 +165,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         const float pb = L.q.pb[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          qb[(lg * 4 + r) * LDQ + col] = edequant(c0[r], cs, L.q.u, pb);
-          qb[(16 + lg * 4 + r) * LDQ + col] = edequant(c1[r], cs, L.q.u, pb);
+          qb[(lg * 4 + r) * LDQQ + col] = edequant(c0[r], cs, L.q.u, pb);
+          qb[(16 + lg * 4 + r) * LDQQ + col] = edequant(c1[r], cs, L.q.u, pb);
         }
       }
       {
@@ -220,10 +221,16 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         for (int i0 = par * 2; i0 < S; i0 += 4) {
           const int qi = i0 + half;
           const int qic = qi < S ? qi : S - 1;
-          const float *qrow = qb + (base + qic) * LDQ + h * DH;
+          const float *qrow = qb + (base + qic) * LDQQ + h * DH;
           float s = 0.0f;
 #pragma unroll
-          for (int k = 0; k < DH; ++k) s = __builtin_fmaf(qrow[k], kreg[k], s);
+          for (int k = 0; k < DH / 4; ++k) {
+            const f4 q4 = *reinterpret_cast<const f4 *>(qrow + 4 * k);
+            s = __builtin_fmaf(q4.x, kreg[4 * k + 0], s);
+            s = __builtin_fmaf(q4.y, kreg[4 * k + 1], s);
+            s = __builtin_fmaf(q4.z, kreg[4 * k + 2], s);
+            s = __builtin_fmaf(q4.w, kreg[4 * k + 3], s);
+          }
           if (a.alpha != 1.0f) s = a.alpha * s;
           s = s + mask;
           if (j >= S) s = lowest;
@@ -283,14 +290,14 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     {
       v4i f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
       v4i b1[KSD], b2[4];
-      load_frags<KSD>(b1, L.ffn1, wave, 0, lane);
-      load_frags<4>(b2, L.ffn2, wave, 0, lane);
-      for (int fc = 0; fc < KSF / 4; ++fc) {
-        const int t1 = fc * 16 + wave;  // FFN1 column tile of this chunk
+      constexpr int NC = KSF / 4;  // chunks of 256 hidden columns
+      // FFN1 of one chunk: this wave's column tile -> relu -> requantise -> hidden buffer
+      auto ffn1_chunk = [&](int fc, char *Hbuf) {
+        const int t1 = fc * 16 + wave;
         v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
         tile_mma2<KSD>(Aq, LDA, b1, lr, lg, c0, c1);
         // b1 is consumed: fetch the next chunk's fragments into the same registers
-        if (fc + 1 < KSF / 4) load_frags<KSD>(b1, L.ffn1, t1 + 16, 0, lane);
+        if (fc + 1 < NC) load_frags<KSD>(b1, L.ffn1, t1 + 16, 0, lane);
         const int col1 = t1 * 16 + lr;
         const int cs = L.ffn1.colsum[col1];
         const float pb = L.ffn1.pb[col1];
@@ -300,12 +307,20 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
           float v1 = edequant(c1[r], cs, L.ffn1.u, pb);
           v0 = v0 > 0.0f ? v0 : 0.0f;
           v1 = v1 > 0.0f ? v1 : 0.0f;
-          Ak[(lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v0, L.ffn2.a_quant);
-          Ak[(16 + lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v1, L.ffn2.a_quant);
+          Hbuf[(lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v0, L.ffn2.a_quant);
+          Hbuf[(16 + lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v1, L.ffn2.a_quant);
         }
-        __syncthreads();
-        tile_mma2<4>(Ak, LDA, b2, lr, lg, f0, f1);
-        if (fc + 1 < KSF / 4) load_frags<4>(b2, L.ffn2, wave, (fc + 1) * 4, lane);
+      };
+      load_frags<KSD>(b1, L.ffn1, wave, 0, lane);
+      load_frags<4>(b2, L.ffn2, wave, 0, lane);
+      ffn1_chunk(0, Ak);
+      __syncthreads();
+      for (int fc = 0; fc < NC; ++fc) {
+        char *Hcur = (fc & 1) ? Av : Ak;
+        char *Hnext = (fc & 1) ? Ak : Av;
+        if (fc + 1 < NC) ffn1_chunk(fc + 1, Hnext);
+        tile_mma2<4>(Hcur, LDA, b2, lr, lg, f0, f1);
+        if (fc + 1 < NC) load_frags<4>(b2, L.ffn2, wave, (fc + 1) * 4, lane);
         __syncthreads();
       }
       const int col = wave * 16 + lr;
@@ -396,8 +411,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
 }
 
 size_t fused_encode_lds_bytes(int D) {
-  return (size_t)ER * (D + 4) * 4 + 3 * (size_t)ER * (D + 16) + 3 * (size_t)ER * (D + 1) * 4 +
-         (size_t)ENW * 64 * 4;
+  return (size_t)ER * (D + 4) * 4 + 3 * (size_t)ER * (D + 16) + (size_t)ER * (D + 4) * 4 +
+         2 * (size_t)ER * (D + 1) * 4 + (size_t)ENW * 64 * 4;
 }
 
 bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S) {

@@ -273,3 +273,21 @@ def test_faithful_vs_portable_model_level(oracle, synth_models):
         row_ok = d.max(axis=1) <= 1e-4 * max(1.0, float(np.abs(a).max()))
         assert row_ok.mean() >= 0.9, row_ok.mean()
         assert d.max() < 0.1
+
+
+def test_oracle_model_is_stateless_across_batches(oracle, synth_models):
+    """Regression: the oracle's per-batch cross-attention K/V cache was keyed
+    on the encoder-output pointer only; a recycled malloc pointer made a second
+    translate() with different input reuse the first batch's K/V."""
+    from slimt_amd import synth
+    m = synth_models("micro", eos_bias=3.0)
+    shared = oracle.OracleModel(m)
+    oracle.set_mode(oracle.PORTABLE)
+    sl = synth.make_shortlist(m.V, 128)
+    for seed in (1, 2, 3, 1):
+        ids, lens = synth.make_batch(m.V, 6, 8, seed=seed, ragged=True)
+        got = shared.translate(ids, lens, sl, want_align=True)
+        fresh = oracle.OracleModel(m).translate(ids, lens, sl, want_align=True)
+        for a, b in zip(got[:3], fresh[:3]):
+            assert np.array_equal(a, b), seed
+    oracle.set_mode(oracle.FAITHFUL)
