@@ -1,0 +1,38 @@
+"""GPU box diagnostic: many different batches, concurrent contexts, every
+result compared with the CPU oracle (PORTABLE order)."""
+import os, sys, threading
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import oracle as O
+from slimt_amd import capi, synth
+
+preset = sys.argv[1] if len(sys.argv) > 1 else "tiny11"
+n_jobs = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+m = synth.make_model(preset, eos_bias=6.0)
+gm = capi.Model(m)
+om = O.OracleModel(m)
+B, S = 32, 20
+sl = synth.make_shortlist(m.V, 1024)
+jobs = [synth.make_batch(m.V, B, S, seed=5000 + i, ragged=True) for i in range(n_jobs)]
+O.set_mode(O.PORTABLE)
+want = [om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3] for ids, lens in jobs]
+ctxs = [capi.Context(gm, B, S) for _ in range(W)]
+bad = []
+lock = threading.Lock()
+
+def work(w):
+    for rep in range(3):
+        for i in range(w, n_jobs, W):
+            got = ctxs[w].translate(jobs[i][0], jobs[i][1], sl, want_align=True)
+            if not all(np.array_equal(a, b) for a, b in zip(got, want[i])):
+                rows = np.nonzero((got[0] != want[i][0]).any(axis=1))[0]
+                with lock:
+                    bad.append((w, rep, i, rows.tolist()[:8]))
+
+ts = [threading.Thread(target=work, args=(w,)) for w in range(W)]
+[t.start() for t in ts]
+[t.join() for t in ts]
+print(f"{preset}: {len(bad)} mismatches vs oracle in {3 * n_jobs} translates on {W} concurrent contexts")
+for b in bad[:10]:
+    print("  ", b)
