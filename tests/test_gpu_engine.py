@@ -19,6 +19,10 @@ CONFIGS = [
     ("tiny11", 6.0, 16, 16, 1024, True),
     ("tiny11", 6.0, 19, 32, 2048, True),
     ("tiny11", 6.0, 7, 11, None, True),
+    ("tiny11", 6.0, 5, 40, 1024, True),    # S > 32: layer-by-layer encoder, generic decoder attention
+    ("tiny11", 6.0, 3, 70, 512, True),     # S > 64: two key slots per lane
+    ("tiny11", 6.0, 2, 128, 512, True),    # the reference's wrap length (Frontend.hh:27)
+    ("mini", 1.0, 4, 100, 256, True),
     ("base", 6.0, 4, 8, 512, True),
 ]
 
