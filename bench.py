@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--profile-kernel", default="auto",
                     help="kernel family bracketed by HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sentences", type=int, default=16)
+    ap.add_argument("--cpu-sentences", type=int, default=128)
     ap.add_argument("--workers", type=int, default=16,
                     help="translate contexts (HIP streams) per GPU, like slimt::Async workers "
                          "(Frontend.cc:212-226): independent batches in flight on one device")
@@ -152,7 +152,8 @@ def main():
     kmap = {"gemm_enc": capi.K_GEMM_ENC, "gemm_dec": capi.K_GEMM_DEC, "logits": capi.K_LOGITS,
             "attn_enc": capi.K_ATTN_ENC, "attn_dec": capi.K_ATTN_DEC, "ssru": capi.K_SSRU,
             "decode_fused": capi.K_DECODE_FUSED, "encode_fused": capi.K_ENCODE_FUSED}
-    auto_kernel = "decode_fused" if args.decode_mode == 0 else "gemm_dec"
+    enc_fused, dec_fused = ctx.plan(S)
+    auto_kernel = "decode_fused" if dec_fused else "gemm_dec"
     prof_name = auto_kernel if args.profile_kernel == "auto" else args.profile_kernel
     for c in ctxs:
         c.profile_enable(kmap.get(prof_name, capi.K_NONE))
@@ -206,7 +207,8 @@ def main():
                             f"{'shortlist ' + str(n_sl) if n_sl else 'full 32k vocabulary'}",
                 "preset": args.preset, "batch_per_gpu": B, "src_len": S, "decode_steps": T,
                 "shortlist": n_sl, "parallelism": f"dp{world} (replicated weights, no collective)",
-                "workers_per_gpu": W, "decode": "fused-persistent" if args.decode_mode == 0 else "step-wise",
+                "workers_per_gpu": W, "decode": "fused-persistent" if dec_fused else "step-wise",
+                "encode": "fused-persistent" if enc_fused else "layer-by-layer",
                 "tokens_per_step_all_gpus": total_tokens_per_step,
                 "int8_ops_per_token": 2.0 * macs_sentence / T,
                 "whole_job_int8_tops": 2.0 * macs_sentence * B * world * args.steps / dt_max / 1e12,

@@ -131,6 +131,11 @@ int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
  * them), 1 = one launch per stage (and per decode step; the kernels behind
  * slimt_hip_decode_step). Same results either way. */
 int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode);
+/* Which kernels a translate call with source length S would use in the current
+ * mode: *encoder_fused / *decoder_fused = 1 for the persistent kernels, 0 for
+ * the per-stage ones. */
+int slimt_hip_ctx_plan(const slimt_hip_ctx *ctx, size_t S, int *encoder_fused,
+                       int *decoder_fused);
 
 /* Model::forward (Model.cc:187-204) = embed + Encoder::forward + the greedy
  * loop of Model::decode (Model.cc:111-185). Host buffers.

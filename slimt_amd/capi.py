@@ -22,7 +22,7 @@ SYMBOLS = [
     "slimt_hip_softmax", "slimt_hip_highway", "slimt_hip_sdpa",
     "slimt_hip_model_create", "slimt_hip_model_destroy", "slimt_hip_model_info",
     "slimt_hip_ctx_create", "slimt_hip_ctx_destroy", "slimt_hip_ctx_stream",
-    "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_translate", "slimt_hip_translate_device",
+    "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_ctx_plan", "slimt_hip_translate", "slimt_hip_translate_device",
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
     "slimt_hip_debug_decode_stamps",
@@ -87,6 +87,7 @@ def lib():
     L.slimt_hip_ctx_stream.argtypes = [vp, vp]
     L.slimt_hip_ctx_synchronize.argtypes = [vp]
     L.slimt_hip_ctx_set_decode_mode.argtypes = [vp, i32]
+    L.slimt_hip_ctx_plan.argtypes = [vp, sz, vp, vp]
     L.slimt_hip_translate.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp]
     L.slimt_hip_translate_device.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp, i32]
     L.slimt_hip_encode.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp]
@@ -284,6 +285,12 @@ class Context:
     def set_decode_mode(self, mode: int):
         """0 = auto (persistent fused decoder when supported), 1 = step-wise launches."""
         _chk(lib().slimt_hip_ctx_set_decode_mode(self.h, mode))
+
+    def plan(self, S: int):
+        """(encoder_fused, decoder_fused) for source length S in the current mode."""
+        e, d = C.c_int(0), C.c_int(0)
+        _chk(lib().slimt_hip_ctx_plan(self.h, S, C.byref(e), C.byref(d)))
+        return bool(e.value), bool(d.value)
 
     def translate(self, ids, lengths, shortlist=None, limit_factor: float = 1.5, eos_id: int = 0,
                   want_align: bool = False):

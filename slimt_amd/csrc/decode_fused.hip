@@ -28,6 +28,11 @@ constexpr int CH = 4;    // weight fragments per prefetch chunk (per wave)
 
 struct Frags {
   v4i f[CH];
+  // epilogue constants of the chunk's tiles (this lane's column), fetched with
+  // the fragments: loading them inside the epilogue costs one exposed memory
+  // round trip per tile (measured: 16 of the 20 us of the logits phase)
+  int cs[CH];
+  float pb[CH];
 };
 
 // y = float(acc + 127 colsum) * u + pb   (Intgemm.inl.cc:146-153)
@@ -65,6 +70,8 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
           if (i < ntw) t = Wp[((size_t)tile * KS + ks) * 64 + lane];
           bb.f[j * KS + ks] = t;
         }
+        bb.cs[j] = i < ntw ? w.colsum[tile * 16 + lr] : 0;
+        bb.pb[j] = i < ntw ? w.pb[tile * 16 + lr] : 0.0f;
       }
     };
     auto compute = [&](const Frags &bb, int c) {
@@ -76,7 +83,7 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
             acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ks], bb.f[j * KS + ks], acc, 0, 0, 0);
-          epi(wave + NW * i, acc);
+          epi(wave + NW * i, acc, bb.cs[j], bb.pb[j]);
         }
       }
     };
@@ -101,6 +108,8 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       const int ks0 = (c % CPT) * CH;
 #pragma unroll
       for (int p = 0; p < CH; ++p) bb.f[p] = Wp[((size_t)tile * KS + ks0 + p) * 64 + lane];
+      bb.cs[0] = w.colsum[tile * 16 + lr];
+      bb.pb[0] = w.pb[tile * 16 + lr];
     };
     v4i acc = {0, 0, 0, 0};
     auto compute = [&](const Frags &bb, int c) {
@@ -111,7 +120,7 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bb.f[p], acc, 0, 0, 0);
       }
       if ((c % CPT) == CPT - 1) {
-        epi(wave + NW * (c / CPT), acc);
+        epi(wave + NW * (c / CPT), acc, bb.cs[0], bb.pb[0]);
         acc = v4i{0, 0, 0, 0};
       }
     };
@@ -415,10 +424,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       SLIMT_STAMP(sb + 2);
       // ---- cross-attention (Modules.cc:287-319) --------------------------
       // Q projection -> xs (x is dead until the end of the layer)
-      stream_gemm<KSD, 1>(A1, LDA, L.q, wave, lane, [&](int tile, const v4i &acc) {
+      stream_gemm<KSD, 1>(A1, LDA, L.q, wave, lane, [&](int tile, const v4i &acc, int cq, float pb) {
         const int col = tile * 16 + lr;
-        const int cq = L.q.colsum[col];
-        const float pb = L.q.pb[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) xs[(lg * 4 + r) * LDF + col] = dequant(acc[r], cq, L.q.u, pb);
       });
@@ -447,10 +454,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       __syncthreads();
       SLIMT_STAMP(sb + 4);
       // O projection + residual h (Modules.cc:308-314)
-      stream_gemm<KSD, 1>(A1, LDA, L.o, wave, lane, [&](int tile, const v4i &acc) {
+      stream_gemm<KSD, 1>(A1, LDA, L.o, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
         const int col = tile * 16 + lr;
-        const int co = L.o.colsum[col];
-        const float pb = L.o.pb[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rl = lg * 4 + r;
@@ -465,10 +470,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       __syncthreads();
       SLIMT_STAMP(sb + 6);
       // ---- FFN (Modules.cc:251-257) ----------------------------------------
-      stream_gemm<KSD, 2>(A1, LDA, L.ffn1, wave, lane, [&](int tile, const v4i &acc) {
+      stream_gemm<KSD, 2>(A1, LDA, L.ffn1, wave, lane, [&](int tile, const v4i &acc, int c1, float pb) {
         const int col = tile * 16 + lr;
-        const int c1 = L.ffn1.colsum[col];
-        const float pb = L.ffn1.pb[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = dequant(acc[r], c1, L.ffn1.u, pb);
@@ -478,10 +481,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       });
       __syncthreads();
       SLIMT_STAMP(sb + 7);
-      stream_gemm<KSF, 2>(A3, LDA3, L.ffn2, wave, lane, [&](int tile, const v4i &acc) {
+      stream_gemm<KSF, 2>(A3, LDA3, L.ffn2, wave, lane, [&](int tile, const v4i &acc, int c2, float pb) {
         const int col = tile * 16 + lr;
-        const int c2 = L.ffn2.colsum[col];
-        const float pb = L.ffn2.pb[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rl = lg * 4 + r;
@@ -505,11 +506,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       bv[r] = -3.402823466e+38f;
       bi[r] = 0x7fffffff;
     }
-    stream_gemm<KSD, 2>(A1, LDA, a.out, wave, lane, [&](int tile, const v4i &acc) {
+    stream_gemm<KSD, 2>(A1, LDA, a.out, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
       const int col = tile * 16 + lr;
       if (col < a.out.N) {
-        const int co = a.out.colsum[col];
-        const float pb = a.out.pb[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = dequant(acc[r], co, a.out.u, pb);

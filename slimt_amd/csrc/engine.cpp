@@ -674,6 +674,17 @@ extern "C" int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode) {
   return 0;
 }
 
+extern "C" int slimt_hip_ctx_plan(const slimt_hip_ctx *ctx, size_t S, int *encoder_fused,
+                                  int *decoder_fused) {
+  if (!ctx) return fail(-1, "ctx is NULL");
+  const slimt_hip_model *m = ctx->model;
+  const bool fused = ctx->decode_mode == 0;
+  if (encoder_fused)
+    *encoder_fused = fused && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
+  if (decoder_fused) *decoder_fused = fused && fused_decode_supported(m->D, m->F, m->H, m->Ld);
+  return 0;
+}
+
 extern "C" int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx) {
   if (!ctx) return fail(-1, "ctx is NULL");
   HIPCHK(hipStreamSynchronize(ctx->stream));
