@@ -101,9 +101,9 @@ float so_row_sum(const float *x, size_t n) {
  * the intgemm path => rintf. */
 static inline int8_t quantize_one(float x, float a_quant) {
   float v = rintf(x * a_quant);
+  if (v != v) return -127; /* cvtps_epi32(NaN) = INT_MIN -> saturating packs -> max(-127) */
   if (v < -127.0f) v = -127.0f;
   if (v > 127.0f) v = 127.0f;
-  if (v != v) v = 0.0f;
   return (int8_t)v;
 }
 

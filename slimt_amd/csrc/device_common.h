@@ -108,12 +108,12 @@ __device__ __forceinline__ float half_max(float v) {
 }
 
 // intgemm PrepareA: round-to-nearest-even, clamp to [-127, 127]
-// (Intgemm.inl.cc:29-34).
+// (Intgemm.inl.cc:29-34). max/min return the non-NaN operand,
+// so NaN quantises to -127 -- what intgemm's cvtps_epi32 (INT_MIN) + saturating
+// packs + max_epi8(-127) produce as well.
 __device__ __forceinline__ int quantize1(float x, float a_quant) {
   float v = __builtin_rintf(x * a_quant);
-  v = v < -127.0f ? -127.0f : v;
-  v = v > 127.0f ? 127.0f : v;
-  if (v != v) v = 0.0f;
+  v = __builtin_fminf(__builtin_fmaxf(v, -127.0f), 127.0f);
   return (int)v;
 }
 

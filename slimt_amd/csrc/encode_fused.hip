@@ -116,6 +116,23 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   auto row_sentence = [&](int r) { return s0 + r / S; };
   auto row_valid = [&](int r) { return r < rows_used && row_sentence(r) < B; };
 
+  // Q/K/V weight fragments of this wave's column tile; those of layer l+1 are
+  // issued before the last LayerNorm of layer l (they do not depend on data)
+  v4i bq[KSD], bk[KSD], bv[KSD];
+  load_frags<KSD>(bq, a.L[0].q, wave, 0, lane);
+  load_frags<KSD>(bk, a.L[0].k, wave, 0, lane);
+  load_frags<KSD>(bv, a.L[0].v, wave, 0, lane);
+  // the three int8 A operands of a layer's Q/K/V projections from row r of xs
+  auto quantise_row = [&](int r, const FusedEncLayerW &L) {
+#pragma unroll
+    for (int i = 0; i < KSD; ++i) {
+      const float v = xs[r * LDX + lane + 64 * i];
+      Aq[r * LDA + lane + 64 * i] = (char)quantize1(v, L.q.a_quant);
+      Ak[r * LDA + lane + 64 * i] = (char)quantize1(v, L.k.a_quant);
+      Av[r * LDA + lane + 64 * i] = (char)quantize1(v, L.v.a_quant);
+    }
+  };
+
   // ---- embedding (Model.cc:195-197) ----------------------------------------
   for (int r = wave; r < ER; r += ENW) {
     const bool ok = row_valid(r);
@@ -132,6 +149,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       xs[r * LDX + lane + 64 * i] = v;
       if (ok && a.embed_out) a.embed_out[((size_t)sb * S + pos) * D + lane + 64 * i] = v;
     }
+    quantise_row(r, a.L[0]);  // same wave, same row: no barrier in between
   }
   __syncthreads();
 
@@ -139,22 +157,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     const FusedEncLayerW &L = a.L[l];
     SLIMT_ESTAMP(0);
     // ---- Attention::forward (Modules.cc:287-319) ---------------------------
-    // the weight fragments of this wave's Q/K/V column tile do not depend on
-    // the activations: issue them first, quantise x underneath
-    v4i bq[KSD], bk[KSD], bv[KSD];
-    load_frags<KSD>(bq, L.q, wave, 0, lane);
-    load_frags<KSD>(bk, L.k, wave, 0, lane);
-    load_frags<KSD>(bv, L.v, wave, 0, lane);
-    for (int r = wave; r < ER; r += ENW) {
-#pragma unroll
-      for (int i = 0; i < KSD; ++i) {
-        const float v = xs[r * LDX + lane + 64 * i];
-        Aq[r * LDA + lane + 64 * i] = (char)quantize1(v, L.q.a_quant);
-        Ak[r * LDA + lane + 64 * i] = (char)quantize1(v, L.k.a_quant);
-        Av[r * LDA + lane + 64 * i] = (char)quantize1(v, L.v.a_quant);
-      }
-    }
-    __syncthreads();
+    // (x was quantised into Aq/Ak/Av by the producer of xs)
     SLIMT_ESTAMP(1);
     {  // Q, K, V projections: wave = column tile of each
       const int col = wave * 16 + lr;
@@ -336,8 +339,16 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     }
     __syncthreads();
     SLIMT_ESTAMP(6);
+    {  // next layer's projection weights, under the LayerNorm (unconditional, so
+       // that the registers are dead between the projections and here)
+      const FusedEncLayerW &Ln = a.L[l + 1 < a.Le ? l + 1 : l];
+      load_frags<KSD>(bq, Ln.q, wave, 0, lane);
+      load_frags<KSD>(bk, Ln.k, wave, 0, lane);
+      load_frags<KSD>(bv, Ln.v, wave, 0, lane);
+    }
     for (int r = wave; r < ER; r += ENW) {
       eln_row<KSD>(xs + r * LDX, L.ffn_ln_s, L.ffn_ln_b, a.eps, lane);
+      if (l + 1 < a.Le) quantise_row(r, a.L[l + 1]);
       if (a.layer_out && row_valid(r)) {
         float *dst = a.layer_out + ((size_t)l * B * S + (size_t)row_sentence(r) * S + r % S) * D;
 #pragma unroll

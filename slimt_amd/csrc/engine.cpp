@@ -86,9 +86,9 @@ extern "C" int slimt_hip_prepare_weight_transposed(const float *weights, int8_t 
   const size_t n = rows * cols;
   for (size_t i = 0; i < n; ++i) {
     float v = rintf(weights[i] * quantization_multiplier);
+    if (v != v) v = -127.0f;  // NaN: what intgemm's convert + saturating packs + max yield
     v = v < -127.0f ? -127.0f : v;
     v = v > 127.0f ? 127.0f : v;
-    if (v != v) v = 0.0f;
     prepared[i] = (int8_t)v;
   }
   return 0;

@@ -95,6 +95,16 @@ def test_affine_with_select(hip, oracle, M, K, N, n_idx):
         assert np.array_equal(got, hip.affine(x, W, bias, aq, bq)[:, idx])
 
 
+def test_affine_non_finite_activations(hip, oracle):
+    """NaN / inf activations quantise like intgemm's PrepareA: NaN -> -127,
+    +inf -> 127, -inf -> -127 (accumulators stay exact)."""
+    M, K, N = 16, 64, 32
+    x, W, bias, aq, bq = make_case(77, M, K, N)
+    x[0, 0], x[1, 5], x[2, 9] = np.nan, np.inf, -np.inf
+    got = hip.affine_acc_i32(x, W, aq)
+    assert np.array_equal(got, oracle.affine_acc(x, W, aq))
+
+
 def test_affine_leading_dims_flatten(hip, oracle):
     """M = x.size / x.dim(-1): leading dims flatten (Intgemm.inl.cc:101-104)."""
     x, W, bias, aq, bq = make_case(9, 6 * 5, 128, 96)

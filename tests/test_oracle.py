@@ -20,6 +20,9 @@ def test_quantize_rne_and_clamp(oracle):
                  dtype=np.float32)
     q = oracle.quantize(x, 1.0)
     assert q.tolist() == [0, 2, 2, 0, -2, -2, 126, 127, 127, -127, -127, 0]
+    # NaN / inf: intgemm's convert (INT_MIN) + saturating packs + max(-127)
+    special = np.array([np.nan, np.inf, -np.inf], dtype=np.float32)
+    assert oracle.quantize(special, 1.0).tolist() == [-127, 127, -127]
     r = rng(1)
     x = r.normal(0, 3, size=4096).astype(np.float32)
     aq = np.float32(17.3)
