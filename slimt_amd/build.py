@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libslimt_hip.so")
+# SLIMT_HIP_LIB: build/load an alternative library file (kernel experiments only)
+LIB_PATH = os.environ.get("SLIMT_HIP_LIB") or os.path.join(LIB_DIR, "libslimt_hip.so")
 
 SOURCES = ["kernels.hip", "decode_kernels.hip", "decode_fused.hip", "encode_fused.hip", "engine.cpp"]
 HEADERS = ["kernels.h", "engine.h", "device_common.h", os.path.join(ROOT, "include", "slimt_hip.h")]

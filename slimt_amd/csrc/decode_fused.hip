@@ -19,6 +19,18 @@
 #include "device_common.h"
 #include "kernels.h"
 
+// Bandwidth experiments only (wrong results): shrink the weight / K-V footprint.
+#ifdef SLIMT_EXP_WSMALL
+#define EXP_TILE(t) ((t) & 3)
+#else
+#define EXP_TILE(t) (t)
+#endif
+#ifdef SLIMT_EXP_KVSMALL
+#define EXP_SENT(b) ((b) & 1)
+#else
+#define EXP_SENT(b) (b)
+#endif
+
 namespace slimt_hip {
 
 namespace {
@@ -37,19 +49,37 @@ struct Frags {
 
 // y = float(acc + 127 colsum) * u + pb   (Intgemm.inl.cc:146-153)
 __device__ __forceinline__ float dequant(int acc, int colsum, float u, float pb) {
-  const float v = (float)(acc + 127 * colsum) * u;
+  const float v = (float)(acc + __mul24(127, colsum)) * u;  // |colsum| <= 127 K < 2^23
   return v + pb;
 }
 
+// Weight streams go through buffer loads: the descriptor and the tile offset
+// are wave-uniform (SGPRs), the only vector operand is lane * 16. That keeps
+// 64-bit per-lane addresses out of the VGPR budget (they used to spill, and a
+// scratch reload inside the loop drains every prefetch in flight), and reads
+// past the last tile return zeros, so prefetches need no predicate and the
+// compiler's s_waitcnt counts stay exact.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ v4i load_frag(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
 // Stream this wave's tiles (tile = wave + 16 i) of a [K = 64 KS] x N weight,
-// A operand (16 x K int8) in LDS. epi(tile, acc) once per finished tile.
-// NB chunks of CH fragments (1 KiB each) are kept in flight per wave.
+// A operand (16 x K int8) in LDS. epi(tile, acc, colsum, pb) once per finished
+// tile. NB chunks of CH fragments (1 KiB each) are kept in flight per wave.
+// `wave` must be wave-uniform in the compiler's eyes (readfirstlane).
 template <int KS, int NB, class Epi>
 __device__ __forceinline__ void stream_gemm(const char *A, int lda, const PreparedWeight &w,
                                             int wave, int lane, Epi &&epi) {
-  const v4i *Wp = reinterpret_cast<const v4i *>(w.Wp);
   const int n_tiles = w.n_tiles;
+  const rsrc_t rw = make_rsrc(w.Wp, (unsigned)n_tiles * KS * 1024u);
+  const rsrc_t rc = make_rsrc(w.colsum, (unsigned)n_tiles * 64u);
+  const rsrc_t rp = make_rsrc(w.pb, (unsigned)n_tiles * 64u);
   const int lr = lane & 15, lg = lane >> 4;
+  const int voff = lane * 16, eoff = lr * 4;
   const int ntw = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;  // my tiles
   Frags b[NB];
   if constexpr (KS <= CH) {
@@ -62,16 +92,12 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
     auto load = [&](Frags &bb, int c) {
 #pragma unroll
       for (int j = 0; j < TPC; ++j) {
-        const int i = c * TPC + j;
-        const int tile = wave + NW * i;
+        const int tile = EXP_TILE(wave + NW * (c * TPC + j));
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          v4i t = {0, 0, 0, 0};
-          if (i < ntw) t = Wp[((size_t)tile * KS + ks) * 64 + lane];
-          bb.f[j * KS + ks] = t;
-        }
-        bb.cs[j] = i < ntw ? w.colsum[tile * 16 + lr] : 0;
-        bb.pb[j] = i < ntw ? w.pb[tile * 16 + lr] : 0.0f;
+        for (int ks = 0; ks < KS; ++ks)
+          bb.f[j * KS + ks] = load_frag(rw, voff, (tile * KS + ks) * 1024);
+        bb.cs[j] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
+        bb.pb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
       }
     };
     auto compute = [&](const Frags &bb, int c) {
@@ -88,15 +114,12 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       }
     };
 #pragma unroll
-    for (int k = 0; k < NB; ++k)
-      if (k < nch) load(b[k], k);
+    for (int k = 0; k < NB; ++k) load(b[k], k);
     for (int c = 0; c < nch; c += NB) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        if (c + k < nch) {
-          compute(b[k], c + k);
-          if (c + k + NB < nch) load(b[k], c + k + NB);
-        }
+        if (c + k < nch) compute(b[k], c + k);
+        load(b[k], c + k + NB);
       }
     }
   } else {
@@ -104,12 +127,12 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
     static_assert(KS % CH == 0, "K/64 must be a multiple of CH here");
     const int nch = ntw * CPT;
     auto load = [&](Frags &bb, int c) {
-      const int tile = wave + NW * (c / CPT);
+      const int tile = EXP_TILE(wave + NW * (c / CPT));
       const int ks0 = (c % CPT) * CH;
 #pragma unroll
-      for (int p = 0; p < CH; ++p) bb.f[p] = Wp[((size_t)tile * KS + ks0 + p) * 64 + lane];
-      bb.cs[0] = w.colsum[tile * 16 + lr];
-      bb.pb[0] = w.pb[tile * 16 + lr];
+      for (int p = 0; p < CH; ++p) bb.f[p] = load_frag(rw, voff, (tile * KS + ks0 + p) * 1024);
+      bb.cs[0] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
+      bb.pb[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
     };
     v4i acc = {0, 0, 0, 0};
     auto compute = [&](const Frags &bb, int c) {
@@ -125,15 +148,12 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       }
     };
 #pragma unroll
-    for (int k = 0; k < NB; ++k)
-      if (k < nch) load(b[k], k);
+    for (int k = 0; k < NB; ++k) load(b[k], k);
     for (int c = 0; c < nch; c += NB) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        if (c + k < nch) {
-          compute(b[k], c + k);
-          if (c + k + NB < nch) load(b[k], c + k + NB);
-        }
+        if (c + k < nch) compute(b[k], c + k);
+        load(b[k], c + k + NB);
       }
     }
   }
@@ -196,29 +216,54 @@ struct AttnRow {
 
 // scaled_dot_product_attention (Modules.cc:24-86) for ONE sentence, all heads,
 // by one wave. Kept out of line: its registers must not add to the GEMM phases'.
+// The K/V cache is streamed once per step by exactly one workgroup; weights are
+// shared by every workgroup. SLIMT_KV_NT marks the cache loads non-temporal so
+// that they do not displace the weights from the XCD's L2.
+#ifdef SLIMT_KV_NT
+#define KV_AUX 2
+#else
+#define KV_AUX 0
+#endif
+
 template <int D, int DH>
-__device__ __noinline__ void attention_row(AttnRow r, int lane) {
+__device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   constexpr int H = D / DH;
   const int S = r.S, len = r.len;
   const float minus_inf = -99999999.0f;  // Input.cc:56-61
   const float lowest = -3.402823466e+38f;
   if (DH == 32 && S <= 32) {
-    // two heads per pass: lane = (head parity, key)
+    // two heads per pass: lane = (head parity, key). Software-pipelined over
+    // the H/2 passes: the K rows of pass p+1 are requested as soon as pass p's
+    // scores are done and its V columns as soon as pass p's output is done, so
+    // a memory round trip hides behind half a pass of arithmetic.
     const int hh = lane >> 5, j = lane & 31;
     const int jc = j < S ? j : S - 1;
     const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+    f4 k4[8];
+    float v[32];
+    // buffer loads: descriptor and pass offsets are scalar, one VGPR of lane
+    // offset each; keys >= S read past the descriptor and return 0 (p is 0 there)
+    const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 4u);
+    const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(S * D) * 4u);
+    const int koff = ((hh * (DH / 4) * S + jc) * 4) * 4;  // [head][dh/4][S][4] floats
+    const int voff = lane * 4;                            // (head parity, d = lane & 31)
+    auto load_k = [&](int hp) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        k4[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                           rk, koff, ((2 * hp * (DH / 4) + i) * S * 4) * 4, KV_AUX));
+    };
+    auto load_v = [&](int hp) {
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj)
+        v[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                              rv, voff, (jj * D + 2 * hp * DH) * 4, KV_AUX));
+    };
+    load_k(0);
+    load_v(0);
+#pragma unroll
     for (int hp = 0; hp < H / 2; ++hp) {
       const int h = 2 * hp + hh;
-      gcf_ptr kr = r.kl + ((size_t)h * (DH / 4) * S + jc) * 4;  // [head][dh/4][S][4]
-      // V column of this lane: (head parity, d = lane & 31). The loads of a
-      // pass are issued up front: one memory round trip per pass, not per key.
-      gcf_ptr vc = r.vl + (2 * hp) * DH + lane;
-      f4 k4[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) k4[i] = *(gcf4_ptr)(kr + (size_t)i * S * 4);
-      float va[16], vb[16];
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) va[jj] = vc[(size_t)(jj < S ? jj : S - 1) * D];
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -228,8 +273,7 @@ __device__ __noinline__ void attention_row(AttnRow r, int lane) {
         s = __builtin_fmaf(q4.z, k4[i].z, s);
         s = __builtin_fmaf(q4.w, k4[i].w, s);
       }
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) vb[jj] = vc[(size_t)((16 + jj) < S ? (16 + jj) : S - 1) * D];
+      if (hp + 1 < H / 2) load_k(hp + 1);
       if (r.alpha != 1.0f) s = r.alpha * s;
       s = s + mask;
       if (j >= S) s = lowest;
@@ -247,21 +291,14 @@ __device__ __noinline__ void attention_row(AttnRow r, int lane) {
       r.pbuf[lane] = p;
       float o = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {  // keys >= S contribute fma(0, v, o) == o
         const f4 p4 = *(lcf4_ptr)(r.pbuf + (lane & 32) + 4 * i);
-        o = __builtin_fmaf(p4.x, va[4 * i + 0], o);
-        o = __builtin_fmaf(p4.y, va[4 * i + 1], o);
-        o = __builtin_fmaf(p4.z, va[4 * i + 2], o);
-        o = __builtin_fmaf(p4.w, va[4 * i + 3], o);
+        o = __builtin_fmaf(p4.x, v[4 * i + 0], o);
+        o = __builtin_fmaf(p4.y, v[4 * i + 1], o);
+        o = __builtin_fmaf(p4.z, v[4 * i + 2], o);
+        o = __builtin_fmaf(p4.w, v[4 * i + 3], o);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {  // keys >= S contribute fma(0, v, o) == o
-        const f4 p4 = *(lcf4_ptr)(r.pbuf + (lane & 32) + 16 + 4 * i);
-        o = __builtin_fmaf(p4.x, vb[4 * i + 0], o);
-        o = __builtin_fmaf(p4.y, vb[4 * i + 1], o);
-        o = __builtin_fmaf(p4.z, vb[4 * i + 2], o);
-        o = __builtin_fmaf(p4.w, vb[4 * i + 3], o);
-      }
+      if (hp + 1 < H / 2) load_v(hp + 1);
       r.arow[2 * hp * DH + lane] = (char)quantize1(o, r.aq_o);
     }
   } else {
@@ -321,6 +358,16 @@ __device__ __noinline__ void attention_row(AttnRow r, int lane) {
       a.stamps[(id)] = wall_clock64();                                                   \
   } while (0)
 
+// Lane-derived LDS / global offsets are recomputed per layer and step from an
+// opaque copy of the lane id: hoisted out of the step loop they only turn into
+// kernel-lifetime registers that spill (a few VALU ops are cheaper than that).
+#define SLIMT_PHASE_LANE                                 \
+  int lane = lane0;                                      \
+  asm volatile("" : "+v"(lane));                         \
+  const int lr = lane & 15, lg = lane >> 4;              \
+  (void)lr;                                              \
+  (void)lg
+
 template <int KSD, int KSF, int DH>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -328,8 +375,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr int LDF = D + 4;    // f32 row stride
   constexpr int LDA = D + 16;   // int8 row stride (K = D)
   constexpr int LDA3 = F + 16;  // int8 row stride (K = F)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 15, lg = lane >> 4;
+  const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * 16;
   const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
 
@@ -367,6 +414,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   for (int t = 0; t < max_steps; ++t) {
     SLIMT_STAMP(0);
     for (int l = 0; l < Ld; ++l) {
+      SLIMT_PHASE_LANE;
       const FusedLayerW &L = a.L[l];
       float *cl = cs + (size_t)l * 16 * D;
       const int sb = 1 + 10 * l;
@@ -381,14 +429,20 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       __syncthreads();
       SLIMT_STAMP(sb + 0);
       for (int tile = wave; tile < D / 16; tile += NW) {
-        const v4i *Wf = reinterpret_cast<const v4i *>(L.rnn_f.Wp);
-        const v4i *Ww = reinterpret_cast<const v4i *>(L.rnn_w.Wp);
+        const rsrc_t rf = make_rsrc(L.rnn_f.Wp, (D / 16) * KSD * 1024u);
+        const rsrc_t rw = make_rsrc(L.rnn_w.Wp, (D / 16) * KSD * 1024u);
+        const rsrc_t rfc = make_rsrc(L.rnn_f.colsum, D * 4u), rfp = make_rsrc(L.rnn_f.pb, D * 4u);
+        const rsrc_t rwc = make_rsrc(L.rnn_w.colsum, D * 4u), rwp = make_rsrc(L.rnn_w.pb, D * 4u);
         v4i bf[KSD], bw[KSD];
 #pragma unroll
         for (int ks = 0; ks < KSD; ++ks) {
-          bf[ks] = Wf[((size_t)tile * KSD + ks) * 64 + lane];
-          bw[ks] = Ww[((size_t)tile * KSD + ks) * 64 + lane];
+          bf[ks] = load_frag(rf, lane * 16, (tile * KSD + ks) * 1024);
+          bw[ks] = load_frag(rw, lane * 16, (tile * KSD + ks) * 1024);
         }
+        const int csf = __builtin_amdgcn_raw_buffer_load_b32(rfc, lr * 4, tile * 64, 0);
+        const int csw = __builtin_amdgcn_raw_buffer_load_b32(rwc, lr * 4, tile * 64, 0);
+        const float pbf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfp, lr * 4, tile * 64, 0));
+        const float pbw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwp, lr * 4, tile * 64, 0));
         v4i accf = {0, 0, 0, 0}, accw = {0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KSD; ++ks) {
@@ -398,8 +452,6 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           accw = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw, bw[ks], accw, 0, 0, 0);
         }
         const int col = tile * 16 + lr;
-        const int csf = L.rnn_f.colsum[col], csw = L.rnn_w.colsum[col];
-        const float pbf = L.rnn_f.pb[col], pbw = L.rnn_w.pb[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rl = lg * 4 + r;
@@ -434,8 +486,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       // SDPA over the cached K/V of sentence b; output quantised into A1
       if (live) {
         AttnRow ar;
-        ar.kl = (gcf_ptr)(a.kv + ((size_t)(2 * l) * B + b) * S * D);
-        ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + b) * S * D);
+        ar.kl = (gcf_ptr)(a.kv + ((size_t)(2 * l) * B + EXP_SENT(b)) * S * D);
+        ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(b)) * S * D);
         ar.qrow = (lcf_ptr)(xs + wave * LDF);
         ar.arow = (lc_ptr)(A1 + wave * LDA);
         ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * 64);
@@ -499,6 +551,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       SLIMT_STAMP(sb + 9);
     }
     // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
+    SLIMT_PHASE_LANE;
     float bv[4];
     int bi[4];
 #pragma unroll
@@ -512,10 +565,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = dequant(acc[r], co, a.out.u, pb);
-          if (v > bv[r] || (v == bv[r] && col < bi[r])) {  // first max wins
-            bv[r] = v;
-            bi[r] = col;
-          }
+          // a lane's columns only grow, so strict > keeps its first maximum
+          const bool better = v > bv[r];
+          bv[r] = better ? v : bv[r];
+          bi[r] = better ? col : bi[r];
         }
       }
     });
