@@ -35,6 +35,14 @@ namespace slimt_hip {
 
 namespace {
 
+// prefetch depth (chunks of CH fragments in flight per wave) of the streamed GEMMs
+#ifndef SLIMT_NB_FFN
+#define SLIMT_NB_FFN 2
+#endif
+#ifndef SLIMT_NB_OUT
+#define SLIMT_NB_OUT 2
+#endif
+
 constexpr int NW = 16;   // waves per workgroup
 constexpr int CH = 4;    // weight fragments per prefetch chunk (per wave)
 
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       __syncthreads();
       SLIMT_STAMP(sb + 6);
       // ---- FFN (Modules.cc:251-257) ----------------------------------------
-      stream_gemm<KSD, 2>(A1, LDA, L.ffn1, wave, lane, [&](int tile, const v4i &acc, int c1, float pb) {
+      stream_gemm<KSD, SLIMT_NB_FFN>(A1, LDA, L.ffn1, wave, lane, [&](int tile, const v4i &acc, int c1, float pb) {
         const int col = tile * 16 + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       });
       __syncthreads();
       SLIMT_STAMP(sb + 7);
-      stream_gemm<KSF, 2>(A3, LDA3, L.ffn2, wave, lane, [&](int tile, const v4i &acc, int c2, float pb) {
+      stream_gemm<KSF, SLIMT_NB_FFN>(A3, LDA3, L.ffn2, wave, lane, [&](int tile, const v4i &acc, int c2, float pb) {
         const int col = tile * 16 + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       bv[r] = -3.402823466e+38f;
       bi[r] = 0x7fffffff;
     }
-    stream_gemm<KSD, 2>(A1, LDA, a.out, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
+    stream_gemm<KSD, SLIMT_NB_OUT>(A1, LDA, a.out, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
       const int col = tile * 16 + lr;
       if (col < a.out.N) {
 #pragma unroll

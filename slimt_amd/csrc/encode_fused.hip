@@ -23,7 +23,7 @@ constexpr int ER = 32;   // rows per workgroup (2 MFMA row tiles)
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float edequant(int acc, int colsum, float u, float pb) {
-  const float v = (float)(acc + 127 * colsum) * u;
+  const float v = (float)(acc + __mul24(127, colsum)) * u;  // |colsum| <= 127 K < 2^23
   return v + pb;
 }
 
@@ -40,19 +40,50 @@ __device__ __forceinline__ void tile_mma2(const char *A, int lda, const v4i (&bf
   }
 }
 
+// Weight streams use buffer loads (see decode_fused.hip): descriptor and tile
+// offset are wave-uniform SGPRs, the only vector operand is lane * 16.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+
 template <int KS>
 __device__ __forceinline__ void load_frags(v4i (&bf)[KS], const PreparedWeight &w, int tile, int ks0,
                                            int lane) {
-  const v4i *Wp = reinterpret_cast<const v4i *>(w.Wp);
   const int KST = w.K >> 6;
+  const rsrc_t r = make_rsrc(w.Wp, (unsigned)w.n_tiles * KST * 1024u);
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) bf[ks] = Wp[((size_t)tile * KST + ks0 + ks) * 64 + lane];
+  for (int ks = 0; ks < KS; ++ks)
+    bf[ks] = __builtin_bit_cast(
+        v4i, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, (tile * KST + ks0 + ks) * 1024, 0));
+}
+
+// epilogue constants of column tile `tile` for this lane's column (lane & 15)
+__device__ __forceinline__ void load_epi(const PreparedWeight &w, int tile, int lr, int &cs, float &pb) {
+  const rsrc_t rc = make_rsrc(w.colsum, (unsigned)w.n_tiles * 64u);
+  const rsrc_t rp = make_rsrc(w.pb, (unsigned)w.n_tiles * 64u);
+  cs = __builtin_amdgcn_raw_buffer_load_b32(rc, lr * 4, tile * 64, 0);
+  pb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, lr * 4, tile * 64, 0));
 }
 
 // canonical in-place LayerNorm of LDS row x[0..D) by one wave
 template <int DPL>
-__device__ __forceinline__ void eln_row(float *x, const float *scale, const float *bias, float eps,
-                                        int lane) {
+__device__ __forceinline__ void load_ln(const float *scale, const float *bias, int lane,
+                                        float (&sc)[DPL], float (&bi)[DPL]) {
+  const rsrc_t rs = make_rsrc(scale, 64u * DPL * 4u), rb = make_rsrc(bias, 64u * DPL * 4u);
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    sc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, i * 256, 0));
+    bi[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, i * 256, 0));
+  }
+}
+
+// scale / bias of this lane's columns are passed in registers: they are the same
+// for every row, and loading them first keeps them ahead of any weight prefetch
+// in the (in-order) vector memory queue
+template <int DPL>
+__device__ __forceinline__ void eln_row(float *x, const float (&scale)[DPL], const float (&bias)[DPL],
+                                        float eps, int lane) {
   constexpr int D = 64 * DPL;
   float v[DPL];
 #pragma unroll
@@ -73,8 +104,8 @@ __device__ __forceinline__ void eln_row(float *x, const float *scale, const floa
 #pragma unroll
   for (int i = 0; i < DPL; ++i) {
     const float t = (v[i] - mean) / sigma;
-    const float m = scale[lane + 64 * i] * t;
-    x[lane + 64 * i] = m + bias[lane + 64 * i];
+    const float m = scale[i] * t;
+    x[lane + 64 * i] = m + bias[i];
   }
 }
 
@@ -87,6 +118,14 @@ __device__ __forceinline__ void eln_row(float *x, const float *scale, const floa
       a.stamps[(id)] = wall_clock64();                                                \
   } while (0)
 
+// see decode_fused.hip: keeps lane-derived offsets from being hoisted and spilled
+#define SLIMT_PHASE_LANE                                 \
+  int lane = lane0;                                      \
+  asm volatile("" : "+v"(lane));                         \
+  const int lr = lane & 15, lg = lane >> 4;              \
+  (void)lr;                                              \
+  (void)lg
+
 template <int KSD, int KSF, int DH>
 __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,8 +135,9 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   constexpr int LDQ = D + 1;   // f32 k/v rows (odd stride: row-per-lane reads are conflict-free)
   constexpr int LDQQ = D + 4;  // f32 q rows (16-byte aligned: read as b128 broadcasts)
   static_assert(D / 16 == ENW, "one 16-column tile of a D-wide GEMM per wave");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 15, lg = lane >> 4;
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  SLIMT_PHASE_LANE;
   const int S = a.S, B = a.B;
   const int spw = ER / S;              // whole sentences per workgroup
   const int s0 = blockIdx.x * spw;     // first sentence
@@ -154,6 +194,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   __syncthreads();
 
   for (int l = 0; l < a.Le; ++l) {
+    SLIMT_PHASE_LANE;
     const FusedEncLayerW &L = a.L[l];
     SLIMT_ESTAMP(0);
     // ---- Attention::forward (Modules.cc:287-319) ---------------------------
@@ -164,8 +205,9 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       {
         v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
         tile_mma2<KSD>(Aq, LDA, bq, lr, lg, c0, c1);
-        const int cs = L.q.colsum[col];
-        const float pb = L.q.pb[col];
+        int cs;
+        float pb;
+        load_epi(L.q, wave, lr, cs, pb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           qb[(lg * 4 + r) * LDQQ + col] = edequant(c0[r], cs, L.q.u, pb);
@@ -175,8 +217,9 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       {
         v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
         tile_mma2<KSD>(Ak, LDA, bk, lr, lg, c0, c1);
-        const int cs = L.k.colsum[col];
-        const float pb = L.k.pb[col];
+        int cs;
+        float pb;
+        load_epi(L.k, wave, lr, cs, pb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           kb[(lg * 4 + r) * LDQ + col] = edequant(c0[r], cs, L.k.u, pb);
@@ -186,8 +229,9 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       {
         v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
         tile_mma2<KSD>(Av, LDA, bv, lr, lg, c0, c1);
-        const int cs = L.v.colsum[col];
-        const float pb = L.v.pb[col];
+        int cs;
+        float pb;
+        load_epi(L.v, wave, lr, cs, pb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           vb[(lg * 4 + r) * LDQ + col] = edequant(c0[r], cs, L.v.u, pb);
@@ -268,8 +312,9 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
       tile_mma2<KSD>(Aq, LDA, bo, lr, lg, c0, c1);
       const int col = wave * 16 + lr;
-      const int cs = L.o.colsum[col];
-      const float pb = L.o.pb[col];
+      int cs;
+      float pb;
+      load_epi(L.o, wave, lr, cs, pb);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float *p0 = xs + (lg * 4 + r) * LDX + col;
@@ -280,8 +325,10 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     }
     __syncthreads();
     SLIMT_ESTAMP(4);
+    float lsc[KSD], lbi[KSD];
+    load_ln<KSD>(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);
     for (int r = wave; r < ER; r += ENW) {
-      eln_row<KSD>(xs + r * LDX, L.attn_ln_s, L.attn_ln_b, a.eps, lane);
+      eln_row<KSD>(xs + r * LDX, lsc, lbi, a.eps, lane);
 #pragma unroll
       for (int i = 0; i < KSD; ++i)
         Aq[r * LDA + lane + 64 * i] = (char)quantize1(xs[r * LDX + lane + 64 * i], L.ffn1.a_quant);
@@ -302,8 +349,9 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         // b1 is consumed: fetch the next chunk's fragments into the same registers
         if (fc + 1 < NC) load_frags<KSD>(b1, L.ffn1, t1 + 16, 0, lane);
         const int col1 = t1 * 16 + lr;
-        const int cs = L.ffn1.colsum[col1];
-        const float pb = L.ffn1.pb[col1];
+        int cs;
+        float pb;
+        load_epi(L.ffn1, t1, lr, cs, pb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v0 = edequant(c0[r], cs, L.ffn1.u, pb);
@@ -327,8 +375,9 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         __syncthreads();
       }
       const int col = wave * 16 + lr;
-      const int cs = L.ffn2.colsum[col];
-      const float pb = L.ffn2.pb[col];
+      int cs;
+      float pb;
+      load_epi(L.ffn2, wave, lr, cs, pb);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float *p0 = xs + (lg * 4 + r) * LDX + col;
@@ -339,6 +388,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     }
     __syncthreads();
     SLIMT_ESTAMP(6);
+    load_ln<KSD>(L.ffn_ln_s, L.ffn_ln_b, lane, lsc, lbi);
     {  // next layer's projection weights, under the LayerNorm (unconditional, so
        // that the registers are dead between the projections and here)
       const FusedEncLayerW &Ln = a.L[l + 1 < a.Le ? l + 1 : l];
@@ -347,7 +397,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       load_frags<KSD>(bv, Ln.v, wave, 0, lane);
     }
     for (int r = wave; r < ER; r += ENW) {
-      eln_row<KSD>(xs + r * LDX, L.ffn_ln_s, L.ffn_ln_b, a.eps, lane);
+      eln_row<KSD>(xs + r * LDX, lsc, lbi, a.eps, lane);
       if (l + 1 < a.Le) quantise_row(r, a.L[l + 1]);
       if (a.layer_out && row_valid(r)) {
         float *dst = a.layer_out + ((size_t)l * B * S + (size_t)row_sentence(r) * S + r % S) * D;
@@ -369,6 +419,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     }
   }
   for (int l = 0; l < a.Ld; ++l) {
+    SLIMT_PHASE_LANE;
     const PreparedWeight &wk = a.dec_k[l], &wv = a.dec_v[l];
     for (int r = wave; r < ER; r += ENW) {
 #pragma unroll
@@ -388,8 +439,9 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     {
       v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
       tile_mma2<KSD>(Ak, LDA, bk, lr, lg, c0, c1);
-      const int cs = wk.colsum[col];
-      const float pb = wk.pb[col];
+      int cs;
+      float pb;
+      load_epi(wk, wave, lr, cs, pb);
       const int hh = col / DH, d = col % DH;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -405,8 +457,9 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     {
       v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
       tile_mma2<KSD>(Av, LDA, bv, lr, lg, c0, c1);
-      const int cs = wv.colsum[col];
-      const float pb = wv.pb[col];
+      int cs;
+      float pb;
+      load_epi(wv, wave, lr, cs, pb);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll

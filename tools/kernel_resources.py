@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
        "-c", "-x", "hip", src, "-I", os.path.join(ROOT, "slimt_amd/csrc"), "-I", os.path.join(ROOT, "include"),
-       "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+       "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("SLIMT_HIPCC_EXTRA", "").split()
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}
 rows = []
