@@ -285,14 +285,10 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       if (r.alpha != 1.0f) s = r.alpha * s;
       s = s + mask;
       if (j >= S) s = lowest;
-      float m = s;
-#pragma unroll
-      for (int x = 1; x < 32; x <<= 1) m = fmaxf(m, __shfl_xor(m, x, 64));
+      const float m = half_max(s);
       const float e = j < S ? exp_p(s - m) : 0.0f;
-      float sum = e;  // canonical order: masks 1..16; the mask-32 step would add +0
-#pragma unroll
-      for (int x = 1; x < 32; x <<= 1) sum = sum + __shfl_xor(sum, x, 64);
-      const float p = e / sum;  // keys >= S: exactly 0
+      const float sum = half_sum(e);  // canonical order: masks 1..16; the mask-32 step would add +0
+      const float p = e / sum;        // keys >= S: exactly 0
       if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
       if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
       // broadcast the probabilities of this lane's head through LDS
@@ -421,6 +417,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   const int max_steps = a.max_steps;
   for (int t = 0; t < max_steps; ++t) {
     SLIMT_STAMP(0);
+    if (a.stamps && blockIdx.x == 0 && tid == 0 && t == a.stamp_step) a.stamps[60] = clock64();
     for (int l = 0; l < Ld; ++l) {
       SLIMT_PHASE_LANE;
       const FusedLayerW &L = a.L[l];
@@ -582,15 +579,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     });
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int x = 1; x < 16; x <<= 1) {
-        const float ov = __shfl_xor(bv[r], x, 64);
-        const int oi = __shfl_xor(bi[r], x, 64);
-        if (ov > bv[r] || (ov == bv[r] && oi < bi[r])) {
-          bv[r] = ov;
-          bi[r] = oi;
-        }
-      }
+      row16_argmax(bv[r], bi[r]);
       if (lr == 0) {
         red_v[wave * 16 + lg * 4 + r] = bv[r];
         red_i[wave * 16 + lg * 4 + r] = bi[r];
@@ -603,16 +592,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     {
       float v = lane < NW ? red_v[lane * 16 + wave] : -3.402823466e+38f;
       int ix = lane < NW ? red_i[lane * 16 + wave] : 0x7fffffff;
-#pragma unroll
-      for (int x = 1; x < 16; x <<= 1) {
-        const float ov = __shfl_xor(v, x, 64);
-        const int oi = __shfl_xor(ix, x, 64);
-        if (ov > v || (ov == v && oi < ix)) {
-          v = ov;
-          ix = oi;
-        }
-      }
-      ix = __shfl(ix, 0, 64);
+      row16_argmax(v, ix);
+      ix = __builtin_amdgcn_readfirstlane(ix);
       if (live) tok = a.shortlist ? a.shortlist[ix] : (uint32_t)ix;
     }
     if (live && !finished) {  // record(), Model.cc:127-137
@@ -640,6 +621,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     }
     __syncthreads();
     SLIMT_STAMP(42);
+    if (a.stamps && blockIdx.x == 0 && tid == 0 && t == a.stamp_step) a.stamps[61] = clock64();
   }
   if (live && lane == 0) a.out_len[b] = n_out;
 }

@@ -45,66 +45,97 @@ __device__ __forceinline__ float sigmoid_p(float x) {
   return e / (1.0f + e);
 }
 
-// Value of lane (l ^ M). Pure data movement, so any mechanism gives the same
-// bits; the cheap ones are used: DPP quad permutes for M = 1, 2 (no LDS
-// crossbar trip), ds_swizzle bit-mask mode for M = 4, 8, 16 (no address VGPR),
-// ds_bpermute only for M = 32.
+// Butterfly partners. The canonical reduction is the xor butterfly with masks
+// ascending (1, 2, 4, ..., 32): at step M every lane combines its value with
+// that of lane (l ^ M). Only WHICH VALUE arrives matters for the bits, not the
+// mechanism, so the cheap VALU data paths are used (no LDS crossbar trip):
+//   M = 1, 2   DPP quad_perm;
+//   M = 4, 8   DPP row_half_mirror / row_mirror: inside a butterfly the groups
+//              of M lanes are already uniform, so lane (7 - l) / (15 - l) holds
+//              the same bits as lane (l ^ 4) / (l ^ 8);
+//   M = 16, 32 gfx950 v_permlane16_swap / v_permlane32_swap.
+// butterfly_pair<M> is therefore only valid as step M of a butterfly whose
+// lower steps have been applied (with a commutative op); wave_sum and friends
+// are the only users.
+typedef unsigned slimt_u2 __attribute__((ext_vector_type(2)));
+// (a, b) = (own value, partner's value) in some order -- enough for a
+// commutative op, and it saves the select after a permlane swap.
 template <int M>
-__device__ __forceinline__ float lane_xor(float v) {
+__device__ __forceinline__ void butterfly_pair(float v, float &a, float &b) {
   const int i = __float_as_int(v);
+  a = v;
 #ifdef SLIMT_REDUCE_BPERMUTE
   (void)i;
-  return __shfl_xor(v, M, 64);
+  b = __shfl_xor(v, M, 64);
+  return;
 #endif
   if constexpr (M == 1) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, false));  // [1,0,3,2]
+    b = __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, false));  // [1,0,3,2]
   } else if constexpr (M == 2) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, false));  // [2,3,0,1]
-  } else if constexpr (M == 4 || M == 8 || M == 16) {
-    return __int_as_float(__builtin_amdgcn_ds_swizzle(i, (M << 10) | 0x1f));
+    b = __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, false));  // [2,3,0,1]
+  } else if constexpr (M == 4) {
+    b = __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x141, 0xf, 0xf, false));  // row_half_mirror
+  } else if constexpr (M == 8) {
+    b = __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x140, 0xf, 0xf, false));  // row_mirror
+  } else if constexpr (M == 16) {
+    // even rows: (.x, .y) = (own, upper neighbour row); odd rows: (lower neighbour row, own)
+    const slimt_u2 r = __builtin_amdgcn_permlane16_swap(i, i, false, false);
+    a = __int_as_float(r.x);
+    b = __int_as_float(r.y);
   } else {
-    return __shfl_xor(v, M, 64);
+    const slimt_u2 r = __builtin_amdgcn_permlane32_swap(i, i, false, false);
+    a = __int_as_float(r.x);
+    b = __int_as_float(r.y);
   }
+}
+
+template <int M>
+__device__ __forceinline__ float bf_add(float v) {
+  float a, b;
+  butterfly_pair<M>(v, a, b);
+  return a + b;
+}
+template <int M>
+__device__ __forceinline__ float bf_max(float v) {
+  float a, b;
+  butterfly_pair<M>(v, a, b);
+  return fmaxf(a, b);
+}
+
+// argmax butterfly over the 16 lanes of a DPP row (masks 1, 2, 4, 8): larger
+// value wins, equal values -> smaller index (a total order, so both partners
+// agree and the mirror trick above stays valid). All 16 lanes end equal.
+template <int M>
+__device__ __forceinline__ void argmax_step(float &v, int &ix) {
+  float a, ov;
+  butterfly_pair<M>(v, a, ov);
+  float ia, oi;
+  butterfly_pair<M>(__int_as_float(ix), ia, oi);
+  const int o = __float_as_int(oi);
+  const bool take = ov > v || (ov == v && o < ix);
+  v = take ? ov : v;
+  ix = take ? o : ix;
+}
+__device__ __forceinline__ void row16_argmax(float &v, int &ix) {
+  argmax_step<1>(v, ix);
+  argmax_step<2>(v, ix);
+  argmax_step<4>(v, ix);
+  argmax_step<8>(v, ix);
 }
 
 // xor butterfly over the 64 lanes, masks ascending; all lanes end equal.
 __device__ __forceinline__ float wave_sum(float v) {
-  v = v + lane_xor<1>(v);
-  v = v + lane_xor<2>(v);
-  v = v + lane_xor<4>(v);
-  v = v + lane_xor<8>(v);
-  v = v + lane_xor<16>(v);
-  v = v + lane_xor<32>(v);
-  return v;
+  return bf_add<32>(bf_add<16>(bf_add<8>(bf_add<4>(bf_add<2>(bf_add<1>(v))))));
 }
-
 __device__ __forceinline__ float wave_max(float v) {
-  v = fmaxf(v, lane_xor<1>(v));
-  v = fmaxf(v, lane_xor<2>(v));
-  v = fmaxf(v, lane_xor<4>(v));
-  v = fmaxf(v, lane_xor<8>(v));
-  v = fmaxf(v, lane_xor<16>(v));
-  v = fmaxf(v, lane_xor<32>(v));
-  return v;
+  return bf_max<32>(bf_max<16>(bf_max<8>(bf_max<4>(bf_max<2>(bf_max<1>(v))))));
 }
-
 // the same butterflies restricted to each 32-lane half (masks 1..16)
 __device__ __forceinline__ float half_sum(float v) {
-  v = v + lane_xor<1>(v);
-  v = v + lane_xor<2>(v);
-  v = v + lane_xor<4>(v);
-  v = v + lane_xor<8>(v);
-  v = v + lane_xor<16>(v);
-  return v;
+  return bf_add<16>(bf_add<8>(bf_add<4>(bf_add<2>(bf_add<1>(v)))));
 }
-
 __device__ __forceinline__ float half_max(float v) {
-  v = fmaxf(v, lane_xor<1>(v));
-  v = fmaxf(v, lane_xor<2>(v));
-  v = fmaxf(v, lane_xor<4>(v));
-  v = fmaxf(v, lane_xor<8>(v));
-  v = fmaxf(v, lane_xor<16>(v));
-  return v;
+  return bf_max<16>(bf_max<8>(bf_max<4>(bf_max<2>(bf_max<1>(v)))));
 }
 
 // intgemm PrepareA: round-to-nearest-even, clamp to [-127, 127]

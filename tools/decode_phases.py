@@ -20,7 +20,8 @@ for step in (5, 20):
     ctx.translate(ids, lens, sl)
     st = ctx.debug_decode_stamps(-1).astype(np.int64)
     t = st[idx]
-    print(f"--- B={B} step {step}: total {(t[-1]-t[0])/100:.1f} us")
+    mhz = (st[61] - st[60]) / max(1, (t[-1] - t[0])) * 100.0
+    print(f"--- B={B} step {step}: total {(t[-1]-t[0])/100:.1f} us   (shader clock ~{mhz:.0f} MHz)")
     for i in range(1, len(idx)):
         print(f"  {names[i]:22s} {(t[i]-t[i-1])/100:7.2f} us")
 
