@@ -60,6 +60,24 @@ def algorithmic_macs_per_sentence(D, F, Le, Ld, S, T, N):
     return S * (Le * (4 * D * D + 2 * D * F) + Ld * 2 * D * D) + T * (Ld * (4 * D * D + 2 * D * F) + D * N)
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC pass
+    (profiles/*_pmc_{FETCH,WRITE}_SIZE.json, written by tools/profile_round.sh:
+    separate rocprofv3 --pmc runs of this same workload). FETCH_SIZE is doubled
+    (gfx950 correction, MI355X_MICROARCH.md, HBM section). None if absent."""
+    import glob
+    out = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{c}.json")))
+        if not files:
+            return None, None
+        rec = json.load(open(files[-1])).get(kernel)
+        if not rec:
+            return None, None
+        out[c] = (rec["avg_KB_per_launch"] * 1024.0, os.path.basename(files[-1]))
+    return 2.0 * out["FETCH_SIZE"][0] + out["WRITE_SIZE"][0], [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]
+
+
 def cpu_baseline(model, S, T, n_sl, n_sent):
     """The CPU port of the reference's op sequence (per-step K/V recompute and
     per-call PrepareBias included), FAITHFUL float order, on the host cores."""
@@ -195,6 +213,8 @@ def main():
         achieved = ops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         macs_sentence = algorithmic_macs_per_sentence(model.D, model.F, model.enc_layers,
                                                       model.dec_layers, S, T, N_out)
+        traffic, traffic_src = pmc_traffic(prof_name)
+        cus = -(-B // 16) if prof_name == "decode_fused" else 256
         out = {
             "metric": "target tokens/sec, en-de tiny11 int8 greedy, batch=256",
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
@@ -215,7 +235,10 @@ def main():
             },
             "roofline": {
                 "kernel": prof_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_INT8_TOPS,
-                "unit": "TOP/s", "frac": achieved / PEAK_INT8_TOPS, "traffic": None,
+                "unit": "TOP/s", "frac": achieved / PEAK_INT8_TOPS, "traffic": traffic,
+                "traffic_source": traffic_src, "cus_per_launch": cus,
+                "frac_of_occupied_cus": achieved / (PEAK_INT8_TOPS * cus / 256.0),
+                "chip_frac_all_launches": 2.0 * macs_sentence * B * args.steps / dt_max / 1e12 / PEAK_INT8_TOPS,  # per GPU
                 "launches": prof["launches"], "avg_launch_us": 1e3 * avg_ms,
                 "note": "per-launch figure of ONE kernel instance; a decode launch occupies "
                         "ceil(B/16) of the 256 CUs and `workers` launches overlap (see config)",
