@@ -129,7 +129,9 @@ int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
 /* Execution strategy of slimt_hip_translate* / slimt_hip_encode: 0 = automatic
  * (persistent fused encoder / decoder kernels when the model shape supports
  * them), 1 = one launch per stage (and per decode step; the kernels behind
- * slimt_hip_decode_step). Same results either way. */
+ * slimt_hip_decode_step), 2 / 3 = automatic, but the persistent decoder is
+ * forced to 16 / 32 sentences per workgroup (tuning and tests; 0 picks by batch
+ * size). Same results in every mode. */
 int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode);
 /* Which kernels a translate call with source length S would use in the current
  * mode: *encoder_fused / *decoder_fused = 1 for the persistent kernels, 0 for

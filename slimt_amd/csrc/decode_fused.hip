@@ -406,6 +406,11 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 
   for (int i = tid; i < Ld * 16 * D; i += 1024) cs[i] = 0.0f;  // start_states, Transformer.cc:78-85
   if (tid == 0) flags[0] = 0;
+  if (live) {  // outputs past a sentence's length read as zero (no memset launches)
+    for (int i = lane; i < a.Tmax; i += 64) a.out_ids[(size_t)b * a.Tmax + i] = 0;
+    if (a.align)
+      for (int i = lane; i < a.Tmax * S; i += 64) a.align[(size_t)b * a.Tmax * S + i] = 0.0f;
+  }
   // step-0 embedding: zeros * sqrt(D) + pos(0)  (Transformer.cc:138-144,160)
 #pragma unroll
   for (int i = 0; i < KSD; ++i) {
@@ -626,6 +631,636 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   if (live && lane == 0) a.out_len[b] = n_out;
 }
 
+// =============================================================================
+// 32 sentences per workgroup (two MFMA row tiles).
+//
+// Every phase of the 16-row kernel above runs at the CU's vector-memory rate
+// (~32 B/clk from L2): per step and workgroup it streams 3.4 MB of weights and
+// 2 MB of K/V. Twice the rows per workgroup halve the weight bytes per sentence
+// (340 -> 234 KB per sentence and step). To fit 32 rows in the CU's 160 KiB:
+//   * two f32 row buffers instead of three: LayerNorm and the residual adds
+//     run in place (P), X holds the layer input / q;
+//   * the FFN hidden layer never exists whole: F is walked in chunks of 256
+//     columns through a double-buffered int8 [32][256] tile, the FFN2
+//     accumulators of a wave's column tile stay in registers;
+//   * the attention scratch aliases the hidden-chunk buffers.
+// Row-wise work (LayerNorm, attention, sampling): wave w owns sentences w and
+// w + 16. Arithmetic is bit-identical to the 16-row kernel.
+namespace {
+
+constexpr int R2 = 32;
+
+template <int KS, int NB, class Epi>
+__device__ __forceinline__ void stream_gemm2(const char *A, int lda, const PreparedWeight &w,
+                                             int wave, int lane, Epi &&epi) {
+  static_assert(KS == CH, "one tile per chunk");
+  const int n_tiles = w.n_tiles;
+  const rsrc_t rw = make_rsrc(w.Wp, (unsigned)n_tiles * KS * 1024u);
+  const rsrc_t rc = make_rsrc(w.colsum, (unsigned)n_tiles * 64u);
+  const rsrc_t rp = make_rsrc(w.pb, (unsigned)n_tiles * 64u);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int voff = lane * 16, eoff = lr * 4;
+  const int ntw = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;  // my tiles
+  v4i a0[KS], a1[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    a0[ks] = *reinterpret_cast<const v4i *>(A + lr * lda + ks * 64 + lg * 16);
+    a1[ks] = *reinterpret_cast<const v4i *>(A + (16 + lr) * lda + ks * 64 + lg * 16);
+  }
+  Frags b[NB];
+  auto load = [&](Frags &bb, int c) {
+    const int tile = EXP_TILE(wave + NW * c);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bb.f[ks] = load_frag(rw, voff, (tile * KS + ks) * 1024);
+    bb.cs[0] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
+    bb.pb[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
+  };
+#pragma unroll
+  for (int k = 0; k < NB; ++k) load(b[k], k);
+  for (int c = 0; c < ntw; c += NB) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      if (c + k < ntw) {
+        v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[ks], b[k].f[ks], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[ks], b[k].f[ks], acc1, 0, 0, 0);
+        }
+        epi(wave + NW * (c + k), acc0, acc1, b[k].cs[0], b[k].pb[0]);
+      }
+      load(b[k], c + k + NB);
+    }
+  }
+}
+
+template <int DPL>
+__device__ __forceinline__ void load_ln_consts(const float *scale, const float *bias, int lane,
+                                               float (&sc)[DPL], float (&bi)[DPL]) {
+  const rsrc_t rs = make_rsrc(scale, 64u * DPL * 4u), rb = make_rsrc(bias, 64u * DPL * 4u);
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    sc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, i * 256, 0));
+    bi[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, i * 256, 0));
+  }
+}
+
+// ln_row with scale / bias already in registers (shared by a wave's two rows)
+template <int DPL>
+__device__ __forceinline__ void ln_row_r(const float *src, const float (&scale)[DPL],
+                                         const float (&bias)[DPL], float eps, float *dst, char *A,
+                                         float aq, int lane) {
+  constexpr int D = 64 * DPL;
+  float v[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) v[i] = src[lane + 64 * i];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) s += v[i];
+  s = wave_sum(s);
+  const float mean = s / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float d = v[i] - mean;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  const float sigma = __builtin_sqrtf(q / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float t = (v[i] - mean) / sigma;
+    const float m = scale[i] * t;
+    const float y = m + bias[i];
+    dst[lane + 64 * i] = y;
+    if (A) A[lane + 64 * i] = (char)quantize1(y, aq);
+  }
+}
+
+// Cross-attention of a wave's two sentences (d_head 32, S <= 32): 2 x H/2
+// passes of two heads each, software-pipelined across both sentences like
+// attention_row's fast path.
+struct AttnPair {
+  const float *kl[2], *vl[2];  // cached K / V of the two sentences
+  const float *qrow[2];        // LDS q rows
+  char *arow[2];               // LDS int8 output rows
+  float *pbuf;                 // LDS: 64 floats of per-wave scratch
+  int S, len[2];
+  bool live[2];
+  float alpha, aq_o;
+  float *attn[2];   // nullable [H][S]
+  float *align[2];  // nullable [S]
+};
+
+template <int D, int DH>
+__device__ __forceinline__ void attention_pair(const AttnPair &r, int lane) {
+  constexpr int H = D / DH, HP = H / 2;
+  const int S = r.S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int hh = lane >> 5, j = lane & 31;
+  const int jc = j < S ? j : S - 1;
+  const int koff = ((hh * (DH / 4) * S + jc) * 4) * 4;  // [head][dh/4][S][4] floats
+  const int voff = lane * 4;                            // (head parity, d = lane & 31)
+  f4 k4[8];
+  float v[32];
+  // pass (sn, hp); past the last pass the descriptor is empty: the loads stay
+  // unconditional (exact s_waitcnt counts) but return zeros without traffic
+  auto load_k = [&](int sn, int hp) {
+    const rsrc_t rk = make_rsrc(sn ? r.kl[1] : r.kl[0], sn < 2 ? (unsigned)(S * D) * 4u : 0u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      k4[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                         rk, koff, ((2 * hp * (DH / 4) + i) * S * 4) * 4, KV_AUX));
+  };
+  auto load_v = [&](int sn, int hp) {
+    const rsrc_t rv = make_rsrc(sn ? r.vl[1] : r.vl[0], sn < 2 ? (unsigned)(S * D) * 4u : 0u);
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj)
+      v[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                            rv, voff, (jj * D + 2 * hp * DH) * 4, KV_AUX));
+  };
+  load_k(0, 0);
+  load_v(0, 0);
+#pragma unroll 1
+  for (int sn = 0; sn < 2; ++sn) {
+    const float *qrow = sn ? r.qrow[1] : r.qrow[0];
+    char *arow = sn ? r.arow[1] : r.arow[0];
+    float *attn = sn ? r.attn[1] : r.attn[0];
+    float *align = sn ? r.align[1] : r.align[0];
+    const int len = sn ? r.len[1] : r.len[0];
+    const bool live = sn ? r.live[1] : r.live[0];
+    const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+#pragma unroll
+    for (int hp = 0; hp < HP; ++hp) {
+      const int h = 2 * hp + hh;
+      const int nsn = hp + 1 < HP ? sn : sn + 1, nhp = hp + 1 < HP ? hp + 1 : 0;
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f4 q4 = *reinterpret_cast<const f4 *>(qrow + h * DH + 4 * i);
+        s = __builtin_fmaf(q4.x, k4[i].x, s);
+        s = __builtin_fmaf(q4.y, k4[i].y, s);
+        s = __builtin_fmaf(q4.z, k4[i].z, s);
+        s = __builtin_fmaf(q4.w, k4[i].w, s);
+      }
+      // keep the prefetches where they are written: hoisted above the arithmetic
+      // that frees their registers they only turn into spills
+      __builtin_amdgcn_sched_barrier(0);
+      load_k(nsn, nhp);
+      __builtin_amdgcn_sched_barrier(0);
+      if (r.alpha != 1.0f) s = r.alpha * s;
+      s = s + mask;
+      if (j >= S) s = lowest;
+      const float m = half_max(s);
+      const float e = j < S ? exp_p(s - m) : 0.0f;
+      const float sum = half_sum(e);  // canonical order: masks 1..16; the mask-32 step would add +0
+      const float pr = e / sum;       // keys >= S: exactly 0
+      if (attn && j < S) attn[(size_t)h * S + j] = pr;
+      if (align && hp == 0 && hh == 0 && j < len) align[j] = pr;
+      r.pbuf[lane] = pr;  // broadcast the probabilities of this lane's head through LDS
+      float o = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // keys >= S contribute fma(0, v, o) == o
+        const f4 p4 = *reinterpret_cast<const f4 *>(r.pbuf + (lane & 32) + 4 * i);
+        o = __builtin_fmaf(p4.x, v[4 * i + 0], o);
+        o = __builtin_fmaf(p4.y, v[4 * i + 1], o);
+        o = __builtin_fmaf(p4.z, v[4 * i + 2], o);
+        o = __builtin_fmaf(p4.w, v[4 * i + 3], o);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_v(nsn, nhp);
+      __builtin_amdgcn_sched_barrier(0);
+      arow[2 * hp * DH + lane] = live ? (char)quantize1(o, r.aq_o) : (char)0;
+    }
+  }
+}
+
+}  // namespace
+
+template <int KSD, int KSF, int DH>
+__global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = 64 * KSD;
+  constexpr int LDF = D + 4;   // f32 row stride
+  constexpr int LDA = D + 16;  // int8 row stride
+  constexpr int NC = KSF / 4;  // FFN chunks of 256 hidden columns
+  static_assert(D / 16 == NW, "one 16-column tile of a D-wide GEMM per wave");
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * R2;
+  const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
+
+  float *X = reinterpret_cast<float *>(smem);  // layer input rows (post-LN); reused for q
+  float *P = X + R2 * LDF;                     // pre-LN accumulation / post-LN residual source
+  float *cs = P + R2 * LDF;                    // SSRU cells [Ld][32][D]
+  char *A1 = reinterpret_cast<char *>(cs + (size_t)Ld * R2 * D);
+  char *HB0 = A1 + R2 * LDA;  // A2 of the SSRU / FFN hidden chunks / attention scratch
+  char *HB1 = HB0 + R2 * LDA;
+  float *red_v = reinterpret_cast<float *>(HB1 + R2 * LDA);  // [NW][32]
+  int *red_i = reinterpret_cast<int *>(red_v + NW * R2);
+  int *flags = red_i + NW * R2;  // [0] = number of finished sentences of this tile
+
+  // per-sentence state of rows wave and wave + 16 (uniform within the wave)
+  int bq[2];
+  bool live[2], finished[2];
+  int len[2];
+  uint32_t n_out[2] = {0, 0};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    bq[t] = m0 + 16 * t + wave;
+    live[t] = bq[t] < B;
+    len[t] = live[t] ? (int)a.lengths[bq[t]] : 0;
+    finished[t] = !live[t];
+  }
+  const int valid_rows = (B - m0) < R2 ? (B - m0) : R2;
+
+  for (int i = tid; i < Ld * R2 * D; i += 1024) cs[i] = 0.0f;  // start_states, Transformer.cc:78-85
+  if (tid == 0) flags[0] = 0;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    if (live[t]) {  // outputs past a sentence's length read as zero (no memset launches)
+      for (int i = lane0; i < a.Tmax; i += 64) a.out_ids[(size_t)bq[t] * a.Tmax + i] = 0;
+      if (a.align)
+        for (int i = lane0; i < a.Tmax * S; i += 64) a.align[(size_t)bq[t] * a.Tmax * S + i] = 0.0f;
+    }
+  {  // step-0 embedding: zeros * sqrt(D) + pos(0)  (Transformer.cc:138-144,160)
+    const int lane = lane0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) {
+        const float z = 0.0f * a.emb.sqrt_d;
+        X[(16 * t + wave) * LDF + lane + 64 * i] = live[t] ? z + a.emb.pos[lane + 64 * i] : 0.0f;
+      }
+  }
+  __syncthreads();
+
+  const int max_steps = a.max_steps;
+  for (int t = 0; t < max_steps; ++t) {
+    SLIMT_STAMP(0);
+    if (a.stamps && blockIdx.x == 0 && tid == 0 && t == a.stamp_step) a.stamps[60] = clock64();
+    for (int l = 0; l < Ld; ++l) {
+      SLIMT_PHASE_LANE;
+      const FusedLayerW &L = a.L[l];
+      float *cl = cs + (size_t)l * R2 * D;
+      const int sb = 1 + 10 * l;
+      float lsc[KSD], lbi[KSD];
+      // ---- SSRU (Modules.cc:190-235) ------------------------------------
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = 16 * rr + wave;
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) {
+          const float v = X[row * LDF + lane + 64 * i];
+          A1[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_f.a_quant);
+          HB0[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
+        }
+      }
+      __syncthreads();
+      SLIMT_STAMP(sb + 0);
+      {
+        const int tile = wave;
+        const rsrc_t rf = make_rsrc(L.rnn_f.Wp, (D / 16) * KSD * 1024u);
+        const rsrc_t rw = make_rsrc(L.rnn_w.Wp, (D / 16) * KSD * 1024u);
+        const rsrc_t rfc = make_rsrc(L.rnn_f.colsum, D * 4u), rfp = make_rsrc(L.rnn_f.pb, D * 4u);
+        const rsrc_t rwc = make_rsrc(L.rnn_w.colsum, D * 4u), rwp = make_rsrc(L.rnn_w.pb, D * 4u);
+        v4i bf[KSD], bw[KSD];
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+          bf[ks] = load_frag(rf, lane * 16, (tile * KSD + ks) * 1024);
+          bw[ks] = load_frag(rw, lane * 16, (tile * KSD + ks) * 1024);
+        }
+        const int csf = __builtin_amdgcn_raw_buffer_load_b32(rfc, lr * 4, tile * 64, 0);
+        const int csw = __builtin_amdgcn_raw_buffer_load_b32(rwc, lr * 4, tile * 64, 0);
+        const float pbf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfp, lr * 4, tile * 64, 0));
+        const float pbw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwp, lr * 4, tile * 64, 0));
+        const int col = tile * 16 + lr;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          v4i accf = {0, 0, 0, 0}, accw = {0, 0, 0, 0};
+#pragma unroll
+          for (int ks = 0; ks < KSD; ++ks) {
+            const v4i af = *reinterpret_cast<const v4i *>(A1 + (16 * rt + lr) * LDA + ks * 64 + lg * 16);
+            const v4i aw = *reinterpret_cast<const v4i *>(HB0 + (16 * rt + lr) * LDA + ks * 64 + lg * 16);
+            accf = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[ks], accf, 0, 0, 0);
+            accw = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw, bw[ks], accw, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = 16 * rt + lg * 4 + r;
+            const float f = dequant(accf[r], csf, L.rnn_f.u, pbf);
+            const float wx = dequant(accw[r], csw, L.rnn_w.u, pbw);
+            const float c = cl[rl * D + col];
+            const float sg = sigmoid_p(f);  // highway(c, Wx, f), TensorOps.cc:674-678
+            const float t1 = sg * c;
+            const float t2 = (1.0f - sg) * wx;
+            const float cn = t1 + t2;
+            cl[rl * D + col] = cn;
+            const float y = cn > 0.0f ? cn : 0.0f;
+            P[rl * LDF + col] = X[rl * LDF + col] + y;  // Modules.cc:230
+          }
+        }
+      }
+      __syncthreads();
+      SLIMT_STAMP(sb + 1);
+      // h = LN(x + relu(c')) in place, quantised for the Q projection
+      load_ln_consts<KSD>(L.rnn_ln_s, L.rnn_ln_b, lane, lsc, lbi);
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = 16 * rr + wave;
+        ln_row_r<KSD>(P + row * LDF, lsc, lbi, a.eps, P + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
+      }
+      __syncthreads();
+      SLIMT_STAMP(sb + 2);
+      // ---- cross-attention (Modules.cc:287-319) --------------------------
+      // Q projection -> X (x is dead until the end of the layer)
+      stream_gemm2<KSD, 1>(A1, LDA, L.q, wave, lane,
+                           [&](int tile, const v4i &c0, const v4i &c1, int cq, float pb) {
+                             const int col = tile * 16 + lr;
+#pragma unroll
+                             for (int r = 0; r < 4; ++r) {
+                               X[(lg * 4 + r) * LDF + col] = dequant(c0[r], cq, L.q.u, pb);
+                               X[(16 + lg * 4 + r) * LDF + col] = dequant(c1[r], cq, L.q.u, pb);
+                             }
+                           });
+      __syncthreads();
+      SLIMT_STAMP(sb + 3);
+      // SDPA over the cached K/V of this wave's two sentences; output quantised into A1
+#ifdef SLIMT_ATTN_PAIR
+      {
+        AttnPair ar;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int bb = live[rr] ? bq[rr] : 0;  // dead rows read sentence 0 and write zeros
+          ar.kl[rr] = a.kv + ((size_t)(2 * l) * B + EXP_SENT(bb)) * S * D;
+          ar.vl[rr] = a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(bb)) * S * D;
+          ar.qrow[rr] = X + (16 * rr + wave) * LDF;
+          ar.arow[rr] = A1 + (16 * rr + wave) * LDA;
+          ar.len[rr] = len[rr];
+          ar.live[rr] = live[rr];
+          ar.attn[rr] = (a.attn && (l + 1 == Ld) && live[rr]) ? a.attn + (size_t)bq[rr] * H * S : nullptr;
+          const bool want_align =
+              a.align && (l + 1 == Ld) && !finished[rr] && ((int)n_out[rr] < a.Tmax);
+          ar.align[rr] = want_align ? a.align + ((size_t)bq[rr] * a.Tmax + n_out[rr]) * S : nullptr;
+        }
+        ar.pbuf = reinterpret_cast<float *>(HB0) + wave * 64;
+        ar.S = S;
+        ar.alpha = a.alpha;
+        ar.aq_o = L.o.a_quant;
+        attention_pair<D, DH>(ar, lane);
+      }
+#else
+#pragma unroll 1
+      for (int rr = 0; rr < 2; ++rr) {
+        const bool lv = rr ? live[1] : live[0];
+        const int row = 16 * rr + wave;
+        if (lv) {
+          const int bb = rr ? bq[1] : bq[0];
+          const bool fin = rr ? finished[1] : finished[0];
+          const int no = rr ? (int)n_out[1] : (int)n_out[0];
+          AttnRow ar;
+          ar.kl = (gcf_ptr)(a.kv + ((size_t)(2 * l) * B + EXP_SENT(bb)) * S * D);
+          ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(bb)) * S * D);
+          ar.qrow = (lcf_ptr)(X + row * LDF);
+          ar.arow = (lc_ptr)(A1 + row * LDA);
+          ar.pbuf = (SLIMT_LDS float *)(reinterpret_cast<float *>(HB0) + wave * 64);
+          ar.S = S;
+          ar.len = rr ? len[1] : len[0];
+          ar.alpha = a.alpha;
+          ar.aq_o = L.o.a_quant;
+          ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)bb * H * S) : (gf_ptr) nullptr;
+          const bool want_align = a.align && (l + 1 == Ld) && !fin && (no < a.Tmax);
+          ar.align = want_align ? (gf_ptr)(a.align + ((size_t)bb * a.Tmax + no) * S) : (gf_ptr) nullptr;
+          attention_row<D, DH>(ar, lane);
+        } else {
+#pragma unroll
+          for (int i = 0; i < KSD; ++i) A1[row * LDA + lane + 64 * i] = 0;
+        }
+      }
+#endif
+      __syncthreads();
+      SLIMT_STAMP(sb + 4);
+      // O projection + residual h, in place (Modules.cc:308-314)
+      stream_gemm2<KSD, 1>(A1, LDA, L.o, wave, lane,
+                           [&](int tile, const v4i &c0, const v4i &c1, int co, float pb) {
+                             const int col = tile * 16 + lr;
+#pragma unroll
+                             for (int r = 0; r < 4; ++r) {
+                               float *p0 = P + (lg * 4 + r) * LDF + col;
+                               float *p1 = P + (16 + lg * 4 + r) * LDF + col;
+                               *p0 = dequant(c0[r], co, L.o.u, pb) + *p0;
+                               *p1 = dequant(c1[r], co, L.o.u, pb) + *p1;
+                             }
+                           });
+      __syncthreads();
+      SLIMT_STAMP(sb + 5);
+      load_ln_consts<KSD>(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = 16 * rr + wave;
+        ln_row_r<KSD>(P + row * LDF, lsc, lbi, a.eps, P + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
+      }
+      __syncthreads();
+      SLIMT_STAMP(sb + 6);
+      // ---- FFN (Modules.cc:251-257): hidden columns in chunks of 256 -----
+      {
+        const rsrc_t r1 = make_rsrc(L.ffn1.Wp, (unsigned)L.ffn1.n_tiles * KSD * 1024u);
+        const rsrc_t r1c = make_rsrc(L.ffn1.colsum, (unsigned)L.ffn1.n_tiles * 64u);
+        const rsrc_t r1p = make_rsrc(L.ffn1.pb, (unsigned)L.ffn1.n_tiles * 64u);
+        const rsrc_t r2 = make_rsrc(L.ffn2.Wp, (unsigned)(D / 16) * KSF * 1024u);
+        v4i f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
+        v4i b1[2][KSD], b2[2][4];
+        int cs1[2];
+        float pb1[2];
+        auto load_b1 = [&](int buf, int fc) {  // past the last chunk: out of range -> zeros
+          const int tile = EXP_TILE(fc * 16 + wave);
+#pragma unroll
+          for (int ks = 0; ks < KSD; ++ks) b1[buf][ks] = load_frag(r1, lane * 16, (tile * KSD + ks) * 1024);
+          cs1[buf] = __builtin_amdgcn_raw_buffer_load_b32(r1c, lr * 4, tile * 64, 0);
+          pb1[buf] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1p, lr * 4, tile * 64, 0));
+        };
+        auto load_b2 = [&](int buf, int fc) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            b2[buf][ks] = load_frag(r2, lane * 16, (EXP_TILE(wave) * KSF + fc * 4 + ks) * 1024);
+        };
+        // FFN1 of one chunk: this wave's column tile -> relu -> requantise -> hidden buffer
+        auto ffn1_chunk = [&](int buf, char *Hb) {
+          v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+          for (int ks = 0; ks < KSD; ++ks) {
+            const v4i x0 = *reinterpret_cast<const v4i *>(A1 + lr * LDA + ks * 64 + lg * 16);
+            const v4i x1 = *reinterpret_cast<const v4i *>(A1 + (16 + lr) * LDA + ks * 64 + lg * 16);
+            c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x0, b1[buf][ks], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x1, b1[buf][ks], c1, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v0 = dequant(c0[r], cs1[buf], L.ffn1.u, pb1[buf]);
+            float v1 = dequant(c1[r], cs1[buf], L.ffn1.u, pb1[buf]);
+            v0 = v0 > 0.0f ? v0 : 0.0f;
+            v1 = v1 > 0.0f ? v1 : 0.0f;
+            Hb[(lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v0, L.ffn2.a_quant);
+            Hb[(16 + lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v1, L.ffn2.a_quant);
+          }
+        };
+        load_b1(0, 0);
+        load_b1(1, 1);
+        load_b2(0, 0);
+        load_b2(1, 1);
+        ffn1_chunk(0, HB0);
+        load_b1(0, 2);
+        __syncthreads();
+#pragma unroll
+        for (int fc = 0; fc < NC; ++fc) {
+          char *Hcur = (fc & 1) ? HB1 : HB0;
+          char *Hnext = (fc & 1) ? HB0 : HB1;
+          if (fc + 1 < NC) {
+            ffn1_chunk((fc + 1) & 1, Hnext);
+            load_b1((fc + 1) & 1, fc + 3);
+          }
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const v4i h0 = *reinterpret_cast<const v4i *>(Hcur + lr * LDA + ks * 64 + lg * 16);
+            const v4i h1 = *reinterpret_cast<const v4i *>(Hcur + (16 + lr) * LDA + ks * 64 + lg * 16);
+            f0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(h0, b2[fc & 1][ks], f0, 0, 0, 0);
+            f1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(h1, b2[fc & 1][ks], f1, 0, 0, 0);
+          }
+          load_b2(fc & 1, fc + 2);
+          __syncthreads();
+        }
+        int c2;
+        float pb2;
+        {
+          const rsrc_t r2c = make_rsrc(L.ffn2.colsum, D * 4u), r2p = make_rsrc(L.ffn2.pb, D * 4u);
+          c2 = __builtin_amdgcn_raw_buffer_load_b32(r2c, lr * 4, wave * 64, 0);
+          pb2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2p, lr * 4, wave * 64, 0));
+        }
+        const int col = wave * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float *p0 = P + (lg * 4 + r) * LDF + col;
+          float *p1 = P + (16 + lg * 4 + r) * LDF + col;
+          *p0 = dequant(f0[r], c2, L.ffn2.u, pb2) + *p0;
+          *p1 = dequant(f1[r], c2, L.ffn2.u, pb2) + *p1;
+        }
+      }
+      __syncthreads();
+      SLIMT_STAMP(sb + 8);
+      // next layer's input; after the last layer: quantised for the logits
+      load_ln_consts<KSD>(L.ffn_ln_s, L.ffn_ln_b, lane, lsc, lbi);
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = 16 * rr + wave;
+        ln_row_r<KSD>(P + row * LDF, lsc, lbi, a.eps, X + row * LDF,
+                      (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
+      }
+      __syncthreads();
+      SLIMT_STAMP(sb + 9);
+    }
+    // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
+    SLIMT_PHASE_LANE;
+    float bv[8];
+    int bi[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      bv[r] = -3.402823466e+38f;
+      bi[r] = 0x7fffffff;
+    }
+    stream_gemm2<KSD, SLIMT_NB_OUT>(A1, LDA, a.out, wave, lane,
+                                    [&](int tile, const v4i &c0, const v4i &c1, int co, float pb) {
+                                      const int col = tile * 16 + lr;
+                                      if (col < a.out.N) {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) {
+                                          // a lane's columns only grow: strict > keeps its first maximum
+                                          const float v0 = dequant(c0[r], co, a.out.u, pb);
+                                          const float v1 = dequant(c1[r], co, a.out.u, pb);
+                                          const bool g0 = v0 > bv[r], g1 = v1 > bv[4 + r];
+                                          bv[r] = g0 ? v0 : bv[r];
+                                          bi[r] = g0 ? col : bi[r];
+                                          bv[4 + r] = g1 ? v1 : bv[4 + r];
+                                          bi[4 + r] = g1 ? col : bi[4 + r];
+                                        }
+                                      }
+                                    });
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      row16_argmax(bv[r], bi[r]);
+      if (lr == 0) {
+        const int row = 16 * (r >> 2) + lg * 4 + (r & 3);
+        red_v[wave * R2 + row] = bv[r];
+        red_i[wave * R2 + row] = bi[r];
+      }
+    }
+    __syncthreads();
+    SLIMT_STAMP(41);
+    // wave w finishes sentences w and w + 16: reduce over the 16 waves' candidates
+    uint32_t tok[2] = {0, 0};
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 16 * rr + wave;
+      float v = lane < NW ? red_v[lane * R2 + row] : -3.402823466e+38f;
+      int ix = lane < NW ? red_i[lane * R2 + row] : 0x7fffffff;
+      row16_argmax(v, ix);
+      ix = __builtin_amdgcn_readfirstlane(ix);
+      if (live[rr]) tok[rr] = a.shortlist ? a.shortlist[ix] : (uint32_t)ix;
+      if (live[rr] && !finished[rr]) {  // record(), Model.cc:127-137
+        if (lane == 0 && (int)n_out[rr] < a.Tmax) a.out_ids[(size_t)bq[rr] * a.Tmax + n_out[rr]] = tok[rr];
+        n_out[rr] += 1;
+        if (tok[rr] == a.eos) {
+          finished[rr] = true;
+          if (lane == 0) atomicAdd(&flags[0], 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (flags[0] >= valid_rows) break;  // every sentence of this tile has emitted EOS
+    if (t + 1 < max_steps) {
+      // next target embedding (Transformer.cc:146-160): position is always 0
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = 16 * rr + wave;
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) {
+          float v = 0.0f;
+          if (live[rr]) {
+            const float e = (float)a.emb.wemb[(size_t)tok[rr] * D + lane + 64 * i] * a.emb.inv_mult;
+            const float sc = e * a.emb.sqrt_d;
+            v = sc + a.emb.pos[lane + 64 * i];
+          }
+          X[row * LDF + lane + 64 * i] = v;
+        }
+      }
+    }
+    __syncthreads();
+    SLIMT_STAMP(42);
+    if (a.stamps && blockIdx.x == 0 && tid == 0 && t == a.stamp_step) a.stamps[61] = clock64();
+  }
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+    if (live[rr] && lane0 == 0) a.out_len[bq[rr]] = n_out[rr];
+}
+
+size_t fused_decode32_lds_bytes(int D, int Ld) {
+  return (size_t)2 * R2 * (D + 4) * 4 + (size_t)Ld * R2 * D * 4 + 3 * (size_t)R2 * (D + 16) +
+         2 * (size_t)NW * R2 * 4 + 64;
+}
+
+// rows per workgroup the fused decoder would use for this shape and batch
+int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced) {
+  const bool ok32 = D == 256 && F % 256 == 0 && F == 1536 && D / H == 32 && Ld <= 2 && S <= 32 &&
+                    fused_decode32_lds_bytes(D, Ld) <= 160 * 1024;
+  (void)B;
+  // Measured (tiny11, B=256, S=32): alone on the GPU the 32-row kernel is 1.29x
+  // faster per sentence (124 us per 32-row step vs 80 us per 16-row step), but
+  // with 8..32 batches in flight it loses (14 vs 18.8 Mtok/s): half as many,
+  // twice as long workgroups pack worse next to the encoders' short ones. So it
+  // is opt-in (decode mode 3) and the 16-row kernel stays the default.
+  return (forced == 32 && ok32) ? 32 : 16;
+}
+
 size_t fused_decode_lds_bytes(int D, int F, int Ld) {
   return (size_t)3 * 16 * (D + 4) * 4 + (size_t)Ld * 16 * D * 4 + 2 * 16 * (size_t)(D + 16) +
          16 * (size_t)(F + 16) + 2 * NW * 16 * 4 + 64 + NW * 64 * 4;
@@ -641,6 +1276,16 @@ bool fused_decode_supported(int D, int F, int H, int Ld) {
 
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st) {
   if (!fused_decode_supported(D, F, H, a.Ld)) return hipErrorInvalidValue;
+  if (fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg) == 32) {
+    const dim3 grid((a.B + R2 - 1) / R2);
+    const size_t lds = fused_decode32_lds_bytes(D, a.Ld);
+    auto k = decode_fused32_kernel<4, 24, 32>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
+    return hipGetLastError();
+  }
   const dim3 grid((a.B + 15) / 16);
   const size_t lds = fused_decode_lds_bytes(D, F, a.Ld);
 #define SLIMT_FUSED_CASE(KSD_, KSF_, DH_)                                                   \

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "kernels.h"
+
 namespace slimt_hip {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -172,6 +174,59 @@ __device__ __forceinline__ void wave_layer_norm_row(const float *x, const float 
     float t = (x[i] - mean) / sigma;
     float sc = scale[i] * t;
     y[i] = sc + bias[i];
+  }
+}
+
+__device__ __forceinline__ int sum_bytes(int w) {
+  return (int)(int8_t)(w & 0xff) + (int)(int8_t)((w >> 8) & 0xff) +
+         (int)(int8_t)((w >> 16) & 0xff) + (int)(int8_t)((w >> 24) & 0xff);
+}
+
+// One 16-column tile of a packing job by `nthreads` (>= 256, a multiple of 64)
+// threads of a workgroup: PrepareB's re-layout + PrepareBias' column sums
+// (Intgemm.inl.cc:48-69,127-136). No barrier inside.
+__device__ __forceinline__ void pack_weight_tile(const PackArgs &a, int ntile, int tid, int nthreads) {
+  v4i *Wp = reinterpret_cast<v4i *>(a.Wp);
+  const int KS = a.K / 64;
+  const int chunks = a.K / 16;  // 16-byte chunks per row
+  for (int c = tid; c < 16 * chunks; c += nthreads) {
+    const int r = c / chunks, ch = c % chunks;
+    const int n = ntile * 16 + r;
+    v4i v = {0, 0, 0, 0};
+    if (n < a.N) {
+      const size_t src = a.idx ? (size_t)a.idx[n] : (size_t)n;
+      v = *reinterpret_cast<const v4i *>(a.W + src * a.K + (size_t)ch * 16);
+    }
+    const int ks = ch >> 2, kg = ch & 3;
+    Wp[((size_t)ntile * KS + ks) * 64 + kg * 16 + r] = v;
+  }
+  if (tid < 256) {  // column sums: 16 threads per row
+    const int r = tid >> 4, sub = tid & 15;
+    const int n = ntile * 16 + r;
+    int s = 0;
+    size_t src = 0;
+    if (n < a.N) {
+      src = a.idx ? (size_t)a.idx[n] : (size_t)n;
+      for (int ch = sub; ch < chunks; ch += 16) {
+        v4i v = *reinterpret_cast<const v4i *>(a.W + src * a.K + (size_t)ch * 16);
+        s += sum_bytes(v.x) + sum_bytes(v.y) + sum_bytes(v.z) + sum_bytes(v.w);
+      }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    if (sub == 0) {
+      float pbv = 0.0f;
+      if (n < a.N) {
+        float v = (float)s * a.mult;  // PrepareBias callback: cvt, mul, add
+        pbv = v + (a.bias ? a.bias[src] : 0.0f);
+      } else {
+        s = 0;
+      }
+      a.colsum[n] = s;
+      a.pb[n] = pbv;
+    }
   }
 }
 

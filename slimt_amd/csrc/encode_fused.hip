@@ -173,6 +173,11 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     }
   };
 
+  // ---- side job: the batch's shortlisted output layer (used by the decoder
+  // launch that follows this one in the stream; independent of the encoder) ----
+  for (int tile = blockIdx.x; tile < a.pack_tiles; tile += gridDim.x)
+    pack_weight_tile(a.pack, tile, tid, 1024);
+
   // ---- embedding (Model.cc:195-197) ----------------------------------------
   for (int r = wave; r < ER; r += ENW) {
     const bool ok = row_valid(r);
@@ -348,7 +353,6 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         tile_mma2<KSD>(Aq, LDA, b1, lr, lg, c0, c1);
         // b1 is consumed: fetch the next chunk's fragments into the same registers
         if (fc + 1 < NC) load_frags<KSD>(b1, L.ffn1, t1 + 16, 0, lane);
-        const int col1 = t1 * 16 + lr;
         int cs;
         float pb;
         load_epi(L.ffn1, t1, lr, cs, pb);

@@ -115,6 +115,28 @@ struct TmpAffine {  // device temporaries of one stateless qmm call
   }
 };
 
+// buffers + descriptor of a prepared weight; the packing itself is a PackArgs job
+int prepare_affine_meta(AffineW &aw, const int8_t *dW, int K, int N, const uint32_t *d_idx,
+                        const float *d_bias, float a_quant, float b_quant, PackArgs &job) {
+  const int n_tiles = (N + 15) / 16;
+  HIPCHK(aw.Wp.reserve(packed_weight_bytes(K, N)));
+  HIPCHK(aw.colsum.reserve((size_t)n_tiles * 16 * sizeof(int)));
+  HIPCHK(aw.pb.reserve((size_t)n_tiles * 16 * sizeof(float)));
+  job.W = dW; job.K = K; job.N = N; job.idx = d_idx; job.bias = d_bias;
+  job.mult = pack_mult(a_quant, b_quant);
+  job.Wp = aw.Wp.p; job.colsum = aw.colsum.as<int>(); job.pb = aw.pb.as<float>();
+  aw.w.Wp = aw.Wp.p;
+  aw.w.colsum = aw.colsum.as<int>();
+  aw.w.pb = aw.pb.as<float>();
+  aw.w.u = 1.0f / (a_quant * b_quant);  // Intgemm.inl.cc:146
+  aw.w.a_quant = a_quant;
+  aw.w.b_quant = b_quant;
+  aw.w.K = K;
+  aw.w.N = N;
+  aw.w.n_tiles = n_tiles;
+  return 0;
+}
+
 int prepare_affine(AffineW &aw, const int8_t *dW, int K, int N, const uint32_t *d_idx,
                    const float *d_bias, float a_quant, float b_quant, hipStream_t st) {
   const int n_tiles = (N + 15) / 16;
@@ -669,7 +691,7 @@ extern "C" int slimt_hip_ctx_stream(slimt_hip_ctx *ctx, void **stream) {
 
 extern "C" int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode) {
   if (!ctx) return fail(-1, "ctx is NULL");
-  if (mode != 0 && mode != 1) return fail(-1, "bad decode mode %d", mode);
+  if (mode < 0 || mode > 3) return fail(-1, "bad decode mode %d", mode);
   ctx->decode_mode = mode;
   return 0;
 }
@@ -678,7 +700,7 @@ extern "C" int slimt_hip_ctx_plan(const slimt_hip_ctx *ctx, size_t S, int *encod
                                   int *decoder_fused) {
   if (!ctx) return fail(-1, "ctx is NULL");
   const slimt_hip_model *m = ctx->model;
-  const bool fused = ctx->decode_mode == 0;
+  const bool fused = ctx->decode_mode != 1;
   if (encoder_fused)
     *encoder_fused = fused && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
   if (decoder_fused) *decoder_fused = fused && fused_decode_supported(m->D, m->F, m->H, m->Ld);
@@ -769,7 +791,9 @@ int check_batch(const slimt_hip_ctx *c, size_t B, size_t S) {
 
 // Model.cc:195-201: embedding + Encoder::forward. d_ids/d_len already in
 // ctx->ids / ctx->lengths. Result in ctx->x0.
-int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layers) {
+int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layers,
+                  const uint32_t *d_ids = nullptr, const uint32_t *d_lengths = nullptr,
+                  const PackArgs *pack = nullptr) {
   const slimt_hip_model *m = c->model;
   hipStream_t st = c->stream;
   const int M = B * S, D = m->D;
@@ -779,7 +803,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
   c->have_encoder_out = false;
   c->decode_ready = false;
   c->kv_ready = false;
-  if (c->decode_mode == 0 && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
+  if (c->decode_mode != 1 && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
     // embedding + every encoder layer + the decoder's K/V cache in one launch
     FusedEncodeArgs f;
     f.B = B; f.S = S; f.Le = m->Le; f.Ld = m->Ld;
@@ -796,11 +820,15 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.dec_v[l] = m->dec[(size_t)l].attn.v.w;
     }
     f.emb = embed_args(c);
-    f.ids = c->ids.as<uint32_t>();
-    f.lengths = c->lengths.as<uint32_t>();
+    f.ids = d_ids ? d_ids : c->ids.as<uint32_t>();
+    f.lengths = d_lengths ? d_lengths : c->lengths.as<uint32_t>();
     f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
     f.kv = c->kv.as<float>();
     f.enc_out = c->x0.as<float>();
+    if (pack) {
+      f.pack = *pack;
+      f.pack_tiles = (pack->N + 15) / 16;
+    }
     if (h_embed) {
       HIPCHK(c->dbg_embed.reserve(nbytes));
       f.embed_out = c->dbg_embed.as<float>();
@@ -1009,34 +1037,62 @@ int decoder_layers(slimt_hip_ctx *c, float *d_align, int Tmax, const uint32_t *d
   return 0;
 }
 
-int translate_device(slimt_hip_ctx *c, size_t B, size_t S, size_t n_sl, float limit_factor,
-                     uint32_t eos_id, uint32_t *d_out_ids, uint32_t *d_out_len, float *d_align,
-                     int steps_hint) {
+// d_ids / d_lengths / d_shortlist: device pointers (the caller's, or the
+// context's staging buffers). When both persistent kernels apply, a translate
+// call is exactly two launches: [encoder + K/V cache + shortlist packing] and
+// [decode loop]; nothing is copied or memset in between (small helper kernels
+// queue behind the long-running decoders of the other workers).
+int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_lengths,
+                     const uint32_t *d_shortlist, size_t B, size_t S, size_t n_sl,
+                     float limit_factor, uint32_t eos_id, uint32_t *d_out_ids, uint32_t *d_out_len,
+                     float *d_align, int steps_hint) {
   const slimt_hip_model *m = c->model;
   hipStream_t st = c->stream;
-  RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr));
-  RCCHK(decode_setup(c, n_sl));
   const size_t Tmax = (size_t)(limit_factor * (float)S);  // Model.cc:160
+  const bool fused_dec = c->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld);
+  const bool lean = fused_dec && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
   DecodeState ds;
   ds.prev = c->prev.as<uint32_t>();
   ds.out_ids = d_out_ids;
   ds.out_len = d_out_len;
   ds.finished = c->finished.as<uint8_t>();
   ds.n_finished = c->n_finished.as<int>();
-  ds.shortlist = n_sl ? c->shortlist.as<uint32_t>() : nullptr;
   ds.Tmax = (int)Tmax;
   ds.eos = eos_id;
-  HIPCHK(hipMemsetAsync(d_out_len, 0, B * 4, st));
-  HIPCHK(hipMemsetAsync(c->finished.p, 0, B, st));
-  HIPCHK(hipMemsetAsync(c->n_finished.p, 0, 16, st));
-  if (d_align) HIPCHK(hipMemsetAsync(d_align, 0, B * Tmax * S * 4, st));
+  if (lean) {
+    PackArgs job;
+    if (n_sl)
+      RCCHK(prepare_affine_meta(c->out_sl, m->out_raw.as<int8_t>(), m->D, (int)n_sl, d_shortlist,
+                                m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, job));
+    RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr));
+    c->n_sl = (int)n_sl;
+  } else {
+    if (d_ids != c->ids.as<uint32_t>())
+      HIPCHK(hipMemcpyAsync(c->ids.p, d_ids, B * S * 4, hipMemcpyDeviceToDevice, st));
+    if (d_lengths != c->lengths.as<uint32_t>())
+      HIPCHK(hipMemcpyAsync(c->lengths.p, d_lengths, B * 4, hipMemcpyDeviceToDevice, st));
+    if (n_sl && d_shortlist != c->shortlist.as<uint32_t>())
+      HIPCHK(hipMemcpyAsync(c->shortlist.p, d_shortlist, n_sl * 4, hipMemcpyDeviceToDevice, st));
+    d_lengths = c->lengths.as<uint32_t>();
+    d_shortlist = c->shortlist.as<uint32_t>();
+    RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr));
+    RCCHK(decode_setup(c, n_sl));
+    HIPCHK(hipMemsetAsync(d_out_ids, 0, B * (Tmax ? Tmax : 1) * 4, st));
+    HIPCHK(hipMemsetAsync(d_out_len, 0, B * 4, st));
+    HIPCHK(hipMemsetAsync(c->finished.p, 0, B, st));
+    HIPCHK(hipMemsetAsync(c->n_finished.p, 0, 16, st));
+    if (d_align) HIPCHK(hipMemsetAsync(d_align, 0, B * Tmax * S * 4, st));
+  }
+  ds.shortlist = n_sl ? d_shortlist : nullptr;
   const AffineW &out = output_layer(c);
-  if (c->decode_mode == 0 && fused_decode_supported(m->D, m->F, m->H, m->Ld)) {
+  if (c->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld)) {
     // the whole greedy loop in one persistent launch (decode_fused.hip)
     FusedDecodeArgs f;
     f.B = (int)B; f.S = (int)S; f.Ld = m->Ld;
     f.max_steps = steps_hint > 0 ? steps_hint : (int)(Tmax > 1 ? Tmax : 1);
     f.Tmax = (int)Tmax;
+    f.rows_per_wg = c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : 0;
+    const int rows = fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, f.rows_per_wg);
     for (int l = 0; l < m->Ld; ++l) {
       const DecLayerW &L = m->dec[(size_t)l];
       FusedLayerW &fl = f.L[l];
@@ -1050,7 +1106,7 @@ int translate_device(slimt_hip_ctx *c, size_t B, size_t S, size_t n_sl, float li
     f.shortlist = ds.shortlist;
     f.emb = embed_args(c);
     f.kv = c->kv.as<float>();
-    f.lengths = c->lengths.as<uint32_t>();
+    f.lengths = d_lengths;
     f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
     f.eos = eos_id;
     f.out_ids = d_out_ids;
@@ -1062,7 +1118,7 @@ int translate_device(slimt_hip_ctx *c, size_t B, size_t S, size_t n_sl, float li
     }
     const double macs = (double)B * f.max_steps *
                         (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.N);
-    const double wbytes = (double)f.max_steps * ((B + 15) / 16) *
+    const double wbytes = (double)f.max_steps * ((B + rows - 1) / rows) *
                           (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.n_tiles * 16);
     ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);
     HIPCHK(launch_decode_fused(f, m->D, m->F, m->H, st));
@@ -1122,13 +1178,8 @@ extern "C" int slimt_hip_translate_device(slimt_hip_ctx *ctx, const uint32_t *d_
   if (n_shortlist > (size_t)ctx->model->V) return fail(-1, "shortlist larger than the vocabulary");
   if (n_shortlist && !d_shortlist) return fail(-1, "shortlist is NULL");
   HIPCHK(hipSetDevice(ctx->model->device));
-  hipStream_t st = ctx->stream;
-  HIPCHK(hipMemcpyAsync(ctx->ids.p, d_src_ids, B * S * 4, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->lengths.p, d_lengths, B * 4, hipMemcpyDeviceToDevice, st));
-  if (n_shortlist)
-    HIPCHK(hipMemcpyAsync(ctx->shortlist.p, d_shortlist, n_shortlist * 4, hipMemcpyDeviceToDevice, st));
-  return translate_device(ctx, B, S, n_shortlist, limit_factor, eos_id, d_out_ids, d_out_len,
-                          d_align, steps_hint);
+  return translate_device(ctx, d_src_ids, d_lengths, d_shortlist, B, S, n_shortlist, limit_factor,
+                          eos_id, d_out_ids, d_out_len, d_align, steps_hint);
 }
 
 extern "C" int slimt_hip_translate(slimt_hip_ctx *ctx, const uint32_t *src_ids,
@@ -1157,9 +1208,10 @@ extern "C" int slimt_hip_translate(slimt_hip_ctx *ctx, const uint32_t *src_ids,
   HIPCHK(hipMemcpyAsync(ctx->lengths.p, lengths, B * 4, hipMemcpyHostToDevice, st));
   if (n_shortlist)
     HIPCHK(hipMemcpyAsync(ctx->shortlist.p, shortlist, n_shortlist * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemsetAsync(ctx->out_ids.p, 0, B * Talloc * 4, st));
-  RCCHK(translate_device(ctx, B, S, n_shortlist, limit_factor, eos_id, ctx->out_ids.as<uint32_t>(),
-                         ctx->out_len.as<uint32_t>(), align ? ctx->align.as<float>() : nullptr, 0));
+  RCCHK(translate_device(ctx, ctx->ids.as<uint32_t>(), ctx->lengths.as<uint32_t>(),
+                         ctx->shortlist.as<uint32_t>(), B, S, n_shortlist, limit_factor, eos_id,
+                         ctx->out_ids.as<uint32_t>(), ctx->out_len.as<uint32_t>(),
+                         align ? ctx->align.as<float>() : nullptr, 0));
   HIPCHK(hipMemcpyAsync(out_ids, ctx->out_ids.p, B * Talloc * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(out_len, ctx->out_len.p, B * 4, hipMemcpyDeviceToHost, st));
   if (align) HIPCHK(hipMemcpyAsync(align, ctx->align.p, B * Talloc * S * 4, hipMemcpyDeviceToHost, st));

@@ -78,7 +78,7 @@ struct slimt_hip_ctx {
   bool decode_ready = false;
   bool kv_ready = false;  // cross-attention K/V already produced by the fused encoder
   slimt_hip::DevBuf dbg_embed, dbg_layers;
-  int decode_mode = 0;  // 0 auto (fused when supported), 1 step-wise launches
+  int decode_mode = 0;  // 0 auto (fused when supported), 1 step-wise launches, 2 / 3 fused with 16 / 32 rows per workgroup
   slimt_hip::DevBuf stamps;  // diagnostic phase stamps of the fused decoder
   int stamp_step = -1;
   // encoder workspace

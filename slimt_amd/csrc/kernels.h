@@ -27,6 +27,24 @@ struct PreparedWeight {
 
 size_t packed_weight_bytes(int K, int N);
 
+// One weight-packing job (load time; once per batch for the shortlisted output
+// layer): rows idx[n] (or n) of W [N_src][K] -> MFMA fragment order + colsum + pb.
+struct PackArgs {
+  const int8_t *W = nullptr;
+  int K = 0, N = 0;
+  const uint32_t *idx = nullptr;  // nullable
+  const float *bias = nullptr;    // nullable, indexed by SOURCE row
+  float mult = 0.f;  // (-1 * (127/aq * 127/bq)) / 127, Intgemm.inl.cc:123-126
+  void *Wp = nullptr;
+  int *colsum = nullptr;
+  float *pb = nullptr;
+};
+inline float pack_mult(float a_quant, float b_quant) {
+  const float a_alpha = 127.0f / a_quant;
+  const float b_alpha = 127.0f / b_quant;
+  return (-1.0f * (a_alpha * b_alpha)) / 127.0f;
+}
+
 // W: device int8 [N_src][K]; idx (device, nullable) selects/gathers rows;
 // bias (device, nullable) is indexed by SOURCE row. Writes Wp/colsum/pb.
 hipError_t launch_pack_weight(const int8_t *W, int K, int N, const uint32_t *idx,
@@ -222,8 +240,10 @@ struct FusedDecodeArgs {
   float *attn = nullptr;        // nullable debug [B][H][S]
   unsigned long long *stamps = nullptr;  // nullable diagnostic [64] phase stamps
   int stamp_step = 0;
+  int rows_per_wg = 0;  // 0 = auto, 16 / 32 = force (32 only where supported)
 };
 bool fused_decode_supported(int D, int F, int H, int Ld);
+int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
 
 // ---- persistent fused encoder (encode_fused.hip) ------------------------------
@@ -242,6 +262,8 @@ struct FusedEncodeArgs {
   const uint32_t *lengths = nullptr;  // [B]
   float alpha = 0.f, eps = 1e-6f;
   float *kv = nullptr;         // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]
+  PackArgs pack;               // the batch's shortlisted output layer, packed by the
+  int pack_tiles = 0;          // encoder's workgroups on the side (0 = nothing to pack)
   float *enc_out = nullptr;    // nullable [B*S][D]
   float *layer_out = nullptr;  // nullable [Le][B*S][D]
   float *embed_out = nullptr;  // nullable [B*S][D]

@@ -26,66 +26,9 @@ size_t packed_weight_bytes(int K, int N) {
   return n_tiles * (size_t)(K / 64) * 64 * 16;
 }
 
-struct PackArgs {
-  const int8_t *W;
-  int K, N;
-  const uint32_t *idx;
-  const float *bias;
-  float mult;  // (-1 * (127/aq * 127/bq)) / 127, Intgemm.inl.cc:123-126
-  v4i *Wp;
-  int *colsum;
-  float *pb;
-};
-
-__device__ __forceinline__ int sum_bytes(int w) {
-  return (int)(int8_t)(w & 0xff) + (int)(int8_t)((w >> 8) & 0xff) +
-         (int)(int8_t)((w >> 16) & 0xff) + (int)(int8_t)((w >> 24) & 0xff);
-}
-
 // one block per 16-column tile of the logical [K, N] matrix
 __global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs a) {
-  const int tid = threadIdx.x;
-  const int ntile = blockIdx.x;
-  const int KS = a.K / 64;
-  const int chunks = a.K / 16;  // 16-byte chunks per row
-  for (int c = tid; c < 16 * chunks; c += 256) {
-    const int r = c / chunks, ch = c % chunks;
-    const int n = ntile * 16 + r;
-    v4i v = {0, 0, 0, 0};
-    if (n < a.N) {
-      const size_t src = a.idx ? (size_t)a.idx[n] : (size_t)n;
-      v = *reinterpret_cast<const v4i *>(a.W + src * a.K + (size_t)ch * 16);
-    }
-    const int ks = ch >> 2, kg = ch & 3;
-    a.Wp[((size_t)ntile * KS + ks) * 64 + kg * 16 + r] = v;
-  }
-  // column sums: 16 threads per row
-  const int r = tid >> 4, sub = tid & 15;
-  const int n = ntile * 16 + r;
-  int s = 0;
-  size_t src = 0;
-  if (n < a.N) {
-    src = a.idx ? (size_t)a.idx[n] : (size_t)n;
-    for (int ch = sub; ch < chunks; ch += 16) {
-      v4i v = *reinterpret_cast<const v4i *>(a.W + src * a.K + (size_t)ch * 16);
-      s += sum_bytes(v.x) + sum_bytes(v.y) + sum_bytes(v.z) + sum_bytes(v.w);
-    }
-  }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  s += __shfl_xor(s, 8, 64);
-  if (sub == 0) {
-    float pbv = 0.0f;
-    if (n < a.N) {
-      float v = (float)s * a.mult;  // PrepareBias callback: cvt, mul, add
-      pbv = v + (a.bias ? a.bias[src] : 0.0f);
-    } else {
-      s = 0;
-    }
-    a.colsum[n] = s;
-    a.pb[n] = pbv;
-  }
+  pack_weight_tile(a, blockIdx.x, threadIdx.x, 256);
 }
 
 hipError_t launch_pack_weight(const int8_t *W, int K, int N, const uint32_t *idx,
@@ -97,10 +40,8 @@ hipError_t launch_pack_weight(const int8_t *W, int K, int N, const uint32_t *idx
   a.N = N;
   a.idx = idx;
   a.bias = bias;
-  float a_alpha = 127.0f / a_quant;
-  float b_alpha = 127.0f / b_quant;
-  a.mult = (-1.0f * (a_alpha * b_alpha)) / 127.0f;
-  a.Wp = reinterpret_cast<v4i *>(Wp);
+  a.mult = pack_mult(a_quant, b_quant);
+  a.Wp = Wp;
   a.colsum = colsum;
   a.pb = pb;
   const int n_tiles = (N + 15) / 16;

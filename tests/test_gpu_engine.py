@@ -19,6 +19,8 @@ CONFIGS = [
     ("tiny11", 6.0, 16, 16, 1024, True),
     ("tiny11", 6.0, 19, 32, 2048, True),
     ("tiny11", 6.0, 7, 11, None, True),
+    ("tiny11", 6.0, 45, 32, 2048, True),   # 32-row decoder tiles: one full, one partly filled
+    ("tiny11", 6.0, 36, 20, None, True),   # ... full vocabulary, second tile only in rows 0..3
     ("tiny11", 6.0, 5, 40, 1024, True),    # S > 32: layer-by-layer encoder, generic decoder attention
     ("tiny11", 6.0, 3, 70, 512, True),     # S > 64: two key slots per lane
     ("tiny11", 6.0, 2, 128, 512, True),    # the reference's wrap length (Frontend.hh:27)
@@ -108,8 +110,9 @@ def test_translate_tokens_lengths_alignments(hip, oracle, engines, preset, eos_b
     w_out, w_ln, w_al, steps = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
     oracle.set_mode(oracle.FAITHFUL)
     # mode 0: persistent fused decoder (when the shape supports it);
-    # mode 1: one launch per stage and step. Same tokens either way.
-    for mode in (0, 1):
+    # mode 1: one launch per stage and step; modes 2 / 3: the persistent decoder
+    # with 16 / 32 sentences per workgroup. Same tokens every way.
+    for mode in (0, 1, 2, 3):
         ctx.set_decode_mode(mode)
         out, ln, al = ctx.translate(ids, lens, sl, limit_factor=1.5, eos_id=0, want_align=True)
         assert np.array_equal(ln, w_ln), (mode, ln, w_ln)
