@@ -111,13 +111,22 @@ def main():
 
     if not torch.cuda.is_available() or capi.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # SLIMT_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- exercises the
+    # torchrun path (rendezvous, barriers, max/sum reduction, rank-0 JSON) on a
+    # one-GPU box. Its numbers mean nothing; the real N-GPU run uses RCCL.
+    rehearsal = os.environ.get("SLIMT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
         dist = dist_mod
 
     B, S = args.batch, args.src_len
@@ -190,7 +199,8 @@ def main():
         c.profile_enable(capi.K_NONE)
 
     from slimt_amd.sharding import reduce_timing
-    dt_max, total_tokens_per_step = reduce_timing(dist, dev, dt, tokens_per_step)
+    dt_max, total_tokens_per_step = reduce_timing(dist, torch.device("cpu") if rehearsal else dev, dt,
+                                                  tokens_per_step)
 
     per_kernel = None
     if args.all_kernels and rank == 0:
