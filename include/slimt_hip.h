@@ -183,6 +183,36 @@ int slimt_hip_decode_begin(slimt_hip_ctx *ctx, const uint32_t *shortlist,
 int slimt_hip_decode_step(slimt_hip_ctx *ctx, const uint32_t *prev,
                           float *logits, float *attn, float *states);
 
+/* ---- lexical shortlist (next row f3: slimt/Shortlist.{hh,cc}) --------------
+ * Replaces ShortlistGenerator (Shortlist.hh:38-90): _create = the constructor's
+ * load() over the binary shortlist blob (Shortlist.cc:41-104; layout
+ * Shortlist.hh:77-84), _generate = generate() (Shortlist.cc:115-175) as Model::
+ * forward calls it per batch on Input::words() (Model.cc:117-120, Input.cc:24).
+ * The blob is copied to the device; the caller keeps ownership of `blob`.
+ * check != 0 also verifies the header checksum (Shortlist.cc:66-76). Offsets and
+ * ids are always range-checked at load (out-of-range data is undefined
+ * behaviour in the reference; here it is rejected). */
+typedef struct slimt_hip_shortlist slimt_hip_shortlist;
+int slimt_hip_shortlist_create(const void *blob, size_t blob_size, size_t source_vocab,
+                               size_t target_vocab, int shared, int check, int device,
+                               slimt_hip_shortlist **out);
+int slimt_hip_shortlist_destroy(slimt_hip_shortlist *sl);
+/* header fields (Shortlist.cc:78-81) */
+int slimt_hip_shortlist_info(const slimt_hip_shortlist *sl, uint64_t *frequent, uint64_t *best);
+/* Host arrays: src_ids [B][S] padded rows, lengths [B] (only the first lengths[b]
+ * tokens of a row are words). out_ids: capacity >= target_vocab; *n_out = number
+ * of ids written (sorted, unique, a multiple of 8 when enough ids are free). */
+int slimt_hip_shortlist_generate(slimt_hip_shortlist *sl, const uint32_t *src_ids,
+                                 const uint32_t *lengths, size_t B, size_t S, uint32_t *out_ids,
+                                 size_t *n_out);
+/* Device arrays, asynchronous on ctx's stream (d_out_ids: capacity >=
+ * target_vocab uint32, d_n_out: one uint32), e.g. ahead of
+ * slimt_hip_translate_device on the same context. */
+int slimt_hip_shortlist_generate_device(slimt_hip_shortlist *sl, slimt_hip_ctx *ctx,
+                                        const uint32_t *d_src_ids, const uint32_t *d_lengths,
+                                        size_t B, size_t S, uint32_t *d_out_ids,
+                                        uint32_t *d_n_out);
+
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, HIP events bracket every launch of kernel family `kernel_id`
  * on the ctx stream; slimt_hip_profile_read returns the number of launches

@@ -88,6 +88,12 @@ def lib():
         L.so_encode.argtypes = [vp, vp, vp, sz, sz, vp]
         L.so_encoder_layer.argtypes = [vp, i32, vp, vp, sz, sz, vp, vp]
         L.so_decode_step.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp, sz, vp, vp]
+        L.so_shortlist_checksum.restype = C.c_uint64
+        L.so_shortlist_checksum.argtypes = [vp, sz]
+        L.so_shortlist_parse.restype = i32
+        L.so_shortlist_parse.argtypes = [vp, sz, i32, sz, vp]
+        L.so_shortlist_generate.restype = sz
+        L.so_shortlist_generate.argtypes = [vp, i32, sz, sz, vp, sz, vp]
         L.so_translate.restype = sz
         L.so_translate.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, C.c_uint32, vp, vp, vp]
         _lib = L
@@ -296,3 +302,42 @@ class OracleModel:
                                    0 if sl is None else sl.size, limit_factor, eos_id,
                                    _p(out_ids), _p(out_len), _p(align))
         return out_ids, out_len, align, int(steps)
+
+
+class _Shortlist(C.Structure):
+    _fields_ = [("frequent", C.c_uint64), ("best", C.c_uint64),
+                ("word_to_offset_size", C.c_uint64), ("shortlist_size", C.c_uint64),
+                ("word_to_offset", C.c_void_p), ("shortlist", C.c_void_p)]
+
+
+def shortlist_checksum(blob: bytes) -> int:
+    return int(lib().so_shortlist_checksum(blob, len(blob)))
+
+
+class OracleShortlist:
+    """ShortlistGenerator (Shortlist.cc:41-175) over a binary shortlist blob."""
+
+    def __init__(self, blob: bytes, source_vocab: int, target_vocab: int, shared: bool = False,
+                 check: bool = False):
+        self._blob = bytes(blob)  # the parsed struct points into it
+        self._buf = C.create_string_buffer(self._blob, len(self._blob))
+        self._sl = _Shortlist()
+        rc = lib().so_shortlist_parse(self._buf, len(self._blob), int(check), target_vocab,
+                                      C.byref(self._sl))
+        if rc != 0:
+            raise ValueError(f"binary shortlist rejected (code {rc})")
+        self.source_vocab, self.target_vocab, self.shared = source_vocab, target_vocab, shared
+        self.frequent, self.best = int(self._sl.frequent), int(self._sl.best)
+
+    def generate(self, ids: np.ndarray, lengths: np.ndarray) -> np.ndarray:
+        """ids [B,S] padded, lengths [B]: the words of Input::words() are the
+        first lengths[b] tokens of every row (Input.cc:24)."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        words = np.concatenate([ids[b, : int(lengths[b])] for b in range(ids.shape[0])]) \
+            if ids.shape[0] else np.zeros((0,), np.uint32)
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        out = np.zeros((max(1, self.target_vocab),), dtype=np.uint32)
+        n = lib().so_shortlist_generate(C.byref(self._sl), int(self.shared), self.source_vocab,
+                                        self.target_vocab, _p(words), words.size, _p(out))
+        return out[: int(n)].copy()
+

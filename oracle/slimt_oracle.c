@@ -1000,3 +1000,80 @@ size_t so_translate(const so_model *m, const uint32_t *src_ids,
   free(enc); free(mask);
   return steps;
 }
+
+/* ---- lexical shortlist (slimt/Shortlist.{hh,cc}) -------------------------- */
+
+/* hash_combine over uint64 words starting at header.frequent (Utils.hh:47-67;
+ * std::hash<uint64_t> is the identity in libstdc++) */
+uint64_t so_shortlist_checksum(const void *blob, size_t size) {
+  if (size < 16) return 0;
+  const unsigned char *p = (const unsigned char *)blob + 16;
+  size_t n = (size - 16) / 8; /* Shortlist.cc:67-73 */
+  uint64_t seed = 0;
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t v;
+    memcpy(&v, p + 8 * i, 8);
+    seed ^= v + 0x9e3779b9ull + (seed << 6) + (seed >> 2);
+  }
+  return seed;
+}
+
+int so_shortlist_parse(const void *blob, size_t size, int check, size_t target_vocab,
+                       so_shortlist *out) {
+  uint64_t h[6];
+  if (size < sizeof(h)) return 1; /* Shortlist.cc:49-51 */
+  memcpy(h, blob, sizeof(h));
+  if (h[0] != SO_SHORTLIST_MAGIC) return 2; /* :56 */
+  uint64_t expected = sizeof(h) + h[4] * 8 + h[5] * 4; /* :58-60 */
+  if (expected != size) return 3;
+  if (check && so_shortlist_checksum(blob, size) != h[1]) return 4; /* :66-76 */
+  out->frequent = h[2];
+  out->best = h[3];
+  out->word_to_offset_size = h[4];
+  out->shortlist_size = h[5];
+  out->word_to_offset = (const uint64_t *)((const char *)blob + sizeof(h));
+  out->shortlist = (const uint32_t *)((const char *)blob + sizeof(h) + h[4] * 8);
+  if (check) { /* content_check(), Shortlist.cc:16-38 */
+    if (h[4] == 0) return 6;
+    for (uint64_t i = 0; i + 1 < h[4]; ++i)
+      if (out->word_to_offset[i] >= h[5]) return 5;
+    if (out->word_to_offset[h[4] - 1] != h[5]) return 6;
+    for (uint64_t j = 0; j < h[5]; ++j)
+      if (out->shortlist[j] >= target_vocab) return 7;
+  }
+  return 0;
+}
+
+size_t so_shortlist_generate(const so_shortlist *sl, int shared, size_t source_vocab,
+                             size_t target_vocab, const uint32_t *words, size_t n_words,
+                             uint32_t *out) {
+  unsigned char *source_table = (unsigned char *)calloc(source_vocab ? source_vocab : 1, 1);
+  unsigned char *target_table = (unsigned char *)calloc(target_vocab ? target_vocab : 1, 1);
+  /* most frequent words, Shortlist.cc:125-127 */
+  for (uint64_t i = 0; i < sl->frequent && i < target_vocab; ++i) target_table[i] = 1;
+  /* unique source words -> their aligned target words, :131-145 */
+  for (size_t k = 0; k < n_words; ++k) {
+    uint32_t word = words[k];
+    if (shared) target_table[word] = 1;
+    if (!source_table[word]) {
+      uint64_t begin = sl->word_to_offset[word], end = sl->word_to_offset[word + 1];
+      for (uint64_t j = begin; j < end; ++j) target_table[sl->shortlist[j]] = 1;
+      source_table[word] = 1;
+    }
+  }
+  /* multiple-of-eight patch, :148-165 */
+  size_t ones = 0;
+  for (size_t i = 0; i < target_vocab; ++i) ones += target_table[i];
+  for (size_t i = sl->frequent; i < target_vocab && ones % 8 != 0; ++i)
+    if (!target_table[i]) {
+      target_table[i] = 1;
+      ones++;
+    }
+  /* bucket sort, :168-173 */
+  size_t n = 0;
+  for (size_t i = 0; i < target_vocab; ++i)
+    if (target_table[i]) out[n++] = (uint32_t)i;
+  free(source_table);
+  free(target_table);
+  return n;
+}

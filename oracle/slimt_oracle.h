@@ -147,6 +147,31 @@ size_t so_translate(const so_model *m, const uint32_t *src_ids,
 /* Input.cc:20-63: mask from lengths: 0 on tokens, -99999999 on pads */
 void so_make_mask(const uint32_t *lengths, size_t B, size_t S, float *mask);
 
+/* ---- lexical shortlist (slimt/Shortlist.{hh,cc}) -------------------------- */
+/* Binary blob layout, Shortlist.hh:77-84 + Shortlist.cc:41-104: header of six
+ * uint64 {magic, checksum, frequent, best, word_to_offset_size, shortlist_size},
+ * then word_to_offset[uint64], then shortlist[uint32]. */
+#define SO_SHORTLIST_MAGIC 0xF11A48D5013417F5ull /* Shortlist.hh:40 */
+typedef struct so_shortlist {
+  uint64_t frequent, best, word_to_offset_size, shortlist_size;
+  const uint64_t *word_to_offset; /* into the blob */
+  const uint32_t *shortlist;      /* into the blob */
+} so_shortlist;
+/* checksum of the blob body as ShortlistGenerator::load computes it
+ * (Shortlist.cc:66-76, Utils.hh:47-67 with libstdc++'s identity std::hash) */
+uint64_t so_shortlist_checksum(const void *blob, size_t size);
+/* load(): 0 on success; 1 too short, 2 bad magic, 3 size mismatch, 4 checksum,
+ * 5 offsets out of range, 6 last offset != size, 7 id >= target vocab
+ * (the reference aborts in each case, Shortlist.cc:16-38,49-76). */
+int so_shortlist_parse(const void *blob, size_t size, int check, size_t target_vocab,
+                       so_shortlist *out);
+/* ShortlistGenerator::generate (Shortlist.cc:115-175): words = the batch's
+ * source tokens without padding (Input::words(), Input.cc:24). out: sorted
+ * unique target ids, capacity target_vocab; returns their count. */
+size_t so_shortlist_generate(const so_shortlist *sl, int shared, size_t source_vocab,
+                             size_t target_vocab, const uint32_t *words, size_t n_words,
+                             uint32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,8 @@ LIB_DIR = os.path.join(HERE, "lib")
 # SLIMT_HIP_LIB: build/load an alternative library file (kernel experiments only)
 LIB_PATH = os.environ.get("SLIMT_HIP_LIB") or os.path.join(LIB_DIR, "libslimt_hip.so")
 
-SOURCES = ["kernels.hip", "decode_kernels.hip", "decode_fused.hip", "encode_fused.hip", "engine.cpp"]
+SOURCES = ["kernels.hip", "decode_kernels.hip", "decode_fused.hip", "encode_fused.hip", "shortlist.hip",
+           "engine.cpp"]
 HEADERS = ["kernels.h", "engine.h", "device_common.h", os.path.join(ROOT, "include", "slimt_hip.h")]
 
 # -ffp-contract=off: the float epilogues are written operation by operation
@@ -72,7 +73,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 HOST_DIR = os.path.join(HERE, "host")
 HOST_TEST = os.path.join(LIB_DIR, "slimt_hip_host_test")
-HOST_SOURCES = ["Io.cc", "QMM.cc", "Model.cc", "host_test.cc"]
+HOST_SOURCES = ["Io.cc", "QMM.cc", "Model.cc", "Shortlist.cc", "host_test.cc"]
 
 
 def build_host(force: bool = False) -> str:

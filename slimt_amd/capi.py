@@ -26,6 +26,8 @@ SYMBOLS = [
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
     "slimt_hip_debug_decode_stamps",
+    "slimt_hip_shortlist_create", "slimt_hip_shortlist_destroy", "slimt_hip_shortlist_info",
+    "slimt_hip_shortlist_generate", "slimt_hip_shortlist_generate_device",
 ]
 
 K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED, K_ENCODE_FUSED = range(9)
@@ -97,6 +99,11 @@ def lib():
     L.slimt_hip_profile_read.argtypes = [vp, vp, vp, vp, vp]
     L.slimt_hip_profile_reset.argtypes = [vp]
     L.slimt_hip_debug_decode_stamps.argtypes = [vp, i32, vp, sz]
+    L.slimt_hip_shortlist_create.argtypes = [vp, sz, sz, sz, i32, i32, i32, vp]
+    L.slimt_hip_shortlist_destroy.argtypes = [vp]
+    L.slimt_hip_shortlist_info.argtypes = [vp, vp, vp]
+    L.slimt_hip_shortlist_generate.argtypes = [vp, vp, vp, sz, sz, vp, vp]
+    L.slimt_hip_shortlist_generate_device.argtypes = [vp, vp, vp, vp, sz, sz, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("slimt_hip_abi_version",):
@@ -365,3 +372,43 @@ class Context:
                                           C.byref(wbytes)))
         return {"launches": n.value, "total_ms": ms.value, "int8_macs": macs.value,
                 "weight_bytes": wbytes.value}
+
+
+class ShortlistGenerator:
+    """slimt::ShortlistGenerator (Shortlist.hh:38-90) on the device."""
+
+    def __init__(self, blob: bytes, source_vocab: int, target_vocab: int, shared: bool = False,
+                 check: bool = False, device: int = 0):
+        self.h = C.c_void_p()
+        self.target_vocab = target_vocab
+        buf = bytes(blob)
+        _chk(lib().slimt_hip_shortlist_create(buf, len(buf), source_vocab, target_vocab, int(shared),
+                                              int(check), device, C.byref(self.h)))
+        f, b = C.c_uint64(), C.c_uint64()
+        _chk(lib().slimt_hip_shortlist_info(self.h, C.byref(f), C.byref(b)))
+        self.frequent, self.best = int(f.value), int(b.value)
+
+    def generate(self, ids, lengths) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        B, S = ids.shape
+        out = np.zeros((self.target_vocab,), dtype=np.uint32)
+        n = C.c_size_t()
+        _chk(lib().slimt_hip_shortlist_generate(self.h, _p(ids), _p(lengths), B, S, _p(out), C.byref(n)))
+        return out[: int(n.value)].copy()
+
+    def generate_device(self, ctx: "Context", d_ids: int, d_lengths: int, B: int, S: int, d_out: int,
+                        d_n: int) -> None:
+        _chk(lib().slimt_hip_shortlist_generate_device(self.h, ctx.h, d_ids, d_lengths, B, S, d_out, d_n))
+
+    def close(self):
+        if self.h:
+            lib().slimt_hip_shortlist_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

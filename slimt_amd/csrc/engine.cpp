@@ -1346,3 +1346,162 @@ extern "C" int slimt_hip_debug_decode_stamps(slimt_hip_ctx *ctx, int step, uint6
   }
   return 0;
 }
+
+// ---------------------------------------------------------------------------
+// lexical shortlist (slimt/Shortlist.{hh,cc})
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr uint64_t kShortlistMagic = 0xF11A48D5013417F5ull;  // Shortlist.hh:40
+
+// hash_combine over uint64 words from header.frequent on (Shortlist.cc:66-73,
+// Utils.hh:47-67 with libstdc++'s identity std::hash<uint64_t>)
+uint64_t shortlist_checksum(const unsigned char *blob, size_t size) {
+  uint64_t seed = 0;
+  for (size_t i = 16; i + 8 <= size; i += 8) {
+    uint64_t v;
+    std::memcpy(&v, blob + i, 8);
+    seed ^= v + 0x9e3779b9ull + (seed << 6) + (seed >> 2);
+  }
+  return seed;
+}
+
+void shortlist_args(const slimt_hip_shortlist *sl, const uint32_t *d_ids, const uint32_t *d_len,
+                    size_t B, size_t S, uint32_t *d_out, uint32_t *d_n, ShortlistArgs &a) {
+  a.w2o = sl->w2o.as<unsigned long long>();
+  a.lists = sl->lists.as<uint32_t>();
+  a.frequent = sl->frequent;
+  a.shared = sl->shared ? 1 : 0;
+  a.src_vocab = (int)sl->source_vocab;
+  a.tgt_vocab = (int)sl->target_vocab;
+  a.ids = d_ids;
+  a.lengths = d_len;
+  a.B = (int)B;
+  a.S = (int)S;
+  a.out = d_out;
+  a.n_out = d_n;
+}
+
+}  // namespace
+
+extern "C" int slimt_hip_shortlist_create(const void *blob, size_t blob_size, size_t source_vocab,
+                                          size_t target_vocab, int shared, int check, int device,
+                                          slimt_hip_shortlist **out) {
+  if (!blob || !out) return fail(-1, "null argument");
+  if (source_vocab == 0 || target_vocab == 0 || source_vocab > (1u << 22) || target_vocab > (1u << 22))
+    return fail(-1, "bad vocabulary sizes %zu / %zu", source_vocab, target_vocab);
+  if (shortlist_lds_bytes((int)source_vocab, (int)target_vocab) > 160 * 1024)
+    return fail(-1, "vocabularies too large for the on-chip truth tables");
+  uint64_t h[6];
+  if (blob_size < sizeof(h))  // Shortlist.cc:49-51
+    return fail(-1, "shortlist length too short to have a header: %zu", blob_size);
+  const unsigned char *p = static_cast<const unsigned char *>(blob);
+  std::memcpy(h, p, sizeof(h));
+  if (h[0] != kShortlistMagic) return fail(-1, "incorrect magic in binary shortlist");  // :56
+  const uint64_t n_off = h[4], n_ids = h[5];
+  if (n_off > (1ull << 32) || n_ids > (1ull << 40)) return fail(-1, "implausible shortlist header");
+  const uint64_t expected = sizeof(h) + n_off * 8 + n_ids * 4;  // :58-64
+  if (expected != blob_size)
+    return fail(-1, "shortlist header claims file size should be %llu but file is %zu",
+                (unsigned long long)expected, blob_size);
+  if (check && shortlist_checksum(p, blob_size) != h[1])  // :66-76
+    return fail(-1, "checksum check failed: this binary shortlist is corrupted");
+  if (n_off != source_vocab + 1)
+    return fail(-1, "shortlist has %llu offsets, expected source vocabulary + 1 = %zu",
+                (unsigned long long)n_off, source_vocab + 1);
+  // content_check (Shortlist.cc:16-38), always: the kernel trusts these ranges
+  const unsigned char *po = p + sizeof(h), *pl = po + n_off * 8;
+  uint64_t prev = 0;
+  for (uint64_t i = 0; i < n_off; ++i) {
+    uint64_t v;
+    std::memcpy(&v, po + 8 * i, 8);
+    if (v > n_ids || v < prev) return fail(-1, "offset table not within shortlist size");
+    prev = v;
+  }
+  if (prev != n_ids) return fail(-1, "word_to_offset != shortlist_size");
+  for (uint64_t j = 0; j < n_ids; ++j) {
+    uint32_t v;
+    std::memcpy(&v, pl + 4 * j, 4);
+    if (v >= target_vocab) return fail(-1, "shortlist indices are out of bounds");
+  }
+  HIPCHK(hipSetDevice(device));
+  auto *sl = new slimt_hip_shortlist();
+  sl->device = device;
+  sl->frequent = h[2];
+  sl->best = h[3];
+  sl->source_vocab = source_vocab;
+  sl->target_vocab = target_vocab;
+  sl->shared = shared != 0;
+  hipError_t e = sl->w2o.reserve(n_off * 8);
+  if (e == hipSuccess) e = sl->lists.reserve(n_ids ? n_ids * 4 : 4);
+  if (e == hipSuccess) e = sl->out.reserve(target_vocab * 4);
+  if (e == hipSuccess) e = sl->n_out.reserve(4);
+  if (e == hipSuccess) e = hipMemcpy(sl->w2o.p, po, n_off * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess && n_ids) e = hipMemcpy(sl->lists.p, pl, n_ids * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    slimt_hip_shortlist_destroy(sl);
+    return fail((int)e, "shortlist upload: %s", hipGetErrorString(e));
+  }
+  *out = sl;
+  return 0;
+}
+
+extern "C" int slimt_hip_shortlist_destroy(slimt_hip_shortlist *sl) {
+  if (!sl) return 0;
+  (void)hipSetDevice(sl->device);
+  for (DevBuf *b : {&sl->w2o, &sl->lists, &sl->ids, &sl->lengths, &sl->out, &sl->n_out}) b->release();
+  delete sl;
+  return 0;
+}
+
+extern "C" int slimt_hip_shortlist_info(const slimt_hip_shortlist *sl, uint64_t *frequent,
+                                        uint64_t *best) {
+  if (!sl) return fail(-1, "shortlist is NULL");
+  if (frequent) *frequent = sl->frequent;
+  if (best) *best = sl->best;
+  return 0;
+}
+
+extern "C" int slimt_hip_shortlist_generate(slimt_hip_shortlist *sl, const uint32_t *src_ids,
+                                            const uint32_t *lengths, size_t B, size_t S,
+                                            uint32_t *out_ids, size_t *n_out) {
+  if (!sl || !src_ids || !lengths || !out_ids || !n_out) return fail(-1, "null argument");
+  if (B == 0 || S == 0) return fail(-1, "empty batch");
+  if (B * S > (1u << 28)) return fail(-1, "batch too large");
+  for (size_t b = 0; b < B; ++b) {
+    if (lengths[b] > S) return fail(-1, "length %u > S", lengths[b]);
+    for (size_t j = 0; j < lengths[b]; ++j)
+      if (src_ids[b * S + j] >= sl->source_vocab)
+        return fail(-1, "token id %u out of range", src_ids[b * S + j]);
+  }
+  HIPCHK(hipSetDevice(sl->device));
+  HIPCHK(sl->ids.reserve(B * S * 4));
+  HIPCHK(sl->lengths.reserve(B * 4));
+  HIPCHK(hipMemcpy(sl->ids.p, src_ids, B * S * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(sl->lengths.p, lengths, B * 4, hipMemcpyHostToDevice));
+  ShortlistArgs a;
+  shortlist_args(sl, sl->ids.as<uint32_t>(), sl->lengths.as<uint32_t>(), B, S,
+                 sl->out.as<uint32_t>(), sl->n_out.as<uint32_t>(), a);
+  HIPCHK(launch_shortlist_generate(a, nullptr));
+  uint32_t n = 0;
+  HIPCHK(hipMemcpy(&n, sl->n_out.p, 4, hipMemcpyDeviceToHost));
+  if (n > sl->target_vocab) return fail(-1, "shortlist kernel returned %u ids", n);
+  if (n) HIPCHK(hipMemcpy(out_ids, sl->out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  *n_out = n;
+  return 0;
+}
+
+extern "C" int slimt_hip_shortlist_generate_device(slimt_hip_shortlist *sl, slimt_hip_ctx *ctx,
+                                                   const uint32_t *d_src_ids,
+                                                   const uint32_t *d_lengths, size_t B, size_t S,
+                                                   uint32_t *d_out_ids, uint32_t *d_n_out) {
+  if (!sl || !ctx || !d_src_ids || !d_lengths || !d_out_ids || !d_n_out)
+    return fail(-1, "null argument");
+  if (B == 0 || S == 0) return fail(-1, "empty batch");
+  if (sl->device != ctx->model->device) return fail(-1, "shortlist and context are on different devices");
+  HIPCHK(hipSetDevice(sl->device));
+  ShortlistArgs a;
+  shortlist_args(sl, d_src_ids, d_lengths, B, S, d_out_ids, d_n_out, a);
+  HIPCHK(launch_shortlist_generate(a, ctx->stream));
+  return 0;
+}

@@ -100,3 +100,14 @@ struct slimt_hip_ctx {
   size_t prof_used = 0;
   double prof_macs = 0, prof_bytes = 0;
 };
+
+// ShortlistGenerator (slimt/Shortlist.hh:38-90): the binary shortlist on the device
+struct slimt_hip_shortlist {
+  int device = 0;
+  uint64_t frequent = 0, best = 0;
+  size_t source_vocab = 0, target_vocab = 0;
+  bool shared = false;
+  slimt_hip::DevBuf w2o, lists;                // word_to_offset (uint64), shortlist (uint32)
+  slimt_hip::DevBuf ids, lengths, out, n_out;  // staging of the host entry point
+};
+

@@ -282,4 +282,20 @@ hipError_t launch_highway(const float *x, const float *y, const float *g, size_t
 hipError_t launch_transpose_heads(const float *in, int B, int d2, int d1, int d0, float *out,
                                   hipStream_t st);
 
+// ---- lexical shortlist generation (shortlist.hip) -------------------------------
+struct ShortlistArgs {
+  const unsigned long long *w2o = nullptr;  // [src_vocab + 1] offsets into lists
+  const uint32_t *lists = nullptr;          // sorted target ids per source word
+  unsigned long long frequent = 0;
+  int shared = 0;
+  int src_vocab = 0, tgt_vocab = 0;
+  const uint32_t *ids = nullptr;      // [B][S] padded source tokens
+  const uint32_t *lengths = nullptr;  // [B]
+  int B = 0, S = 0;
+  uint32_t *out = nullptr;    // [tgt_vocab] capacity
+  uint32_t *n_out = nullptr;  // [1]
+};
+size_t shortlist_lds_bytes(int src_vocab, int tgt_vocab);
+hipError_t launch_shortlist_generate(const ShortlistArgs &a, hipStream_t st);
+
 }  // namespace slimt_hip

@@ -11,9 +11,11 @@
 #include <fstream>
 #include <iostream>
 #include <iterator>
+#include <stdexcept>
 #include <vector>
 
 #include "Model.hh"
+#include "Shortlist.hh"
 #include "QMM.hh"
 
 namespace {
@@ -49,8 +51,8 @@ void put(std::ofstream &o, const T *p, size_t n) {
 }  // namespace
 
 int main(int argc, char **argv) {
-  if (argc != 4) {
-    std::fprintf(stderr, "usage: %s model.bin case.bin out.bin\n", argv[0]);
+  if (argc != 4 && argc != 5) {
+    std::fprintf(stderr, "usage: %s model.bin case.bin out.bin [lexical_shortlist.bin]\n", argv[0]);
     return 2;
   }
   using namespace slimt;
@@ -81,6 +83,18 @@ int main(int argc, char **argv) {
       input.add(Words(ids.begin() + size_t(b) * S, ids.begin() + size_t(b) * S + lens[b]));
     std::optional<Words> shortlist;
     if (n_sl) shortlist = sl;
+    if (argc == 5) {  // Model::forward's order: generate the batch's shortlist first (Model.cc:117-120)
+      std::vector<char> blob = slurp(argv[4]);
+      int32_t vocab = 0;
+      if (slimt_hip_model_info(model.handle(), nullptr, nullptr, &vocab, nullptr)) throw std::runtime_error("model_info");
+      const size_t V = static_cast<size_t>(vocab);
+      ShortlistGenerator generator(View{blob.data(), blob.size()}, V, V);
+      Shortlist generated = generator.generate(input.words());
+      shortlist = generated.words();
+      const uint32_t n = static_cast<uint32_t>(generated.words().size());
+      put(out, &n, 1);
+      put(out, generated.words().data(), n);
+    }
     Histories hs = worker.forward(input, shortlist, true);
     for (uint32_t b = 0; b < B; ++b) {
       const uint32_t n = static_cast<uint32_t>(hs[b]->target.size());

@@ -169,6 +169,40 @@ def make_shortlist(V: int, n: int, seed: int = 99, frequent: int = 100) -> np.nd
     return ids
 
 
+SHORTLIST_MAGIC = 0xF11A48D5013417F5  # Shortlist.hh:40
+
+
+def shortlist_checksum(body: bytes) -> int:
+    """hash_combine over the uint64 words after {magic, checksum}
+    (Shortlist.cc:66-76, Utils.hh:47-67; libstdc++'s std::hash<uint64_t> is the identity)."""
+    seed = 0
+    mask = (1 << 64) - 1
+    for (v,) in struct.iter_unpack("<Q", body[: len(body) // 8 * 8]):
+        seed ^= (v + 0x9E3779B9 + ((seed << 6) & mask) + (seed >> 2)) & mask
+    return seed
+
+
+def make_lexical_shortlist(V_src: int, V_tgt: int, frequent: int = 100, best: int = 100,
+                           seed: int = 7, empty_fraction: float = 0.1) -> bytes:
+    """A synthetic binary lexical shortlist in the layout ShortlistGenerator::load
+    reads (Shortlist.hh:77-84, Shortlist.cc:41-104): header of six uint64, the
+    word_to_offset table (V_src + 1 entries), then per source word a sorted list
+    of <= `best` unique target ids; some words have an empty list."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    counts = rng.integers(0, best + 1, size=V_src)
+    counts[rng.random(V_src) < empty_fraction] = 0
+    offsets = np.zeros(V_src + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(counts)
+    lists = np.zeros(int(offsets[-1]), dtype=np.uint32)
+    for w in range(V_src):
+        k = int(counts[w])
+        if k:
+            lists[int(offsets[w]): int(offsets[w + 1])] = np.sort(
+                rng.choice(V_tgt, size=k, replace=False)).astype(np.uint32)
+    body = struct.pack("<4Q", frequent, best, offsets.size, lists.size) + offsets.tobytes() + lists.tobytes()
+    return struct.pack("<2Q", SHORTLIST_MAGIC, shortlist_checksum(body)) + body
+
+
 def make_batch(
     V: int, B: int, S: int, seed: int = 4321, eos_id: int = 0, ragged: bool = False,
     pad_id: int = 0,

@@ -88,3 +88,47 @@ def test_cpp_model_forward_and_qmm(hip, oracle, synth_models, preset, eos_bias, 
     assert np.array_equal(y2, oracle.affine(x, W, None, float(aq), float(bq)))
     assert np.array_equal(y3, oracle.affine_select(x, W, bias, float(aq), float(bq), idx))
     oracle.set_mode(oracle.FAITHFUL)
+
+
+@pytest.mark.gpu
+def test_cpp_shortlist_generator_then_forward(hip, oracle, synth_models):
+    """The C++ mirror of slimt::ShortlistGenerator feeding Worker::forward, as
+    Model::forward does (Model.cc:117-120): generated ids and translation both
+    equal the oracle's."""
+    from slimt_amd import synth
+    exe = _build_host()
+    m = synth_models("micro", 3.0)
+    B, S = 6, 8
+    ids, lens = synth.make_batch(m.V, B, S, seed=21, ragged=True)
+    blob = synth.make_lexical_shortlist(m.V, m.V, frequent=16, best=5, seed=4)
+    with tempfile.TemporaryDirectory() as d:
+        mb, cb, ob, sb = (os.path.join(d, n) for n in ("model.bin", "case.bin", "out.bin", "lex.bin"))
+        open(mb, "wb").write(synth.write_bin(m))
+        open(sb, "wb").write(blob)
+        x = np.zeros((1, 64), np.float32)
+        W = np.zeros((16, 64), np.int8)
+        bias = np.zeros(16, np.float32)
+        idx = np.arange(8, dtype=np.uint32)
+        with open(cb, "wb") as f:
+            f.write(struct.pack("<9I3f", m.enc_layers, m.dec_layers, m.H, B, S, 0, 1, 64, 16, 1.5, 1.0, 1.0))
+            for a in (ids, lens, np.zeros(0, np.uint32), x, W, bias):
+                f.write(np.ascontiguousarray(a).tobytes())
+            f.write(struct.pack("<I", idx.size) + idx.tobytes())
+        res = subprocess.run([exe, mb, cb, ob, sb], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        raw = open(ob, "rb").read()
+    want_sl = oracle.OracleShortlist(blob, m.V, m.V).generate(ids, lens)
+    (n,) = struct.unpack_from("<I", raw, 0)
+    got_sl = np.frombuffer(raw, np.uint32, n, 4)
+    assert np.array_equal(got_sl, want_sl)
+    off = 4 + 4 * n
+    oracle.set_mode(oracle.PORTABLE)
+    w_out, w_ln, _, _ = oracle.OracleModel(m).translate(ids, lens, want_sl, 1.5, 0)
+    oracle.set_mode(oracle.FAITHFUL)
+    for b in range(B):
+        (k,) = struct.unpack_from("<I", raw, off)
+        off += 4
+        toks = np.frombuffer(raw, np.uint32, k, off)
+        off += 4 * k + 4 * k * int(lens[b])
+        assert k == w_ln[b] and np.array_equal(toks, w_out[b, :k])
+
