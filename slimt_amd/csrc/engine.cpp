@@ -564,7 +564,7 @@ void ctx_free(slimt_hip_ctx *c) {
                     &c->h8, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
                     &c->state, &c->part_val, &c->part_idx, &c->prev, &c->out_ids, &c->out_len,
                     &c->finished, &c->n_finished, &c->align, &c->shortlist, &c->logits,
-                    &c->attn_dbg, &c->stamps, &c->dbg_embed, &c->dbg_layers};
+                    &c->attn_dbg, &c->stamps, &c->dbg_embed, &c->dbg_layers, &c->sl_scratch};
   for (auto *b : bufs) b->release();
   free_affine(c->out_sl);
   if (c->n_finished_host) (void)hipHostFree(c->n_finished_host);
@@ -1366,6 +1366,16 @@ uint64_t shortlist_checksum(const unsigned char *blob, size_t size) {
   return seed;
 }
 
+// bitmaps start zeroed and every generate call leaves them zeroed
+int shortlist_scratch(DevBuf &buf, const slimt_hip_shortlist *sl, hipStream_t st) {
+  const size_t need = shortlist_scratch_bytes((int)sl->source_vocab, (int)sl->target_vocab);
+  if (buf.bytes < need) {
+    HIPCHK(buf.reserve(need));
+    HIPCHK(hipMemsetAsync(buf.p, 0, buf.bytes, st));
+  }
+  return 0;
+}
+
 void shortlist_args(const slimt_hip_shortlist *sl, const uint32_t *d_ids, const uint32_t *d_len,
                     size_t B, size_t S, uint32_t *d_out, uint32_t *d_n, ShortlistArgs &a) {
   a.w2o = sl->w2o.as<unsigned long long>();
@@ -1415,7 +1425,9 @@ extern "C" int slimt_hip_shortlist_create(const void *blob, size_t blob_size, si
   for (uint64_t i = 0; i < n_off; ++i) {
     uint64_t v;
     std::memcpy(&v, po + 8 * i, 8);
-    if (v > n_ids || v < prev) return fail(-1, "offset table not within shortlist size");
+    // the reference's check wants every offset but the last strictly inside (Shortlist.cc:18-21)
+    if (v > n_ids || v < prev || (check && i + 1 < n_off && v >= n_ids))
+      return fail(-1, "offset table not within shortlist size");
     prev = v;
   }
   if (prev != n_ids) return fail(-1, "word_to_offset != shortlist_size");
@@ -1449,7 +1461,8 @@ extern "C" int slimt_hip_shortlist_create(const void *blob, size_t blob_size, si
 extern "C" int slimt_hip_shortlist_destroy(slimt_hip_shortlist *sl) {
   if (!sl) return 0;
   (void)hipSetDevice(sl->device);
-  for (DevBuf *b : {&sl->w2o, &sl->lists, &sl->ids, &sl->lengths, &sl->out, &sl->n_out}) b->release();
+  for (DevBuf *b : {&sl->w2o, &sl->lists, &sl->ids, &sl->lengths, &sl->out, &sl->n_out, &sl->scratch})
+    b->release();
   delete sl;
   return 0;
 }
@@ -1479,9 +1492,11 @@ extern "C" int slimt_hip_shortlist_generate(slimt_hip_shortlist *sl, const uint3
   HIPCHK(sl->lengths.reserve(B * 4));
   HIPCHK(hipMemcpy(sl->ids.p, src_ids, B * S * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(sl->lengths.p, lengths, B * 4, hipMemcpyHostToDevice));
+  RCCHK(shortlist_scratch(sl->scratch, sl, nullptr));
   ShortlistArgs a;
   shortlist_args(sl, sl->ids.as<uint32_t>(), sl->lengths.as<uint32_t>(), B, S,
                  sl->out.as<uint32_t>(), sl->n_out.as<uint32_t>(), a);
+  a.scratch = sl->scratch.as<uint32_t>();
   HIPCHK(launch_shortlist_generate(a, nullptr));
   uint32_t n = 0;
   HIPCHK(hipMemcpy(&n, sl->n_out.p, 4, hipMemcpyDeviceToHost));
@@ -1500,8 +1515,10 @@ extern "C" int slimt_hip_shortlist_generate_device(slimt_hip_shortlist *sl, slim
   if (B == 0 || S == 0) return fail(-1, "empty batch");
   if (sl->device != ctx->model->device) return fail(-1, "shortlist and context are on different devices");
   HIPCHK(hipSetDevice(sl->device));
+  RCCHK(shortlist_scratch(ctx->sl_scratch, sl, ctx->stream));
   ShortlistArgs a;
   shortlist_args(sl, d_src_ids, d_lengths, B, S, d_out_ids, d_n_out, a);
+  a.scratch = ctx->sl_scratch.as<uint32_t>();
   HIPCHK(launch_shortlist_generate(a, ctx->stream));
   return 0;
 }

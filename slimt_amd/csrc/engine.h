@@ -91,6 +91,7 @@ struct slimt_hip_ctx {
   slimt_hip::DevBuf part_val, part_idx;
   slimt_hip::DevBuf prev, out_ids, out_len, finished, n_finished, align;
   slimt_hip::DevBuf shortlist;
+  slimt_hip::DevBuf sl_scratch;  // bitmaps of slimt_hip_shortlist_generate_device (kept zeroed)
   slimt_hip::AffineW out_sl;  // shortlisted output layer (per batch)
   slimt_hip::DevBuf logits, attn_dbg;
   int *n_finished_host = nullptr;  // pinned
@@ -109,5 +110,6 @@ struct slimt_hip_shortlist {
   bool shared = false;
   slimt_hip::DevBuf w2o, lists;                // word_to_offset (uint64), shortlist (uint32)
   slimt_hip::DevBuf ids, lengths, out, n_out;  // staging of the host entry point
+  slimt_hip::DevBuf scratch;                   // ... and its bitmaps
 };
 

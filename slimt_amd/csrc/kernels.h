@@ -294,8 +294,10 @@ struct ShortlistArgs {
   int B = 0, S = 0;
   uint32_t *out = nullptr;    // [tgt_vocab] capacity
   uint32_t *n_out = nullptr;  // [1]
+  uint32_t *scratch = nullptr;  // target + source bitmaps, zero on entry and on exit
 };
 size_t shortlist_lds_bytes(int src_vocab, int tgt_vocab);
+size_t shortlist_scratch_bytes(int src_vocab, int tgt_vocab);
 hipError_t launch_shortlist_generate(const ShortlistArgs &a, hipStream_t st);
 
 }  // namespace slimt_hip

@@ -191,6 +191,7 @@ def make_lexical_shortlist(V_src: int, V_tgt: int, frequent: int = 100, best: in
     rng = np.random.Generator(np.random.PCG64(seed))
     counts = rng.integers(0, best + 1, size=V_src)
     counts[rng.random(V_src) < empty_fraction] = 0
+    counts[-1] = max(1, min(best, V_tgt))  # content_check wants every offset but the last < size (Shortlist.cc:18-21)
     offsets = np.zeros(V_src + 1, dtype=np.uint64)
     offsets[1:] = np.cumsum(counts)
     lists = np.zeros(int(offsets[-1]), dtype=np.uint32)

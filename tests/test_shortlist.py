@@ -37,6 +37,9 @@ CASES = [  # V_src, V_tgt, frequent, best, B, S, shared, seed
     (300, 2048, 100, 3, 2, 5, False, 4),     # few aligned words: the x8 patch adds ids
     (2048, 300, 100, 50, 16, 32, False, 5),  # nearly everything selected
     (32000, 32000, 100, 100, 64, 32, False, 6),
+    (4096, 4096, 100, 100, 256, 32, False, 7),  # nearly full table: the x8 patch has to search far
+    (640, 640, 64, 2, 3, 4, False, 8),          # frequent on a bitmap word boundary
+    (640, 640, 700, 2, 3, 4, False, 9),         # frequent > vocabulary: no room for the patch
 ]
 
 

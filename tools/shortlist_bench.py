@@ -45,4 +45,4 @@ alg = ids.size * 4 + lens.size * 4 + nz.size * 16 + list_bytes + got.size * 4
 print(json.dumps({"workload": f"ShortlistGenerator::generate, B={B} S={S} V={V} frequent=best=100",
                   "ids_out": int(got.size), "gpu_kernel_us": gpu_us, "cpu_oracle_us": cpu_us,
                   "algorithmic_bytes": alg, "achieved_GBs": alg / gpu_us / 1e3,
-                  "note": "single workgroup, LDS bitmaps; latency-bound (one CU), bit-exact vs oracle"}))
+                  "note": "two launches: wave-per-64-tokens marking into LDS bitmaps (<=16 workgroups) + one-workgroup patch/scan/emit; latency-bound; bit-exact vs oracle"}))
