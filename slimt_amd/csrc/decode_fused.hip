@@ -37,10 +37,10 @@ namespace {
 
 // prefetch depth (chunks of CH fragments in flight per wave) of the streamed GEMMs
 #ifndef SLIMT_NB_FFN
-#define SLIMT_NB_FFN 2
+#define SLIMT_NB_FFN 3
 #endif
 #ifndef SLIMT_NB_OUT
-#define SLIMT_NB_OUT 2
+#define SLIMT_NB_OUT 4
 #endif
 
 constexpr int NW = 16;   // waves per workgroup
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
       const int sb = 1 + 10 * l;
       float lsc[KSD], lbi[KSD];
       // ---- SSRU (Modules.cc:190-235) ------------------------------------
-#pragma unroll
+#pragma unroll 1  // code size: this kernel shares a 64 KB instruction cache with its neighbour CU
       for (int rr = 0; rr < 2; ++rr) {
         const int row = 16 * rr + wave;
 #pragma unroll
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
       SLIMT_STAMP(sb + 1);
       // h = LN(x + relu(c')) in place, quantised for the Q projection
       load_ln_consts<KSD>(L.rnn_ln_s, L.rnn_ln_b, lane, lsc, lbi);
-#pragma unroll
+#pragma unroll 1
       for (int rr = 0; rr < 2; ++rr) {
         const int row = 16 * rr + wave;
         ln_row_r<KSD>(P + row * LDF, lsc, lbi, a.eps, P + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
       __syncthreads();
       SLIMT_STAMP(sb + 5);
       load_ln_consts<KSD>(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);
-#pragma unroll
+#pragma unroll 1
       for (int rr = 0; rr < 2; ++rr) {
         const int row = 16 * rr + wave;
         ln_row_r<KSD>(P + row * LDF, lsc, lbi, a.eps, P + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
@@ -1112,22 +1112,29 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
         ffn1_chunk(0, HB0);
         load_b1(0, 2);
         __syncthreads();
-#pragma unroll
-        for (int fc = 0; fc < NC; ++fc) {
-          char *Hcur = (fc & 1) ? HB1 : HB0;
-          char *Hnext = (fc & 1) ? HB0 : HB1;
-          if (fc + 1 < NC) {
-            ffn1_chunk((fc + 1) & 1, Hnext);
-            load_b1((fc + 1) & 1, fc + 3);
-          }
+        static_assert(NC % 2 == 0, "two chunks per rolled iteration");
+        auto ffn2_chunk = [&](int buf, const char *Hb) {
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
-            const v4i h0 = *reinterpret_cast<const v4i *>(Hcur + lr * LDA + ks * 64 + lg * 16);
-            const v4i h1 = *reinterpret_cast<const v4i *>(Hcur + (16 + lr) * LDA + ks * 64 + lg * 16);
-            f0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(h0, b2[fc & 1][ks], f0, 0, 0, 0);
-            f1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(h1, b2[fc & 1][ks], f1, 0, 0, 0);
+            const v4i h0 = *reinterpret_cast<const v4i *>(Hb + lr * LDA + ks * 64 + lg * 16);
+            const v4i h1 = *reinterpret_cast<const v4i *>(Hb + (16 + lr) * LDA + ks * 64 + lg * 16);
+            f0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(h0, b2[buf][ks], f0, 0, 0, 0);
+            f1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(h1, b2[buf][ks], f1, 0, 0, 0);
           }
-          load_b2(fc & 1, fc + 2);
+        };
+#pragma unroll 1  // two chunks per iteration keep the buffer indices static (code size, see above)
+        for (int fc = 0; fc < NC; fc += 2) {
+          ffn1_chunk(1, HB1);  // chunk fc + 1
+          load_b1(1, fc + 3);
+          ffn2_chunk(0, HB0);  // chunk fc
+          load_b2(0, fc + 2);
+          __syncthreads();
+          if (fc + 2 < NC) {
+            ffn1_chunk(0, HB0);  // chunk fc + 2
+            load_b1(0, fc + 4);
+          }
+          ffn2_chunk(1, HB1);  // chunk fc + 1
+          load_b2(1, fc + 3);
           __syncthreads();
         }
         int c2;
@@ -1150,7 +1157,7 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
       SLIMT_STAMP(sb + 8);
       // next layer's input; after the last layer: quantised for the logits
       load_ln_consts<KSD>(L.ffn_ln_s, L.ffn_ln_b, lane, lsc, lbi);
-#pragma unroll
+#pragma unroll 1
       for (int rr = 0; rr < 2; ++rr) {
         const int row = 16 * rr + wave;
         ln_row_r<KSD>(P + row * LDF, lsc, lbi, a.eps, X + row * LDF,
