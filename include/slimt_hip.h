@@ -123,6 +123,12 @@ int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
 int slimt_hip_ctx_create(slimt_hip_model *model, size_t max_batch,
                          size_t max_source_length, void *stream,
                          slimt_hip_ctx **out);
+/* Same, for token-budget batching (slimt/Batcher.cc:95-120: many short
+ * sentences or few long ones, (B + 1) * S <= max_words): the workspace holds
+ * batches with B <= max_batch, S <= max_source_length and B * S <= max_tokens. */
+int slimt_hip_ctx_create_budget(slimt_hip_model *model, size_t max_batch,
+                                size_t max_source_length, size_t max_tokens, void *stream,
+                                slimt_hip_ctx **out);
 int slimt_hip_ctx_destroy(slimt_hip_ctx *ctx);
 int slimt_hip_ctx_stream(slimt_hip_ctx *ctx, void **stream);
 int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);

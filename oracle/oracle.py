@@ -341,3 +341,38 @@ class OracleShortlist:
                                         self.target_vocab, _p(words), words.size, _p(out))
         return out[: int(n)].copy()
 
+
+def batcher_generate(requests, max_words: int, wrap_length: int, tgt_length_limit_factor: float = 3.0):
+    """Batcher::enqueue of every request, then Batcher::generate until empty
+    (slimt/Batcher.cc:77-147). requests: list of lists of segment lengths (request
+    id = list index). Returns the batches as lists of (request id, segment index)."""
+    pivot_slack = int(np.float32(wrap_length) * np.float32(tgt_length_limit_factor) - np.float32(wrap_length))
+    n_buckets = wrap_length + pivot_slack + 1
+    if n_buckets - 1 > max_words:
+        raise ValueError("wrap_length > max_words")
+    buckets = {}
+    running_max = 0
+    for rid, lengths in enumerate(requests):
+        for idx, n in enumerate(lengths):
+            buckets.setdefault(int(n), []).append((rid, idx))  # std::set order: (request id, index)
+            running_max = max(running_max, int(n))
+    for b in buckets.values():
+        b.sort()
+    batches = []
+    while True:
+        batch = []
+        full = False
+        for length in range(0, running_max + 1):
+            bucket = buckets.get(length, [])
+            while bucket:
+                if (len(batch) + 1) * length <= max_words:
+                    batch.append(bucket.pop(0))
+                else:
+                    full = True
+                    break
+            if full:
+                break
+        if not batch:
+            return batches
+        batches.append(batch)
+

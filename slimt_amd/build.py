@@ -73,7 +73,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 HOST_DIR = os.path.join(HERE, "host")
 HOST_TEST = os.path.join(LIB_DIR, "slimt_hip_host_test")
-HOST_SOURCES = ["Io.cc", "QMM.cc", "Model.cc", "Shortlist.cc", "host_test.cc"]
+HOST_SOURCES = ["Io.cc", "QMM.cc", "Model.cc", "Shortlist.cc", "Batcher.cc", "host_test.cc"]
 
 
 def build_host(force: bool = False) -> str:
@@ -89,7 +89,7 @@ def build_host(force: bool = False) -> str:
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", HOST_DIR,
            "-I", os.path.join(ROOT, "include")] + srcs + [
         "-L", LIB_DIR, "-lslimt_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + rocm_lib,
-        "-Wl,-rpath," + rocm_lib, "-o", HOST_TEST]
+        "-Wl,-rpath," + rocm_lib, "-pthread", "-o", HOST_TEST]
     subprocess.check_call(cmd)
     return HOST_TEST
 

@@ -21,7 +21,7 @@ SYMBOLS = [
     "slimt_hip_prepare_weight_quantized_transposed", "slimt_hip_layer_norm",
     "slimt_hip_softmax", "slimt_hip_highway", "slimt_hip_sdpa",
     "slimt_hip_model_create", "slimt_hip_model_destroy", "slimt_hip_model_info",
-    "slimt_hip_ctx_create", "slimt_hip_ctx_destroy", "slimt_hip_ctx_stream",
+    "slimt_hip_ctx_create", "slimt_hip_ctx_create_budget", "slimt_hip_ctx_destroy", "slimt_hip_ctx_stream",
     "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_ctx_plan", "slimt_hip_translate", "slimt_hip_translate_device",
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
@@ -99,6 +99,7 @@ def lib():
     L.slimt_hip_profile_read.argtypes = [vp, vp, vp, vp, vp]
     L.slimt_hip_profile_reset.argtypes = [vp]
     L.slimt_hip_debug_decode_stamps.argtypes = [vp, i32, vp, sz]
+    L.slimt_hip_ctx_create_budget.argtypes = [vp, sz, sz, sz, vp, vp]
     L.slimt_hip_shortlist_create.argtypes = [vp, sz, sz, sz, i32, i32, i32, vp]
     L.slimt_hip_shortlist_destroy.argtypes = [vp]
     L.slimt_hip_shortlist_info.argtypes = [vp, vp, vp]

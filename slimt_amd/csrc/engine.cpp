@@ -1,6 +1,7 @@
 // C ABI (include/slimt_hip.h) + host-side engine of the MI355X slimt backend.
 #include "engine.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -577,7 +578,7 @@ void ctx_free(slimt_hip_ctx *c) {
 
 int ctx_alloc(slimt_hip_ctx *c) {
   const slimt_hip_model *m = c->model;
-  const size_t B = c->max_B, S = c->max_S, M = B * S;
+  const size_t B = c->max_B, S = c->max_S, M = c->max_M;
   const size_t D = (size_t)m->D, F = (size_t)m->F, V = (size_t)m->V;
   std::vector<float> pos;
   sinusoid_table((int)S, (int)D, pos);
@@ -644,9 +645,16 @@ double gemm_bytes(const PreparedWeight &w) { return (double)w.K * w.n_tiles * 16
 
 extern "C" int slimt_hip_ctx_create(slimt_hip_model *model, size_t max_batch,
                                     size_t max_source_length, void *stream, slimt_hip_ctx **out) {
+  return slimt_hip_ctx_create_budget(model, max_batch, max_source_length,
+                                     max_batch * max_source_length, stream, out);
+}
+
+extern "C" int slimt_hip_ctx_create_budget(slimt_hip_model *model, size_t max_batch,
+                                           size_t max_source_length, size_t max_tokens,
+                                           void *stream, slimt_hip_ctx **out) {
   if (!model || !out) return fail(-1, "null argument");
   *out = nullptr;
-  if (max_batch == 0 || max_source_length == 0) return fail(-1, "empty workspace");
+  if (max_batch == 0 || max_source_length == 0 || max_tokens == 0) return fail(-1, "empty workspace");
   if (max_source_length > 128)
     return fail(-1, "max_source_length %zu > 128 (slimt wraps at 128, Frontend.hh:27)", max_source_length);
   HIPCHK(hipSetDevice(model->device));
@@ -654,6 +662,7 @@ extern "C" int slimt_hip_ctx_create(slimt_hip_model *model, size_t max_batch,
   c->model = model;
   c->max_B = max_batch;
   c->max_S = max_source_length;
+  c->max_M = std::min(max_batch * max_source_length, max_tokens);
   if (stream) {
     c->stream = reinterpret_cast<hipStream_t>(stream);
   } else {
@@ -784,8 +793,9 @@ int run_affine_relu_q(slimt_hip_ctx *c, int family, const AffineW &w, const floa
 
 int check_batch(const slimt_hip_ctx *c, size_t B, size_t S) {
   if (B == 0 || S == 0) return fail(-1, "empty batch");
-  if (B > c->max_B || S > c->max_S)
-    return fail(-1, "batch %zux%zu exceeds the context workspace %zux%zu", B, S, c->max_B, c->max_S);
+  if (B > c->max_B || S > c->max_S || B * S > c->max_M)
+    return fail(-1, "batch %zux%zu exceeds the context workspace %zux%zu (%zu padded tokens)", B, S,
+                c->max_B, c->max_S, c->max_M);
   return 0;
 }
 

@@ -71,6 +71,7 @@ struct slimt_hip_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   size_t max_B = 0, max_S = 0;
+  size_t max_M = 0;  // padded tokens (B * S) the workspace holds
   // current batch
   int B = 0, S = 0;
   int n_sl = 0;  // 0 => full vocabulary

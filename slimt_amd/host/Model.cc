@@ -46,9 +46,11 @@ Model::Model(const Config &config, const void *model_bin, size_t size) : config_
 
 Model::~Model() { slimt_hip_model_destroy(model_); }
 
-Worker::Worker(const Model &model, size_t max_batch, size_t max_length) : model_(model) {
-  if (slimt_hip_ctx_create(model.handle(), max_batch, max_length, nullptr, &ctx_))
-    raise("slimt_hip_ctx_create");
+Worker::Worker(const Model &model, size_t max_batch, size_t max_length, size_t max_tokens)
+    : model_(model) {
+  if (slimt_hip_ctx_create_budget(model.handle(), max_batch, max_length,
+                                  max_tokens ? max_tokens : max_batch * max_length, nullptr, &ctx_))
+    raise("slimt_hip_ctx_create_budget");
 }
 
 Worker::~Worker() { slimt_hip_ctx_destroy(ctx_); }
@@ -70,6 +72,7 @@ Histories Worker::forward(const Input &input, const std::optional<Words> &shortl
   histories.reserve(B);
   for (size_t b = 0; b < B; ++b) {
     auto hyp = std::make_shared<Hypothesis>();
+    hyp->padded_length = S;
     const size_t n = out_len[b] < T ? out_len[b] : T;
     hyp->target.assign(out_ids.begin() + b * T, out_ids.begin() + b * T + n);
     if (with_alignments) {

@@ -25,6 +25,7 @@ using Alignment = std::vector<Distribution>;
 struct Hypothesis {  // slimt/Types.hh:55-61
   Words target;
   Alignment alignment;
+  size_t padded_length = 0;  // diagnostic: the S of the batch this sentence was translated in
 };
 using History = std::shared_ptr<Hypothesis>;
 using Histories = std::vector<History>;
@@ -76,7 +77,8 @@ class Model {
 
 class Worker {
  public:
-  Worker(const Model &model, size_t max_batch, size_t max_length);
+  // max_tokens: padded-token budget (B * S) of the workspace; 0 = max_batch * max_length
+  Worker(const Model &model, size_t max_batch, size_t max_length, size_t max_tokens = 0);
   ~Worker();
   Worker(const Worker &) = delete;
   Worker &operator=(const Worker &) = delete;

@@ -6,14 +6,18 @@
 //           f32 bias[N], u32 n_idx, u32 idx[n_idx]
 // out.bin : per sentence u32 n, u32 tokens[n], f32 align[n][len];
 //           then f32 affine[M*N], f32 dot[M*N], f32 select[M*n_idx]
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <iterator>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
+#include "Batcher.hh"
 #include "Model.hh"
 #include "Shortlist.hh"
 #include "QMM.hh"
@@ -50,7 +54,88 @@ void put(std::ofstream &o, const T *p, size_t n) {
 }
 }  // namespace
 
+// Batching modes:
+//   host_test --batcher case.bin out.bin            Batcher alone (no GPU work): enqueue every
+//       request, then generate() until empty; writes the batches.
+//   host_test --async model.bin case.bin out.bin    Async over `workers` worker threads on GPU 0.
+// case.bin: u32 {enc_layers, dec_layers, heads, max_words, wrap_length, workers, n_requests},
+//           f32 limit_factor, then per request u32 n_segments, per segment u32 len + u32 tokens[len].
+static int batching_main(int argc, char **argv) {
+  using namespace slimt;
+  const bool async = std::string(argv[1]) == "--async";
+  if (argc != (async ? 5 : 4)) return 2;
+  std::vector<char> cs = slurp(argv[async ? 3 : 2]);
+  Cur c{cs.data()};
+  const uint32_t Le = c.get<uint32_t>(), Ld = c.get<uint32_t>(), H = c.get<uint32_t>();
+  const uint32_t max_words = c.get<uint32_t>(), wrap = c.get<uint32_t>(), workers = c.get<uint32_t>();
+  const uint32_t n_req = c.get<uint32_t>();
+  const float limit = c.get<float>();
+  std::vector<Ptr<Request>> requests;
+  for (uint32_t r = 0; r < n_req; ++r) {
+    const uint32_t n_seg = c.get<uint32_t>();
+    std::vector<Segment> segs;
+    for (uint32_t i = 0; i < n_seg; ++i) {
+      const uint32_t len = c.get<uint32_t>();
+      segs.push_back(c.vec<uint32_t>(len));
+    }
+    requests.push_back(std::make_shared<Request>(r, std::move(segs)));
+  }
+  std::ofstream out(argv[async ? 4 : 3], std::ios::binary);
+  try {
+    if (!async) {
+      Batcher batcher(max_words, wrap, limit);
+      for (auto &r : requests) batcher.enqueue(r);
+      for (Batch b = batcher.generate(); !b.empty(); b = batcher.generate()) {
+        const uint32_t n = static_cast<uint32_t>(b.size()), ml = static_cast<uint32_t>(b.max_length());
+        put(out, &n, 1);
+        put(out, &ml, 1);
+        for (const auto &ref : b.segment_refs()) {
+          const uint32_t rid = static_cast<uint32_t>(ref.request().id()), idx = static_cast<uint32_t>(ref.index());
+          put(out, &rid, 1);
+          put(out, &idx, 1);
+        }
+      }
+      return 0;
+    }
+    std::vector<char> bin = slurp(argv[2]);
+    Model::Config cfg;
+    cfg.encoder_layers = Le;
+    cfg.decoder_layers = Ld;
+    cfg.num_heads = H;
+    Model model(cfg, bin.data(), bin.size());
+    Async::Config ac;
+    ac.max_words = max_words;
+    ac.wrap_length = wrap;
+    ac.tgt_length_limit_factor = limit;
+    ac.workers = workers;
+    std::vector<std::future<Histories>> futures;
+    {
+      Async service(ac, {&model});
+      const auto t0 = std::chrono::steady_clock::now();
+      for (auto &r : requests) futures.push_back(service.translate(r));
+      for (auto &f : futures) f.wait();
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      std::fprintf(stderr, "async: %zu requests translated in %.3f ms\n", requests.size(), ms);
+    }  // joins the workers
+    for (auto &f : futures) {
+      Histories hs = f.get();
+      for (const auto &h : hs) {
+        const uint32_t S = static_cast<uint32_t>(h->padded_length), n = static_cast<uint32_t>(h->target.size());
+        put(out, &S, 1);
+        put(out, &n, 1);
+        put(out, h->target.data(), n);
+      }
+    }
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "host_test: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc >= 2 && (std::string(argv[1]) == "--batcher" || std::string(argv[1]) == "--async"))
+    return batching_main(argc, argv);
   if (argc != 4 && argc != 5) {
     std::fprintf(stderr, "usage: %s model.bin case.bin out.bin [lexical_shortlist.bin]\n", argv[0]);
     return 2;
