@@ -205,3 +205,66 @@ def test_concurrent_contexts_share_one_model(hip, oracle, engines):
     for c in ctxs:
         c.close()
     assert not problems, problems
+
+
+@pytest.mark.parametrize("preset,B,S,n_sl", [("micro", 1, 1, None), ("tiny11", 1, 1, 8), ("tiny11", 1, 32, 4096),
+                                              ("mini", 17, 2, 64), ("tiny11", 33, 3, None)])
+def test_translate_edge_shapes(hip, oracle, engines, preset, B, S, n_sl):
+    """Smallest shapes: one sentence, one source token (floor(1.5 * 1) = 1 decode
+    step), a shortlist of one MFMA half-tile, odd batch sizes."""
+    from slimt_amd import synth
+    m, gm, om = engines(preset, 6.0 if preset == "tiny11" else 1.0)
+    ids, lens = synth.make_batch(m.V, B, S, seed=B * 31 + S, ragged=True)
+    sl = synth.make_shortlist(m.V, n_sl, frequent=min(100, n_sl)) if n_sl else None
+    ctx = hip.Context(gm, B, S)
+    oracle.set_mode(oracle.PORTABLE)
+    w_out, w_ln, w_al, _ = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
+    oracle.set_mode(oracle.FAITHFUL)
+    for mode in (0, 1, 3):
+        ctx.set_decode_mode(mode)
+        out, ln, al = ctx.translate(ids, lens, sl, want_align=True)
+        assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out) and np.array_equal(al, w_al), mode
+    ctx.close()
+
+
+def test_translate_everything_finishes_at_step_one(hip, oracle, engines):
+    """EOS bias so large that every sentence emits EOS first: the persistent
+    decoder leaves its loop early and the remaining output stays zero."""
+    from slimt_amd import synth
+    m, gm, om = engines("tiny11", 100.0)
+    B, S = 40, 12
+    ids, lens = synth.make_batch(m.V, B, S, seed=3, ragged=True)
+    sl = synth.make_shortlist(m.V, 512)
+    ctx = hip.Context(gm, B, S)
+    out, ln, al = ctx.translate(ids, lens, sl, want_align=True)
+    assert np.all(ln == 1) and np.all(out[:, 0] == 0) and np.all(out[:, 1:] == 0)
+    oracle.set_mode(oracle.PORTABLE)
+    w_out, w_ln, w_al, _ = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
+    oracle.set_mode(oracle.FAITHFUL)
+    assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out) and np.array_equal(al, w_al)
+    ctx.close()
+
+
+def test_context_workspace_limits_and_errors(hip, engines):
+    from slimt_amd import synth
+    m, gm, _ = engines("micro", 3.0)
+    ctx = hip.Context(gm, 4, 8)
+    ids, lens = synth.make_batch(m.V, 5, 8, seed=1)
+    with pytest.raises(hip.SlimtHipError, match="exceeds the context workspace"):
+        ctx.translate(ids, lens, None)
+    ids, lens = synth.make_batch(m.V, 4, 9, seed=1)
+    with pytest.raises(hip.SlimtHipError, match="exceeds the context workspace"):
+        ctx.translate(ids, lens, None)
+    ids, lens = synth.make_batch(m.V, 4, 8, seed=1)
+    bad = ids.copy(); bad[0, 0] = m.V
+    with pytest.raises(hip.SlimtHipError, match="out of range"):
+        ctx.translate(bad, lens, None)
+    with pytest.raises(hip.SlimtHipError, match="length"):
+        ctx.translate(ids, lens + 9, None)
+    with pytest.raises(hip.SlimtHipError, match="shortlist id"):
+        ctx.translate(ids, lens, np.array([0, 1, 2, 3, 4, 5, 6, m.V], np.uint32))
+    out, ln, _ = ctx.translate(ids, lens, None)  # the context is still usable after errors
+    assert out.shape[0] == 4 and ln.min() >= 1
+    with pytest.raises(hip.SlimtHipError):
+        hip.Context(gm, 4, 129)  # slimt wraps at 128 (Frontend.hh:27)
+    ctx.close()
