@@ -344,38 +344,53 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     // FFN2 accumulators of this wave's column tile stay in registers.
     {
       v4i f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
-      v4i b1[KSD], b2[4];
+      // fragments of two chunks in flight (with the whole GPU streaming, a weight
+      // fetch takes longer than one chunk's arithmetic); loads past the last chunk
+      // read beyond the descriptor / into the next tile and are never used
+      v4i b1[2][KSD], b2[2][4];
+      int cs1[2];
+      float pb1[2];
       constexpr int NC = KSF / 4;  // chunks of 256 hidden columns
+      static_assert(NC % 2 == 0, "two chunks per rolled iteration");
+      auto load_b1 = [&](int buf, int fc) {
+        load_frags<KSD>(b1[buf], L.ffn1, fc * 16 + wave, 0, lane);
+        load_epi(L.ffn1, fc * 16 + wave, lr, cs1[buf], pb1[buf]);
+      };
+      auto load_b2 = [&](int buf, int fc) { load_frags<4>(b2[buf], L.ffn2, wave, fc * 4, lane); };
       // FFN1 of one chunk: this wave's column tile -> relu -> requantise -> hidden buffer
-      auto ffn1_chunk = [&](int fc, char *Hbuf) {
-        const int t1 = fc * 16 + wave;
+      auto ffn1_chunk = [&](int buf, char *Hbuf) {
         v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-        tile_mma2<KSD>(Aq, LDA, b1, lr, lg, c0, c1);
-        // b1 is consumed: fetch the next chunk's fragments into the same registers
-        if (fc + 1 < NC) load_frags<KSD>(b1, L.ffn1, t1 + 16, 0, lane);
-        int cs;
-        float pb;
-        load_epi(L.ffn1, t1, lr, cs, pb);
+        tile_mma2<KSD>(Aq, LDA, b1[buf], lr, lg, c0, c1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v0 = edequant(c0[r], cs, L.ffn1.u, pb);
-          float v1 = edequant(c1[r], cs, L.ffn1.u, pb);
+          float v0 = edequant(c0[r], cs1[buf], L.ffn1.u, pb1[buf]);
+          float v1 = edequant(c1[r], cs1[buf], L.ffn1.u, pb1[buf]);
           v0 = v0 > 0.0f ? v0 : 0.0f;
           v1 = v1 > 0.0f ? v1 : 0.0f;
           Hbuf[(lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v0, L.ffn2.a_quant);
           Hbuf[(16 + lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v1, L.ffn2.a_quant);
         }
       };
-      load_frags<KSD>(b1, L.ffn1, wave, 0, lane);
-      load_frags<4>(b2, L.ffn2, wave, 0, lane);
+      load_b1(0, 0);
+      load_b1(1, 1);
+      load_b2(0, 0);
+      load_b2(1, 1);
       ffn1_chunk(0, Ak);
+      load_b1(0, 2);
       __syncthreads();
-      for (int fc = 0; fc < NC; ++fc) {
-        char *Hcur = (fc & 1) ? Av : Ak;
-        char *Hnext = (fc & 1) ? Ak : Av;
-        if (fc + 1 < NC) ffn1_chunk(fc + 1, Hnext);
-        tile_mma2<4>(Hcur, LDA, b2, lr, lg, f0, f1);
-        if (fc + 1 < NC) load_frags<4>(b2, L.ffn2, wave, (fc + 1) * 4, lane);
+#pragma unroll 1
+      for (int fc = 0; fc < NC; fc += 2) {
+        ffn1_chunk(1, Av);  // chunk fc + 1
+        load_b1(1, fc + 3);
+        tile_mma2<4>(Ak, LDA, b2[0], lr, lg, f0, f1);  // chunk fc
+        load_b2(0, fc + 2);
+        __syncthreads();
+        if (fc + 2 < NC) {
+          ffn1_chunk(0, Ak);  // chunk fc + 2
+          load_b1(0, fc + 4);
+        }
+        tile_mma2<4>(Av, LDA, b2[1], lr, lg, f0, f1);  // chunk fc + 1
+        load_b2(1, fc + 3);
         __syncthreads();
       }
       const int col = wave * 16 + lr;
