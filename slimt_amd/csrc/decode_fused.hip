@@ -6,9 +6,10 @@
 // for ALL steps with no inter-workgroup communication at all:
 //   * activations, the SSRU cell states and the int8 A operands live in LDS
 //     for the whole loop; nothing but tokens / alignments is written to HBM;
-//   * the ~3 MB of decoder + shortlist weights are streamed from L2 each step
-//     in MFMA-fragment order (1 KiB coalesced per operand), 16 waves keeping
-//     2 x 8 fragments in flight each;
+//   * the ~3.4 MB of decoder + shortlist weights are streamed from L2 each step
+//     in MFMA-fragment order (1 KiB coalesced per operand) through buffer loads
+//     with scalar addressing, 16 waves keeping 3-4 chunks of 4 fragments in
+//     flight each (SLIMT_NB_FFN / SLIMT_NB_OUT);
 //   * one wave per sentence does LayerNorm, embedding lookup, cross-attention
 //     (two heads per wave64 pass when S <= 32, d_head == 32) and the greedy
 //     bookkeeping (EOS / lengths / alignments);
@@ -199,8 +200,9 @@ __device__ __forceinline__ void ln_row(const float *src, const float *scale, con
   }
 }
 
-// Address spaces are spelled out: across a non-inlined call the compiler
-// would otherwise fall back to FLAT loads, which it serialises one by one.
+// Address spaces are spelled out in the per-sentence argument block: through
+// generic pointers the compiler falls back to FLAT loads (the generic S > 32
+// path still loads through these), which it serialises one by one.
 #define SLIMT_GLOBAL __attribute__((address_space(1)))
 #define SLIMT_LDS __attribute__((address_space(3)))
 typedef const SLIMT_GLOBAL float *gcf_ptr;
@@ -223,7 +225,9 @@ struct AttnRow {
 };
 
 // scaled_dot_product_attention (Modules.cc:24-86) for ONE sentence, all heads,
-// by one wave. Kept out of line: its registers must not add to the GEMM phases'.
+// by one wave. Inlined: with buffer loads (no per-lane 64-bit addresses) its
+// registers no longer collide with the GEMM phases', and a call would save and
+// restore 48 callee-saved VGPRs through scratch every layer and step.
 // The K/V cache is streamed once per step by exactly one workgroup; weights are
 // shared by every workgroup. SLIMT_KV_NT marks the cache loads non-temporal so
 // that they do not displace the weights from the XCD's L2.
