@@ -246,62 +246,94 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     }
     __syncthreads();
     SLIMT_ESTAMP(2);
-    // scaled_dot_product_attention (Modules.cc:24-86): wave = (head, query
-    // parity); two queries per pass (lane half = query), keys/values of the
-    // sentence held in registers. Output quantised for the O projection into
-    // Aq (dead since the projections).
+    // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one
+    // wave per (sentence, head). A chain of v_mfma_f32_32x32x2_f32 over ascending
+    // k is bit-identical to the ascending fmaf chain the other kernels and the
+    // oracle use (tools/probe_mfma_f32.py: 65536 of 65536 elements, magnitudes
+    // 1e-38 .. 1e18), so only the instruction count changes (~3x fewer VALU
+    // instructions than the lane-per-key formulation it replaces):
+    //   S^T = K Q^T        lane (n, hh) <- key row / query row n, d = k0 + hh;
+    //                      result register r: key m = 8 (r / 4) + 4 hh + r % 4, query n
+    //   softmax over keys  the canonical 32-lane butterfly (masks 1, 2, 4, 8, 16 on
+    //                      the key index) = register pairs, one half-wave exchange,
+    //                      register pairs
+    //   O = P V            keys 2 i (lanes hh = 0) and 2 i + 1 (hh = 1) per step:
+    //                      half of P changes half-waves first (v_permlane32_swap)
+    // Output quantised for the O projection into Aq (dead since the projections).
     {
-      const int h = wave % H, par = wave / H;  // ENW == 2 * H for the supported shapes
-      float *pw = pbufs + wave * 64;
-      const int half = lane >> 5, j = lane & 31;
+      typedef float v16f __attribute__((ext_vector_type(16)));
+      const int n = lane & 31, hh = lane >> 5;
       const float minus_inf = -99999999.0f;  // Input.cc:56-61
       const float lowest = -3.402823466e+38f;
-      for (int sl = 0; sl < spw; ++sl) {
+      auto tree32 = [&](const float(&x)[16], auto op, auto op_halves) -> float {
+        float t4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)  // masks 1, 2: inside a group of four registers
+          t4[g] = op(op(x[4 * g], x[4 * g + 1]), op(x[4 * g + 2], x[4 * g + 3]));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t4[g] = op_halves(t4[g]);  // mask 4: the other half-wave
+        return op(op(t4[0], t4[1]), op(t4[2], t4[3]));          // masks 8, 16
+      };
+      auto fadd = [](float x, float y) { return x + y; };
+      auto fmax_ = [](float x, float y) { return fmaxf(x, y); };
+      auto add_halves = [](float x) { return bf_add<32>(x); };
+      auto max_halves = [](float x) { return bf_max<32>(x); };
+      for (int job = wave; job < spw * H; job += ENW) {
+        const int sl = job / H, h = job % H;
         const int sb = s0 + sl;
-        if (sb >= B) break;
+        if (sb >= B) continue;
         const int base = sl * S;
         const int len = (int)a.lengths[sb];
-        const int jc = j < S ? j : S - 1;
-        float kreg[DH], vreg[32];
+        const int rc = base + (n < S ? n : S - 1);  // this lane's key row (A) / query row (B), clamped
+        const float *kp = kb + rc * LDQ + h * DH + hh;
+        const float *qp = qb + rc * LDQQ + h * DH + hh;
+        v16f st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < DH; ++k) kreg[k] = kb[(base + jc) * LDQ + h * DH + k];
+        for (int k0 = 0; k0 < DH; k0 += 2)
+          st = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[k0], qp[k0], st, 0, 0, 0);
+        float sc[16];
 #pragma unroll
-        for (int jj = 0; jj < 32; ++jj)
-          vreg[jj] = vb[(base + (jj < S ? jj : S - 1)) * LDQ + h * DH + (lane & (DH - 1))];
-        const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-        // queries of this wave: positions par*2 + half + 4*i
-        for (int i0 = par * 2; i0 < S; i0 += 4) {
-          const int qi = i0 + half;
-          const int qic = qi < S ? qi : S - 1;
-          const float *qrow = qb + (base + qic) * LDQQ + h * DH;
-          float s = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+          const int m = 8 * (r >> 2) + 4 * hh + (r & 3);  // key of this register
+          float v = st[r];
+          if (a.alpha != 1.0f) v = a.alpha * v;
+          v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
+          if (m >= S) v = lowest;
+          sc[r] = v;
+        }
+        const float mx = tree32(sc, fmax_, max_halves);
 #pragma unroll
-          for (int k = 0; k < DH / 4; ++k) {
-            const f4 q4 = *reinterpret_cast<const f4 *>(qrow + 4 * k);
-            s = __builtin_fmaf(q4.x, kreg[4 * k + 0], s);
-            s = __builtin_fmaf(q4.y, kreg[4 * k + 1], s);
-            s = __builtin_fmaf(q4.z, kreg[4 * k + 2], s);
-            s = __builtin_fmaf(q4.w, kreg[4 * k + 3], s);
-          }
-          if (a.alpha != 1.0f) s = a.alpha * s;
-          s = s + mask;
-          if (j >= S) s = lowest;
-          const float m = half_max(s);
-          const float e = j < S ? exp_p(s - m) : 0.0f;
-          const float sum = half_sum(e);  // canonical order: masks 1..16; the mask-32 step would add +0
-          const float p = e / sum;  // keys >= S: exactly 0
-          // broadcast this half's probabilities through the wave's LDS scratch
-          pw[lane] = p;
-          float o = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+          const int m = 8 * (r >> 2) + 4 * hh + (r & 3);
+          sc[r] = m < S ? exp_p(sc[r] - mx) : 0.0f;
+        }
+        const float sum = tree32(sc, fadd, add_halves);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {  // keys >= S contribute fma(0, v, o) == o
-            const f4 p4 = *reinterpret_cast<const f4 *>(pw + (lane & 32) + 4 * i);
-            o = __builtin_fmaf(p4.x, vreg[4 * i + 0], o);
-            o = __builtin_fmaf(p4.y, vreg[4 * i + 1], o);
-            o = __builtin_fmaf(p4.z, vreg[4 * i + 2], o);
-            o = __builtin_fmaf(p4.w, vreg[4 * i + 3], o);
-          }
-          if (qi < S && j < DH) Aq[(base + qi) * LDA + h * DH + j] = (char)quantize1(o, L.o.a_quant);
+        for (int r = 0; r < 16; ++r) sc[r] = sc[r] / sum;  // keys >= S: exactly 0
+        // P operand of step i: keys 2 i (hh = 0) / 2 i + 1 (hh = 1)
+        float pa[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const slimt_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * g + 0]),
+                                                                __float_as_int(sc[4 * g + 1]), false, false);
+          const slimt_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * g + 2]),
+                                                                __float_as_int(sc[4 * g + 3]), false, false);
+          pa[4 * g + 0] = __int_as_float(s01.x);  // keys 8 g + 0, 8 g + 1
+          pa[4 * g + 1] = __int_as_float(s23.x);  // keys 8 g + 2, 8 g + 3
+          pa[4 * g + 2] = __int_as_float(s01.y);  // keys 8 g + 4, 8 g + 5
+          pa[4 * g + 3] = __int_as_float(s23.y);  // keys 8 g + 6, 8 g + 7
+        }
+        v16f o = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {  // keys >= S contribute fma(0, v, o) == o
+          const int key = 2 * i + hh;
+          const float vv = vb[(base + (key < S ? key : S - 1)) * LDQ + h * DH + n];
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], vv, o, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = 8 * (r >> 2) + 4 * hh + (r & 3);  // query of this register
+          if (m < S) Aq[(base + m) * LDA + h * DH + n] = (char)quantize1(o[r], L.o.a_quant);
         }
       }
     }
