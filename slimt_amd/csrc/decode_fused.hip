@@ -237,6 +237,119 @@ struct AttnRow {
 #define KV_AUX 0
 #endif
 
+// Cross-attention of one sentence for 32 < S <= 128 (d_head 32). Out of line:
+// it is register-hungry (two groups of K or V in flight) and rare enough that
+// the callee-saved spills of a call do not matter, while inlined it would cost
+// the S <= 32 path its registers.
+__device__ __forceinline__ const float *uniform_ptr(const float *p) {
+  // function arguments arrive in VGPRs; a buffer descriptor built from them would
+  // make every load a waterfall loop. These values are wave-uniform: say so.
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
+}
+
+template <int D, int DH>
+__device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
+  constexpr int H = D / DH;
+  const int S = __builtin_amdgcn_readfirstlane(r.S), len = __builtin_amdgcn_readfirstlane(r.len);
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  {
+    // 32 < S <= 128: two heads per pass as above, each lane holding the keys
+    // j, j + 32, j + 64, j + 96 of its head. K arrives 32 keys (8 x 16 B per
+    // lane) at a time with the next group in flight, V likewise in groups of 32
+    // keys; the probabilities of a head go through LDS (pbuf: 2 x 128 floats).
+    // Row sums keep the canonical 128-column order: lane L = key % 64 first adds
+    // keys L and L + 64, then the 64-lane butterfly -- here (e0 + e2), (e1 + e3)
+    // in the lane, the 32-lane butterfly on both, and their sum.
+    const int hh = lane >> 5, j = lane & 31;
+    const int ng = (S + 31) >> 5;
+    const rsrc_t rk = make_rsrc(uniform_ptr((const float *)r.kl), (unsigned)(S * D) * 4u);
+    const rsrc_t rv = make_rsrc(uniform_ptr((const float *)r.vl), (unsigned)(S * D) * 4u);
+    const int koff = ((hh * (DH / 4) * S + j) * 4) * 4;
+    const int voff = lane * 4;
+#pragma unroll 1
+    for (int hp = 0; hp < H / 2; ++hp) {
+      const int h = 2 * hp + hh;
+      auto load_k = [&](f4(&k4)[8], int g) {  // keys 32 g + j; past S: the group is skipped below
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          k4[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rk, koff, (((2 * hp * (DH / 4) + i) * S + 32 * g) * 4) * 4, KV_AUX));
+      };
+      float sc[4];
+      f4 ka[8], kb[8];
+      load_k(ka, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f4(&cur)[8] = (g & 1) ? kb : ka;
+        f4(&nxt)[8] = (g & 1) ? ka : kb;
+        float s = lowest;
+        if (g < ng) {
+          if (g + 1 < ng) load_k(nxt, g + 1);
+          const int key = 32 * g + j;
+          s = 0.0f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const f4 q4 = *(lcf4_ptr)(r.qrow + h * DH + 4 * i);
+            s = __builtin_fmaf(q4.x, cur[i].x, s);
+            s = __builtin_fmaf(q4.y, cur[i].y, s);
+            s = __builtin_fmaf(q4.z, cur[i].z, s);
+            s = __builtin_fmaf(q4.w, cur[i].w, s);
+          }
+          if (r.alpha != 1.0f) s = r.alpha * s;
+          s = s + (1.0f - (key < len ? 1.0f : 0.0f)) * minus_inf;
+          if (key >= S) s = lowest;
+        }
+        sc[g] = s;
+      }
+      const float m = half_max(fmaxf(fmaxf(sc[0], sc[2]), fmaxf(sc[1], sc[3])));
+#pragma unroll
+      for (int g = 0; g < 4; ++g) sc[g] = (32 * g + j) < S ? exp_p(sc[g] - m) : 0.0f;
+      const float sum = half_sum(sc[0] + sc[2]) + half_sum(sc[1] + sc[3]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int key = 32 * g + j;
+        const float p = sc[g] / sum;  // keys >= S: exactly 0
+        if (g < ng) {
+          if (r.attn && key < S) r.attn[(size_t)h * S + key] = p;
+          if (r.align && hp == 0 && hh == 0 && key < len) r.align[key] = p;
+          r.pbuf[hh * 128 + key] = p;
+        }
+      }
+      // V columns of this lane: (head parity, d = lane & 31), 32 keys per group
+      auto load_v = [&](float(&v)[32], int g) {
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj)
+          v[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                rv, voff, ((32 * g + jj) * D + 2 * hp * DH) * 4, KV_AUX));
+      };
+      float va[32], vb[32];
+      load_v(va, 0);
+      float o = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float(&cur)[32] = (g & 1) ? vb : va;
+        float(&nxt)[32] = (g & 1) ? va : vb;
+        if (g < ng) {
+          if (g + 1 < ng) load_v(nxt, g + 1);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {  // keys >= S: p == 0 and v == 0 (past the descriptor)
+            const f4 p4 = *(lcf4_ptr)(r.pbuf + hh * 128 + 32 * g + 4 * i);
+            o = __builtin_fmaf(p4.x, cur[4 * i + 0], o);
+            o = __builtin_fmaf(p4.y, cur[4 * i + 1], o);
+            o = __builtin_fmaf(p4.z, cur[4 * i + 2], o);
+            o = __builtin_fmaf(p4.w, cur[4 * i + 3], o);
+          }
+        }
+      }
+      r.arow[2 * hp * DH + lane] = (char)quantize1(o, r.aq_o);
+    }
+  }
+}
+
 template <int D, int DH>
 __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   constexpr int H = D / DH;
@@ -309,6 +422,8 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       if (hp + 1 < H / 2) load_v(hp + 1);
       r.arow[2 * hp * DH + lane] = (char)quantize1(o, r.aq_o);
     }
+  } else if (DH == 32 && S <= 128) {
+    attention_row_long<D, DH>(r, lane);
   } else {
     // generic: one head per pass, keys lane and lane + 64
     const int j0 = lane < S ? lane : S - 1;
@@ -398,7 +513,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   float *red_v = reinterpret_cast<float *>(A3 + 16 * LDA3);  // [NW][16]
   int *red_i = reinterpret_cast<int *>(red_v + NW * 16);
   int *flags = red_i + NW * 16;  // [0] = number of finished sentences of this tile
-  float *pbufs = reinterpret_cast<float *>(flags + 16);  // [NW][64] attention scratch
+  float *pbufs = reinterpret_cast<float *>(flags + 16);  // [NW][256] attention scratch
 
   // per-sentence state, owned by wave `wave` (uniform within the wave)
   const int b = m0 + wave;
@@ -504,7 +619,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(b)) * S * D);
         ar.qrow = (lcf_ptr)(xs + wave * LDF);
         ar.arow = (lc_ptr)(A1 + wave * LDA);
-        ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * 64);
+        ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * 256);
         ar.S = S;
         ar.len = len;
         ar.alpha = a.alpha;
@@ -1274,7 +1389,7 @@ int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced) {
 
 size_t fused_decode_lds_bytes(int D, int F, int Ld) {
   return (size_t)3 * 16 * (D + 4) * 4 + (size_t)Ld * 16 * D * 4 + 2 * 16 * (size_t)(D + 16) +
-         16 * (size_t)(F + 16) + 2 * NW * 16 * 4 + 64 + NW * 64 * 4;
+         16 * (size_t)(F + 16) + 2 * NW * 16 * 4 + 64 + NW * 256 * 4;
 }
 
 bool fused_decode_supported(int D, int F, int H, int Ld) {

@@ -150,7 +150,6 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   float *qb = reinterpret_cast<float *>(Av + ER * LDA);
   float *kb = qb + ER * LDQQ;
   float *vb = kb + ER * LDQ;
-  float *pbufs = vb + ER * LDQ;  // [ENW][64] attention scratch (16-byte aligned: see lds bytes)
 
   // row r of this workgroup: sentence s0 + r / S, position r % S
   auto row_sentence = [&](int r) { return s0 + r / S; };
@@ -527,7 +526,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
 
 size_t fused_encode_lds_bytes(int D) {
   return (size_t)ER * (D + 4) * 4 + 3 * (size_t)ER * (D + 16) + (size_t)ER * (D + 4) * 4 +
-         2 * (size_t)ER * (D + 1) * 4 + (size_t)ENW * 64 * 4;
+         2 * (size_t)ER * (D + 1) * 4;
 }
 
 bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S) {

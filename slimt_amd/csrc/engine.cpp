@@ -711,7 +711,8 @@ extern "C" int slimt_hip_ctx_plan(const slimt_hip_ctx *ctx, size_t S, int *encod
   const slimt_hip_model *m = ctx->model;
   const bool fused = ctx->decode_mode != 1;
   if (encoder_fused)
-    *encoder_fused = fused && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
+    *encoder_fused = fused && (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
+                               long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
   if (decoder_fused) *decoder_fused = fused && fused_decode_supported(m->D, m->F, m->H, m->Ld);
   return 0;
 }
@@ -855,6 +856,58 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       const double macs = (double)M * (m->Le * (4.0 * D * D + 2.0 * D * m->F) + m->Ld * 2.0 * D * D);
       ProfScope p(c, SLIMT_HIP_K_ENCODE_FUSED, macs, 0);
       HIPCHK(launch_encode_fused(f, m->D, m->F, m->H, st));
+    }
+    if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, c->dbg_embed.p, nbytes, hipMemcpyDeviceToHost, st));
+    if (h_layers)
+      HIPCHK(hipMemcpyAsync(h_layers, c->dbg_layers.p, nbytes * (size_t)m->Le, hipMemcpyDeviceToHost, st));
+    c->have_encoder_out = true;
+    c->kv_ready = true;
+    return 0;
+  }
+  if (c->decode_mode != 1 && long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
+    // 32 < S <= 128: one persistent workgroup per sentence (kernels.hip, encode_long_kernel)
+    LongEncodeArgs a;
+    FusedEncodeArgs &f = a.f;
+    f.B = B; f.S = S; f.Le = m->Le; f.Ld = m->Ld;
+    for (int l = 0; l < m->Le; ++l) {
+      const EncLayerW &L = m->enc[(size_t)l];
+      FusedEncLayerW &fl = f.L[l];
+      fl.q = L.attn.q.w; fl.k = L.attn.k.w; fl.v = L.attn.v.w; fl.o = L.attn.o.w;
+      fl.ffn1 = L.ffn1.w; fl.ffn2 = L.ffn2.w;
+      fl.attn_ln_s = L.attn.ln.scale.as<float>(); fl.attn_ln_b = L.attn.ln.bias.as<float>();
+      fl.ffn_ln_s = L.ffn_ln.scale.as<float>(); fl.ffn_ln_b = L.ffn_ln.bias.as<float>();
+    }
+    for (int l = 0; l < m->Ld; ++l) {
+      f.dec_k[l] = m->dec[(size_t)l].attn.k.w;
+      f.dec_v[l] = m->dec[(size_t)l].attn.v.w;
+    }
+    f.emb = embed_args(c);
+    f.ids = d_ids ? d_ids : c->ids.as<uint32_t>();
+    f.lengths = d_lengths ? d_lengths : c->lengths.as<uint32_t>();
+    f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
+    f.kv = c->kv.as<float>();
+    f.enc_out = c->x0.as<float>();
+    if (pack) {
+      f.pack = *pack;
+      f.pack_tiles = (pack->N + 15) / 16;
+    }
+    if (h_embed) {
+      HIPCHK(c->dbg_embed.reserve(nbytes));
+      f.embed_out = c->dbg_embed.as<float>();
+    }
+    if (h_layers) {
+      HIPCHK(c->dbg_layers.reserve(nbytes * (size_t)m->Le));
+      f.layer_out = c->dbg_layers.as<float>();
+    }
+    a.H = m->H; a.D = m->D; a.F = m->F;
+    a.x = c->x0.as<float>(); a.y = c->x1.as<float>();
+    a.q = c->q.as<float>(); a.k = c->k.as<float>(); a.v = c->v.as<float>();
+    a.att = c->att.as<float>();
+    a.h8 = c->h8.as<int8_t>();
+    {
+      const double macs = (double)M * (m->Le * (4.0 * D * D + 2.0 * D * m->F) + m->Ld * 2.0 * D * D);
+      ProfScope p(c, SLIMT_HIP_K_ENCODE_FUSED, macs, 0);
+      HIPCHK(launch_encode_long(a, st));
     }
     if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, c->dbg_embed.p, nbytes, hipMemcpyDeviceToHost, st));
     if (h_layers)
@@ -1060,7 +1113,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   hipStream_t st = c->stream;
   const size_t Tmax = (size_t)(limit_factor * (float)S);  // Model.cc:160
   const bool fused_dec = c->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld);
-  const bool lean = fused_dec && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
+  const bool lean = fused_dec && (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
+                                  long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
   DecodeState ds;
   ds.prev = c->prev.as<uint32_t>();
   ds.out_ids = d_out_ids;

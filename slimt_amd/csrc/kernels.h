@@ -300,4 +300,20 @@ size_t shortlist_lds_bytes(int src_vocab, int tgt_vocab);
 size_t shortlist_scratch_bytes(int src_vocab, int tgt_vocab);
 hipError_t launch_shortlist_generate(const ShortlistArgs &a, hipStream_t st);
 
+// ---- persistent per-sentence encoder for 32 < S <= 128 (kernels.hip) -----------
+// One workgroup owns one sentence for the whole encoder: the stages of the
+// layer-by-layer path (same tile code, same numbers) run back to back inside
+// one launch with workgroup barriers in between; the f32 / int8 intermediates
+// go through the context's global scratch (L2-resident per sentence).
+struct LongEncodeArgs {
+  FusedEncodeArgs f;  // sizes, layer weights, decoder K/V projections, embedding, inputs, outputs, pack job
+  int H = 0, D = 0, F = 0;
+  float *x = nullptr, *y = nullptr;                    // [B*S][D] residual stream (ping-pong)
+  float *q = nullptr, *k = nullptr, *v = nullptr;      // [B*S][D]
+  float *att = nullptr;                                // [B*S][D]
+  int8_t *h8 = nullptr;                                // [B*S][F]
+};
+bool long_encode_supported(int D, int F, int H, int Le, int Ld, int S);
+hipError_t launch_encode_long(const LongEncodeArgs &a, hipStream_t st);
+
 }  // namespace slimt_hip

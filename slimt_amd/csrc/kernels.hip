@@ -106,17 +106,21 @@ __device__ __forceinline__ void stage_A_i8(char *A_lds, const int8_t *x, int lda
   }
 }
 
+// One block tile of the GEMM: rows [row0 + bx * R, ...) below row_end, column
+// block by. A kernel of its own (gemm_rows_kernel) or a stage of the persistent
+// per-sentence encoder (encode_long_kernel), which walks the tiles of its
+// sentence with a barrier between calls.
 template <int RM, int NT, int EPI>
-__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmKArgs ka) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_rows_body(const GemmKArgs &ka, int bx, int by, int row0,
+                                               int row_end, char *smem) {
   const GemmArgs &a = ka.g;
   constexpr int R = 16 * RM;
   constexpr int BN = 64 * NT;  // columns per block
   char *A_lds = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int m0 = blockIdx.x * R;
-  const int nt0 = (blockIdx.y * 4 + wave) * NT;  // first 16-col tile of this wave
+  const int m0 = row0 + bx * R;
+  const int nt0 = (by * 4 + wave) * NT;  // first 16-col tile of this wave
   const int K = a.w.K, KS = ka.KS;
   const int n_tiles = a.w.n_tiles;
   const v4i *Wp = reinterpret_cast<const v4i *>(a.w.Wp);
@@ -131,9 +135,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmKArgs ka) {
     const int kc = (K - k0) < KCH ? (K - k0) : KCH;
     if (k0) __syncthreads();
     if (a.x_f32)
-      stage_A_f32<RM>(A_lds, a.x_f32, a.lda, a.M, m0, k0, kc, a.w.a_quant, tid);
+      stage_A_f32<RM>(A_lds, a.x_f32, a.lda, row_end, m0, k0, kc, a.w.a_quant, tid);
     else
-      stage_A_i8<RM>(A_lds, a.x_i8, a.lda, a.M, m0, k0, kc, tid);
+      stage_A_i8<RM>(A_lds, a.x_i8, a.lda, row_end, m0, k0, kc, tid);
     __syncthreads();
     const int ksteps = kc >> 6;
     for (int ks = 0; ks < ksteps; ++ks) {
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmKArgs ka) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + rm * 16 + lg * 4 + r;
-          if (row >= a.M || col >= a.w.N) continue;
+          if (row >= row_end || col >= a.w.N) continue;
           const int accS = acc[rm][nt][r] + 127 * cs;
           if constexpr (EPI == EPI_ACC) {
             a.acc_out[(size_t)row * a.w.N + col] = accS;
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmKArgs ka) {
           const int rl = rm * 16 + lg * 4 + r;
           const int row = m0 + rl;
           float v = 0.0f;
-          if (row < a.M) {
+          if (row < row_end) {
             v = (float)(acc[rm][nt][r] + 127 * cs) * u;
             v = v + pb;
             v = v + a.res[(size_t)row * a.ldres + col];
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmKArgs ka) {
     __syncthreads();
     for (int rl = wave; rl < R; rl += 4) {
       const int row = m0 + rl;
-      if (row < a.M)
+      if (row < row_end)
         wave_layer_norm_row(rowbuf + rl * LDR, a.ln_scale, a.ln_bias, a.eps, BN,
                             a.y + (size_t)row * a.ldy, lane);
     }
@@ -277,12 +281,18 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmKArgs ka) {
           bi = oi;
         }
       }
-      if (row < a.M) {
-        a.part_val[(size_t)row * a.n_parts + blockIdx.y] = bv;
-        a.part_idx[(size_t)row * a.n_parts + blockIdx.y] = bi;
+      if (row < row_end) {
+        a.part_val[(size_t)row * a.n_parts + by] = bv;
+        a.part_idx[(size_t)row * a.n_parts + by] = bi;
       }
     }
   }
+}
+
+template <int RM, int NT, int EPI>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmKArgs ka) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_rows_body<RM, NT, EPI>(ka, blockIdx.x, blockIdx.y, 0, ka.g.M, smem);
 }
 
 int gemm_col_blocks(int N, int epilogue, int *nt_out) {
@@ -556,10 +566,8 @@ hipError_t launch_embed_decoder(const EmbedArgs &e, const uint32_t *prev, int B,
 // ---------------------------------------------------------------------------
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void attention_body(const AttnArgs &a, int b, int h, char *smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int S = a.S, dh = a.dh, LDK = dh + 1;
   float *Ks = reinterpret_cast<float *>(smem);
   float *Vs = Ks + S * LDK;
@@ -629,6 +637,12 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
     }
     if (lane < dh) a.out[(size_t)(b * a.Tq + qi) * a.ldo + h * dh + lane] = o;
   }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attention_body<NW>(a, blockIdx.x / a.H, blockIdx.x % a.H, smem);
 }
 
 hipError_t launch_attention(const AttnArgs &a, hipStream_t st) {
@@ -711,6 +725,154 @@ __global__ void transpose_heads_kernel(const float *in, int d2, int d1, int d0, 
 hipError_t launch_transpose_heads(const float *in, int B, int d2, int d1, int d0, float *out,
                                   hipStream_t st) {
   hipLaunchKernelGGL(transpose_heads_kernel, dim3(d1, d2, B), dim3(64), 0, st, in, d2, d1, d0, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// persistent per-sentence encoder (32 < S <= 128)
+// ---------------------------------------------------------------------------
+// The persistent encoder of encode_fused.hip keeps a sentence's rows in LDS and
+// stops at 32 rows. Longer sentences used to take ~50 launches per batch; with
+// every CU held by another batch's millisecond-long decoder workgroups each of
+// those small launches waited for a CU (B=128, S=64: 1.8 M tok/s against
+// 18.9 M at S=32). Here one workgroup of 256 threads walks ITS sentence through
+// the very same stages -- gemm_rows_body / attention_body tiles, so the numbers
+// are those of the layer-by-layer path bit for bit -- with a workgroup barrier
+// where a launch boundary used to be. Rows of other sentences are never read.
+namespace {
+
+__device__ __forceinline__ GemmKArgs long_gemm(const PreparedWeight &w, const float *x_f32,
+                                               const int8_t *x_i8, int lda) {
+  GemmKArgs ka;
+  ka.g = GemmArgs();
+  ka.g.x_f32 = x_f32;
+  ka.g.x_i8 = x_i8;
+  ka.g.lda = lda;
+  ka.g.w = w;
+  ka.KS = w.K / 64;
+  ka.u = w.u;
+  return ka;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void encode_long_kernel(LongEncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RM = 2, R = 16 * RM;  // 32-row tiles
+  const FusedEncodeArgs &f = a.f;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x, S = f.S, D = a.D, F = a.F;
+  const int row0 = b * S, row1 = row0 + S;
+  const int n_rt = (S + R - 1) / R;
+
+  // side job: the batch's shortlisted output layer (see encode_fused.hip)
+  for (int tile = blockIdx.x; tile < f.pack_tiles; tile += gridDim.x)
+    pack_weight_tile(f.pack, tile, tid, 256);
+
+  // embedding (Model.cc:195-197)
+  for (int i = tid; i < S * D; i += 256) {
+    const int j = i / D, d = i - j * D;
+    const float v = embed1(f.emb, f.ids[row0 + j], d, f.emb.pos + (size_t)j * D);
+    a.x[(size_t)(row0 + j) * D + d] = v;
+    if (f.embed_out) f.embed_out[(size_t)(row0 + j) * D + d] = v;
+  }
+  __syncthreads();
+
+  float *x = a.x, *y = a.y;
+  for (int l = 0; l < f.Le; ++l) {
+    const FusedEncLayerW &L = f.L[l];
+    // Attention::forward (Modules.cc:287-319): Q, K, V projections
+    for (int which = 0; which < 3; ++which) {
+      GemmKArgs ka = long_gemm(which == 0 ? L.q : which == 1 ? L.k : L.v, x, nullptr, D);
+      ka.g.y = which == 0 ? a.q : which == 1 ? a.k : a.v;
+      ka.g.ldy = D;
+      for (int bx = 0; bx < n_rt; ++bx) {
+        gemm_rows_body<RM, 4, EPI_PLAIN>(ka, bx, 0, row0, row1, smem);
+        __syncthreads();
+      }
+    }
+    {
+      AttnArgs aa;
+      aa.q = a.q; aa.k = a.k; aa.v = a.v;
+      aa.ldq = aa.ldk = aa.ldv = aa.ldo = D;
+      aa.lengths = f.lengths;
+      aa.B = f.B; aa.H = a.H; aa.Tq = S; aa.S = S; aa.dh = D / a.H;
+      aa.alpha = f.alpha;
+      aa.out = a.att;
+      for (int h = 0; h < a.H; ++h) {
+        attention_body<4>(aa, b, h, smem);
+        __syncthreads();
+      }
+    }
+    {  // O projection + residual + LayerNorm: x -> y (Modules.cc:308-316)
+      GemmKArgs ka = long_gemm(L.o, a.att, nullptr, D);
+      ka.g.y = y; ka.g.ldy = D;
+      ka.g.res = x; ka.g.ldres = D;
+      ka.g.ln_scale = L.attn_ln_s; ka.g.ln_bias = L.attn_ln_b; ka.g.eps = f.eps;
+      for (int bx = 0; bx < n_rt; ++bx) {
+        gemm_rows_body<RM, 4, EPI_RES_LN>(ka, bx, 0, row0, row1, smem);
+        __syncthreads();
+      }
+    }
+    {  // FFN (Modules.cc:326-331): y -> h8 -> x
+      GemmKArgs k1 = long_gemm(L.ffn1, y, nullptr, D);
+      k1.g.y_i8 = a.h8; k1.g.ldy8 = F; k1.g.a_quant_out = L.ffn2.a_quant;
+      const int cb = (F + 255) / 256;
+      for (int bx = 0; bx < n_rt; ++bx)
+        for (int by = 0; by < cb; ++by) {
+          gemm_rows_body<RM, 4, EPI_RELU_Q>(k1, bx, by, row0, row1, smem);
+          __syncthreads();
+        }
+      GemmKArgs k2 = long_gemm(L.ffn2, nullptr, a.h8, F);
+      k2.g.y = x; k2.g.ldy = D;
+      k2.g.res = y; k2.g.ldres = D;
+      k2.g.ln_scale = L.ffn_ln_s; k2.g.ln_bias = L.ffn_ln_b; k2.g.eps = f.eps;
+      for (int bx = 0; bx < n_rt; ++bx) {
+        gemm_rows_body<RM, 4, EPI_RES_LN>(k2, bx, 0, row0, row1, smem);
+        __syncthreads();
+      }
+    }
+    if (f.layer_out) {
+      float *dst = f.layer_out + (size_t)l * f.B * S * D;
+      for (int i = tid; i < S * D; i += 256) dst[(size_t)row0 * D + i] = x[(size_t)row0 * D + i];
+    }
+  }
+  // encoder output (already in x) + the decoder's cross-attention K/V cache
+  // (Modules.cc:248-249, computed once per batch)
+  if (f.enc_out && f.enc_out != x)
+    for (int i = tid; i < S * D; i += 256) f.enc_out[(size_t)row0 * D + i] = x[(size_t)row0 * D + i];
+  const size_t M = (size_t)f.B * S;
+  for (int l = 0; l < f.Ld; ++l) {
+    GemmKArgs kk = long_gemm(f.dec_k[l], x, nullptr, D);
+    kk.g.y = f.kv + (size_t)(2 * l) * M * D;
+    kk.g.ldy = D;
+    kk.g.kc_S = S;  // K in the cache layout [sentence][head][d/4][key][4]
+    kk.g.kc_dh = D / a.H;
+    GemmKArgs kv = long_gemm(f.dec_v[l], x, nullptr, D);
+    kv.g.y = f.kv + (size_t)(2 * l + 1) * M * D;
+    kv.g.ldy = D;
+    for (int bx = 0; bx < n_rt; ++bx) {
+      gemm_rows_body<RM, 4, EPI_PLAIN>(kk, bx, 0, row0, row1, smem);
+      __syncthreads();
+      gemm_rows_body<RM, 4, EPI_PLAIN>(kv, bx, 0, row0, row1, smem);
+      __syncthreads();
+    }
+  }
+}
+
+bool long_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
+  if (S < 1 || S > 128 || Le < 1 || Le > 6 || Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
+  // gemm_rows_body<2, 4, *>: 256-column blocks; the LayerNorm epilogue owns whole rows
+  return D == 256 && F % 256 == 0 && D / H <= 64;
+}
+
+hipError_t launch_encode_long(const LongEncodeArgs &a, hipStream_t st) {
+  if (!long_encode_supported(a.D, a.F, a.H, a.f.Le, a.f.Ld, a.f.S)) return hipErrorInvalidValue;
+  constexpr int R = 32;
+  const size_t lds_gemm = (size_t)R * LDA + (size_t)R * (256 + 4) * sizeof(float);
+  const size_t lds_attn = 2 * (size_t)a.f.S * (a.D / a.H + 1) * sizeof(float);
+  const size_t lds = lds_gemm > lds_attn ? lds_gemm : lds_attn;
+  hipLaunchKernelGGL(encode_long_kernel, dim3(a.f.B), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
