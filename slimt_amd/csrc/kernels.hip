@@ -131,6 +131,25 @@ __device__ __forceinline__ void gemm_rows_body(const GemmKArgs &ka, int bx, int 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = v4i{0, 0, 0, 0};
 
+  // The B fragments of a whole K chunk (KCH / 64 steps x NT tiles) are requested
+  // at once, before A is staged: weights do not depend on the activations, so the
+  // fetch overlaps the staging + barrier instead of stalling every k-step.
+  constexpr int KSC = KCH / 64;
+  v4i bf[KSC][NT];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) {
+      const int kstep = (k0 >> 6) + ks;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ntile = nt0 + nt;
+        v4i t = {0, 0, 0, 0};
+        if (ntile < n_tiles && kstep < KS) t = Wp[((size_t)ntile * KS + kstep) * 64 + lane];
+        bf[ks][nt] = t;
+      }
+    }
+  };
+  load_chunk(0);
   for (int k0 = 0; k0 < K; k0 += KCH) {
     const int kc = (K - k0) < KCH ? (K - k0) : KCH;
     if (k0) __syncthreads();
@@ -140,23 +159,21 @@ __device__ __forceinline__ void gemm_rows_body(const GemmKArgs &ka, int bx, int 
       stage_A_i8<RM>(A_lds, a.x_i8, a.lda, row_end, m0, k0, kc, tid);
     __syncthreads();
     const int ksteps = kc >> 6;
-    for (int ks = 0; ks < ksteps; ++ks) {
-      v4i af[RM];
 #pragma unroll
-      for (int rm = 0; rm < RM; ++rm)
-        af[rm] = *reinterpret_cast<const v4i *>(A_lds + (rm * 16 + lr) * LDA + ks * 64 + lg * 16);
-      const int kstep = (k0 >> 6) + ks;
+    for (int ks = 0; ks < KSC; ++ks) {
+      if (ks < ksteps) {
+        v4i af[RM];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int ntile = nt0 + nt;
-        if (ntile < n_tiles) {
-          const v4i bf = Wp[((size_t)ntile * KS + kstep) * 64 + lane];
+        for (int rm = 0; rm < RM; ++rm)
+          af[rm] = *reinterpret_cast<const v4i *>(A_lds + (rm * 16 + lr) * LDA + ks * 64 + lg * 16);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int rm = 0; rm < RM; ++rm)
-            acc[rm][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rm], bf, acc[rm][nt], 0, 0, 0);
-        }
+            acc[rm][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rm], bf[ks][nt], acc[rm][nt], 0, 0, 0);
       }
     }
+    if (k0 + KCH < K) load_chunk(k0 + KCH);  // under the next chunk's staging
   }
 
   // ---- epilogue -----------------------------------------------------------
@@ -756,14 +773,141 @@ __device__ __forceinline__ GemmKArgs long_gemm(const PreparedWeight &w, const fl
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void encode_long_kernel(LongEncodeArgs a) {
+// Self-attention of one sentence (S <= 128 keys, d_head 32) on the f32 matrix
+// cores, for the persistent per-sentence encoder: per head the q / k / v slices
+// are staged in LDS, then wave w takes the 32 queries of tile w. Same scheme as
+// encode_fused.hip (chains of v_mfma_f32_32x32x2_f32 over ascending k are
+// bit-identical to the fmaf chains of attention_body), extended to four key
+// tiles: a row sum in the canonical 128-column order first adds keys L and
+// L + 64 (tiles g and g + 2), then runs the 64-lane butterfly -- masks 1, 2 and
+// 8, 16 inside a lane's registers, 4 across half-waves, 32 between tiles 0 / 1.
+__device__ __forceinline__ void attention_mfma_long(const LongEncodeArgs &a, int b, char *smem) {
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  constexpr int DH = 32, LDH = DH + 1;
+  const FusedEncodeArgs &f = a.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = f.S, D = a.D, H = a.H;
+  const int row0 = b * S;
+  const int len = (int)f.lengths[b];
+  const int ng = (S + 31) >> 5;
+  float *Qs = reinterpret_cast<float *>(smem);
+  float *Ks = Qs + 128 * LDH;
+  float *Vs = Ks + 128 * LDH;
+  const int n = lane & 31, hh = lane >> 5;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  auto tree32 = [&](const float(&x)[16], auto op, auto op_halves) -> float {
+    float t4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      t4[g] = op(op(x[4 * g], x[4 * g + 1]), op(x[4 * g + 2], x[4 * g + 3]));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) t4[g] = op_halves(t4[g]);
+    return op(op(t4[0], t4[1]), op(t4[2], t4[3]));
+  };
+  auto fadd = [](float x, float y) { return x + y; };
+  auto fmax_ = [](float x, float y) { return fmaxf(x, y); };
+  auto add_halves = [](float x) { return bf_add<32>(x); };
+  auto max_halves = [](float x) { return bf_max<32>(x); };
+  for (int h = 0; h < H; ++h) {
+    for (int i = tid; i < S * DH; i += 256) {
+      const int j = i >> 5, d = i & 31;
+      const size_t src = (size_t)(row0 + j) * D + h * DH + d;
+      Qs[j * LDH + d] = a.q[src];
+      Ks[j * LDH + d] = a.k[src];
+      Vs[j * LDH + d] = a.v[src];
+    }
+    __syncthreads();
+    const int qt = wave;  // query tile of this wave
+    if (qt * 32 < S) {
+      const int qrow = (qt * 32 + n) < S ? (qt * 32 + n) : S - 1;
+      float sc[4][16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v16f st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (g < ng) {
+          const int krow = (32 * g + n) < S ? (32 * g + n) : S - 1;
+#pragma unroll
+          for (int k0 = 0; k0 < DH; k0 += 2)
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[krow * LDH + k0 + hh], Qs[qrow * LDH + k0 + hh], st, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * g + 8 * (r >> 2) + 4 * hh + (r & 3);
+          float v = st[r];
+          if (f.alpha != 1.0f) v = f.alpha * v;
+          v = v + (1.0f - (key < len ? 1.0f : 0.0f)) * minus_inf;
+          if (key >= S) v = lowest;
+          sc[g][r] = v;
+        }
+      }
+      float m;
+      {
+        float mx[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx[r] = fmaxf(fmaxf(sc[0][r], sc[2][r]), fmaxf(sc[1][r], sc[3][r]));
+        m = tree32(mx, fmax_, max_halves);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * g + 8 * (r >> 2) + 4 * hh + (r & 3);
+          sc[g][r] = key < S ? exp_p(sc[g][r] - m) : 0.0f;
+        }
+      float sum;
+      {
+        float u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = sc[0][r] + sc[2][r];  // keys L, L + 64
+        const float t0 = tree32(u, fadd, add_halves);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = sc[1][r] + sc[3][r];  // keys L + 32, L + 96
+        sum = t0 + tree32(u, fadd, add_halves);
+      }
+      v16f o = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g < ng) {
+          float pa[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[g][r] = sc[g][r] / sum;  // keys >= S: exactly 0
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {  // half of P changes half-waves (see encode_fused.hip)
+            const slimt_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[g][4 * q4 + 0]),
+                                                                  __float_as_int(sc[g][4 * q4 + 1]), false, false);
+            const slimt_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[g][4 * q4 + 2]),
+                                                                  __float_as_int(sc[g][4 * q4 + 3]), false, false);
+            pa[4 * q4 + 0] = __int_as_float(s01.x);
+            pa[4 * q4 + 1] = __int_as_float(s23.x);
+            pa[4 * q4 + 2] = __int_as_float(s01.y);
+            pa[4 * q4 + 3] = __int_as_float(s23.y);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = 32 * g + 2 * i + hh;
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], Vs[(key < S ? key : S - 1) * LDH + n], o, 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = qt * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+        if (qi < S) a.att[(size_t)(row0 + qi) * D + h * DH + n] = o[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void encode_long_kernel(LongEncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int RM = 2, R = 16 * RM;  // 32-row tiles
+  constexpr int RM = 4, R = 16 * RM;  // 64-row tiles: a sentence is one or two of them
   const FusedEncodeArgs &f = a.f;
   const int tid = threadIdx.x;
   const int b = blockIdx.x, S = f.S, D = a.D, F = a.F;
   const int row0 = b * S, row1 = row0 + S;
-  const int n_rt = (S + R - 1) / R;
+  const int n_rt = (S + R - 1) / R, n_rt2 = (S + 31) / 32;
 
   // side job: the batch's shortlisted output layer (see encode_fused.hip)
   for (int tile = blockIdx.x; tile < f.pack_tiles; tile += gridDim.x)
@@ -791,26 +935,14 @@ __global__ __launch_bounds__(256) void encode_long_kernel(LongEncodeArgs a) {
         __syncthreads();
       }
     }
-    {
-      AttnArgs aa;
-      aa.q = a.q; aa.k = a.k; aa.v = a.v;
-      aa.ldq = aa.ldk = aa.ldv = aa.ldo = D;
-      aa.lengths = f.lengths;
-      aa.B = f.B; aa.H = a.H; aa.Tq = S; aa.S = S; aa.dh = D / a.H;
-      aa.alpha = f.alpha;
-      aa.out = a.att;
-      for (int h = 0; h < a.H; ++h) {
-        attention_body<4>(aa, b, h, smem);
-        __syncthreads();
-      }
-    }
+    attention_mfma_long(a, b, smem);
     {  // O projection + residual + LayerNorm: x -> y (Modules.cc:308-316)
       GemmKArgs ka = long_gemm(L.o, a.att, nullptr, D);
       ka.g.y = y; ka.g.ldy = D;
       ka.g.res = x; ka.g.ldres = D;
       ka.g.ln_scale = L.attn_ln_s; ka.g.ln_bias = L.attn_ln_b; ka.g.eps = f.eps;
-      for (int bx = 0; bx < n_rt; ++bx) {
-        gemm_rows_body<RM, 4, EPI_RES_LN>(ka, bx, 0, row0, row1, smem);
+      for (int bx = 0; bx < n_rt2; ++bx) {  // whole rows per tile: 32-row tiles keep the LDS small
+        gemm_rows_body<2, 4, EPI_RES_LN>(ka, bx, 0, row0, row1, smem);
         __syncthreads();
       }
     }
@@ -827,8 +959,8 @@ __global__ __launch_bounds__(256) void encode_long_kernel(LongEncodeArgs a) {
       k2.g.y = x; k2.g.ldy = D;
       k2.g.res = y; k2.g.ldres = D;
       k2.g.ln_scale = L.ffn_ln_s; k2.g.ln_bias = L.ffn_ln_b; k2.g.eps = f.eps;
-      for (int bx = 0; bx < n_rt; ++bx) {
-        gemm_rows_body<RM, 4, EPI_RES_LN>(k2, bx, 0, row0, row1, smem);
+      for (int bx = 0; bx < n_rt2; ++bx) {
+        gemm_rows_body<2, 4, EPI_RES_LN>(k2, bx, 0, row0, row1, smem);
         __syncthreads();
       }
     }
@@ -863,14 +995,13 @@ __global__ __launch_bounds__(256) void encode_long_kernel(LongEncodeArgs a) {
 bool long_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
   if (S < 1 || S > 128 || Le < 1 || Le > 6 || Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
   // gemm_rows_body<2, 4, *>: 256-column blocks; the LayerNorm epilogue owns whole rows
-  return D == 256 && F % 256 == 0 && D / H <= 64;
+  return D == 256 && F % 256 == 0 && D / H == 32;
 }
 
 hipError_t launch_encode_long(const LongEncodeArgs &a, hipStream_t st) {
   if (!long_encode_supported(a.D, a.F, a.H, a.f.Le, a.f.Ld, a.f.S)) return hipErrorInvalidValue;
-  constexpr int R = 32;
-  const size_t lds_gemm = (size_t)R * LDA + (size_t)R * (256 + 4) * sizeof(float);
-  const size_t lds_attn = 2 * (size_t)a.f.S * (a.D / a.H + 1) * sizeof(float);
+  const size_t lds_gemm = (size_t)32 * LDA + (size_t)32 * (256 + 4) * sizeof(float);  // RES_LN, 32 rows (> 64 * LDA)
+  const size_t lds_attn = 3 * (size_t)128 * 33 * sizeof(float);  // q, k, v slices of one head
   const size_t lds = lds_gemm > lds_attn ? lds_gemm : lds_attn;
   hipLaunchKernelGGL(encode_long_kernel, dim3(a.f.B), dim3(256), lds, st, a);
   return hipGetLastError();
