@@ -524,6 +524,447 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   }
 }
 
+// =============================================================================
+// Sentences of 33..128 tokens: one 16-wave workgroup per sentence.
+//
+// A sentence longer than 32 rows does not fit the LDS-resident kernel above
+// (f32 residual + all-head q/k/v). Here only the int8 MFMA operands live in LDS
+// (the quantised rows of the current GEMM, the FFN's hidden chunks, and two
+// heads' q/k/v slices at a time for the attention); the f32 tensors of the
+// sentence -- residual, pre-LayerNorm sums, q, k, v: 5 x S x 1 KiB -- go through
+// the context's scratch buffers, which stay in L2 between the phases of the one
+// workgroup that touches them. Tiling as above: wave w owns column tile w of
+// every 256-wide output, with up to 8 row tiles of accumulators, so a weight
+// fragment is used for up to 128 rows. Same arithmetic, same order, same bits.
+namespace {
+
+constexpr int LR = 128;  // rows of LDS operands (a sentence)
+
+// row-wise LayerNorm of a register-held row (the arithmetic of eln_row)
+template <int DPL>
+__device__ __forceinline__ void ln_regs(float (&v)[DPL], const float (&scale)[DPL],
+                                        const float (&bias)[DPL], float eps) {
+  constexpr int D = 64 * DPL;
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) s += v[i];
+  s = wave_sum(s);
+  const float mean = s / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float d = v[i] - mean;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  const float sigma = __builtin_sqrtf(q / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float t = (v[i] - mean) / sigma;
+    const float m = scale[i] * t;
+    v[i] = m + bias[i];
+  }
+}
+
+}  // namespace
+
+// NG: key tiles of 32 the attention is compiled for (2: S <= 64, 4: S <= 128)
+template <int NG>
+__global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  constexpr int KSD = 4, D = 256, DH = 32, H = D / DH;
+  constexpr int LDA = D + 16;   // int8 operand rows
+  constexpr int LDH = DH + 1;   // staged q / k / v head slices (f32)
+  constexpr int NRT = 2 * NG;  // row tiles at most (32 rows per key tile)
+  const FusedEncodeArgs &f = a.f;
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  SLIMT_PHASE_LANE;
+  const int b = blockIdx.x, S = f.S;
+  const int row0 = b * S;
+  const int nrt = (S + 15) >> 4;  // row tiles in use (uniform)
+  const int len = (int)f.lengths[b];
+
+  char *A = smem;                                          // [128][272] int8
+  char *H0 = A + LR * LDA, *H1 = H0 + LR * LDA;            // FFN hidden chunks
+  float *stage = reinterpret_cast<float *>(A + LR * LDA);  // attention: [2 heads][q,k,v][128][33] (aliases H0/H1)
+  float *X = a.x + (size_t)row0 * D, *Y = a.y + (size_t)row0 * D;
+  float *Qg = a.q + (size_t)row0 * D, *Kg = a.k + (size_t)row0 * D, *Vg = a.v + (size_t)row0 * D;
+
+  // side job: the batch's shortlisted output layer (see above)
+  for (int tile = blockIdx.x; tile < f.pack_tiles; tile += gridDim.x) pack_weight_tile(f.pack, tile, tid, 1024);
+
+  // quantise the sentence's rows of `src` (global f32) with aq into A
+  auto quantise_rows = [&](const float *src, float aq) {
+    for (int r = wave; r < 16 * nrt; r += ENW) {
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) {
+        const float v = r < S ? src[(size_t)r * D + lane + 64 * i] : 0.0f;
+        A[r * LDA + lane + 64 * i] = (char)quantize1(v, aq);
+      }
+    }
+  };
+  // acc[rt] += A(row tile rt) x fragments of this wave's column tile
+  auto mma_rows = [&](const char *Aop, const v4i(&bf)[KSD], v4i(&acc)[NRT]) {
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      if (rt < nrt) {
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+          const v4i av = *reinterpret_cast<const v4i *>(Aop + (16 * rt + lr) * LDA + ks * 64 + lg * 16);
+          acc[rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bf[ks], acc[rt], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto zero_acc = [&](v4i(&acc)[NRT]) {
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) acc[rt] = v4i{0, 0, 0, 0};
+  };
+
+  // ---- embedding (Model.cc:195-197) ----------------------------------------
+  for (int r = wave; r < S; r += ENW) {
+    const uint32_t tok = f.ids[(size_t)row0 + r];
+#pragma unroll
+    for (int i = 0; i < KSD; ++i) {
+      const float e = (float)f.emb.wemb[(size_t)tok * D + lane + 64 * i] * f.emb.inv_mult;
+      const float sc = e * f.emb.sqrt_d;
+      const float v = sc + f.emb.pos[(size_t)r * D + lane + 64 * i];
+      X[(size_t)r * D + lane + 64 * i] = v;
+      if (f.embed_out) f.embed_out[((size_t)row0 + r) * D + lane + 64 * i] = v;
+    }
+  }
+  __syncthreads();
+
+  for (int l = 0; l < f.Le; ++l) {
+    SLIMT_PHASE_LANE;
+    const FusedEncLayerW &L = f.L[l];
+    const int col = wave * 16 + lr;
+    // ---- Q, K, V projections (Modules.cc:287-300) -> global f32 ----------------
+    for (int which = 0; which < 3; ++which) {
+      const PreparedWeight &W = which == 0 ? L.q : which == 1 ? L.k : L.v;
+      float *dst = which == 0 ? Qg : which == 1 ? Kg : Vg;
+      v4i bf[KSD];
+      load_frags<KSD>(bf, W, wave, 0, lane);
+      int cs;
+      float pb;
+      load_epi(W, wave, lr, cs, pb);
+      quantise_rows(X, W.a_quant);
+      __syncthreads();
+      v4i acc[NRT];
+      zero_acc(acc);
+      mma_rows(A, bf, acc);
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        if (rt < nrt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + lg * 4 + r;
+            if (row < S) dst[(size_t)row * D + col] = edequant(acc[rt][r], cs, W.u, pb);
+          }
+        }
+      __syncthreads();
+    }
+    // ---- scaled_dot_product_attention (Modules.cc:24-86), two heads staged at a
+    // time, a wave per (head, 32-query tile); f32 MFMA chains as above, four key
+    // tiles (see attention_mfma_long in kernels.hip). Output -> A, quantised for
+    // the O projection.
+    {
+      const int n = lane & 31, hh = lane >> 5;
+      const int ng = (S + 31) >> 5;
+      const float minus_inf = -99999999.0f;  // Input.cc:56-61
+      const float lowest = -3.402823466e+38f;
+      auto tree32 = [&](const float(&x)[16], auto op, auto op_halves) -> float {
+        float t4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t4[g] = op(op(x[4 * g], x[4 * g + 1]), op(x[4 * g + 2], x[4 * g + 3]));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t4[g] = op_halves(t4[g]);
+        return op(op(t4[0], t4[1]), op(t4[2], t4[3]));
+      };
+      auto fadd = [](float x, float y) { return x + y; };
+      auto fmax_ = [](float x, float y) { return fmaxf(x, y); };
+      auto add_halves = [](float x) { return bf_add<32>(x); };
+      auto max_halves = [](float x) { return bf_max<32>(x); };
+      for (int hp = 0; hp < H / 2; ++hp) {
+        // stage q / k / v of heads 2 hp, 2 hp + 1: [slot][matrix][row][33]
+        for (int i = tid; i < S * 64; i += 1024) {
+          const int j = i >> 6, c = i & 63;  // c: 2 heads x 32 dims, contiguous in the row
+          const size_t src = (size_t)j * D + hp * 64 + c;
+          float *dst = stage + ((c >> 5) * 3) * LR * LDH + j * LDH + (c & 31);
+          dst[0] = Qg[src];
+          dst[LR * LDH] = Kg[src];
+          dst[2 * LR * LDH] = Vg[src];
+        }
+        __syncthreads();
+        const int slot = wave & 1, qt = wave >> 1;  // job of this wave
+        if (qt * 32 < S) {
+          const int h = 2 * hp + slot;
+          const float *Qs = stage + (slot * 3) * LR * LDH, *Ks = Qs + LR * LDH, *Vs = Ks + LR * LDH;
+          const int qrow = (qt * 32 + n) < S ? (qt * 32 + n) : S - 1;
+          float sc[NG][16];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            v16f st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (g < ng) {
+              const int krow = (32 * g + n) < S ? (32 * g + n) : S - 1;
+#pragma unroll
+              for (int k0 = 0; k0 < DH; k0 += 2)
+                st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[krow * LDH + k0 + hh], Qs[qrow * LDH + k0 + hh], st, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = 32 * g + 8 * (r >> 2) + 4 * hh + (r & 3);
+              float v = st[r];
+              if (f.alpha != 1.0f) v = f.alpha * v;
+              v = v + (1.0f - (key < len ? 1.0f : 0.0f)) * minus_inf;
+              if (key >= S) v = lowest;
+              sc[g][r] = v;
+            }
+          }
+          float m;
+          {
+            float mx[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              mx[r] = NG == 4 ? fmaxf(fmaxf(sc[0][r], sc[NG - 2][r]), fmaxf(sc[1][r], sc[NG - 1][r]))
+                              : fmaxf(sc[0][r], sc[1][r]);
+            m = tree32(mx, fmax_, max_halves);
+          }
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = 32 * g + 8 * (r >> 2) + 4 * hh + (r & 3);
+              sc[g][r] = key < S ? exp_p(sc[g][r] - m) : 0.0f;
+            }
+          float sum;
+          {
+            float u[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)  // keys L, L + 64 (with S <= 64 the second term is an exact + 0)
+              u[r] = NG == 4 ? sc[0][r] + sc[NG - 2][r] : sc[0][r];
+            const float t0 = tree32(u, fadd, add_halves);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)  // keys L + 32, L + 96
+              u[r] = NG == 4 ? sc[1][r] + sc[NG - 1][r] : sc[1][r];
+            sum = t0 + tree32(u, fadd, add_halves);
+          }
+          v16f o = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            if (g < ng) {
+              float pa[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) sc[g][r] = sc[g][r] / sum;  // keys >= S: exactly 0
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                const slimt_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[g][4 * q4 + 0]),
+                                                                      __float_as_int(sc[g][4 * q4 + 1]), false, false);
+                const slimt_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[g][4 * q4 + 2]),
+                                                                      __float_as_int(sc[g][4 * q4 + 3]), false, false);
+                pa[4 * q4 + 0] = __int_as_float(s01.x);
+                pa[4 * q4 + 1] = __int_as_float(s23.x);
+                pa[4 * q4 + 2] = __int_as_float(s01.y);
+                pa[4 * q4 + 3] = __int_as_float(s23.y);
+              }
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                const int key = 32 * g + 2 * i + hh;
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], Vs[(key < S ? key : S - 1) * LDH + n], o, 0, 0, 0);
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qi = qt * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+            if (qi < S) A[qi * LDA + h * DH + n] = (char)quantize1(o[r], L.o.a_quant);
+          }
+        }
+        __syncthreads();
+      }
+      // rows past the sentence in the last row tile keep a defined operand
+      for (int r = S + wave; r < 16 * nrt; r += ENW)
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) A[r * LDA + lane + 64 * i] = 0;
+      __syncthreads();
+    }
+    float lsc[KSD], lbi[KSD];
+    {  // O projection + residual (Modules.cc:308-314): Y = X + O(att)
+      v4i bf[KSD];
+      load_frags<KSD>(bf, L.o, wave, 0, lane);
+      int cs;
+      float pb;
+      load_epi(L.o, wave, lr, cs, pb);
+      v4i acc[NRT];
+      zero_acc(acc);
+      mma_rows(A, bf, acc);
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        if (rt < nrt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + lg * 4 + r;
+            if (row < S) Y[(size_t)row * D + col] = X[(size_t)row * D + col] + edequant(acc[rt][r], cs, L.o.u, pb);
+          }
+        }
+    }
+    __syncthreads();
+    // LayerNorm -> X (the FFN's residual source), quantised for FFN1 into A
+    load_ln<KSD>(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);
+    for (int r = wave; r < 16 * nrt; r += ENW) {
+      float v[KSD];
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) v[i] = r < S ? Y[(size_t)r * D + lane + 64 * i] : 0.0f;
+      ln_regs<KSD>(v, lsc, lbi, f.eps);
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) {
+        if (r < S) X[(size_t)r * D + lane + 64 * i] = v[i];
+        A[r * LDA + lane + 64 * i] = r < S ? (char)quantize1(v[i], L.ffn1.a_quant) : (char)0;
+      }
+    }
+    __syncthreads();
+    // ---- FFN (Modules.cc:326-331): hidden columns in chunks of 256 ---------------
+    {
+      const int NC = a.F / 256;
+      const int KSF = a.F / 64;
+      v4i f2[NRT];
+      zero_acc(f2);
+      v4i b1[KSD], b2[4];
+      int cs1;
+      float pb1;
+      auto ffn1_chunk = [&](int fc, char *Hb) {
+        v4i c1[NRT];
+        zero_acc(c1);
+        mma_rows(A, b1, c1);
+        const int cs = cs1;
+        const float pb = pb1;
+        // fragments consumed: request the next chunk's (reads past the last tile return zeros)
+        load_frags<KSD>(b1, L.ffn1, (fc + 1) * 16 + wave, 0, lane);
+        load_epi(L.ffn1, (fc + 1) * 16 + wave, lr, cs1, pb1);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+          if (rt < nrt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = edequant(c1[rt][r], cs, L.ffn1.u, pb);
+              v = v > 0.0f ? v : 0.0f;
+              Hb[(16 * rt + lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v, L.ffn2.a_quant);
+            }
+          }
+      };
+      load_frags<KSD>(b1, L.ffn1, wave, 0, lane);
+      load_epi(L.ffn1, wave, lr, cs1, pb1);
+      load_frags<4>(b2, L.ffn2, wave, 0, lane);
+      ffn1_chunk(0, H0);
+      __syncthreads();
+      for (int fc = 0; fc < NC; ++fc) {
+        char *Hcur = (fc & 1) ? H1 : H0;
+        char *Hnext = (fc & 1) ? H0 : H1;
+        if (fc + 1 < NC) ffn1_chunk(fc + 1, Hnext);
+        mma_rows(Hcur, b2, f2);
+        {  // next k-chunk of this wave's FFN2 tile (past the last: clamped, unused)
+          const int nk = (fc + 1 < NC ? fc + 1 : fc) * 4;
+          (void)KSF;
+          load_frags<4>(b2, L.ffn2, wave, nk, lane);
+        }
+        __syncthreads();
+      }
+      int cs;
+      float pb;
+      load_epi(L.ffn2, wave, lr, cs, pb);
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        if (rt < nrt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + lg * 4 + r;
+            if (row < S) Y[(size_t)row * D + col] = edequant(f2[rt][r], cs, L.ffn2.u, pb) + X[(size_t)row * D + col];
+          }
+        }
+    }
+    __syncthreads();
+    load_ln<KSD>(L.ffn_ln_s, L.ffn_ln_b, lane, lsc, lbi);
+    for (int r = wave; r < S; r += ENW) {
+      float v[KSD];
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) v[i] = Y[(size_t)r * D + lane + 64 * i];
+      ln_regs<KSD>(v, lsc, lbi, f.eps);
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) {
+        X[(size_t)r * D + lane + 64 * i] = v[i];
+        if (f.layer_out) f.layer_out[((size_t)l * f.B * S + row0 + r) * D + lane + 64 * i] = v[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- encoder output + decoder cross-attention K/V (Modules.cc:248-249) ---------
+  if (f.enc_out && f.enc_out != a.x)
+    for (int r = wave; r < S; r += ENW)
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) f.enc_out[((size_t)row0 + r) * D + lane + 64 * i] = X[(size_t)r * D + lane + 64 * i];
+  const size_t M = (size_t)f.B * S;
+  for (int l = 0; l < f.Ld; ++l) {
+    SLIMT_PHASE_LANE;
+    const int col = wave * 16 + lr;
+    for (int which = 0; which < 2; ++which) {
+      const PreparedWeight &W = which == 0 ? f.dec_k[l] : f.dec_v[l];
+      float *out = f.kv + (size_t)(2 * l + which) * M * D;
+      v4i bf[KSD];
+      load_frags<KSD>(bf, W, wave, 0, lane);
+      int cs;
+      float pb;
+      load_epi(W, wave, lr, cs, pb);
+      quantise_rows(X, W.a_quant);
+      __syncthreads();
+      v4i acc[NRT];
+      zero_acc(acc);
+      mma_rows(A, bf, acc);
+      const int hcol = col / DH, d = col % DH;
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        if (rt < nrt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + lg * 4 + r;
+            if (row < S) {
+              const float v = edequant(acc[rt][r], cs, W.u, pb);
+              if (which == 0) {  // K cache layout [sentence][head][d/4][key][4]
+                const size_t chunk = ((size_t)b * H + hcol) * (DH / 4) + (d >> 2);
+                out[(chunk * S + row) * 4 + (d & 3)] = v;
+              } else {
+                out[((size_t)row0 + row) * D + col] = v;
+              }
+            }
+          }
+        }
+      __syncthreads();
+    }
+  }
+}
+
+size_t long16_lds_bytes() {
+  return (size_t)LR * (256 + 16) + 2 * 3 * (size_t)LR * 33 * sizeof(float);
+}
+
+bool long_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
+  if (S < 1 || S > LR || Le < 1 || Le > 6 || Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
+  return D == 256 && F % 256 == 0 && F <= 4096 && D / H == 32 && long16_lds_bytes() <= 160 * 1024;
+}
+
+hipError_t launch_encode_long(const LongEncodeArgs &a, hipStream_t st) {
+  if (!long_encode_supported(a.D, a.F, a.H, a.f.Le, a.f.Ld, a.f.S)) return hipErrorInvalidValue;
+  const size_t lds = long16_lds_bytes();
+  auto k = a.f.S <= 64 ? encode_long16_kernel<2> : encode_long16_kernel<4>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(a.f.B), dim3(1024), lds, st, a);
+  return hipGetLastError();
+}
+
 size_t fused_encode_lds_bytes(int D) {
   return (size_t)ER * (D + 4) * 4 + 3 * (size_t)ER * (D + 16) + (size_t)ER * (D + 4) * 4 +
          2 * (size_t)ER * (D + 1) * 4;

@@ -745,266 +745,4 @@ hipError_t launch_transpose_heads(const float *in, int B, int d2, int d1, int d0
   return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------
-// persistent per-sentence encoder (32 < S <= 128)
-// ---------------------------------------------------------------------------
-// The persistent encoder of encode_fused.hip keeps a sentence's rows in LDS and
-// stops at 32 rows. Longer sentences used to take ~50 launches per batch; with
-// every CU held by another batch's millisecond-long decoder workgroups each of
-// those small launches waited for a CU (B=128, S=64: 1.8 M tok/s against
-// 18.9 M at S=32). Here one workgroup of 256 threads walks ITS sentence through
-// the very same stages -- gemm_rows_body / attention_body tiles, so the numbers
-// are those of the layer-by-layer path bit for bit -- with a workgroup barrier
-// where a launch boundary used to be. Rows of other sentences are never read.
-namespace {
-
-__device__ __forceinline__ GemmKArgs long_gemm(const PreparedWeight &w, const float *x_f32,
-                                               const int8_t *x_i8, int lda) {
-  GemmKArgs ka;
-  ka.g = GemmArgs();
-  ka.g.x_f32 = x_f32;
-  ka.g.x_i8 = x_i8;
-  ka.g.lda = lda;
-  ka.g.w = w;
-  ka.KS = w.K / 64;
-  ka.u = w.u;
-  return ka;
-}
-
-}  // namespace
-
-// Self-attention of one sentence (S <= 128 keys, d_head 32) on the f32 matrix
-// cores, for the persistent per-sentence encoder: per head the q / k / v slices
-// are staged in LDS, then wave w takes the 32 queries of tile w. Same scheme as
-// encode_fused.hip (chains of v_mfma_f32_32x32x2_f32 over ascending k are
-// bit-identical to the fmaf chains of attention_body), extended to four key
-// tiles: a row sum in the canonical 128-column order first adds keys L and
-// L + 64 (tiles g and g + 2), then runs the 64-lane butterfly -- masks 1, 2 and
-// 8, 16 inside a lane's registers, 4 across half-waves, 32 between tiles 0 / 1.
-__device__ __forceinline__ void attention_mfma_long(const LongEncodeArgs &a, int b, char *smem) {
-  typedef float v16f __attribute__((ext_vector_type(16)));
-  constexpr int DH = 32, LDH = DH + 1;
-  const FusedEncodeArgs &f = a.f;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int S = f.S, D = a.D, H = a.H;
-  const int row0 = b * S;
-  const int len = (int)f.lengths[b];
-  const int ng = (S + 31) >> 5;
-  float *Qs = reinterpret_cast<float *>(smem);
-  float *Ks = Qs + 128 * LDH;
-  float *Vs = Ks + 128 * LDH;
-  const int n = lane & 31, hh = lane >> 5;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  auto tree32 = [&](const float(&x)[16], auto op, auto op_halves) -> float {
-    float t4[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      t4[g] = op(op(x[4 * g], x[4 * g + 1]), op(x[4 * g + 2], x[4 * g + 3]));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) t4[g] = op_halves(t4[g]);
-    return op(op(t4[0], t4[1]), op(t4[2], t4[3]));
-  };
-  auto fadd = [](float x, float y) { return x + y; };
-  auto fmax_ = [](float x, float y) { return fmaxf(x, y); };
-  auto add_halves = [](float x) { return bf_add<32>(x); };
-  auto max_halves = [](float x) { return bf_max<32>(x); };
-  for (int h = 0; h < H; ++h) {
-    for (int i = tid; i < S * DH; i += 256) {
-      const int j = i >> 5, d = i & 31;
-      const size_t src = (size_t)(row0 + j) * D + h * DH + d;
-      Qs[j * LDH + d] = a.q[src];
-      Ks[j * LDH + d] = a.k[src];
-      Vs[j * LDH + d] = a.v[src];
-    }
-    __syncthreads();
-    const int qt = wave;  // query tile of this wave
-    if (qt * 32 < S) {
-      const int qrow = (qt * 32 + n) < S ? (qt * 32 + n) : S - 1;
-      float sc[4][16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        v16f st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        if (g < ng) {
-          const int krow = (32 * g + n) < S ? (32 * g + n) : S - 1;
-#pragma unroll
-          for (int k0 = 0; k0 < DH; k0 += 2)
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[krow * LDH + k0 + hh], Qs[qrow * LDH + k0 + hh], st, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = 32 * g + 8 * (r >> 2) + 4 * hh + (r & 3);
-          float v = st[r];
-          if (f.alpha != 1.0f) v = f.alpha * v;
-          v = v + (1.0f - (key < len ? 1.0f : 0.0f)) * minus_inf;
-          if (key >= S) v = lowest;
-          sc[g][r] = v;
-        }
-      }
-      float m;
-      {
-        float mx[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx[r] = fmaxf(fmaxf(sc[0][r], sc[2][r]), fmaxf(sc[1][r], sc[3][r]));
-        m = tree32(mx, fmax_, max_halves);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = 32 * g + 8 * (r >> 2) + 4 * hh + (r & 3);
-          sc[g][r] = key < S ? exp_p(sc[g][r] - m) : 0.0f;
-        }
-      float sum;
-      {
-        float u[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = sc[0][r] + sc[2][r];  // keys L, L + 64
-        const float t0 = tree32(u, fadd, add_halves);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = sc[1][r] + sc[3][r];  // keys L + 32, L + 96
-        sum = t0 + tree32(u, fadd, add_halves);
-      }
-      v16f o = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (g < ng) {
-          float pa[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[g][r] = sc[g][r] / sum;  // keys >= S: exactly 0
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {  // half of P changes half-waves (see encode_fused.hip)
-            const slimt_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[g][4 * q4 + 0]),
-                                                                  __float_as_int(sc[g][4 * q4 + 1]), false, false);
-            const slimt_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[g][4 * q4 + 2]),
-                                                                  __float_as_int(sc[g][4 * q4 + 3]), false, false);
-            pa[4 * q4 + 0] = __int_as_float(s01.x);
-            pa[4 * q4 + 1] = __int_as_float(s23.x);
-            pa[4 * q4 + 2] = __int_as_float(s01.y);
-            pa[4 * q4 + 3] = __int_as_float(s23.y);
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = 32 * g + 2 * i + hh;
-            o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], Vs[(key < S ? key : S - 1) * LDH + n], o, 0, 0, 0);
-          }
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qi = qt * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
-        if (qi < S) a.att[(size_t)(row0 + qi) * D + h * DH + n] = o[r];
-      }
-    }
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void encode_long_kernel(LongEncodeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int RM = 4, R = 16 * RM;  // 64-row tiles: a sentence is one or two of them
-  const FusedEncodeArgs &f = a.f;
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x, S = f.S, D = a.D, F = a.F;
-  const int row0 = b * S, row1 = row0 + S;
-  const int n_rt = (S + R - 1) / R, n_rt2 = (S + 31) / 32;
-
-  // side job: the batch's shortlisted output layer (see encode_fused.hip)
-  for (int tile = blockIdx.x; tile < f.pack_tiles; tile += gridDim.x)
-    pack_weight_tile(f.pack, tile, tid, 256);
-
-  // embedding (Model.cc:195-197)
-  for (int i = tid; i < S * D; i += 256) {
-    const int j = i / D, d = i - j * D;
-    const float v = embed1(f.emb, f.ids[row0 + j], d, f.emb.pos + (size_t)j * D);
-    a.x[(size_t)(row0 + j) * D + d] = v;
-    if (f.embed_out) f.embed_out[(size_t)(row0 + j) * D + d] = v;
-  }
-  __syncthreads();
-
-  float *x = a.x, *y = a.y;
-  for (int l = 0; l < f.Le; ++l) {
-    const FusedEncLayerW &L = f.L[l];
-    // Attention::forward (Modules.cc:287-319): Q, K, V projections
-    for (int which = 0; which < 3; ++which) {
-      GemmKArgs ka = long_gemm(which == 0 ? L.q : which == 1 ? L.k : L.v, x, nullptr, D);
-      ka.g.y = which == 0 ? a.q : which == 1 ? a.k : a.v;
-      ka.g.ldy = D;
-      for (int bx = 0; bx < n_rt; ++bx) {
-        gemm_rows_body<RM, 4, EPI_PLAIN>(ka, bx, 0, row0, row1, smem);
-        __syncthreads();
-      }
-    }
-    attention_mfma_long(a, b, smem);
-    {  // O projection + residual + LayerNorm: x -> y (Modules.cc:308-316)
-      GemmKArgs ka = long_gemm(L.o, a.att, nullptr, D);
-      ka.g.y = y; ka.g.ldy = D;
-      ka.g.res = x; ka.g.ldres = D;
-      ka.g.ln_scale = L.attn_ln_s; ka.g.ln_bias = L.attn_ln_b; ka.g.eps = f.eps;
-      for (int bx = 0; bx < n_rt2; ++bx) {  // whole rows per tile: 32-row tiles keep the LDS small
-        gemm_rows_body<2, 4, EPI_RES_LN>(ka, bx, 0, row0, row1, smem);
-        __syncthreads();
-      }
-    }
-    {  // FFN (Modules.cc:326-331): y -> h8 -> x
-      GemmKArgs k1 = long_gemm(L.ffn1, y, nullptr, D);
-      k1.g.y_i8 = a.h8; k1.g.ldy8 = F; k1.g.a_quant_out = L.ffn2.a_quant;
-      const int cb = (F + 255) / 256;
-      for (int bx = 0; bx < n_rt; ++bx)
-        for (int by = 0; by < cb; ++by) {
-          gemm_rows_body<RM, 4, EPI_RELU_Q>(k1, bx, by, row0, row1, smem);
-          __syncthreads();
-        }
-      GemmKArgs k2 = long_gemm(L.ffn2, nullptr, a.h8, F);
-      k2.g.y = x; k2.g.ldy = D;
-      k2.g.res = y; k2.g.ldres = D;
-      k2.g.ln_scale = L.ffn_ln_s; k2.g.ln_bias = L.ffn_ln_b; k2.g.eps = f.eps;
-      for (int bx = 0; bx < n_rt2; ++bx) {
-        gemm_rows_body<2, 4, EPI_RES_LN>(k2, bx, 0, row0, row1, smem);
-        __syncthreads();
-      }
-    }
-    if (f.layer_out) {
-      float *dst = f.layer_out + (size_t)l * f.B * S * D;
-      for (int i = tid; i < S * D; i += 256) dst[(size_t)row0 * D + i] = x[(size_t)row0 * D + i];
-    }
-  }
-  // encoder output (already in x) + the decoder's cross-attention K/V cache
-  // (Modules.cc:248-249, computed once per batch)
-  if (f.enc_out && f.enc_out != x)
-    for (int i = tid; i < S * D; i += 256) f.enc_out[(size_t)row0 * D + i] = x[(size_t)row0 * D + i];
-  const size_t M = (size_t)f.B * S;
-  for (int l = 0; l < f.Ld; ++l) {
-    GemmKArgs kk = long_gemm(f.dec_k[l], x, nullptr, D);
-    kk.g.y = f.kv + (size_t)(2 * l) * M * D;
-    kk.g.ldy = D;
-    kk.g.kc_S = S;  // K in the cache layout [sentence][head][d/4][key][4]
-    kk.g.kc_dh = D / a.H;
-    GemmKArgs kv = long_gemm(f.dec_v[l], x, nullptr, D);
-    kv.g.y = f.kv + (size_t)(2 * l + 1) * M * D;
-    kv.g.ldy = D;
-    for (int bx = 0; bx < n_rt; ++bx) {
-      gemm_rows_body<RM, 4, EPI_PLAIN>(kk, bx, 0, row0, row1, smem);
-      __syncthreads();
-      gemm_rows_body<RM, 4, EPI_PLAIN>(kv, bx, 0, row0, row1, smem);
-      __syncthreads();
-    }
-  }
-}
-
-bool long_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
-  if (S < 1 || S > 128 || Le < 1 || Le > 6 || Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
-  // gemm_rows_body<2, 4, *>: 256-column blocks; the LayerNorm epilogue owns whole rows
-  return D == 256 && F % 256 == 0 && D / H == 32;
-}
-
-hipError_t launch_encode_long(const LongEncodeArgs &a, hipStream_t st) {
-  if (!long_encode_supported(a.D, a.F, a.H, a.f.Le, a.f.Ld, a.f.S)) return hipErrorInvalidValue;
-  const size_t lds_gemm = (size_t)32 * LDA + (size_t)32 * (256 + 4) * sizeof(float);  // RES_LN, 32 rows (> 64 * LDA)
-  const size_t lds_attn = 3 * (size_t)128 * 33 * sizeof(float);  // q, k, v slices of one head
-  const size_t lds = lds_gemm > lds_attn ? lds_gemm : lds_attn;
-  hipLaunchKernelGGL(encode_long_kernel, dim3(a.f.B), dim3(256), lds, st, a);
-  return hipGetLastError();
-}
-
 }  // namespace slimt_hip
