@@ -350,7 +350,10 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
   }
 }
 
-template <int D, int DH>
+// LONG: compile the 32 < S <= 128 path in (a call to attention_row_long). The
+// S <= 32 instantiation of the kernel leaves it out: the mere call site cost
+// the flagship path ~4 us per step (scratch frame, register allocation).
+template <int D, int DH, bool LONG>
 __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   constexpr int H = D / DH;
   const int S = r.S, len = r.len;
@@ -422,7 +425,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       if (hp + 1 < H / 2) load_v(hp + 1);
       r.arow[2 * hp * DH + lane] = (char)quantize1(o, r.aq_o);
     }
-  } else if (DH == 32 && S <= 128) {
+  } else if (LONG && DH == 32 && S <= 128) {
     attention_row_long<D, DH>(r, lane);
   } else {
     // generic: one head per pass, keys lane and lane + 64
@@ -491,7 +494,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   (void)lr;                                              \
   (void)lg
 
-template <int KSD, int KSF, int DH>
+template <int KSD, int KSF, int DH, bool LONG>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 64 * KSD, F = 64 * KSF;
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
         const bool want_align = a.align && (l + 1 == Ld) && !finished && ((int)n_out < a.Tmax);
         ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + n_out) * S) : (gf_ptr) nullptr;
-        attention_row<D, DH>(ar, lane);
+        attention_row<D, DH, LONG>(ar, lane);
       } else {
 #pragma unroll
         for (int i = 0; i < KSD; ++i) A1[wave * LDA + lane + 64 * i] = 0;
@@ -1151,7 +1154,7 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
           ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)bb * H * S) : (gf_ptr) nullptr;
           const bool want_align = a.align && (l + 1 == Ld) && !fin && (no < a.Tmax);
           ar.align = want_align ? (gf_ptr)(a.align + ((size_t)bb * a.Tmax + no) * S) : (gf_ptr) nullptr;
-          attention_row<D, DH>(ar, lane);
+          attention_row<D, DH, false>(ar, lane);  // this kernel requires S <= 32
         } else {
 #pragma unroll
           for (int i = 0; i < KSD; ++i) A1[row * LDA + lane + 64 * i] = 0;
@@ -1400,6 +1403,16 @@ bool fused_decode_supported(int D, int F, int H, int Ld) {
   return shape && fused_decode_lds_bytes(D, F, Ld) <= 160 * 1024;
 }
 
+// the long-sentence instantiation exists for d_head 32 only (attention_row_long)
+template <int KSD, int KSF, int DH>
+static auto decode_fused_pick(bool long_sentences) -> void (*)(FusedDecodeArgs) {
+  if constexpr (DH == 32) {
+    if (long_sentences) return decode_fused_kernel<KSD, KSF, DH, true>;
+  }
+  (void)long_sentences;
+  return decode_fused_kernel<KSD, KSF, DH, false>;
+}
+
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st) {
   if (!fused_decode_supported(D, F, H, a.Ld)) return hipErrorInvalidValue;
   if (fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg) == 32) {
@@ -1416,7 +1429,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hi
   const size_t lds = fused_decode_lds_bytes(D, F, a.Ld);
 #define SLIMT_FUSED_CASE(KSD_, KSF_, DH_)                                                   \
   if (D == 64 * KSD_ && F == 64 * KSF_ && D / H == DH_) {                                    \
-    auto k = decode_fused_kernel<KSD_, KSF_, DH_>;                                           \
+    auto k = decode_fused_pick<KSD_, KSF_, DH_>(a.S > 32);                                   \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                           \
