@@ -21,8 +21,12 @@ CONFIGS = [
     ("tiny11", 6.0, 7, 11, None, True),
     ("tiny11", 6.0, 45, 32, 2048, True),   # 32-row decoder tiles: one full, one partly filled
     ("tiny11", 6.0, 36, 20, None, True),   # ... full vocabulary, second tile only in rows 0..3
-    ("tiny11", 6.0, 5, 40, 1024, True),    # S > 32: layer-by-layer encoder, generic decoder attention
-    ("tiny11", 6.0, 3, 70, 512, True),     # S > 64: two key slots per lane
+    ("tiny11", 6.0, 5, 40, 1024, True),    # S > 32: per-sentence encoder, 128-key decoder attention
+    ("tiny11", 6.0, 3, 33, 512, True),     # ... just past the 32-row kernel: 3 row tiles, 2 key tiles
+    ("tiny11", 6.0, 2, 64, None, True),    # ... last length of the 2-key-tile encoder variant
+    ("tiny11", 6.0, 2, 65, 1024, True),    # ... first length of the 4-key-tile variant
+    ("tiny11", 6.0, 3, 70, 512, True),     # S > 64: keys L and L + 64 share a lane in the row sums
+    ("tiny11", 6.0, 2, 96, 512, False),    # ... three key tiles, full-length sentences
     ("tiny11", 6.0, 2, 128, 512, True),    # the reference's wrap length (Frontend.hh:27)
     ("mini", 1.0, 4, 100, 256, True),
     ("base", 6.0, 4, 8, 512, True),
