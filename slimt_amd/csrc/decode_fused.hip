@@ -859,105 +859,6 @@ __device__ __forceinline__ void ln_row_r(const float *src, const float (&scale)[
   }
 }
 
-// Cross-attention of a wave's two sentences (d_head 32, S <= 32): 2 x H/2
-// passes of two heads each, software-pipelined across both sentences like
-// attention_row's fast path.
-struct AttnPair {
-  const float *kl[2], *vl[2];  // cached K / V of the two sentences
-  const float *qrow[2];        // LDS q rows
-  char *arow[2];               // LDS int8 output rows
-  float *pbuf;                 // LDS: 64 floats of per-wave scratch
-  int S, len[2];
-  bool live[2];
-  float alpha, aq_o;
-  float *attn[2];   // nullable [H][S]
-  float *align[2];  // nullable [S]
-};
-
-template <int D, int DH>
-__device__ __forceinline__ void attention_pair(const AttnPair &r, int lane) {
-  constexpr int H = D / DH, HP = H / 2;
-  const int S = r.S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int hh = lane >> 5, j = lane & 31;
-  const int jc = j < S ? j : S - 1;
-  const int koff = ((hh * (DH / 4) * S + jc) * 4) * 4;  // [head][dh/4][S][4] floats
-  const int voff = lane * 4;                            // (head parity, d = lane & 31)
-  f4 k4[8];
-  float v[32];
-  // pass (sn, hp); past the last pass the descriptor is empty: the loads stay
-  // unconditional (exact s_waitcnt counts) but return zeros without traffic
-  auto load_k = [&](int sn, int hp) {
-    const rsrc_t rk = make_rsrc(sn ? r.kl[1] : r.kl[0], sn < 2 ? (unsigned)(S * D) * 4u : 0u);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      k4[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
-                                         rk, koff, ((2 * hp * (DH / 4) + i) * S * 4) * 4, KV_AUX));
-  };
-  auto load_v = [&](int sn, int hp) {
-    const rsrc_t rv = make_rsrc(sn ? r.vl[1] : r.vl[0], sn < 2 ? (unsigned)(S * D) * 4u : 0u);
-#pragma unroll
-    for (int jj = 0; jj < 32; ++jj)
-      v[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                            rv, voff, (jj * D + 2 * hp * DH) * 4, KV_AUX));
-  };
-  load_k(0, 0);
-  load_v(0, 0);
-#pragma unroll 1
-  for (int sn = 0; sn < 2; ++sn) {
-    const float *qrow = sn ? r.qrow[1] : r.qrow[0];
-    char *arow = sn ? r.arow[1] : r.arow[0];
-    float *attn = sn ? r.attn[1] : r.attn[0];
-    float *align = sn ? r.align[1] : r.align[0];
-    const int len = sn ? r.len[1] : r.len[0];
-    const bool live = sn ? r.live[1] : r.live[0];
-    const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-#pragma unroll
-    for (int hp = 0; hp < HP; ++hp) {
-      const int h = 2 * hp + hh;
-      const int nsn = hp + 1 < HP ? sn : sn + 1, nhp = hp + 1 < HP ? hp + 1 : 0;
-      float s = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f4 q4 = *reinterpret_cast<const f4 *>(qrow + h * DH + 4 * i);
-        s = __builtin_fmaf(q4.x, k4[i].x, s);
-        s = __builtin_fmaf(q4.y, k4[i].y, s);
-        s = __builtin_fmaf(q4.z, k4[i].z, s);
-        s = __builtin_fmaf(q4.w, k4[i].w, s);
-      }
-      // keep the prefetches where they are written: hoisted above the arithmetic
-      // that frees their registers they only turn into spills
-      __builtin_amdgcn_sched_barrier(0);
-      load_k(nsn, nhp);
-      __builtin_amdgcn_sched_barrier(0);
-      if (r.alpha != 1.0f) s = r.alpha * s;
-      s = s + mask;
-      if (j >= S) s = lowest;
-      const float m = half_max(s);
-      const float e = j < S ? exp_p(s - m) : 0.0f;
-      const float sum = half_sum(e);  // canonical order: masks 1..16; the mask-32 step would add +0
-      const float pr = e / sum;       // keys >= S: exactly 0
-      if (attn && j < S) attn[(size_t)h * S + j] = pr;
-      if (align && hp == 0 && hh == 0 && j < len) align[j] = pr;
-      r.pbuf[lane] = pr;  // broadcast the probabilities of this lane's head through LDS
-      float o = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {  // keys >= S contribute fma(0, v, o) == o
-        const f4 p4 = *reinterpret_cast<const f4 *>(r.pbuf + (lane & 32) + 4 * i);
-        o = __builtin_fmaf(p4.x, v[4 * i + 0], o);
-        o = __builtin_fmaf(p4.y, v[4 * i + 1], o);
-        o = __builtin_fmaf(p4.z, v[4 * i + 2], o);
-        o = __builtin_fmaf(p4.w, v[4 * i + 3], o);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      load_v(nsn, nhp);
-      __builtin_amdgcn_sched_barrier(0);
-      arow[2 * hp * DH + lane] = live ? (char)quantize1(o, r.aq_o) : (char)0;
-    }
-  }
-}
-
 }  // namespace
 
 template <int KSD, int KSF, int DH>
@@ -1109,30 +1010,6 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
       __syncthreads();
       SLIMT_STAMP(sb + 3);
       // SDPA over the cached K/V of this wave's two sentences; output quantised into A1
-#ifdef SLIMT_ATTN_PAIR
-      {
-        AttnPair ar;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int bb = live[rr] ? bq[rr] : 0;  // dead rows read sentence 0 and write zeros
-          ar.kl[rr] = a.kv + ((size_t)(2 * l) * B + EXP_SENT(bb)) * S * D;
-          ar.vl[rr] = a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(bb)) * S * D;
-          ar.qrow[rr] = X + (16 * rr + wave) * LDF;
-          ar.arow[rr] = A1 + (16 * rr + wave) * LDA;
-          ar.len[rr] = len[rr];
-          ar.live[rr] = live[rr];
-          ar.attn[rr] = (a.attn && (l + 1 == Ld) && live[rr]) ? a.attn + (size_t)bq[rr] * H * S : nullptr;
-          const bool want_align =
-              a.align && (l + 1 == Ld) && !finished[rr] && ((int)n_out[rr] < a.Tmax);
-          ar.align[rr] = want_align ? a.align + ((size_t)bq[rr] * a.Tmax + n_out[rr]) * S : nullptr;
-        }
-        ar.pbuf = reinterpret_cast<float *>(HB0) + wave * 64;
-        ar.S = S;
-        ar.alpha = a.alpha;
-        ar.aq_o = L.o.a_quant;
-        attention_pair<D, DH>(ar, lane);
-      }
-#else
 #pragma unroll 1
       for (int rr = 0; rr < 2; ++rr) {
         const bool lv = rr ? live[1] : live[0];
@@ -1160,7 +1037,6 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
           for (int i = 0; i < KSD; ++i) A1[row * LDA + lane + 64 * i] = 0;
         }
       }
-#endif
       __syncthreads();
       SLIMT_STAMP(sb + 4);
       // O projection + residual h, in place (Modules.cc:308-314)
