@@ -20,19 +20,23 @@ struct View {  // slimt/Types.hh:37-40
   size_t size = 0;
 };
 
-class Shortlist {  // slimt/Shortlist.hh:15-36
+// The batch's selected target ids, sorted: position in this list = column of the
+// shortlisted output layer (slimt/Shortlist.hh:15-36: words / reverse_map /
+// try_forward_map).
+class Shortlist {
  public:
-  explicit Shortlist(Words words) : words_(std::move(words)) {}
-  const std::vector<Word> &words() const { return words_; }
-  Word reverse_map(int idx) const { return words_[static_cast<size_t>(idx)]; }
-  int try_forward_map(Word w_idx) const {
-    auto first = std::lower_bound(words_.begin(), words_.end(), w_idx);
-    if (first != words_.end() && *first == w_idx) return static_cast<int>(std::distance(words_.begin(), first));
-    return -1;
+  explicit Shortlist(Words sorted_ids) : ids_(std::move(sorted_ids)) {}
+  const Words &words() const { return ids_; }
+  // column -> vocabulary id
+  Word reverse_map(int column) const { return ids_.at(static_cast<size_t>(column)); }
+  // vocabulary id -> column, or -1 when the id is not in the shortlist
+  int try_forward_map(Word id) const {
+    const auto range = std::equal_range(ids_.begin(), ids_.end(), id);
+    return range.first == range.second ? -1 : static_cast<int>(range.first - ids_.begin());
   }
 
  private:
-  std::vector<Word> words_;  // [packed shortlist index] -> word index
+  Words ids_;
 };
 
 class ShortlistGenerator {  // slimt/Shortlist.hh:38-90
