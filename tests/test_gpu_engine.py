@@ -272,3 +272,33 @@ def test_context_workspace_limits_and_errors(hip, engines):
     with pytest.raises(hip.SlimtHipError):
         hip.Context(gm, 4, 129)  # slimt wraps at 128 (Frontend.hh:27)
     ctx.close()
+
+
+@pytest.mark.parametrize("B,S", [(96, 64), (40, 128)])
+def test_decode_invariants_long_sentences(hip, engines, B, S):
+    """The size-independent properties of test_decode_invariants_at_bench_size for
+    the long-sentence kernels (per-sentence encoder, 128-key decoder attention) at
+    sizes the oracle would take minutes for: rows are independent (permutation,
+    split), tokens come from the shortlist, lengths are capped, runs repeat."""
+    from slimt_amd import synth
+    m, gm, _ = engines("tiny11", 6.0)
+    ids, lens = synth.make_batch(m.V, B, S, seed=S, ragged=True)
+    sl = synth.make_shortlist(m.V, 2048)
+    ctx = hip.Context(gm, B, S)
+    T = int(np.float32(1.5) * np.float32(S))
+    out, ln, _ = ctx.translate(ids, lens, sl)
+    assert out.shape == (B, T) and ln.max() <= T and ln.min() >= 1
+    for b in range(B):
+        assert np.all(np.isin(out[b, : ln[b]], sl))
+    out2, ln2, _ = ctx.translate(ids, lens, sl)
+    assert np.array_equal(out2, out) and np.array_equal(ln2, ln)
+    perm = np.random.Generator(np.random.PCG64(2)).permutation(B)
+    out_p, ln_p, _ = ctx.translate(ids[perm], lens[perm], sl)
+    assert np.array_equal(out_p, out[perm]) and np.array_equal(ln_p, ln[perm])
+    third = B // 3
+    out_h, ln_h, _ = ctx.translate(ids[:third], lens[:third], sl)
+    assert np.array_equal(out_h, out[:third]) and np.array_equal(ln_h, ln[:third])
+    ctx.set_decode_mode(1)  # one launch per stage: same tokens
+    out_s, ln_s, _ = ctx.translate(ids[:8], lens[:8], sl)
+    assert np.array_equal(out_s, out[:8]) and np.array_equal(ln_s, ln[:8])
+    ctx.close()
