@@ -12,7 +12,8 @@ W = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 m = synth.make_model(preset, eos_bias=6.0)
 gm = capi.Model(m)
 om = O.OracleModel(m)
-B, S = 32, 20
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+S = int(sys.argv[5]) if len(sys.argv) > 5 else 20
 sl = synth.make_shortlist(m.V, 1024)
 jobs = [synth.make_batch(m.V, B, S, seed=5000 + i, ragged=True) for i in range(n_jobs)]
 O.set_mode(O.PORTABLE)
