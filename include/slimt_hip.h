@@ -219,6 +219,18 @@ int slimt_hip_shortlist_generate_device(slimt_hip_shortlist *sl, slimt_hip_ctx *
                                         size_t B, size_t S, uint32_t *d_out_ids,
                                         uint32_t *d_n_out);
 
+/* Model::forward with its shortlist step on the device (Model.cc:117-120,195-203):
+ * generates the batch's lexical shortlist on ctx's stream, then translates with
+ * it. With the persistent kernels nothing returns to the host in between (the
+ * shortlist's size stays on the device: three launches in all, asynchronous like
+ * slimt_hip_translate_device); with the stage kernels one 4-byte read-back sizes
+ * the launches. The shortlist's target vocabulary must be the model's. */
+int slimt_hip_translate_device_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *shortlist,
+                                         const uint32_t *d_src_ids, const uint32_t *d_lengths,
+                                         size_t B, size_t S, float limit_factor, uint32_t eos_id,
+                                         uint32_t *d_out_ids, uint32_t *d_out_len, float *d_align,
+                                         int steps_hint);
+
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, HIP events bracket every launch of kernel family `kernel_id`
  * on the ctx stream; slimt_hip_profile_read returns the number of launches

@@ -28,6 +28,7 @@ SYMBOLS = [
     "slimt_hip_debug_decode_stamps",
     "slimt_hip_shortlist_create", "slimt_hip_shortlist_destroy", "slimt_hip_shortlist_info",
     "slimt_hip_shortlist_generate", "slimt_hip_shortlist_generate_device",
+    "slimt_hip_translate_device_generated",
 ]
 
 K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED, K_ENCODE_FUSED = range(9)
@@ -105,6 +106,7 @@ def lib():
     L.slimt_hip_shortlist_info.argtypes = [vp, vp, vp]
     L.slimt_hip_shortlist_generate.argtypes = [vp, vp, vp, sz, sz, vp, vp]
     L.slimt_hip_shortlist_generate_device.argtypes = [vp, vp, vp, vp, sz, sz, vp, vp]
+    L.slimt_hip_translate_device_generated.argtypes = [vp, vp, vp, vp, sz, sz, f32, u32, vp, vp, vp, i32]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("slimt_hip_abi_version",):
@@ -326,6 +328,15 @@ class Context:
             self.h, vp(d_ids), vp(d_lengths), B, S, vp(d_shortlist) if n_shortlist else None,
             n_shortlist, limit_factor, eos_id, vp(d_out_ids), vp(d_out_len),
             vp(d_align) if d_align else None, steps_hint))
+
+    def translate_device_generated(self, gen: "ShortlistGenerator", d_ids: int, d_lengths: int, B: int,
+                                   S: int, limit_factor: float, eos_id: int, d_out_ids: int,
+                                   d_out_len: int, d_align: int = 0, steps_hint: int = 0):
+        """Shortlist generation + translate, all on this context's stream."""
+        vp = C.c_void_p
+        _chk(lib().slimt_hip_translate_device_generated(
+            self.h, gen.h, vp(d_ids), vp(d_lengths), B, S, limit_factor, eos_id, vp(d_out_ids),
+            vp(d_out_len), vp(d_align) if d_align else None, steps_hint))
 
     def encode(self, ids, lengths, want_embed=False, want_layers=False):
         ids = np.ascontiguousarray(ids, dtype=np.uint32)

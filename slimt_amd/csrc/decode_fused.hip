@@ -541,6 +541,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   }
   __syncthreads();
 
+  // the output layer's column count may live on the device (a shortlist generated there)
+  PreparedWeight outw = a.out;
+  if (a.out_n_dev) {
+    outw.N = (int)*a.out_n_dev;
+    outw.n_tiles = (outw.N + 15) / 16;
+  }
   const int max_steps = a.max_steps;
   for (int t = 0; t < max_steps; ++t) {
     SLIMT_STAMP(0);
@@ -691,9 +697,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       bv[r] = -3.402823466e+38f;
       bi[r] = 0x7fffffff;
     }
-    stream_gemm<KSD, SLIMT_NB_OUT>(A1, LDA, a.out, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
+    stream_gemm<KSD, SLIMT_NB_OUT>(A1, LDA, outw, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
       const int col = tile * 16 + lr;
-      if (col < a.out.N) {
+      if (col < outw.N) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = dequant(acc[r], co, a.out.u, pb);
@@ -919,6 +925,11 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
   }
   __syncthreads();
 
+  PreparedWeight outw = a.out;  // see decode_fused_kernel
+  if (a.out_n_dev) {
+    outw.N = (int)*a.out_n_dev;
+    outw.n_tiles = (outw.N + 15) / 16;
+  }
   const int max_steps = a.max_steps;
   for (int t = 0; t < max_steps; ++t) {
     SLIMT_STAMP(0);
@@ -1173,10 +1184,10 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
       bv[r] = -3.402823466e+38f;
       bi[r] = 0x7fffffff;
     }
-    stream_gemm2<KSD, SLIMT_NB_OUT>(A1, LDA, a.out, wave, lane,
+    stream_gemm2<KSD, SLIMT_NB_OUT>(A1, LDA, outw, wave, lane,
                                     [&](int tile, const v4i &c0, const v4i &c1, int co, float pb) {
                                       const int col = tile * 16 + lr;
-                                      if (col < a.out.N) {
+                                      if (col < outw.N) {
 #pragma unroll
                                         for (int r = 0; r < 4; ++r) {
                                           // a lane's columns only grow: strict > keeps its first maximum

@@ -187,13 +187,15 @@ __device__ __forceinline__ int sum_bytes(int w) {
 // (Intgemm.inl.cc:48-69,127-136). No barrier inside.
 __device__ __forceinline__ void pack_weight_tile(const PackArgs &a, int ntile, int tid, int nthreads) {
   v4i *Wp = reinterpret_cast<v4i *>(a.Wp);
+  const int N = a.n_dev ? (int)*a.n_dev : a.N;
+  if (ntile * 16 >= N) return;  // device-side N: tiles past it are not part of the matrix
   const int KS = a.K / 64;
   const int chunks = a.K / 16;  // 16-byte chunks per row
   for (int c = tid; c < 16 * chunks; c += nthreads) {
     const int r = c / chunks, ch = c % chunks;
     const int n = ntile * 16 + r;
     v4i v = {0, 0, 0, 0};
-    if (n < a.N) {
+    if (n < N) {
       const size_t src = a.idx ? (size_t)a.idx[n] : (size_t)n;
       v = *reinterpret_cast<const v4i *>(a.W + src * a.K + (size_t)ch * 16);
     }
@@ -205,7 +207,7 @@ __device__ __forceinline__ void pack_weight_tile(const PackArgs &a, int ntile, i
     const int n = ntile * 16 + r;
     int s = 0;
     size_t src = 0;
-    if (n < a.N) {
+    if (n < N) {
       src = a.idx ? (size_t)a.idx[n] : (size_t)n;
       for (int ch = sub; ch < chunks; ch += 16) {
         v4i v = *reinterpret_cast<const v4i *>(a.W + src * a.K + (size_t)ch * 16);
@@ -218,7 +220,7 @@ __device__ __forceinline__ void pack_weight_tile(const PackArgs &a, int ntile, i
     s += __shfl_xor(s, 8, 64);
     if (sub == 0) {
       float pbv = 0.0f;
-      if (n < a.N) {
+      if (n < N) {
         float v = (float)s * a.mult;  // PrepareBias callback: cvt, mul, add
         pbv = v + (a.bias ? a.bias[src] : 0.0f);
       } else {

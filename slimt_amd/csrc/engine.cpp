@@ -565,7 +565,7 @@ void ctx_free(slimt_hip_ctx *c) {
                     &c->h8, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
                     &c->state, &c->part_val, &c->part_idx, &c->prev, &c->out_ids, &c->out_len,
                     &c->finished, &c->n_finished, &c->align, &c->shortlist, &c->logits,
-                    &c->attn_dbg, &c->stamps, &c->dbg_embed, &c->dbg_layers, &c->sl_scratch};
+                    &c->attn_dbg, &c->stamps, &c->dbg_embed, &c->dbg_layers, &c->sl_scratch, &c->n_sl_dev};
   for (auto *b : bufs) b->release();
   free_affine(c->out_sl);
   if (c->n_finished_host) (void)hipHostFree(c->n_finished_host);
@@ -1108,7 +1108,9 @@ int decoder_layers(slimt_hip_ctx *c, float *d_align, int Tmax, const uint32_t *d
 int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_lengths,
                      const uint32_t *d_shortlist, size_t B, size_t S, size_t n_sl,
                      float limit_factor, uint32_t eos_id, uint32_t *d_out_ids, uint32_t *d_out_len,
-                     float *d_align, int steps_hint) {
+                     float *d_align, int steps_hint, const uint32_t *d_n_sl = nullptr) {
+  // d_n_sl != nullptr: the shortlist was generated on this stream; its size is on
+  // the device and n_sl is only the capacity of d_shortlist (persistent kernels only)
   const slimt_hip_model *m = c->model;
   hipStream_t st = c->stream;
   const size_t Tmax = (size_t)(limit_factor * (float)S);  // Model.cc:160
@@ -1128,6 +1130,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     if (n_sl)
       RCCHK(prepare_affine_meta(c->out_sl, m->out_raw.as<int8_t>(), m->D, (int)n_sl, d_shortlist,
                                 m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, job));
+    job.n_dev = d_n_sl;
     RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr));
     c->n_sl = (int)n_sl;
   } else {
@@ -1167,6 +1170,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       fl.ffn_ln_s = L.ffn_ln.scale.as<float>(); fl.ffn_ln_b = L.ffn_ln.bias.as<float>();
     }
     f.out = out.w;
+    f.out_n_dev = d_n_sl;
     f.shortlist = ds.shortlist;
     f.emb = embed_args(c);
     f.kv = c->kv.as<float>();
@@ -1585,4 +1589,41 @@ extern "C" int slimt_hip_shortlist_generate_device(slimt_hip_shortlist *sl, slim
   a.scratch = ctx->sl_scratch.as<uint32_t>();
   HIPCHK(launch_shortlist_generate(a, ctx->stream));
   return 0;
+}
+
+extern "C" int slimt_hip_translate_device_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl,
+                                                    const uint32_t *d_src_ids,
+                                                    const uint32_t *d_lengths, size_t B, size_t S,
+                                                    float limit_factor, uint32_t eos_id,
+                                                    uint32_t *d_out_ids, uint32_t *d_out_len,
+                                                    float *d_align, int steps_hint) {
+  if (!ctx || !sl || !d_src_ids || !d_lengths || !d_out_ids || !d_out_len)
+    return fail(-1, "null argument");
+  RCCHK(check_batch(ctx, B, S));
+  const slimt_hip_model *m = ctx->model;
+  if (sl->device != m->device) return fail(-1, "shortlist and context are on different devices");
+  if (sl->target_vocab != (size_t)m->V)
+    return fail(-1, "shortlist target vocabulary %zu != model vocabulary %d", sl->target_vocab, m->V);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t st = ctx->stream;
+  // Model::forward's order (Model.cc:117-120): the batch's shortlist first
+  HIPCHK(ctx->n_sl_dev.reserve(4));
+  RCCHK(shortlist_scratch(ctx->sl_scratch, sl, st));
+  ShortlistArgs a;
+  shortlist_args(sl, d_src_ids, d_lengths, B, S, ctx->shortlist.as<uint32_t>(),
+                 ctx->n_sl_dev.as<uint32_t>(), a);
+  a.scratch = ctx->sl_scratch.as<uint32_t>();
+  HIPCHK(launch_shortlist_generate(a, st));
+  const bool lean = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
+                    (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
+                     long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
+  if (lean)  // the size stays on the device: capacity V, actual count read by the kernels
+    return translate_device(ctx, d_src_ids, d_lengths, ctx->shortlist.as<uint32_t>(), B, S,
+                            (size_t)m->V, limit_factor, eos_id, d_out_ids, d_out_len, d_align,
+                            steps_hint, ctx->n_sl_dev.as<uint32_t>());
+  uint32_t n = 0;  // stage kernels are sized on the host: one 4-byte read-back
+  HIPCHK(hipMemcpyAsync(&n, ctx->n_sl_dev.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return translate_device(ctx, d_src_ids, d_lengths, ctx->shortlist.as<uint32_t>(), B, S, n,
+                          limit_factor, eos_id, d_out_ids, d_out_len, d_align, steps_hint);
 }

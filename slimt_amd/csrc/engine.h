@@ -93,6 +93,7 @@ struct slimt_hip_ctx {
   slimt_hip::DevBuf prev, out_ids, out_len, finished, n_finished, align;
   slimt_hip::DevBuf shortlist;
   slimt_hip::DevBuf sl_scratch;  // bitmaps of slimt_hip_shortlist_generate_device (kept zeroed)
+  slimt_hip::DevBuf n_sl_dev;    // [1] size of a shortlist generated on this context's stream
   slimt_hip::AffineW out_sl;  // shortlisted output layer (per batch)
   slimt_hip::DevBuf logits, attn_dbg;
   int *n_finished_host = nullptr;  // pinned

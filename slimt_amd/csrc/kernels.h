@@ -38,6 +38,7 @@ struct PackArgs {
   void *Wp = nullptr;
   int *colsum = nullptr;
   float *pb = nullptr;
+  const uint32_t *n_dev = nullptr;  // nullable: the actual N lives on the device (N is then an upper bound)
 };
 inline float pack_mult(float a_quant, float b_quant) {
   const float a_alpha = 127.0f / a_quant;
@@ -228,6 +229,7 @@ struct FusedDecodeArgs {
   int Tmax = 0;       // row length of out_ids / align
   FusedLayerW L[4];
   PreparedWeight out;                   // (shortlisted) output layer
+  const uint32_t *out_n_dev = nullptr;  // nullable: number of output columns, on the device
   const uint32_t *shortlist = nullptr;  // nullable: column -> vocabulary id
   EmbedArgs emb;
   const float *kv = nullptr;            // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]

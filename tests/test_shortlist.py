@@ -126,3 +126,67 @@ def test_gpu_generated_shortlist_feeds_translate(hip, oracle):
     oracle.set_mode(oracle.FAITHFUL)
     assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out)
     ctx.close(); gm.close(); gen.close()
+
+
+class _Hip:
+    """Minimal device-buffer helper over libamdhip64 (tests only)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.rt = C.CDLL("libamdhip64.so")
+        self.rt.hipMalloc.argtypes = [C.c_void_p, C.c_size_t]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.bufs = []
+
+    def to_dev(self, a):
+        a = np.ascontiguousarray(a)
+        p = self.C.c_void_p()
+        assert self.rt.hipMalloc(self.C.byref(p), max(a.nbytes, 16)) == 0
+        assert self.rt.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0
+        self.bufs.append(p)
+        return p.value
+
+    def from_dev(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert self.rt.hipMemcpy(out.ctypes.data, self.C.c_void_p(ptr), out.nbytes, 2) == 0
+        return out
+
+    def free(self):
+        for p in self.bufs:
+            self.rt.hipFree(p)
+        self.bufs = []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,B,S,mode", [("tiny11", 20, 12, 0), ("tiny11", 5, 40, 0), ("mini", 6, 9, 0),
+                                              ("micro", 6, 9, 1)])
+def test_gpu_translate_with_generated_shortlist_on_device(hip, oracle, synth_models, preset, B, S, mode):
+    """slimt_hip_translate_device_generated: shortlist generation and translation on
+    one stream, the shortlist's size never visiting the host (persistent kernels;
+    mode 1: one read-back). Against the oracle doing both steps on the CPU."""
+    m = synth_models(preset, 6.0 if preset == "tiny11" else 1.0)
+    blob = synth.make_lexical_shortlist(m.V, m.V, frequent=24, best=4, seed=B + S)
+    ids, lens = synth.make_batch(m.V, B, S, seed=S, ragged=True)
+    want_sl = oracle.OracleShortlist(blob, m.V, m.V).generate(ids, lens)
+    oracle.set_mode(oracle.PORTABLE)
+    w_out, w_ln, _, _ = oracle.OracleModel(m).translate(ids, lens, want_sl, 1.5, 0)
+    oracle.set_mode(oracle.FAITHFUL)
+    gm = hip.Model(m)
+    ctx = hip.Context(gm, B, S)
+    ctx.set_decode_mode(mode)
+    gen = hip.ShortlistGenerator(blob, m.V, m.V)
+    dev = _Hip()
+    T = max(1, int(np.float32(1.5) * np.float32(S)))
+    d_ids, d_len = dev.to_dev(ids), dev.to_dev(lens)
+    d_out, d_olen = dev.to_dev(np.full((B, T), 7, np.uint32)), dev.to_dev(np.zeros(B, np.uint32))
+    for _ in range(2):
+        ctx.translate_device_generated(gen, d_ids, d_len, B, S, 1.5, 0, d_out, d_olen)
+        ctx.synchronize()
+        ln = dev.from_dev(d_olen, (B,), np.uint32)
+        out = dev.from_dev(d_out, (B, T), np.uint32)
+        assert np.array_equal(ln, w_ln)
+        for b in range(B):
+            assert np.array_equal(out[b, : ln[b]], w_out[b, : w_ln[b]]), b
+    dev.free(); gen.close(); ctx.close(); gm.close()
