@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--profile-kernel", default="auto",
                     help="kernel family bracketed by HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sentences", type=int, default=128)
+    ap.add_argument("--cpu-sentences", type=int, default=128, help="sentences per CPU worker")
     ap.add_argument("--workers", type=int, default=16,
                     help="translate contexts (HIP streams) per GPU, like slimt::Async workers "
                          "(Frontend.cc:212-226): independent batches in flight on one device")
@@ -80,24 +80,54 @@ def pmc_traffic(kernel):
 
 def cpu_baseline(model, S, T, n_sl, n_sent):
     """The CPU port of the reference's op sequence (per-step K/V recompute and
-    per-call PrepareBias included), FAITHFUL float order, on the host cores."""
+    per-call PrepareBias included), FAITHFUL float order, on the host cores --
+    run the way slimt runs on a CPU: one single-threaded worker per core, each
+    translating its own batch (Async, Frontend.cc:207-227). `n_sent` sentences
+    per worker."""
+    import threading
     from oracle import oracle as O
     from slimt_amd import synth
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(threads, 64))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # the CPU share of the container (cgroup v2 quota), not the host's core count
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    # half of the share: above that the quota throttles erratically (measured on a
+    # 16-core share: 8 workers 8.9 k tok/s, 10..16 workers 2.9..6.5 k), and the HIP
+    # runtime's own threads are still alive in this process
+    workers = max(1, int(os.environ.get("SLIMT_CPU_WORKERS", str(max(1, cores // 2)))))
+    try:  # keep the port's per-op buffers on the heap: 64 KiB..MiB mmap / munmap pairs per op
+        import ctypes  # would make it a page-fault benchmark
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 1 << 30)  # M_MMAP_THRESHOLD
+        libc.mallopt(-1, 1 << 30)  # M_TRIM_THRESHOLD
+    except OSError:
+        pass
     O.set_mode(O.FAITHFUL)
-    om = O.OracleModel(model, reference_cost=True, threads=threads)
-    ids, lens = synth.make_batch(model.V, n_sent, S, seed=4321)
     sl = synth.make_shortlist(model.V, n_sl) if n_sl else None
+    oms = [O.OracleModel(model, reference_cost=True, threads=1) for _ in range(workers)]
+    jobs = [synth.make_batch(model.V, n_sent, S, seed=4321 + w) for w in range(workers)]
+    toks = [0] * workers
+    steps = [0] * workers
+
+    def work(w):
+        out, ln, _, st = oms[w].translate(jobs[w][0], jobs[w][1], sl, 1.5, 0)
+        toks[w], steps[w] = int(ln.sum()), int(st)
+
+    ts = [threading.Thread(target=work, args=(w,)) for w in range(workers)]
     t0 = time.perf_counter()
-    out, ln, _, steps = om.translate(ids, lens, sl, 1.5, 0)
+    [t.start() for t in ts]
+    [t.join() for t in ts]
     dt = time.perf_counter() - t0
-    toks = int(ln.sum())
+    total = sum(toks)
     return {
-        "value": toks / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-        "sample": f"{n_sent} sentences x S={S}, {steps} decode steps, {toks} tokens in {dt:.2f}s; "
-                  "C port of slimt's intgemm op sequence (AVX512-VNNI vpdpbusd when available, "
-                  "per-step K/V recompute + PrepareBias as in the reference), OpenMP over rows",
+        "value": total / dt, "unit": "tokens/s", "cores": workers, "kind": "port",
+        "sample": f"{workers} single-threaded workers x {n_sent} sentences x S={S}, {max(steps)} decode "
+                  f"steps, {total} tokens in {dt:.2f}s; C port of slimt's intgemm op sequence "
+                  "(AVX512-VNNI vpdpbusd when available, per-step K/V recompute + PrepareBias as in "
+                  "the reference), one batch per worker like slimt's Async",
     }
 
 
