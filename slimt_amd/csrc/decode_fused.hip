@@ -427,6 +427,62 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
     }
   } else if (LONG && DH == 32 && S <= 128) {
     attention_row_long<D, DH>(r, lane);
+  } else if (DH == 64 && S <= 32) {
+    // d_head 64 ("base"): one head per pass. Scores: lane = key (both wave
+    // halves hold the same 32 keys, so the 32-lane reductions serve both);
+    // output: lane = d. 16 K loads of 16 B and 32 V loads of 4 B per lane and
+    // pass, all issued before the first use.
+    const int j = lane & 31;
+    const int jc = j < S ? j : S - 1;
+    const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+    const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 4u);
+    const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(S * D) * 4u);
+    const int koff = jc * 16;    // [head][dh/4][S][4] floats
+    const int voff = lane * 4;   // d = lane
+#pragma unroll 1
+    for (int h = 0; h < H; ++h) {
+      f4 k4[16];
+      float v[32];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        k4[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                           rk, koff, ((h * (DH / 4) + i) * S * 4) * 4, KV_AUX));
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj)
+        v[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                              rv, voff, (jj * D + h * DH) * 4, KV_AUX));
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f4 q4 = *(lcf4_ptr)(r.qrow + h * DH + 4 * i);
+        s = __builtin_fmaf(q4.x, k4[i].x, s);
+        s = __builtin_fmaf(q4.y, k4[i].y, s);
+        s = __builtin_fmaf(q4.z, k4[i].z, s);
+        s = __builtin_fmaf(q4.w, k4[i].w, s);
+      }
+      if (r.alpha != 1.0f) s = r.alpha * s;
+      s = s + mask;
+      if (j >= S) s = lowest;
+      const float m = half_max(s);
+      const float e = j < S ? exp_p(s - m) : 0.0f;
+      const float sum = half_sum(e);
+      const float p = e / sum;  // keys >= S: exactly 0
+      if (lane < 32) {
+        if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
+        if (r.align && h == 0 && j < len) r.align[j] = p;
+      }
+      r.pbuf[lane] = p;
+      float o = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // keys >= S: fma(0, 0, o) == o
+        const f4 p4 = *(lcf4_ptr)(r.pbuf + (lane & 32) + 4 * i);
+        o = __builtin_fmaf(p4.x, v[4 * i + 0], o);
+        o = __builtin_fmaf(p4.y, v[4 * i + 1], o);
+        o = __builtin_fmaf(p4.z, v[4 * i + 2], o);
+        o = __builtin_fmaf(p4.w, v[4 * i + 3], o);
+      }
+      r.arow[h * DH + lane] = (char)quantize1(o, r.aq_o);
+    }
   } else {
     // generic: one head per pass, keys lane and lane + 64
     const int j0 = lane < S ? lane : S - 1;
@@ -506,11 +562,17 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   const int m0 = blockIdx.x * 16;
   const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
 
+  // D > 256 ("base") does not fit the layout below in 160 KiB: the pre-LN
+  // buffer then aliases hs (every pre-LN write reads at most the same element
+  // of hs, LayerNorm runs from registers) and the SSRU cells live in global
+  // memory (a.cells, [Ld][B][D]; 4 KiB per sentence, read and written once per
+  // layer and step).
+  constexpr bool BIG = KSD > 4;
   float *xs = reinterpret_cast<float *>(smem);  // layer input rows (post-LN); reused for q
   float *hs = xs + 16 * LDF;                    // h / o rows (post-LN residual source)
-  float *pre = hs + 16 * LDF;                   // pre-LN accumulation
-  float *cs = pre + 16 * LDF;                   // SSRU cells [Ld][16][D]
-  char *A1 = reinterpret_cast<char *>(cs + (size_t)Ld * 16 * D);
+  float *pre = BIG ? hs : hs + 16 * LDF;        // pre-LN accumulation
+  float *cs = pre + 16 * LDF;                   // SSRU cells [Ld][16][D] (LDS layout only)
+  char *A1 = reinterpret_cast<char *>(cs + (BIG ? 0 : (size_t)Ld * 16 * D));
   char *A2 = A1 + 16 * LDA;
   char *A3 = A2 + 16 * LDA;
   float *red_v = reinterpret_cast<float *>(A3 + 16 * LDA3);  // [NW][16]
@@ -526,7 +588,13 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   bool finished = !live;
   const int valid_rows = (B - m0) < 16 ? (B - m0) : 16;
 
-  for (int i = tid; i < Ld * 16 * D; i += 1024) cs[i] = 0.0f;  // start_states, Transformer.cc:78-85
+  // start_states, Transformer.cc:78-85
+  if constexpr (BIG) {
+    for (int l = 0; l < Ld; ++l)
+      for (int i = tid; i < valid_rows * D; i += 1024) a.cells[((size_t)l * B + m0) * D + i] = 0.0f;
+  } else {
+    for (int i = tid; i < Ld * 16 * D; i += 1024) cs[i] = 0.0f;
+  }
   if (tid == 0) flags[0] = 0;
   if (live) {  // outputs past a sentence's length read as zero (no memset launches)
     for (int i = lane; i < a.Tmax; i += 64) a.out_ids[(size_t)b * a.Tmax + i] = 0;
@@ -554,7 +622,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     for (int l = 0; l < Ld; ++l) {
       SLIMT_PHASE_LANE;
       const FusedLayerW &L = a.L[l];
-      float *cl = cs + (size_t)l * 16 * D;
+      float *cl = BIG ? a.cells + ((size_t)l * B + m0) * D : cs + (size_t)l * 16 * D;
       const int sb = 1 + 10 * l;
       // ---- SSRU (Modules.cc:190-235) ------------------------------------
       // quantise x twice (Wf / W have their own multipliers)
@@ -595,12 +663,13 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           const int rl = lg * 4 + r;
           const float f = dequant(accf[r], csf, L.rnn_f.u, pbf);
           const float wx = dequant(accw[r], csw, L.rnn_w.u, pbw);
-          const float c = cl[rl * D + col];
+          const bool cell_ok = !BIG || rl < valid_rows;  // global cells: rows of this batch only
+          const float c = cell_ok ? cl[rl * D + col] : 0.0f;
           const float sg = sigmoid_p(f);  // highway(c, Wx, f), TensorOps.cc:674-678
           const float t1 = sg * c;
           const float t2 = (1.0f - sg) * wx;
           const float cn = t1 + t2;
-          cl[rl * D + col] = cn;
+          if (cell_ok) cl[rl * D + col] = cn;
           const float y = cn > 0.0f ? cn : 0.0f;
           pre[rl * LDF + col] = xs[rl * LDF + col] + y;  // Modules.cc:230
         }
@@ -1278,15 +1347,18 @@ int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced) {
 }
 
 size_t fused_decode_lds_bytes(int D, int F, int Ld) {
-  return (size_t)3 * 16 * (D + 4) * 4 + (size_t)Ld * 16 * D * 4 + 2 * 16 * (size_t)(D + 16) +
-         16 * (size_t)(F + 16) + 2 * NW * 16 * 4 + 64 + NW * 256 * 4;
+  // D > 256: two f32 row buffers, SSRU cells in global memory (see the kernel)
+  const size_t rows = D > 256 ? (size_t)2 * 16 * (D + 4) * 4
+                              : (size_t)3 * 16 * (D + 4) * 4 + (size_t)Ld * 16 * D * 4;
+  return rows + 2 * 16 * (size_t)(D + 16) + 16 * (size_t)(F + 16) + 2 * NW * 16 * 4 + 64 +
+         NW * 256 * 4;
 }
 
 bool fused_decode_supported(int D, int F, int H, int Ld) {
   if (Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
   const int dh = D / H;
   const bool shape = (D == 64 && F == 128 && dh == 16) || (D == 128 && F == 256 && dh == 16) ||
-                     (D == 256 && F == 1536 && dh == 32);
+                     (D == 256 && F == 1536 && dh == 32) || (D == 512 && F == 2048 && dh == 64);
   return shape && fused_decode_lds_bytes(D, F, Ld) <= 160 * 1024;
 }
 
@@ -1324,6 +1396,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hi
     return hipGetLastError();                                                                \
   }
   SLIMT_FUSED_CASE(1, 2, 16) SLIMT_FUSED_CASE(2, 4, 16) SLIMT_FUSED_CASE(4, 24, 32)
+  SLIMT_FUSED_CASE(8, 32, 64)
 #undef SLIMT_FUSED_CASE
   return hipErrorInvalidValue;
 }

@@ -1174,6 +1174,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.shortlist = ds.shortlist;
     f.emb = embed_args(c);
     f.kv = c->kv.as<float>();
+    f.cells = c->state.as<float>();
     f.lengths = d_lengths;
     f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
     f.eos = eos_id;

@@ -233,6 +233,7 @@ struct FusedDecodeArgs {
   const uint32_t *shortlist = nullptr;  // nullable: column -> vocabulary id
   EmbedArgs emb;
   const float *kv = nullptr;            // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]
+  float *cells = nullptr;               // [Ld][B][D] SSRU cells, used (and zeroed) when D > 256
   const uint32_t *lengths = nullptr;
   float alpha = 0.f, eps = 1e-6f;
   uint32_t eos = 0;

@@ -30,6 +30,8 @@ CONFIGS = [
     ("tiny11", 6.0, 2, 128, 512, True),    # the reference's wrap length (Frontend.hh:27)
     ("mini", 1.0, 4, 100, 256, True),
     ("base", 6.0, 4, 8, 512, True),
+    ("base", 6.0, 19, 32, 1024, True),     # d_head 64 decoder attention, cells in global memory, ragged tile
+    ("base", 6.0, 3, 40, 512, True),       # ... S > 32: the generic attention path
 ]
 
 
