@@ -562,7 +562,7 @@ void sinusoid_table(int S, int D, std::vector<float> &out) {
 
 void ctx_free(slimt_hip_ctx *c) {
   DevBuf *bufs[] = {&c->pos, &c->ids, &c->lengths, &c->x0, &c->x1, &c->q, &c->k, &c->v, &c->att,
-                    &c->h8, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
+                    &c->h8, &c->a8, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
                     &c->state, &c->part_val, &c->part_idx, &c->prev, &c->out_ids, &c->out_len,
                     &c->finished, &c->n_finished, &c->align, &c->shortlist, &c->logits,
                     &c->attn_dbg, &c->stamps, &c->dbg_embed, &c->dbg_layers, &c->sl_scratch, &c->n_sl_dev};
@@ -593,6 +593,7 @@ int ctx_alloc(slimt_hip_ctx *c) {
   HIPCHK(c->v.reserve(M * D * 4));
   HIPCHK(c->att.reserve(M * D * 4));
   HIPCHK(c->h8.reserve(M * F));
+  HIPCHK(c->a8.reserve(M * D));
   HIPCHK(c->kv.reserve((size_t)m->Ld * 2 * M * D * 4));
   HIPCHK(c->dx.reserve(B * D * 4));
   HIPCHK(c->dx_pre.reserve(B * D * 4));
@@ -777,10 +778,30 @@ int run_affine_res_ln(slimt_hip_ctx *c, int family, const AffineW &w, const floa
   return 0;
 }
 
-int run_affine_relu_q(slimt_hip_ctx *c, int family, const AffineW &w, const float *x, int M,
-                      float a_quant_next, int8_t *y8, int rows_per_block) {
+// affine + residual on M rows (f32 or int8 in) -> f32 pre-LayerNorm sum
+int run_affine_res(slimt_hip_ctx *c, int family, const AffineW &w, const float *x_f32,
+                   const int8_t *x_i8, int M, const float *res, float *y, int rows_per_block) {
+  GemmArgs g;
+  g.x_f32 = x_f32;
+  g.x_i8 = x_i8;
+  g.lda = w.w.K;
+  g.M = M;
+  g.w = w.w;
+  g.y = y;
+  g.ldy = w.w.N;
+  g.res = res;
+  g.ldres = w.w.N;
+  ProfScope p(c, family, gemm_macs(M, w.w), gemm_bytes(w.w));
+  HIPCHK(launch_gemm(g, EPI_PLAIN, rows_per_block, c->stream));
+  return 0;
+}
+
+int run_affine_relu_q(slimt_hip_ctx *c, int family, const AffineW &w, const float *x,
+                      const int8_t *x_i8, int M, float a_quant_next, int8_t *y8,
+                      int rows_per_block) {
   GemmArgs g;
   g.x_f32 = x;
+  g.x_i8 = x_i8;
   g.lda = w.w.K;
   g.M = M;
   g.w = w.w;
@@ -919,14 +940,20 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
   float *x = c->x0.as<float>(), *y = c->x1.as<float>();
   HIPCHK(launch_embed_encoder(embed_args(c), c->ids.as<uint32_t>(), B, S, x, st));
   if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, x, nbytes, hipMemcpyDeviceToHost, st));
-  const int rpb = M >= 2048 ? 64 : (M >= 512 ? 32 : 16);
-  const int rpb_ln = M >= 4096 ? 32 : 16;
+  int rpb = M >= 2048 ? 64 : (M >= 512 ? 32 : 16);
+  int rpb_ln = M >= 4096 ? 32 : 16;
+  int rpb_n = M >= 2048 ? 32 : rpb;  // N <= 512: more, smaller blocks
+  bool big = M >= 2048 && (D == 64 || D == 128 || D == 256 || D == 512);
+  if (const char *e = getenv("SLIMT_EXP_RPB")) rpb = atoi(e);
+  if (const char *e = getenv("SLIMT_EXP_RPB_LN")) rpb_ln = atoi(e);
+  if (const char *e = getenv("SLIMT_EXP_RPB_N")) rpb_n = atoi(e);
+  if (const char *e = getenv("SLIMT_EXP_BIG")) big = atoi(e) != 0;
   for (int l = 0; l < m->Le; ++l) {
     const EncLayerW &L = m->enc[(size_t)l];
     // Attention::forward (Modules.cc:287-319)
-    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.q, x, M, c->q.as<float>(), rpb));
-    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.k, x, M, c->k.as<float>(), rpb));
-    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.v, x, M, c->v.as<float>(), rpb));
+    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.q, x, M, c->q.as<float>(), rpb_n));
+    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.k, x, M, c->k.as<float>(), rpb_n));
+    RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.v, x, M, c->v.as<float>(), rpb_n));
     AttnArgs a;
     a.q = c->q.as<float>(); a.k = c->k.as<float>(); a.v = c->v.as<float>();
     a.ldq = a.ldk = a.ldv = a.ldo = D;
@@ -938,13 +965,26 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       ProfScope p(c, SLIMT_HIP_K_ATTN_ENC, 0, 0);
       HIPCHK(launch_attention(a, st));
     }
-    RCCHK(run_affine_res_ln(c, SLIMT_HIP_K_GEMM_ENC, L.attn.o, c->att.as<float>(), nullptr, M, x,
-                            L.attn.ln, y, rpb_ln));
-    // FFN (Modules.cc:326-331): y -> x
-    RCCHK(run_affine_relu_q(c, SLIMT_HIP_K_GEMM_ENC, L.ffn1, y, M, L.ffn2.w.a_quant,
-                            c->h8.as<int8_t>(), rpb));
-    RCCHK(run_affine_res_ln(c, SLIMT_HIP_K_GEMM_ENC, L.ffn2, nullptr, c->h8.as<int8_t>(), M, y,
-                            L.ffn_ln, x, rpb_ln));
+    if (big) {
+      // many rows: residual sums from narrow GEMM blocks (no block has to own whole
+      // rows), LayerNorm as a pass of its own that also writes FFN1's int8 operand
+      RCCHK(run_affine_res(c, SLIMT_HIP_K_GEMM_ENC, L.attn.o, c->att.as<float>(), nullptr, M, x, y, rpb_n));
+      HIPCHK(launch_layer_norm_q(y, L.attn.ln.scale.as<float>(), L.attn.ln.bias.as<float>(), 1e-6f, M, D,
+                                 y, c->a8.as<int8_t>(), L.ffn1.w.a_quant, st));
+      RCCHK(run_affine_relu_q(c, SLIMT_HIP_K_GEMM_ENC, L.ffn1, nullptr, c->a8.as<int8_t>(), M,
+                              L.ffn2.w.a_quant, c->h8.as<int8_t>(), rpb));
+      RCCHK(run_affine_res(c, SLIMT_HIP_K_GEMM_ENC, L.ffn2, nullptr, c->h8.as<int8_t>(), M, y, x, rpb_n));
+      HIPCHK(launch_layer_norm_q(x, L.ffn_ln.scale.as<float>(), L.ffn_ln.bias.as<float>(), 1e-6f, M, D, x,
+                                 nullptr, 0.0f, st));
+    } else {
+      RCCHK(run_affine_res_ln(c, SLIMT_HIP_K_GEMM_ENC, L.attn.o, c->att.as<float>(), nullptr, M, x,
+                              L.attn.ln, y, rpb_ln));
+      // FFN (Modules.cc:326-331): y -> x
+      RCCHK(run_affine_relu_q(c, SLIMT_HIP_K_GEMM_ENC, L.ffn1, y, nullptr, M, L.ffn2.w.a_quant,
+                              c->h8.as<int8_t>(), rpb));
+      RCCHK(run_affine_res_ln(c, SLIMT_HIP_K_GEMM_ENC, L.ffn2, nullptr, c->h8.as<int8_t>(), M, y,
+                              L.ffn_ln, x, rpb_ln));
+    }
     if (h_layers)
       HIPCHK(hipMemcpyAsync(h_layers + (size_t)l * M * D, x, nbytes, hipMemcpyDeviceToHost, st));
   }
@@ -960,7 +1000,8 @@ int decode_setup(slimt_hip_ctx *c, size_t n_sl) {
   hipStream_t st = c->stream;
   const int B = c->B, S = c->S, M = B * S, D = m->D;
   if (!c->have_encoder_out) return fail(-1, "decode before encode");
-  const int rpb = M >= 2048 ? 64 : (M >= 512 ? 32 : 16);
+  int rpb = M >= 512 ? 32 : 16;
+  if (const char *e = getenv("SLIMT_EXP_RPB_KV")) rpb = atoi(e);
   float *kv = c->kv.as<float>();
   for (int l = 0; l < m->Ld && !c->kv_ready; ++l) {
     const DecLayerW &L = m->dec[(size_t)l];

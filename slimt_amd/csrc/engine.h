@@ -85,7 +85,7 @@ struct slimt_hip_ctx {
   // encoder workspace
   slimt_hip::DevBuf pos;  // [max_S][D]
   slimt_hip::DevBuf ids, lengths;
-  slimt_hip::DevBuf x0, x1, q, k, v, att, h8;
+  slimt_hip::DevBuf x0, x1, q, k, v, att, h8, a8;
   slimt_hip::DevBuf kv;  // [Ld][2][B*S][D]
   // decoder workspace
   slimt_hip::DevBuf dx, dx_pre, dh, datt8, dout, df8, state;

@@ -79,7 +79,7 @@ struct GemmArgs {
   //   [sentence][head][d/4][key][4]  (row = sentence*kc_S + key, col = head*kc_dh + d)
   // so that a wave reading one head's keys issues fully coalesced 16-byte loads.
   int kc_S = 0, kc_dh = 0;
-  // EPI_RES_LN
+  // EPI_RES_LN; EPI_PLAIN: nullable residual added to the output
   const float *res = nullptr;
   int ldres = 0;
   const float *ln_scale = nullptr;
@@ -276,6 +276,10 @@ struct FusedEncodeArgs {
 bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S);
 hipError_t launch_encode_fused(const FusedEncodeArgs &a, int D, int F, int H, hipStream_t st);
 
+// rows of 64 / 128 / 256 / 512 columns; y8 (nullable): int8 copy quantised with aq8
+hipError_t launch_layer_norm_q(const float *x, const float *scale, const float *bias, float eps,
+                               int rows, int cols, float *y, int8_t *y8, float aq8,
+                               hipStream_t st);
 hipError_t launch_layer_norm(const float *x, const float *scale, const float *bias, float eps,
                              int rows, int cols, float *y, hipStream_t st);
 hipError_t launch_softmax(const float *x, int rows, int cols, float *y, hipStream_t st);

@@ -92,6 +92,59 @@ __device__ __forceinline__ void stage_A_f32(char *A_lds, const float *x, int lda
   }
 }
 
+// Full-chunk staging in two halves: fetch_* issues a group of G global loads
+// (row-clamped, unconditional) so that they are all in flight at once, put_*
+// quantises / stores them to LDS. With the loop above each thread's 4..16
+// loads were dependent round trips (load, quantise, store, next): an encoder
+// GEMM over 8192 rows spent most of its time on that latency chain.
+template <int G>
+__device__ __forceinline__ void fetch_A_f32(float4 (&f)[G], const float *x, int lda, int M,
+                                            int m0, int k0, int u0, int tid) {
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    const int u = u0 + tid + 256 * i, r = u >> 6, c4 = u & 63;  // KCH / 4 = 64 units per row
+    int row = m0 + r;
+    row = row < M ? row : M - 1;
+    f[i] = *reinterpret_cast<const float4 *>(x + (size_t)row * lda + k0 + c4 * 4);
+  }
+}
+
+template <int G>
+__device__ __forceinline__ void put_A_f32(char *A_lds, const float4 (&f)[G], int M, int m0,
+                                          float aq, int u0, int tid) {
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    const int u = u0 + tid + 256 * i, r = u >> 6, c4 = u & 63;
+    int packed = pack4(quantize1(f[i].x, aq), quantize1(f[i].y, aq), quantize1(f[i].z, aq),
+                       quantize1(f[i].w, aq));
+    if (m0 + r >= M) packed = 0;
+    *reinterpret_cast<int *>(A_lds + r * LDA + c4 * 4) = packed;
+  }
+}
+
+template <int RM>
+__device__ __forceinline__ void fetch_A_i8(v4i (&g)[RM], const int8_t *x, int lda, int M, int m0,
+                                           int k0, int tid) {
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    const int u = tid + 256 * i, r = u >> 4, c = u & 15;  // KCH / 16 = 16 units per row
+    int row = m0 + r;
+    row = row < M ? row : M - 1;
+    g[i] = *reinterpret_cast<const v4i *>(x + (size_t)row * lda + k0 + c * 16);
+  }
+}
+
+template <int RM>
+__device__ __forceinline__ void put_A_i8(char *A_lds, const v4i (&g)[RM], int M, int m0, int tid) {
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    const int u = tid + 256 * i, r = u >> 4, c = u & 15;
+    v4i v = g[i];
+    if (m0 + r >= M) v = v4i{0, 0, 0, 0};
+    *reinterpret_cast<v4i *>(A_lds + r * LDA + c * 16) = v;
+  }
+}
+
 template <int RM>
 __device__ __forceinline__ void stage_A_i8(char *A_lds, const int8_t *x, int lda, int M, int m0,
                                            int k0, int kc, int tid) {
@@ -150,13 +203,32 @@ __device__ __forceinline__ void gemm_rows_body(const GemmKArgs &ka, int bx, int 
     }
   };
   load_chunk(0);
+  // K a multiple of the chunk: all of a chunk's A loads in flight at once
+  // (fetch_* / put_*). Holding the NEXT chunk's rows in registers across the
+  // MFMA loop was tried: 360 instead of 174 registers, one block per CU.
+  const bool whole_chunks = (K % KCH) == 0;
   for (int k0 = 0; k0 < K; k0 += KCH) {
     const int kc = (K - k0) < KCH ? (K - k0) : KCH;
     if (k0) __syncthreads();
-    if (a.x_f32)
+    if (whole_chunks) {
+      if (a.x_f32) {
+        constexpr int G = (NT >= 8 || 4 * RM < 8) ? 4 : 8;  // loads in flight per thread (registers)
+#pragma unroll
+        for (int g = 0; g < 4 * RM / G; ++g) {
+          float4 fa[G];
+          fetch_A_f32<G>(fa, a.x_f32, a.lda, row_end, m0, k0, g * G * 256, tid);
+          put_A_f32<G>(A_lds, fa, row_end, m0, a.w.a_quant, g * G * 256, tid);
+        }
+      } else {
+        v4i ga[RM];
+        fetch_A_i8<RM>(ga, a.x_i8, a.lda, row_end, m0, k0, tid);
+        put_A_i8<RM>(A_lds, ga, row_end, m0, tid);
+      }
+    } else if (a.x_f32) {
       stage_A_f32<RM>(A_lds, a.x_f32, a.lda, row_end, m0, k0, kc, a.w.a_quant, tid);
-    else
+    } else {
       stage_A_i8<RM>(A_lds, a.x_i8, a.lda, row_end, m0, k0, kc, tid);
+    }
     __syncthreads();
     const int ksteps = kc >> 6;
 #pragma unroll
@@ -206,6 +278,7 @@ __device__ __forceinline__ void gemm_rows_body(const GemmKArgs &ka, int bx, int 
                 const size_t chunk = ((size_t)sb * (a.w.N / a.kc_dh) + h) * (a.kc_dh >> 2) + (d >> 2);
                 a.y[(chunk * a.kc_S + j) * 4 + (d & 3)] = v;
               } else {
+                if (a.res) v = v + a.res[(size_t)row * a.ldres + col];  // residual, Modules.cc:254,314
                 a.y[(size_t)row * a.ldy + col] = v;
               }
             } else {
@@ -662,8 +735,152 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
   attention_body<NW>(a, blockIdx.x / a.H, blockIdx.x % a.H, smem);
 }
 
+// Self-attention with Tq == S <= 32 and d_head 32 / 64 on the f32 matrix cores:
+// one wave per (sentence, head), the formulation of the persistent encoder
+// (encode_fused.hip): S^T = K Q^T as a chain of v_mfma_f32_32x32x2_f32 over
+// ascending d (bit-identical to the ascending fmaf chain of attention_body,
+// tools/probe_mfma_f32.py), the canonical 32-key butterfly on the accumulator
+// layout, O = P V over ascending keys. Q and K rows are staged through a
+// per-wave LDS region (row stride DH + 2 floats: conflict-free operand reads);
+// V operands come straight from global memory (128 B per half-wave).
+template <int DH>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  constexpr int LDH = DH + 2;
+  constexpr int NDB = DH / 32;  // 32-column blocks of the output
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int job = blockIdx.x * 4 + wave;
+  if (job >= a.B * a.H) return;  // waves are independent: no workgroup barrier below
+  const int b = job / a.H, h = job - b * a.H;
+  const int S = a.S;
+  float *Qs = reinterpret_cast<float *>(smem) + (size_t)wave * 2 * 32 * LDH;
+  float *Ks = Qs + 32 * LDH;
+  const int n = lane & 31, hh = lane >> 5;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+
+  // V operand of step i (keys 2 i + hh), requested first: it is needed last
+  float vv[NDB][16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int key = 2 * i + hh;
+    const float *vp = a.v + (size_t)(b * S + (key < S ? key : S - 1)) * a.ldv + h * DH + n;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) vv[db][i] = vp[32 * db];
+  }
+  {
+    constexpr int LPR = DH / 4, RPI = 64 / LPR;  // lanes per row, rows per load instruction
+    float4 q4[32 / RPI], k4[32 / RPI];
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int r = i * RPI + lane / LPR, c = (lane % LPR) * 4;
+      const size_t row = (size_t)(b * S + (r < S ? r : S - 1));
+      q4[i] = *reinterpret_cast<const float4 *>(a.q + row * a.ldq + h * DH + c);
+      k4[i] = *reinterpret_cast<const float4 *>(a.k + row * a.ldk + h * DH + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int r = i * RPI + lane / LPR, c = (lane % LPR) * 4;
+      float2 *qd = reinterpret_cast<float2 *>(Qs + r * LDH + c);
+      float2 *kd = reinterpret_cast<float2 *>(Ks + r * LDH + c);
+      qd[0] = make_float2(q4[i].x, q4[i].y);
+      qd[1] = make_float2(q4[i].z, q4[i].w);
+      kd[0] = make_float2(k4[i].x, k4[i].y);
+      kd[1] = make_float2(k4[i].z, k4[i].w);
+    }
+  }
+  // LDS operations of one wave execute in order; only the compiler must not move
+  // the operand reads above the stores
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  v16f st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  {
+    const float *kp = Ks + n * LDH + hh, *qp = Qs + n * LDH + hh;
+#pragma unroll
+    for (int k0 = 0; k0 < DH; k0 += 2)
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[k0], qp[k0], st, 0, 0, 0);
+  }
+  const int len = a.mask ? 0 : (int)a.lengths[b];
+  float sc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = 8 * (r >> 2) + 4 * hh + (r & 3);  // key of this register
+    float v = st[r];
+    if (a.alpha != 1.0f) v = a.alpha * v;
+    float mk;
+    if (a.mask)
+      mk = m < S ? a.mask[(size_t)b * S + m] : 0.0f;
+    else
+      mk = (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
+    v = v + mk;
+    if (m >= S) v = lowest;
+    sc[r] = v;
+  }
+  // canonical butterfly over 32 keys: masks 1, 2 = register pairs, mask 4 = the
+  // other half-wave, masks 8, 16 = register groups
+  float t4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    t4[g] = bf_max<32>(fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3])));
+  const float mx = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = 8 * (r >> 2) + 4 * hh + (r & 3);
+    sc[r] = m < S ? exp_p(sc[r] - mx) : 0.0f;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    t4[g] = bf_add<32>((sc[4 * g] + sc[4 * g + 1]) + (sc[4 * g + 2] + sc[4 * g + 3]));
+  const float sum = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sc[r] = sc[r] / sum;  // keys >= S: exactly 0
+  // P operand of step i: keys 2 i (hh = 0) / 2 i + 1 (hh = 1)
+  float pa[16];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const slimt_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * g + 0]),
+                                                          __float_as_int(sc[4 * g + 1]), false, false);
+    const slimt_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * g + 2]),
+                                                          __float_as_int(sc[4 * g + 3]), false, false);
+    pa[4 * g + 0] = __int_as_float(s01.x);  // keys 8 g + 0, 8 g + 1
+    pa[4 * g + 1] = __int_as_float(s23.x);  // keys 8 g + 2, 8 g + 3
+    pa[4 * g + 2] = __int_as_float(s01.y);  // keys 8 g + 4, 8 g + 5
+    pa[4 * g + 3] = __int_as_float(s23.y);  // keys 8 g + 6, 8 g + 7
+  }
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) {
+    v16f o = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i)  // keys >= S contribute fma(0, v, o) == o
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], vv[db][i], o, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 8 * (r >> 2) + 4 * hh + (r & 3);  // query of this register
+      if (m < S) a.out[(size_t)(b * S + m) * a.ldo + h * DH + 32 * db + n] = o[r];
+    }
+  }
+}
+
+template <int DH>
+static hipError_t launch_attention_mfma(const AttnArgs &a, hipStream_t st) {
+  const size_t lds = (size_t)4 * 2 * 32 * (DH + 2) * sizeof(float);
+  auto k = attention_mfma_kernel<DH>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3((a.B * a.H + 3) / 4), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_attention(const AttnArgs &a, hipStream_t st) {
   if (a.S < 1 || a.S > 128 || a.dh < 1 || a.dh > 64) return hipErrorInvalidValue;
+  const auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (a.Tq == a.S && a.S <= 32 && (a.dh == 32 || a.dh == 64) && !a.attn && !a.align &&
+      a.ldq % 4 == 0 && a.ldk % 4 == 0 && aligned16(a.q) && aligned16(a.k))
+    return a.dh == 32 ? launch_attention_mfma<32>(a, st) : launch_attention_mfma<64>(a, st);
   const size_t lds = 2 * (size_t)a.S * (a.dh + 1) * sizeof(float);
   const dim3 grid(a.B * a.H);
   if (a.Tq == 1)
@@ -684,6 +901,58 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float *x, const f
   if (row < rows)
     wave_layer_norm_row(x + (size_t)row * cols, scale, bias, eps, cols, y + (size_t)row * cols,
                         threadIdx.x & 63);
+}
+
+// LayerNorm of rows of 64 DPL columns held in registers, one wave per row, with an
+// optional int8 copy quantised for the next affine (x and y may alias).
+template <int DPL>
+__global__ __launch_bounds__(256) void layer_norm_q_kernel(const float *x, const float *scale,
+                                                           const float *bias, float eps, int rows,
+                                                           float *y, int8_t *y8, float aq8) {
+  constexpr int D = 64 * DPL;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float *xr = x + (size_t)row * D;
+  float v[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) v[i] = xr[lane + 64 * i];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) s += v[i];
+  s = wave_sum(s);
+  const float mean = s / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float d = v[i] - mean;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  const float sigma = __builtin_sqrtf(q / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float t = (v[i] - mean) / sigma;
+    const float sc = scale[lane + 64 * i] * t;
+    const float o = sc + bias[lane + 64 * i];
+    y[(size_t)row * D + lane + 64 * i] = o;
+    if (y8) y8[(size_t)row * D + lane + 64 * i] = (int8_t)quantize1(o, aq8);
+  }
+}
+
+hipError_t launch_layer_norm_q(const float *x, const float *scale, const float *bias, float eps,
+                               int rows, int cols, float *y, int8_t *y8, float aq8,
+                               hipStream_t st) {
+  const dim3 grid((rows + 3) / 4);
+#define SLIMT_LNQ_CASE(DPL_)                                                                    \
+  if (cols == 64 * DPL_) {                                                                      \
+    hipLaunchKernelGGL(layer_norm_q_kernel<DPL_>, grid, dim3(256), 0, st, x, scale, bias, eps,  \
+                       rows, y, y8, aq8);                                                       \
+    return hipGetLastError();                                                                   \
+  }
+  SLIMT_LNQ_CASE(1) SLIMT_LNQ_CASE(2) SLIMT_LNQ_CASE(4) SLIMT_LNQ_CASE(8)
+#undef SLIMT_LNQ_CASE
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_layer_norm(const float *x, const float *scale, const float *bias, float eps,
