@@ -940,14 +940,12 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
   float *x = c->x0.as<float>(), *y = c->x1.as<float>();
   HIPCHK(launch_embed_encoder(embed_args(c), c->ids.as<uint32_t>(), B, S, x, st));
   if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, x, nbytes, hipMemcpyDeviceToHost, st));
-  int rpb = M >= 2048 ? 64 : (M >= 512 ? 32 : 16);
-  int rpb_ln = M >= 4096 ? 32 : 16;
-  int rpb_n = M >= 2048 ? 32 : rpb;  // N <= 512: more, smaller blocks
-  bool big = M >= 2048 && (D == 64 || D == 128 || D == 256 || D == 512);
-  if (const char *e = getenv("SLIMT_EXP_RPB")) rpb = atoi(e);
-  if (const char *e = getenv("SLIMT_EXP_RPB_LN")) rpb_ln = atoi(e);
-  if (const char *e = getenv("SLIMT_EXP_RPB_N")) rpb_n = atoi(e);
-  if (const char *e = getenv("SLIMT_EXP_BIG")) big = atoi(e) != 0;
+  const int rpb = M >= 2048 ? 64 : (M >= 512 ? 32 : 16);
+  const int rpb_ln = M >= 4096 ? 32 : 16;
+  // measured at M = 8192, K = N = 512 (base): 64-row blocks 20.9 us, 32-row blocks
+  // 14.5 us (twice the blocks in flight); FFN1 (N = 2048) prefers 64 rows
+  const int rpb_n = M >= 2048 ? 32 : rpb;
+  const bool big = M >= 2048 && (D == 64 || D == 128 || D == 256 || D == 512);
   for (int l = 0; l < m->Le; ++l) {
     const EncLayerW &L = m->enc[(size_t)l];
     // Attention::forward (Modules.cc:287-319)
@@ -1000,8 +998,7 @@ int decode_setup(slimt_hip_ctx *c, size_t n_sl) {
   hipStream_t st = c->stream;
   const int B = c->B, S = c->S, M = B * S, D = m->D;
   if (!c->have_encoder_out) return fail(-1, "decode before encode");
-  int rpb = M >= 512 ? 32 : 16;
-  if (const char *e = getenv("SLIMT_EXP_RPB_KV")) rpb = atoi(e);
+  const int rpb = M >= 512 ? 32 : 16;
   float *kv = c->kv.as<float>();
   for (int l = 0; l < m->Ld && !c->kv_ready; ++l) {
     const DecLayerW &L = m->dec[(size_t)l];

@@ -204,8 +204,11 @@ __device__ __forceinline__ void gemm_rows_body(const GemmKArgs &ka, int bx, int 
   };
   load_chunk(0);
   // K a multiple of the chunk: all of a chunk's A loads in flight at once
-  // (fetch_* / put_*). Holding the NEXT chunk's rows in registers across the
-  // MFMA loop was tried: 360 instead of 174 registers, one block per CU.
+  // (fetch_* / put_*). Tried and measured, not kept: holding the NEXT chunk's
+  // rows in registers across the MFMA loop, and a full software pipeline (two
+  // LDS tiles, two sets of B fragments): 250-360 registers = one block per CU,
+  // and M = 8192 GEMMs ran 1.5x SLOWER (31 vs 20 us) -- two resident blocks per
+  // CU hide more latency than the deeper prefetch of one.
   const bool whole_chunks = (K % KCH) == 0;
   for (int k0 = 0; k0 < K; k0 += KCH) {
     const int kc = (K - k0) < KCH ? (K - k0) : KCH;
