@@ -36,8 +36,8 @@ PEAK_HBM_GBS = 8000.0    # HBM3E spec (MI355X_MICROARCH.md, Chip-level parameter
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=384)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--preset", default="tiny11")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--src-len", type=int, default=32)
@@ -255,6 +255,45 @@ def main():
                                                       model.dec_layers, S, T, N_out)
         traffic, traffic_src = pmc_traffic(prof_name)
         cus = -(-B // 16) if prof_name == "decode_fused" else 256
+        in_flight = prof["total_ms"] / (1e3 * dt) if dt > 0 else 0.0  # launches of this kernel running at once (this rank)
+        mfma = {
+            "achieved": achieved, "peak": PEAK_INT8_TOPS, "unit": "TOP/s", "frac": achieved / PEAK_INT8_TOPS,
+            "frac_of_occupied_cus": achieved / (PEAK_INT8_TOPS * cus / 256.0),
+            "chip_frac_all_kernels": 2.0 * macs_sentence * B * args.steps / dt_max / 1e12 / PEAK_INT8_TOPS,  # per GPU
+            "algorithmic_ops_per_launch": ops,
+        }
+        if prof_name == "decode_fused":
+            # The persistent decoder is a streaming kernel (16 rows per workgroup: <10 % MFMA duty).
+            # Algorithmic memory-side bytes of one launch: the cross-attention
+            # K/V cache is re-read every step and, with >= 8 batches in flight, exceeds the 256 MB
+            # Infinity Cache (PMC: profiles/r01_v12_fullocc_pmc.txt); weights once per step and batch
+            # (they are shared through L2 by the batch's workgroups); target embeddings; ids out.
+            D, F, Ld = model.D, model.F, model.dec_layers
+            kv_bytes = float(B) * T * Ld * 2 * S * D * 4
+            w_bytes = float(T) * (Ld * (4 * D * D + 2 * D * F) + D * N_out)
+            io_bytes = float(B) * T * (D + 4)
+            alg_bytes = kv_bytes + w_bytes + io_bytes
+            gbs = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roofline = {
+                "kernel": prof_name, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_model": {"kv_cache_reread_per_step": kv_bytes, "weights_once_per_step": w_bytes,
+                                "embedding_rows_and_ids": io_bytes},
+                "launches": prof["launches"], "avg_launch_us": 1e3 * avg_ms,
+                "cus_per_launch": cus, "launches_in_flight": in_flight,
+                "chip_achieved": gbs * in_flight, "chip_frac": gbs * in_flight / PEAK_HBM_GBS,
+                "note": "achieved/frac are per launch of ONE kernel instance, which occupies ceil(B/16) of the "
+                        "256 CUs; `launches_in_flight` of them overlap (plus the other workers' encoders), "
+                        "chip_* = per-launch rate x launches in flight",
+                "l2_stream_bytes_per_launch": wbytes + kv_bytes,  # weights per workgroup and step + K/V
+                "l2_stream_GBs_per_cu": (wbytes + kv_bytes) / (avg_ms * 1e-3) / 1e9 / cus if avg_ms > 0 else 0.0,
+                "mfma": mfma,
+            }
+        else:
+            roofline = dict(mfma, kernel=prof_name, bound="mfma", traffic=traffic, traffic_source=traffic_src,
+                            cus_per_launch=cus, launches=prof["launches"], avg_launch_us=1e3 * avg_ms,
+                            launches_in_flight=in_flight, algorithmic_weight_bytes_per_launch=wbytes)
         out = {
             "metric": "target tokens/sec, en-de tiny11 int8 greedy, batch=256",
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
@@ -273,19 +312,7 @@ def main():
                 "int8_ops_per_token": 2.0 * macs_sentence / T,
                 "whole_job_int8_tops": 2.0 * macs_sentence * B * world * args.steps / dt_max / 1e12,
             },
-            "roofline": {
-                "kernel": prof_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_INT8_TOPS,
-                "unit": "TOP/s", "frac": achieved / PEAK_INT8_TOPS, "traffic": traffic,
-                "traffic_source": traffic_src, "cus_per_launch": cus,
-                "frac_of_occupied_cus": achieved / (PEAK_INT8_TOPS * cus / 256.0),
-                "chip_frac_all_launches": 2.0 * macs_sentence * B * args.steps / dt_max / 1e12 / PEAK_INT8_TOPS,  # per GPU
-                "launches": prof["launches"], "avg_launch_us": 1e3 * avg_ms,
-                "note": "per-launch figure of ONE kernel instance; a decode launch occupies "
-                        "ceil(B/16) of the 256 CUs and `workers` launches overlap (see config)",
-                "algorithmic_ops_per_launch": ops, "algorithmic_weight_bytes_per_launch": wbytes,
-                "hbm_achieved_GBs": wbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-                "hbm_frac": (wbytes / (avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if avg_ms > 0 else 0.0,
-            },
+            "roofline": roofline,
         }
         if per_kernel is not None:
             out["per_kernel"] = per_kernel
