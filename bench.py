@@ -46,9 +46,11 @@ def parse():
                     help="kernel family bracketed by HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sentences", type=int, default=128, help="sentences per CPU worker")
-    ap.add_argument("--workers", type=int, default=16,
+    ap.add_argument("--workers", type=int, default=20,
                     help="translate contexts (HIP streams) per GPU, like slimt::Async workers "
                          "(Frontend.cc:212-226): independent batches in flight on one device")
+    ap.add_argument("--decoder-budget", type=int, default=-1,
+                    help="decoder workgroups admitted at a time (-1 = library default: 3/4 of the CUs, 0 = no limit)")
     ap.add_argument("--decode-mode", type=int, default=0, help="0 = fused persistent decoder, 1 = step-wise")
     ap.add_argument("--all-kernels", action="store_true",
                     help="after the timed region, time every kernel family (untimed pass)")
@@ -166,6 +168,8 @@ def main():
     sl = synth.make_shortlist(model.V, n_sl) if n_sl else None
     N_out = n_sl if n_sl else model.V
     gm = capi.Model(model, device=local_rank)
+    if args.decoder_budget >= 0:
+        gm.set_decoder_budget(args.decoder_budget)
     W = max(1, args.workers)
     ctxs = [capi.Context(gm, B, S) for _ in range(W)]
     for c in ctxs:

@@ -116,6 +116,12 @@ int slimt_hip_model_create(const slimt_hip_param *params, size_t n_params,
                            const slimt_hip_dims *dims, int device,
                            slimt_hip_model **out);
 int slimt_hip_model_destroy(slimt_hip_model *model);
+/* Admission of the persistent decoders of all contexts of `model`: at most
+ * about `workgroups` decoder workgroups (one CU each, 16 sentences) run at a
+ * time, later launches wait on their own stream; the remaining CUs stay with
+ * the encoders of the batches behind them. Default: 3/4 of the device's CUs;
+ * 0 = no limit. Results do not depend on it. */
+int slimt_hip_model_set_decoder_budget(slimt_hip_model *model, int workgroups);
 int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
                          int32_t *dim_ffn, int32_t *vocab, int32_t *heads);
 
@@ -258,6 +264,13 @@ int slimt_hip_profile_reset(slimt_hip_ctx *ctx);
  * call (step < 0 disables stamping). */
 int slimt_hip_debug_decode_stamps(slimt_hip_ctx *ctx, int step, uint64_t *out,
                                   size_t n);
+/* Diagnostic (process-wide): while device_buf != NULL, thread 0 of every
+ * workgroup of the persistent encoder / decoder appends a begin and an end
+ * event to it: device_buf[0] = event counter (zero it first), then 3 uint64
+ * per event {kernel (1 = decoder, 2 = encoder) | end << 8 | blockIdx << 16,
+ * HW_ID | XCC_ID << 32, 100 MHz wall clock}; events past `capacity` are
+ * dropped. NULL switches it off. tools/occupancy_trace.py reads it. */
+int slimt_hip_debug_occupancy_trace(void *device_buf, size_t capacity);
 
 #ifdef __cplusplus
 }

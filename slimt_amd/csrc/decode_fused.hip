@@ -536,7 +536,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
 // step; a.stamps == nullptr in normal runs (one uniform branch per phase).
 #define SLIMT_STAMP(id)                                                                  \
   do {                                                                                   \
-    if (a.stamps && blockIdx.x == 0 && tid == 0 && t == a.stamp_step)                    \
+    if (a.stamps && m0 == 0 && tid == 0 && t == a.stamp_step)                            \
       a.stamps[(id)] = wall_clock64();                                                   \
   } while (0)
 
@@ -559,7 +559,6 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr int LDA3 = F + 16;  // int8 row stride (K = F)
   const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * 16;
   const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
 
   // D > 256 ("base") does not fit the layout below in 160 KiB: the pre-LN
@@ -579,6 +578,24 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   int *red_i = reinterpret_cast<int *>(red_v + NW * 16);
   int *flags = red_i + NW * 16;  // [0] = number of finished sentences of this tile
   float *pbufs = reinterpret_cast<float *>(flags + 16);  // [NW][256] attention scratch
+
+  // Which 16 sentences? With a ticket counter the grid is over-subscribed (2 x the
+  // tiles) and the first workgroups to START claim the tiles; the rest leave at
+  // once. A workgroup needs a whole CU, and the hardware binds a workgroup to a
+  // shader engine when the kernel is dispatched, not when a CU frees up: with
+  // exactly one workgroup per tile, tiles waited for a CU on "their" engine while
+  // CUs of other engines sat idle (20 % of the CU time under the 16-worker load,
+  // tools/occupancy_trace.py, tools/probes/mix_probe.hip). Tiles are independent,
+  // so who runs which changes nothing in the results.
+  int tile = blockIdx.x;
+  if (a.ticket) {
+    if (tid == 0) flags[1] = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
+    __syncthreads();
+    tile = flags[1];
+    if ((unsigned)tile >= (unsigned)((B + 15) / 16)) return;
+  }
+  const int m0 = tile * 16;
+  if (tid == 0) occ_trace_event(a.trace, 1, 0);
 
   // per-sentence state, owned by wave `wave` (uniform within the wave)
   const int b = m0 + wave;
@@ -618,7 +635,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   const int max_steps = a.max_steps;
   for (int t = 0; t < max_steps; ++t) {
     SLIMT_STAMP(0);
-    if (a.stamps && blockIdx.x == 0 && tid == 0 && t == a.stamp_step) a.stamps[60] = clock64();
+    if (a.stamps && m0 == 0 && tid == 0 && t == a.stamp_step) a.stamps[60] = clock64();
     for (int l = 0; l < Ld; ++l) {
       SLIMT_PHASE_LANE;
       const FusedLayerW &L = a.L[l];
@@ -823,9 +840,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     }
     __syncthreads();
     SLIMT_STAMP(42);
-    if (a.stamps && blockIdx.x == 0 && tid == 0 && t == a.stamp_step) a.stamps[61] = clock64();
+    if (a.stamps && m0 == 0 && tid == 0 && t == a.stamp_step) a.stamps[61] = clock64();
   }
   if (live && lane == 0) a.out_len[b] = n_out;
+  if (tid == 0) occ_trace_event(a.trace, 1, 1);
 }
 
 // =============================================================================
@@ -1346,6 +1364,9 @@ int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced) {
   return (forced == 32 && ok32) ? 32 : 16;
 }
 
+// workgroups launched for B sentences by the 16-row kernel: with tickets, twice the tiles
+int fused_decode_grid(int B, bool tickets) { return (tickets ? 2 : 1) * ((B + 15) / 16); }
+
 size_t fused_decode_lds_bytes(int D, int F, int Ld) {
   // D > 256: two f32 row buffers, SSRU cells in global memory (see the kernel)
   const size_t rows = D > 256 ? (size_t)2 * 16 * (D + 4) * 4
@@ -1384,7 +1405,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hi
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
     return hipGetLastError();
   }
-  const dim3 grid((a.B + 15) / 16);
+  const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr));
   const size_t lds = fused_decode_lds_bytes(D, F, a.Ld);
 #define SLIMT_FUSED_CASE(KSD_, KSF_, DH_)                                                   \
   if (D == 64 * KSD_ && F == 64 * KSF_ && D / H == DH_) {                                    \

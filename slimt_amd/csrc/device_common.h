@@ -177,6 +177,19 @@ __device__ __forceinline__ void wave_layer_norm_row(const float *x, const float 
   }
 }
 
+// one event of the diagnostic occupancy trace (kernels.h, OccTrace); call from ONE thread
+__device__ __forceinline__ void occ_trace_event(const OccTrace &t, unsigned kernel, unsigned end) {
+  if (!t.buf) return;
+  const unsigned long long slot = atomicAdd(t.buf, 1ull);
+  if (slot >= t.capacity) return;
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: CU / SH / SE
+  const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+  unsigned long long *r = t.buf + 1 + 3 * slot;
+  r[0] = (unsigned long long)kernel | ((unsigned long long)end << 8) | ((unsigned long long)blockIdx.x << 16);
+  r[1] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  r[2] = wall_clock64();
+}
+
 __device__ __forceinline__ int sum_bytes(int w) {
   return (int)(int8_t)(w & 0xff) + (int)(int8_t)((w >> 8) & 0xff) +
          (int)(int8_t)((w >> 16) & 0xff) + (int)(int8_t)((w >> 24) & 0xff);

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   const int spw = ER / S;              // whole sentences per workgroup
   const int s0 = blockIdx.x * spw;     // first sentence
   const int rows_used = spw * S;
+  if (tid == 0) occ_trace_event(a.trace, 2, 0);
 
   float *xs = reinterpret_cast<float *>(smem);
   char *Aq = reinterpret_cast<char *>(xs + ER * LDX);
@@ -522,6 +523,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     }
     __syncthreads();
   }
+  if (tid == 0) occ_trace_event(a.trace, 2, 1);
 }
 
 // =============================================================================

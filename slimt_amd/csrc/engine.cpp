@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 
 using namespace slimt_hip;
@@ -105,6 +106,10 @@ extern "C" int slimt_hip_prepare_weight_quantized_transposed(const int8_t *input
 // ---------------------------------------------------------------------------
 // op level
 // ---------------------------------------------------------------------------
+// process-wide diagnostic switch (slimt_hip_debug_occupancy_trace)
+static slimt_hip::OccTrace g_occ_trace;
+
+
 namespace {
 
 struct TmpAffine {  // device temporaries of one stateless qmm call
@@ -421,6 +426,8 @@ void model_free(slimt_hip_model *m) {
   }
   m->wemb.release(); m->out_raw.release(); m->out_bias.release();
   free_affine(m->out_full);
+  for (hipEvent_t ev : m->gate_ev) (void)hipEventDestroy(ev);
+  m->gate_ev.clear();
 }
 
 int model_build(slimt_hip_model *m, const slimt_hip_param *params, size_t n,
@@ -509,6 +516,10 @@ extern "C" int slimt_hip_model_create(const slimt_hip_param *params, size_t n_pa
   HIPCHK(hipSetDevice(device));
   auto *m = new slimt_hip_model();
   m->device = device;
+  {  // default decoder admission: three quarters of the CUs (measured optimum)
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->decoder_budget = 3 * prop.multiProcessorCount / 4;
+  }
   int rc = model_build(m, params, n_params, dims);
   if (rc) {
     model_free(m);
@@ -524,6 +535,14 @@ extern "C" int slimt_hip_model_destroy(slimt_hip_model *model) {
   (void)hipSetDevice(model->device);
   model_free(model);
   delete model;
+  return 0;
+}
+
+extern "C" int slimt_hip_model_set_decoder_budget(slimt_hip_model *model, int workgroups) {
+  if (!model) return fail(-1, "model is NULL");
+  if (workgroups < 0) return fail(-1, "decoder budget %d < 0", workgroups);
+  std::lock_guard<std::mutex> lock(model->gate_mu);
+  model->decoder_budget = workgroups;
   return 0;
 }
 
@@ -562,7 +581,7 @@ void sinusoid_table(int S, int D, std::vector<float> &out) {
 
 void ctx_free(slimt_hip_ctx *c) {
   DevBuf *bufs[] = {&c->pos, &c->ids, &c->lengths, &c->x0, &c->x1, &c->q, &c->k, &c->v, &c->att,
-                    &c->h8, &c->a8, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
+                    &c->h8, &c->a8, &c->ticket, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
                     &c->state, &c->part_val, &c->part_idx, &c->prev, &c->out_ids, &c->out_len,
                     &c->finished, &c->n_finished, &c->align, &c->shortlist, &c->logits,
                     &c->attn_dbg, &c->stamps, &c->dbg_embed, &c->dbg_layers, &c->sl_scratch, &c->n_sl_dev};
@@ -594,6 +613,8 @@ int ctx_alloc(slimt_hip_ctx *c) {
   HIPCHK(c->att.reserve(M * D * 4));
   HIPCHK(c->h8.reserve(M * F));
   HIPCHK(c->a8.reserve(M * D));
+  HIPCHK(c->ticket.reserve(4));
+  HIPCHK(hipMemset(c->ticket.p, 0, 4));
   HIPCHK(c->kv.reserve((size_t)m->Ld * 2 * M * D * 4));
   HIPCHK(c->dx.reserve(B * D * 4));
   HIPCHK(c->dx_pre.reserve(B * D * 4));
@@ -869,6 +890,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       HIPCHK(c->dbg_layers.reserve(nbytes * (size_t)m->Le));
       f.layer_out = c->dbg_layers.as<float>();
     }
+    f.trace = g_occ_trace;
     if (c->stamp_step >= 0 && c->stamps.p) {  // encoder stamps live in slots 48..55
       f.stamps = c->stamps.as<unsigned long long>() + 48;
       f.stamp_layer = c->stamp_step < m->Le ? c->stamp_step : m->Le - 1;
@@ -1219,6 +1241,12 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.out_ids = d_out_ids;
     f.out_len = d_out_len;
     f.align = d_align;
+    f.trace = g_occ_trace;
+    if (rows == 16) {
+      f.ticket = c->ticket.as<unsigned>();
+      f.ticket_base = c->ticket_base;
+      c->ticket_base += (unsigned)fused_decode_grid((int)B, true);
+    }
     if (c->stamp_step >= 0 && c->stamps.p) {
       f.stamps = c->stamps.as<unsigned long long>();
       f.stamp_step = c->stamp_step;
@@ -1227,6 +1255,28 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
                         (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.N);
     const double wbytes = (double)f.max_steps * ((B + rows - 1) / rows) *
                           (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.n_tiles * 16);
+    slimt_hip_model *gm = c->model;
+    const int wgs = ((int)B + rows - 1) / rows;
+    if (gm->decoder_budget > 0) {
+      // decoder admission (engine.h): launch k waits for launch k - n on its own stream
+      constexpr size_t kRing = 64;
+      std::lock_guard<std::mutex> lock(gm->gate_mu);
+      while (gm->gate_ev.size() < kRing) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        gm->gate_ev.push_back(ev);
+      }
+      size_t n = (size_t)std::max(1, gm->decoder_budget / wgs);
+      if (n > kRing) n = kRing;
+      if (gm->gate_seq >= n) HIPCHK(hipStreamWaitEvent(st, gm->gate_ev[(gm->gate_seq - n) % kRing], 0));
+      {
+        ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);
+        HIPCHK(launch_decode_fused(f, m->D, m->F, m->H, st));
+      }
+      HIPCHK(hipEventRecord(gm->gate_ev[gm->gate_seq % kRing], st));
+      gm->gate_seq += 1;
+      return 0;
+    }
     ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);
     HIPCHK(launch_decode_fused(f, m->D, m->F, m->H, st));
     return 0;
@@ -1432,6 +1482,13 @@ extern "C" int slimt_hip_profile_read(slimt_hip_ctx *ctx, uint64_t *launches, do
   if (total_ms) *total_ms = ms;
   if (int8_macs) *int8_macs = ctx->prof_macs;
   if (weight_bytes) *weight_bytes = ctx->prof_bytes;
+  return 0;
+}
+
+// Diagnostic occupancy trace of the persistent kernels (kernels.h, OccTrace)
+extern "C" int slimt_hip_debug_occupancy_trace(void *device_buf, size_t capacity) {
+  g_occ_trace.buf = static_cast<unsigned long long *>(device_buf);
+  g_occ_trace.capacity = device_buf ? (unsigned)capacity : 0u;
   return 0;
 }
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/slimt_hip.h"
@@ -64,6 +65,14 @@ struct slimt_hip_model {
   slimt_hip::DevBuf out_bias;  // decoder_ff_logit_out_b [V]
   float out_a_quant = 0.f;     // none_QuantMultA (Transformer.cc:111-113)
   slimt_hip::AffineW out_full; // full-vocabulary output layer
+  // Admission of persistent decoders (all contexts of this model): at most
+  // `decoder_budget` decoder workgroups are meant to run at a time; launch k waits
+  // (on its stream, not the host) for launch k - n, n = budget / its workgroups.
+  // The other CUs stay with the encoders of the batches behind. 0 = no limit.
+  std::mutex gate_mu;
+  std::vector<hipEvent_t> gate_ev;  // ring, created on first use
+  size_t gate_seq = 0;
+  int decoder_budget = 0;
 };
 
 struct slimt_hip_ctx {
@@ -86,6 +95,8 @@ struct slimt_hip_ctx {
   slimt_hip::DevBuf pos;  // [max_S][D]
   slimt_hip::DevBuf ids, lengths;
   slimt_hip::DevBuf x0, x1, q, k, v, att, h8, a8;
+  slimt_hip::DevBuf ticket;      // ticket counter of the over-subscribed decoder launches
+  unsigned ticket_base = 0;      // tickets handed out by earlier launches
   slimt_hip::DevBuf kv;  // [Ld][2][B*S][D]
   // decoder workspace
   slimt_hip::DevBuf dx, dx_pre, dh, datt8, dout, df8, state;

@@ -27,6 +27,15 @@ struct PreparedWeight {
 
 size_t packed_weight_bytes(int K, int N);
 
+// Diagnostic occupancy trace (tools/occupancy_trace.py): when buf != nullptr,
+// thread 0 of every workgroup of the persistent kernels appends a begin and an
+// end event {kernel | end << 8 | blockIdx << 16, HW_ID | XCC_ID << 32, 100 MHz
+// wall clock} (3 x u64) after the header buf[0] = event counter.
+struct OccTrace {
+  unsigned long long *buf = nullptr;
+  unsigned capacity = 0;  // events
+};
+
 // One weight-packing job (load time; once per batch for the shortlisted output
 // layer): rows idx[n] (or n) of W [N_src][K] -> MFMA fragment order + colsum + pb.
 struct PackArgs {
@@ -244,7 +253,13 @@ struct FusedDecodeArgs {
   unsigned long long *stamps = nullptr;  // nullable diagnostic [64] phase stamps
   int stamp_step = 0;
   int rows_per_wg = 0;  // 0 = auto, 16 / 32 = force (32 only where supported)
+  // nullable: ticket counter of the over-subscribed launch (16-row kernel). Every workgroup
+  // of every launch takes one ticket; ticket - ticket_base is the tile it runs (or none).
+  unsigned *ticket = nullptr;
+  unsigned ticket_base = 0;
+  OccTrace trace;
 };
+int fused_decode_grid(int B, bool tickets);
 bool fused_decode_supported(int D, int F, int H, int Ld);
 int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
@@ -267,6 +282,7 @@ struct FusedEncodeArgs {
   float *kv = nullptr;         // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]
   PackArgs pack;               // the batch's shortlisted output layer, packed by the
   int pack_tiles = 0;          // encoder's workgroups on the side (0 = nothing to pack)
+  OccTrace trace;
   float *enc_out = nullptr;    // nullable [B*S][D]
   float *layer_out = nullptr;  // nullable [Le][B*S][D]
   float *embed_out = nullptr;  // nullable [B*S][D]
