@@ -16,6 +16,7 @@ CPU port of the reference path, timed on this box's host cores, N=1 only).
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -36,7 +37,7 @@ PEAK_HBM_GBS = 8000.0    # HBM3E spec (MI355X_MICROARCH.md, Chip-level parameter
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=384)
+    ap.add_argument("--steps", type=int, default=768)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--preset", default="tiny11")
     ap.add_argument("--batch", type=int, default=256)
@@ -70,7 +71,8 @@ def pmc_traffic(kernel):
     import glob
     out = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{c}.json")))
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{c}.json")),
+                       key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])  # r01_v9 < r01_v13
         if not files:
             return None, None
         rec = json.load(open(files[-1])).get(kernel)

@@ -964,7 +964,6 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
   static_assert(D / 16 == NW, "one 16-column tile of a D-wide GEMM per wave");
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * R2;
   const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
 
   float *X = reinterpret_cast<float *>(smem);  // layer input rows (post-LN); reused for q
@@ -976,6 +975,15 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
   float *red_v = reinterpret_cast<float *>(HB1 + R2 * LDA);  // [NW][32]
   int *red_i = reinterpret_cast<int *>(red_v + NW * R2);
   int *flags = red_i + NW * R2;  // [0] = number of finished sentences of this tile
+
+  int tile = blockIdx.x;  // over-subscribed launch: see decode_fused_kernel
+  if (a.ticket) {
+    if (tid == 0) flags[1] = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
+    __syncthreads();
+    tile = flags[1];
+    if ((unsigned)tile >= (unsigned)((B + R2 - 1) / R2)) return;
+  }
+  const int m0 = tile * R2;
 
   // per-sentence state of rows wave and wave + 16 (uniform within the wave)
   int bq[2];
@@ -1364,8 +1372,12 @@ int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced) {
   return (forced == 32 && ok32) ? 32 : 16;
 }
 
-// workgroups launched for B sentences by the 16-row kernel: with tickets, twice the tiles
-int fused_decode_grid(int B, bool tickets) { return (tickets ? 2 : 1) * ((B + 15) / 16); }
+// workgroups launched for B sentences: with tickets 2 x the tiles (16 rows) / 4 x (32 rows),
+// i.e. one candidate per shader engine of every XCD for a batch of 256
+int fused_decode_grid(int B, bool tickets, int rows) {
+  const int tiles = (B + rows - 1) / rows;
+  return tickets ? tiles * (rows == 16 ? 2 : 4) : tiles;
+}
 
 size_t fused_decode_lds_bytes(int D, int F, int Ld) {
   // D > 256: two f32 row buffers, SSRU cells in global memory (see the kernel)
@@ -1396,7 +1408,7 @@ static auto decode_fused_pick(bool long_sentences) -> void (*)(FusedDecodeArgs) 
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st) {
   if (!fused_decode_supported(D, F, H, a.Ld)) return hipErrorInvalidValue;
   if (fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg) == 32) {
-    const dim3 grid((a.B + R2 - 1) / R2);
+    const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, R2));
     const size_t lds = fused_decode32_lds_bytes(D, a.Ld);
     auto k = decode_fused32_kernel<4, 24, 32>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -1405,7 +1417,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hi
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
     return hipGetLastError();
   }
-  const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr));
+  const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, 16));
   const size_t lds = fused_decode_lds_bytes(D, F, a.Ld);
 #define SLIMT_FUSED_CASE(KSD_, KSF_, DH_)                                                   \
   if (D == 64 * KSD_ && F == 64 * KSF_ && D / H == DH_) {                                    \

@@ -1242,11 +1242,9 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.out_len = d_out_len;
     f.align = d_align;
     f.trace = g_occ_trace;
-    if (rows == 16) {
-      f.ticket = c->ticket.as<unsigned>();
-      f.ticket_base = c->ticket_base;
-      c->ticket_base += (unsigned)fused_decode_grid((int)B, true);
-    }
+    f.ticket = c->ticket.as<unsigned>();
+    f.ticket_base = c->ticket_base;
+    c->ticket_base += (unsigned)fused_decode_grid((int)B, true, rows);
     if (c->stamp_step >= 0 && c->stamps.p) {
       f.stamps = c->stamps.as<unsigned long long>();
       f.stamp_step = c->stamp_step;

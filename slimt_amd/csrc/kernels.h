@@ -259,7 +259,7 @@ struct FusedDecodeArgs {
   unsigned ticket_base = 0;
   OccTrace trace;
 };
-int fused_decode_grid(int B, bool tickets);
+int fused_decode_grid(int B, bool tickets, int rows);
 bool fused_decode_supported(int D, int F, int H, int Ld);
 int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
