@@ -1243,8 +1243,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.align = d_align;
     f.trace = g_occ_trace;
     f.ticket = c->ticket.as<unsigned>();
-    f.ticket_base = c->ticket_base;
-    c->ticket_base += (unsigned)fused_decode_grid((int)B, true, rows);
+    f.ticket_base = c->ticket_base;  // advanced below, once the launch is in the stream
+    const unsigned tickets = (unsigned)fused_decode_grid((int)B, true, rows);
     if (c->stamp_step >= 0 && c->stamps.p) {
       f.stamps = c->stamps.as<unsigned long long>();
       f.stamp_step = c->stamp_step;
@@ -1271,12 +1271,14 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
         ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);
         HIPCHK(launch_decode_fused(f, m->D, m->F, m->H, st));
       }
+      c->ticket_base += tickets;
       HIPCHK(hipEventRecord(gm->gate_ev[gm->gate_seq % kRing], st));
       gm->gate_seq += 1;
       return 0;
     }
     ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);
     HIPCHK(launch_decode_fused(f, m->D, m->F, m->H, st));
+    c->ticket_base += tickets;
     return 0;
   }
   const int n_parts = dgemm_col_blocks(out.w.K, out.w.N, (int)B);

@@ -304,3 +304,37 @@ def test_decode_invariants_long_sentences(hip, engines, B, S):
     out_s, ln_s, _ = ctx.translate(ids[:8], lens[:8], sl)
     assert np.array_equal(out_s, out[:8]) and np.array_equal(ln_s, ln[:8])
     ctx.close()
+
+
+@pytest.mark.parametrize("budget", [0, 1, 3, 1000])
+def test_decoder_admission_and_ticket_launches_keep_results(hip, oracle, engines, budget):
+    """Concurrent contexts of one model under every decoder budget (0 = no limit, 1 = one
+    decoder at a time, 3 = a launch of 2 workgroups after one of 2): the over-subscribed
+    ticket launches and the admission gate only decide where and when a tile runs."""
+    import threading
+    from slimt_amd import synth
+    m, gm, om = engines("tiny11", 6.0)
+    B, S, W = 27, 14, 3  # 2 tiles per batch, the second partly filled
+    sl = synth.make_shortlist(m.V, 1024)
+    jobs = [synth.make_batch(m.V, B, S, seed=7100 + i, ragged=True) for i in range(6)]
+    oracle.set_mode(oracle.PORTABLE)
+    want = [om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3] for ids, lens in jobs]
+    oracle.set_mode(oracle.FAITHFUL)
+    gm.set_decoder_budget(budget)
+    ctxs = [hip.Context(gm, B, S) for _ in range(W)]
+    bad = []
+
+    def work(w):
+        for rep in range(2):
+            for i in range(w, len(jobs), W):
+                got = ctxs[w].translate(jobs[i][0], jobs[i][1], sl, want_align=True)
+                if not all(np.array_equal(a, b) for a, b in zip(got, want[i])):
+                    bad.append((w, rep, i))
+
+    ts = [threading.Thread(target=work, args=(w,)) for w in range(W)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for c in ctxs:
+        c.close()
+    gm.set_decoder_budget(192)
+    assert not bad, bad
