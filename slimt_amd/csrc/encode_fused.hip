@@ -58,6 +58,23 @@ __device__ __forceinline__ void load_frags(v4i (&bf)[KS], const PreparedWeight &
         v4i, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, (tile * KST + ks0 + ks) * 1024, 0));
 }
 
+// k-steps [ks0, ks0 + KS) of ONE column tile, through a descriptor that ends with the
+// tile: a prefetch past the last k-step returns zeros without touching memory (through
+// the whole-matrix descriptor of load_frags it would fetch the next tile's fragments --
+// 128 KB of useless traffic per layer at the end of the FFN loop, queued ahead of the
+// LayerNorm's loads in the in-order return path).
+template <int KS>
+__device__ __forceinline__ void load_frags_k(v4i (&bf)[KS], const PreparedWeight &w, int tile, int ks0,
+                                             int lane) {
+  const int KST = w.K >> 6;
+  const rsrc_t r = make_rsrc(reinterpret_cast<const char *>(w.Wp) + (size_t)tile * KST * 1024,
+                             (unsigned)KST * 1024u);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    bf[ks] = __builtin_bit_cast(
+        v4i, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, (ks0 + ks) * 1024, 0));
+}
+
 // epilogue constants of column tile `tile` for this lane's column (lane & 15)
 __device__ __forceinline__ void load_epi(const PreparedWeight &w, int tile, int lr, int &cs, float &pb) {
   const rsrc_t rc = make_rsrc(w.colsum, (unsigned)w.n_tiles * 64u);
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         load_frags<KSD>(b1[buf], L.ffn1, fc * 16 + wave, 0, lane);
         load_epi(L.ffn1, fc * 16 + wave, lr, cs1[buf], pb1[buf]);
       };
-      auto load_b2 = [&](int buf, int fc) { load_frags<4>(b2[buf], L.ffn2, wave, fc * 4, lane); };
+      auto load_b2 = [&](int buf, int fc) { load_frags_k<4>(b2[buf], L.ffn2, wave, fc * 4, lane); };
       // FFN1 of one chunk: this wave's column tile -> relu -> requantise -> hidden buffer
       auto ffn1_chunk = [&](int buf, char *Hbuf) {
         v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
