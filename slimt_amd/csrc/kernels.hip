@@ -170,7 +170,8 @@ __device__ __forceinline__ void gemm_rows_body(const GemmKArgs &ka, int bx, int 
   constexpr int R = 16 * RM;
   constexpr int BN = 64 * NT;  // columns per block
   char *A_lds = smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform in the compiler's eyes
   const int lr = lane & 15, lg = lane >> 4;
   const int m0 = row0 + bx * R;
   const int nt0 = (by * 4 + wave) * NT;  // first 16-col tile of this wave
@@ -189,16 +190,19 @@ __device__ __forceinline__ void gemm_rows_body(const GemmKArgs &ka, int bx, int 
   // fetch overlaps the staging + barrier instead of stalling every k-step.
   constexpr int KSC = KCH / 64;
   v4i bf[KSC][NT];
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<v4i *>(Wp), 0, (unsigned)n_tiles * KS * 1024u, 0x00020000);
   auto load_chunk = [&](int k0) {
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) {
       const int kstep = (k0 >> 6) + ks;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+        // buffer load: descriptor and fragment offset are scalar, the only vector operand
+        // is lane * 16 (no 64-bit per-lane addresses); past the matrix it returns zeros
         const int ntile = nt0 + nt;
-        v4i t = {0, 0, 0, 0};
-        if (ntile < n_tiles && kstep < KS) t = Wp[((size_t)ntile * KS + kstep) * 64 + lane];
-        bf[ks][nt] = t;
+        const int frag = (ntile < n_tiles && kstep < KS) ? ntile * KS + kstep : n_tiles * KS;
+        bf[ks][nt] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, frag * 1024, 0));
       }
     }
   };
@@ -215,7 +219,7 @@ __device__ __forceinline__ void gemm_rows_body(const GemmKArgs &ka, int bx, int 
     if (k0) __syncthreads();
     if (whole_chunks) {
       if (a.x_f32) {
-        constexpr int G = (NT >= 8 || 4 * RM < 8) ? 4 : 8;  // loads in flight per thread (registers)
+        constexpr int G = (NT >= 8 || RM <= 2) ? 4 : 8;  // loads in flight per thread (registers -> blocks per CU)
 #pragma unroll
         for (int g = 0; g < 4 * RM / G; ++g) {
           float4 fa[G];
