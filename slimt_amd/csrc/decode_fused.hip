@@ -771,7 +771,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       // next layer's input; after the last layer: quantised for the logits
       ln_row<KSD>(pre + wave * LDF, L.ffn_ln_s, L.ffn_ln_b, a.eps, xs + wave * LDF,
                   (l + 1 == Ld) ? A1 + wave * LDA : nullptr, a.out.a_quant, lane);
-      __syncthreads();
+      // Between layers no barrier: the next phase (the SSRU's quantisation) reads and writes
+      // only this wave's own row; the barrier after it covers both.
+      if (l + 1 == Ld) __syncthreads();
       SLIMT_STAMP(sb + 9);
     }
     // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         xs[wave * LDF + lane + 64 * i] = v;
       }
     }
-    __syncthreads();
+    // no barrier: the next step starts with this wave quantising its own row
     SLIMT_STAMP(42);
     if (a.stamps && m0 == 0 && tid == 0 && t == a.stamp_step) a.stamps[61] = clock64();
   }
