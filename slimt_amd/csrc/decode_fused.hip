@@ -633,6 +633,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     outw.n_tiles = (outw.N + 15) / 16;
   }
   const int max_steps = a.max_steps;
+  bool all_done = false;
   for (int t = 0; t < max_steps; ++t) {
     SLIMT_STAMP(0);
     if (a.stamps && m0 == 0 && tid == 0 && t == a.stamp_step) a.stamps[60] = clock64();
@@ -650,6 +651,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         A2[wave * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
       }
       __syncthreads();
+      // every sentence of this tile has emitted EOS (counted in the previous step's sampling
+      // phase; checked here, behind the first barrier that follows it anyway)
+      if (l == 0 && flags[0] >= valid_rows) {
+        all_done = true;
+        break;
+      }
       SLIMT_STAMP(sb + 0);
       for (int tile = wave; tile < D / 16; tile += NW) {
         const rsrc_t rf = make_rsrc(L.rnn_f.Wp, (D / 16) * KSD * 1024u);
@@ -776,6 +783,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       if (l + 1 == Ld) __syncthreads();
       SLIMT_STAMP(sb + 9);
     }
+    if (all_done) break;
     // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
     SLIMT_PHASE_LANE;
     float bv[4];
@@ -825,8 +833,6 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         if (lane == 0) atomicAdd(&flags[0], 1);
       }
     }
-    __syncthreads();
-    if (flags[0] >= valid_rows) break;  // every sentence of this tile has emitted EOS
     if (t + 1 < max_steps) {
       // next target embedding (Transformer.cc:146-160): position is always 0
 #pragma unroll
