@@ -180,14 +180,20 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   load_frags<KSD>(bk, a.L[0].k, wave, 0, lane);
   load_frags<KSD>(bv, a.L[0].v, wave, 0, lane);
   // the three int8 A operands of a layer's Q/K/V projections from row r of xs
+  // (lane = 4 consecutive columns: one 16-byte read and three 4-byte writes per row
+  // instead of 4 + 12 single-element LDS operations; the row was written by this wave)
+  static_assert(KSD == 4, "one float4 per lane covers the row");
   auto quantise_row = [&](int r, const FusedEncLayerW &L) {
-#pragma unroll
-    for (int i = 0; i < KSD; ++i) {
-      const float v = xs[r * LDX + lane + 64 * i];
-      Aq[r * LDA + lane + 64 * i] = (char)quantize1(v, L.q.a_quant);
-      Ak[r * LDA + lane + 64 * i] = (char)quantize1(v, L.k.a_quant);
-      Av[r * LDA + lane + 64 * i] = (char)quantize1(v, L.v.a_quant);
-    }
+    const float4 v = *reinterpret_cast<const float4 *>(xs + r * LDX + 4 * lane);
+    *reinterpret_cast<int *>(Aq + r * LDA + 4 * lane) =
+        pack4(quantize1(v.x, L.q.a_quant), quantize1(v.y, L.q.a_quant), quantize1(v.z, L.q.a_quant),
+              quantize1(v.w, L.q.a_quant));
+    *reinterpret_cast<int *>(Ak + r * LDA + 4 * lane) =
+        pack4(quantize1(v.x, L.k.a_quant), quantize1(v.y, L.k.a_quant), quantize1(v.z, L.k.a_quant),
+              quantize1(v.w, L.k.a_quant));
+    *reinterpret_cast<int *>(Av + r * LDA + 4 * lane) =
+        pack4(quantize1(v.x, L.v.a_quant), quantize1(v.y, L.v.a_quant), quantize1(v.z, L.v.a_quant),
+              quantize1(v.w, L.v.a_quant));
   };
 
   // ---- side job: the batch's shortlisted output layer (used by the decoder
@@ -383,9 +389,10 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     load_ln<KSD>(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);
     for (int r = wave; r < ER; r += ENW) {
       eln_row<KSD>(xs + r * LDX, lsc, lbi, a.eps, lane);
-#pragma unroll
-      for (int i = 0; i < KSD; ++i)
-        Aq[r * LDA + lane + 64 * i] = (char)quantize1(xs[r * LDX + lane + 64 * i], L.ffn1.a_quant);
+      const float4 v = *reinterpret_cast<const float4 *>(xs + r * LDX + 4 * lane);
+      *reinterpret_cast<int *>(Aq + r * LDA + 4 * lane) =
+          pack4(quantize1(v.x, L.ffn1.a_quant), quantize1(v.y, L.ffn1.a_quant),
+                quantize1(v.z, L.ffn1.a_quant), quantize1(v.w, L.ffn1.a_quant));
     }
     __syncthreads();
     SLIMT_ESTAMP(5);
