@@ -131,7 +131,7 @@ __device__ __forceinline__ void eln_row(float *x, const float (&scale)[DPL], con
 // Diagnostic phase stamps (100 MHz wall clock) of workgroup 0 in one layer.
 #define SLIMT_ESTAMP(id)                                                              \
   do {                                                                                \
-    if (a.stamps && blockIdx.x == 0 && tid == 0 && l == a.stamp_layer)                \
+    if (a.stamps && s0 == 0 && tid == 0 && l == a.stamp_layer)                        \
       a.stamps[(id)] = wall_clock64();                                                \
   } while (0)
 
@@ -157,7 +157,20 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   SLIMT_PHASE_LANE;
   const int S = a.S, B = a.B;
   const int spw = ER / S;              // whole sentences per workgroup
-  const int s0 = blockIdx.x * spw;     // first sentence
+  // Over-subscribed launch (as in decode_fused.hip): the grid holds more workgroups than
+  // tiles, the first to START claim the tiles, the rest leave. The tail of an encoder
+  // launch then goes to whichever CUs free up first instead of waiting for CUs of the
+  // shader engines its last workgroups were bound to at dispatch.
+  __shared__ int claimed;
+  const int n_tiles = (B + spw - 1) / spw;
+  int tile = blockIdx.x;
+  if (a.ticket) {
+    if (tid == 0) claimed = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
+    __syncthreads();
+    tile = claimed;
+    if ((unsigned)tile >= (unsigned)n_tiles) return;
+  }
+  const int s0 = tile * spw;           // first sentence
   const int rows_used = spw * S;
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
 
@@ -198,8 +211,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
 
   // ---- side job: the batch's shortlisted output layer (used by the decoder
   // launch that follows this one in the stream; independent of the encoder) ----
-  for (int tile = blockIdx.x; tile < a.pack_tiles; tile += gridDim.x)
-    pack_weight_tile(a.pack, tile, tid, 1024);
+  for (int pt = tile; pt < a.pack_tiles; pt += n_tiles) pack_weight_tile(a.pack, pt, tid, 1024);
 
   // ---- embedding (Model.cc:195-197) ----------------------------------------
   for (int r = wave; r < ER; r += ENW) {
@@ -991,6 +1003,16 @@ hipError_t launch_encode_long(const LongEncodeArgs &a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// workgroups launched: with tickets a quarter more than tiles (at least 32 more: one
+// candidate per shader engine and XCD), rounded up to a multiple of 32
+int fused_encode_grid(int B, int S, bool tickets) {
+  const int spw = ER / S;
+  const int tiles = (B + spw - 1) / spw;
+  if (!tickets) return tiles;
+  const int extra = tiles / 4 > 32 ? tiles / 4 : 32;
+  return (tiles + extra + 31) / 32 * 32;
+}
+
 size_t fused_encode_lds_bytes(int D) {
   return (size_t)ER * (D + 4) * 4 + 3 * (size_t)ER * (D + 16) + (size_t)ER * (D + 4) * 4 +
          2 * (size_t)ER * (D + 1) * 4;
@@ -1004,8 +1026,7 @@ bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
 
 hipError_t launch_encode_fused(const FusedEncodeArgs &a, int D, int F, int H, hipStream_t st) {
   if (!fused_encode_supported(D, F, H, a.Le, a.Ld, a.S)) return hipErrorInvalidValue;
-  const int spw = ER / a.S;
-  const dim3 grid((a.B + spw - 1) / spw);
+  const dim3 grid(fused_encode_grid(a.B, a.S, a.ticket != nullptr));
   const size_t lds = fused_encode_lds_bytes(D);
   hipError_t e = hipSuccess;
 #define SLIMT_ENC_CASE(KSF_)                                                                   \

@@ -613,8 +613,8 @@ int ctx_alloc(slimt_hip_ctx *c) {
   HIPCHK(c->att.reserve(M * D * 4));
   HIPCHK(c->h8.reserve(M * F));
   HIPCHK(c->a8.reserve(M * D));
-  HIPCHK(c->ticket.reserve(4));
-  HIPCHK(hipMemset(c->ticket.p, 0, 4));
+  HIPCHK(c->ticket.reserve(8));  // [0] decoder, [1] fused encoder
+  HIPCHK(hipMemset(c->ticket.p, 0, 8));
   HIPCHK(c->kv.reserve((size_t)m->Ld * 2 * M * D * 4));
   HIPCHK(c->dx.reserve(B * D * 4));
   HIPCHK(c->dx_pre.reserve(B * D * 4));
@@ -895,11 +895,14 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.stamps = c->stamps.as<unsigned long long>() + 48;
       f.stamp_layer = c->stamp_step < m->Le ? c->stamp_step : m->Le - 1;
     }
+    f.ticket = c->ticket.as<unsigned>() + 1;  // over-subscribed launch, tiles claimed by ticket
+    f.ticket_base = c->enc_ticket_base;
     {
       const double macs = (double)M * (m->Le * (4.0 * D * D + 2.0 * D * m->F) + m->Ld * 2.0 * D * D);
       ProfScope p(c, SLIMT_HIP_K_ENCODE_FUSED, macs, 0);
       HIPCHK(launch_encode_fused(f, m->D, m->F, m->H, st));
     }
+    c->enc_ticket_base += (unsigned)fused_encode_grid(B, S, true);
     if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, c->dbg_embed.p, nbytes, hipMemcpyDeviceToHost, st));
     if (h_layers)
       HIPCHK(hipMemcpyAsync(h_layers, c->dbg_layers.p, nbytes * (size_t)m->Le, hipMemcpyDeviceToHost, st));

@@ -97,6 +97,7 @@ struct slimt_hip_ctx {
   slimt_hip::DevBuf x0, x1, q, k, v, att, h8, a8;
   slimt_hip::DevBuf ticket;      // ticket counter of the over-subscribed decoder launches
   unsigned ticket_base = 0;      // tickets handed out by earlier launches
+  unsigned enc_ticket_base = 0;  // the same for the fused encoder (second counter of `ticket`)
   slimt_hip::DevBuf kv;  // [Ld][2][B*S][D]
   // decoder workspace
   slimt_hip::DevBuf dx, dx_pre, dh, datt8, dout, df8, state;

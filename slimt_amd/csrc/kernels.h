@@ -260,6 +260,7 @@ struct FusedDecodeArgs {
   OccTrace trace;
 };
 int fused_decode_grid(int B, bool tickets, int rows);
+int fused_encode_grid(int B, int S, bool tickets);
 bool fused_decode_supported(int D, int F, int H, int Ld);
 int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
@@ -282,6 +283,8 @@ struct FusedEncodeArgs {
   float *kv = nullptr;         // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]
   PackArgs pack;               // the batch's shortlisted output layer, packed by the
   int pack_tiles = 0;          // encoder's workgroups on the side (0 = nothing to pack)
+  unsigned *ticket = nullptr;  // nullable: over-subscribed launch (see FusedDecodeArgs)
+  unsigned ticket_base = 0;
   OccTrace trace;
   float *enc_out = nullptr;    // nullable [B*S][D]
   float *layer_out = nullptr;  // nullable [Le][B*S][D]
