@@ -229,13 +229,13 @@ struct AttnRow {
 // registers no longer collide with the GEMM phases', and a call would save and
 // restore 48 callee-saved VGPRs through scratch every layer and step.
 // The K/V cache is streamed once per step by exactly one workgroup; weights are
-// shared by every workgroup. SLIMT_KV_NT marks the cache loads non-temporal so
-// that they do not displace the weights from the XCD's L2.
-#ifdef SLIMT_KV_NT
-#define KV_AUX 2
-#else
-#define KV_AUX 0
-#endif
+// shared by every workgroup. KV_AUX (a template parameter of the attention code: the
+// cache-policy immediate of its buffer loads) = 2 marks the cache loads non-temporal.
+// Which is better depends on the load: while the K/V of all decoders in flight fits
+// the 256 MB Infinity Cache, every step re-reads it from there and non-temporal loads
+// only lose that (1 / 4 / 8 workers: -8 / -12 / -8 %); beyond it they stop the streams
+// from displacing the weights (20 workers: +3 %, 64-token sentences +7 %). The engine
+// picks the variant per launch (translate_device).
 
 // Cross-attention of one sentence for 32 < S <= 128 (d_head 32). Out of line:
 // it is register-hungry (two groups of K or V in flight) and rare enough that
@@ -250,7 +250,7 @@ __device__ __forceinline__ const float *uniform_ptr(const float *p) {
   return reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
 }
 
-template <int D, int DH>
+template <int D, int DH, int KV_AUX>
 __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
   constexpr int H = D / DH;
   const int S = __builtin_amdgcn_readfirstlane(r.S), len = __builtin_amdgcn_readfirstlane(r.len);
@@ -353,7 +353,7 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
 // LONG: compile the 32 < S <= 128 path in (a call to attention_row_long). The
 // S <= 32 instantiation of the kernel leaves it out: the mere call site cost
 // the flagship path ~4 us per step (scratch frame, register allocation).
-template <int D, int DH, bool LONG>
+template <int D, int DH, bool LONG, int KV_AUX = 0>
 __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   constexpr int H = D / DH;
   const int S = r.S, len = r.len;
@@ -426,7 +426,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       r.arow[2 * hp * DH + lane] = (char)quantize1(o, r.aq_o);
     }
   } else if (LONG && DH == 32 && S <= 128) {
-    attention_row_long<D, DH>(r, lane);
+    attention_row_long<D, DH, KV_AUX>(r, lane);
   } else if (DH == 64 && S <= 32) {
     // d_head 64 ("base"): one head per pass. Scores: lane = key (both wave
     // halves hold the same 32 keys, so the 32-lane reductions serve both);
@@ -550,7 +550,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   (void)lr;                                              \
   (void)lg
 
-template <int KSD, int KSF, int DH, bool LONG>
+template <int KSD, int KSF, int DH, bool LONG, bool NT>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 64 * KSD, F = 64 * KSF;
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
         const bool want_align = a.align && (l + 1 == Ld) && !finished && ((int)n_out < a.Tmax);
         ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + n_out) * S) : (gf_ptr) nullptr;
-        attention_row<D, DH, LONG>(ar, lane);
+        attention_row<D, DH, LONG, NT ? 2 : 0>(ar, lane);
       } else {
 #pragma unroll
         for (int i = 0; i < KSD; ++i) A1[wave * LDA + lane + 64 * i] = 0;
@@ -1403,14 +1403,17 @@ bool fused_decode_supported(int D, int F, int H, int Ld) {
   return shape && fused_decode_lds_bytes(D, F, Ld) <= 160 * 1024;
 }
 
-// the long-sentence instantiation exists for d_head 32 only (attention_row_long)
+// the long-sentence instantiation exists for d_head 32 only (attention_row_long), the
+// non-temporal K/V variant for the tiny11 shape only
 template <int KSD, int KSF, int DH>
-static auto decode_fused_pick(bool long_sentences) -> void (*)(FusedDecodeArgs) {
+static auto decode_fused_pick(bool long_sentences, bool nt) -> void (*)(FusedDecodeArgs) {
   if constexpr (DH == 32) {
-    if (long_sentences) return decode_fused_kernel<KSD, KSF, DH, true>;
+    if (long_sentences) return nt ? decode_fused_kernel<KSD, KSF, DH, true, true> : decode_fused_kernel<KSD, KSF, DH, true, false>;
+    if (nt) return decode_fused_kernel<KSD, KSF, DH, false, true>;
   }
   (void)long_sentences;
-  return decode_fused_kernel<KSD, KSF, DH, false>;
+  (void)nt;
+  return decode_fused_kernel<KSD, KSF, DH, false, false>;
 }
 
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st) {
@@ -1429,7 +1432,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hi
   const size_t lds = fused_decode_lds_bytes(D, F, a.Ld);
 #define SLIMT_FUSED_CASE(KSD_, KSF_, DH_)                                                   \
   if (D == 64 * KSD_ && F == 64 * KSF_ && D / H == DH_) {                                    \
-    auto k = decode_fused_pick<KSD_, KSF_, DH_>(a.S > 32);                                   \
+    auto k = decode_fused_pick<KSD_, KSF_, DH_>(a.S > 32, a.kv_nt);                           \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                           \

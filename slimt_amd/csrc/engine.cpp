@@ -709,6 +709,12 @@ extern "C" int slimt_hip_ctx_destroy(slimt_hip_ctx *ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->model->device);
   (void)hipStreamSynchronize(ctx->stream);
+  {
+    std::lock_guard<std::mutex> lock(ctx->model->gate_mu);
+    auto &v = ctx->model->gate_ctx;
+    for (size_t i = 0; i < v.size();)
+      if (v[i].ctx == ctx) v.erase(v.begin() + (long)i); else ++i;
+  }
   ctx_free(ctx);
   delete ctx;
   return 0;
@@ -1269,6 +1275,29 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       }
       size_t n = (size_t)std::max(1, gm->decoder_budget / wgs);
       if (n > kRing) n = kRing;
+      // K/V cache policy (decode_fused.hip, KV_AUX). Contexts are streams, so at most one
+      // decoder per context runs at a time; those with a decoder still pending hold
+      // `pending` bytes of K/V between them. About 60 % of them decode at any moment (the
+      // others encode or wait for admission), and the caches that are being read should fit
+      // the 256 MB Infinity Cache: measured crossover (B=256, S=32: 33.5 MB per context)
+      // between 10 and 14 contexts = 400 MB; 20 contexts of B=64 (168 MB) lose 13 % with
+      // non-temporal loads, 20 of B=256 gain 3 %, 64-token sentences 7 %.
+      const double kv_bytes = (double)m->Ld * 2.0 * (double)B * (double)S * m->D * 4.0;
+      double pending = kv_bytes;
+      bool known = false;
+      for (auto &g : gm->gate_ctx) {
+        if (g.ctx == c) {
+          g.seq = gm->gate_seq;
+          g.kv_bytes = kv_bytes;
+          known = true;
+        } else if (gm->gate_seq - g.seq < kRing &&
+                   hipEventQuery(gm->gate_ev[g.seq % kRing]) == hipErrorNotReady) {
+          pending += g.kv_bytes;
+        }
+      }
+      (void)hipGetLastError();  // hipErrorNotReady is not an error here
+      if (!known) gm->gate_ctx.push_back({c, gm->gate_seq, kv_bytes});
+      f.kv_nt = pending > 400.0e6;
       if (gm->gate_seq >= n) HIPCHK(hipStreamWaitEvent(st, gm->gate_ev[(gm->gate_seq - n) % kRing], 0));
       {
         ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);

@@ -54,6 +54,8 @@ struct DecLayerW {
 
 }  // namespace slimt_hip
 
+struct slimt_hip_ctx;
+
 struct slimt_hip_model {
   int device = 0;
   int D = 0, F = 0, H = 0, V = 0, Le = 0, Ld = 0;
@@ -73,6 +75,14 @@ struct slimt_hip_model {
   std::vector<hipEvent_t> gate_ev;  // ring, created on first use
   size_t gate_seq = 0;
   int decoder_budget = 0;
+  // per context: its latest admitted decoder launch and that batch's K/V bytes (choice of
+  // the K/V cache policy: how much K/V do the contexts with a pending decoder hold together)
+  struct GateCtx {
+    const slimt_hip_ctx *ctx;
+    size_t seq;
+    double kv_bytes;
+  };
+  std::vector<GateCtx> gate_ctx;
 };
 
 struct slimt_hip_ctx {

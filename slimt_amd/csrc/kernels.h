@@ -257,6 +257,7 @@ struct FusedDecodeArgs {
   // of every launch takes one ticket; ticket - ticket_base is the tile it runs (or none).
   unsigned *ticket = nullptr;
   unsigned ticket_base = 0;
+  bool kv_nt = false;  // non-temporal K/V cache loads (d_head 32 shapes; see decode_fused.hip)
   OccTrace trace;
 };
 int fused_decode_grid(int B, bool tickets, int rows);
