@@ -1404,11 +1404,13 @@ bool fused_decode_supported(int D, int F, int H, int Ld) {
 }
 
 // the long-sentence instantiation exists for d_head 32 only (attention_row_long), the
-// non-temporal K/V variant for the tiny11 shape only
+// non-temporal K/V variant for d_head 32 and 64 (the buffer-load paths of attention_row)
 template <int KSD, int KSF, int DH>
 static auto decode_fused_pick(bool long_sentences, bool nt) -> void (*)(FusedDecodeArgs) {
   if constexpr (DH == 32) {
     if (long_sentences) return nt ? decode_fused_kernel<KSD, KSF, DH, true, true> : decode_fused_kernel<KSD, KSF, DH, true, false>;
+  }
+  if constexpr (DH >= 32) {
     if (nt) return decode_fused_kernel<KSD, KSF, DH, false, true>;
   }
   (void)long_sentences;
