@@ -122,6 +122,12 @@ int slimt_hip_model_destroy(slimt_hip_model *model);
  * the encoders of the batches behind them. Default: 3/4 of the device's CUs;
  * 0 = no limit. Results do not depend on it. */
 int slimt_hip_model_set_decoder_budget(slimt_hip_model *model, int workgroups);
+/* Cache policy of the persistent decoder's K/V cache loads: 0 (default) = chosen
+ * per launch (non-temporal once the K/V of the contexts with a pending decoder
+ * exceeds what the Infinity Cache can serve), 1 = always
+ * temporal, 2 = always non-temporal. Results do not depend on it. Needs the
+ * decoder admission (budget > 0) for 0 and 2. */
+int slimt_hip_model_set_kv_cache_policy(slimt_hip_model *model, int policy);
 int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
                          int32_t *dim_ffn, int32_t *vocab, int32_t *heads);
 

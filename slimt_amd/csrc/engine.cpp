@@ -546,6 +546,14 @@ extern "C" int slimt_hip_model_set_decoder_budget(slimt_hip_model *model, int wo
   return 0;
 }
 
+extern "C" int slimt_hip_model_set_kv_cache_policy(slimt_hip_model *model, int policy) {
+  if (!model) return fail(-1, "model is NULL");
+  if (policy < 0 || policy > 2) return fail(-1, "K/V cache policy %d not in 0..2", policy);
+  std::lock_guard<std::mutex> lock(model->gate_mu);
+  model->kv_policy = policy;
+  return 0;
+}
+
 extern "C" int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
                                     int32_t *dim_ffn, int32_t *vocab, int32_t *heads) {
   if (!model) return fail(-1, "model is NULL");
@@ -1297,7 +1305,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       }
       (void)hipGetLastError();  // hipErrorNotReady is not an error here
       if (!known) gm->gate_ctx.push_back({c, gm->gate_seq, kv_bytes});
-      f.kv_nt = pending > 400.0e6;
+      f.kv_nt = gm->kv_policy == 0 ? pending > 400.0e6 : gm->kv_policy == 2;
       if (gm->gate_seq >= n) HIPCHK(hipStreamWaitEvent(st, gm->gate_ev[(gm->gate_seq - n) % kRing], 0));
       {
         ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);

@@ -83,6 +83,7 @@ struct slimt_hip_model {
     double kv_bytes;
   };
   std::vector<GateCtx> gate_ctx;
+  int kv_policy = 0;  // 0 = chosen per launch, 1 = always temporal, 2 = always non-temporal K/V loads
 };
 
 struct slimt_hip_ctx {

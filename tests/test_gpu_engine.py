@@ -306,6 +306,29 @@ def test_decode_invariants_long_sentences(hip, engines, B, S):
     ctx.close()
 
 
+@pytest.mark.parametrize("preset,B,S", [("tiny11", 27, 14), ("tiny11", 5, 40), ("base", 19, 16)])
+def test_kv_cache_policy_keeps_results(hip, oracle, engines, preset, B, S):
+    """The non-temporal K/V variants of the persistent decoder (d_head 32 short and long
+    sentences, d_head 64) are separate kernel instantiations that small tests would never
+    reach through the per-launch choice: force each policy."""
+    from slimt_amd import synth
+    m, gm, om = engines(preset, 6.0)
+    sl = synth.make_shortlist(m.V, 512)
+    ids, lens = synth.make_batch(m.V, B, S, seed=7300 + B, ragged=True)
+    oracle.set_mode(oracle.PORTABLE)
+    want = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+    oracle.set_mode(oracle.FAITHFUL)
+    ctx = hip.Context(gm, B, S)
+    try:
+        for policy in (2, 1, 0):
+            gm.set_kv_cache_policy(policy)
+            got = ctx.translate(ids, lens, sl, want_align=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), policy
+    finally:
+        gm.set_kv_cache_policy(0)
+        ctx.close()
+
+
 @pytest.mark.parametrize("budget", [0, 1, 3, 1000])
 def test_decoder_admission_and_ticket_launches_keep_results(hip, oracle, engines, budget):
     """Concurrent contexts of one model under every decoder budget (0 = no limit, 1 = one
