@@ -1,0 +1,54 @@
+"""GPU box: per-phase time of one decoder workgroup (tile 0 of context 0, one step) WHILE
+the other workers run the bench load -- which phases do the neighbours stretch?
+usage: python tools/decode_phases_loaded.py [workers=20]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+import numpy as np
+import torch
+from slimt_amd import capi, synth
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B, S, n_sl = 256, 32, 4096
+dev = torch.device("cuda", 0)
+m = synth.make_model("tiny11", seed=1234, eos_bias=-100.0)
+gm = capi.Model(m)
+ctxs = [capi.Context(gm, B, S) for _ in range(W)]
+T = int(np.float32(1.5) * np.float32(S))
+to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+ids, lens = (to_dev(x) for x in synth.make_batch(m.V, B, S))
+d_sl = to_dev(synth.make_shortlist(m.V, n_sl))
+outs = [torch.zeros((B, T), dtype=torch.int32, device=dev) for _ in range(W)]
+olen = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(W)]
+
+
+def step(i):
+    w = i % W
+    ctxs[w].translate_device(ids.data_ptr(), lens.data_ptr(), B, S, d_sl.data_ptr(), n_sl, 1.5, 0,
+                             outs[w].data_ptr(), olen[w].data_ptr(), 0, steps_hint=T)
+
+
+names = ["step_start"]
+for l in range(2):
+    names += [f"L{l}.ssru_quant", f"L{l}.ssru_gemm", f"L{l}.ln_h", f"L{l}.q_gemm", f"L{l}.attention",
+              f"L{l}.o_gemm", f"L{l}.ln_o", f"L{l}.ffn1", f"L{l}.ffn2", f"L{l}.ln_x"]
+idx = list(range(21)) + [41, 42]
+names += ["logits+argmax", "sample/record/embed"]
+for i in range(4 * W):
+    step(i)
+torch.cuda.synchronize()
+acc = np.zeros(len(idx) - 1)
+n = 0
+for rep in range(6):
+    ctxs[0].debug_decode_stamps(10 + 5 * rep)  # arms context 0's next launch (synchronises its stream)
+    for i in range(4 * W):
+        step(i)
+    torch.cuda.synchronize()
+    st = ctxs[0].debug_decode_stamps(-1).astype(np.int64)
+    t = st[idx]
+    if t[-1] > t[0]:
+        acc += np.diff(t) / 100.0
+        n += 1
+print(f"--- {W} workers, B={B}: decoder step under load, mean of {n} samples: total {acc.sum() / n:.1f} us")
+for i in range(len(acc)):
+    print(f"  {names[i + 1]:22s} {acc[i] / n:7.2f} us")
