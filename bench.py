@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--workers", type=int, default=20,
                     help="translate contexts (HIP streams) per GPU, like slimt::Async workers "
                          "(Frontend.cc:212-226): independent batches in flight on one device")
+    ap.add_argument("--ragged", action="store_true",
+                    help="sentence lengths uniform in [S/4, S] instead of all S (not the headline config)")
     ap.add_argument("--decoder-budget", type=int, default=-1,
                     help="decoder workgroups admitted at a time (-1 = library default: 3/4 of the CUs, 0 = no limit)")
     ap.add_argument("--decode-mode", type=int, default=0, help="0 = fused persistent decoder, 1 = step-wise")
@@ -186,7 +188,7 @@ def main():
     n_batches = 4
     batches = []
     for i in range(n_batches):
-        ids, lens = synth.make_batch(model.V, B, S, seed=4321 + 97 * rank + i)
+        ids, lens = synth.make_batch(model.V, B, S, seed=4321 + 97 * rank + i, ragged=args.ragged)
         batches.append((to_dev(ids), to_dev(lens)))
     d_sl = to_dev(sl) if sl is not None else None
     d_outs = [torch.zeros((B, T), dtype=torch.int32, device=dev) for _ in range(W)]

@@ -267,17 +267,18 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
     const int hh = lane >> 5, j = lane & 31;
     const int ng = (S + 31) >> 5;
     const rsrc_t rk = make_rsrc(uniform_ptr((const float *)r.kl), (unsigned)(S * D) * 4u);
-    const rsrc_t rv = make_rsrc(uniform_ptr((const float *)r.vl), (unsigned)(S * D) * 4u);
-    const int koff = ((hh * (DH / 4) * S + j) * 4) * 4;
+    const rsrc_t rv = make_rsrc(uniform_ptr((const float *)r.vl), (unsigned)(len * D) * 4u);  // padding is
+    const int koff = ((hh * (DH / 4) * S + j) * 4) * 4;                                        // not fetched
     const int voff = lane * 4;
 #pragma unroll 1
     for (int hp = 0; hp < H / 2; ++hp) {
       const int h = 2 * hp + hh;
-      auto load_k = [&](f4(&k4)[8], int g) {  // keys 32 g + j; past S: the group is skipped below
+      auto load_k = [&](f4(&k4)[8], int g) {  // keys 32 g + j; masked keys: past the descriptor (zeros, no traffic)
+        const int kg = (32 * g + j) < len ? koff : 0x40000000;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           k4[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
-                                             rk, koff, (((2 * hp * (DH / 4) + i) * S + 32 * g) * 4) * 4, KV_AUX));
+                                             rk, kg, (((2 * hp * (DH / 4) + i) * S + 32 * g) * 4) * 4, KV_AUX));
       };
       float sc[4];
       f4 ka[8], kb[8];
@@ -353,6 +354,8 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
 // LONG: compile the 32 < S <= 128 path in (a call to attention_row_long). The
 // S <= 32 instantiation of the kernel leaves it out: the mere call site cost
 // the flagship path ~4 us per step (scratch frame, register allocation).
+constexpr int kPastDescriptor = 0x40000000;  // lane offset no K/V descriptor reaches
+
 template <int D, int DH, bool LONG, int KV_AUX = 0>
 __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   constexpr int H = D / DH;
@@ -371,9 +374,13 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
     float v[32];
     // buffer loads: descriptor and pass offsets are scalar, one VGPR of lane
     // offset each; keys >= S read past the descriptor and return 0 (p is 0 there)
+    // Padding is never fetched: a masked key's probability is exactly 0 whatever its
+    // score (exp_p underflows to 0 eighty-six units below the maximum, the mask is -1e8),
+    // and fma(0, v, o) == o. Keys >= len therefore read past the descriptors (V: it ends
+    // after len rows; K: a lane offset beyond it) and cost no memory traffic.
     const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 4u);
-    const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(S * D) * 4u);
-    const int koff = ((hh * (DH / 4) * S + jc) * 4) * 4;  // [head][dh/4][S][4] floats
+    const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(__builtin_amdgcn_readfirstlane(len) * D) * 4u);
+    const int koff = j < len ? ((hh * (DH / 4) * S + jc) * 4) * 4 : kPastDescriptor;  // [head][dh/4][S][4] floats
     const int voff = lane * 4;                            // (head parity, d = lane & 31)
     auto load_k = [&](int hp) {
 #pragma unroll
@@ -436,8 +443,8 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
     const int jc = j < S ? j : S - 1;
     const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
     const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 4u);
-    const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(S * D) * 4u);
-    const int koff = jc * 16;    // [head][dh/4][S][4] floats
+    const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(__builtin_amdgcn_readfirstlane(len) * D) * 4u);  // padding is not fetched
+    const int koff = j < len ? jc * 16 : kPastDescriptor;  // [head][dh/4][S][4] floats
     const int voff = lane * 4;   // d = lane
 #pragma unroll 1
     for (int h = 0; h < H; ++h) {
