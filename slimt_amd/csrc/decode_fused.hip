@@ -254,6 +254,7 @@ template <int D, int DH, int KV_AUX>
 __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
   constexpr int H = D / DH;
   const int S = __builtin_amdgcn_readfirstlane(r.S), len = __builtin_amdgcn_readfirstlane(r.len);
+  const int lenf = len > 0 ? len : S;  // keys fetched
   const float minus_inf = -99999999.0f;  // Input.cc:56-61
   const float lowest = -3.402823466e+38f;
   {
@@ -267,14 +268,14 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
     const int hh = lane >> 5, j = lane & 31;
     const int ng = (S + 31) >> 5;
     const rsrc_t rk = make_rsrc(uniform_ptr((const float *)r.kl), (unsigned)(S * D) * 4u);
-    const rsrc_t rv = make_rsrc(uniform_ptr((const float *)r.vl), (unsigned)(len * D) * 4u);  // padding is
+    const rsrc_t rv = make_rsrc(uniform_ptr((const float *)r.vl), (unsigned)(lenf * D) * 4u);  // padding is
     const int koff = ((hh * (DH / 4) * S + j) * 4) * 4;                                        // not fetched
     const int voff = lane * 4;
 #pragma unroll 1
     for (int hp = 0; hp < H / 2; ++hp) {
       const int h = 2 * hp + hh;
       auto load_k = [&](f4(&k4)[8], int g) {  // keys 32 g + j; masked keys: past the descriptor (zeros, no traffic)
-        const int kg = (32 * g + j) < len ? koff : 0x40000000;
+        const int kg = (32 * g + j) < lenf ? koff : 0x40000000;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           k4[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -360,6 +361,7 @@ template <int D, int DH, bool LONG, int KV_AUX = 0>
 __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   constexpr int H = D / DH;
   const int S = r.S, len = r.len;
+  const int lenf = len > 0 ? len : S;  // keys fetched (an empty sentence masks everything: uniform weights over real V)
   const float minus_inf = -99999999.0f;  // Input.cc:56-61
   const float lowest = -3.402823466e+38f;
   if (DH == 32 && S <= 32) {
@@ -379,8 +381,8 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
     // and fma(0, v, o) == o. Keys >= len therefore read past the descriptors (V: it ends
     // after len rows; K: a lane offset beyond it) and cost no memory traffic.
     const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 4u);
-    const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(__builtin_amdgcn_readfirstlane(len) * D) * 4u);
-    const int koff = j < len ? ((hh * (DH / 4) * S + jc) * 4) * 4 : kPastDescriptor;  // [head][dh/4][S][4] floats
+    const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(__builtin_amdgcn_readfirstlane(lenf) * D) * 4u);
+    const int koff = j < lenf ? ((hh * (DH / 4) * S + jc) * 4) * 4 : kPastDescriptor;  // [head][dh/4][S][4] floats
     const int voff = lane * 4;                            // (head parity, d = lane & 31)
     auto load_k = [&](int hp) {
 #pragma unroll
@@ -443,8 +445,8 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
     const int jc = j < S ? j : S - 1;
     const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
     const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 4u);
-    const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(__builtin_amdgcn_readfirstlane(len) * D) * 4u);  // padding is not fetched
-    const int koff = j < len ? jc * 16 : kPastDescriptor;  // [head][dh/4][S][4] floats
+    const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(__builtin_amdgcn_readfirstlane(lenf) * D) * 4u);  // padding is not fetched
+    const int koff = j < lenf ? jc * 16 : kPastDescriptor;  // [head][dh/4][S][4] floats
     const int voff = lane * 4;   // d = lane
 #pragma unroll 1
     for (int h = 0; h < H; ++h) {

@@ -361,3 +361,29 @@ def test_decoder_admission_and_ticket_launches_keep_results(hip, oracle, engines
         c.close()
     gm.set_decoder_budget(192)
     assert not bad, bad
+
+
+def test_translate_with_an_empty_sentence(hip, oracle, engines):
+    """Length 0 (nothing but padding): every key is masked, the softmax is uniform over
+    the S padded positions and their real K/V rows -- the one case in which the decoder's
+    padding skip must not skip."""
+    from slimt_amd import synth
+    m, gm, om = engines("tiny11", 6.0)
+    B, S = 18, 12
+    ids, lens = synth.make_batch(m.V, B, S, seed=7400, ragged=True)
+    lens = lens.copy()
+    lens[3] = 0
+    ids = ids.copy()
+    ids[3, :] = 0
+    sl = synth.make_shortlist(m.V, 512)
+    oracle.set_mode(oracle.PORTABLE)
+    want = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+    oracle.set_mode(oracle.FAITHFUL)
+    ctx = hip.Context(gm, B, S)
+    try:
+        for mode in (0, 1):
+            ctx.set_decode_mode(mode)
+            got = ctx.translate(ids, lens, sl, want_align=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), mode
+    finally:
+        ctx.close()
