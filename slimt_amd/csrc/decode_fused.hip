@@ -738,7 +738,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
         const bool want_align = a.align && (l + 1 == Ld) && !finished && ((int)n_out < a.Tmax);
         ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + n_out) * S) : (gf_ptr) nullptr;
-        attention_row<D, DH, LONG, NT ? 2 : 0>(ar, lane);
+        if (NT && l >= a.kv_temporal_layers)
+          attention_row<D, DH, LONG, 2>(ar, lane);
+        else
+          attention_row<D, DH, LONG, 0>(ar, lane);
       } else {
 #pragma unroll
         for (int i = 0; i < KSD; ++i) A1[wave * LDA + lane + 64 * i] = 0;

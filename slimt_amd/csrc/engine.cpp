@@ -1283,15 +1283,20 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       }
       size_t n = (size_t)std::max(1, gm->decoder_budget / wgs);
       if (n > kRing) n = kRing;
-      // K/V cache policy (decode_fused.hip, KV_AUX). Contexts are streams, so at most one
-      // decoder per context runs at a time; those with a decoder still pending hold
-      // `pending` bytes of K/V between them. About 60 % of them decode at any moment (the
-      // others encode or wait for admission), and the caches that are being read should fit
-      // the 256 MB Infinity Cache: measured crossover (B=256, S=32: 33.5 MB per context)
-      // between 10 and 14 contexts = 400 MB; 20 contexts of B=64 (168 MB) lose 13 % with
-      // non-temporal loads, 20 of B=256 gain 3 %, 64-token sentences 7 %.
+      // K/V cache policy (decode_fused.hip, KV_AUX). The caches that are being read at any
+      // moment are those of the decoders that run: at most one per context (a context is a
+      // stream) and at most n by admission. While they fit the 256 MB Infinity Cache every
+      // step re-reads them from there and non-temporal loads only lose that; beyond it the
+      // cache streams from HBM anyway and non-temporal loads keep it from displacing the
+      // weights. In between, the first layers' caches stay temporal (they then fit) and the
+      // rest stream: t_layers = as many of the Ld per-layer caches as 300 MB cover.
+      // Measured (tok/s, t_layers 0 / 1 / 2, Ld = 2): B=256, S=32 at 8 workers 17.1 / - /
+      // 18.8 M, 12: 21.9 / 22.5 / 22.1, 16: 23.6 / 24.2 / 22.6, 20: 23.9 / 24.5 / 23.5;
+      // B=512 full vocabulary 16.7 / 17.1 / 15.8; B=128, S=64 9.0 / 8.5 / 7.9; B=64, S=32
+      // 11.9 / - / 13.6; base 6.4 / 5.9 / 5.7.
       const double kv_bytes = (double)m->Ld * 2.0 * (double)B * (double)S * m->D * 4.0;
       double pending = kv_bytes;
+      size_t contexts = 1;
       bool known = false;
       for (auto &g : gm->gate_ctx) {
         if (g.ctx == c) {
@@ -1301,11 +1306,16 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
         } else if (gm->gate_seq - g.seq < kRing &&
                    hipEventQuery(gm->gate_ev[g.seq % kRing]) == hipErrorNotReady) {
           pending += g.kv_bytes;
+          contexts += 1;
         }
       }
       (void)hipGetLastError();  // hipErrorNotReady is not an error here
       if (!known) gm->gate_ctx.push_back({c, gm->gate_seq, kv_bytes});
-      f.kv_nt = gm->kv_policy == 0 ? pending > 400.0e6 : gm->kv_policy == 2;
+      const double active = pending / (double)contexts * (double)std::min(contexts, n);
+      int t_layers = gm->kv_policy == 1 ? m->Ld : gm->kv_policy == 2 ? 0
+                     : (int)std::min((double)m->Ld, std::floor((double)m->Ld * 300.0e6 / active));
+      f.kv_nt = t_layers < m->Ld;
+      f.kv_temporal_layers = t_layers;
       if (gm->gate_seq >= n) HIPCHK(hipStreamWaitEvent(st, gm->gate_ev[(gm->gate_seq - n) % kRing], 0));
       {
         ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);

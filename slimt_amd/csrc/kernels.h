@@ -257,7 +257,8 @@ struct FusedDecodeArgs {
   // of every launch takes one ticket; ticket - ticket_base is the tile it runs (or none).
   unsigned *ticket = nullptr;
   unsigned ticket_base = 0;
-  bool kv_nt = false;  // non-temporal K/V cache loads (d_head 32 shapes; see decode_fused.hip)
+  bool kv_nt = false;  // non-temporal K/V cache loads (d_head 32 / 64 shapes; see decode_fused.hip)
+  int kv_temporal_layers = 0;  // with kv_nt: the first layers' caches are still read temporally
   OccTrace trace;
 };
 int fused_decode_grid(int B, bool tickets, int rows);
