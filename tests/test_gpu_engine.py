@@ -387,3 +387,46 @@ def test_translate_with_an_empty_sentence(hip, oracle, engines):
             assert all(np.array_equal(a, b) for a, b in zip(got, want)), mode
     finally:
         ctx.close()
+
+
+def test_deep_async_queues_keep_results(hip, oracle, engines):
+    """Many more launches queued than the admission ring holds (64 events), on more contexts
+    than decoders are admitted: every one of the 216 asynchronous translates must still
+    produce the oracle's tokens (tickets, admission waits, K/V policy queries, ring reuse)."""
+    from slimt_amd import synth
+    from test_shortlist import _Hip
+    m, gm, om = engines("tiny11", 6.0)
+    B, S, W, rounds = 40, 12, 18, 12
+    T = int(np.float32(1.5) * np.float32(S))
+    sl = synth.make_shortlist(m.V, 512)
+    jobs = [synth.make_batch(m.V, B, S, seed=7500 + i, ragged=True) for i in range(3)]
+    oracle.set_mode(oracle.PORTABLE)
+    want = [om.translate(ids, lens, sl, 1.5, 0)[:2] for ids, lens in jobs]
+    oracle.set_mode(oracle.FAITHFUL)
+    dev = _Hip()
+    gm.set_decoder_budget(12)  # 3 workgroups per batch: 4 decoders admitted at a time
+    ctxs = [hip.Context(gm, B, S) for _ in range(W)]
+    try:
+        d_in = [(dev.to_dev(ids), dev.to_dev(lens)) for ids, lens in jobs]
+        d_sl = dev.to_dev(sl)
+        outs = []
+        for r in range(rounds):
+            for w in range(W):
+                j = (r + w) % len(jobs)
+                d_out = dev.to_dev(np.full((B, T), 7, np.uint32))
+                d_len = dev.to_dev(np.full(B, 99, np.uint32))
+                ctxs[w].translate_device(d_in[j][0], d_in[j][1], B, S, d_sl, sl.size, 1.5, 0, d_out, d_len,
+                                         0, steps_hint=T)
+                outs.append((j, d_out, d_len))
+        for c in ctxs:
+            c.synchronize()
+        for j, d_out, d_len in outs:
+            ln = dev.from_dev(d_len, (B,), np.uint32)
+            out = dev.from_dev(d_out, (B, T), np.uint32)
+            assert np.array_equal(ln, want[j][1])
+            assert np.array_equal(out, want[j][0][:, :T])
+    finally:
+        for c in ctxs:
+            c.close()
+        gm.set_decoder_budget(192)
+        dev.free()
