@@ -3,11 +3,21 @@
 batch 256 (BASELINE.json), on N MI355X of one node.
 
 A "step" = one pass of the hot path (Model::forward: embed + 6-layer encoder +
-greedy decode loop) over one batch of 256 synthetic sentences, inputs already
-resident in HBM. N > 1: one process per GPU (torchrun), weights replicated,
-each rank translates its own batches, no data-path collective (sentences are
-independent); torch.distributed is used only for the barrier and the
-max-over-ranks of the elapsed time.
+greedy decode loop) over one batch of 256 synthetic sentences ON EVERY WORKER of
+the rank: `workers` independent translate contexts (slimt::Async workers,
+Frontend.cc:212-226) each get one batch per step, so a step is
+workers x 256 sentences and the timed region of the driver's `--steps 20` is 400
+batches (ramp and tail < 2 %). Inputs are resident in HBM before the timed region.
+
+N > 1: one process per GPU, weights replicated, each rank translates its own
+batches, NO data-path collective and no RCCL at all (sentences are independent):
+ranks line up and reduce (MAX time, SUM tokens) over a gloo (TCP) group.
+`python bench.py --gpus N` spawns the N ranks itself (before anything touches
+the GPU); under `torch.distributed.run` the ranks come from the environment.
+
+`--total-sentences 4096` = BASELINE config 5 (strong scaling): a fixed set of
+sentences is cut into batches of `--batch`, the batches are dealt to the ranks
+(slimt_amd.sharding.plan_shards) and a step translates the whole set once.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on
 the stream the kernel runs on, over the timed region) and `cpu_baseline` (the
@@ -17,6 +27,8 @@ import argparse
 import json
 import os
 import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,8 +37,6 @@ import time
 # set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -34,15 +44,18 @@ PEAK_INT8_TOPS = 5000.0  # dense int8 MFMA, 2x the ~2.5 PF bf16 (MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0    # HBM3E spec (MI355X_MICROARCH.md, Chip-level parameters)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=768)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--preset", default="tiny11")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--src-len", type=int, default=32)
     ap.add_argument("--shortlist", type=int, default=4096, help="0 = full vocabulary")
+    ap.add_argument("--total-sentences", type=int, default=0,
+                    help="strong scaling (BASELINE config 5): a fixed set of sentences, cut into batches of "
+                         "--batch and dealt to the ranks; a step translates the whole set once")
     ap.add_argument("--profile-kernel", default="auto",
                     help="kernel family bracketed by HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -53,11 +66,39 @@ def parse():
     ap.add_argument("--ragged", action="store_true",
                     help="sentence lengths uniform in [S/4, S] instead of all S (not the headline config)")
     ap.add_argument("--decoder-budget", type=int, default=-1,
-                    help="decoder workgroups admitted at a time (-1 = library default: 3/4 of the CUs, 0 = no limit)")
+                    help="decoder workgroups admitted at a time (-1 = library default, 0 = no limit)")
     ap.add_argument("--decode-mode", type=int, default=0, help="0 = fused persistent decoder, 1 = step-wise")
+    ap.add_argument("--sustained-steps", type=int, default=40,
+                    help="after the timed region, one longer untimed-by-the-driver region of this many steps "
+                         "(reported as `sustained`; 0 = skip)")
     ap.add_argument("--all-kernels", action="store_true",
                     help="after the timed region, time every kernel family (untimed pass)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N fresh rank processes (this
+    process has not touched the GPU and never will), wait, return the worst exit code.
+    Rank 0's stdout (the JSON line) is this process's stdout."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SLIMT_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
 
 
 def algorithmic_macs_per_sentence(D, F, Le, Ld, S, T, N):
@@ -84,15 +125,17 @@ def pmc_traffic(kernel):
     return 2.0 * out["FETCH_SIZE"][0] + out["WRITE_SIZE"][0], [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]
 
 
-def cpu_baseline(model, S, T, n_sl, n_sent):
-    """The CPU port of the reference's op sequence (per-step K/V recompute and
-    per-call PrepareBias included), FAITHFUL float order, on the host cores --
-    run the way slimt runs on a CPU: one single-threaded worker per core, each
-    translating its own batch (Async, Frontend.cc:207-227). `n_sent` sentences
-    per worker."""
-    import threading
-    from oracle import oracle as O
-    from slimt_amd import synth
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_share():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # the CPU share of the container (cgroup v2 quota), not the host's core count
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -100,20 +143,18 @@ def cpu_baseline(model, S, T, n_sl, n_sent):
             cores = max(1, min(cores, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
-    # half of the share: above that the quota throttles erratically (measured on a
-    # 16-core share: 8 workers 8.9 k tok/s, 10..16 workers 2.9..6.5 k), and the HIP
-    # runtime's own threads are still alive in this process
-    workers = max(1, int(os.environ.get("SLIMT_CPU_WORKERS", str(max(1, cores // 2)))))
-    try:  # keep the port's per-op buffers on the heap: 64 KiB..MiB mmap / munmap pairs per op
-        import ctypes  # would make it a page-fault benchmark
-        libc = ctypes.CDLL("libc.so.6")
-        libc.mallopt(-3, 1 << 30)  # M_MMAP_THRESHOLD
-        libc.mallopt(-1, 1 << 30)  # M_TRIM_THRESHOLD
-    except OSError:
-        pass
+    return cores
+
+
+def cpu_translate(model, S, n_sl, n_sent, workers, reference_cost):
+    """`workers` single-threaded oracle workers, each translating its own batch of
+    `n_sent` sentences (slimt's Async, Frontend.cc:207-227). Returns tokens, seconds, steps."""
+    import threading
+    from oracle import oracle as O
+    from slimt_amd import synth
     O.set_mode(O.FAITHFUL)
     sl = synth.make_shortlist(model.V, n_sl) if n_sl else None
-    oms = [O.OracleModel(model, reference_cost=True, threads=1) for _ in range(workers)]
+    oms = [O.OracleModel(model, reference_cost=reference_cost, threads=1) for _ in range(workers)]
     jobs = [synth.make_batch(model.V, n_sent, S, seed=4321 + w) for w in range(workers)]
     toks = [0] * workers
     steps = [0] * workers
@@ -126,102 +167,187 @@ def cpu_baseline(model, S, T, n_sl, n_sent):
     t0 = time.perf_counter()
     [t.start() for t in ts]
     [t.join() for t in ts]
-    dt = time.perf_counter() - t0
-    total = sum(toks)
-    return {
+    return sum(toks), time.perf_counter() - t0, max(steps)
+
+
+def cpu_baseline(model, S, T, n_sl, n_sent):
+    """The CPU port of the reference's op sequence (per-step K/V recompute and
+    per-call PrepareBias included), FAITHFUL float order, on the host cores --
+    run the way slimt runs on a CPU: one single-threaded worker per core, each
+    translating its own batch (Async, Frontend.cc:207-227). `n_sent` sentences
+    per worker. `variants` adds the single-thread rate and the rate with the
+    cross-attention K/V cached per batch (what this repo's GPU path does;
+    the reference recomputes them every step, Modules.cc:248)."""
+    cores = cpu_share()
+    # half of the share: above that the quota throttles erratically (measured on a
+    # 16-core share: 8 workers 8.9 k tok/s, 10..16 workers 2.9..6.5 k), and the HIP
+    # runtime's own threads are still alive in this process
+    workers = max(1, int(os.environ.get("SLIMT_CPU_WORKERS", str(max(1, cores // 2)))))
+    try:  # keep the port's per-op buffers on the heap: 64 KiB..MiB mmap / munmap pairs per op
+        import ctypes  # would make it a page-fault benchmark
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 1 << 30)  # M_MMAP_THRESHOLD
+        libc.mallopt(-1, 1 << 30)  # M_TRIM_THRESHOLD
+    except OSError:
+        pass
+    total, dt, steps = cpu_translate(model, S, n_sl, n_sent, workers, True)
+    out = {
         "value": total / dt, "unit": "tokens/s", "cores": workers, "kind": "port",
-        "sample": f"{workers} single-threaded workers x {n_sent} sentences x S={S}, {max(steps)} decode "
+        "cpu_model": cpu_model_string(), "cpu_share_cores": cores,
+        "sample": f"{workers} single-threaded workers x {n_sent} sentences x S={S}, {steps} decode "
                   f"steps, {total} tokens in {dt:.2f}s; C port of slimt's intgemm op sequence "
                   "(AVX512-VNNI vpdpbusd when available, per-step K/V recompute + PrepareBias as in "
                   "the reference), one batch per worker like slimt's Async",
     }
+    variants = {}
+    half = max(16, n_sent // 2)
+    tk, d1, _ = cpu_translate(model, S, n_sl, half, 1, True)
+    variants["as_reference_1_thread"] = {"value": tk / d1, "cores": 1,
+                                         "sample": f"1 worker x {half} sentences, {tk} tokens in {d1:.2f}s"}
+    tk, d2, _ = cpu_translate(model, S, n_sl, n_sent, workers, False)
+    variants["cached_kv"] = {"value": tk / d2, "cores": workers,
+                             "sample": f"{workers} workers x {n_sent} sentences, cross-attention K/V and "
+                                       f"prepared bias computed once per batch, {tk} tokens in {d2:.2f}s"}
+    tk, d3, _ = cpu_translate(model, S, n_sl, half, 1, False)
+    variants["cached_kv_1_thread"] = {"value": tk / d3, "cores": 1,
+                                      "sample": f"1 worker x {half} sentences, {tk} tokens in {d3:.2f}s"}
+    out["variants"] = variants
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one. Nothing has touched the GPU in this process.
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    from slimt_amd import capi, synth
-
-    if not torch.cuda.is_available() or capi.device_count() <= 0:
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    # SLIMT_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- exercises the
-    # torchrun path (rendezvous, barriers, max/sum reduction, rank-0 JSON) on a
-    # one-GPU box. Its numbers mean nothing; the real N-GPU run uses RCCL.
+    dry = os.environ.get("SLIMT_BENCH_DRY") == "1"
+    # SLIMT_BENCH_REHEARSAL=1: every rank on GPU 0 -- exercises the N-rank path
+    # (rendezvous, barriers, max/sum reduction, rank-0 JSON) on a one-GPU box.
     rehearsal = os.environ.get("SLIMT_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    import torch
+    from slimt_amd import synth
+    from slimt_amd.sharding import plan_shards, reduce_timing
+
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
+        # gloo, not RCCL: the ranks exchange one barrier and two scalars, on the host.
+        # gloo announces its connections on stdout; stdout is the JSON line's.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
             dist_mod.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist_mod.init_process_group("nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", local_rank))
+            dist_mod.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         dist = dist_mod
 
     B, S = args.batch, args.src_len
     T = int(np.float32(1.5) * np.float32(S))
-    model = synth.make_model(args.preset, seed=1234, eos_bias=-100.0)  # nobody emits EOS
-    n_sl = args.shortlist
-    sl = synth.make_shortlist(model.V, n_sl) if n_sl else None
-    N_out = n_sl if n_sl else model.V
-    gm = capi.Model(model, device=local_rank)
-    if args.decoder_budget >= 0:
-        gm.set_decoder_budget(args.decoder_budget)
     W = max(1, args.workers)
-    ctxs = [capi.Context(gm, B, S) for _ in range(W)]
-    for c in ctxs:
-        c.set_decode_mode(args.decode_mode)
-    ctx = ctxs[0]
-    dev = torch.device("cuda", local_rank)
+    n_sl = args.shortlist
+    D, F, H, Le, Ld, V = synth.PRESETS[args.preset]
+    N_out = n_sl if n_sl else V
+    strong = args.total_sentences > 0
+    if strong:
+        my_batches = plan_shards(args.total_sentences, B, world)[rank]  # [(start, count)]
+        batches_per_step = len(my_batches)
+    else:
+        my_batches = [(0, B)] * W
+        batches_per_step = W
 
-    def to_dev(a):
-        return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    if dry:
+        def step(i):
+            time.sleep(0.001)
 
-    # a few distinct batches, resident in HBM before the timed region
-    n_batches = 4
-    batches = []
-    for i in range(n_batches):
-        ids, lens = synth.make_batch(model.V, B, S, seed=4321 + 97 * rank + i, ragged=args.ragged)
-        batches.append((to_dev(ids), to_dev(lens)))
-    d_sl = to_dev(sl) if sl is not None else None
-    d_outs = [torch.zeros((B, T), dtype=torch.int32, device=dev) for _ in range(W)]
-    d_lens_out = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(W)]
-    d_len = d_lens_out[0]
+        def sync():
+            pass
 
-    def step(i):
-        # step i runs on worker i % W; calls are asynchronous (fixed step count)
-        w = i % W
-        d_ids, d_lens = batches[i % n_batches]
-        ctxs[w].translate_device(d_ids.data_ptr(), d_lens.data_ptr(), B, S,
-                                 d_sl.data_ptr() if d_sl is not None else 0, n_sl, 1.5, 0,
-                                 d_outs[w].data_ptr(), d_lens_out[w].data_ptr(), 0, steps_hint=T)
+        tokens_per_step = sum(c for _, c in my_batches) * T
+        prof = {"launches": 0, "total_ms": 0.0, "int8_macs": 0.0, "weight_bytes": 0.0}
+        enc_fused = dec_fused = False
+        prof_name = "none"
+        ctxs = []
+        gm = None
+    else:
+        from slimt_amd import capi
+        if not torch.cuda.is_available() or capi.device_count() <= 0:
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        model = synth.make_model(args.preset, seed=1234, eos_bias=-100.0)  # nobody emits EOS
+        sl = synth.make_shortlist(model.V, n_sl) if n_sl else None
+        gm = capi.Model(model, device=local_rank)
+        if args.decoder_budget >= 0:
+            gm.set_decoder_budget(args.decoder_budget)
+        ctxs = [capi.Context(gm, B, S) for _ in range(W)]
+        for c in ctxs:
+            c.set_decode_mode(args.decode_mode)
+        dev = torch.device("cuda", local_rank)
+
+        def to_dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+
+        # distinct batches, resident in HBM before the timed region
+        if strong:
+            total = args.total_sentences
+            ids_all, lens_all = synth.make_batch(model.V, total, S, seed=4321, ragged=args.ragged)
+            batches = [(to_dev(ids_all[s: s + c]), to_dev(lens_all[s: s + c]), c) for s, c in my_batches]
+        else:
+            batches = []
+            for i in range(4):
+                ids, lens = synth.make_batch(model.V, B, S, seed=4321 + 97 * rank + i, ragged=args.ragged)
+                batches.append((to_dev(ids), to_dev(lens), B))
+        d_sl = to_dev(sl) if sl is not None else None
+        n_slots = max(W, 1)
+        d_outs = [torch.zeros((B, T), dtype=torch.int32, device=dev) for _ in range(n_slots)]
+        d_lens_out = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(n_slots)]
+
+        def step(i):
+            # one batch on every worker (weak) / every batch of this rank's shard, dealt to
+            # the workers round-robin (strong); the calls are asynchronous (fixed step count)
+            for j in range(batches_per_step):
+                w = j % W
+                d_ids, d_lens, nb = batches[j] if strong else batches[(i * W + j) % len(batches)]
+                ctxs[w].translate_device(d_ids.data_ptr(), d_lens.data_ptr(), nb, S,
+                                         d_sl.data_ptr() if d_sl is not None else 0, n_sl, 1.5, 0,
+                                         d_outs[w].data_ptr(), d_lens_out[w].data_ptr(), 0, steps_hint=T)
+
+        def sync():
+            torch.cuda.synchronize()
+
+        for i in range(max(1, args.warmup)):
+            step(i)
+        sync()
+        tokens_per_step = sum(c for _, c in my_batches) * T  # nobody emits EOS: T tokens per sentence
+        if not strong:
+            check = int(d_lens_out[0].sum().item())
+            if check != B * T:
+                raise SystemExit(f"bench: expected {B * T} tokens from one batch, got {check}")
+
+        kmap = {"gemm_enc": capi.K_GEMM_ENC, "gemm_dec": capi.K_GEMM_DEC, "logits": capi.K_LOGITS,
+                "attn_enc": capi.K_ATTN_ENC, "attn_dec": capi.K_ATTN_DEC, "ssru": capi.K_SSRU,
+                "decode_fused": capi.K_DECODE_FUSED, "encode_fused": capi.K_ENCODE_FUSED}
+        enc_fused, dec_fused = ctxs[0].plan(S)
+        auto_kernel = "decode_fused" if dec_fused else "gemm_dec"
+        prof_name = auto_kernel if args.profile_kernel == "auto" else args.profile_kernel
+        for c in ctxs:
+            c.profile_enable(kmap.get(prof_name, capi.K_NONE))
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(max(args.warmup, W)):
-        step(i)
-    torch.cuda.synchronize()
-    tokens_per_step = int(d_len.sum().item())
-
-    kmap = {"gemm_enc": capi.K_GEMM_ENC, "gemm_dec": capi.K_GEMM_DEC, "logits": capi.K_LOGITS,
-            "attn_enc": capi.K_ATTN_ENC, "attn_dec": capi.K_ATTN_DEC, "ssru": capi.K_SSRU,
-            "decode_fused": capi.K_DECODE_FUSED, "encode_fused": capi.K_ENCODE_FUSED}
-    enc_fused, dec_fused = ctx.plan(S)
-    auto_kernel = "decode_fused" if dec_fused else "gemm_dec"
-    prof_name = auto_kernel if args.profile_kernel == "auto" else args.profile_kernel
-    for c in ctxs:
-        c.profile_enable(kmap.get(prof_name, capi.K_NONE))
+        sync()
 
     barrier()
     t0 = time.perf_counter()
@@ -229,102 +355,130 @@ def main():
         step(i)
     barrier()
     dt = time.perf_counter() - t0
-    prof = {"launches": 0, "total_ms": 0.0, "int8_macs": 0.0, "weight_bytes": 0.0}
-    for c in ctxs:
-        r = c.profile_read()
-        for k in prof:
-            prof[k] += r[k]
-        c.profile_enable(capi.K_NONE)
+    if not dry:
+        prof = {"launches": 0, "total_ms": 0.0, "int8_macs": 0.0, "weight_bytes": 0.0}
+        for c in ctxs:
+            r = c.profile_read()
+            for k in prof:
+                prof[k] += r[k]
+            c.profile_enable(capi.K_NONE)
 
-    from slimt_amd.sharding import reduce_timing
-    dt_max, total_tokens_per_step = reduce_timing(dist, torch.device("cpu") if rehearsal else dev, dt,
-                                                  tokens_per_step)
+    cpu = torch.device("cpu")
+    dt_max, total_tokens_per_step = reduce_timing(dist, cpu, dt, tokens_per_step)
+
+    sustained = None
+    if args.sustained_steps > 0 and not dry:
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.sustained_steps):
+            step(i)
+        barrier()
+        dts, _ = reduce_timing(dist, cpu, time.perf_counter() - t1, tokens_per_step)
+        sustained = {"steps": args.sustained_steps, "batches_per_gpu": args.sustained_steps * batches_per_step,
+                     "value": total_tokens_per_step * args.sustained_steps / dts, "seconds": dts}
 
     per_kernel = None
-    if args.all_kernels and rank == 0:
+    if args.all_kernels and rank == 0 and not dry:
         per_kernel = {}
         for name, kid in kmap.items():
-            ctx.profile_enable(kid)
-            for i in range(2):
-                step(i)
-            r = ctx.profile_read()
-            per_kernel[name] = {"launches_per_step": r["launches"] / 2,
-                                "ms_per_step": r["total_ms"] / 2,
-                                "avg_us": 1e3 * r["total_ms"] / max(1, r["launches"])}
-        ctx.profile_enable(capi.K_NONE)
+            for c in ctxs:
+                c.profile_enable(kid)
+            step(0)
+            sync()
+            launches, ms = 0, 0.0
+            for c in ctxs:
+                r = c.profile_read()
+                launches += r["launches"]
+                ms += r["total_ms"]
+                c.profile_enable(capi.K_NONE)
+            per_kernel[name] = {"launches_per_step": launches, "ms_per_step_sum_over_streams": ms,
+                                "avg_us": 1e3 * ms / max(1, launches)}
 
     if rank == 0:
         value = total_tokens_per_step * args.steps / dt_max
+        macs_sentence = algorithmic_macs_per_sentence(D, F, Le, Ld, S, T, N_out)
+        sentences_per_step = total_tokens_per_step // T
+        whole_job_tops = 2.0 * macs_sentence * sentences_per_step * args.steps / dt_max / 1e12
         avg_ms = prof["total_ms"] / max(1, prof["launches"])
         ops = 2.0 * prof["int8_macs"] / max(1, prof["launches"])       # algorithmic int8 OPs / launch
-        wbytes = prof["weight_bytes"] / max(1, prof["launches"])       # algorithmic weight bytes / launch
+        wbytes = prof["weight_bytes"] / max(1, prof["launches"])       # weight bytes streamed / launch
         achieved = ops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        macs_sentence = algorithmic_macs_per_sentence(model.D, model.F, model.enc_layers,
-                                                      model.dec_layers, S, T, N_out)
         traffic, traffic_src = pmc_traffic(prof_name)
         cus = -(-B // 16) if prof_name == "decode_fused" else 256
         in_flight = prof["total_ms"] / (1e3 * dt) if dt > 0 else 0.0  # launches of this kernel running at once (this rank)
-        mfma = {
-            "achieved": achieved, "peak": PEAK_INT8_TOPS, "unit": "TOP/s", "frac": achieved / PEAK_INT8_TOPS,
+        # the path is a dense int8 contraction, so the bound is the int8 MFMA
+        # roofline. `achieved` = algorithmic int8 OPs of one launch of the dominant kernel /
+        # its mean duration (HIP events on its own stream); one launch occupies `cus_per_launch`
+        # of the 256 CUs and `launches_in_flight` of them overlap (with the other workers'
+        # encoders), so the chip-level figures are given beside it.
+        roofline = {
+            "kernel": prof_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
+            "frac": achieved / PEAK_INT8_TOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_ops_per_launch": ops, "launches": prof["launches"], "avg_launch_us": 1e3 * avg_ms,
+            "cus_per_launch": cus, "launches_in_flight": in_flight,
             "frac_of_occupied_cus": achieved / (PEAK_INT8_TOPS * cus / 256.0),
-            "chip_frac_all_kernels": 2.0 * macs_sentence * B * args.steps / dt_max / 1e12 / PEAK_INT8_TOPS,  # per GPU
-            "algorithmic_ops_per_launch": ops,
+            "whole_job": {"achieved": whole_job_tops / world, "frac": whole_job_tops / world / PEAK_INT8_TOPS,
+                          "note": "all kernels, per GPU: algorithmic int8 OPs of every translated sentence / "
+                                  "wall time of the timed region"},
         }
         if prof_name == "decode_fused":
-            # The persistent decoder is a streaming kernel (16 rows per workgroup: <10 % MFMA duty).
-            # Algorithmic memory-side bytes of one launch: the cross-attention
-            # K/V cache is re-read every step and, with >= 8 batches in flight, exceeds the 256 MB
-            # Infinity Cache (PMC: profiles/r01_v12_fullocc_pmc.txt); weights once per step and batch
-            # (they are shared through L2 by the batch's workgroups); target embeddings; ids out.
-            D, F, Ld = model.D, model.F, model.dec_layers
-            kv_bytes = float(B) * T * Ld * 2 * S * D * 4
-            w_bytes = float(T) * (Ld * (4 * D * D + 2 * D * F) + D * N_out)
+            # HBM view of the same kernel. SURVEY 8(d) counts the cross-attention K/V cache as
+            # written once and re-read on-chip: `algorithmic_bytes_per_launch` = weights + target
+            # embedding rows + K/V once. This implementation re-reads the f32 K/V cache from the
+            # memory side every step (9..12 batches decode at a time: their caches exceed the
+            # 256 MB Infinity Cache): `implementation_bytes_per_launch`, and its ratio.
+            kv_once = float(B) * Ld * 2 * S * D * 4
+            w_once = float(Ld * (4 * D * D + 2 * D * F) + D * N_out)
             io_bytes = float(B) * T * (D + 4)
-            alg_bytes = kv_bytes + w_bytes + io_bytes
+            alg_bytes = w_once + io_bytes + kv_once
+            kv_reread = kv_once * T
+            impl_bytes = kv_reread + w_once * T + io_bytes
             gbs = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            roofline = {
-                "kernel": prof_name, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            roofline["hbm_view"] = {
+                "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "bytes_model": {"kv_cache_reread_per_step": kv_bytes, "weights_once_per_step": w_bytes,
+                "implementation_bytes_per_launch": impl_bytes,
+                "implementation_over_algorithmic": impl_bytes / alg_bytes,
+                "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                "bytes_model": {"kv_cache_once": kv_once, "kv_cache_reread_every_step": kv_reread,
+                                "weights_once": w_once, "weights_once_per_step": w_once * T,
                                 "embedding_rows_and_ids": io_bytes},
-                "launches": prof["launches"], "avg_launch_us": 1e3 * avg_ms,
-                "cus_per_launch": cus, "launches_in_flight": in_flight,
-                "chip_achieved": gbs * in_flight, "chip_frac": gbs * in_flight / PEAK_HBM_GBS,
-                "note": "achieved/frac are per launch of ONE kernel instance, which occupies ceil(B/16) of the "
-                        "256 CUs; `launches_in_flight` of them overlap (plus the other workers' encoders), "
-                        "chip_* = per-launch rate x launches in flight",
-                "l2_stream_bytes_per_launch": wbytes + kv_bytes,  # weights per workgroup and step + K/V
-                "l2_stream_GBs_per_cu": (wbytes + kv_bytes) / (avg_ms * 1e-3) / 1e9 / cus if avg_ms > 0 else 0.0,
-                "mfma": mfma,
+                "implementation_GBs_per_launch": impl_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                "implementation_GBs_chip": impl_bytes / (avg_ms * 1e-3) / 1e9 * in_flight if avg_ms > 0 else 0.0,
+                "l2_stream_bytes_per_launch": wbytes + kv_reread,  # weights per workgroup and step + K/V
+                "l2_stream_GBs_per_cu": (wbytes + kv_reread) / (avg_ms * 1e-3) / 1e9 / cus if avg_ms > 0 else 0.0,
             }
-        else:
-            roofline = dict(mfma, kernel=prof_name, bound="mfma", traffic=traffic, traffic_source=traffic_src,
-                            cus_per_launch=cus, launches=prof["launches"], avg_launch_us=1e3 * avg_ms,
-                            launches_in_flight=in_flight, algorithmic_weight_bytes_per_launch=wbytes)
         out = {
             "metric": "target tokens/sec, en-de tiny11 int8 greedy, batch=256",
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8", "data": "synthetic",
+            "warmup": max(1, args.warmup), "ms_per_step": 1e3 * dt_max / args.steps,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "int8", "data": "dry-run: no device work (SLIMT_BENCH_DRY)" if dry else "synthetic",
             "config": {
-                "workload": f"en-de {args.preset} int8 greedy decode, batch={B} sentences/GPU, "
-                            f"S={S} source tokens, T={T} decode steps, "
-                            f"{'shortlist ' + str(n_sl) if n_sl else 'full 32k vocabulary'}",
-                "preset": args.preset, "batch_per_gpu": B, "src_len": S, "decode_steps": T,
-                "shortlist": n_sl, "parallelism": f"dp{world} (replicated weights, no collective)",
-                "workers_per_gpu": W, "decode": "fused-persistent" if dec_fused else "step-wise",
+                "workload": (f"en-de {args.preset} int8 greedy decode, batch={B} sentences per translate call, "
+                             f"S={S} source tokens, T={T} decode steps, "
+                             f"{'shortlist ' + str(n_sl) if n_sl else 'full 32k vocabulary'}; "
+                             + (f"one step = the same {args.total_sentences} sentences cut into batches of {B} "
+                                f"and dealt to {world} GPU(s)" if strong else
+                                f"one step = one batch on each of the {W} workers of every GPU "
+                                f"({W * B} sentences per GPU and step)")),
+                "preset": args.preset, "batch": B, "src_len": S, "decode_steps": T,
+                "shortlist": n_sl, "parallelism": f"dp{world} (replicated weights, no collective, no RCCL)",
+                "workers_per_gpu": W, "batches_per_step_per_gpu": batches_per_step,
+                "sentences_per_step_all_gpus": sentences_per_step,
+                "decode": "fused-persistent" if dec_fused else "step-wise",
                 "encode": "fused-persistent" if enc_fused else "layer-by-layer",
                 "tokens_per_step_all_gpus": total_tokens_per_step,
                 "int8_ops_per_token": 2.0 * macs_sentence / T,
-                "whole_job_int8_tops": 2.0 * macs_sentence * B * world * args.steps / dt_max / 1e12,
+                "whole_job_int8_tops": whole_job_tops,
             },
             "roofline": roofline,
         }
+        if sustained is not None:
+            out["sustained"] = sustained
         if per_kernel is not None:
             out["per_kernel"] = per_kernel
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(model, S, T, n_sl, args.cpu_sentences)
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -332,7 +486,8 @@ def main():
         dist.destroy_process_group()
     for c in ctxs:
         c.close()
-    gm.close()
+    if gm is not None:
+        gm.close()
 
 
 if __name__ == "__main__":

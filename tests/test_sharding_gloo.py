@@ -71,3 +71,63 @@ def test_two_rank_gloo_reduction(tmp_path):
     assert res["dt"] == 2.0            # MAX over ranks
     assert res["total"] == 1000 * 48   # SUM over ranks: every sentence counted once
     assert res["mine"] == 512          # rank 0: batches 0 and 2 (256 + 256)
+
+
+def _run_bench(extra, env_extra=None, timeout=300):
+    env = dict(os.environ, SLIMT_BENCH_DRY="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    return lines
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must RUN two ranks
+    (one process per GPU, gloo rendezvous on 127.0.0.1) and print exactly one JSON
+    line with n_gpus = 2. SLIMT_BENCH_DRY replaces the device work by no-ops: what
+    is under test is the launcher, the barrier and the MAX / SUM reduction."""
+    import json
+    lines = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workers", "4"])
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["warmup"] == 1
+    # a step = one batch of 256 on each of the 4 workers of each of the 2 ranks
+    assert d["config"]["sentences_per_step_all_gpus"] == 2 * 4 * 256
+    assert d["config"]["tokens_per_step_all_gpus"] == 2 * 4 * 256 * 48
+    assert "dry-run" in d["data"] and "roofline" in d and d["vs_baseline"] is None
+
+
+def test_bench_fixed_4096_sentences_strong_scaling():
+    """BASELINE config 5: the SAME 4096 sentences at every N (8 x 512 on 8 GPUs; here
+    2 ranks x 4 batches of 512, and 16 x 256 dealt to 2 ranks)."""
+    import json
+    for batch, per_rank in ((512, 4), (256, 8)):
+        lines = _run_bench(["--gpus", "2", "--steps", "2", "--total-sentences", "4096", "--batch", str(batch)])
+        d = json.loads(lines[-1])
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+        assert d["config"]["sentences_per_step_all_gpus"] == 4096
+        assert d["config"]["batches_per_step_per_gpu"] == per_rank
+
+
+def test_bench_under_a_launcher_environment():
+    """The driver's way: torch.distributed.run exports RANK / WORLD_SIZE / MASTER_*;
+    bench.py must then NOT spawn but join as the rank it is told to be."""
+    import json
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, SLIMT_BENCH_DRY="1", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                                       "--workers", "2"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    assert outs[1][0].strip() == ""  # only rank 0 prints
+    d = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["sentences_per_step_all_gpus"] == 2 * 2 * 256
