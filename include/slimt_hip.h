@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLIMT_HIP_ABI_VERSION 1
+#define SLIMT_HIP_ABI_VERSION 2
 
 /* ---- status -------------------------------------------------------------- */
 int slimt_hip_abi_version(void);
@@ -100,6 +100,8 @@ typedef struct slimt_hip_param {
   int32_t rows;     /* shape[-2] */
   int32_t cols;     /* shape[-1] */
   const void *data; /* host memory, borrowed for the duration of the call */
+  uint64_t bytes;   /* size of `data`; checked against rows * cols (+ the trailing
+                       multiplier) before anything is read. 0 = not stated */
 } slimt_hip_param;
 
 typedef struct slimt_hip_dims { /* Model::Config (Model.hh:33-51) */
@@ -162,7 +164,8 @@ int slimt_hip_ctx_plan(const slimt_hip_ctx *ctx, size_t S, int *encoder_fused,
  *  src_ids  [B,S] padded token ids, lengths [B]
  *  shortlist sorted unique target ids (Shortlist.cc:115-175), n_shortlist == 0
  *            => full vocabulary (Transformer.cc:181)
- *  out_ids  [B,Tmax], Tmax = (size_t)(limit_factor * S)  (Model.cc:160)
+ *  out_ids  [B,Tmax], Tmax = max(1, (size_t)(limit_factor * S)): the first step is
+ *           unconditional, the loop then runs while i < limit_factor * S (Model.cc:144-161)
  *  out_len  [B] tokens recorded per sentence, EOS included (Model.cc:127-137)
  *  align    nullable [B,Tmax,S]: row t = attention of head 0 of the LAST
  *           decoder layer over the first lengths[b] keys (Model.cc:84-108) */
@@ -171,6 +174,20 @@ int slimt_hip_translate(slimt_hip_ctx *ctx, const uint32_t *src_ids,
                         const uint32_t *shortlist, size_t n_shortlist,
                         float limit_factor, uint32_t eos_id, uint32_t *out_ids,
                         uint32_t *out_len, float *align);
+/* Same without the final wait: the H2D copies, the kernels and the D2H copies are
+ * queued on the ctx stream and the call returns; slimt_hip_ctx_synchronize(ctx)
+ * waits for them. Every buffer must stay valid (and unchanged) until then, and
+ * should be pinned (slimt_hip_host_alloc) for the copies to be truly
+ * asynchronous. One call in flight per ctx: a worker that wants to assemble its
+ * next batch while this one runs uses two contexts (host/Service.cc). */
+int slimt_hip_translate_async(slimt_hip_ctx *ctx, const uint32_t *src_ids,
+                              const uint32_t *lengths, size_t B, size_t S,
+                              const uint32_t *shortlist, size_t n_shortlist,
+                              float limit_factor, uint32_t eos_id,
+                              uint32_t *out_ids, uint32_t *out_len, float *align);
+/* Pinned (page-locked) host memory for the staging buffers of the call above. */
+int slimt_hip_host_alloc(size_t bytes, void **out);
+int slimt_hip_host_free(void *p);
 /* Same with every buffer already resident in device memory; asynchronous on
  * the ctx stream when `steps_hint` > 0 (runs exactly that many decode steps,
  * no early-exit read-back), otherwise syncs every few steps to stop as soon
@@ -217,7 +234,13 @@ int slimt_hip_shortlist_create(const void *blob, size_t blob_size, size_t source
 int slimt_hip_shortlist_destroy(slimt_hip_shortlist *sl);
 /* header fields (Shortlist.cc:78-81) */
 int slimt_hip_shortlist_info(const slimt_hip_shortlist *sl, uint64_t *frequent, uint64_t *best);
-/* Host arrays: src_ids [B][S] padded rows, lengths [B] (only the first lengths[b]
+/* Threading: a handle may be shared by any number of threads, like the reference's
+ * const generate() on one shared generator (Model.cc:117-120). _generate stages
+ * through buffers of the handle and serialises its callers internally;
+ * _generate_device / slimt_hip_translate_device_generated only read the handle and
+ * use the calling context's scratch and stream, so they run concurrently (one
+ * context per thread, as everywhere).
+ * Host arrays: src_ids [B][S] padded rows, lengths [B] (only the first lengths[b]
  * tokens of a row are words). out_ids: capacity >= target_vocab; *n_out = number
  * of ids written (sorted, unique, a multiple of 8 when enough ids are free). */
 int slimt_hip_shortlist_generate(slimt_hip_shortlist *sl, const uint32_t *src_ids,

@@ -968,6 +968,9 @@ size_t so_translate(const so_model *m, const uint32_t *src_ids,
   free(emb);
 
   size_t max_seq_length = (size_t)(limit_factor * (float)S); /* :160 */
+  /* the first step (:144-157) is unconditional: one token is always recorded, so the
+   * output arrays have max(max_seq_length, 1) columns */
+  if (max_seq_length == 0) max_seq_length = 1;
   float *states = (float *)calloc((size_t)m->Ld * B * D, sizeof(float)); /* :145 */
   float *logits = (float *)malloc(B * N * sizeof(float));
   float *attn = (float *)malloc(B * H * S * sizeof(float));

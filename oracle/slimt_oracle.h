@@ -136,7 +136,7 @@ void so_decode_step(const so_model *m, const float *encoder_out,
                     const float *mask, size_t B, size_t S, float *states,
                     const uint32_t *prev, const uint32_t *shortlist,
                     size_t n_sl, float *logits, float *attn);
-/* Model.cc:111-204 greedy loop. out_ids [B,Tmax] (Tmax = (size_t)(limit*S)),
+/* Model.cc:111-204 greedy loop. out_ids [B,Tmax] (Tmax = max(1, (size_t)(limit*S))),
  * out_len [B], align nullable [B,Tmax,S] (rows: head 0 of last layer,
  * first lengths[b] keys, zero elsewhere). returns steps executed. */
 size_t so_translate(const so_model *m, const uint32_t *src_ids,

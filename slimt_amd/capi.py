@@ -31,6 +31,7 @@ SYMBOLS = [
     "slimt_hip_shortlist_create", "slimt_hip_shortlist_destroy", "slimt_hip_shortlist_info",
     "slimt_hip_shortlist_generate", "slimt_hip_shortlist_generate_device",
     "slimt_hip_translate_device_generated",
+    "slimt_hip_translate_async", "slimt_hip_host_alloc", "slimt_hip_host_free",
 ]
 
 K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED, K_ENCODE_FUSED = range(9)
@@ -44,7 +45,7 @@ class SlimtHipError(RuntimeError):
 
 class _Param(C.Structure):
     _fields_ = [("name", C.c_char_p), ("type", C.c_int32), ("rows", C.c_int32),
-                ("cols", C.c_int32), ("data", C.c_void_p)]
+                ("cols", C.c_int32), ("data", C.c_void_p), ("bytes", C.c_uint64)]
 
 
 class _Dims(C.Structure):
@@ -94,6 +95,9 @@ def lib():
     L.slimt_hip_ctx_set_decode_mode.argtypes = [vp, i32]
     L.slimt_hip_ctx_plan.argtypes = [vp, sz, vp, vp]
     L.slimt_hip_translate.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp]
+    L.slimt_hip_translate_async.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp]
+    L.slimt_hip_host_alloc.argtypes = [sz, vp]
+    L.slimt_hip_host_free.argtypes = [vp]
     L.slimt_hip_translate_device.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp, i32]
     L.slimt_hip_encode.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp]
     L.slimt_hip_decode_begin.argtypes = [vp, vp, sz]
@@ -243,7 +247,7 @@ class Model:
             name = p.name.encode()
             keep += [buf, name]
             arr[i] = _Param(name, 0 if p.kind == "f32" else 1, p.rows, p.cols,
-                            buf.ctypes.data_as(C.c_void_p))
+                            buf.ctypes.data_as(C.c_void_p), buf.nbytes)
         dims = _Dims(model.enc_layers, model.dec_layers, model.H)
         h = C.c_void_p()
         _chk(lib().slimt_hip_model_create(C.cast(arr, C.c_void_p), len(model.params),

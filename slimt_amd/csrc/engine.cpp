@@ -433,8 +433,19 @@ void model_free(slimt_hip_model *m) {
 int model_build(slimt_hip_model *m, const slimt_hip_param *params, size_t n,
                 const slimt_hip_dims *dims) {
   ParamTable t;
-  for (size_t i = 0; i < n; ++i)
-    if (params[i].name && params[i].data) t.by_name[params[i].name] = &params[i];
+  for (size_t i = 0; i < n; ++i) {
+    const slimt_hip_param &p = params[i];
+    if (!p.name || !p.data) continue;
+    if (p.type != 0 && p.type != 1) return fail(-1, "parameter %s: unknown type %d", p.name, p.type);
+    if (p.rows <= 0 || p.cols <= 0)
+      return fail(-1, "parameter %s: bad shape [%d,%d]", p.name, p.rows, p.cols);
+    // a truncated or malformed file must not make the uploads below read past its mapping
+    const uint64_t need = (uint64_t)p.rows * (uint64_t)p.cols * (p.type == 0 ? 4u : 1u) + (p.type == 1 ? 4u : 0u);
+    if (p.bytes && p.bytes < need)
+      return fail(-1, "parameter %s: %llu bytes, its shape [%d,%d] needs %llu", p.name,
+                  (unsigned long long)p.bytes, p.rows, p.cols, (unsigned long long)need);
+    t.by_name[p.name] = &p;
+  }
   const slimt_hip_param *wemb = t.get("Wemb");
   if (!wemb) return fail(-1, "missing parameter Wemb");
   if (wemb->type != 1) return fail(-1, "Wemb must be intgemm8");
@@ -1190,7 +1201,9 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   // the device and n_sl is only the capacity of d_shortlist (persistent kernels only)
   const slimt_hip_model *m = c->model;
   hipStream_t st = c->stream;
-  const size_t Tmax = (size_t)(limit_factor * (float)S);  // Model.cc:160
+  // Model.cc:144-161: the first step is unconditional (one token is always recorded), the
+  // loop then runs while i < (size_t)(limit_factor * S): at least one output column
+  const size_t Tmax = std::max<size_t>(1, (size_t)(limit_factor * (float)S));
   const bool fused_dec = c->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld);
   const bool lean = fused_dec && (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                                   long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
@@ -1389,11 +1402,11 @@ extern "C" int slimt_hip_translate_device(slimt_hip_ctx *ctx, const uint32_t *d_
                           eos_id, d_out_ids, d_out_len, d_align, steps_hint);
 }
 
-extern "C" int slimt_hip_translate(slimt_hip_ctx *ctx, const uint32_t *src_ids,
-                                   const uint32_t *lengths, size_t B, size_t S,
-                                   const uint32_t *shortlist, size_t n_shortlist,
-                                   float limit_factor, uint32_t eos_id, uint32_t *out_ids,
-                                   uint32_t *out_len, float *align) {
+namespace {
+// Model::forward on host buffers: validate, queue H2D + kernels + D2H on the ctx stream.
+int translate_host(slimt_hip_ctx *ctx, const uint32_t *src_ids, const uint32_t *lengths, size_t B,
+                   size_t S, const uint32_t *shortlist, size_t n_shortlist, float limit_factor,
+                   uint32_t eos_id, uint32_t *out_ids, uint32_t *out_len, float *align, bool wait) {
   if (!ctx || !src_ids || !lengths || !out_ids || !out_len) return fail(-1, "null argument");
   RCCHK(check_batch(ctx, B, S));
   const slimt_hip_model *m = ctx->model;
@@ -1407,22 +1420,54 @@ extern "C" int slimt_hip_translate(slimt_hip_ctx *ctx, const uint32_t *src_ids,
     if (lengths[i] > S) return fail(-1, "length %u > S", lengths[i]);
   HIPCHK(hipSetDevice(m->device));
   hipStream_t st = ctx->stream;
-  const size_t Tmax = (size_t)(limit_factor * (float)S);
-  const size_t Talloc = Tmax ? Tmax : 1;
-  HIPCHK(ctx->out_ids.reserve(B * Talloc * 4));
-  if (align) HIPCHK(ctx->align.reserve(B * Talloc * S * 4));
+  const size_t Tmax = std::max<size_t>(1, (size_t)(limit_factor * (float)S));
+  HIPCHK(ctx->out_ids.reserve(B * Tmax * 4));
+  if (align) HIPCHK(ctx->align.reserve(B * Tmax * S * 4));
   HIPCHK(hipMemcpyAsync(ctx->ids.p, src_ids, B * S * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->lengths.p, lengths, B * 4, hipMemcpyHostToDevice, st));
   if (n_shortlist)
     HIPCHK(hipMemcpyAsync(ctx->shortlist.p, shortlist, n_shortlist * 4, hipMemcpyHostToDevice, st));
+  // asynchronous callers never read back inside the loop: a fixed step budget (the persistent
+  // decoder still leaves its loop as soon as every sentence has emitted EOS)
   RCCHK(translate_device(ctx, ctx->ids.as<uint32_t>(), ctx->lengths.as<uint32_t>(),
                          ctx->shortlist.as<uint32_t>(), B, S, n_shortlist, limit_factor, eos_id,
                          ctx->out_ids.as<uint32_t>(), ctx->out_len.as<uint32_t>(),
-                         align ? ctx->align.as<float>() : nullptr, 0));
-  HIPCHK(hipMemcpyAsync(out_ids, ctx->out_ids.p, B * Talloc * 4, hipMemcpyDeviceToHost, st));
+                         align ? ctx->align.as<float>() : nullptr, wait ? 0 : (int)Tmax));
+  HIPCHK(hipMemcpyAsync(out_ids, ctx->out_ids.p, B * Tmax * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(out_len, ctx->out_len.p, B * 4, hipMemcpyDeviceToHost, st));
-  if (align) HIPCHK(hipMemcpyAsync(align, ctx->align.p, B * Talloc * S * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  if (align) HIPCHK(hipMemcpyAsync(align, ctx->align.p, B * Tmax * S * 4, hipMemcpyDeviceToHost, st));
+  if (wait) HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+}  // namespace
+
+extern "C" int slimt_hip_translate(slimt_hip_ctx *ctx, const uint32_t *src_ids,
+                                   const uint32_t *lengths, size_t B, size_t S,
+                                   const uint32_t *shortlist, size_t n_shortlist,
+                                   float limit_factor, uint32_t eos_id, uint32_t *out_ids,
+                                   uint32_t *out_len, float *align) {
+  return translate_host(ctx, src_ids, lengths, B, S, shortlist, n_shortlist, limit_factor, eos_id,
+                        out_ids, out_len, align, true);
+}
+
+extern "C" int slimt_hip_translate_async(slimt_hip_ctx *ctx, const uint32_t *src_ids,
+                                         const uint32_t *lengths, size_t B, size_t S,
+                                         const uint32_t *shortlist, size_t n_shortlist,
+                                         float limit_factor, uint32_t eos_id, uint32_t *out_ids,
+                                         uint32_t *out_len, float *align) {
+  return translate_host(ctx, src_ids, lengths, B, S, shortlist, n_shortlist, limit_factor, eos_id,
+                        out_ids, out_len, align, false);
+}
+
+extern "C" int slimt_hip_host_alloc(size_t bytes, void **out) {
+  if (!out) return fail(-1, "null argument");
+  *out = nullptr;
+  HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return 0;
+}
+
+extern "C" int slimt_hip_host_free(void *p) {
+  if (p) HIPCHK(hipHostFree(p));
   return 0;
 }
 
@@ -1701,6 +1746,10 @@ extern "C" int slimt_hip_shortlist_generate(slimt_hip_shortlist *sl, const uint3
       if (src_ids[b * S + j] >= sl->source_vocab)
         return fail(-1, "token id %u out of range", src_ids[b * S + j]);
   }
+  // ShortlistGenerator::generate is const and is called by every Async worker on ONE shared
+  // generator (Model.cc:117-120); this entry point stages through per-handle buffers, so
+  // concurrent callers take turns (the _device variants use the caller's context instead)
+  std::lock_guard<std::mutex> lock(sl->mu);
   HIPCHK(hipSetDevice(sl->device));
   HIPCHK(sl->ids.reserve(B * S * 4));
   HIPCHK(sl->lengths.reserve(B * 4));

@@ -136,5 +136,6 @@ struct slimt_hip_shortlist {
   slimt_hip::DevBuf w2o, lists;                // word_to_offset (uint64), shortlist (uint32)
   slimt_hip::DevBuf ids, lengths, out, n_out;  // staging of the host entry point
   slimt_hip::DevBuf scratch;                   // ... and its bitmaps
+  std::mutex mu;  // the host entry point stages through the buffers above: one caller at a time
 };
 

@@ -68,12 +68,20 @@ std::vector<Item> load_items(const void *data, size_t size) {
   for (uint64_t i = 0; i < n; ++i) {
     items[i].bytes = headers[i].data_length;
     items[i].data = r.take(headers[i].data_length);
-    if (items[i].type == ItemType::ig8) {
-      size_t elems = 1;
-      for (int d : items[i].shape) elems *= static_cast<size_t>(d);
-      if (items[i].bytes < elems + sizeof(float))
-        throw std::runtime_error("intgemm8 item " + items[i].name + " lacks its multiplier");
+    if (items[i].type == ItemType::other) continue;  // kept as an opaque view (e.g. special:model.yml)
+    // the payload must cover the shape: consumers index it by rows * cols
+    uint64_t elems = 1;
+    for (int d : items[i].shape) {
+      if (d <= 0) throw std::runtime_error("item " + items[i].name + " has a non-positive dimension");
+      elems *= static_cast<uint64_t>(d);
+      if (elems > (1ull << 40)) throw std::runtime_error("item " + items[i].name + " has an implausible shape");
     }
+    const uint64_t need = items[i].type == ItemType::f32 ? elems * sizeof(float)
+                          : items[i].type == ItemType::ig8 ? elems + sizeof(float) : elems;
+    if (items[i].bytes < need)
+      throw std::runtime_error((items[i].type == ItemType::ig8 ? "intgemm8 item " + items[i].name + " lacks its multiplier"
+                                                               : "item " + items[i].name + " is shorter than its shape") +
+                               " (" + std::to_string(items[i].bytes) + " < " + std::to_string(need) + " bytes)");
   }
   return items;
 }

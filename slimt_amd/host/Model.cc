@@ -34,6 +34,7 @@ Model::Model(const Config &config, const void *model_bin, size_t size) : config_
     p.rows = it.shape.size() >= 2 ? it.shape[it.shape.size() - 2] : 1;
     p.cols = it.shape.empty() ? 1 : it.shape.back();
     p.data = it.data;
+    p.bytes = it.bytes;
     params.push_back(p);
   }
   slimt_hip_dims dims;
@@ -68,17 +69,36 @@ Histories Worker::forward(const Input &input, const std::optional<Words> &shortl
                           input.limit_factor(), model_.config().eos_id, out_ids.data(),
                           out_len.data(), with_alignments ? align.data() : nullptr))
     raise("slimt_hip_translate");
+  return collect(out_ids.data(), out_len.data(), with_alignments ? align.data() : nullptr,
+                 input.lengths().data(), B, S, T);
+}
+
+void Worker::forward_async(const uint32_t *ids, const uint32_t *lengths, size_t B, size_t S,
+                           const uint32_t *shortlist, size_t n_shortlist, float limit_factor,
+                           uint32_t *out_ids, uint32_t *out_len, float *align) {
+  if (slimt_hip_translate_async(ctx_, ids, lengths, B, S, shortlist, n_shortlist, limit_factor,
+                                model_.config().eos_id, out_ids, out_len, align))
+    raise("slimt_hip_translate_async");
+}
+
+void Worker::wait() {
+  if (slimt_hip_ctx_synchronize(ctx_)) raise("slimt_hip_ctx_synchronize");
+}
+
+Histories collect(const uint32_t *out_ids, const uint32_t *out_len, const float *align,
+                  const uint32_t *lengths, size_t B, size_t S, size_t T) {
   Histories histories;
   histories.reserve(B);
   for (size_t b = 0; b < B; ++b) {
     auto hyp = std::make_shared<Hypothesis>();
     hyp->padded_length = S;
     const size_t n = out_len[b] < T ? out_len[b] : T;
-    hyp->target.assign(out_ids.begin() + b * T, out_ids.begin() + b * T + n);
-    if (with_alignments) {
-      const size_t len = input.lengths()[b];
-      for (size_t t = 0; t < n; ++t) {  // rows of `length` probabilities, slimt/Model.cc:95-106
-        const float *row = align.data() + (b * T + t) * S;
+    hyp->target.assign(out_ids + b * T, out_ids + b * T + n);
+    if (align) {
+      const size_t len = lengths[b];
+      hyp->alignment.reserve(n);
+      for (size_t t = 0; t < n; ++t) {
+        const float *row = align + (b * T + t) * S;
         hyp->alignment.emplace_back(row, row + len);
       }
     }

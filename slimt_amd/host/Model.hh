@@ -86,10 +86,23 @@ class Worker {
   // the batch (slimt/Model.cc:117-120) or nullopt for the full vocabulary.
   Histories forward(const Input &input, const std::optional<Words> &shortlist = std::nullopt,
                     bool with_alignments = true);
+  // The same pass without waiting for it (slimt_hip_translate_async): every array belongs to
+  // the caller, must stay untouched until wait() returns and should be pinned. One pass in
+  // flight per Worker; out_ids [B][T], out_len [B], align nullable [B][T][S] with
+  // T = max(1, (size_t)(limit_factor * S)).
+  void forward_async(const uint32_t *ids, const uint32_t *lengths, size_t B, size_t S,
+                     const uint32_t *shortlist, size_t n_shortlist, float limit_factor,
+                     uint32_t *out_ids, uint32_t *out_len, float *align);
+  void wait();
 
  private:
   const Model &model_;
   slimt_hip_ctx *ctx_ = nullptr;
 };
+
+// Raw outputs of a pass -> Histories (targets cut at out_len, alignment rows cut at the
+// sentence's own length, slimt/Model.cc:95-106,163-176).
+Histories collect(const uint32_t *out_ids, const uint32_t *out_len, const float *align,
+                  const uint32_t *lengths, size_t B, size_t S, size_t T);
 
 }  // namespace slimt

@@ -1,0 +1,124 @@
+// Multi-device translation service of the HIP backend.
+//
+// What it replaces in slimt: the request -> batch -> worker plumbing between
+// `Async::translate` and `Model::forward` (slimt/Frontend.cc:207-227 with
+// slimt/Batcher.{hh,cc}). This is NOT that code: the reference keeps ordered
+// sets of segment references per length and hands one batch at a time to a
+// worker that blocks in `forward`. Here
+//   * waiting sentences live in per-length binary heaps keyed by arrival order
+//     (LengthQueue) -- only the batch-FORMING RULE is the reference's, because
+//     the padding a sentence travels with is visible in its result: walk the
+//     lengths upwards and keep adding sentences while (count + 1) * length fits
+//     the word budget (slimt/Batcher.cc:95-120);
+//   * every worker owns TWO device contexts with pinned staging buffers and keeps
+//     one batch running on the GPU while it assembles, uploads and launches the
+//     next one and then unpacks the previous one's results (double buffering over
+//     slimt_hip_translate_async): host work and PCIe copies hide behind kernels;
+//   * workers are spread over any number of model replicas (one per GPU).
+// Text processing is out of scope, so a request is its tokenised sentences.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstddef>
+#include <cstdint>
+#include <exception>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <thread>
+#include <vector>
+
+#include "Model.hh"
+
+namespace slimt {
+
+// One translate() call in flight: its sentences, the slots for their results and
+// the promise that is fulfilled by whichever worker delivers the last one.
+class Pending {
+ public:
+  explicit Pending(std::vector<Words> sentences);
+  size_t size() const { return sentences_.size(); }
+  const Words &sentence(size_t i) const { return sentences_[i]; }
+  std::future<Histories> future() { return promise_.get_future(); }
+  void deliver(size_t i, History history);   // thread-safe; the last delivery fulfils the promise
+  void fail(const std::exception_ptr &error);  // first failure wins; later deliveries are dropped
+
+ private:
+  std::vector<Words> sentences_;
+  Histories results_;
+  std::atomic<size_t> left_;
+  std::atomic<bool> settled_{false};
+  std::promise<Histories> promise_;
+};
+
+// A sentence waiting for a batch.
+struct Unit {
+  uint64_t order = 0;  // (request sequence number << 24) | sentence index: FIFO among equal lengths
+  std::shared_ptr<Pending> owner;
+  uint32_t index = 0;
+  uint32_t length = 0;
+};
+
+// Waiting sentences, grouped by length. Not thread-safe (the service locks around it).
+class LengthQueue {
+ public:
+  // `longest` = the longest sentence accepted; the budget must hold at least one
+  // such sentence (the reference's check, slimt/Batcher.cc:85-91).
+  LengthQueue(size_t max_words, size_t longest);
+  void push(Unit unit);
+  // Next batch under the reference's rule (slimt/Batcher.cc:95-120): lengths
+  // ascending, arrival order within a length, stop at the first sentence that
+  // would push (count + 1) * its length over the budget. Empty when nothing waits.
+  std::vector<Unit> take();
+  size_t waiting() const { return waiting_; }
+  size_t longest() const { return heaps_.size() - 1; }
+
+ private:
+  size_t max_words_;
+  std::vector<std::vector<Unit>> heaps_;  // heaps_[len]: min-heap on Unit::order
+  size_t low_ = 0, high_ = 0;             // lengths outside [low_, high_] are empty
+  size_t waiting_ = 0;
+};
+
+struct ServiceConfig {
+  size_t max_words = 8192;   // word budget of a batch: (B + 1) * S <= max_words
+  size_t wrap_length = 128;  // longest sentence (slimt wraps there, Frontend.hh:27)
+  float tgt_length_limit_factor = 1.5F;
+  size_t workers_per_device = 4;
+  uint32_t pad_id = 0;
+  bool alignments = true;
+  // One shortlist policy for the service's lifetime (immutable after construction):
+  // sorted target ids, or nullopt for the full vocabulary.
+  std::optional<Words> shortlist;
+};
+
+class Service {
+ public:
+  // replicas[d]: the model on GPU d. Worker w of device d = thread d * workers_per_device + w.
+  Service(const ServiceConfig &config, std::vector<const Model *> replicas);
+  ~Service();  // drains the queue, then joins the workers
+  Service(const Service &) = delete;
+  Service &operator=(const Service &) = delete;
+  // Queue one request. Throws std::invalid_argument for an empty sentence or one longer
+  // than the service accepts; a failure on a worker arrives through the future.
+  std::future<Histories> translate(std::vector<Words> sentences);
+
+ private:
+  struct Slot;
+  void work(const Model *model);
+  std::vector<Unit> next_batch(bool may_block);
+  void launch(Slot &slot, std::vector<Unit> batch);
+  void finish(Slot &slot);
+
+  ServiceConfig config_;
+  size_t longest_;
+  LengthQueue queue_;
+  uint64_t sequence_ = 0;
+  bool closing_ = false;
+  std::mutex mutex_;
+  std::condition_variable wake_;
+  std::vector<std::thread> threads_;
+};
+
+}  // namespace slimt

@@ -8,6 +8,7 @@
 //           then f32 affine[M*N], f32 dot[M*N], f32 select[M*n_idx]
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <future>
@@ -17,7 +18,8 @@
 #include <string>
 #include <vector>
 
-#include "Batcher.hh"
+#include "Service.hh"
+#include "Io.hh"
 #include "Model.hh"
 #include "Shortlist.hh"
 #include "QMM.hh"
@@ -55,11 +57,12 @@ void put(std::ofstream &o, const T *p, size_t n) {
 }  // namespace
 
 // Batching modes:
-//   host_test --batcher case.bin out.bin            Batcher alone (no GPU work): enqueue every
-//       request, then generate() until empty; writes the batches.
-//   host_test --async model.bin case.bin out.bin    Async over `workers` worker threads on GPU 0.
+//   host_test --batcher case.bin out.bin            LengthQueue alone (no GPU work): push every
+//       sentence, then take() until empty; writes the batches.
+//   host_test --async model.bin case.bin out.bin    Service: `workers` double-buffered workers on GPU 0.
 // case.bin: u32 {enc_layers, dec_layers, heads, max_words, wrap_length, workers, n_requests},
 //           f32 limit_factor, then per request u32 n_segments, per segment u32 len + u32 tokens[len].
+//   optional trailing u32 n_shortlist + u32 ids[n] (--async only; absent = full vocabulary)
 static int batching_main(int argc, char **argv) {
   using namespace slimt;
   const bool async = std::string(argv[1]) == "--async";
@@ -70,27 +73,40 @@ static int batching_main(int argc, char **argv) {
   const uint32_t max_words = c.get<uint32_t>(), wrap = c.get<uint32_t>(), workers = c.get<uint32_t>();
   const uint32_t n_req = c.get<uint32_t>();
   const float limit = c.get<float>();
-  std::vector<Ptr<Request>> requests;
+  std::vector<std::vector<Words>> requests;
   for (uint32_t r = 0; r < n_req; ++r) {
     const uint32_t n_seg = c.get<uint32_t>();
-    std::vector<Segment> segs;
+    std::vector<Words> segs;
     for (uint32_t i = 0; i < n_seg; ++i) {
       const uint32_t len = c.get<uint32_t>();
       segs.push_back(c.vec<uint32_t>(len));
     }
-    requests.push_back(std::make_shared<Request>(r, std::move(segs)));
+    requests.push_back(std::move(segs));
   }
   std::ofstream out(argv[async ? 4 : 3], std::ios::binary);
   try {
     if (!async) {
-      Batcher batcher(max_words, wrap, limit);
-      for (auto &r : requests) batcher.enqueue(r);
-      for (Batch b = batcher.generate(); !b.empty(); b = batcher.generate()) {
-        const uint32_t n = static_cast<uint32_t>(b.size()), ml = static_cast<uint32_t>(b.max_length());
+      // the longest sentence the reference's batcher provisions for: the wrap length plus the
+      // slack for sentences that overflow it (slimt/Batcher.cc:77-92)
+      const size_t longest = wrap + static_cast<size_t>(static_cast<float>(wrap) * limit - static_cast<float>(wrap));
+      LengthQueue queue(max_words, longest);
+      for (uint32_t r = 0; r < n_req; ++r) {
+        auto owner = std::make_shared<Pending>(requests[r]);
+        for (uint32_t i = 0; i < requests[r].size(); ++i) {
+          Unit u;
+          u.order = (static_cast<uint64_t>(r) << 24) | i;
+          u.owner = owner;
+          u.index = i;
+          u.length = static_cast<uint32_t>(requests[r][i].size());
+          queue.push(std::move(u));
+        }
+      }
+      for (std::vector<Unit> b = queue.take(); !b.empty(); b = queue.take()) {
+        const uint32_t n = static_cast<uint32_t>(b.size()), ml = b.back().length;
         put(out, &n, 1);
         put(out, &ml, 1);
-        for (const auto &ref : b.segment_refs()) {
-          const uint32_t rid = static_cast<uint32_t>(ref.request().id()), idx = static_cast<uint32_t>(ref.index());
+        for (const Unit &u : b) {
+          const uint32_t rid = static_cast<uint32_t>(u.order >> 24), idx = u.index;
           put(out, &rid, 1);
           put(out, &idx, 1);
         }
@@ -103,22 +119,36 @@ static int batching_main(int argc, char **argv) {
     cfg.decoder_layers = Ld;
     cfg.num_heads = H;
     Model model(cfg, bin.data(), bin.size());
-    Async::Config ac;
-    ac.max_words = max_words;
-    ac.wrap_length = wrap;
-    ac.tgt_length_limit_factor = limit;
-    ac.workers = workers;
+    ServiceConfig sc;
+    sc.max_words = max_words;
+    sc.wrap_length = wrap;
+    sc.tgt_length_limit_factor = limit;
+    sc.workers_per_device = workers;
+    if (c.p < cs.data() + cs.size()) {
+      const uint32_t n_sl = c.get<uint32_t>();
+      if (n_sl) sc.shortlist = c.vec<uint32_t>(n_sl);
+    }
+    if (const char *e = std::getenv("SLIMT_SERVICE_NO_ALIGN")) sc.alignments = e[0] != '1';
     std::vector<std::future<Histories>> futures;
+    std::vector<Histories> results;
     {
-      Async service(ac, {&model});
+      Service service(sc, {&model});
+      // first request alone and untimed: worker start-up (contexts, pinned buffers)
       const auto t0 = std::chrono::steady_clock::now();
       for (auto &r : requests) futures.push_back(service.translate(r));
-      for (auto &f : futures) f.wait();
+      for (auto &f : futures) results.push_back(f.get());
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       std::fprintf(stderr, "async: %zu requests translated in %.3f ms\n", requests.size(), ms);
-    }  // joins the workers
-    for (auto &f : futures) {
-      Histories hs = f.get();
+      if (std::getenv("SLIMT_SERVICE_REPEAT")) {  // steady state: the same requests again, workers warm
+        std::vector<std::future<Histories>> again;
+        const auto t1 = std::chrono::steady_clock::now();
+        for (auto &r : requests) again.push_back(service.translate(r));
+        for (auto &f : again) f.wait();
+        const double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        std::fprintf(stderr, "async-warm: %zu requests translated in %.3f ms\n", requests.size(), ms2);
+      }
+    }  // drains and joins the workers
+    for (const Histories &hs : results) {
       for (const auto &h : hs) {
         const uint32_t S = static_cast<uint32_t>(h->padded_length), n = static_cast<uint32_t>(h->target.size());
         put(out, &S, 1);
@@ -133,9 +163,76 @@ static int batching_main(int argc, char **argv) {
   return 0;
 }
 
+// host_test --service-errors model.bin Le Ld H: bad requests are refused or reported, never fatal.
+static int service_errors_main(int argc, char **argv) {
+  using namespace slimt;
+  if (argc != 6) return 2;
+  try {
+    std::vector<char> bin = slurp(argv[2]);
+    Model::Config cfg;
+    cfg.encoder_layers = static_cast<size_t>(std::atoi(argv[3]));
+    cfg.decoder_layers = static_cast<size_t>(std::atoi(argv[4]));
+    cfg.num_heads = static_cast<size_t>(std::atoi(argv[5]));
+    Model model(cfg, bin.data(), bin.size());
+    int32_t vocab = 0;
+    if (slimt_hip_model_info(model.handle(), nullptr, nullptr, &vocab, nullptr)) throw std::runtime_error("model_info");
+    ServiceConfig sc;
+    sc.max_words = 96;
+    sc.wrap_length = 24;
+    sc.workers_per_device = 2;
+    Service service(sc, {&model});
+    try {
+      service.translate({Words{}});
+      std::printf("accepted empty\n");
+    } catch (const std::invalid_argument &) {
+      std::printf("rejected empty\n");
+    }
+    try {
+      service.translate({Words(25, 1)});
+      std::printf("accepted overlong\n");
+    } catch (const std::invalid_argument &) {
+      std::printf("rejected overlong\n");
+    }
+    // a token id outside the vocabulary: the engine refuses the batch on the worker; the
+    // error must come back through the future (and the innocent request in the same batch too)
+    auto bad = service.translate({Words{1, 2, static_cast<Word>(vocab), 0}});
+    try {
+      bad.get();
+      std::printf("worker failure lost\n");
+    } catch (const std::runtime_error &e) {
+      std::printf("worker failure reported: %s\n", e.what());
+    }
+    auto good = service.translate({Words{5, 6, 0}, Words{7, 0}, Words{9, 10, 11, 12, 0}});
+    Histories hs = good.get();
+    size_t ok = 0;
+    for (const auto &h : hs) ok += (h && !h->target.empty()) ? 1 : 0;
+    std::printf("survived: %zu sentences\n", ok);
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "host_test: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
+
+// host_test --load model.bin: io::load_items alone (no GPU): prints the item count or the error.
+static int load_main(int argc, char **argv) {
+  if (argc != 3) return 2;
+  std::vector<char> bin = slurp(argv[2]);
+  try {
+    std::vector<slimt::io::Item> items = slimt::io::load_items(bin.data(), bin.size());
+    std::printf("loaded %zu items\n", items.size());
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "host_test: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc >= 2 && (std::string(argv[1]) == "--batcher" || std::string(argv[1]) == "--async"))
     return batching_main(argc, argv);
+  if (argc >= 2 && std::string(argv[1]) == "--service-errors") return service_errors_main(argc, argv);
+  if (argc >= 2 && std::string(argv[1]) == "--load") return load_main(argc, argv);
   if (argc != 4 && argc != 5) {
     std::fprintf(stderr, "usage: %s model.bin case.bin out.bin [lexical_shortlist.bin]\n", argv[0]);
     return 2;

@@ -1,9 +1,11 @@
-"""Batching pipeline (slimt/Batcher.{hh,cc}, Frontend.cc:207-227).
+"""Batching pipeline (what slimt does in Batcher.{hh,cc} and
+Frontend.cc:207-227; here slimt_amd/host/Service.{hh,cc}, an own multi-device queue).
 
-CPU: the C++ Batcher against a Python restatement of Batcher::generate.
-GPU: the Async worker loop (several workers, token-budget batches) -- every
-sentence's translation equals the oracle's for that sentence padded to the
-length of the batch it travelled in (rows never interact)."""
+CPU: the C++ LengthQueue forms the same batches as a Python restatement of the
+reference's batch-forming rule (Batcher::generate) -- padding is visible in results.
+GPU: the Service's double-buffered workers (token-budget batches, pinned staging,
+optional shortlist) -- every sentence's translation equals the oracle's for that
+sentence padded to the length of the batch it travelled in (rows never interact)."""
 import os
 import struct
 import subprocess
@@ -19,13 +21,15 @@ def _exe():
     return B.build_host()
 
 
-def _case(path, dims, max_words, wrap, workers, limit, requests):
+def _case(path, dims, max_words, wrap, workers, limit, requests, shortlist=None):
     with open(path, "wb") as f:
         f.write(struct.pack("<7If", *dims, max_words, wrap, workers, len(requests), limit))
         for segs in requests:
             f.write(struct.pack("<I", len(segs)))
             for s in segs:
                 f.write(struct.pack("<I", len(s)) + np.asarray(s, np.uint32).tobytes())
+        if shortlist is not None:
+            f.write(struct.pack("<I", len(shortlist)) + np.asarray(shortlist, np.uint32).tobytes())
 
 
 def _requests(V, n_req, seed, max_len):
@@ -73,16 +77,19 @@ def test_batcher_rejects_wrap_longer_than_budget():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workers", [1, 3])
-def test_async_workers_translate_every_sentence(hip, oracle, synth_models, workers):
+@pytest.mark.parametrize("workers,n_sl", [(1, None), (3, None), (4, 128)])
+def test_async_workers_translate_every_sentence(hip, oracle, synth_models, workers, n_sl):
     m = synth_models("micro", 3.0)
-    reqs = _requests(m.V, 12, 7 + workers, 20)
+    reqs = _requests(m.V, 12 if workers < 4 else 40, 7 + workers, 20)
+    sl = None if n_sl is None else synth.make_shortlist(m.V, n_sl, frequent=16)
     with tempfile.TemporaryDirectory() as d:
         mb, cb, ob = (os.path.join(d, n) for n in ("model.bin", "case.bin", "out.bin"))
         open(mb, "wb").write(synth.write_bin(m))
-        _case(cb, (m.enc_layers, m.dec_layers, m.H), 96, 24, workers, 1.5, reqs)
-        res = subprocess.run([_exe(), "--async", mb, cb, ob], capture_output=True, text=True, timeout=600)
+        _case(cb, (m.enc_layers, m.dec_layers, m.H), 96, 24, workers, 1.5, reqs, sl)
+        env = dict(os.environ, SLIMT_SERVICE_REPEAT="1")  # a second, warm pass over the same workers
+        res = subprocess.run([_exe(), "--async", mb, cb, ob], capture_output=True, text=True, timeout=600, env=env)
         assert res.returncode == 0, res.stderr
+        assert "async-warm" in res.stderr
         raw = open(ob, "rb").read()
     oracle.set_mode(oracle.PORTABLE)
     om = oracle.OracleModel(m)
@@ -96,7 +103,22 @@ def test_async_workers_translate_every_sentence(hip, oracle, synth_models, worke
             assert S >= len(s)
             ids = np.zeros((1, S), np.uint32)
             ids[0, : len(s)] = s
-            w_out, w_ln, _, _ = om.translate(ids, np.array([len(s)], np.uint32), None, 1.5, 0)
+            w_out, w_ln, _, _ = om.translate(ids, np.array([len(s)], np.uint32), sl, 1.5, 0)
             assert n == w_ln[0] and np.array_equal(toks, w_out[0, :n])
     oracle.set_mode(oracle.FAITHFUL)
     assert off == len(raw)
+
+
+@pytest.mark.gpu
+def test_service_rejects_bad_requests_and_survives(hip, synth_models):
+    """An empty or overlong sentence is refused at translate() (the engine would fail the
+    whole batch); the workers keep running and later requests are translated."""
+    m = synth_models("micro", 3.0)
+    with tempfile.TemporaryDirectory() as d:
+        mb = os.path.join(d, "model.bin")
+        open(mb, "wb").write(synth.write_bin(m))
+        res = subprocess.run([_exe(), "--service-errors", mb, str(m.enc_layers), str(m.dec_layers), str(m.H)],
+                             capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr + res.stdout
+    assert "rejected empty" in res.stdout and "rejected overlong" in res.stdout
+    assert "worker failure reported" in res.stdout and "survived: 3 sentences" in res.stdout

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(dll, n), f"{n} declared in slimt_hip.h but not exported"
     assert sorted(capi.SYMBOLS) == names
-    assert capi.lib().slimt_hip_abi_version() == 1
+    assert capi.lib().slimt_hip_abi_version() == 2
 
 
 def test_no_oracle_in_product():
@@ -83,3 +83,47 @@ def test_bin_roundtrip():
     import struct
     n = struct.unpack_from("<Q", buf, 8)[0]
     assert n == len(m.params) + 1
+
+
+def test_loader_rejects_malformed_bins(tmp_path):
+    """io::load_items (host/Io.cc; slimt/Io.cc:114-161) must refuse a file whose payloads do
+    not cover their shapes instead of letting the uploads read past the mapping."""
+    import struct
+    import subprocess
+    from slimt_amd import build, synth
+    exe = build.build_host()
+    m = synth.make_model("micro", eos_bias=0.0)
+    good = synth.write_bin(m)
+
+    def run(blob):
+        f = tmp_path / "m.bin"
+        f.write_bytes(blob)
+        return subprocess.run([exe, "--load", str(f)], capture_output=True, text=True, timeout=60)
+
+    r = run(good)
+    assert r.returncode == 0 and "loaded" in r.stdout, r.stderr
+    r = run(good[: len(good) // 2])
+    assert r.returncode == 1 and "truncated" in r.stderr
+    # an f32 item whose shape claims more elements than its payload holds
+    n = struct.unpack_from("<Q", good, 8)[0]
+    headers = [list(struct.unpack_from("<QQQQ", good, 16 + 32 * i)) for i in range(n)]
+    names_off = 16 + 32 * n
+    shapes_off = names_off + sum(h[0] for h in headers)
+    off = shapes_off
+    victim = None
+    for i, h in enumerate(headers):
+        if h[1] == synth.TYPE_F32 and victim is None:
+            victim = (i, off)
+        off += 4 * h[2]
+    i, soff = victim
+    bad = bytearray(good)
+    dims = list(struct.unpack_from("<%di" % headers[i][2], good, soff))
+    dims[-1] *= 3
+    struct.pack_into("<%di" % headers[i][2], bad, soff, *dims)
+    r = run(bytes(bad))
+    assert r.returncode == 1 and "shorter than its shape" in r.stderr, r.stderr
+    bad = bytearray(good)
+    dims[-1] = -4
+    struct.pack_into("<%di" % headers[i][2], bad, soff, *dims)
+    r = run(bytes(bad))
+    assert r.returncode == 1 and "non-positive" in r.stderr, r.stderr

@@ -135,11 +135,17 @@ def test_translate_limit_factor_and_reuse(hip, oracle, engines):
     m, gm, om = engines("micro", 3.0)
     ctx = hip.Context(gm, 16, 16)
     oracle.set_mode(oracle.PORTABLE)
-    for (B, S, lf) in [(1, 1, 1.5), (2, 3, 1.0), (16, 16, 0.5), (3, 5, 2.5)]:
+    for (B, S, lf) in [(1, 1, 1.5), (2, 3, 1.0), (16, 16, 0.5), (3, 5, 2.5), (2, 1, 0.5), (3, 3, 0.25)]:
         ids, lens = synth.make_batch(m.V, B, S, seed=B + S, ragged=B > 2)
-        out, ln, _ = ctx.translate(ids, lens, None, limit_factor=lf)
-        w_out, w_ln, _, _ = om.translate(ids, lens, None, lf, 0)
-        assert np.array_equal(out, w_out) and np.array_equal(ln, w_ln), (B, S, lf)
+        w_out, w_ln, w_al, _ = om.translate(ids, lens, None, lf, 0, want_align=True)
+        # limit_factor * S < 1: the first step is unconditional (Model.cc:144-157), one token
+        assert w_ln.min() >= 1 and w_out.shape[1] == max(1, int(np.float32(lf) * np.float32(S)))
+        for mode in (0, 1):
+            ctx.set_decode_mode(mode)
+            out, ln, al = ctx.translate(ids, lens, None, limit_factor=lf, want_align=True)
+            assert np.array_equal(out, w_out) and np.array_equal(ln, w_ln), (B, S, lf, mode)
+            assert np.array_equal(al, w_al), (B, S, lf, mode)
+    ctx.set_decode_mode(0)
     oracle.set_mode(oracle.FAITHFUL)
     with pytest.raises(hip.SlimtHipError):
         ctx.translate(np.zeros((17, 4), np.uint32), np.full(17, 4, np.uint32))  # B > workspace
@@ -430,3 +436,23 @@ def test_deep_async_queues_keep_results(hip, oracle, engines):
             c.close()
         gm.set_decoder_budget(192)
         dev.free()
+
+
+def test_model_create_checks_payload_sizes(hip, synth_models):
+    """slimt_hip_param.bytes: a payload shorter than its shape (truncated file) is refused
+    before anything is uploaded."""
+    import copy
+    m = copy.copy(synth_models("micro", 3.0))
+    m.params = dict(m.params)
+    victim = copy.copy(m.params["encoder_l1_ffn_W1"])
+    full = victim.payload()
+
+    class Short:
+        name, kind, rows, cols = victim.name, victim.kind, victim.rows, victim.cols
+
+        def payload(self):
+            return full[: len(full) // 2]
+
+    m.params["encoder_l1_ffn_W1"] = Short()
+    with pytest.raises(hip.SlimtHipError, match="bytes, its shape"):
+        hip.Model(m)

@@ -88,6 +88,38 @@ def test_gpu_generate_matches_oracle(hip, oracle, Vs, Vt, frequent, best, B, S, 
 
 
 @pytest.mark.gpu
+def test_gpu_generate_is_safe_on_one_shared_handle(hip, oracle):
+    """ShortlistGenerator::generate is const and every Async worker calls it on ONE shared
+    generator (Model.cc:117-120, Frontend.cc:212-226): six threads with batches of very
+    different sizes (the staging buffers get re-reserved) on one handle, every result must
+    be that thread's own batch's shortlist."""
+    import threading
+    Vs = Vt = 4000
+    blob = synth.make_lexical_shortlist(Vs, Vt, 50, 20, seed=3)
+    osl = oracle.OracleShortlist(blob, Vs, Vt)
+    jobs = []
+    for i, (B, S) in enumerate([(1, 3), (64, 32), (7, 128), (256, 32), (2, 2), (33, 17)]):
+        ids, lens = synth.make_batch(Vs, B, S, seed=100 + i, ragged=True)
+        jobs.append((ids, lens, osl.generate(ids, lens)))
+    assert len({j[2].tobytes() for j in jobs}) == len(jobs)  # all different
+    gen = hip.ShortlistGenerator(blob, Vs, Vt)
+    bad = []
+
+    def work(i):
+        ids, lens, want = jobs[i]
+        for rep in range(20):
+            got = gen.generate(ids, lens)
+            if not np.array_equal(got, want):
+                bad.append((i, rep))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    gen.close()
+    assert not bad, bad
+
+
+@pytest.mark.gpu
 def test_gpu_rejects_bad_blobs(hip):
     blob = bytearray(synth.make_lexical_shortlist(64, 64, 8, 4, seed=9))
     bad = bytearray(blob); bad[0] ^= 1

@@ -10,7 +10,7 @@ if [ $rc -ne 0 ]; then grep -E "^(FAILED|ERROR)|Error|assert" gpurun_out/test_$T
 timeout -k 10 400 python bench.py --steps 10 --warmup 2 --profile-kernel none --no-cpu-baseline > gpurun_out/bench_$TAG.log 2>&1
 rc=$?; echo "[bench] rc=$rc"; tail -1 gpurun_out/bench_$TAG.log | cut -c1-260
 if [ $rc -ne 0 ]; then tail -20 gpurun_out/bench_$TAG.log; exit $rc; fi
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run through gpurun)}"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --steps 5 --warmup 1 --profile-kernel none --no-cpu-baseline > gpurun_out/prof_$TAG.log 2>&1
 rc=$?; echo "[rocprof] rc=$rc"
 f=$(ls gpurun_out/prof_$TAG/*/*_kernel_stats.csv 2>/dev/null | head -1)

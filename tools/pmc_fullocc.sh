@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC of ONE decode launch at full occupancy (B=4096 -> 256 workgroups): fabric-side
 # fetch bytes and L2 hit/miss requests. Separate passes per counter set.
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run through gpurun)}"
 for c in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
   tag=$(echo $c | tr ' ' '_')
   rm -rf gpurun_out/pmc_full_$tag
