@@ -80,10 +80,22 @@ __device__ __forceinline__ v4i load_frag(rsrc_t r, int voff, int soff) {
 // A operand (16 x K int8) in LDS. epi(tile, acc, colsum, pb) once per finished
 // tile. NB chunks of CH fragments (1 KiB each) are kept in flight per wave.
 // `wave` must be wave-uniform in the compiler's eyes (readfirstlane).
-template <int KS, int NB, class Epi>
+// NT > 0: every wave has exactly NT tiles (n_tiles == 16 NT, known at compile time): the
+// tile loop is then fully unrolled. Not for speed of the loop itself: in the ROLLED loop the
+// compiler's s_waitcnt insertion merges the preheader's and the back edge's pending loads
+// and emits s_waitcnt vmcnt(0) at the top of every iteration (seen in the ISA of the FFN
+// loops), which drains all NB chunks in flight and exposes a full memory round trip per
+// iteration; straight-line code gets exact counts.
+// PADDED (with NT == 0, a column count known only at run time: the output layer): the tile
+// loop runs whole rounds of NB chunks with no conditional inside -- tiles past the last one
+// read zeros (nothing is fetched past a descriptor) and `epi` must ignore them itself (the
+// arg-max epilogue does: its columns are >= N). A branch-free single-block loop is what
+// the s_waitcnt insertion counts exactly; with the `if (chunk < n)` of the general form
+// inside, it falls back to vmcnt(0) at the loop head whenever register allocation shifts.
+template <int KS, int NB, int NT = 0, bool PADDED = false, class Epi>
 __device__ __forceinline__ void stream_gemm(const char *A, int lda, const PreparedWeight &w,
                                             int wave, int lane, Epi &&epi) {
-  const int n_tiles = w.n_tiles;
+  const int n_tiles = NT > 0 ? NT * NW : w.n_tiles;
   const rsrc_t rw = make_rsrc(w.Wp, (unsigned)n_tiles * KS * 1024u);
   const rsrc_t rc = make_rsrc(w.colsum, (unsigned)n_tiles * 64u);
   const rsrc_t rp = make_rsrc(w.pb, (unsigned)n_tiles * 64u);
@@ -105,8 +117,13 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
           bb.f[j * KS + ks] = load_frag(rw, voff, (tile * KS + ks) * 1024);
+#ifdef SLIMT_EXP_NOEPI  // timing experiment (wrong results): no epilogue-constant loads
+        bb.cs[j] = 1;
+        bb.pb[j] = 0.5f;
+#else
         bb.cs[j] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
         bb.pb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
+#endif
       }
     };
     auto compute = [&](const Frags &bb, int c) {
@@ -122,13 +139,49 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
         }
       }
     };
+    if constexpr (NT > 0) {
+      constexpr int NCH = (NT + TPC - 1) / TPC;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) load(b[k], k);
-    for (int c = 0; c < nch; c += NB) {
+      for (int k = 0; k < NB && k < NCH; ++k) load(b[k], k);
+      __builtin_amdgcn_sched_barrier(0);  // straight-line code: keep the scheduler from sinking
+#pragma unroll                            // the prefetches next to their uses
+      for (int c = 0; c < NCH; ++c) {
+        compute(b[c % NB], c);
+        if (c + NB < NCH) load(b[c % NB], c + NB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (PADDED) {
+      static_assert(TPC == 1, "one tile per chunk");
+      // the chunks are requested in the same order before and inside the loop (the
+      // scheduler would otherwise regroup the prologue's loads, and the pending-load
+      // orders of the two loop entries would no longer match)
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        if (c + k < nch) compute(b[k], c + k);
-        load(b[k], c + k + NB);
+        load(b[k], k);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int nchp = (nch + NB - 1) / NB * NB;
+      for (int c = 0; c < nchp; c += NB) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          v4i acc = {0, 0, 0, 0};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ks], b[k].f[ks], acc, 0, 0, 0);
+          epi(wave + NW * (c + k), acc, b[k].cs[0], b[k].pb[0]);
+          load(b[k], c + k + NB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) load(b[k], k);
+      for (int c = 0; c < nch; c += NB) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          if (c + k < nch) compute(b[k], c + k);
+          load(b[k], c + k + NB);
+        }
       }
     }
   } else {
@@ -156,13 +209,51 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
         acc = v4i{0, 0, 0, 0};
       }
     };
+    if constexpr (NT > 0) {
+      constexpr int NCH = NT * CPT;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) load(b[k], k);
-    for (int c = 0; c < nch; c += NB) {
+      for (int k = 0; k < NB && k < NCH; ++k) load(b[k], k);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        compute(b[c % NB], c);
+        if (c + NB < NCH) load(b[c % NB], c + NB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (PADDED) {
+      static_assert(NB % CPT == 0, "whole tiles per round");
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        if (c + k < nch) compute(b[k], c + k);
-        load(b[k], c + k + NB);
+        load(b[k], k);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int nchp = (nch + NB - 1) / NB * NB;
+      for (int c = 0; c < nchp; c += NB) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          const int ks0 = (k % CPT) * CH;  // c is a multiple of NB, NB of CPT
+#pragma unroll
+          for (int p = 0; p < CH; ++p) {
+            const v4i af = *reinterpret_cast<const v4i *>(A + lr * lda + (ks0 + p) * 64 + lg * 16);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, b[k].f[p], acc, 0, 0, 0);
+          }
+          if ((k % CPT) == CPT - 1) {
+            epi(wave + NW * ((c + k) / CPT), acc, b[k].cs[0], b[k].pb[0]);
+            acc = v4i{0, 0, 0, 0};
+          }
+          load(b[k], c + k + NB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) load(b[k], k);
+      for (int c = 0; c < nch; c += NB) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          if (c + k < nch) compute(b[k], c + k);
+          load(b[k], c + k + NB);
+        }
       }
     }
   }
@@ -365,39 +456,45 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   const float minus_inf = -99999999.0f;  // Input.cc:56-61
   const float lowest = -3.402823466e+38f;
   if (DH == 32 && S <= 32) {
-    // two heads per pass: lane = (head parity, key). Software-pipelined over
-    // the H/2 passes: the K rows of pass p+1 are requested as soon as pass p's
-    // scores are done and its V columns as soon as pass p's output is done, so
-    // a memory round trip hides behind half a pass of arithmetic.
+    // Scores: two heads per pass, lane = (head parity, key); the K rows of pass p+1 are
+    // requested as soon as pass p's scores are done. The probabilities of all H heads
+    // go to LDS (pbuf: [H][32]).
+    // Output: V is streamed as WHOLE rows -- one 16-byte load per lane fetches a key's
+    // row for all heads (D floats = 64 lanes x 16 B), lane l owning columns 4 l .. 4 l + 3
+    // of head l / 8 -- in key order, 8 rows per group with the next group in flight, the
+    // first group requested before the first score pass. Per column the sum is still the
+    // ascending-key fmaf chain of the canonical order. 32 V loads per sentence and layer
+    // instead of 128 four-byte ones: this phase is bound by the number of vector-memory
+    // instructions the CU's address unit takes, not by their bytes (measured: with every
+    // K/V load hitting two hot sentences the phase kept 11.3 of its 12.2 us).
+    // Padding is never fetched: a masked key's probability is exactly 0 whatever its score
+    // (exp_p underflows to 0 eighty-six units below the maximum, the mask is -1e8), and
+    // fma(0, v, o) == o. Keys >= len therefore read past the descriptors (V: it ends after
+    // len rows; K: a lane offset beyond it), return zeros and cost no memory traffic.
+    static_assert(DH != 32 || D == 256, "a V row is one 16-byte load per lane");
     const int hh = lane >> 5, j = lane & 31;
     const int jc = j < S ? j : S - 1;
     const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
     f4 k4[8];
-    float v[32];
-    // buffer loads: descriptor and pass offsets are scalar, one VGPR of lane
-    // offset each; keys >= S read past the descriptor and return 0 (p is 0 there)
-    // Padding is never fetched: a masked key's probability is exactly 0 whatever its
-    // score (exp_p underflows to 0 eighty-six units below the maximum, the mask is -1e8),
-    // and fma(0, v, o) == o. Keys >= len therefore read past the descriptors (V: it ends
-    // after len rows; K: a lane offset beyond it) and cost no memory traffic.
+    f4 vq[3][4];  // V rows in flight: three groups of four rows
     const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 4u);
     const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(__builtin_amdgcn_readfirstlane(lenf) * D) * 4u);
     const int koff = j < lenf ? ((hh * (DH / 4) * S + jc) * 4) * 4 : kPastDescriptor;  // [head][dh/4][S][4] floats
-    const int voff = lane * 4;                            // (head parity, d = lane & 31)
+    const int voff = lane * 16;  // columns 4 lane .. 4 lane + 3 of a row
     auto load_k = [&](int hp) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         k4[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
                                            rk, koff, ((2 * hp * (DH / 4) + i) * S * 4) * 4, KV_AUX));
     };
-    auto load_v = [&](int hp) {
+    auto load_v = [&](f4(&vv)[4], int g) {  // rows 4 g .. 4 g + 3
 #pragma unroll
-      for (int jj = 0; jj < 32; ++jj)
-        v[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                              rv, voff, (jj * D + 2 * hp * DH) * 4, KV_AUX));
+      for (int i = 0; i < 4; ++i)
+        vv[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, ((4 * g + i) * D) * 4, KV_AUX));
     };
     load_k(0);
-    load_v(0);
+    load_v(vq[0], 0);  // needed only after the last score pass: a long head start
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int hp = 0; hp < H / 2; ++hp) {
       const int h = 2 * hp + hh;
@@ -410,7 +507,13 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
         s = __builtin_fmaf(q4.z, k4[i].z, s);
         s = __builtin_fmaf(q4.w, k4[i].w, s);
       }
-      if (hp + 1 < H / 2) load_k(hp + 1);
+      if (hp + 1 < H / 2) {
+        load_k(hp + 1);
+      } else {  // the K registers are free: two more groups of V rows
+        load_v(vq[1], 1);
+        load_v(vq[2], 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       if (r.alpha != 1.0f) s = r.alpha * s;
       s = s + mask;
       if (j >= S) s = lowest;
@@ -420,46 +523,61 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       const float p = e / sum;        // keys >= S: exactly 0
       if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
       if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
-      // broadcast the probabilities of this lane's head through LDS
-      r.pbuf[lane] = p;
-      float o = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {  // keys >= S contribute fma(0, v, o) == o
-        const f4 p4 = *(lcf4_ptr)(r.pbuf + (lane & 32) + 4 * i);
-        o = __builtin_fmaf(p4.x, v[4 * i + 0], o);
-        o = __builtin_fmaf(p4.y, v[4 * i + 1], o);
-        o = __builtin_fmaf(p4.z, v[4 * i + 2], o);
-        o = __builtin_fmaf(p4.w, v[4 * i + 3], o);
-      }
-      if (hp + 1 < H / 2) load_v(hp + 1);
-      r.arow[2 * hp * DH + lane] = (char)quantize1(o, r.aq_o);
+      r.pbuf[h * 32 + j] = p;
     }
+    // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
+    const int ph = (lane >> 3) * 32;
+    f4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      f4(&cur)[4] = vq[g % 3];
+      const f4 p4 = *(lcf4_ptr)(r.pbuf + ph + 4 * g);
+      const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {  // keys >= S: p == 0, fma(0, v, o) == o
+        const f4 v4 = cur[c];
+        o.x = __builtin_fmaf(pj[c], v4.x, o.x);
+        o.y = __builtin_fmaf(pj[c], v4.y, o.y);
+        o.z = __builtin_fmaf(pj[c], v4.z, o.z);
+        o.w = __builtin_fmaf(pj[c], v4.w, o.w);
+      }
+      if (g + 3 < 8) load_v(vq[g % 3], g + 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+        pack4(quantize1(o.x, r.aq_o), quantize1(o.y, r.aq_o), quantize1(o.z, r.aq_o), quantize1(o.w, r.aq_o));
   } else if (LONG && DH == 32 && S <= 128) {
     attention_row_long<D, DH, KV_AUX>(r, lane);
   } else if (DH == 64 && S <= 32) {
-    // d_head 64 ("base"): one head per pass. Scores: lane = key (both wave
-    // halves hold the same 32 keys, so the 32-lane reductions serve both);
-    // output: lane = d. 16 K loads of 16 B and 32 V loads of 4 B per lane and
-    // pass, all issued before the first use.
+    // d_head 64 ("base"): one head per score pass, lane = key (both wave halves hold the
+    // same 32 keys, so the 32-lane reductions serve both); all heads' probabilities go to
+    // LDS, then V is streamed as whole rows (D = 512 floats = two 16-byte loads per lane:
+    // columns 4 l .. 4 l + 3 of head l / 16 and of head 4 + l / 16), 4 rows per group with
+    // the next group in flight: 64 V loads per sentence and layer instead of 256.
+    static_assert(DH != 64 || D == 512, "a V row is two 16-byte loads per lane");
     const int j = lane & 31;
     const int jc = j < S ? j : S - 1;
     const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
     const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 4u);
     const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(__builtin_amdgcn_readfirstlane(lenf) * D) * 4u);  // padding is not fetched
     const int koff = j < lenf ? jc * 16 : kPastDescriptor;  // [head][dh/4][S][4] floats
-    const int voff = lane * 4;   // d = lane
+    const int voff = lane * 16;
+    f4 vq[3][4];  // V rows in flight: three groups of two rows (two halves each)
+    auto load_v = [&](f4(&vv)[4], int g) {  // rows 2 g, 2 g + 1
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        vv[2 * i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, ((2 * g + i) * D) * 4, KV_AUX));
+        vv[2 * i + 1] = __builtin_bit_cast(
+            f4, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, ((2 * g + i) * D + D / 2) * 4, KV_AUX));
+      }
+    };
 #pragma unroll 1
     for (int h = 0; h < H; ++h) {
       f4 k4[16];
-      float v[32];
 #pragma unroll
       for (int i = 0; i < 16; ++i)
         k4[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
                                            rk, koff, ((h * (DH / 4) + i) * S * 4) * 4, KV_AUX));
-#pragma unroll
-      for (int jj = 0; jj < 32; ++jj)
-        v[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                              rv, voff, (jj * D + h * DH) * 4, KV_AUX));
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -479,19 +597,38 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       if (lane < 32) {
         if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
         if (r.align && h == 0 && j < len) r.align[j] = p;
+        r.pbuf[h * 32 + j] = p;
       }
-      r.pbuf[lane] = p;
-      float o = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {  // keys >= S: fma(0, 0, o) == o
-        const f4 p4 = *(lcf4_ptr)(r.pbuf + (lane & 32) + 4 * i);
-        o = __builtin_fmaf(p4.x, v[4 * i + 0], o);
-        o = __builtin_fmaf(p4.y, v[4 * i + 1], o);
-        o = __builtin_fmaf(p4.z, v[4 * i + 2], o);
-        o = __builtin_fmaf(p4.w, v[4 * i + 3], o);
-      }
-      r.arow[h * DH + lane] = (char)quantize1(o, r.aq_o);
     }
+    load_v(vq[0], 0);  // (held across the head loop, a group of V rows would be spilled)
+    load_v(vq[1], 1);
+    load_v(vq[2], 2);
+    __builtin_amdgcn_sched_barrier(0);
+    const int ph0 = (lane >> 4) * 32, ph1 = (4 + (lane >> 4)) * 32;
+    f4 o0 = {0.0f, 0.0f, 0.0f, 0.0f}, o1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      f4(&cur)[4] = vq[g % 3];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {  // keys >= S: p == 0, fma(0, v, o) == o
+        const float pa = r.pbuf[ph0 + 2 * g + c], pb = r.pbuf[ph1 + 2 * g + c];
+        const f4 v0 = cur[2 * c], v1 = cur[2 * c + 1];
+        o0.x = __builtin_fmaf(pa, v0.x, o0.x);
+        o0.y = __builtin_fmaf(pa, v0.y, o0.y);
+        o0.z = __builtin_fmaf(pa, v0.z, o0.z);
+        o0.w = __builtin_fmaf(pa, v0.w, o0.w);
+        o1.x = __builtin_fmaf(pb, v1.x, o1.x);
+        o1.y = __builtin_fmaf(pb, v1.y, o1.y);
+        o1.z = __builtin_fmaf(pb, v1.z, o1.z);
+        o1.w = __builtin_fmaf(pb, v1.w, o1.w);
+      }
+      if (g + 3 < 16) load_v(vq[g % 3], g + 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+        pack4(quantize1(o0.x, r.aq_o), quantize1(o0.y, r.aq_o), quantize1(o0.z, r.aq_o), quantize1(o0.w, r.aq_o));
+    *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) =
+        pack4(quantize1(o1.x, r.aq_o), quantize1(o1.y, r.aq_o), quantize1(o1.z, r.aq_o), quantize1(o1.w, r.aq_o));
   } else {
     // generic: one head per pass, keys lane and lane + 64
     const int j0 = lane < S ? lane : S - 1;
@@ -566,6 +703,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr int LDF = D + 4;    // f32 row stride
   constexpr int LDA = D + 16;   // int8 row stride (K = D)
   constexpr int LDA3 = F + 16;  // int8 row stride (K = F)
+  // column tiles per wave where every wave has the same number (else 0: rolled loops)
+  constexpr int NT_D = (D / 16) % NW == 0 ? (D / 16) / NW : 0;
+  constexpr int NT_F1 = (F / 16) % NW == 0 ? (F / 16) / NW : 0;
   const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
@@ -716,7 +856,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       SLIMT_STAMP(sb + 2);
       // ---- cross-attention (Modules.cc:287-319) --------------------------
       // Q projection -> xs (x is dead until the end of the layer)
-      stream_gemm<KSD, 1>(A1, LDA, L.q, wave, lane, [&](int tile, const v4i &acc, int cq, float pb) {
+      stream_gemm<KSD, 1, NT_D>(A1, LDA, L.q, wave, lane, [&](int tile, const v4i &acc, int cq, float pb) {
         const int col = tile * 16 + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) xs[(lg * 4 + r) * LDF + col] = dequant(acc[r], cq, L.q.u, pb);
@@ -749,7 +889,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       __syncthreads();
       SLIMT_STAMP(sb + 4);
       // O projection + residual h (Modules.cc:308-314)
-      stream_gemm<KSD, 1>(A1, LDA, L.o, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
+      stream_gemm<KSD, 1, NT_D>(A1, LDA, L.o, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
         const int col = tile * 16 + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -765,7 +905,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       __syncthreads();
       SLIMT_STAMP(sb + 6);
       // ---- FFN (Modules.cc:251-257) ----------------------------------------
-      stream_gemm<KSD, SLIMT_NB_FFN>(A1, LDA, L.ffn1, wave, lane, [&](int tile, const v4i &acc, int c1, float pb) {
+      stream_gemm<KSD, SLIMT_NB_FFN, NT_F1>(A1, LDA, L.ffn1, wave, lane, [&](int tile, const v4i &acc, int c1, float pb) {
         const int col = tile * 16 + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -776,7 +916,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       });
       __syncthreads();
       SLIMT_STAMP(sb + 7);
-      stream_gemm<KSF, SLIMT_NB_FFN>(A3, LDA3, L.ffn2, wave, lane, [&](int tile, const v4i &acc, int c2, float pb) {
+      stream_gemm<KSF, SLIMT_NB_FFN, NT_D>(A3, LDA3, L.ffn2, wave, lane, [&](int tile, const v4i &acc, int c2, float pb) {
         const int col = tile * 16 + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -805,17 +945,31 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       bv[r] = -3.402823466e+38f;
       bi[r] = 0x7fffffff;
     }
-    stream_gemm<KSD, SLIMT_NB_OUT>(A1, LDA, outw, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
+#ifdef SLIMT_EXP_LOGITS_TWICE  // timing experiment: the same loop twice, stamped in between
+    stream_gemm<KSD, SLIMT_NB_OUT, 0, (KSD >= 4)>(A1, LDA, outw, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
       const int col = tile * 16 + lr;
-      if (col < outw.N) {
+      const bool in_range = col < outw.N;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = dequant(acc[r], co, a.out.u, pb);
-          // a lane's columns only grow, so strict > keeps its first maximum
-          const bool better = v > bv[r];
-          bv[r] = better ? v : bv[r];
-          bi[r] = better ? col : bi[r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float v = dequant(acc[r], co, a.out.u, pb);
+        const bool better = in_range && v > bv[r];
+        bv[r] = better ? v : bv[r];
+        bi[r] = better ? col : bi[r];
+      }
+    });
+    __syncthreads();
+    SLIMT_STAMP(45);
+#endif
+    stream_gemm<KSD, SLIMT_NB_OUT, 0, (KSD >= 4)>(A1, LDA, outw, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
+      const int col = tile * 16 + lr;
+      const bool in_range = col < outw.N;  // no branch: the streaming loop stays one block
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = dequant(acc[r], co, a.out.u, pb);
+        // a lane's columns only grow, so strict > keeps its first maximum
+        const bool better = in_range && v > bv[r];
+        bv[r] = better ? v : bv[r];
+        bi[r] = better ? col : bi[r];
       }
     });
 #pragma unroll
@@ -1149,7 +1303,7 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
           ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(bb)) * S * D);
           ar.qrow = (lcf_ptr)(X + row * LDF);
           ar.arow = (lc_ptr)(A1 + row * LDA);
-          ar.pbuf = (SLIMT_LDS float *)(reinterpret_cast<float *>(HB0) + wave * 64);
+          ar.pbuf = (SLIMT_LDS float *)(reinterpret_cast<float *>(HB0) + wave * 256);  // [H][32]: spans HB0 and HB1 (16 KiB)
           ar.S = S;
           ar.len = rr ? len[1] : len[0];
           ar.alpha = a.alpha;
