@@ -218,6 +218,27 @@ int slimt_hip_decode_begin(slimt_hip_ctx *ctx, const uint32_t *shortlist,
 int slimt_hip_decode_step(slimt_hip_ctx *ctx, const uint32_t *prev,
                           float *logits, float *attn, float *states);
 
+/* The same three steps with the reference's own ARGUMENTS, for the class-level
+ * mirror (host/Transformer.hh): Encoder::forward takes the transformed embedding
+ * and the mask (Transformer.cc:57-69), Decoder::step takes encoder_out, mask and
+ * the caller's states on every call (Transformer.cc:120-183).
+ * _encode_embedded: embedding host [B,S,D] (after transform_embedding), lengths
+ *   [B] (= the mask: the first lengths[b] keys are tokens) -> enc_out host [B,S,D].
+ *   Always the per-stage kernels (the persistent encoder starts from token ids).
+ * _decode_begin_from: like _decode_begin for an encoder output handed in from
+ *   the host (uploads it, computes the cross-attention K/V, gathers the shortlist).
+ * _decode_step_states: like _decode_step, but the SSRU cells are the caller's:
+ *   states_in [Ld,B,D] is uploaded first, states_out receives them after the step. */
+int slimt_hip_encode_embedded(slimt_hip_ctx *ctx, const float *embedding,
+                              const uint32_t *lengths, size_t B, size_t S,
+                              float *enc_out);
+int slimt_hip_decode_begin_from(slimt_hip_ctx *ctx, const float *encoder_out,
+                                const uint32_t *lengths, size_t B, size_t S,
+                                const uint32_t *shortlist, size_t n_shortlist);
+int slimt_hip_decode_step_states(slimt_hip_ctx *ctx, const uint32_t *prev,
+                                 const float *states_in, float *logits,
+                                 float *attn, float *states_out);
+
 /* ---- lexical shortlist (next row f3: slimt/Shortlist.{hh,cc}) --------------
  * Replaces ShortlistGenerator (Shortlist.hh:38-90): _create = the constructor's
  * load() over the binary shortlist blob (Shortlist.cc:41-104; layout

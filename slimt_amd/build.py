@@ -73,7 +73,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 HOST_DIR = os.path.join(HERE, "host")
 HOST_TEST = os.path.join(LIB_DIR, "slimt_hip_host_test")
-HOST_SOURCES = ["Io.cc", "QMM.cc", "Model.cc", "Shortlist.cc", "Service.cc", "host_test.cc"]
+HOST_SOURCES = ["Io.cc", "QMM.cc", "Model.cc", "Shortlist.cc", "Service.cc", "Transformer.cc", "host_test.cc"]
 
 
 def build_host(force: bool = False) -> str:

@@ -32,6 +32,7 @@ SYMBOLS = [
     "slimt_hip_shortlist_generate", "slimt_hip_shortlist_generate_device",
     "slimt_hip_translate_device_generated",
     "slimt_hip_translate_async", "slimt_hip_host_alloc", "slimt_hip_host_free",
+    "slimt_hip_encode_embedded", "slimt_hip_decode_begin_from", "slimt_hip_decode_step_states",
 ]
 
 K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED, K_ENCODE_FUSED = range(9)
@@ -101,6 +102,9 @@ def lib():
     L.slimt_hip_translate_device.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp, i32]
     L.slimt_hip_encode.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp]
     L.slimt_hip_decode_begin.argtypes = [vp, vp, sz]
+    L.slimt_hip_encode_embedded.argtypes = [vp, vp, vp, sz, sz, vp]
+    L.slimt_hip_decode_begin_from.argtypes = [vp, vp, vp, sz, sz, vp, sz]
+    L.slimt_hip_decode_step_states.argtypes = [vp, vp, vp, vp, vp, vp]
     L.slimt_hip_decode_step.argtypes = [vp, vp, vp, vp, vp]
     L.slimt_hip_profile_enable.argtypes = [vp, i32]
     L.slimt_hip_profile_read.argtypes = [vp, vp, vp, vp, vp]

@@ -870,9 +870,11 @@ int check_batch(const slimt_hip_ctx *c, size_t B, size_t S) {
 
 // Model.cc:195-201: embedding + Encoder::forward. d_ids/d_len already in
 // ctx->ids / ctx->lengths. Result in ctx->x0.
+// embedded: ctx->x0 already holds the transformed embedding [B,S,D] (Encoder::forward's
+// argument, Transformer.cc:57): the stage kernels run from there.
 int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layers,
                   const uint32_t *d_ids = nullptr, const uint32_t *d_lengths = nullptr,
-                  const PackArgs *pack = nullptr) {
+                  const PackArgs *pack = nullptr, bool embedded = false) {
   const slimt_hip_model *m = c->model;
   hipStream_t st = c->stream;
   const int M = B * S, D = m->D;
@@ -882,7 +884,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
   c->have_encoder_out = false;
   c->decode_ready = false;
   c->kv_ready = false;
-  if (c->decode_mode != 1 && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
+  if (!embedded && c->decode_mode != 1 && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
     // embedding + every encoder layer + the decoder's K/V cache in one launch
     FusedEncodeArgs f;
     f.B = B; f.S = S; f.Le = m->Le; f.Ld = m->Ld;
@@ -936,7 +938,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     c->kv_ready = true;
     return 0;
   }
-  if (c->decode_mode != 1 && long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
+  if (!embedded && c->decode_mode != 1 && long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
     // 32 < S <= 128: one persistent workgroup per sentence (kernels.hip, encode_long_kernel)
     LongEncodeArgs a;
     FusedEncodeArgs &f = a.f;
@@ -989,7 +991,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     return 0;
   }
   float *x = c->x0.as<float>(), *y = c->x1.as<float>();
-  HIPCHK(launch_embed_encoder(embed_args(c), c->ids.as<uint32_t>(), B, S, x, st));
+  if (!embedded) HIPCHK(launch_embed_encoder(embed_args(c), c->ids.as<uint32_t>(), B, S, x, st));
   if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, x, nbytes, hipMemcpyDeviceToHost, st));
   const int rpb = M >= 2048 ? 64 : (M >= 512 ? 32 : 16);
   const int rpb_ln = M >= 4096 ? 32 : 16;
@@ -1491,6 +1493,44 @@ extern "C" int slimt_hip_encode(slimt_hip_ctx *ctx, const uint32_t *src_ids,
   return 0;
 }
 
+extern "C" int slimt_hip_encode_embedded(slimt_hip_ctx *ctx, const float *embedding,
+                                         const uint32_t *lengths, size_t B, size_t S, float *enc_out) {
+  if (!ctx || !embedding || !lengths || !enc_out) return fail(-1, "null argument");
+  RCCHK(check_batch(ctx, B, S));
+  const slimt_hip_model *m = ctx->model;
+  for (size_t i = 0; i < B; ++i)
+    if (lengths[i] > S) return fail(-1, "length %u > S", lengths[i]);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t st = ctx->stream;
+  const size_t nbytes = B * S * (size_t)m->D * 4;
+  HIPCHK(hipMemcpyAsync(ctx->x0.p, embedding, nbytes, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->lengths.p, lengths, B * 4, hipMemcpyHostToDevice, st));
+  RCCHK(encode_device(ctx, (int)B, (int)S, nullptr, nullptr, nullptr, nullptr, nullptr, true));
+  HIPCHK(hipMemcpyAsync(enc_out, ctx->x0.p, nbytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int slimt_hip_decode_begin_from(slimt_hip_ctx *ctx, const float *encoder_out,
+                                           const uint32_t *lengths, size_t B, size_t S,
+                                           const uint32_t *shortlist, size_t n_shortlist) {
+  if (!ctx || !encoder_out || !lengths) return fail(-1, "null argument");
+  RCCHK(check_batch(ctx, B, S));
+  const slimt_hip_model *m = ctx->model;
+  for (size_t i = 0; i < B; ++i)
+    if (lengths[i] > S) return fail(-1, "length %u > S", lengths[i]);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(ctx->x0.p, encoder_out, B * S * (size_t)m->D * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->lengths.p, lengths, B * 4, hipMemcpyHostToDevice, st));
+  ctx->B = (int)B;
+  ctx->S = (int)S;
+  ctx->have_encoder_out = true;
+  ctx->kv_ready = false;  // the cross-attention K/V of THIS encoder output are computed below
+  ctx->decode_ready = false;
+  return slimt_hip_decode_begin(ctx, shortlist, n_shortlist);
+}
+
 extern "C" int slimt_hip_decode_begin(slimt_hip_ctx *ctx, const uint32_t *shortlist,
                                       size_t n_shortlist) {
   if (!ctx) return fail(-1, "ctx is NULL");
@@ -1508,8 +1548,23 @@ extern "C" int slimt_hip_decode_begin(slimt_hip_ctx *ctx, const uint32_t *shortl
   return 0;
 }
 
+static int decode_step_impl(slimt_hip_ctx *ctx, const uint32_t *prev, const float *states_in,
+                            float *logits, float *attn, float *states);
+
 extern "C" int slimt_hip_decode_step(slimt_hip_ctx *ctx, const uint32_t *prev, float *logits,
                                      float *attn, float *states) {
+  return decode_step_impl(ctx, prev, nullptr, logits, attn, states);
+}
+
+extern "C" int slimt_hip_decode_step_states(slimt_hip_ctx *ctx, const uint32_t *prev,
+                                            const float *states_in, float *logits, float *attn,
+                                            float *states_out) {
+  if (!states_in) return fail(-1, "null argument");
+  return decode_step_impl(ctx, prev, states_in, logits, attn, states_out);
+}
+
+static int decode_step_impl(slimt_hip_ctx *ctx, const uint32_t *prev, const float *states_in,
+                            float *logits, float *attn, float *states) {
   if (!ctx || !logits) return fail(-1, "null argument");
   if (!ctx->decode_ready) return fail(-1, "decode_step before decode_begin");
   const slimt_hip_model *m = ctx->model;
@@ -1521,6 +1576,8 @@ extern "C" int slimt_hip_decode_step(slimt_hip_ctx *ctx, const uint32_t *prev, f
       if (prev[i] >= (uint32_t)m->V) return fail(-1, "token id %u out of range", prev[i]);
     HIPCHK(hipMemcpyAsync(ctx->prev.p, prev, B * 4, hipMemcpyHostToDevice, st));
   }
+  if (states_in)  // the caller's SSRU cells (Decoder::step's `states`, Transformer.cc:120-128)
+    HIPCHK(hipMemcpyAsync(ctx->state.p, states_in, (size_t)m->Ld * B * D * 4, hipMemcpyHostToDevice, st));
   HIPCHK(launch_embed_decoder(embed_args(ctx), ctx->prev.as<uint32_t>(), (int)B, prev == nullptr,
                               ctx->dx.as<float>(), st));
   if (attn) HIPCHK(ctx->attn_dbg.reserve(B * (size_t)m->H * S * 4));

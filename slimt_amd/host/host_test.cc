@@ -22,6 +22,7 @@
 #include "Io.hh"
 #include "Model.hh"
 #include "Shortlist.hh"
+#include "Transformer.hh"
 #include "QMM.hh"
 
 namespace {
@@ -214,6 +215,80 @@ static int service_errors_main(int argc, char **argv) {
   return 0;
 }
 
+// host_test --transformer model.bin case.bin out.bin
+// The class-level mirror (host/Transformer.hh) driven the way slimt::Model::forward and
+// Model::decode drive the reference's classes (Model.cc:111-204): index_select +
+// transform_embedding, Encoder::forward, Decoder::start_states, then Decoder::step +
+// greedy_sample* per step with the EOS bookkeeping. case.bin as in the default mode.
+// out.bin: f32 encoder_out[B*S*D]; per sentence u32 n, u32 tokens[n], f32 align[n][len].
+static int transformer_main(int argc, char **argv) {
+  using namespace slimt;
+  if (argc != 5) return 2;
+  std::vector<char> bin = slurp(argv[2]), cs = slurp(argv[3]);
+  Cur c{cs.data()};
+  const uint32_t Le = c.get<uint32_t>(), Ld = c.get<uint32_t>(), H = c.get<uint32_t>();
+  const uint32_t B = c.get<uint32_t>(), S = c.get<uint32_t>(), n_sl = c.get<uint32_t>();
+  c.get<uint32_t>(); c.get<uint32_t>(); c.get<uint32_t>();  // M, K, N of the qmm part: unused here
+  const float limit = c.get<float>();
+  c.get<float>(); c.get<float>();
+  auto ids = c.vec<uint32_t>(size_t(B) * S);
+  auto lens = c.vec<uint32_t>(B);
+  auto sl = c.vec<uint32_t>(n_sl);
+  std::ofstream out(argv[4], std::ios::binary);
+  try {
+    Transformer transformer(Le, Ld, H, /*feed_forward_depth=*/0, View{bin.data(), bin.size()});
+    const Vocabulary vocabulary(transformer.vocab(), /*eos_id=*/0, /*pad_id=*/0);
+    // Input (Input.cc:20-63): indices [B,S] and the additive mask
+    Tensor indices(Type::u32, Shape({B, S}), "indices");
+    std::memcpy(indices.data<uint32_t>(), ids.data(), ids.size() * sizeof(uint32_t));
+    Tensor mask(Type::f32, Shape({B, S}), "mask");
+    for (uint32_t b = 0; b < B; ++b)
+      for (uint32_t j = 0; j < S; ++j) mask.data<float>()[size_t(b) * S + j] = j < lens[b] ? 0.0F : -99999999.0F;
+    // Model::forward (Model.cc:187-204)
+    Tensor word_embedding = index_select(transformer.embedding(), indices, "word_embedding");
+    transform_embedding(word_embedding);
+    Tensor encoder_out = transformer.encoder().forward(word_embedding, mask);
+    put(out, encoder_out.data<float>(), encoder_out.size());
+    // Model::decode (Model.cc:111-185)
+    std::optional<Words> shortlist;
+    if (n_sl) shortlist = sl;
+    std::vector<bool> complete(B, false);
+    std::vector<Words> sentences(B);
+    std::vector<std::vector<std::vector<float>>> alignments(B);
+    const Decoder &decoder = transformer.decoder();
+    std::vector<Tensor> states = decoder.start_states(B);
+    Words previous;
+    const size_t max_steps = static_cast<size_t>(limit * static_cast<float>(S));
+    size_t remaining = B;
+    for (size_t i = 0; i == 0 || (i < max_steps && remaining > 0); ++i) {
+      auto [logits, attn] = decoder.step(encoder_out, mask, states, previous, shortlist);
+      previous = shortlist ? greedy_sample_from_words(logits, vocabulary, *shortlist, B)
+                           : greedy_sample(logits, vocabulary, B);
+      size_t finished = 0;
+      for (uint32_t b = 0; b < B; ++b) {
+        if (!complete[b]) {  // update_alignment, then record (Model.cc:84-108,127-137)
+          const float *row = attn.data<float>() + size_t(b) * H * S;  // head 0
+          alignments[b].emplace_back(row, row + lens[b]);
+          complete[b] = previous[b] == vocabulary.eos_id();
+          sentences[b].push_back(previous[b]);
+        }
+        finished += complete[b] ? 1 : 0;
+      }
+      remaining = B - finished;
+    }
+    for (uint32_t b = 0; b < B; ++b) {
+      const uint32_t n = static_cast<uint32_t>(sentences[b].size());
+      put(out, &n, 1);
+      put(out, sentences[b].data(), n);
+      for (const auto &row : alignments[b]) put(out, row.data(), row.size());
+    }
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "host_test: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
+
 // host_test --load model.bin: io::load_items alone (no GPU): prints the item count or the error.
 static int load_main(int argc, char **argv) {
   if (argc != 3) return 2;
@@ -233,6 +308,7 @@ int main(int argc, char **argv) {
     return batching_main(argc, argv);
   if (argc >= 2 && std::string(argv[1]) == "--service-errors") return service_errors_main(argc, argv);
   if (argc >= 2 && std::string(argv[1]) == "--load") return load_main(argc, argv);
+  if (argc >= 2 && std::string(argv[1]) == "--transformer") return transformer_main(argc, argv);
   if (argc != 4 && argc != 5) {
     std::fprintf(stderr, "usage: %s model.bin case.bin out.bin [lexical_shortlist.bin]\n", argv[0]);
     return 2;

@@ -132,3 +132,48 @@ def test_cpp_shortlist_generator_then_forward(hip, oracle, synth_models):
         off += 4 * k + 4 * k * int(lens[b])
         assert k == w_ln[b] and np.array_equal(toks, w_out[b, :k])
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,eos_bias,B,S,n_sl", [("micro", 3.0, 6, 8, 128), ("tiny11", 6.0, 9, 14, 1024),
+                                                      ("tiny11", 8.0, 20, 32, 0), ("base", 6.0, 5, 11, 512)])
+def test_cpp_transformer_classes_drive_model_forward(hip, oracle, synth_models, preset, eos_bias, B, S, n_sl):
+    """host/Transformer.hh: Encoder::forward(embedding, mask), Decoder::start_states / step(encoder_out,
+    mask, states, previous, shortlist), greedy_sample*, transform_embedding, index_select with the
+    reference's signatures (Transformer.hh:15-72), driven like Model::forward + Model::decode
+    (Model.cc:111-204): encoder output, tokens and alignment rows equal the oracle's."""
+    from slimt_amd import synth
+    exe = _build_host()
+    m = synth_models(preset, eos_bias)
+    ids, lens = synth.make_batch(m.V, B, S, seed=B + S + 40, ragged=True)
+    sl = synth.make_shortlist(m.V, n_sl) if n_sl else np.zeros(0, np.uint32)
+    with tempfile.TemporaryDirectory() as d:
+        mb, cb, ob = (os.path.join(d, n) for n in ("model.bin", "case.bin", "out.bin"))
+        open(mb, "wb").write(synth.write_bin(m))
+        with open(cb, "wb") as f:
+            f.write(struct.pack("<9I3f", m.enc_layers, m.dec_layers, m.H, B, S, sl.size, 0, 0, 0, 1.5, 1.0, 1.0))
+            for a in (ids, lens, sl):
+                f.write(np.ascontiguousarray(a).tobytes())
+        res = subprocess.run([exe, "--transformer", mb, cb, ob], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr
+        raw = open(ob, "rb").read()
+    oracle.set_mode(oracle.PORTABLE)
+    om = oracle.OracleModel(m)
+    mask = oracle.make_mask(lens, S)
+    want_enc = om.encode(om.embed(ids), mask)
+    w_out, w_ln, w_al, _ = om.translate(ids, lens, sl if n_sl else None, 1.5, 0, want_align=True)
+    oracle.set_mode(oracle.FAITHFUL)
+    enc = np.frombuffer(raw, np.float32, B * S * m.D, 0).reshape(B, S, m.D)
+    assert np.array_equal(enc, want_enc)
+    off = 4 * B * S * m.D
+    for b in range(B):
+        (n,) = struct.unpack_from("<I", raw, off)
+        off += 4
+        toks = np.frombuffer(raw, np.uint32, n, off)
+        off += 4 * n
+        L = int(lens[b])
+        al = np.frombuffer(raw, np.float32, n * L, off).reshape(n, L)
+        off += 4 * n * L
+        assert n == w_ln[b] and np.array_equal(toks, w_out[b, :n]), b
+        assert np.array_equal(al, w_al[b, :n, :L]), b
+    assert off == len(raw)
