@@ -204,7 +204,8 @@ int affine_common(const float *x, size_t M, size_t K, const int8_t *W_nk, size_t
     HIPCHK(t.y.reserve(M * Nout * sizeof(float)));
     g.y = t.y.as<float>();
     g.ldy = (int)Nout;
-    HIPCHK(launch_gemm(g, EPI_PLAIN, M >= 64 ? 64 : 16, st));
+    // many rows: the 128-row tiling (rows_per_block 0 asks for it where it applies)
+    HIPCHK(launch_gemm(g, EPI_PLAIN, M >= 1024 ? 0 : (M >= 64 ? 64 : 16), st));
     HIPCHK(hipMemcpyAsync(y, t.y.p, M * Nout * sizeof(float), hipMemcpyDeviceToHost, st));
   }
   HIPCHK(hipStreamSynchronize(st));

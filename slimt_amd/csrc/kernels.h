@@ -104,6 +104,10 @@ struct GemmArgs {
 // fragment). Returns the number of column blocks used (EPI_ARGMAX: n_parts).
 int gemm_col_blocks(int N, int epilogue, int *nt_out);
 hipError_t launch_gemm(const GemmArgs &a, int epilogue, int rows_per_block, hipStream_t st);
+// Large-M tiling of the same GEMM (gemm_tile.hip): 128-row blocks, bit-identical results.
+// launch_gemm routes EPI_PLAIN / EPI_RELU_Q calls there when gemm_tile_supported().
+bool gemm_tile_supported(const GemmArgs &a, int epilogue);
+hipError_t launch_gemm_tile(const GemmArgs &a, int epilogue, hipStream_t st);
 
 struct SsruArgs {
   const float *x = nullptr;  // [B][D]

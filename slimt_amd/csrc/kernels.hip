@@ -434,6 +434,10 @@ static hipError_t launch_gemm_t(const GemmKArgs &ka, int epi, dim3 grid, hipStre
 
 hipError_t launch_gemm(const GemmArgs &a, int epilogue, int rows_per_block, hipStream_t st) {
   if (a.w.K % 64 != 0 || a.w.K <= 0 || a.M <= 0 || a.w.N <= 0) return hipErrorInvalidValue;
+  // the 128-row tiling (gemm_tile.hip): where it measures faster (its header), or on request
+  if ((epilogue == EPI_RELU_Q || rows_per_block == 0) && gemm_tile_supported(a, epilogue))
+    return launch_gemm_tile(a, epilogue, st);
+  if (rows_per_block == 0) rows_per_block = a.M >= 512 ? 32 : 16;
   if ((a.x_f32 == nullptr) == (a.x_i8 == nullptr)) return hipErrorInvalidValue;
   if (a.x_f32 && (a.lda % 4 != 0)) return hipErrorInvalidValue;
   if (a.x_i8 && (a.lda % 16 != 0)) return hipErrorInvalidValue;

@@ -40,6 +40,9 @@ SHAPES = [
     (1, 64, 8), (3, 64, 16), (16, 64, 16), (17, 128, 24), (5, 256, 40),
     (64, 256, 256), (64, 256, 512), (64, 256, 1536), (64, 1536, 256), (64, 256, 4096),
     (256, 512, 512), (2048, 256, 256), (300, 256, 1536), (130, 2048, 512), (33, 512, 2048),
+    # many rows: slimt_hip_affine takes the 128-row tiling (gemm_tile.hip): a ragged last row
+    # block, K in one / three / four 512-deep chunks, N not a multiple of the 128-column block
+    (1100, 512, 512), (1024, 1536, 256), (1300, 2048, 576), (2048, 256, 1536),
 ]
 
 
