@@ -68,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--decoder-budget", type=int, default=-1,
                     help="decoder workgroups admitted at a time (-1 = library default, 0 = no limit)")
     ap.add_argument("--decode-mode", type=int, default=0, help="0 = fused persistent decoder, 1 = step-wise")
+    ap.add_argument("--kv-policy", type=int, default=0,
+                    help="decoder K/V cache loads: 0 = chosen per launch (default), 1 = temporal, 2 = non-temporal")
     ap.add_argument("--sustained-steps", type=int, default=40,
                     help="after the timed region, one longer untimed-by-the-driver region of this many steps "
                          "(reported as `sustained`; 0 = skip)")
@@ -289,6 +291,8 @@ def main():
         gm = capi.Model(model, device=local_rank)
         if args.decoder_budget >= 0:
             gm.set_decoder_budget(args.decoder_budget)
+        if args.kv_policy:
+            gm.set_kv_cache_policy(args.kv_policy)
         ctxs = [capi.Context(gm, B, S) for _ in range(W)]
         for c in ctxs:
             c.set_decode_mode(args.decode_mode)

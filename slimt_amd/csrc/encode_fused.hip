@@ -408,70 +408,127 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     }
     __syncthreads();
     SLIMT_ESTAMP(5);
-    // ---- FFN (Modules.cc:326-331): F is walked in chunks of 256 columns; the
-    // FFN2 accumulators of this wave's column tile stay in registers.
+    // ---- FFN (Modules.cc:326-331). The whole hidden layer (32 x F int8, 49 KiB for F = 1536)
+    // lives in the dead q/k/v buffers, so the phase is two streams with ONE barrier between
+    // them (FFN1: 6 column tiles per wave, three in flight; FFN2: 24 k-steps of this wave's
+    // column tile, three chunks of four in flight) instead of a barrier per 256 hidden columns
+    // (13 per layer before: every barrier re-aligned the waves and drained the weight stream).
+    // The MFMA operands are swapped (weights as A): an accumulator lane holds 4 consecutive
+    // columns of one row, so the requantised hidden values leave as one 4-byte LDS store per
+    // row tile and the FFN2 result meets the residual as float4.
     {
+      constexpr int LDH = 64 * KSF + 16;  // hidden row stride (bytes)
+      char *Hb = reinterpret_cast<char *>(qb);
+      static_assert((size_t)ER * LDH <= (size_t)ER * LDQQ * 4 + 2 * (size_t)ER * LDQ * 4, "hidden layer fits q/k/v");
+      constexpr int NT1 = (KSF * 4) / ENW;  // FFN1 column tiles per wave
+      static_assert((KSF * 4) % ENW == 0 && KSF % 4 == 0, "whole tiles / whole chunks per wave");
+      {
+        v4i a0[KSD], a1[KSD];  // this wave's view of the 32 input rows, all of K
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+          a0[ks] = *reinterpret_cast<const v4i *>(Aq + lr * LDA + ks * 64 + lg * 16);
+          a1[ks] = *reinterpret_cast<const v4i *>(Aq + (16 + lr) * LDA + ks * 64 + lg * 16);
+        }
+        const rsrc_t r1 = make_rsrc(L.ffn1.Wp, (unsigned)L.ffn1.n_tiles * KSD * 1024u);
+        const rsrc_t r1c = make_rsrc(L.ffn1.colsum, (unsigned)L.ffn1.n_tiles * 64u);
+        const rsrc_t r1p = make_rsrc(L.ffn1.pb, (unsigned)L.ffn1.n_tiles * 64u);
+        v4i bw[3][KSD], cs4[3];
+        float4 pb4[3];
+        auto load1 = [&](int buf, int i) {
+          const int tile = wave + ENW * i;
+#pragma unroll
+          for (int ks = 0; ks < KSD; ++ks)
+            bw[buf][ks] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r1, lane * 16, (tile * KSD + ks) * 1024, 0));
+          cs4[buf] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r1c, lg * 16, tile * 64, 0));
+          pb4[buf] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1p, lg * 16, tile * 64, 0));
+        };
+#pragma unroll
+        for (int i = 0; i < 3 && i < NT1; ++i) {
+          load1(i, i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < NT1; ++i) {
+          const int buf = i % 3;
+          v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+          for (int ks = 0; ks < KSD; ++ks) {  // lane: row lr (c0) / 16 + lr (c1), columns 4 lg .. 4 lg + 3 of the tile
+            c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[buf][ks], a0[ks], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[buf][ks], a1[ks], c1, 0, 0, 0);
+          }
+          const float pbv[4] = {pb4[buf].x, pb4[buf].y, pb4[buf].z, pb4[buf].w};
+          int q0[4], q1[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v0 = edequant(c0[r], cs4[buf][r], L.ffn1.u, pbv[r]);
+            float v1 = edequant(c1[r], cs4[buf][r], L.ffn1.u, pbv[r]);
+            v0 = v0 > 0.0f ? v0 : 0.0f;
+            v1 = v1 > 0.0f ? v1 : 0.0f;
+            q0[r] = quantize1(v0, L.ffn2.a_quant);
+            q1[r] = quantize1(v1, L.ffn2.a_quant);
+          }
+          const int col = (wave + ENW * i) * 16 + lg * 4;
+          *reinterpret_cast<int *>(Hb + lr * LDH + col) = pack4(q0[0], q0[1], q0[2], q0[3]);
+          *reinterpret_cast<int *>(Hb + (16 + lr) * LDH + col) = pack4(q1[0], q1[1], q1[2], q1[3]);
+          if (i + 3 < NT1) load1(buf, i + 3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // FFN2's first weight chunks do not depend on the hidden layer: request them before the barrier
+      const rsrc_t r2 = make_rsrc(reinterpret_cast<const char *>(L.ffn2.Wp) + (size_t)wave * KSF * 1024, (unsigned)KSF * 1024u);
+      constexpr int NC2 = KSF / 4;  // chunks of four k-steps
+      v4i b2[3][4];
+      auto load2 = [&](int buf, int c) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          b2[buf][ks] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r2, lane * 16, (c * 4 + ks) * 1024, 0));
+      };
+#pragma unroll
+      for (int c = 0; c < 3 && c < NC2; ++c) {
+        load2(c, c);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      int cs2i[4];
+      float pb2v[4];
+      {
+        const rsrc_t r2c = make_rsrc(L.ffn2.colsum, (unsigned)L.ffn2.n_tiles * 64u);
+        const rsrc_t r2p = make_rsrc(L.ffn2.pb, (unsigned)L.ffn2.n_tiles * 64u);
+        const v4i c4 = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r2c, lg * 16, wave * 64, 0));
+        const float4 p4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r2p, lg * 16, wave * 64, 0));
+        cs2i[0] = c4[0]; cs2i[1] = c4[1]; cs2i[2] = c4[2]; cs2i[3] = c4[3];
+        pb2v[0] = p4.x; pb2v[1] = p4.y; pb2v[2] = p4.z; pb2v[3] = p4.w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // the hidden layer is complete
       v4i f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
-      // fragments of two chunks in flight (with the whole GPU streaming, a weight
-      // fetch takes longer than one chunk's arithmetic); loads past the last chunk
-      // read beyond the descriptor / into the next tile and are never used
-      v4i b1[2][KSD], b2[2][4];
-      int cs1[2];
-      float pb1[2];
-      constexpr int NC = KSF / 4;  // chunks of 256 hidden columns
-      static_assert(NC % 2 == 0, "two chunks per rolled iteration");
-      auto load_b1 = [&](int buf, int fc) {
-        load_frags<KSD>(b1[buf], L.ffn1, fc * 16 + wave, 0, lane);
-        load_epi(L.ffn1, fc * 16 + wave, lr, cs1[buf], pb1[buf]);
-      };
-      auto load_b2 = [&](int buf, int fc) { load_frags_k<4>(b2[buf], L.ffn2, wave, fc * 4, lane); };
-      // FFN1 of one chunk: this wave's column tile -> relu -> requantise -> hidden buffer
-      auto ffn1_chunk = [&](int buf, char *Hbuf) {
-        v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-        tile_mma2<KSD>(Aq, LDA, b1[buf], lr, lg, c0, c1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v0 = edequant(c0[r], cs1[buf], L.ffn1.u, pb1[buf]);
-          float v1 = edequant(c1[r], cs1[buf], L.ffn1.u, pb1[buf]);
-          v0 = v0 > 0.0f ? v0 : 0.0f;
-          v1 = v1 > 0.0f ? v1 : 0.0f;
-          Hbuf[(lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v0, L.ffn2.a_quant);
-          Hbuf[(16 + lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v1, L.ffn2.a_quant);
-        }
-      };
-      load_b1(0, 0);
-      load_b1(1, 1);
-      load_b2(0, 0);
-      load_b2(1, 1);
-      ffn1_chunk(0, Ak);
-      load_b1(0, 2);
-      __syncthreads();
-#pragma unroll 1
-      for (int fc = 0; fc < NC; fc += 2) {
-        ffn1_chunk(1, Av);  // chunk fc + 1
-        load_b1(1, fc + 3);
-        tile_mma2<4>(Ak, LDA, b2[0], lr, lg, f0, f1);  // chunk fc
-        load_b2(0, fc + 2);
-        __syncthreads();
-        if (fc + 2 < NC) {
-          ffn1_chunk(0, Ak);  // chunk fc + 2
-          load_b1(0, fc + 4);
-        }
-        tile_mma2<4>(Av, LDA, b2[1], lr, lg, f0, f1);  // chunk fc + 1
-        load_b2(1, fc + 3);
-        __syncthreads();
-      }
-      const int col = wave * 16 + lr;
-      int cs;
-      float pb;
-      load_epi(L.ffn2, wave, lr, cs, pb);
+      for (int c = 0; c < NC2; ++c) {
+        const int buf = c % 3;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float *p0 = xs + (lg * 4 + r) * LDX + col;
-        float *p1 = xs + (16 + lg * 4 + r) * LDX + col;
-        *p0 = edequant(f0[r], cs, L.ffn2.u, pb) + *p0;
-        *p1 = edequant(f1[r], cs, L.ffn2.u, pb) + *p1;
+        for (int ks = 0; ks < 4; ++ks) {
+          const v4i h0 = *reinterpret_cast<const v4i *>(Hb + lr * LDH + (c * 4 + ks) * 64 + lg * 16);
+          const v4i h1 = *reinterpret_cast<const v4i *>(Hb + (16 + lr) * LDH + (c * 4 + ks) * 64 + lg * 16);
+          f0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[buf][ks], h0, f0, 0, 0, 0);
+          f1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[buf][ks], h1, f1, 0, 0, 0);
+        }
+        if (c + 3 < NC2) load2(buf, c + 3);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      // x = FFN2(...) + x: this lane's 4 columns of rows lr and 16 + lr
+      const int col = wave * 16 + lg * 4;
+      float4 *p0 = reinterpret_cast<float4 *>(xs + lr * LDX + col);
+      float4 *p1 = reinterpret_cast<float4 *>(xs + (16 + lr) * LDX + col);
+      float4 x0 = *p0, x1 = *p1;
+      x0.x = edequant(f0[0], cs2i[0], L.ffn2.u, pb2v[0]) + x0.x;
+      x0.y = edequant(f0[1], cs2i[1], L.ffn2.u, pb2v[1]) + x0.y;
+      x0.z = edequant(f0[2], cs2i[2], L.ffn2.u, pb2v[2]) + x0.z;
+      x0.w = edequant(f0[3], cs2i[3], L.ffn2.u, pb2v[3]) + x0.w;
+      x1.x = edequant(f1[0], cs2i[0], L.ffn2.u, pb2v[0]) + x1.x;
+      x1.y = edequant(f1[1], cs2i[1], L.ffn2.u, pb2v[1]) + x1.y;
+      x1.z = edequant(f1[2], cs2i[2], L.ffn2.u, pb2v[2]) + x1.z;
+      x1.w = edequant(f1[3], cs2i[3], L.ffn2.u, pb2v[3]) + x1.w;
+      *p0 = x0;
+      *p1 = x1;
     }
     __syncthreads();
     SLIMT_ESTAMP(6);
