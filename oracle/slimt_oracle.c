@@ -726,6 +726,17 @@ void so_model_set_threads(so_model *m, int n) {
 #endif
 }
 
+/* OpenMP's thread count is a per-thread setting: a model used from another host thread (the
+ * bench's one-worker-per-core CPU baseline, pytest workers) would otherwise run its GEMMs on
+ * a team as large as the machine, whatever set_threads said. Every entry point calls this. */
+static void use_model_threads(const so_model *m) {
+#ifdef _OPENMP
+  omp_set_num_threads(m->threads);
+#else
+  (void)m;
+#endif
+}
+
 /* affine()/linear() wrappers of Modules.cc:145-180 */
 static void apply_affine(const so_model *m, const so_affine_p *a_, const float *x,
                          size_t M, float *y) {
@@ -812,6 +823,7 @@ static void ffn_block(const so_model *m, const so_affine_p *f1, const so_affine_
 void so_encoder_layer(const so_model *m, int layer, const float *x,
                       const float *mask, size_t B, size_t S, float *out,
                       float *attn) {
+  use_model_threads(m);
   const so_enc_layer *L = &m->enc[layer - 1];
   size_t D = (size_t)m->D;
   float *a = (float *)malloc(B * S * D * sizeof(float));
@@ -823,6 +835,7 @@ void so_encoder_layer(const so_model *m, int layer, const float *x,
 /* Model.cc:195-197 */
 void so_embed(const so_model *m, const uint32_t *ids, size_t B, size_t S,
               float *out) {
+  use_model_threads(m);
   so_index_select(m->embedding, ids, B * S, (size_t)m->D, out);
   so_transform_embedding(out, B, S, (size_t)m->D, 0);
 }
@@ -830,6 +843,7 @@ void so_embed(const so_model *m, const uint32_t *ids, size_t B, size_t S,
 /* Encoder::forward (Transformer.cc:57-69) */
 void so_encode(const so_model *m, const float *x, const float *mask, size_t B,
                size_t S, float *out) {
+  use_model_threads(m);
   size_t n = B * S * (size_t)m->D;
   float *cur = (float *)malloc(n * sizeof(float));
   float *nxt = (float *)malloc(n * sizeof(float));
@@ -898,6 +912,7 @@ void so_decode_step(const so_model *m, const float *encoder_out,
                     const float *mask, size_t B, size_t S, float *states,
                     const uint32_t *prev, const uint32_t *shortlist,
                     size_t n_sl, float *logits, float *attn) {
+  use_model_threads(m);
   size_t D = (size_t)m->D, H = (size_t)m->H, n = B * D;
   float *x = (float *)malloc(n * sizeof(float));
   if (!prev) {
@@ -956,6 +971,7 @@ size_t so_translate(const so_model *m, const uint32_t *src_ids,
                     const uint32_t *shortlist, size_t n_sl,
                     float limit_factor, uint32_t eos_id, uint32_t *out_ids,
                     uint32_t *out_len, float *align) {
+  use_model_threads(m);
   size_t D = (size_t)m->D, H = (size_t)m->H;
   size_t N = shortlist ? n_sl : (size_t)m->V;
   ((so_model *)m)->kv_src = NULL; /* new batch: the cross-attention K/V cache is stale */
