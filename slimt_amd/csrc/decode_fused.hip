@@ -92,7 +92,9 @@ __device__ __forceinline__ v4i load_frag(rsrc_t r, int voff, int soff) {
 // arg-max epilogue does: its columns are >= N). A branch-free single-block loop is what
 // the s_waitcnt insertion counts exactly; with the `if (chunk < n)` of the general form
 // inside, it falls back to vmcnt(0) at the loop head whenever register allocation shifts.
-template <int KS, int NB, int NT = 0, bool PADDED = false, class Epi>
+// RT row tiles (16 RT rows of A): every weight fragment feeds RT MFMAs; epi(tile, rt, ...)
+// runs once per finished (column tile, row tile).
+template <int KS, int NB, int NT = 0, bool PADDED = false, int RT = 1, class Epi>
 __device__ __forceinline__ void stream_gemm(const char *A, int lda, const PreparedWeight &w,
                                             int wave, int lane, Epi &&epi) {
   const int n_tiles = NT > 0 ? NT * NW : w.n_tiles;
@@ -105,10 +107,12 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
   Frags b[NB];
   if constexpr (KS <= CH) {
     constexpr int TPC = CH / KS;  // whole tiles per chunk
-    v4i af[KS];
+    v4i af[RT][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      af[ks] = *reinterpret_cast<const v4i *>(A + lr * lda + ks * 64 + lg * 16);
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        af[rt][ks] = *reinterpret_cast<const v4i *>(A + (rt * 16 + lr) * lda + ks * 64 + lg * 16);
     const int nch = (ntw + TPC - 1) / TPC;
     auto load = [&](Frags &bb, int c) {
 #pragma unroll
@@ -117,26 +121,27 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
           bb.f[j * KS + ks] = load_frag(rw, voff, (tile * KS + ks) * 1024);
-#ifdef SLIMT_EXP_NOEPI  // timing experiment (wrong results): no epilogue-constant loads
-        bb.cs[j] = 1;
-        bb.pb[j] = 0.5f;
-#else
         bb.cs[j] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
         bb.pb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
-#endif
       }
+    };
+    auto tile_mma = [&](const Frags &bb, int j, int tile) {
+      v4i acc[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = v4i{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          acc[rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rt][ks], bb.f[j * KS + ks], acc[rt], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) epi(tile, rt, acc[rt], bb.cs[j], bb.pb[j]);
     };
     auto compute = [&](const Frags &bb, int c) {
 #pragma unroll
       for (int j = 0; j < TPC; ++j) {
         const int i = c * TPC + j;
-        if (i < ntw) {
-          v4i acc = {0, 0, 0, 0};
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ks], bb.f[j * KS + ks], acc, 0, 0, 0);
-          epi(wave + NW * i, acc, bb.cs[j], bb.pb[j]);
-        }
+        if (i < ntw) tile_mma(bb, j, wave + NW * i);
       }
     };
     if constexpr (NT > 0) {
@@ -164,11 +169,7 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       for (int c = 0; c < nchp; c += NB) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-          v4i acc = {0, 0, 0, 0};
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ks], b[k].f[ks], acc, 0, 0, 0);
-          epi(wave + NW * (c + k), acc, b[k].cs[0], b[k].pb[0]);
+          tile_mma(b[k], 0, wave + NW * (c + k));
           load(b[k], c + k + NB);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -196,17 +197,25 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       bb.cs[0] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
       bb.pb[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
     };
-    v4i acc = {0, 0, 0, 0};
-    auto compute = [&](const Frags &bb, int c) {
-      const int ks0 = (c % CPT) * CH;
+    v4i acc[RT];
 #pragma unroll
-      for (int p = 0; p < CH; ++p) {
-        const v4i af = *reinterpret_cast<const v4i *>(A + lr * lda + (ks0 + p) * 64 + lg * 16);
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bb.f[p], acc, 0, 0, 0);
-      }
-      if ((c % CPT) == CPT - 1) {
-        epi(wave + NW * (c / CPT), acc, bb.cs[0], bb.pb[0]);
-        acc = v4i{0, 0, 0, 0};
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = v4i{0, 0, 0, 0};
+    // chunk c of the stream: kc = its position inside its tile (compile time where unrolled)
+    auto chunk_mma = [&](const Frags &bb, int kc, int tile) {
+      const int ks0 = kc * CH;
+#pragma unroll
+      for (int p = 0; p < CH; ++p)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const v4i af = *reinterpret_cast<const v4i *>(A + (rt * 16 + lr) * lda + (ks0 + p) * 64 + lg * 16);
+          acc[rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bb.f[p], acc[rt], 0, 0, 0);
+        }
+      if (kc == CPT - 1) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          epi(tile, rt, acc[rt], bb.cs[0], bb.pb[0]);
+          acc[rt] = v4i{0, 0, 0, 0};
+        }
       }
     };
     if constexpr (NT > 0) {
@@ -216,7 +225,7 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        compute(b[c % NB], c);
+        chunk_mma(b[c % NB], c % CPT, wave + NW * (c / CPT));
         if (c + NB < NCH) load(b[c % NB], c + NB);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -230,17 +239,8 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       const int nchp = (nch + NB - 1) / NB * NB;
       for (int c = 0; c < nchp; c += NB) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-          const int ks0 = (k % CPT) * CH;  // c is a multiple of NB, NB of CPT
-#pragma unroll
-          for (int p = 0; p < CH; ++p) {
-            const v4i af = *reinterpret_cast<const v4i *>(A + lr * lda + (ks0 + p) * 64 + lg * 16);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, b[k].f[p], acc, 0, 0, 0);
-          }
-          if ((k % CPT) == CPT - 1) {
-            epi(wave + NW * ((c + k) / CPT), acc, b[k].cs[0], b[k].pb[0]);
-            acc = v4i{0, 0, 0, 0};
-          }
+        for (int k = 0; k < NB; ++k) {  // c is a multiple of NB, NB of CPT
+          chunk_mma(b[k], k % CPT, wave + NW * ((c + k) / CPT));
           load(b[k], c + k + NB);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -251,7 +251,7 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       for (int c = 0; c < nch; c += NB) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-          if (c + k < nch) compute(b[k], c + k);
+          if (c + k < nch) chunk_mma(b[k], (c + k) % CPT, wave + NW * ((c + k) / CPT));
           load(b[k], c + k + NB);
         }
       }
@@ -696,82 +696,97 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   (void)lr;                                              \
   (void)lg
 
-template <int KSD, int KSF, int DH, bool LONG, bool NT>
+// RT = row tiles per workgroup: 1 (16 sentences) or 2 (32 sentences). Every streamed weight
+// fragment then feeds RT MFMAs (half the weight bytes per sentence and step at RT = 2), wave w
+// owns sentences w and w + 16 in the row-wise phases.
+template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 64 * KSD, F = 64 * KSF;
+  constexpr int R = 16 * RT;    // rows (sentences) per workgroup
   constexpr int LDF = D + 4;    // f32 row stride
   constexpr int LDA = D + 16;   // int8 row stride (K = D)
   constexpr int LDA3 = F + 16;  // int8 row stride (K = F)
   // column tiles per wave where every wave has the same number (else 0: rolled loops)
   constexpr int NT_D = (D / 16) % NW == 0 ? (D / 16) / NW : 0;
   constexpr int NT_F1 = (F / 16) % NW == 0 ? (F / 16) / NW : 0;
+  // chunks of weight fragments in flight per wave: with two row tiles a chunk feeds twice the
+  // MFMAs and epilogues (the same cover from fewer chunks) and the A fragments take 16 more registers
+  constexpr int NB_FFN = RT > 1 ? 2 : SLIMT_NB_FFN;
+  constexpr int NB_OUT = RT > 1 ? (KSD > 4 ? 2 : 3) : SLIMT_NB_OUT;
   const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
 
-  // D > 256 ("base") does not fit the layout below in 160 KiB: the pre-LN
-  // buffer then aliases hs (every pre-LN write reads at most the same element
-  // of hs, LayerNorm runs from registers) and the SSRU cells live in global
-  // memory (a.cells, [Ld][B][D]; 4 KiB per sentence, read and written once per
-  // layer and step).
-  constexpr bool BIG = KSD > 4;
+  // 16 rows x 512 ("base") or 32 rows x 256 do not fit the full layout in 160 KiB: the
+  // pre-LN buffer then aliases hs (every pre-LN write reads at most the same element of hs,
+  // LayerNorm runs from registers) and the SSRU cells live in global memory (a.cells,
+  // [Ld][B][D]; 1 KiB per sentence and layer, read and written once per step).
+  constexpr bool LEAN = KSD * RT > 4;
   float *xs = reinterpret_cast<float *>(smem);  // layer input rows (post-LN); reused for q
-  float *hs = xs + 16 * LDF;                    // h / o rows (post-LN residual source)
-  float *pre = BIG ? hs : hs + 16 * LDF;        // pre-LN accumulation
-  float *cs = pre + 16 * LDF;                   // SSRU cells [Ld][16][D] (LDS layout only)
-  char *A1 = reinterpret_cast<char *>(cs + (BIG ? 0 : (size_t)Ld * 16 * D));
-  char *A2 = A1 + 16 * LDA;
-  char *A3 = A2 + 16 * LDA;
-  float *red_v = reinterpret_cast<float *>(A3 + 16 * LDA3);  // [NW][16]
-  int *red_i = reinterpret_cast<int *>(red_v + NW * 16);
-  int *flags = red_i + NW * 16;  // [0] = number of finished sentences of this tile
+  float *hs = xs + R * LDF;                     // h / o rows (post-LN residual source)
+  float *pre = LEAN ? hs : hs + R * LDF;        // pre-LN accumulation
+  float *cs = pre + R * LDF;                    // SSRU cells [Ld][R][D] (full layout only)
+  char *A1 = reinterpret_cast<char *>(cs + (LEAN ? 0 : (size_t)Ld * R * D));
+  char *A2 = A1 + R * LDA;
+  char *A3 = A2 + R * LDA;
+  float *red_v = reinterpret_cast<float *>(A3 + R * LDA3);  // [NW][R]
+  int *red_i = reinterpret_cast<int *>(red_v + NW * R);
+  int *flags = red_i + NW * R;  // [0] = number of finished sentences of this tile
   float *pbufs = reinterpret_cast<float *>(flags + 16);  // [NW][256] attention scratch
 
-  // Which 16 sentences? With a ticket counter the grid is over-subscribed (2 x the
-  // tiles) and the first workgroups to START claim the tiles; the rest leave at
-  // once. A workgroup needs a whole CU, and the hardware binds a workgroup to a
-  // shader engine when the kernel is dispatched, not when a CU frees up: with
-  // exactly one workgroup per tile, tiles waited for a CU on "their" engine while
-  // CUs of other engines sat idle (20 % of the CU time under the 16-worker load,
-  // tools/occupancy_trace.py, tools/probes/mix_probe.hip). Tiles are independent,
-  // so who runs which changes nothing in the results.
+  // Which R sentences? With a ticket counter the grid is over-subscribed and the first
+  // workgroups to START claim the tiles; the rest leave at once. A workgroup needs a whole
+  // CU, and the hardware binds a workgroup to a shader engine when the kernel is dispatched,
+  // not when a CU frees up: with exactly one workgroup per tile, tiles waited for a CU on
+  // "their" engine while CUs of other engines sat idle (20 % of the CU time under the
+  // 16-worker load, tools/occupancy_trace.py, tools/probes/mix_probe.hip). Tiles are
+  // independent, so who runs which changes nothing in the results.
   int tile = blockIdx.x;
   if (a.ticket) {
     if (tid == 0) flags[1] = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
     __syncthreads();
     tile = flags[1];
-    if ((unsigned)tile >= (unsigned)((B + 15) / 16)) return;
+    if ((unsigned)tile >= (unsigned)((B + R - 1) / R)) return;
   }
-  const int m0 = tile * 16;
+  const int m0 = tile * R;
   if (tid == 0) occ_trace_event(a.trace, 1, 0);
 
-  // per-sentence state, owned by wave `wave` (uniform within the wave)
-  const int b = m0 + wave;
-  const bool live = b < B;
-  const int len = live ? (int)a.lengths[b] : 0;
-  uint32_t n_out = 0;
-  bool finished = !live;
-  const int valid_rows = (B - m0) < 16 ? (B - m0) : 16;
+  // per-sentence state of rows wave + 16 rr, owned by wave `wave` (uniform within the wave)
+  int bq[RT], len[RT];
+  bool live[RT], finished[RT];
+  uint32_t n_out[RT];
+#pragma unroll
+  for (int rr = 0; rr < RT; ++rr) {
+    bq[rr] = m0 + 16 * rr + wave;
+    live[rr] = bq[rr] < B;
+    len[rr] = live[rr] ? (int)a.lengths[bq[rr]] : 0;
+    finished[rr] = !live[rr];
+    n_out[rr] = 0;
+  }
+  const int valid_rows = (B - m0) < R ? (B - m0) : R;
 
   // start_states, Transformer.cc:78-85
-  if constexpr (BIG) {
+  if constexpr (LEAN) {
     for (int l = 0; l < Ld; ++l)
       for (int i = tid; i < valid_rows * D; i += 1024) a.cells[((size_t)l * B + m0) * D + i] = 0.0f;
   } else {
-    for (int i = tid; i < Ld * 16 * D; i += 1024) cs[i] = 0.0f;
+    for (int i = tid; i < Ld * R * D; i += 1024) cs[i] = 0.0f;
   }
   if (tid == 0) flags[0] = 0;
-  if (live) {  // outputs past a sentence's length read as zero (no memset launches)
-    for (int i = lane; i < a.Tmax; i += 64) a.out_ids[(size_t)b * a.Tmax + i] = 0;
-    if (a.align)
-      for (int i = lane; i < a.Tmax * S; i += 64) a.align[(size_t)b * a.Tmax * S + i] = 0.0f;
-  }
-  // step-0 embedding: zeros * sqrt(D) + pos(0)  (Transformer.cc:138-144,160)
 #pragma unroll
-  for (int i = 0; i < KSD; ++i) {
-    const float z = 0.0f * a.emb.sqrt_d;
-    xs[wave * LDF + lane + 64 * i] = live ? z + a.emb.pos[lane + 64 * i] : 0.0f;
+  for (int rr = 0; rr < RT; ++rr) {
+    if (live[rr]) {  // outputs past a sentence's length read as zero (no memset launches)
+      for (int i = lane; i < a.Tmax; i += 64) a.out_ids[(size_t)bq[rr] * a.Tmax + i] = 0;
+      if (a.align)
+        for (int i = lane; i < a.Tmax * S; i += 64) a.align[(size_t)bq[rr] * a.Tmax * S + i] = 0.0f;
+    }
+    // step-0 embedding: zeros * sqrt(D) + pos(0)  (Transformer.cc:138-144,160)
+#pragma unroll
+    for (int i = 0; i < KSD; ++i) {
+      const float z = 0.0f * a.emb.sqrt_d;
+      xs[(16 * rr + wave) * LDF + lane + 64 * i] = live[rr] ? z + a.emb.pos[lane + 64 * i] : 0.0f;
+    }
   }
   __syncthreads();
 
@@ -789,15 +804,19 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     for (int l = 0; l < Ld; ++l) {
       SLIMT_PHASE_LANE;
       const FusedLayerW &L = a.L[l];
-      float *cl = BIG ? a.cells + ((size_t)l * B + m0) * D : cs + (size_t)l * 16 * D;
+      float *cl = LEAN ? a.cells + ((size_t)l * B + m0) * D : cs + (size_t)l * R * D;
       const int sb = 1 + 10 * l;
       // ---- SSRU (Modules.cc:190-235) ------------------------------------
       // quantise x twice (Wf / W have their own multipliers)
 #pragma unroll
-      for (int i = 0; i < KSD; ++i) {
-        const float v = xs[wave * LDF + lane + 64 * i];
-        A1[wave * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_f.a_quant);
-        A2[wave * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
+      for (int rr = 0; rr < RT; ++rr) {
+        const int row = 16 * rr + wave;
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) {
+          const float v = xs[row * LDF + lane + 64 * i];
+          A1[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_f.a_quant);
+          A2[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
+        }
       }
       __syncthreads();
       // every sentence of this tile has emitted EOS (counted in the previous step's sampling
@@ -822,430 +841,14 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         const int csw = __builtin_amdgcn_raw_buffer_load_b32(rwc, lr * 4, tile * 64, 0);
         const float pbf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfp, lr * 4, tile * 64, 0));
         const float pbw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwp, lr * 4, tile * 64, 0));
-        v4i accf = {0, 0, 0, 0}, accw = {0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < KSD; ++ks) {
-          const v4i af = *reinterpret_cast<const v4i *>(A1 + lr * LDA + ks * 64 + lg * 16);
-          const v4i aw = *reinterpret_cast<const v4i *>(A2 + lr * LDA + ks * 64 + lg * 16);
-          accf = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[ks], accf, 0, 0, 0);
-          accw = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw, bw[ks], accw, 0, 0, 0);
-        }
         const int col = tile * 16 + lr;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rl = lg * 4 + r;
-          const float f = dequant(accf[r], csf, L.rnn_f.u, pbf);
-          const float wx = dequant(accw[r], csw, L.rnn_w.u, pbw);
-          const bool cell_ok = !BIG || rl < valid_rows;  // global cells: rows of this batch only
-          const float c = cell_ok ? cl[rl * D + col] : 0.0f;
-          const float sg = sigmoid_p(f);  // highway(c, Wx, f), TensorOps.cc:674-678
-          const float t1 = sg * c;
-          const float t2 = (1.0f - sg) * wx;
-          const float cn = t1 + t2;
-          if (cell_ok) cl[rl * D + col] = cn;
-          const float y = cn > 0.0f ? cn : 0.0f;
-          pre[rl * LDF + col] = xs[rl * LDF + col] + y;  // Modules.cc:230
-        }
-      }
-      __syncthreads();
-      SLIMT_STAMP(sb + 1);
-      // h = LN(x + relu(c')), quantised for the Q projection
-      ln_row<KSD>(pre + wave * LDF, L.rnn_ln_s, L.rnn_ln_b, a.eps, hs + wave * LDF, A1 + wave * LDA,
-                  L.q.a_quant, lane);
-      __syncthreads();
-      SLIMT_STAMP(sb + 2);
-      // ---- cross-attention (Modules.cc:287-319) --------------------------
-      // Q projection -> xs (x is dead until the end of the layer)
-      stream_gemm<KSD, 1, NT_D>(A1, LDA, L.q, wave, lane, [&](int tile, const v4i &acc, int cq, float pb) {
-        const int col = tile * 16 + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xs[(lg * 4 + r) * LDF + col] = dequant(acc[r], cq, L.q.u, pb);
-      });
-      __syncthreads();
-      SLIMT_STAMP(sb + 3);
-      // SDPA over the cached K/V of sentence b; output quantised into A1
-      if (live) {
-        AttnRow ar;
-        ar.kl = (gcf_ptr)(a.kv + ((size_t)(2 * l) * B + EXP_SENT(b)) * S * D);
-        ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(b)) * S * D);
-        ar.qrow = (lcf_ptr)(xs + wave * LDF);
-        ar.arow = (lc_ptr)(A1 + wave * LDA);
-        ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * 256);
-        ar.S = S;
-        ar.len = len;
-        ar.alpha = a.alpha;
-        ar.aq_o = L.o.a_quant;
-        ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
-        const bool want_align = a.align && (l + 1 == Ld) && !finished && ((int)n_out < a.Tmax);
-        ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + n_out) * S) : (gf_ptr) nullptr;
-        if (NT && l >= a.kv_temporal_layers)
-          attention_row<D, DH, LONG, 2>(ar, lane);
-        else
-          attention_row<D, DH, LONG, 0>(ar, lane);
-      } else {
-#pragma unroll
-        for (int i = 0; i < KSD; ++i) A1[wave * LDA + lane + 64 * i] = 0;
-      }
-      __syncthreads();
-      SLIMT_STAMP(sb + 4);
-      // O projection + residual h (Modules.cc:308-314)
-      stream_gemm<KSD, 1, NT_D>(A1, LDA, L.o, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
-        const int col = tile * 16 + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rl = lg * 4 + r;
-          const float v = dequant(acc[r], co, L.o.u, pb);
-          pre[rl * LDF + col] = v + hs[rl * LDF + col];
-        }
-      });
-      __syncthreads();
-      SLIMT_STAMP(sb + 5);
-      ln_row<KSD>(pre + wave * LDF, L.attn_ln_s, L.attn_ln_b, a.eps, hs + wave * LDF,
-                  A1 + wave * LDA, L.ffn1.a_quant, lane);
-      __syncthreads();
-      SLIMT_STAMP(sb + 6);
-      // ---- FFN (Modules.cc:251-257) ----------------------------------------
-      stream_gemm<KSD, SLIMT_NB_FFN, NT_F1>(A1, LDA, L.ffn1, wave, lane, [&](int tile, const v4i &acc, int c1, float pb) {
-        const int col = tile * 16 + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = dequant(acc[r], c1, L.ffn1.u, pb);
-          v = v > 0.0f ? v : 0.0f;
-          A3[(lg * 4 + r) * LDA3 + col] = (char)quantize1(v, L.ffn2.a_quant);
-        }
-      });
-      __syncthreads();
-      SLIMT_STAMP(sb + 7);
-      stream_gemm<KSF, SLIMT_NB_FFN, NT_D>(A3, LDA3, L.ffn2, wave, lane, [&](int tile, const v4i &acc, int c2, float pb) {
-        const int col = tile * 16 + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rl = lg * 4 + r;
-          const float v = dequant(acc[r], c2, L.ffn2.u, pb);
-          pre[rl * LDF + col] = v + hs[rl * LDF + col];
-        }
-      });
-      __syncthreads();
-      SLIMT_STAMP(sb + 8);
-      // next layer's input; after the last layer: quantised for the logits
-      ln_row<KSD>(pre + wave * LDF, L.ffn_ln_s, L.ffn_ln_b, a.eps, xs + wave * LDF,
-                  (l + 1 == Ld) ? A1 + wave * LDA : nullptr, a.out.a_quant, lane);
-      // Between layers no barrier: the next phase (the SSRU's quantisation) reads and writes
-      // only this wave's own row; the barrier after it covers both.
-      if (l + 1 == Ld) __syncthreads();
-      SLIMT_STAMP(sb + 9);
-    }
-    if (all_done) break;
-    // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
-    SLIMT_PHASE_LANE;
-    float bv[4];
-    int bi[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      bv[r] = -3.402823466e+38f;
-      bi[r] = 0x7fffffff;
-    }
-#ifdef SLIMT_EXP_LOGITS_TWICE  // timing experiment: the same loop twice, stamped in between
-    stream_gemm<KSD, SLIMT_NB_OUT, 0, (KSD >= 4)>(A1, LDA, outw, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
-      const int col = tile * 16 + lr;
-      const bool in_range = col < outw.N;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = dequant(acc[r], co, a.out.u, pb);
-        const bool better = in_range && v > bv[r];
-        bv[r] = better ? v : bv[r];
-        bi[r] = better ? col : bi[r];
-      }
-    });
-    __syncthreads();
-    SLIMT_STAMP(45);
-#endif
-    stream_gemm<KSD, SLIMT_NB_OUT, 0, (KSD >= 4)>(A1, LDA, outw, wave, lane, [&](int tile, const v4i &acc, int co, float pb) {
-      const int col = tile * 16 + lr;
-      const bool in_range = col < outw.N;  // no branch: the streaming loop stays one block
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = dequant(acc[r], co, a.out.u, pb);
-        // a lane's columns only grow, so strict > keeps its first maximum
-        const bool better = in_range && v > bv[r];
-        bv[r] = better ? v : bv[r];
-        bi[r] = better ? col : bi[r];
-      }
-    });
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      row16_argmax(bv[r], bi[r]);
-      if (lr == 0) {
-        red_v[wave * 16 + lg * 4 + r] = bv[r];
-        red_i[wave * 16 + lg * 4 + r] = bi[r];
-      }
-    }
-    __syncthreads();
-    SLIMT_STAMP(41);
-    // wave w finishes sentence w: reduce over the 16 waves' candidates
-    uint32_t tok = 0;
-    {
-      float v = lane < NW ? red_v[lane * 16 + wave] : -3.402823466e+38f;
-      int ix = lane < NW ? red_i[lane * 16 + wave] : 0x7fffffff;
-      row16_argmax(v, ix);
-      ix = __builtin_amdgcn_readfirstlane(ix);
-      if (live) tok = a.shortlist ? a.shortlist[ix] : (uint32_t)ix;
-    }
-    if (live && !finished) {  // record(), Model.cc:127-137
-      if (lane == 0 && (int)n_out < a.Tmax) a.out_ids[(size_t)b * a.Tmax + n_out] = tok;
-      n_out += 1;
-      if (tok == a.eos) {
-        finished = true;
-        if (lane == 0) atomicAdd(&flags[0], 1);
-      }
-    }
-    if (t + 1 < max_steps) {
-      // next target embedding (Transformer.cc:146-160): position is always 0
-#pragma unroll
-      for (int i = 0; i < KSD; ++i) {
-        float v = 0.0f;
-        if (live) {
-          const float e = (float)a.emb.wemb[(size_t)tok * D + lane + 64 * i] * a.emb.inv_mult;
-          const float sc = e * a.emb.sqrt_d;
-          v = sc + a.emb.pos[lane + 64 * i];
-        }
-        xs[wave * LDF + lane + 64 * i] = v;
-      }
-    }
-    // no barrier: the next step starts with this wave quantising its own row
-    SLIMT_STAMP(42);
-    if (a.stamps && m0 == 0 && tid == 0 && t == a.stamp_step) a.stamps[61] = clock64();
-  }
-  if (live && lane == 0) a.out_len[b] = n_out;
-  if (tid == 0) occ_trace_event(a.trace, 1, 1);
-}
-
-// =============================================================================
-// 32 sentences per workgroup (two MFMA row tiles).
-//
-// Every phase of the 16-row kernel above runs at the CU's vector-memory rate
-// (~32 B/clk from L2): per step and workgroup it streams 3.4 MB of weights and
-// 2 MB of K/V. Twice the rows per workgroup halve the weight bytes per sentence
-// (340 -> 234 KB per sentence and step). To fit 32 rows in the CU's 160 KiB:
-//   * two f32 row buffers instead of three: LayerNorm and the residual adds
-//     run in place (P), X holds the layer input / q;
-//   * the FFN hidden layer never exists whole: F is walked in chunks of 256
-//     columns through a double-buffered int8 [32][256] tile, the FFN2
-//     accumulators of a wave's column tile stay in registers;
-//   * the attention scratch aliases the hidden-chunk buffers.
-// Row-wise work (LayerNorm, attention, sampling): wave w owns sentences w and
-// w + 16. Arithmetic is bit-identical to the 16-row kernel.
-namespace {
-
-constexpr int R2 = 32;
-
-template <int KS, int NB, class Epi>
-__device__ __forceinline__ void stream_gemm2(const char *A, int lda, const PreparedWeight &w,
-                                             int wave, int lane, Epi &&epi) {
-  static_assert(KS == CH, "one tile per chunk");
-  const int n_tiles = w.n_tiles;
-  const rsrc_t rw = make_rsrc(w.Wp, (unsigned)n_tiles * KS * 1024u);
-  const rsrc_t rc = make_rsrc(w.colsum, (unsigned)n_tiles * 64u);
-  const rsrc_t rp = make_rsrc(w.pb, (unsigned)n_tiles * 64u);
-  const int lr = lane & 15, lg = lane >> 4;
-  const int voff = lane * 16, eoff = lr * 4;
-  const int ntw = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;  // my tiles
-  v4i a0[KS], a1[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    a0[ks] = *reinterpret_cast<const v4i *>(A + lr * lda + ks * 64 + lg * 16);
-    a1[ks] = *reinterpret_cast<const v4i *>(A + (16 + lr) * lda + ks * 64 + lg * 16);
-  }
-  Frags b[NB];
-  auto load = [&](Frags &bb, int c) {
-    const int tile = EXP_TILE(wave + NW * c);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bb.f[ks] = load_frag(rw, voff, (tile * KS + ks) * 1024);
-    bb.cs[0] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
-    bb.pb[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
-  };
-#pragma unroll
-  for (int k = 0; k < NB; ++k) load(b[k], k);
-  for (int c = 0; c < ntw; c += NB) {
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      if (c + k < ntw) {
-        v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[ks], b[k].f[ks], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[ks], b[k].f[ks], acc1, 0, 0, 0);
-        }
-        epi(wave + NW * (c + k), acc0, acc1, b[k].cs[0], b[k].pb[0]);
-      }
-      load(b[k], c + k + NB);
-    }
-  }
-}
-
-template <int DPL>
-__device__ __forceinline__ void load_ln_consts(const float *scale, const float *bias, int lane,
-                                               float (&sc)[DPL], float (&bi)[DPL]) {
-  const rsrc_t rs = make_rsrc(scale, 64u * DPL * 4u), rb = make_rsrc(bias, 64u * DPL * 4u);
-#pragma unroll
-  for (int i = 0; i < DPL; ++i) {
-    sc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, i * 256, 0));
-    bi[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, i * 256, 0));
-  }
-}
-
-// ln_row with scale / bias already in registers (shared by a wave's two rows)
-template <int DPL>
-__device__ __forceinline__ void ln_row_r(const float *src, const float (&scale)[DPL],
-                                         const float (&bias)[DPL], float eps, float *dst, char *A,
-                                         float aq, int lane) {
-  constexpr int D = 64 * DPL;
-  float v[DPL];
-#pragma unroll
-  for (int i = 0; i < DPL; ++i) v[i] = src[lane + 64 * i];
-  float s = 0.0f;
-#pragma unroll
-  for (int i = 0; i < DPL; ++i) s += v[i];
-  s = wave_sum(s);
-  const float mean = s / (float)D;
-  float q = 0.0f;
-#pragma unroll
-  for (int i = 0; i < DPL; ++i) {
-    const float d = v[i] - mean;
-    q += d * d;
-  }
-  q = wave_sum(q);
-  const float sigma = __builtin_sqrtf(q / (float)D + eps);
-#pragma unroll
-  for (int i = 0; i < DPL; ++i) {
-    const float t = (v[i] - mean) / sigma;
-    const float m = scale[i] * t;
-    const float y = m + bias[i];
-    dst[lane + 64 * i] = y;
-    if (A) A[lane + 64 * i] = (char)quantize1(y, aq);
-  }
-}
-
-}  // namespace
-
-template <int KSD, int KSF, int DH>
-__global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int D = 64 * KSD;
-  constexpr int LDF = D + 4;   // f32 row stride
-  constexpr int LDA = D + 16;  // int8 row stride
-  constexpr int NC = KSF / 4;  // FFN chunks of 256 hidden columns
-  static_assert(D / 16 == NW, "one 16-column tile of a D-wide GEMM per wave");
-  const int tid = threadIdx.x, lane0 = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
-
-  float *X = reinterpret_cast<float *>(smem);  // layer input rows (post-LN); reused for q
-  float *P = X + R2 * LDF;                     // pre-LN accumulation / post-LN residual source
-  float *cs = P + R2 * LDF;                    // SSRU cells [Ld][32][D]
-  char *A1 = reinterpret_cast<char *>(cs + (size_t)Ld * R2 * D);
-  char *HB0 = A1 + R2 * LDA;  // A2 of the SSRU / FFN hidden chunks / attention scratch
-  char *HB1 = HB0 + R2 * LDA;
-  float *red_v = reinterpret_cast<float *>(HB1 + R2 * LDA);  // [NW][32]
-  int *red_i = reinterpret_cast<int *>(red_v + NW * R2);
-  int *flags = red_i + NW * R2;  // [0] = number of finished sentences of this tile
-
-  int tile = blockIdx.x;  // over-subscribed launch: see decode_fused_kernel
-  if (a.ticket) {
-    if (tid == 0) flags[1] = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
-    __syncthreads();
-    tile = flags[1];
-    if ((unsigned)tile >= (unsigned)((B + R2 - 1) / R2)) return;
-  }
-  const int m0 = tile * R2;
-
-  // per-sentence state of rows wave and wave + 16 (uniform within the wave)
-  int bq[2];
-  bool live[2], finished[2];
-  int len[2];
-  uint32_t n_out[2] = {0, 0};
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    bq[t] = m0 + 16 * t + wave;
-    live[t] = bq[t] < B;
-    len[t] = live[t] ? (int)a.lengths[bq[t]] : 0;
-    finished[t] = !live[t];
-  }
-  const int valid_rows = (B - m0) < R2 ? (B - m0) : R2;
-
-  for (int i = tid; i < Ld * R2 * D; i += 1024) cs[i] = 0.0f;  // start_states, Transformer.cc:78-85
-  if (tid == 0) flags[0] = 0;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-    if (live[t]) {  // outputs past a sentence's length read as zero (no memset launches)
-      for (int i = lane0; i < a.Tmax; i += 64) a.out_ids[(size_t)bq[t] * a.Tmax + i] = 0;
-      if (a.align)
-        for (int i = lane0; i < a.Tmax * S; i += 64) a.align[(size_t)bq[t] * a.Tmax * S + i] = 0.0f;
-    }
-  {  // step-0 embedding: zeros * sqrt(D) + pos(0)  (Transformer.cc:138-144,160)
-    const int lane = lane0;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int i = 0; i < KSD; ++i) {
-        const float z = 0.0f * a.emb.sqrt_d;
-        X[(16 * t + wave) * LDF + lane + 64 * i] = live[t] ? z + a.emb.pos[lane + 64 * i] : 0.0f;
-      }
-  }
-  __syncthreads();
-
-  PreparedWeight outw = a.out;  // see decode_fused_kernel
-  if (a.out_n_dev) {
-    outw.N = (int)*a.out_n_dev;
-    outw.n_tiles = (outw.N + 15) / 16;
-  }
-  const int max_steps = a.max_steps;
-  for (int t = 0; t < max_steps; ++t) {
-    SLIMT_STAMP(0);
-    if (a.stamps && blockIdx.x == 0 && tid == 0 && t == a.stamp_step) a.stamps[60] = clock64();
-    for (int l = 0; l < Ld; ++l) {
-      SLIMT_PHASE_LANE;
-      const FusedLayerW &L = a.L[l];
-      float *cl = cs + (size_t)l * R2 * D;
-      const int sb = 1 + 10 * l;
-      float lsc[KSD], lbi[KSD];
-      // ---- SSRU (Modules.cc:190-235) ------------------------------------
-#pragma unroll 1  // code size: this kernel shares a 64 KB instruction cache with its neighbour CU
-      for (int rr = 0; rr < 2; ++rr) {
-        const int row = 16 * rr + wave;
-#pragma unroll
-        for (int i = 0; i < KSD; ++i) {
-          const float v = X[row * LDF + lane + 64 * i];
-          A1[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_f.a_quant);
-          HB0[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
-        }
-      }
-      __syncthreads();
-      SLIMT_STAMP(sb + 0);
-      {
-        const int tile = wave;
-        const rsrc_t rf = make_rsrc(L.rnn_f.Wp, (D / 16) * KSD * 1024u);
-        const rsrc_t rw = make_rsrc(L.rnn_w.Wp, (D / 16) * KSD * 1024u);
-        const rsrc_t rfc = make_rsrc(L.rnn_f.colsum, D * 4u), rfp = make_rsrc(L.rnn_f.pb, D * 4u);
-        const rsrc_t rwc = make_rsrc(L.rnn_w.colsum, D * 4u), rwp = make_rsrc(L.rnn_w.pb, D * 4u);
-        v4i bf[KSD], bw[KSD];
-#pragma unroll
-        for (int ks = 0; ks < KSD; ++ks) {
-          bf[ks] = load_frag(rf, lane * 16, (tile * KSD + ks) * 1024);
-          bw[ks] = load_frag(rw, lane * 16, (tile * KSD + ks) * 1024);
-        }
-        const int csf = __builtin_amdgcn_raw_buffer_load_b32(rfc, lr * 4, tile * 64, 0);
-        const int csw = __builtin_amdgcn_raw_buffer_load_b32(rwc, lr * 4, tile * 64, 0);
-        const float pbf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfp, lr * 4, tile * 64, 0));
-        const float pbw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwp, lr * 4, tile * 64, 0));
-        const int col = tile * 16 + lr;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           v4i accf = {0, 0, 0, 0}, accw = {0, 0, 0, 0};
 #pragma unroll
           for (int ks = 0; ks < KSD; ++ks) {
             const v4i af = *reinterpret_cast<const v4i *>(A1 + (16 * rt + lr) * LDA + ks * 64 + lg * 16);
-            const v4i aw = *reinterpret_cast<const v4i *>(HB0 + (16 * rt + lr) * LDA + ks * 64 + lg * 16);
+            const v4i aw = *reinterpret_cast<const v4i *>(A2 + (16 * rt + lr) * LDA + ks * 64 + lg * 16);
             accf = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[ks], accf, 0, 0, 0);
             accw = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw, bw[ks], accw, 0, 0, 0);
           }
@@ -1254,64 +857,65 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
             const int rl = 16 * rt + lg * 4 + r;
             const float f = dequant(accf[r], csf, L.rnn_f.u, pbf);
             const float wx = dequant(accw[r], csw, L.rnn_w.u, pbw);
-            const float c = cl[rl * D + col];
+            const bool cell_ok = !LEAN || rl < valid_rows;  // global cells: rows of this batch only
+            const float c = cell_ok ? cl[rl * D + col] : 0.0f;
             const float sg = sigmoid_p(f);  // highway(c, Wx, f), TensorOps.cc:674-678
             const float t1 = sg * c;
             const float t2 = (1.0f - sg) * wx;
             const float cn = t1 + t2;
-            cl[rl * D + col] = cn;
+            if (cell_ok) cl[rl * D + col] = cn;
             const float y = cn > 0.0f ? cn : 0.0f;
-            P[rl * LDF + col] = X[rl * LDF + col] + y;  // Modules.cc:230
+            pre[rl * LDF + col] = xs[rl * LDF + col] + y;  // Modules.cc:230
           }
         }
       }
       __syncthreads();
       SLIMT_STAMP(sb + 1);
-      // h = LN(x + relu(c')) in place, quantised for the Q projection
-      load_ln_consts<KSD>(L.rnn_ln_s, L.rnn_ln_b, lane, lsc, lbi);
-#pragma unroll 1
-      for (int rr = 0; rr < 2; ++rr) {
+      // h = LN(x + relu(c')), quantised for the Q projection
+#pragma unroll
+      for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
-        ln_row_r<KSD>(P + row * LDF, lsc, lbi, a.eps, P + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
+        ln_row<KSD>(pre + row * LDF, L.rnn_ln_s, L.rnn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
       }
       __syncthreads();
       SLIMT_STAMP(sb + 2);
       // ---- cross-attention (Modules.cc:287-319) --------------------------
-      // Q projection -> X (x is dead until the end of the layer)
-      stream_gemm2<KSD, 1>(A1, LDA, L.q, wave, lane,
-                           [&](int tile, const v4i &c0, const v4i &c1, int cq, float pb) {
-                             const int col = tile * 16 + lr;
+      // Q projection -> xs (x is dead until the end of the layer)
+      stream_gemm<KSD, 1, NT_D, false, RT>(A1, LDA, L.q, wave, lane,
+                                           [&](int tile, int rt, const v4i &acc, int cq, float pb) {
+                                             const int col = tile * 16 + lr;
 #pragma unroll
-                             for (int r = 0; r < 4; ++r) {
-                               X[(lg * 4 + r) * LDF + col] = dequant(c0[r], cq, L.q.u, pb);
-                               X[(16 + lg * 4 + r) * LDF + col] = dequant(c1[r], cq, L.q.u, pb);
-                             }
-                           });
+                                             for (int r = 0; r < 4; ++r)
+                                               xs[(16 * rt + lg * 4 + r) * LDF + col] = dequant(acc[r], cq, L.q.u, pb);
+                                           });
       __syncthreads();
       SLIMT_STAMP(sb + 3);
-      // SDPA over the cached K/V of this wave's two sentences; output quantised into A1
+      // SDPA over the cached K/V of this wave's sentence(s); output quantised into A1
 #pragma unroll 1
-      for (int rr = 0; rr < 2; ++rr) {
-        const bool lv = rr ? live[1] : live[0];
+      for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
+        const bool lv = rr ? live[RT - 1] : live[0];
         if (lv) {
-          const int bb = rr ? bq[1] : bq[0];
-          const bool fin = rr ? finished[1] : finished[0];
-          const int no = rr ? (int)n_out[1] : (int)n_out[0];
+          const int b = rr ? bq[RT - 1] : bq[0];
+          const bool fin = rr ? finished[RT - 1] : finished[0];
+          const int no = rr ? (int)n_out[RT - 1] : (int)n_out[0];
           AttnRow ar;
-          ar.kl = (gcf_ptr)(a.kv + ((size_t)(2 * l) * B + EXP_SENT(bb)) * S * D);
-          ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(bb)) * S * D);
-          ar.qrow = (lcf_ptr)(X + row * LDF);
+          ar.kl = (gcf_ptr)(a.kv + ((size_t)(2 * l) * B + EXP_SENT(b)) * S * D);
+          ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(b)) * S * D);
+          ar.qrow = (lcf_ptr)(xs + row * LDF);
           ar.arow = (lc_ptr)(A1 + row * LDA);
-          ar.pbuf = (SLIMT_LDS float *)(reinterpret_cast<float *>(HB0) + wave * 256);  // [H][32]: spans HB0 and HB1 (16 KiB)
+          ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * 256);
           ar.S = S;
-          ar.len = rr ? len[1] : len[0];
+          ar.len = rr ? len[RT - 1] : len[0];
           ar.alpha = a.alpha;
           ar.aq_o = L.o.a_quant;
-          ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)bb * H * S) : (gf_ptr) nullptr;
+          ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
           const bool want_align = a.align && (l + 1 == Ld) && !fin && (no < a.Tmax);
-          ar.align = want_align ? (gf_ptr)(a.align + ((size_t)bb * a.Tmax + no) * S) : (gf_ptr) nullptr;
-          attention_row<D, DH, false>(ar, lane);  // this kernel requires S <= 32
+          ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + no) * S) : (gf_ptr) nullptr;
+          if (NT && l >= a.kv_temporal_layers)
+            attention_row<D, DH, LONG, 2>(ar, lane);
+          else
+            attention_row<D, DH, LONG, 0>(ar, lane);
         } else {
 #pragma unroll
           for (int i = 0; i < KSD; ++i) A1[row * LDA + lane + 64 * i] = 0;
@@ -1319,230 +923,150 @@ __global__ __launch_bounds__(1024) void decode_fused32_kernel(FusedDecodeArgs a)
       }
       __syncthreads();
       SLIMT_STAMP(sb + 4);
-      // O projection + residual h, in place (Modules.cc:308-314)
-      stream_gemm2<KSD, 1>(A1, LDA, L.o, wave, lane,
-                           [&](int tile, const v4i &c0, const v4i &c1, int co, float pb) {
-                             const int col = tile * 16 + lr;
+      // O projection + residual h (Modules.cc:308-314)
+      stream_gemm<KSD, 1, NT_D, false, RT>(A1, LDA, L.o, wave, lane,
+                                           [&](int tile, int rt, const v4i &acc, int co, float pb) {
+                                             const int col = tile * 16 + lr;
 #pragma unroll
-                             for (int r = 0; r < 4; ++r) {
-                               float *p0 = P + (lg * 4 + r) * LDF + col;
-                               float *p1 = P + (16 + lg * 4 + r) * LDF + col;
-                               *p0 = dequant(c0[r], co, L.o.u, pb) + *p0;
-                               *p1 = dequant(c1[r], co, L.o.u, pb) + *p1;
-                             }
-                           });
+                                             for (int r = 0; r < 4; ++r) {
+                                               const int rl = 16 * rt + lg * 4 + r;
+                                               const float v = dequant(acc[r], co, L.o.u, pb);
+                                               pre[rl * LDF + col] = v + hs[rl * LDF + col];
+                                             }
+                                           });
       __syncthreads();
       SLIMT_STAMP(sb + 5);
-      load_ln_consts<KSD>(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);
-#pragma unroll 1
-      for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+      for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
-        ln_row_r<KSD>(P + row * LDF, lsc, lbi, a.eps, P + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
+        ln_row<KSD>(pre + row * LDF, L.attn_ln_s, L.attn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA,
+                    L.ffn1.a_quant, lane);
       }
       __syncthreads();
       SLIMT_STAMP(sb + 6);
-      // ---- FFN (Modules.cc:251-257): hidden columns in chunks of 256 -----
-      {
-        const rsrc_t r1 = make_rsrc(L.ffn1.Wp, (unsigned)L.ffn1.n_tiles * KSD * 1024u);
-        const rsrc_t r1c = make_rsrc(L.ffn1.colsum, (unsigned)L.ffn1.n_tiles * 64u);
-        const rsrc_t r1p = make_rsrc(L.ffn1.pb, (unsigned)L.ffn1.n_tiles * 64u);
-        const rsrc_t r2 = make_rsrc(L.ffn2.Wp, (unsigned)(D / 16) * KSF * 1024u);
-        v4i f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
-        v4i b1[2][KSD], b2[2][4];
-        int cs1[2];
-        float pb1[2];
-        auto load_b1 = [&](int buf, int fc) {  // past the last chunk: out of range -> zeros
-          const int tile = EXP_TILE(fc * 16 + wave);
+      // ---- FFN (Modules.cc:251-257) ----------------------------------------
+      stream_gemm<KSD, NB_FFN, NT_F1, false, RT>(
+          A1, LDA, L.ffn1, wave, lane, [&](int tile, int rt, const v4i &acc, int c1, float pb) {
+            const int col = tile * 16 + lr;
 #pragma unroll
-          for (int ks = 0; ks < KSD; ++ks) b1[buf][ks] = load_frag(r1, lane * 16, (tile * KSD + ks) * 1024);
-          cs1[buf] = __builtin_amdgcn_raw_buffer_load_b32(r1c, lr * 4, tile * 64, 0);
-          pb1[buf] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1p, lr * 4, tile * 64, 0));
-        };
-        auto load_b2 = [&](int buf, int fc) {
+            for (int r = 0; r < 4; ++r) {
+              float v = dequant(acc[r], c1, L.ffn1.u, pb);
+              v = v > 0.0f ? v : 0.0f;
+              A3[(16 * rt + lg * 4 + r) * LDA3 + col] = (char)quantize1(v, L.ffn2.a_quant);
+            }
+          });
+      __syncthreads();
+      SLIMT_STAMP(sb + 7);
+      stream_gemm<KSF, NB_FFN, NT_D, false, RT>(
+          A3, LDA3, L.ffn2, wave, lane, [&](int tile, int rt, const v4i &acc, int c2, float pb) {
+            const int col = tile * 16 + lr;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
-            b2[buf][ks] = load_frag(r2, lane * 16, (EXP_TILE(wave) * KSF + fc * 4 + ks) * 1024);
-        };
-        // FFN1 of one chunk: this wave's column tile -> relu -> requantise -> hidden buffer
-        auto ffn1_chunk = [&](int buf, char *Hb) {
-          v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-#pragma unroll
-          for (int ks = 0; ks < KSD; ++ks) {
-            const v4i x0 = *reinterpret_cast<const v4i *>(A1 + lr * LDA + ks * 64 + lg * 16);
-            const v4i x1 = *reinterpret_cast<const v4i *>(A1 + (16 + lr) * LDA + ks * 64 + lg * 16);
-            c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x0, b1[buf][ks], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x1, b1[buf][ks], c1, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v0 = dequant(c0[r], cs1[buf], L.ffn1.u, pb1[buf]);
-            float v1 = dequant(c1[r], cs1[buf], L.ffn1.u, pb1[buf]);
-            v0 = v0 > 0.0f ? v0 : 0.0f;
-            v1 = v1 > 0.0f ? v1 : 0.0f;
-            Hb[(lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v0, L.ffn2.a_quant);
-            Hb[(16 + lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v1, L.ffn2.a_quant);
-          }
-        };
-        load_b1(0, 0);
-        load_b1(1, 1);
-        load_b2(0, 0);
-        load_b2(1, 1);
-        ffn1_chunk(0, HB0);
-        load_b1(0, 2);
-        __syncthreads();
-        static_assert(NC % 2 == 0, "two chunks per rolled iteration");
-        auto ffn2_chunk = [&](int buf, const char *Hb) {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const v4i h0 = *reinterpret_cast<const v4i *>(Hb + lr * LDA + ks * 64 + lg * 16);
-            const v4i h1 = *reinterpret_cast<const v4i *>(Hb + (16 + lr) * LDA + ks * 64 + lg * 16);
-            f0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(h0, b2[buf][ks], f0, 0, 0, 0);
-            f1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(h1, b2[buf][ks], f1, 0, 0, 0);
-          }
-        };
-#pragma unroll 1  // two chunks per iteration keep the buffer indices static (code size, see above)
-        for (int fc = 0; fc < NC; fc += 2) {
-          ffn1_chunk(1, HB1);  // chunk fc + 1
-          load_b1(1, fc + 3);
-          ffn2_chunk(0, HB0);  // chunk fc
-          load_b2(0, fc + 2);
-          __syncthreads();
-          if (fc + 2 < NC) {
-            ffn1_chunk(0, HB0);  // chunk fc + 2
-            load_b1(0, fc + 4);
-          }
-          ffn2_chunk(1, HB1);  // chunk fc + 1
-          load_b2(1, fc + 3);
-          __syncthreads();
-        }
-        int c2;
-        float pb2;
-        {
-          const rsrc_t r2c = make_rsrc(L.ffn2.colsum, D * 4u), r2p = make_rsrc(L.ffn2.pb, D * 4u);
-          c2 = __builtin_amdgcn_raw_buffer_load_b32(r2c, lr * 4, wave * 64, 0);
-          pb2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2p, lr * 4, wave * 64, 0));
-        }
-        const int col = wave * 16 + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float *p0 = P + (lg * 4 + r) * LDF + col;
-          float *p1 = P + (16 + lg * 4 + r) * LDF + col;
-          *p0 = dequant(f0[r], c2, L.ffn2.u, pb2) + *p0;
-          *p1 = dequant(f1[r], c2, L.ffn2.u, pb2) + *p1;
-        }
-      }
+            for (int r = 0; r < 4; ++r) {
+              const int rl = 16 * rt + lg * 4 + r;
+              const float v = dequant(acc[r], c2, L.ffn2.u, pb);
+              pre[rl * LDF + col] = v + hs[rl * LDF + col];
+            }
+          });
       __syncthreads();
       SLIMT_STAMP(sb + 8);
       // next layer's input; after the last layer: quantised for the logits
-      load_ln_consts<KSD>(L.ffn_ln_s, L.ffn_ln_b, lane, lsc, lbi);
-#pragma unroll 1
-      for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+      for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
-        ln_row_r<KSD>(P + row * LDF, lsc, lbi, a.eps, X + row * LDF,
-                      (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
+        ln_row<KSD>(pre + row * LDF, L.ffn_ln_s, L.ffn_ln_b, a.eps, xs + row * LDF,
+                    (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
       }
-      __syncthreads();
+      // Between layers no barrier: the next phase (the SSRU's quantisation) reads and writes
+      // only this wave's own rows; the barrier after it covers both.
+      if (l + 1 == Ld) __syncthreads();
       SLIMT_STAMP(sb + 9);
     }
+    if (all_done) break;
     // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
     SLIMT_PHASE_LANE;
-    float bv[8];
-    int bi[8];
+    float bv[RT][4];
+    int bi[RT][4];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      bv[r] = -3.402823466e+38f;
-      bi[r] = 0x7fffffff;
-    }
-    stream_gemm2<KSD, SLIMT_NB_OUT>(A1, LDA, outw, wave, lane,
-                                    [&](int tile, const v4i &c0, const v4i &c1, int co, float pb) {
-                                      const int col = tile * 16 + lr;
-                                      if (col < outw.N) {
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                                        for (int r = 0; r < 4; ++r) {
-                                          // a lane's columns only grow: strict > keeps its first maximum
-                                          const float v0 = dequant(c0[r], co, a.out.u, pb);
-                                          const float v1 = dequant(c1[r], co, a.out.u, pb);
-                                          const bool g0 = v0 > bv[r], g1 = v1 > bv[4 + r];
-                                          bv[r] = g0 ? v0 : bv[r];
-                                          bi[r] = g0 ? col : bi[r];
-                                          bv[4 + r] = g1 ? v1 : bv[4 + r];
-                                          bi[4 + r] = g1 ? col : bi[4 + r];
-                                        }
-                                      }
-                                    });
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      row16_argmax(bv[r], bi[r]);
-      if (lr == 0) {
-        const int row = 16 * (r >> 2) + lg * 4 + (r & 3);
-        red_v[wave * R2 + row] = bv[r];
-        red_i[wave * R2 + row] = bi[r];
+      for (int r = 0; r < 4; ++r) {
+        bv[rt][r] = -3.402823466e+38f;
+        bi[rt][r] = 0x7fffffff;
       }
-    }
+    stream_gemm<KSD, NB_OUT, 0, (KSD >= 4), RT>(
+        A1, LDA, outw, wave, lane, [&](int tile, int rt, const v4i &acc, int co, float pb) {
+          const int col = tile * 16 + lr;
+          const bool in_range = col < outw.N;  // no branch: the streaming loop stays one block
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = dequant(acc[r], co, a.out.u, pb);
+            // a lane's columns only grow, so strict > keeps its first maximum
+            const bool better = in_range && v > bv[rt][r];
+            bv[rt][r] = better ? v : bv[rt][r];
+            bi[rt][r] = better ? col : bi[rt][r];
+          }
+        });
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        row16_argmax(bv[rt][r], bi[rt][r]);
+        if (lr == 0) {
+          red_v[wave * R + 16 * rt + lg * 4 + r] = bv[rt][r];
+          red_i[wave * R + 16 * rt + lg * 4 + r] = bi[rt][r];
+        }
+      }
     __syncthreads();
     SLIMT_STAMP(41);
-    // wave w finishes sentences w and w + 16: reduce over the 16 waves' candidates
-    uint32_t tok[2] = {0, 0};
+    // wave w finishes sentences w (+ 16): reduce over the 16 waves' candidates
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
+    for (int rr = 0; rr < RT; ++rr) {
       const int row = 16 * rr + wave;
-      float v = lane < NW ? red_v[lane * R2 + row] : -3.402823466e+38f;
-      int ix = lane < NW ? red_i[lane * R2 + row] : 0x7fffffff;
-      row16_argmax(v, ix);
-      ix = __builtin_amdgcn_readfirstlane(ix);
-      if (live[rr]) tok[rr] = a.shortlist ? a.shortlist[ix] : (uint32_t)ix;
+      uint32_t tok = 0;
+      {
+        float v = lane < NW ? red_v[lane * R + row] : -3.402823466e+38f;
+        int ix = lane < NW ? red_i[lane * R + row] : 0x7fffffff;
+        row16_argmax(v, ix);
+        ix = __builtin_amdgcn_readfirstlane(ix);
+        if (live[rr]) tok = a.shortlist ? a.shortlist[ix] : (uint32_t)ix;
+      }
       if (live[rr] && !finished[rr]) {  // record(), Model.cc:127-137
-        if (lane == 0 && (int)n_out[rr] < a.Tmax) a.out_ids[(size_t)bq[rr] * a.Tmax + n_out[rr]] = tok[rr];
+        if (lane == 0 && (int)n_out[rr] < a.Tmax) a.out_ids[(size_t)bq[rr] * a.Tmax + n_out[rr]] = tok;
         n_out[rr] += 1;
-        if (tok[rr] == a.eos) {
+        if (tok == a.eos) {
           finished[rr] = true;
           if (lane == 0) atomicAdd(&flags[0], 1);
         }
       }
-    }
-    __syncthreads();
-    if (flags[0] >= valid_rows) break;  // every sentence of this tile has emitted EOS
-    if (t + 1 < max_steps) {
-      // next target embedding (Transformer.cc:146-160): position is always 0
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const int row = 16 * rr + wave;
+      if (t + 1 < max_steps) {
+        // next target embedding (Transformer.cc:146-160): position is always 0
 #pragma unroll
         for (int i = 0; i < KSD; ++i) {
           float v = 0.0f;
           if (live[rr]) {
-            const float e = (float)a.emb.wemb[(size_t)tok[rr] * D + lane + 64 * i] * a.emb.inv_mult;
+            const float e = (float)a.emb.wemb[(size_t)tok * D + lane + 64 * i] * a.emb.inv_mult;
             const float sc = e * a.emb.sqrt_d;
             v = sc + a.emb.pos[lane + 64 * i];
           }
-          X[row * LDF + lane + 64 * i] = v;
+          xs[row * LDF + lane + 64 * i] = v;
         }
       }
     }
-    __syncthreads();
+    // no barrier: the next step starts with this wave quantising its own rows
     SLIMT_STAMP(42);
-    if (a.stamps && blockIdx.x == 0 && tid == 0 && t == a.stamp_step) a.stamps[61] = clock64();
+    if (a.stamps && m0 == 0 && tid == 0 && t == a.stamp_step) a.stamps[61] = clock64();
   }
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr)
-    if (live[rr] && lane0 == 0) a.out_len[bq[rr]] = n_out[rr];
+  for (int rr = 0; rr < RT; ++rr)
+    if (live[rr] && lane == 0) a.out_len[bq[rr]] = n_out[rr];
+  if (tid == 0) occ_trace_event(a.trace, 1, 1);
 }
 
-size_t fused_decode32_lds_bytes(int D, int Ld) {
-  return (size_t)2 * R2 * (D + 4) * 4 + (size_t)Ld * R2 * D * 4 + 3 * (size_t)R2 * (D + 16) +
-         2 * (size_t)NW * R2 * 4 + 64;
-}
-
-// rows per workgroup the fused decoder would use for this shape and batch
+// rows per workgroup the fused decoder uses: 32 (two row tiles) only on request (decode mode
+// 3) and only for the D = 256 shapes with short sentences
 int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced) {
-  const bool ok32 = D == 256 && F % 256 == 0 && F == 1536 && D / H == 32 && Ld <= 2 && S <= 32 &&
-                    fused_decode32_lds_bytes(D, Ld) <= 160 * 1024;
   (void)B;
-  // Measured (tiny11, B=256, S=32): alone on the GPU the 32-row kernel is 1.29x
-  // faster per sentence (124 us per 32-row step vs 80 us per 16-row step), but
-  // with 8..32 batches in flight it loses (14 vs 18.8 Mtok/s): half as many,
-  // twice as long workgroups pack worse next to the encoders' short ones. So it
-  // is opt-in (decode mode 3) and the 16-row kernel stays the default.
+  const bool ok32 = D == 256 && F == 1536 && D / H == 32 && Ld <= 4 && S <= 32;
   return (forced == 32 && ok32) ? 32 : 16;
 }
 
@@ -1553,12 +1077,12 @@ int fused_decode_grid(int B, bool tickets, int rows) {
   return tickets ? tiles * (rows == 16 ? 2 : 4) : tiles;
 }
 
-size_t fused_decode_lds_bytes(int D, int F, int Ld) {
-  // D > 256: two f32 row buffers, SSRU cells in global memory (see the kernel)
-  const size_t rows = D > 256 ? (size_t)2 * 16 * (D + 4) * 4
-                              : (size_t)3 * 16 * (D + 4) * 4 + (size_t)Ld * 16 * D * 4;
-  return rows + 2 * 16 * (size_t)(D + 16) + 16 * (size_t)(F + 16) + 2 * NW * 16 * 4 + 64 +
-         NW * 256 * 4;
+size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows) {
+  // D * rows > 256 * 16: two f32 row buffers, SSRU cells in global memory (see the kernel)
+  const size_t R = (size_t)rows;
+  const bool lean = (size_t)D * R > 256 * 16;
+  const size_t f32rows = lean ? 2 * R * (D + 4) * 4 : 3 * R * (D + 4) * 4 + (size_t)Ld * R * D * 4;
+  return f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 + NW * 256 * 4;
 }
 
 bool fused_decode_supported(int D, int F, int H, int Ld) {
@@ -1566,7 +1090,7 @@ bool fused_decode_supported(int D, int F, int H, int Ld) {
   const int dh = D / H;
   const bool shape = (D == 64 && F == 128 && dh == 16) || (D == 128 && F == 256 && dh == 16) ||
                      (D == 256 && F == 1536 && dh == 32) || (D == 512 && F == 2048 && dh == 64);
-  return shape && fused_decode_lds_bytes(D, F, Ld) <= 160 * 1024;
+  return shape && fused_decode_lds_bytes(D, F, Ld, 16) <= 160 * 1024;
 }
 
 // the long-sentence instantiation exists for d_head 32 only (attention_row_long), the
@@ -1586,18 +1110,18 @@ static auto decode_fused_pick(bool long_sentences, bool nt) -> void (*)(FusedDec
 
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st) {
   if (!fused_decode_supported(D, F, H, a.Ld)) return hipErrorInvalidValue;
-  if (fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg) == 32) {
-    const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, R2));
-    const size_t lds = fused_decode32_lds_bytes(D, a.Ld);
-    auto k = decode_fused32_kernel<4, 24, 32>;
+  const int rows = fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg);
+  const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, rows));
+  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows);
+  if (rows == 32) {
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto k = a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
     return hipGetLastError();
   }
-  const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, 16));
-  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld);
 #define SLIMT_FUSED_CASE(KSD_, KSF_, DH_)                                                   \
   if (D == 64 * KSD_ && F == 64 * KSF_ && D / H == DH_) {                                    \
     auto k = decode_fused_pick<KSD_, KSF_, DH_>(a.S > 32, a.kv_nt);                           \

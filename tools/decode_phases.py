@@ -7,6 +7,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 S, n_sl = 32, 4096
 m = synth.make_model("tiny11", eos_bias=-100.0)
 gm = capi.Model(m); ctx = capi.Context(gm, B, S)
+ctx.set_decode_mode(int(os.environ.get("SLIMT_DECODE_MODE", "0")))  # 3 = 32 sentences per workgroup
 ids, lens = synth.make_batch(m.V, B, S); sl = synth.make_shortlist(m.V, n_sl)
 ctx.translate(ids, lens, sl)
 names = ["step_start"]

@@ -14,6 +14,8 @@ dev = torch.device("cuda", 0)
 m = synth.make_model("tiny11", seed=1234, eos_bias=-100.0)
 gm = capi.Model(m)
 ctxs = [capi.Context(gm, B, S) for _ in range(W)]
+for c in ctxs:
+    c.set_decode_mode(int(os.environ.get("SLIMT_DECODE_MODE", "0")))  # 3 = 32 sentences per workgroup
 T = int(np.float32(1.5) * np.float32(S))
 to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
 ids, lens = (to_dev(x) for x in synth.make_batch(m.V, B, S))
