@@ -1078,11 +1078,13 @@ size_t fused_encode_lds_bytes(int D) {
 bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
   if (S < 1 || S > ER || Le < 1 || Le > 6 || Ld < 1 || Ld > 4) return false;
   if (H <= 0 || D % H || F % 256) return false;
+  if (wide_encode_supported(D, F, H, Le, Ld, S)) return true;
   return D == 256 && D / H == 32 && fused_encode_lds_bytes(D) <= 160 * 1024;
 }
 
 hipError_t launch_encode_fused(const FusedEncodeArgs &a, int D, int F, int H, hipStream_t st) {
   if (!fused_encode_supported(D, F, H, a.Le, a.Ld, a.S)) return hipErrorInvalidValue;
+  if (wide_encode_supported(D, F, H, a.Le, a.Ld, a.S)) return launch_encode_wide(a, st);
   const dim3 grid(fused_encode_grid(a.B, a.S, a.ticket != nullptr));
   const size_t lds = fused_encode_lds_bytes(D);
   hipError_t e = hipSuccess;

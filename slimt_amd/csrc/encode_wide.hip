@@ -1,0 +1,549 @@
+// Persistent fused encoder for D = 512 ("base": F = 2048, 8 heads of 64): embedding + all
+// encoder layers + the decoder's cross-attention K/V cache in ONE launch, 32 rows
+// (= floor(32 / S) whole sentences, S <= 32) per workgroup -- what encode_fused.hip does for
+// D = 256, re-planned because at D = 512 nothing fits the same way in 160 KiB of LDS:
+//
+//   * the residual stream (32 x 512 f32 = 64 KiB) lives in REGISTERS: wave w owns rows 2 w and
+//     2 w + 1, lane L holds columns L + 64 i (the element-to-lane map of the canonical row sum),
+//     16 registers. LayerNorm, the residual adds, the embedding and every quantisation of x run
+//     on the owner from registers;
+//   * ONE int8 A-operand buffer (32 x 528 B): x is quantised with the multiplier of the
+//     projection that is about to run (Q, K, V have their own), so the three projections of a
+//     round run one after the other instead of from three buffers;
+//   * heads are staged in two rounds of four: q / k / v of four heads in f32 (97 KiB), their
+//     attention on the f32 matrix cores (v_mfma_f32_32x32x2_f32 chains over ascending k, bit
+//     identical to the ascending fmaf chain; 32 + 2 x 16 MFMAs per (sentence, head)), output
+//     quantised into a second int8 buffer (the O projection's A operand);
+//   * GEMM outputs that meet the residual (O projection, FFN2) cross from the column-tile
+//     owner to the row owner through an f32 exchange tile that time-shares the q / k / v
+//     region, as does the FFN's hidden layer (32 x 2048 int8): FFN2's accumulators stay in
+//     registers until every wave has read the hidden layer, then become the exchange tile.
+//
+// Weights stream from L2 in MFMA-fragment order with the operands swapped (weights as A):
+// an accumulator lane holds 4 consecutive columns of one row, so outputs leave as 16-byte /
+// 4-byte pieces and epilogue constants arrive as 16-byte loads. Arithmetic is bit-identical
+// to the layer-by-layer kernels (kernels.hip) and to the oracle's portable order.
+// Reference: Model.cc:195-201, Transformer.cc:57-69, Modules.cc:287-334, TensorOps.cc:542-580.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace slimt_hip {
+
+namespace {
+
+constexpr int WNW = 16;  // waves per workgroup
+constexpr int WR = 32;   // rows per workgroup
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t wrsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ v4i wload(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float wdequant(int acc, int colsum, float u, float pb) {
+  const float v = (float)(acc + __mul24(127, colsum)) * u;  // |colsum| <= 127 K < 2^23
+  return v + pb;
+}
+
+// epilogue constants of column tile `tile` for this lane's 4 columns (4 lg .. 4 lg + 3)
+struct Epi4 {
+  int cs[4];
+  float pb[4];
+};
+__device__ __forceinline__ Epi4 load_epi4(const PreparedWeight &w, int tile, int lg) {
+  const rsrc_t rc = wrsrc(w.colsum, (unsigned)w.n_tiles * 64u), rp = wrsrc(w.pb, (unsigned)w.n_tiles * 64u);
+  const v4i c = wload(rc, lg * 16, tile * 64);
+  const float4 p = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rp, lg * 16, tile * 64, 0));
+  Epi4 e;
+  e.cs[0] = c[0]; e.cs[1] = c[1]; e.cs[2] = c[2]; e.cs[3] = c[3];
+  e.pb[0] = p.x; e.pb[1] = p.y; e.pb[2] = p.z; e.pb[3] = p.w;
+  return e;
+}
+
+// canonical LayerNorm of one row held in registers (v[i] = column lane + 64 i), in place
+template <int DPL>
+__device__ __forceinline__ void ln_regs(float (&v)[DPL], const float (&scale)[DPL], const float (&bias)[DPL],
+                                        float eps) {
+  constexpr int D = 64 * DPL;
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) s += v[i];
+  s = wave_sum(s);
+  const float mean = s / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float d = v[i] - mean;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  const float sigma = __builtin_sqrtf(q / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const float t = (v[i] - mean) / sigma;
+    const float m = scale[i] * t;
+    v[i] = m + bias[i];
+  }
+}
+
+template <int DPL>
+__device__ __forceinline__ void load_ln_regs(const float *scale, const float *bias, int lane, float (&sc)[DPL],
+                                             float (&bi)[DPL]) {
+  const rsrc_t rs = wrsrc(scale, 64u * DPL * 4u), rb = wrsrc(bias, 64u * DPL * 4u);
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    sc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, i * 256, 0));
+    bi[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, i * 256, 0));
+  }
+}
+
+}  // namespace
+
+// see decode_fused.hip: keeps lane-derived offsets from being hoisted and spilled
+#define SLIMT_WPHASE_LANE                               \
+  int lane = lane0;                                     \
+  asm volatile("" : "+v"(lane));                        \
+  const int lr = lane & 15, lg = lane >> 4;             \
+  (void)lr;                                             \
+  (void)lg
+
+template <int KSD, int KSF, int DH>
+__global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = 64 * KSD, F = 64 * KSF, H = D / DH;
+  constexpr int HR = 4;              // heads per round
+  constexpr int RC = HR * DH;        // q / k / v columns per round
+  constexpr int NR = H / HR;         // rounds
+  constexpr int LDA = D + 16;        // int8 A rows
+  constexpr int LDQ = RC + 1;        // f32 q / k / v rows (odd stride: row-per-lane reads are conflict-free)
+  constexpr int LDY = D + 4;         // f32 exchange rows
+  constexpr int LDH = F + 16;        // int8 hidden rows
+  static_assert(RC / 16 == WNW, "one 16-column tile of a round's projection per wave");
+  static_assert(D / 16 == 2 * WNW, "two 16-column tiles of a D-wide GEMM per wave");
+  static_assert(DH == 64 && KSD == 8, "planned for D = 512, d_head = 64");
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = a.S, B = a.B;
+  const int spw = WR / S;  // whole sentences per workgroup
+
+  __shared__ int claimed;
+  const int n_wg = (B + spw - 1) / spw;
+  int tile = blockIdx.x;
+  if (a.ticket) {  // over-subscribed launch: the first workgroups to START take the tiles
+    if (tid == 0) claimed = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
+    __syncthreads();
+    tile = claimed;
+    if ((unsigned)tile >= (unsigned)n_wg) return;
+  }
+  const int s0 = tile * spw;  // first sentence
+  const int rows_used = spw * S;
+  if (tid == 0) occ_trace_event(a.trace, 2, 0);
+
+  char *Abuf = smem;                 // the projection / FFN1 input, int8
+  char *Obuf = Abuf + WR * LDA;      // attention output, int8
+  char *region = Obuf + WR * LDA;    // q, k, v of four heads | exchange tile | hidden layer
+  float *qb = reinterpret_cast<float *>(region);
+  float *kb = qb + WR * LDQ;
+  float *vb = kb + WR * LDQ;
+  float *Yb = reinterpret_cast<float *>(region);
+  char *Hb = region;
+
+  auto row_sentence = [&](int r) { return s0 + r / S; };
+  auto row_valid = [&](int r) { return r < rows_used && row_sentence(r) < B; };
+
+  // side job: the batch's shortlisted output layer (used by the decoder launch behind this one)
+  for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+
+  // ---- embedding (Model.cc:195-197) into the owner's registers ------------------------------
+  float x[2][KSD];
+  {
+    SLIMT_WPHASE_LANE;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = 2 * wave + rr;
+      const bool ok = row_valid(r);
+      const int sb = row_sentence(r), pos = r % S;
+      const uint32_t tok = ok ? a.ids[(size_t)sb * S + pos] : 0;
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) {
+        float v = 0.0f;
+        if (ok) {
+          const float e = (float)a.emb.wemb[(size_t)tok * D + lane + 64 * i] * a.emb.inv_mult;
+          const float sc = e * a.emb.sqrt_d;
+          v = sc + a.emb.pos[(size_t)pos * D + lane + 64 * i];
+        }
+        x[rr][i] = v;
+        if (ok && a.embed_out) a.embed_out[((size_t)sb * S + pos) * D + lane + 64 * i] = v;
+      }
+    }
+  }
+  // the owner's rows, quantised for the next affine, into the A buffer
+  auto quantise_x = [&](float aq, int lane) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) Abuf[(2 * wave + rr) * LDA + lane + 64 * i] = (char)quantize1(x[rr][i], aq);
+  };
+  // one 16-column tile of weight `w` (K = D) against the 32 rows of `A`: acc lane = row lr /
+  // 16 + lr, columns 4 lg .. 4 lg + 3 of the tile (weights as the MFMA A operand)
+  auto tile_gemm = [&](const char *A, const PreparedWeight &w, int ct, int lane, v4i &c0, v4i &c1) {
+    const int lr = lane & 15, lg = lane >> 4;
+    const rsrc_t rw = wrsrc(w.Wp, (unsigned)w.n_tiles * KSD * 1024u);
+    v4i bw[KSD];
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) bw[ks] = wload(rw, lane * 16, (ct * KSD + ks) * 1024);
+    c0 = v4i{0, 0, 0, 0};
+    c1 = v4i{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) {
+      const v4i a0 = *reinterpret_cast<const v4i *>(A + lr * LDA + ks * 64 + lg * 16);
+      const v4i a1 = *reinterpret_cast<const v4i *>(A + (16 + lr) * LDA + ks * 64 + lg * 16);
+      c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[ks], a0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[ks], a1, c1, 0, 0, 0);
+    }
+  };
+
+  for (int l = 0; l < a.Le; ++l) {
+    const FusedEncLayerW &L = a.L[l];
+    // ---- Attention::forward (Modules.cc:287-319), four heads per round -----------------------
+    for (int hr = 0; hr < NR; ++hr) {
+      // Q, K, V projections of this round's heads: wave = column tile
+      for (int p = 0; p < 3; ++p) {
+        SLIMT_WPHASE_LANE;
+        const PreparedWeight &w = p == 0 ? L.q : (p == 1 ? L.k : L.v);
+        if (p || hr || l) __syncthreads();  // the A buffer / this round's q / k / v are free
+        quantise_x(w.a_quant, lane);
+        __syncthreads();
+        const int ct = hr * WNW + wave;
+        v4i c0, c1;
+        tile_gemm(Abuf, w, ct, lane, c0, c1);
+        const Epi4 e = load_epi4(w, ct, lg);
+        const int col = wave * 16 + lg * 4;  // column inside the round
+        float *dst = p == 0 ? qb : (p == 1 ? kb : vb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dst[lr * LDQ + col + r] = wdequant(c0[r], e.cs[r], w.u, e.pb[r]);
+          dst[(16 + lr) * LDQ + col + r] = wdequant(c1[r], e.cs[r], w.u, e.pb[r]);
+        }
+      }
+      __syncthreads();
+      // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one wave per
+      // (sentence, head of the round). Same operand maps and reduction order as
+      // attention_mfma_kernel<64> (kernels.hip), operands read from LDS.
+      {
+        SLIMT_WPHASE_LANE;
+        typedef float v16f __attribute__((ext_vector_type(16)));
+        const int n = lane & 31, hh = lane >> 5;
+        const float minus_inf = -99999999.0f;  // Input.cc:56-61
+        const float lowest = -3.402823466e+38f;
+        for (int job = wave; job < spw * HR; job += WNW) {
+          const int sl = job / HR, hl = job % HR;
+          const int sb = s0 + sl;
+          if (sb >= B) continue;
+          const int base = sl * S;
+          const int len = (int)a.lengths[sb];
+          const int rc = base + (n < S ? n : S - 1);  // this lane's key row (A) / query row (B), clamped
+          const float *kp = kb + rc * LDQ + hl * DH + hh;
+          const float *qp = qb + rc * LDQ + hl * DH + hh;
+          v16f st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int k0 = 0; k0 < DH; k0 += 2) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[k0], qp[k0], st, 0, 0, 0);
+          float sc[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = 8 * (r >> 2) + 4 * hh + (r & 3);  // key of this register
+            float v = st[r];
+            if (a.alpha != 1.0f) v = a.alpha * v;
+            v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
+            if (m >= S) v = lowest;
+            sc[r] = v;
+          }
+          // canonical butterfly over 32 keys: masks 1, 2 = register pairs, mask 4 = the other
+          // half-wave, masks 8, 16 = register groups
+          float t4[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            t4[g] = bf_max<32>(fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3])));
+          const float mx = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = 8 * (r >> 2) + 4 * hh + (r & 3);
+            sc[r] = m < S ? exp_p(sc[r] - mx) : 0.0f;
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            t4[g] = bf_add<32>((sc[4 * g] + sc[4 * g + 1]) + (sc[4 * g + 2] + sc[4 * g + 3]));
+          const float sum = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] = sc[r] / sum;  // keys >= S: exactly 0
+          float pa[16];  // P operand of step i: keys 2 i (hh = 0) / 2 i + 1 (hh = 1)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const slimt_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * g + 0]),
+                                                                  __float_as_int(sc[4 * g + 1]), false, false);
+            const slimt_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * g + 2]),
+                                                                  __float_as_int(sc[4 * g + 3]), false, false);
+            pa[4 * g + 0] = __int_as_float(s01.x);
+            pa[4 * g + 1] = __int_as_float(s23.x);
+            pa[4 * g + 2] = __int_as_float(s01.y);
+            pa[4 * g + 3] = __int_as_float(s23.y);
+          }
+#pragma unroll
+          for (int db = 0; db < DH / 32; ++db) {
+            v16f o = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {  // keys >= S contribute fma(0, v, o) == o
+              const int key = 2 * i + hh;
+              const float vv = vb[(base + (key < S ? key : S - 1)) * LDQ + hl * DH + 32 * db + n];
+              o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], vv, o, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = 8 * (r >> 2) + 4 * hh + (r & 3);  // query of this register
+              if (m < S)
+                Obuf[(base + m) * LDA + (hr * HR + hl) * DH + 32 * db + n] = (char)quantize1(o[r], L.o.a_quant);
+            }
+          }
+        }
+        // rows that belong to no sentence keep a defined A operand
+        for (int r = rows_used + wave; r < WR; r += WNW)
+#pragma unroll
+          for (int i = 0; i < RC / 64; ++i) Obuf[r * LDA + hr * RC + lane + 64 * i] = 0;
+      }
+    }
+    __syncthreads();  // attention of the last round is complete: q / k / v are dead
+    {  // O projection (Modules.cc:308-314): two column tiles per wave -> exchange tile
+      SLIMT_WPHASE_LANE;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int ct = wave + WNW * t2;
+        v4i c0, c1;
+        tile_gemm(Obuf, L.o, ct, lane, c0, c1);
+        const Epi4 e = load_epi4(L.o, ct, lg);
+        float4 v0, v1;
+        v0.x = wdequant(c0[0], e.cs[0], L.o.u, e.pb[0]); v0.y = wdequant(c0[1], e.cs[1], L.o.u, e.pb[1]);
+        v0.z = wdequant(c0[2], e.cs[2], L.o.u, e.pb[2]); v0.w = wdequant(c0[3], e.cs[3], L.o.u, e.pb[3]);
+        v1.x = wdequant(c1[0], e.cs[0], L.o.u, e.pb[0]); v1.y = wdequant(c1[1], e.cs[1], L.o.u, e.pb[1]);
+        v1.z = wdequant(c1[2], e.cs[2], L.o.u, e.pb[2]); v1.w = wdequant(c1[3], e.cs[3], L.o.u, e.pb[3]);
+        *reinterpret_cast<float4 *>(Yb + lr * LDY + ct * 16 + lg * 4) = v0;
+        *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + ct * 16 + lg * 4) = v1;
+      }
+    }
+    __syncthreads();
+    {  // x = LN(x + O(...)); quantised for FFN1
+      SLIMT_WPHASE_LANE;
+      float lsc[KSD], lbi[KSD];
+      load_ln_regs<KSD>(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) x[rr][i] = x[rr][i] + Yb[(2 * wave + rr) * LDY + lane + 64 * i];
+        ln_regs<KSD>(x[rr], lsc, lbi, a.eps);
+      }
+      quantise_x(L.ffn1.a_quant, lane);
+    }
+    __syncthreads();  // the exchange tile is dead, FFN1's input is complete
+    // ---- FFN (Modules.cc:326-331) ----------------------------------------------------------
+    {  // FFN1: 8 column tiles per wave, two in flight; relu, requantised into the hidden layer
+      SLIMT_WPHASE_LANE;
+      constexpr int NT1 = (F / 16) / WNW;
+      const rsrc_t r1 = wrsrc(L.ffn1.Wp, (unsigned)L.ffn1.n_tiles * KSD * 1024u);
+      const rsrc_t r1c = wrsrc(L.ffn1.colsum, (unsigned)L.ffn1.n_tiles * 64u);
+      const rsrc_t r1p = wrsrc(L.ffn1.pb, (unsigned)L.ffn1.n_tiles * 64u);
+      v4i bw[2][KSD], cs4[2];
+      float4 pb4[2];
+      auto load1 = [&](int buf, int i) {
+        const int t = wave + WNW * i;
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) bw[buf][ks] = wload(r1, lane * 16, (t * KSD + ks) * 1024);
+        cs4[buf] = wload(r1c, lg * 16, t * 64);
+        pb4[buf] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1p, lg * 16, t * 64, 0));
+      };
+      load1(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load1(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NT1; ++i) {
+        const int buf = i & 1;
+        v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+          const v4i a0 = *reinterpret_cast<const v4i *>(Abuf + lr * LDA + ks * 64 + lg * 16);
+          const v4i a1 = *reinterpret_cast<const v4i *>(Abuf + (16 + lr) * LDA + ks * 64 + lg * 16);
+          c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[buf][ks], a0, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[buf][ks], a1, c1, 0, 0, 0);
+        }
+        const float pbv[4] = {pb4[buf].x, pb4[buf].y, pb4[buf].z, pb4[buf].w};
+        int q0[4], q1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v0 = wdequant(c0[r], cs4[buf][r], L.ffn1.u, pbv[r]);
+          float v1 = wdequant(c1[r], cs4[buf][r], L.ffn1.u, pbv[r]);
+          v0 = v0 > 0.0f ? v0 : 0.0f;
+          v1 = v1 > 0.0f ? v1 : 0.0f;
+          q0[r] = quantize1(v0, L.ffn2.a_quant);
+          q1[r] = quantize1(v1, L.ffn2.a_quant);
+        }
+        const int col = (wave + WNW * i) * 16 + lg * 4;
+        *reinterpret_cast<int *>(Hb + lr * LDH + col) = pack4(q0[0], q0[1], q0[2], q0[3]);
+        *reinterpret_cast<int *>(Hb + (16 + lr) * LDH + col) = pack4(q1[0], q1[1], q1[2], q1[3]);
+        if (i + 2 < NT1) load1(buf, i + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {  // FFN2: this wave's two column tiles over K = F, chunks of 4 k-steps, two in flight
+      SLIMT_WPHASE_LANE;
+      constexpr int NC2 = KSF / 4;
+      // one descriptor per column tile, ending with the tile: the prefetch past the last chunk
+      // returns zeros without touching memory
+      const char *w2 = reinterpret_cast<const char *>(L.ffn2.Wp);
+      const rsrc_t r2[2] = {wrsrc(w2 + (size_t)wave * KSF * 1024, KSF * 1024u),
+                            wrsrc(w2 + (size_t)(wave + WNW) * KSF * 1024, KSF * 1024u)};
+      v4i b2[2][2][4];  // [buffer][column tile][k-step]
+      auto load2 = [&](int buf, int c) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) b2[buf][t2][ks] = wload(r2[t2], lane * 16, (c * 4 + ks) * 1024);
+      };
+      load2(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load2(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // the hidden layer is complete
+      v4i f[2][2];      // [column tile][row tile]
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) f[t2][rt] = v4i{0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < NC2; c += 2) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const v4i h0 = *reinterpret_cast<const v4i *>(Hb + lr * LDH + ((c + h2) * 4 + ks) * 64 + lg * 16);
+            const v4i h1 = *reinterpret_cast<const v4i *>(Hb + (16 + lr) * LDH + ((c + h2) * 4 + ks) * 64 + lg * 16);
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+              f[t2][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[h2][t2][ks], h0, f[t2][0], 0, 0, 0);
+              f[t2][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[h2][t2][ks], h1, f[t2][1], 0, 0, 0);
+            }
+          }
+          load2(h2, c + h2 + 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();  // every wave has read the hidden layer: the region becomes the exchange tile
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int ct = wave + WNW * t2;
+        const Epi4 e = load_epi4(L.ffn2, ct, lg);
+        float4 v0, v1;
+        v0.x = wdequant(f[t2][0][0], e.cs[0], L.ffn2.u, e.pb[0]); v0.y = wdequant(f[t2][0][1], e.cs[1], L.ffn2.u, e.pb[1]);
+        v0.z = wdequant(f[t2][0][2], e.cs[2], L.ffn2.u, e.pb[2]); v0.w = wdequant(f[t2][0][3], e.cs[3], L.ffn2.u, e.pb[3]);
+        v1.x = wdequant(f[t2][1][0], e.cs[0], L.ffn2.u, e.pb[0]); v1.y = wdequant(f[t2][1][1], e.cs[1], L.ffn2.u, e.pb[1]);
+        v1.z = wdequant(f[t2][1][2], e.cs[2], L.ffn2.u, e.pb[2]); v1.w = wdequant(f[t2][1][3], e.cs[3], L.ffn2.u, e.pb[3]);
+        *reinterpret_cast<float4 *>(Yb + lr * LDY + ct * 16 + lg * 4) = v0;
+        *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + ct * 16 + lg * 4) = v1;
+      }
+    }
+    __syncthreads();
+    {  // x = LN(FFN2(...) + x)
+      SLIMT_WPHASE_LANE;
+      float lsc[KSD], lbi[KSD];
+      load_ln_regs<KSD>(L.ffn_ln_s, L.ffn_ln_b, lane, lsc, lbi);
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * wave + rr;
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) x[rr][i] = Yb[r * LDY + lane + 64 * i] + x[rr][i];
+        ln_regs<KSD>(x[rr], lsc, lbi, a.eps);
+        if (a.layer_out && row_valid(r)) {
+          float *dst = a.layer_out + ((size_t)l * B * S + (size_t)row_sentence(r) * S + r % S) * D;
+#pragma unroll
+          for (int i = 0; i < KSD; ++i) dst[lane + 64 * i] = x[rr][i];
+        }
+      }
+    }
+    // (the next phase starts with a barrier before it touches the A buffer or the region)
+  }
+
+  // ---- encoder output + decoder cross-attention K/V (Modules.cc:248-249, once per batch) ------
+  {
+    SLIMT_WPHASE_LANE;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = 2 * wave + rr;
+      if (a.enc_out && row_valid(r)) {
+        float *dst = a.enc_out + ((size_t)row_sentence(r) * S + r % S) * D;
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) dst[lane + 64 * i] = x[rr][i];
+      }
+    }
+  }
+  for (int l = 0; l < a.Ld; ++l) {
+    for (int p = 0; p < 2; ++p) {
+      SLIMT_WPHASE_LANE;
+      const PreparedWeight &w = p == 0 ? a.dec_k[l] : a.dec_v[l];
+      float *out = a.kv + (size_t)(2 * l + p) * B * S * D;
+      __syncthreads();
+      quantise_x(w.a_quant, lane);
+      __syncthreads();
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int ct = wave + WNW * t2;
+        v4i c0, c1;
+        tile_gemm(Abuf, w, ct, lane, c0, c1);
+        const Epi4 e = load_epi4(w, ct, lg);
+        const int col = ct * 16 + lg * 4;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int rrow = rt * 16 + lr;
+          if (!row_valid(rrow)) continue;
+          const v4i &c = rt ? c1 : c0;
+          float4 v;
+          v.x = wdequant(c[0], e.cs[0], w.u, e.pb[0]); v.y = wdequant(c[1], e.cs[1], w.u, e.pb[1]);
+          v.z = wdequant(c[2], e.cs[2], w.u, e.pb[2]); v.w = wdequant(c[3], e.cs[3], w.u, e.pb[3]);
+          if (p == 0) {  // K cache layout [sentence][head][d/4][key][4]: the lane's 4 columns are one d/4 group
+            const int hh = col / DH, d = col % DH;
+            const size_t chunk = ((size_t)row_sentence(rrow) * H + hh) * (DH / 4) + (d >> 2);
+            *reinterpret_cast<float4 *>(out + (chunk * S + rrow % S) * 4) = v;
+          } else {
+            *reinterpret_cast<float4 *>(out + ((size_t)row_sentence(rrow) * S + rrow % S) * D + col) = v;
+          }
+        }
+      }
+    }
+  }
+  if (tid == 0) occ_trace_event(a.trace, 2, 1);
+}
+
+size_t wide_encode_lds_bytes() {
+  constexpr int D = 512, F = 2048, RC = 256;
+  const size_t qkv = 3 * (size_t)WR * (RC + 1) * 4;
+  const size_t y = (size_t)WR * (D + 4) * 4, h = (size_t)WR * (F + 16);
+  size_t region = qkv > y ? qkv : y;
+  region = region > h ? region : h;
+  return 2 * (size_t)WR * (D + 16) + region;
+}
+
+bool wide_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
+  if (S < 1 || S > WR || Le < 1 || Le > 6 || Ld < 1 || Ld > 4) return false;
+  return D == 512 && F == 2048 && H == 8 && wide_encode_lds_bytes() <= 160 * 1024;
+}
+
+hipError_t launch_encode_wide(const FusedEncodeArgs &a, hipStream_t st) {
+  const dim3 grid(fused_encode_grid(a.B, a.S, a.ticket != nullptr));
+  const size_t lds = wide_encode_lds_bytes();
+  auto k = encode_wide_kernel<8, 32, 64>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace slimt_hip

@@ -300,6 +300,9 @@ struct FusedEncodeArgs {
 };
 bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S);
 hipError_t launch_encode_fused(const FusedEncodeArgs &a, int D, int F, int H, hipStream_t st);
+// D = 512 / F = 2048 / 8 heads (encode_wide.hip): same arguments, reached through launch_encode_fused
+bool wide_encode_supported(int D, int F, int H, int Le, int Ld, int S);
+hipError_t launch_encode_wide(const FusedEncodeArgs &a, hipStream_t st);
 
 // rows of 64 / 128 / 256 / 512 columns; y8 (nullable): int8 copy quantised with aq8
 hipError_t launch_layer_norm_q(const float *x, const float *scale, const float *bias, float eps,
