@@ -57,17 +57,43 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    extra = os.environ.get("SLIMT_HIPCC_EXTRA", "").split()  # experiments only
-    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + [
-        "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH,
-    ]
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+
+
+def _compile_one(args):
+    src, obj, cmd, verbose = args
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per source (compiled in parallel, rebuilt only when the source or a header
+    changed), then one link: an edit to one kernel file costs that file's compile time."""
+    if not force and not is_stale():
+        return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    extra = os.environ.get("SLIMT_HIPCC_EXTRA", "").split()  # experiments only
+    tag = ("_" + str(abs(hash(" ".join(extra))) % 10**8)) if extra else ""
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + tag + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(newest_hdr, os.path.getmtime(src)):
+            jobs.append((src, obj, [hipcc()] + cflags + extra + ["-c", src, "-I", CSRC, "-I",
+                                                                  os.path.join(ROOT, "include"), "-o", obj], verbose))
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(_compile_one, jobs))
+    link = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
     return LIB_PATH
 
 

@@ -101,6 +101,13 @@ __device__ __forceinline__ void load_ln_regs(const float *scale, const float *bi
 }  // namespace
 
 // see decode_fused.hip: keeps lane-derived offsets from being hoisted and spilled
+// Diagnostic phase stamps (100 MHz wall clock) of workgroup 0 in one layer (slots 0..10).
+#define SLIMT_WSTAMP(id)                                                              \
+  do {                                                                                \
+    if (a.stamps && s0 == 0 && tid == 0 && l == a.stamp_layer)                        \
+      a.stamps[(id)] = wall_clock64();                                                \
+  } while (0)
+
 #define SLIMT_WPHASE_LANE                               \
   int lane = lane0;                                     \
   asm volatile("" : "+v"(lane));                        \
@@ -185,27 +192,47 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
 #pragma unroll
       for (int i = 0; i < KSD; ++i) Abuf[(2 * wave + rr) * LDA + lane + 64 * i] = (char)quantize1(x[rr][i], aq);
   };
-  // one 16-column tile of weight `w` (K = D) against the 32 rows of `A`: acc lane = row lr /
-  // 16 + lr, columns 4 lg .. 4 lg + 3 of the tile (weights as the MFMA A operand)
-  auto tile_gemm = [&](const char *A, const PreparedWeight &w, int ct, int lane, v4i &c0, v4i &c1) {
-    const int lr = lane & 15, lg = lane >> 4;
+  // Weight fragments are requested one phase ahead of their use, across the barriers and the
+  // LayerNorm / attention phases in between: bw[0] and bw[1] hold one 16-column tile (K = D) each,
+  // or -- in FFN2 -- one chunk of 4 k-steps of the wave's two column tiles.
+  v4i bw[2][KSD];
+  v4i ecs[2];    // FFN1: colsum / prepared bias of the tile in bw[buf], requested with it (loads
+  float4 epb[2]; // return in order: constants asked for later would wait behind the next tile)
+  auto load_w = [&](v4i (&f)[KSD], const PreparedWeight &w, int ct, int lane) {
     const rsrc_t rw = wrsrc(w.Wp, (unsigned)w.n_tiles * KSD * 1024u);
-    v4i bw[KSD];
 #pragma unroll
-    for (int ks = 0; ks < KSD; ++ks) bw[ks] = wload(rw, lane * 16, (ct * KSD + ks) * 1024);
+    for (int ks = 0; ks < KSD; ++ks) f[ks] = wload(rw, lane * 16, (ct * KSD + ks) * 1024);
+  };
+  // one 16-column tile against the 32 rows of `A`: accumulator lane = rows lr / 16 + lr, columns
+  // 4 lg .. 4 lg + 3 of the tile (weights as the MFMA A operand)
+  auto mma = [&](const char *A, const v4i (&f)[KSD], int lane, v4i &c0, v4i &c1) {
+    const int lr = lane & 15, lg = lane >> 4;
     c0 = v4i{0, 0, 0, 0};
     c1 = v4i{0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < KSD; ++ks) {
       const v4i a0 = *reinterpret_cast<const v4i *>(A + lr * LDA + ks * 64 + lg * 16);
       const v4i a1 = *reinterpret_cast<const v4i *>(A + (16 + lr) * LDA + ks * 64 + lg * 16);
-      c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[ks], a0, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[ks], a1, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], a0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], a1, c1, 0, 0, 0);
     }
   };
+  auto dequant4 = [&](const v4i &c, const Epi4 &e, float u) {
+    float4 v;
+    v.x = wdequant(c[0], e.cs[0], u, e.pb[0]);
+    v.y = wdequant(c[1], e.cs[1], u, e.pb[1]);
+    v.z = wdequant(c[2], e.cs[2], u, e.pb[2]);
+    v.w = wdequant(c[3], e.cs[3], u, e.pb[3]);
+    return v;
+  };
+  {
+    SLIMT_WPHASE_LANE;
+    load_w(bw[0], a.L[0].q, wave, lane);
+  }
 
   for (int l = 0; l < a.Le; ++l) {
     const FusedEncLayerW &L = a.L[l];
+    SLIMT_WSTAMP(0);
     // ---- Attention::forward (Modules.cc:287-319), four heads per round -----------------------
     for (int hr = 0; hr < NR; ++hr) {
       // Q, K, V projections of this round's heads: wave = column tile
@@ -213,12 +240,21 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         SLIMT_WPHASE_LANE;
         const PreparedWeight &w = p == 0 ? L.q : (p == 1 ? L.k : L.v);
         if (p || hr || l) __syncthreads();  // the A buffer / this round's q / k / v are free
+        if (p == 0 && hr == 1) SLIMT_WSTAMP(2);
         quantise_x(w.a_quant, lane);
-        __syncthreads();
         const int ct = hr * WNW + wave;
-        v4i c0, c1;
-        tile_gemm(Abuf, w, ct, lane, c0, c1);
         const Epi4 e = load_epi4(w, ct, lg);
+        __syncthreads();
+        v4i c0, c1;
+        mma(Abuf, bw[0], lane, c0, c1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p < 2)
+          load_w(bw[0], p == 0 ? L.k : L.v, ct, lane);
+        else if (hr + 1 < NR)
+          load_w(bw[0], L.q, ct + WNW, lane);
+        else
+          load_w(bw[0], L.o, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
         const int col = wave * 16 + lg * 4;  // column inside the round
         float *dst = p == 0 ? qb : (p == 1 ? kb : vb);
 #pragma unroll
@@ -228,6 +264,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         }
       }
       __syncthreads();
+      SLIMT_WSTAMP(hr == 0 ? 1 : 3);
       // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one wave per
       // (sentence, head of the round). Same operand maps and reduction order as
       // attention_mfma_kernel<64> (kernels.hip), operands read from LDS.
@@ -313,24 +350,29 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       }
     }
     __syncthreads();  // attention of the last round is complete: q / k / v are dead
+    SLIMT_WSTAMP(4);
     {  // O projection (Modules.cc:308-314): two column tiles per wave -> exchange tile
       SLIMT_WPHASE_LANE;
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const int ct = wave + WNW * t2;
-        v4i c0, c1;
-        tile_gemm(Obuf, L.o, ct, lane, c0, c1);
-        const Epi4 e = load_epi4(L.o, ct, lg);
-        float4 v0, v1;
-        v0.x = wdequant(c0[0], e.cs[0], L.o.u, e.pb[0]); v0.y = wdequant(c0[1], e.cs[1], L.o.u, e.pb[1]);
-        v0.z = wdequant(c0[2], e.cs[2], L.o.u, e.pb[2]); v0.w = wdequant(c0[3], e.cs[3], L.o.u, e.pb[3]);
-        v1.x = wdequant(c1[0], e.cs[0], L.o.u, e.pb[0]); v1.y = wdequant(c1[1], e.cs[1], L.o.u, e.pb[1]);
-        v1.z = wdequant(c1[2], e.cs[2], L.o.u, e.pb[2]); v1.w = wdequant(c1[3], e.cs[3], L.o.u, e.pb[3]);
-        *reinterpret_cast<float4 *>(Yb + lr * LDY + ct * 16 + lg * 4) = v0;
-        *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + ct * 16 + lg * 4) = v1;
-      }
+      load_w(bw[1], L.o, wave + WNW, lane);
+      const Epi4 e0 = load_epi4(L.o, wave, lg);
+      const Epi4 e1 = load_epi4(L.o, wave + WNW, lg);
+      __builtin_amdgcn_sched_barrier(0);
+      v4i c0, c1;
+      mma(Obuf, bw[0], lane, c0, c1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(bw[0], L.ffn1, wave, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      *reinterpret_cast<float4 *>(Yb + lr * LDY + wave * 16 + lg * 4) = dequant4(c0, e0, L.o.u);
+      *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + wave * 16 + lg * 4) = dequant4(c1, e0, L.o.u);
+      mma(Obuf, bw[1], lane, c0, c1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(bw[1], L.ffn1, wave + WNW, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      *reinterpret_cast<float4 *>(Yb + lr * LDY + (wave + WNW) * 16 + lg * 4) = dequant4(c0, e1, L.o.u);
+      *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + (wave + WNW) * 16 + lg * 4) = dequant4(c1, e1, L.o.u);
     }
     __syncthreads();
+    SLIMT_WSTAMP(5);
     {  // x = LN(x + O(...)); quantised for FFN1
       SLIMT_WPHASE_LANE;
       float lsc[KSD], lbi[KSD];
@@ -342,115 +384,111 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         ln_regs<KSD>(x[rr], lsc, lbi, a.eps);
       }
       quantise_x(L.ffn1.a_quant, lane);
+      const rsrc_t r1c = wrsrc(L.ffn1.colsum, (unsigned)L.ffn1.n_tiles * 64u);
+      const rsrc_t r1p = wrsrc(L.ffn1.pb, (unsigned)L.ffn1.n_tiles * 64u);
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        ecs[t2] = wload(r1c, lg * 16, (wave + WNW * t2) * 64);
+        epb[t2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1p, lg * 16, (wave + WNW * t2) * 64, 0));
+      }
     }
     __syncthreads();  // the exchange tile is dead, FFN1's input is complete
+    SLIMT_WSTAMP(6);
     // ---- FFN (Modules.cc:326-331) ----------------------------------------------------------
+    // one descriptor per FFN2 column tile, ending with the tile: a prefetch past the last chunk
+    // returns zeros without touching memory
+    const char *w2 = reinterpret_cast<const char *>(L.ffn2.Wp);
+    const rsrc_t r2[2] = {wrsrc(w2 + (size_t)wave * KSF * 1024, KSF * 1024u),
+                          wrsrc(w2 + (size_t)(wave + WNW) * KSF * 1024, KSF * 1024u)};
+    // FFN2 chunk c (k-steps 4 c .. 4 c + 3 of both column tiles) into buffer `buf`
+    auto load2 = [&](int buf, int c, int lane) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bw[buf][t2 * 4 + ks] = wload(r2[t2], lane * 16, (c * 4 + ks) * 1024);
+    };
     {  // FFN1: 8 column tiles per wave, two in flight; relu, requantised into the hidden layer
       SLIMT_WPHASE_LANE;
       constexpr int NT1 = (F / 16) / WNW;
-      const rsrc_t r1 = wrsrc(L.ffn1.Wp, (unsigned)L.ffn1.n_tiles * KSD * 1024u);
       const rsrc_t r1c = wrsrc(L.ffn1.colsum, (unsigned)L.ffn1.n_tiles * 64u);
       const rsrc_t r1p = wrsrc(L.ffn1.pb, (unsigned)L.ffn1.n_tiles * 64u);
-      v4i bw[2][KSD], cs4[2];
-      float4 pb4[2];
-      auto load1 = [&](int buf, int i) {
-        const int t = wave + WNW * i;
-#pragma unroll
-        for (int ks = 0; ks < KSD; ++ks) bw[buf][ks] = wload(r1, lane * 16, (t * KSD + ks) * 1024);
-        cs4[buf] = wload(r1c, lg * 16, t * 64);
-        pb4[buf] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1p, lg * 16, t * 64, 0));
-      };
-      load1(0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      load1(1, 1);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NT1; ++i) {
-        const int buf = i & 1;
-        v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < KSD; ++ks) {
-          const v4i a0 = *reinterpret_cast<const v4i *>(Abuf + lr * LDA + ks * 64 + lg * 16);
-          const v4i a1 = *reinterpret_cast<const v4i *>(Abuf + (16 + lr) * LDA + ks * 64 + lg * 16);
-          c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[buf][ks], a0, c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[buf][ks], a1, c1, 0, 0, 0);
-        }
-        const float pbv[4] = {pb4[buf].x, pb4[buf].y, pb4[buf].z, pb4[buf].w};
+        const int buf = i & 1, t = wave + WNW * i;
+        v4i c0, c1;
+        mma(Abuf, bw[buf], lane, c0, c1);
+        const v4i cs4 = ecs[buf];
+        const float4 pb4 = epb[buf];
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 2 < NT1) {
+          load_w(bw[buf], L.ffn1, t + 2 * WNW, lane);
+          ecs[buf] = wload(r1c, lg * 16, (t + 2 * WNW) * 64);
+          epb[buf] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1p, lg * 16, (t + 2 * WNW) * 64, 0));
+        } else
+          load2(buf, i + 2 - NT1, lane);  // the first two chunks of FFN2
+        __builtin_amdgcn_sched_barrier(0);
+        const float pbv[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
         int q0[4], q1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v0 = wdequant(c0[r], cs4[buf][r], L.ffn1.u, pbv[r]);
-          float v1 = wdequant(c1[r], cs4[buf][r], L.ffn1.u, pbv[r]);
+          float v0 = wdequant(c0[r], cs4[r], L.ffn1.u, pbv[r]);
+          float v1 = wdequant(c1[r], cs4[r], L.ffn1.u, pbv[r]);
           v0 = v0 > 0.0f ? v0 : 0.0f;
           v1 = v1 > 0.0f ? v1 : 0.0f;
           q0[r] = quantize1(v0, L.ffn2.a_quant);
           q1[r] = quantize1(v1, L.ffn2.a_quant);
         }
-        const int col = (wave + WNW * i) * 16 + lg * 4;
+        const int col = t * 16 + lg * 4;
         *reinterpret_cast<int *>(Hb + lr * LDH + col) = pack4(q0[0], q0[1], q0[2], q0[3]);
         *reinterpret_cast<int *>(Hb + (16 + lr) * LDH + col) = pack4(q1[0], q1[1], q1[2], q1[3]);
-        if (i + 2 < NT1) load1(buf, i + 2);
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    __syncthreads();  // the hidden layer is complete
+    SLIMT_WSTAMP(7);
     {  // FFN2: this wave's two column tiles over K = F, chunks of 4 k-steps, two in flight
       SLIMT_WPHASE_LANE;
       constexpr int NC2 = KSF / 4;
-      // one descriptor per column tile, ending with the tile: the prefetch past the last chunk
-      // returns zeros without touching memory
-      const char *w2 = reinterpret_cast<const char *>(L.ffn2.Wp);
-      const rsrc_t r2[2] = {wrsrc(w2 + (size_t)wave * KSF * 1024, KSF * 1024u),
-                            wrsrc(w2 + (size_t)(wave + WNW) * KSF * 1024, KSF * 1024u)};
-      v4i b2[2][2][4];  // [buffer][column tile][k-step]
-      auto load2 = [&](int buf, int c) {
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) b2[buf][t2][ks] = wload(r2[t2], lane * 16, (c * 4 + ks) * 1024);
-      };
-      load2(0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      load2(1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // the hidden layer is complete
-      v4i f[2][2];      // [column tile][row tile]
+      static_assert(NC2 % 2 == 0, "two chunk buffers");
+      v4i f[2][2];  // [column tile][row tile]
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) f[t2][rt] = v4i{0, 0, 0, 0};
 #pragma unroll
-      for (int c = 0; c < NC2; c += 2) {
+      for (int c = 0; c < NC2; ++c) {
+        const int buf = c & 1;
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
+        for (int ks = 0; ks < 4; ++ks) {
+          const v4i h0 = *reinterpret_cast<const v4i *>(Hb + lr * LDH + (c * 4 + ks) * 64 + lg * 16);
+          const v4i h1 = *reinterpret_cast<const v4i *>(Hb + (16 + lr) * LDH + (c * 4 + ks) * 64 + lg * 16);
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const v4i h0 = *reinterpret_cast<const v4i *>(Hb + lr * LDH + ((c + h2) * 4 + ks) * 64 + lg * 16);
-            const v4i h1 = *reinterpret_cast<const v4i *>(Hb + (16 + lr) * LDH + ((c + h2) * 4 + ks) * 64 + lg * 16);
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-              f[t2][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[h2][t2][ks], h0, f[t2][0], 0, 0, 0);
-              f[t2][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[h2][t2][ks], h1, f[t2][1], 0, 0, 0);
-            }
+          for (int t2 = 0; t2 < 2; ++t2) {
+            f[t2][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[buf][t2 * 4 + ks], h0, f[t2][0], 0, 0, 0);
+            f[t2][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[buf][t2 * 4 + ks], h1, f[t2][1], 0, 0, 0);
           }
-          load2(h2, c + h2 + 2);
-          __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NC2) {
+          load2(buf, c + 2, lane);
+        } else if (c + 2 == NC2) {  // buffer 0 is free: the next projection's first tile
+          if (l + 1 < a.Le)
+            load_w(bw[0], a.L[l + 1].q, wave, lane);
+          else
+            load_w(bw[0], a.dec_k[0], wave, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      const Epi4 e0 = load_epi4(L.ffn2, wave, lg);
+      const Epi4 e1 = load_epi4(L.ffn2, wave + WNW, lg);
       __syncthreads();  // every wave has read the hidden layer: the region becomes the exchange tile
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const int ct = wave + WNW * t2;
-        const Epi4 e = load_epi4(L.ffn2, ct, lg);
-        float4 v0, v1;
-        v0.x = wdequant(f[t2][0][0], e.cs[0], L.ffn2.u, e.pb[0]); v0.y = wdequant(f[t2][0][1], e.cs[1], L.ffn2.u, e.pb[1]);
-        v0.z = wdequant(f[t2][0][2], e.cs[2], L.ffn2.u, e.pb[2]); v0.w = wdequant(f[t2][0][3], e.cs[3], L.ffn2.u, e.pb[3]);
-        v1.x = wdequant(f[t2][1][0], e.cs[0], L.ffn2.u, e.pb[0]); v1.y = wdequant(f[t2][1][1], e.cs[1], L.ffn2.u, e.pb[1]);
-        v1.z = wdequant(f[t2][1][2], e.cs[2], L.ffn2.u, e.pb[2]); v1.w = wdequant(f[t2][1][3], e.cs[3], L.ffn2.u, e.pb[3]);
-        *reinterpret_cast<float4 *>(Yb + lr * LDY + ct * 16 + lg * 4) = v0;
-        *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + ct * 16 + lg * 4) = v1;
-      }
+      SLIMT_WSTAMP(8);
+      *reinterpret_cast<float4 *>(Yb + lr * LDY + wave * 16 + lg * 4) = dequant4(f[0][0], e0, L.ffn2.u);
+      *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + wave * 16 + lg * 4) = dequant4(f[0][1], e0, L.ffn2.u);
+      *reinterpret_cast<float4 *>(Yb + lr * LDY + (wave + WNW) * 16 + lg * 4) = dequant4(f[1][0], e1, L.ffn2.u);
+      *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + (wave + WNW) * 16 + lg * 4) = dequant4(f[1][1], e1, L.ffn2.u);
     }
     __syncthreads();
+    SLIMT_WSTAMP(9);
     {  // x = LN(FFN2(...) + x)
       SLIMT_WPHASE_LANE;
       float lsc[KSD], lbi[KSD];
@@ -468,6 +506,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         }
       }
     }
+    SLIMT_WSTAMP(10);
     // (the next phase starts with a barrier before it touches the A buffer or the region)
   }
 
@@ -489,24 +528,30 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       SLIMT_WPHASE_LANE;
       const PreparedWeight &w = p == 0 ? a.dec_k[l] : a.dec_v[l];
       float *out = a.kv + (size_t)(2 * l + p) * B * S * D;
+      load_w(bw[1], w, wave + WNW, lane);
       __syncthreads();
       quantise_x(w.a_quant, lane);
       __syncthreads();
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const int ct = wave + WNW * t2;
-        v4i c0, c1;
-        tile_gemm(Abuf, w, ct, lane, c0, c1);
         const Epi4 e = load_epi4(w, ct, lg);
+        v4i c0, c1;
+        mma(Abuf, bw[t2], lane, c0, c1);
+        if (t2 == 0) {  // the next projection's first tile
+          __builtin_amdgcn_sched_barrier(0);
+          if (p == 0)
+            load_w(bw[0], a.dec_v[l], wave, lane);
+          else if (l + 1 < a.Ld)
+            load_w(bw[0], a.dec_k[l + 1], wave, lane);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         const int col = ct * 16 + lg * 4;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           const int rrow = rt * 16 + lr;
           if (!row_valid(rrow)) continue;
-          const v4i &c = rt ? c1 : c0;
-          float4 v;
-          v.x = wdequant(c[0], e.cs[0], w.u, e.pb[0]); v.y = wdequant(c[1], e.cs[1], w.u, e.pb[1]);
-          v.z = wdequant(c[2], e.cs[2], w.u, e.pb[2]); v.w = wdequant(c[3], e.cs[3], w.u, e.pb[3]);
+          const float4 v = dequant4(rt ? c1 : c0, e, w.u);
           if (p == 0) {  // K cache layout [sentence][head][d/4][key][4]: the lane's 4 columns are one d/4 group
             const int hh = col / DH, d = col % DH;
             const size_t chunk = ((size_t)row_sentence(rrow) * H + hh) * (DH / 4) + (d >> 2);
