@@ -480,9 +480,10 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
   // first 16 V rows for this lane's output column
   const int dc = lane < DH ? lane : DH - 1;
   const float *vb = a.v + (size_t)bc * S * a.ldv + h * DH + dc;
-  float v0[16];
+  constexpr int VPF = DH > 32 ? 4 : 16;  // V rows requested before Q is known (register budget)
+  float v0[VPF];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) v0[j] = vb[(size_t)(j < S ? j : S - 1) * a.ldv];
+  for (int j = 0; j < VPF; ++j) v0[j] = vb[(size_t)(j < S ? j : S - 1) * a.ldv];
 
   if (a.x.ln_scale) rows_layer_norm<1>(x, a.x.ln_scale, a.x.ln_bias, a.eps, D, lane);
   rows_quantize_to_lds<1>(x, a.wq.a_quant, A_lds, lda, wave, D, lane);
@@ -562,10 +563,22 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
   // 5. out[d] = key-ascending fmaf chain of p[j] * V[j][d]
   float o = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < VPF; ++j) {
     if (j < S) {
       const float pj = __shfl(p0, j, 64);
       o = __builtin_fmaf(pj, v0[j], o);
+    }
+  }
+  if constexpr (VPF < 16) {
+    float vv[16 - VPF];
+#pragma unroll
+    for (int j = VPF; j < 16; ++j) vv[j - VPF] = vb[(size_t)(j < S ? j : S - 1) * a.ldv];
+#pragma unroll
+    for (int j = VPF; j < 16; ++j) {
+      if (j < S) {
+        const float pj = __shfl(p0, j, 64);
+        o = __builtin_fmaf(pj, vv[j - VPF], o);
+      }
     }
   }
   for (int jb = 16; jb < S; jb += 16) {

@@ -686,6 +686,18 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
   float *stage = reinterpret_cast<float *>(A + LR * LDA);  // attention: [2 heads][q,k,v][128][33] (aliases H0/H1)
   float *X = a.x + (size_t)row0 * D, *Y = a.y + (size_t)row0 * D;
   float *Qg = a.q + (size_t)row0 * D, *Kg = a.k + (size_t)row0 * D, *Vg = a.v + (size_t)row0 * D;
+  // The GEMM epilogues address the sentence's f32 tensors through buffer descriptors: one
+  // 32-bit lane offset + a compile-time row offset per access (32 per-lane 64-bit addresses,
+  // one per accumulator row, used to be hoisted and spilled), and rows >= S fall outside the
+  // descriptor: their stores are dropped, their loads return 0.
+  const unsigned sbytes = (unsigned)S * D * 4u;
+  const rsrc_t rX = make_rsrc(X, sbytes), rY = make_rsrc(Y, sbytes);
+  auto bstore = [](rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+  };
+  auto bload = [](rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  };
 
   // side job: the batch's shortlisted output layer (see above)
   for (int tile = blockIdx.x; tile < f.pack_tiles; tile += gridDim.x) pack_weight_tile(f.pack, tile, tid, 1024);
@@ -739,7 +751,8 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
     // ---- Q, K, V projections (Modules.cc:287-300) -> global f32 ----------------
     for (int which = 0; which < 3; ++which) {
       const PreparedWeight &W = which == 0 ? L.q : which == 1 ? L.k : L.v;
-      float *dst = which == 0 ? Qg : which == 1 ? Kg : Vg;
+      const rsrc_t rd = make_rsrc(which == 0 ? Qg : which == 1 ? Kg : Vg, sbytes);
+      const int voff = (lg * 4 * D + col) * 4;
       v4i bf[KSD];
       load_frags<KSD>(bf, W, wave, 0, lane);
       int cs;
@@ -754,10 +767,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
       for (int rt = 0; rt < NRT; ++rt)
         if (rt < nrt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * rt + lg * 4 + r;
-            if (row < S) dst[(size_t)row * D + col] = edequant(acc[rt][r], cs, W.u, pb);
-          }
+          for (int r = 0; r < 4; ++r) bstore(rd, voff, (16 * rt + r) * D * 4, edequant(acc[rt][r], cs, W.u, pb));
         }
       __syncthreads();
     }
@@ -797,68 +807,84 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
         if (qt * 32 < S) {
           const int h = 2 * hp + slot;
           const float *Qs = stage + (slot * 3) * LR * LDH, *Ks = Qs + LR * LDH, *Vs = Ks + LR * LDH;
-          const int qrow = (qt * 32 + n) < S ? (qt * 32 + n) : S - 1;
-          float sc[NG][16];
-#pragma unroll
-          for (int g = 0; g < NG; ++g) {
+          // opaque per head pair: otherwise the 64 clamped V-row offsets and the 128 key masks are
+          // hoisted out of the head loop as loop invariants and spilled (VGPRs and SGPRs)
+          int nv = n, hv = hh;
+          asm volatile("" : "+v"(nv), "+v"(hv));
+          const int qrow = (qt * 32 + nv) < S ? (qt * 32 + nv) : S - 1;
+          // The scores of a key tile are recomputed in each of the three passes (max, sum,
+          // P V) instead of being held for all NG tiles: 16 MFMAs per tile and pass are cheap,
+          // 64 more live registers under the 128 of a 16-wave workgroup are not (they spilled).
+          // Same values every time, so the results are those of the one-pass form.
+          auto scores = [&](int g, float(&sc)[16]) {
             v16f st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            if (g < ng) {
-              const int krow = (32 * g + n) < S ? (32 * g + n) : S - 1;
+            const int krow = (32 * g + nv) < S ? (32 * g + nv) : S - 1;
 #pragma unroll
-              for (int k0 = 0; k0 < DH; k0 += 2)
-                st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[krow * LDH + k0 + hh], Qs[qrow * LDH + k0 + hh], st, 0, 0, 0);
-            }
+            for (int k0 = 0; k0 < DH; k0 += 2)
+              st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[krow * LDH + k0 + hv], Qs[qrow * LDH + k0 + hv], st, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int key = 32 * g + 8 * (r >> 2) + 4 * hh + (r & 3);
+              const int key = 32 * g + 8 * (r >> 2) + 4 * hv + (r & 3);
               float v = st[r];
               if (f.alpha != 1.0f) v = f.alpha * v;
               v = v + (1.0f - (key < len ? 1.0f : 0.0f)) * minus_inf;
               if (key >= S) v = lowest;
-              sc[g][r] = v;
+              sc[r] = v;
             }
-          }
+          };
           float m;
           {
             float mx[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              mx[r] = NG == 4 ? fmaxf(fmaxf(sc[0][r], sc[NG - 2][r]), fmaxf(sc[1][r], sc[NG - 1][r]))
-                              : fmaxf(sc[0][r], sc[1][r]);
+            for (int r = 0; r < 16; ++r) mx[r] = lowest;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+              if (g < ng) {
+                float sc[16];
+                scores(g, sc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx[r] = fmaxf(mx[r], sc[r]);
+              }
             m = tree32(mx, fmax_, max_halves);
           }
-#pragma unroll
-          for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int key = 32 * g + 8 * (r >> 2) + 4 * hh + (r & 3);
-              sc[g][r] = key < S ? exp_p(sc[g][r] - m) : 0.0f;
-            }
           float sum;
           {
-            float u[16];
+            float u[2][16];  // keys L, L + 64 | keys L + 32, L + 96 (0 + e and e + 0 are exact)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)  // keys L, L + 64 (with S <= 64 the second term is an exact + 0)
-              u[r] = NG == 4 ? sc[0][r] + sc[NG - 2][r] : sc[0][r];
-            const float t0 = tree32(u, fadd, add_halves);
+            for (int r = 0; r < 16; ++r) u[0][r] = u[1][r] = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)  // keys L + 32, L + 96
-              u[r] = NG == 4 ? sc[1][r] + sc[NG - 1][r] : sc[1][r];
-            sum = t0 + tree32(u, fadd, add_halves);
+            for (int g = 0; g < NG; ++g)
+              if (g < ng) {
+                float sc[16];
+                scores(g, sc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const int key = 32 * g + 8 * (r >> 2) + 4 * hv + (r & 3);
+                  const float e = key < S ? exp_p(sc[r] - m) : 0.0f;
+                  u[g & 1][r] = u[g & 1][r] + e;
+                }
+              }
+            const float t0 = tree32(u[0], fadd, add_halves);
+            sum = t0 + tree32(u[1], fadd, add_halves);
           }
           v16f o = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
             if (g < ng) {
-              float pa[16];
+              float sc[16], pa[16];
+              scores(g, sc);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) sc[g][r] = sc[g][r] / sum;  // keys >= S: exactly 0
+              for (int r = 0; r < 16; ++r) {
+                const int key = 32 * g + 8 * (r >> 2) + 4 * hv + (r & 3);
+                const float e = key < S ? exp_p(sc[r] - m) : 0.0f;
+                sc[r] = e / sum;  // keys >= S: exactly 0
+              }
 #pragma unroll
               for (int q4 = 0; q4 < 4; ++q4) {
-                const slimt_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[g][4 * q4 + 0]),
-                                                                      __float_as_int(sc[g][4 * q4 + 1]), false, false);
-                const slimt_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[g][4 * q4 + 2]),
-                                                                      __float_as_int(sc[g][4 * q4 + 3]), false, false);
+                const slimt_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * q4 + 0]),
+                                                                      __float_as_int(sc[4 * q4 + 1]), false, false);
+                const slimt_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * q4 + 2]),
+                                                                      __float_as_int(sc[4 * q4 + 3]), false, false);
                 pa[4 * q4 + 0] = __int_as_float(s01.x);
                 pa[4 * q4 + 1] = __int_as_float(s23.x);
                 pa[4 * q4 + 2] = __int_as_float(s01.y);
@@ -866,8 +892,8 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
               }
 #pragma unroll
               for (int i = 0; i < 16; ++i) {
-                const int key = 32 * g + 2 * i + hh;
-                o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], Vs[(key < S ? key : S - 1) * LDH + n], o, 0, 0, 0);
+                const int key = 32 * g + 2 * i + hv;
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], Vs[(key < S ? key : S - 1) * LDH + nv], o, 0, 0, 0);
               }
             }
           }
@@ -900,8 +926,8 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
         if (rt < nrt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * rt + lg * 4 + r;
-            if (row < S) Y[(size_t)row * D + col] = X[(size_t)row * D + col] + edequant(acc[rt][r], cs, L.o.u, pb);
+            const int voff = (lg * 4 * D + col) * 4, soff = (16 * rt + r) * D * 4;
+            bstore(rY, voff, soff, bload(rX, voff, soff) + edequant(acc[rt][r], cs, L.o.u, pb));
           }
         }
     }
@@ -974,8 +1000,8 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
         if (rt < nrt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * rt + lg * 4 + r;
-            if (row < S) Y[(size_t)row * D + col] = edequant(f2[rt][r], cs, L.ffn2.u, pb) + X[(size_t)row * D + col];
+            const int voff = (lg * 4 * D + col) * 4, soff = (16 * rt + r) * D * 4;
+            bstore(rY, voff, soff, edequant(f2[rt][r], cs, L.ffn2.u, pb) + bload(rX, voff, soff));
           }
         }
     }
@@ -1017,22 +1043,20 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
       v4i acc[NRT];
       zero_acc(acc);
       mma_rows(A, bf, acc);
-      const int hcol = col / DH, d = col % DH;
+      // K cache layout [sentence][head][d/4][key][4]: this wave's columns lie in one head
+      // (hw), whose [d/4][S][4] block is the descriptor; V: the sentence's [S][D] rows
+      const int hw = __builtin_amdgcn_readfirstlane((wave * 16) / DH), d = col % DH;
+      const rsrc_t ro = which == 0 ? make_rsrc(out + ((size_t)b * H + hw) * DH * S, (unsigned)S * DH * 4u)
+                                   : make_rsrc(out + (size_t)row0 * D, sbytes);
+      const int voff = which == 0 ? (((d >> 2) * S + lg * 4) * 4 + (d & 3)) * 4 : (lg * 4 * D + col) * 4;
+      const int rstep = which == 0 ? 16 : D * 4;  // bytes per row
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt)
         if (rt < nrt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * rt + lg * 4 + r;
-            if (row < S) {
-              const float v = edequant(acc[rt][r], cs, W.u, pb);
-              if (which == 0) {  // K cache layout [sentence][head][d/4][key][4]
-                const size_t chunk = ((size_t)b * H + hcol) * (DH / 4) + (d >> 2);
-                out[(chunk * S + row) * 4 + (d & 3)] = v;
-              } else {
-                out[((size_t)row0 + row) * D + col] = v;
-              }
-            }
+            if (row < S) bstore(ro, voff, (16 * rt + r) * rstep, edequant(acc[rt][r], cs, W.u, pb));
           }
         }
       __syncthreads();

@@ -32,16 +32,21 @@ def engines(hip, oracle, synth_models):
         gm.close()
 
 
-# (preset, B, S, ragged, modes): mode 1 = one launch per stage (tiny11's default is
-# the fused encoder; `base` has no fused encoder so both modes take the stage path)
+# (preset, B, S, ragged, modes): mode 0 = the persistent encoders (encode_fused.hip for
+# D = 256, encode_wide.hip for D = 512), mode 1 = one launch per stage (the `big` M >= 2048
+# branch of the stage path at these sizes)
 ENCODER_CASES = [
     ("tiny11", 64, 32, True, (1,)),     # M = 2048: first size of the `big` branch, 64-row FFN1 blocks
     ("tiny11", 128, 32, False, (1,)),   # M = 4096: 32-row LayerNorm-GEMM threshold
     ("tiny11", 256, 32, True, (0, 1)),  # headline batch: fused encoder == stage kernels == oracle
-    ("base", 64, 32, True, (0,)),       # D = 512, M = 2048
-    ("base", 128, 32, True, (0,)),      # M = 4096, ragged lengths
-    ("base", 256, 32, False, (0,)),     # BASELINE config 3: M = 8192
-    ("base", 100, 21, True, (0,)),      # M = 2100: not a multiple of the 64-row block
+    ("base", 64, 32, True, (0, 1)),     # D = 512, M = 2048
+    ("base", 128, 32, True, (0, 1)),    # M = 4096, ragged lengths
+    ("base", 256, 32, False, (0, 1)),   # BASELINE config 3: M = 8192
+    ("base", 100, 21, True, (0, 1)),    # M = 2100: not a multiple of the 64-row block; one sentence per workgroup
+    ("base", 37, 5, True, (0,)),        # wide encoder: 6 sentences per workgroup, last workgroup partly empty
+    ("base", 33, 11, True, (0,)),       # 2 sentences per workgroup, 10 rows of every tile unused
+    ("base", 9, 16, True, (0,)),        # 2 sentences fill the tile exactly
+    ("base", 3, 1, False, (0,)),        # one-token sentences
 ]
 
 
