@@ -1,0 +1,298 @@
+"""The reference's Python API over the HIP engine: what
+`bindings/python/slimt.cpp:144-221` exposes -- Package, Config, preset, Model,
+Service.translate / .pivot, Response, AnnotatedText, Range, Encoding -- with one
+addition, the `device` the model's weights live on.
+
+    from slimt_amd import frontend as slimt
+    model = slimt.Model(slimt.preset.tiny(), slimt.Package(model="model.bin",
+                        vocabulary="vocab.spm", shortlist="lex.s2t.bin"), device=0)
+    service = slimt.Service(workers=4)
+    responses = service.translate(model, ["Hello world. How are you?"], html=False)
+    responses[0].target.text, responses[0].alignments
+
+Text in, text out: TextProcessor (text.py) splits and tokenises, a length-sorted
+token-budget batcher (Batcher.cc:77-147 semantics: batches of at most `max_words`
+padded tokens, longest sentences first) feeds `slimt_hip_translate` on one context
+per worker, and the returned ids / alignment rows become the Response
+(Request.cc:136-170). The compute is the C-ABI library's; nothing here falls back
+to a CPU model.
+"""
+from __future__ import annotations
+
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import capi, synth
+from .text import AnnotatedText, Encoding, Range, TextProcessor, Vocabulary  # noqa: F401 (API surface)
+
+Alignment = List[List[float]]  # [target token][source token], p(source | target)
+
+
+@dataclass
+class Package:  # slimt.cpp:182-191: paths (or bytes) of the three model files
+    model: str | bytes = ""
+    vocabulary: str | bytes = ""
+    shortlist: str | bytes = ""
+    ssplit: str | bytes = ""  # optional non-breaking-prefix list (Package.hh ssplit)
+
+
+@dataclass
+class Config:  # Model::Config, Model.hh:33-51
+    encoder_layers: int = 6
+    decoder_layers: int = 2
+    feed_forward_depth: int = 2
+    num_heads: int = 8
+    split_mode: str = "sentence"
+
+
+class preset:  # Model.cc:206-245
+    @staticmethod
+    def tiny() -> Config:
+        return Config(6, 2, 2, 8, "sentence")
+
+    @staticmethod
+    def base() -> Config:
+        return Config(6, 2, 2, 8, "sentence")
+
+    @staticmethod
+    def nano() -> Config:
+        return Config(4, 2, 2, 8, "sentence")
+
+
+@dataclass
+class Response:  # Response.hh: source / target with sentence + token ranges, soft alignments
+    source: AnnotatedText = field(default_factory=AnnotatedText)
+    target: AnnotatedText = field(default_factory=AnnotatedText)
+    alignments: List[Alignment] = field(default_factory=list)
+
+    def to(self, encoding: Encoding) -> None:
+        self.source.to(encoding)
+        self.target.to(encoding)
+
+
+def _blob(x) -> bytes:
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        return bytes(x)
+    with open(x, "rb") as f:
+        return f.read()
+
+
+class Model:
+    """slimt::Model (Model.hh:31-83): vocabulary + text processor + the transformer's weights on
+    `device` + the optional lexical shortlist generator."""
+
+    _next_id = 0
+
+    def __init__(self, config: Config, package: Package, device: int = 0):
+        self.config = config
+        self.id = Model._next_id
+        Model._next_id += 1
+        self.vocabulary = Vocabulary(package.vocabulary)
+        self.processor = TextProcessor(config.split_mode, self.vocabulary,
+                                       _blob(package.ssplit) if package.ssplit else b"")
+        host = synth.model_from_bin(_blob(package.model), heads=config.num_heads,
+                                    enc_layers=config.encoder_layers, dec_layers=config.decoder_layers)
+        if self.vocabulary.size() > host.V:
+            raise ValueError("vocabulary has %d pieces, the model's embedding %d rows"
+                             % (self.vocabulary.size(), host.V))
+        self.device = device
+        self.engine = capi.Model(host, device)
+        self.dims = (host.D, host.F, host.V)
+        self.shortlist_generator = None
+        if package.shortlist:  # Model::make_shortlist_generator, Model.cc:60-72
+            self.shortlist_generator = capi.ShortlistGenerator(_blob(package.shortlist), host.V, host.V,
+                                                               shared=True, check=False, device=device)
+
+    def close(self) -> None:
+        if self.shortlist_generator is not None:
+            self.shortlist_generator.close()
+            self.shortlist_generator = None
+        self.engine.close()
+
+
+@dataclass
+class _Unit:  # one segment of one request
+    request: int
+    index: int
+    words: List[int]
+
+
+class Service:
+    """slimt::Async (Frontend.hh:20-78) behind the binding's blocking calls (slimt.cpp:44-135)."""
+
+    def __init__(self, workers: int = 1, cache_size: int = 0, max_words: int = 1024, wrap_length: int = 128,
+                 tgt_length_limit_factor: float = 1.5):
+        if workers < 1:
+            raise ValueError("workers must be >= 1")
+        self.workers = workers
+        self.cache_size = cache_size  # accepted for signature parity; no translation cache here
+        self.max_words = max_words
+        self.wrap_length = wrap_length
+        self.limit_factor = tgt_length_limit_factor
+        self._pool = ThreadPoolExecutor(max_workers=workers)
+        self._contexts = {}  # (model id, worker thread) -> capi.Context
+        self._lock = threading.Lock()
+
+    # -- batching ---------------------------------------------------------------------------------
+    def _batches(self, units: Sequence[_Unit]) -> List[List[_Unit]]:
+        """Longest first; a batch closes when (sentences x its longest) would pass max_words."""
+        order = sorted(units, key=lambda u: (-len(u.words), u.request, u.index))
+        out, cur = [], []
+        for u in order:
+            width = len(cur[0].words) if cur else len(u.words)
+            if cur and (len(cur) + 1) * width > self.max_words:
+                out.append(cur)
+                cur = []
+            cur.append(u)
+        if cur:
+            out.append(cur)
+        return out
+
+    def _context(self, model: Model, B: int, S: int) -> capi.Context:
+        key = (model.id, threading.get_ident())
+        with self._lock:
+            entry = self._contexts.get(key)
+        if entry is None or entry[1] < B or entry[2] < S:
+            if entry is not None:
+                entry[0].close()
+            cap_b, cap_s = max(B, entry[1] if entry else 0), max(S, entry[2] if entry else 0)
+            entry = (capi.Context(model.engine, cap_b, cap_s), cap_b, cap_s)
+            with self._lock:
+                self._contexts[key] = entry
+        return entry[0]
+
+    def _run_batch(self, model: Model, batch: List[_Unit]):
+        B, S = len(batch), max(len(u.words) for u in batch)
+        ids = np.zeros((B, S), np.uint32)
+        lens = np.zeros(B, np.uint32)
+        for i, u in enumerate(batch):
+            ids[i, :len(u.words)] = u.words
+            lens[i] = len(u.words)
+        ctx = self._context(model, B, S)
+        shortlist = model.shortlist_generator.generate(ids, lens) if model.shortlist_generator else None
+        out_ids, out_len, align = ctx.translate(ids, lens, shortlist, self.limit_factor,
+                                                model.vocabulary.eos_id(), want_align=True)
+        results = []
+        for i, u in enumerate(batch):
+            n, L = int(out_len[i]), int(lens[i])
+            results.append((u, out_ids[i, :n].tolist(), align[i, :n, :L].tolist()))
+        return results
+
+    def _translate_segments(self, model: Model, per_request: List[List[List[int]]]):
+        units = [_Unit(r, i, seg) for r, segs in enumerate(per_request) for i, seg in enumerate(segs)]
+        histories = [[None] * len(segs) for segs in per_request]
+        futures = [self._pool.submit(self._run_batch, model, b) for b in self._batches(units)]
+        for f in futures:
+            for u, words, alignment in f.result():
+                histories[u.request][u.index] = (words, alignment)
+        return histories
+
+    # -- the binding's calls -----------------------------------------------------------------------
+    @staticmethod
+    def _respond(model: Model, source: AnnotatedText, histories) -> Response:
+        """Request::complete (Request.cc:136-170): decode every sentence, keep the source's gaps."""
+        resp = Response(source=source)
+        for s, (words, alignment) in enumerate(histories):
+            decoded, views = model.vocabulary.decode(words, ignore_eos=False)
+            resp.target.append_sentence(source.gap(s), [decoded[b:e] for b, e in views])
+            resp.alignments.append(alignment)
+        if histories:
+            resp.target.append_ending_whitespace(source.gap(len(histories)))
+        else:
+            resp.target.append_ending_whitespace(source.data)
+        return resp
+
+    def translate(self, model: Model, texts: Sequence[str], html: bool = False,
+                  encoding: Encoding = Encoding.UTF8) -> List[Response]:
+        if html:
+            raise NotImplementedError("HTML markup transfer is outside the ported path (SURVEY.md §2)")
+        processed = [model.processor.process(t, self.wrap_length) for t in texts]
+        histories = self._translate_segments(model, [segs for _, segs in processed])
+        out = []
+        for (source, _), hist in zip(processed, histories):
+            r = self._respond(model, source, hist)
+            r.to(encoding)
+            out.append(r)
+        return out
+
+    def pivot(self, first: Model, second: Model, texts: Sequence[str], html: bool = False) -> List[Response]:
+        """source -> pivot with `first`, pivot -> target with `second`, sentence for sentence;
+        alignments are marginalised over the pivot tokens (Response.cc:13-195)."""
+        if html:
+            raise NotImplementedError("HTML markup transfer is outside the ported path (SURVEY.md §2)")
+        firsts = self.translate(first, texts, encoding=Encoding.Byte)
+        second_in = [second.processor.process_annotated(r.target) for r in firsts]
+        histories = self._translate_segments(second, [segs for _, segs in second_in])
+        out = []
+        for r1, (src2, _), hist in zip(firsts, second_in, histories):
+            r2 = self._respond(second, src2, hist)
+            out.append(combine(r1, r2))
+        return out
+
+    def close(self) -> None:
+        self._pool.shutdown(wait=True)
+        for ctx, _, _ in self._contexts.values():
+            ctx.close()
+        self._contexts.clear()
+
+
+# -------------------------------------------------------------------------------------------------
+def transfer_through_characters(source_side_pivots: Sequence[Range], target_side_pivots: Sequence[Range],
+                                pivot_given_targets: Alignment) -> Alignment:
+    """p(q' | t) over the second model's pivot tokens q' -> p(q | t) over the first model's
+    pivot tokens q: each q' spreads its probability evenly over its bytes, each q collects
+    what falls into its range; a trailing zero-width q' (EOS) is shared out evenly
+    (Response.cc:13-116)."""
+    T, nq = len(pivot_given_targets), len(source_side_pivots)
+    out = [[0.0] * nq for _ in range(T)]
+    sq = qt = 0
+    while sq < nq and qt < len(target_side_pivots):
+        a, b = source_side_pivots[sq], target_side_pivots[qt]
+        if a.begin == b.begin and a.end == b.end:
+            for t in range(T):
+                out[t][sq] += pivot_given_targets[t][qt]
+            sq, qt = sq + 1, qt + 1
+            continue
+        left, right = max(a.begin, b.begin), min(a.end, b.end)
+        if right > left:
+            share = (right - left) / float(b.size())
+            for t in range(T):
+                out[t][sq] += share * pivot_given_targets[t][qt]
+        if a.end == b.end:
+            sq, qt = sq + 1, qt + 1
+        elif a.end > b.end:
+            qt += 1
+        else:
+            sq += 1
+    while qt < len(target_side_pivots):  # what is left has no surface: EOS
+        for t in range(T):
+            gift = pivot_given_targets[t][qt] / max(1, nq)
+            for s in range(nq):
+                out[t][s] += gift
+        qt += 1
+    return out
+
+
+def remap_alignments(first: Response, second: Response) -> List[Alignment]:
+    """p(s | t) = sum_q p(s | q) p(q | t) per sentence (Response.cc:118-177)."""
+    out = []
+    for sid in range(first.source.sentence_count()):
+        s_given_q, q_given_t = first.alignments[sid], second.alignments[sid]
+        q1 = [first.target.word_as_range(sid, i) for i in range(first.target.word_count(sid))]
+        q2 = [second.source.word_as_range(sid, i) for i in range(second.source.word_count(sid))]
+        remapped = np.asarray(transfer_through_characters(q1, q2, q_given_t), np.float32).reshape(len(q_given_t), len(q1))
+        sq = np.asarray(s_given_q, np.float32).reshape(len(q1), -1)
+        out.append((remapped @ sq).tolist())
+    return out
+
+
+def combine(first: Response, second: Response) -> Response:  # Response.cc:179-191
+    r = Response()
+    if first.alignments:
+        r.alignments = remap_alignments(first, second)
+    r.source, r.target = first.source, second.target
+    return r

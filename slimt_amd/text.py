@@ -1,0 +1,373 @@
+"""Text side of the translation path: sentence splitting,
+SentencePiece vocabulary, segment wrapping and the annotated source / target text
+a Response carries. Host code only -- it feeds `slimt_hip_translate` token ids and
+turns the returned ids back into text.
+
+Mirrors the reference's interface (same names, argument meaning and results):
+  Range, AnnotatedText        slimt/Annotation.hh:16-230, Annotation.cc:15-85
+  Vocabulary                  slimt/Vocabulary.cc:24-104 (encode -> ids + byte views, decode)
+  Splitter, sentence_stream   slimt/Splitter.cc:23-46,125-245 (rules), :247-360 (modes)
+  TextProcessor               slimt/TextProcessor.cc:66-199 (tokenize, process, wrap)
+
+All ranges are BYTE offsets into the UTF-8 text (the reference's Encoding::Byte);
+`AnnotatedText.to(Encoding.UTF8)` converts them to code-point offsets as
+Annotation.cc:87-160 does. SentencePiece itself comes from the `sentencepiece`
+wheel (the reference links the same library, Vocabulary.hh:9).
+"""
+from __future__ import annotations
+
+import bisect
+import enum
+from dataclasses import dataclass
+from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import regex
+
+
+class Encoding(enum.IntEnum):  # Types.hh (Encoding::Byte / Encoding::UTF8)
+    Byte = 0
+    UTF8 = 1
+
+
+@dataclass(frozen=True)
+class Range:
+    begin: int = 0
+    end: int = 0
+
+    def size(self) -> int:
+        return self.end - self.begin
+
+    def __repr__(self) -> str:  # bindings/python/slimt.cpp:151-154
+        return "{%d, %d}" % (self.begin, self.end)
+
+
+class AnnotatedText:
+    """A text blob with sentence and (sub)word boundaries. Between two sentences lies
+    a gap (whitespace the translation keeps); gap i precedes sentence i and gap
+    sentence_count() follows the last one (Annotation.hh:16-60)."""
+
+    def __init__(self, text: str | bytes = b""):
+        self.data: bytes = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        self._words: List[List[int]] = []  # per sentence: token begin offsets + sentence end
+        self._encoding = Encoding.Byte
+        self._cp: Optional[List[int]] = None
+
+    # -- the reference's accessors -----------------------------------------------------------
+    @property
+    def text(self) -> str:
+        return self.data.decode("utf-8", errors="replace")
+
+    def sentence_count(self) -> int:
+        return len(self._words)
+
+    def word_count(self, sentence_id: int) -> int:
+        return len(self._words[sentence_id]) - 1
+
+    def _range(self, b: int, e: int) -> Range:
+        if self._encoding == Encoding.UTF8:
+            cp = self._codepoints()
+            return Range(cp[b], cp[e])
+        return Range(b, e)
+
+    def word_as_range(self, sentence_id: int, word_id: int) -> Range:
+        w = self._words[sentence_id]
+        return self._range(w[word_id], w[word_id + 1])
+
+    def sentence_as_range(self, sentence_id: int) -> Range:
+        w = self._words[sentence_id]
+        return self._range(w[0], w[-1])
+
+    def _gap_bytes(self, gap_id: int) -> Tuple[int, int]:
+        b = self._words[gap_id - 1][-1] if gap_id > 0 else 0
+        e = self._words[gap_id][0] if gap_id < len(self._words) else len(self.data)
+        return b, e
+
+    def gap_as_range(self, gap_id: int) -> Range:
+        return self._range(*self._gap_bytes(gap_id))
+
+    def word(self, sentence_id: int, word_id: int) -> str:
+        w = self._words[sentence_id]
+        return self.data[w[word_id]:w[word_id + 1]].decode("utf-8", errors="replace")
+
+    def sentence(self, sentence_id: int) -> str:
+        w = self._words[sentence_id]
+        return self.data[w[0]:w[-1]].decode("utf-8", errors="replace")
+
+    def gap(self, gap_id: int) -> str:
+        b, e = self._gap_bytes(gap_id)
+        return self.data[b:e].decode("utf-8", errors="replace")
+
+    def to(self, encoding: Encoding) -> None:
+        """Ranges in bytes or in code points (Annotation.cc:87-160)."""
+        self._encoding = Encoding(encoding)
+
+    def _codepoints(self) -> List[int]:
+        """cp[i] = code points that start before byte i (token boundaries are lead bytes)."""
+        if self._cp is None or len(self._cp) != len(self.data) + 1:
+            cp, n = [0] * (len(self.data) + 1), 0
+            for i, c in enumerate(self.data):
+                cp[i] = n
+                if (c & 0xC0) != 0x80:
+                    n += 1
+            cp[len(self.data)] = n
+            self._cp = cp
+        return self._cp
+
+    # -- construction --------------------------------------------------------------------------
+    def record_existing_sentence(self, token_ranges: Sequence[Tuple[int, int]], sentence_begin: int) -> None:
+        """A sentence that already lies in the text: contiguous (begin, end) byte ranges of
+        its tokens (Annotation.cc:54-85). An empty list records an empty sentence."""
+        if token_ranges:
+            offs = [b for b, _ in token_ranges] + [token_ranges[-1][1]]
+            for (b0, e0), (b1, _) in zip(token_ranges, token_ranges[1:]):
+                if e0 != b1:
+                    raise ValueError("tokens of a sentence must be contiguous")
+        else:
+            offs = [sentence_begin]
+        last = self._words[-1][-1] if self._words else 0
+        if offs[0] < last or offs[-1] > len(self.data):
+            raise ValueError("sentence outside the text or before the previous one")
+        self._words.append(offs)
+
+    def append_sentence(self, prefix: bytes | str, tokens: Sequence[bytes]) -> None:
+        """Append gap text, then a sentence given as its token strings (Annotation.cc:20-43)."""
+        self.append_ending_whitespace(prefix)
+        offs, o = [], len(self.data)
+        for t in tokens:
+            offs.append(o)
+            o += len(t)
+        offs.append(o)
+        self.data += b"".join(tokens)
+        self._words.append(offs)
+        self._cp = None
+
+    def append_ending_whitespace(self, whitespace: bytes | str) -> None:
+        self.data += whitespace.encode("utf-8") if isinstance(whitespace, str) else whitespace
+        self._cp = None
+
+
+# ----------------------------------------------------------------------------------------------
+class Vocabulary:
+    """SentencePiece model: text <-> ids with the byte range of every piece."""
+
+    def __init__(self, model: str | bytes):
+        import sentencepiece
+        if isinstance(model, (bytes, bytearray, memoryview)):  # Vocabulary(View), Vocabulary.cc:24-27
+            self.sp = sentencepiece.SentencePieceProcessor(model_proto=bytes(model))
+        else:  # Vocabulary(path), Vocabulary.cc:29-32
+            self.sp = sentencepiece.SentencePieceProcessor(model_file=model)
+
+    def size(self) -> int:
+        return self.sp.get_piece_size()
+
+    def eos_id(self) -> int:
+        return self.sp.eos_id()
+
+    def pad_id(self) -> int:
+        return self.sp.pad_id()
+
+    def encode(self, line: bytes | str, add_eos: bool = False) -> Tuple[List[int], List[Tuple[int, int]]]:
+        """ids and, per id, the (begin, end) byte range of its surface in `line`
+        (Vocabulary.cc:34-75; the appended EOS has no range, as there)."""
+        raw = line.encode("utf-8") if isinstance(line, str) else bytes(line)
+        proto = self.sp.encode(raw.decode("utf-8", errors="replace"), out_type="proto")
+        words = [p.id for p in proto.pieces]
+        views = [(p.begin, p.end) for p in proto.pieces]
+        if add_eos:
+            words.append(self.eos_id())
+        return words, views
+
+    def encode_batch(self, lines: Sequence[bytes], num_threads: int = 0):
+        """encode() of many lines on SentencePiece's own thread pool (the reference
+        tokenises sentence by sentence, TextProcessor.cc:111-124; this is where the text
+        side gets its throughput from)."""
+        texts = [l.decode("utf-8", errors="replace") for l in lines]
+        protos = self.sp.encode(texts, out_type="proto", num_threads=num_threads or None)
+        return [([p.id for p in pr.pieces], [(p.begin, p.end) for p in pr.pieces]) for pr in protos]
+
+    def decode(self, words: Sequence[int], ignore_eos: bool = False) -> Tuple[bytes, List[Tuple[int, int]]]:
+        """Decoded text and the byte range of every piece in it; the EOS piece is an empty
+        range at the end and is dropped with ignore_eos (Vocabulary.cc:77-104)."""
+        proto = self.sp.decode([int(w) for w in words], out_type="proto")
+        views = [(p.begin, p.end) for p in proto.pieces]
+        if ignore_eos and views:
+            views.pop()
+        return proto.text.encode("utf-8"), views
+
+
+# ----------------------------------------------------------------------------------------------
+_EOS_MARKS = ".?!։。？！"  # . ? ! Armenian full stop, CJK 。？！
+_CANDIDATE = regex.compile(
+    r"(?P<prefix>[\p{L}\p{N}]*)(?P<punct>[" + regex.escape(_EOS_MARKS) + r"]+)"
+    r"(?P<tail>['\")\]’”\p{Pf}]*(?:\[\p{Nd}+[\p{Nd},\s]*\p{Nd}\])?['\")\]’”\p{Pf}]*)"
+    r"(?P<ws>\s*)", regex.UNICODE)
+_NEXT_WORD = regex.compile(r"[^\s\p{L}\p{N}\p{M}\p{S}]*\s*(?P<lead>[\p{L}\p{M}\p{N}]*)", regex.UNICODE)
+_LOWER = regex.compile(r"\p{M}*\p{Ll}", regex.UNICODE)
+_UPPER = regex.compile(r"\p{M}*[\p{Lu}\p{Lt}]", regex.UNICODE)
+_DIGIT = regex.compile(r"[\p{Nd}\p{Nl}]", regex.UNICODE)
+_OTHER = regex.compile(r"\p{M}*\p{Lo}", regex.UNICODE)
+
+
+class Splitter:
+    """Rule-based sentence boundary detection with a list of non-breaking prefixes.
+
+    A boundary is a run of sentence-final punctuation (+ closing quotes / brackets / a
+    footnote mark) followed by whitespace (none needed after 。！？), unless what follows
+    starts in lower case, or the mark is a single '.' after a known prefix ("Mr.", or a
+    NUMERIC_ONLY prefix before a digit: "No. 5"), or it is a bracketed ellipsis "[...]".
+    Marks inside a token ("a.b.c", "3.14") have no whitespace after them and never break.
+    (Behaviour of Splitter.cc:125-245.)"""
+
+    def __init__(self, prefix_file: str = ""):
+        self.prefix_type = {}
+        if prefix_file:
+            self.load(prefix_file)
+
+    def load(self, fname: str) -> None:
+        with open(fname, "rb") as f:
+            self.load_from_serialized(f.read())
+
+    def load_from_serialized(self, buffer: bytes | str) -> None:
+        text = buffer.decode("utf-8", errors="replace") if isinstance(buffer, (bytes, bytearray)) else buffer
+        for line in text.splitlines():  # "<prefix> [#NUMERIC_ONLY#]", '#' starts a comment (Splitter.cc:30-46)
+            m = regex.match(r"([^#\s]*)\s*(#\s*NUMERIC_ONLY\s*#)?", line)
+            if m and m.group(1):
+                self.prefix_type[m.group(1)] = 2 if m.group(2) else 1
+
+    def prefix_class(self, prefix: str) -> int:
+        return self.prefix_type.get(prefix, 0)
+
+    def split(self, paragraph: str) -> Iterator[Tuple[int, int]]:
+        """(begin, end) character ranges of the sentences of one paragraph."""
+        n = len(paragraph)
+        pos = 0
+        while True:
+            while pos < n and paragraph[pos].isspace():
+                pos += 1
+            if pos >= n:
+                return
+            start, scan, end = pos, pos, None
+            while end is None:
+                m = _CANDIDATE.search(paragraph, scan)
+                if not m:
+                    break
+                scan = m.end()
+                punct, ws = m.group("punct"), m.group("ws")
+                if not ws and punct not in ("。", "！", "？"):
+                    scan = m.end("punct") if m.end("punct") > m.start() else m.end()
+                    continue
+                lead = _NEXT_WORD.match(paragraph, m.end()).group("lead")
+                if _OTHER.match(lead):
+                    pass  # a letter without case (CJK, ...): break
+                elif _LOWER.match(lead):
+                    continue
+                elif _UPPER.match(lead):
+                    if punct == "." and self.prefix_class(m.group("prefix")) != 0:
+                        continue
+                elif _DIGIT.match(lead):
+                    if punct == "." and self.prefix_class(m.group("prefix")) == 2:
+                        continue
+                else:
+                    if punct == "..." and m.group("tail") == "]" and m.start("punct") > start + 1 and \
+                            paragraph[m.start("punct") - 1] == "[":
+                        continue
+                end = m.start("ws")
+            if end is None:  # no boundary left: the rest, right-trimmed, is the last sentence
+                end = n
+                while end > start and paragraph[end - 1].isspace():
+                    end -= 1
+                yield start, end
+                return
+            yield start, end
+            pos = end
+
+
+def sentence_stream(text: bytes, splitter: Splitter, mode: str) -> Iterator[Tuple[int, int]]:
+    """(begin, end) byte ranges of the sentences of `text` (SentenceStream, Splitter.cc:301-360).
+    mode: "sentence" = one sentence per line; "paragraph" = one paragraph per line, split by the
+    rules; "wrapped_text" = paragraphs separated by blank lines, line breaks inside a paragraph
+    are ordinary whitespace. Empty lines yield empty sentences, as the reference's stream does
+    (TextProcessor.cc:118 drops them after tokenisation)."""
+    if mode not in ("sentence", "paragraph", "wrapped_text"):
+        raise ValueError("Unknown ssplitmode %r, choose one of sentence, paragraph, wrapped_text" % mode)
+    if mode == "wrapped_text":
+        paragraphs = []
+        for m in regex.finditer(rb"(?:[^\n]|\n(?![\r\n]))+", text):
+            paragraphs.append((m.start(), m.end()))
+    else:
+        paragraphs, pos = [], 0
+        while pos < len(text):
+            nl = text.find(b"\n", pos)
+            end = len(text) if nl < 0 else nl
+            e = end
+            while e > pos and text[e - 1:e] == b"\r":
+                e -= 1
+            paragraphs.append((pos, e))
+            pos = end + 1
+    for b, e in paragraphs:
+        if mode == "sentence":
+            yield b, e
+            continue
+        para = text[b:e].decode("utf-8", errors="replace")
+        # character -> byte offsets of this paragraph
+        offs, o = [], b
+        for ch in para:
+            offs.append(o)
+            o += len(ch.encode("utf-8"))
+        offs.append(o)
+        for cb, ce in splitter.split(para):
+            yield offs[cb], offs[ce]
+
+
+# ----------------------------------------------------------------------------------------------
+class TextProcessor:
+    """text -> (annotated source, segments of token ids ending in EOS) (TextProcessor.cc:78-199)."""
+
+    def __init__(self, mode: str, vocabulary: Vocabulary, prefixes: bytes | str = b""):
+        if mode not in ("sentence", "paragraph", "wrapped_text"):
+            raise ValueError("Unknown ssplitmode %r, choose one of sentence, paragraph, wrapped_text" % mode)
+        self.mode = mode
+        self.vocabulary = vocabulary
+        self.splitter = Splitter()
+        if prefixes:
+            self.splitter.load_from_serialized(prefixes)
+
+    def process(self, text: str | bytes, wrap_length: int, num_threads: int = 0) -> Tuple[AnnotatedText, List[List[int]]]:
+        """Split, tokenise, wrap every sentence into segments of at most wrap_length ids
+        including the EOS appended to each (TextProcessor.cc:101-163)."""
+        if wrap_length < 2:
+            raise ValueError("wrap_length must leave room for one token and EOS")
+        source = AnnotatedText(text)
+        spans = list(sentence_stream(source.data, self.splitter, self.mode))
+        encoded = self.vocabulary.encode_batch([source.data[b:e] for b, e in spans], num_threads)
+        eos, step = self.vocabulary.eos_id(), wrap_length - 1
+        segments: List[List[int]] = []
+        for (b, _), (words, views) in zip(spans, encoded):
+            for off in range(0, len(words), step):  # nothing for a sentence without tokens
+                part = views[off:off + step]
+                ranges = [(b + pb, b + pe) for pb, pe in part]
+                # sentencepiece's views of one sentence are contiguous; wrapped parts start where
+                # their first token starts, and the EOS is an empty range at the end
+                ranges.append((ranges[-1][1], ranges[-1][1]))
+                source.record_existing_sentence(ranges, ranges[0][0])
+                segments.append(list(words[off:off + step]) + [eos])
+        return source, segments
+
+    def process_annotated(self, source: AnnotatedText) -> Tuple[AnnotatedText, List[List[int]]]:
+        """Re-tokenise text whose sentences are already marked (the pivot's second hop): one
+        segment per sentence, no wrapping (TextProcessor.cc:165-199)."""
+        out = AnnotatedText(source.data)
+        eos = self.vocabulary.eos_id()
+        spans = []
+        for s in range(source.sentence_count()):
+            w = source._words[s]
+            spans.append((w[0], w[-1]))
+        encoded = self.vocabulary.encode_batch([out.data[b:e] for b, e in spans])
+        segments = []
+        for (b, e), (words, views) in zip(spans, encoded):
+            ranges = [(b + pb, b + pe) for pb, pe in views]
+            end = ranges[-1][1] if ranges else e
+            ranges.append((end, end))
+            out.record_existing_sentence(ranges, ranges[0][0])
+            segments.append(list(words) + [eos])
+        return out, segments

@@ -1,0 +1,50 @@
+"""GPU box: text in -> text out through slimt_amd.frontend.
+Where the time goes once the model runs at > 1 M tok/s: sentence splitting + SentencePiece
+(host), batching, the engine, decoding ids back to text.
+usage: python tools/text_bench.py [documents] [workers]"""
+import io, json, os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sentencepiece
+from slimt_amd import frontend, synth
+
+docs_n = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+workers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+V = 8000
+rnd = random.Random(11)
+words = ["".join(rnd.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rnd.randint(2, 9))) for _ in range(40000)]
+def sentence():
+    s = " ".join(rnd.choice(words) for _ in range(rnd.randint(6, 22)))
+    return s[0].upper() + s[1:] + rnd.choice(".?!")
+corpus = [sentence() for _ in range(60000)]
+t0 = time.time()
+out = io.BytesIO()
+sentencepiece.SentencePieceTrainer.train(sentence_iterator=iter(corpus), model_writer=out, vocab_size=V, model_type="unigram",
+                                         pad_id=-1, unk_id=1, bos_id=-1, eos_id=0, minloglevel=2)
+t_train = time.time() - t0
+m = synth.make_model("tiny11", eos_bias=2.0, dims=(256, 1536, 8, 6, 2, V))
+blob = synth.make_lexical_shortlist(V, V, frequent=100, best=50, seed=5)
+model = frontend.Model(frontend.Config(split_mode="paragraph"),
+                       frontend.Package(model=synth.write_bin(m), vocabulary=out.getvalue(), shortlist=blob), device=0)
+texts = [" ".join(sentence() for _ in range(8)) for _ in range(docs_n)]
+chars = sum(len(t) for t in texts)
+res = {"documents": docs_n, "sentences": docs_n * 8, "chars": chars, "workers": workers, "vocab": V,
+       "spm_train_s": round(t_train, 1)}
+# 1. the text side alone
+t0 = time.time()
+processed = [model.processor.process(t, 128) for t in texts]
+dt = time.time() - t0
+src_tokens = sum(len(s) for _, segs in processed for s in segs)
+res["text_processor"] = {"seconds": round(dt, 3), "source_tokens_per_s": round(src_tokens / dt), "threads": "sentencepiece pool"}
+# 2. end to end
+for max_words in (4096, 16384):
+    svc = frontend.Service(workers=workers, max_words=max_words)
+    svc.translate(model, texts[:64])  # warm-up: contexts, kernels
+    t0 = time.time()
+    responses = svc.translate(model, texts)
+    dt = time.time() - t0
+    tgt_tokens = sum(r.target.word_count(s) for r in responses for s in range(r.target.sentence_count()))
+    res[f"end_to_end_max_words_{max_words}"] = {"seconds": round(dt, 3), "source_tokens_per_s": round(src_tokens / dt),
+                                                 "target_tokens_per_s": round(tgt_tokens / dt),
+                                                 "sentences_per_s": round(docs_n * 8 / dt)}
+    svc.close()
+print(json.dumps(res))
