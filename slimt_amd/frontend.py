@@ -29,7 +29,7 @@ import numpy as np
 from . import capi, synth
 from .text import AnnotatedText, Encoding, Range, TextProcessor, Vocabulary  # noqa: F401 (API surface)
 
-Alignment = List[List[float]]  # [target token][source token], p(source | target)
+Alignment = np.ndarray  # [target token][source token] f32, p(source | target); indexes like a list of rows
 
 
 @dataclass
@@ -176,11 +176,7 @@ class Service:
         shortlist = model.shortlist_generator.generate(ids, lens) if model.shortlist_generator else None
         out_ids, out_len, align = ctx.translate(ids, lens, shortlist, self.limit_factor,
                                                 model.vocabulary.eos_id(), want_align=True)
-        results = []
-        for i, u in enumerate(batch):
-            n, L = int(out_len[i]), int(lens[i])
-            results.append((u, out_ids[i, :n].tolist(), align[i, :n, :L].tolist()))
-        return results
+        return [(u, out_ids[i, :int(out_len[i])], align[i, :int(out_len[i]), :int(lens[i])]) for i, u in enumerate(batch)]
 
     def _translate_segments(self, model: Model, per_request: List[List[List[int]]]):
         units = [_Unit(r, i, seg) for r, segs in enumerate(per_request) for i, seg in enumerate(segs)]
@@ -192,31 +188,32 @@ class Service:
         return histories
 
     # -- the binding's calls -----------------------------------------------------------------------
-    @staticmethod
-    def _respond(model: Model, source: AnnotatedText, histories) -> Response:
-        """Request::complete (Request.cc:136-170): decode every sentence, keep the source's gaps."""
-        resp = Response(source=source)
-        for s, (words, alignment) in enumerate(histories):
-            decoded, views = model.vocabulary.decode(words, ignore_eos=False)
-            resp.target.append_sentence(source.gap(s), [decoded[b:e] for b, e in views])
-            resp.alignments.append(alignment)
-        if histories:
-            resp.target.append_ending_whitespace(source.gap(len(histories)))
-        else:
-            resp.target.append_ending_whitespace(source.data)
-        return resp
+    def _respond_many(self, model: Model, sources: Sequence[AnnotatedText], histories) -> List[Response]:
+        """Request::complete (Request.cc:136-170) for a whole call: every sentence's ids decoded in
+        one SentencePiece batch, the source's gaps kept, target token ranges resolved on demand."""
+        flat = [words for hist in histories for words, _ in hist]
+        decoded = model.vocabulary.decode_text_batch(flat, self.workers) if flat else []
+        out, k, v = [], 0, model.vocabulary
+        for source, hist in zip(sources, histories):
+            resp = Response(source=source)
+            for s, (words, alignment) in enumerate(hist):
+                resp.target.append_lazy_sentence(source.gap_bytes(s), decoded[k].encode("utf-8"), len(words),
+                                                 lambda words=words: v.decode_boundaries(words))
+                resp.alignments.append(alignment)
+                k += 1
+            resp.target.append_ending_whitespace(source.gap_bytes(len(hist)) if hist else source.data)
+            out.append(resp)
+        return out
 
     def translate(self, model: Model, texts: Sequence[str], html: bool = False,
                   encoding: Encoding = Encoding.UTF8) -> List[Response]:
         if html:
             raise NotImplementedError("HTML markup transfer is outside the ported path (SURVEY.md §2)")
-        processed = [model.processor.process(t, self.wrap_length) for t in texts]
+        processed = model.processor.process_many(texts, self.wrap_length, self.workers)
         histories = self._translate_segments(model, [segs for _, segs in processed])
-        out = []
-        for (source, _), hist in zip(processed, histories):
-            r = self._respond(model, source, hist)
+        out = self._respond_many(model, [src for src, _ in processed], histories)
+        for r in out:
             r.to(encoding)
-            out.append(r)
         return out
 
     def pivot(self, first: Model, second: Model, texts: Sequence[str], html: bool = False) -> List[Response]:
@@ -227,11 +224,8 @@ class Service:
         firsts = self.translate(first, texts, encoding=Encoding.Byte)
         second_in = [second.processor.process_annotated(r.target) for r in firsts]
         histories = self._translate_segments(second, [segs for _, segs in second_in])
-        out = []
-        for r1, (src2, _), hist in zip(firsts, second_in, histories):
-            r2 = self._respond(second, src2, hist)
-            out.append(combine(r1, r2))
-        return out
+        seconds = self._respond_many(second, [src for src, _ in second_in], histories)
+        return [combine(r1, r2) for r1, r2 in zip(firsts, seconds)]
 
     def close(self) -> None:
         self._pool.shutdown(wait=True)
@@ -256,6 +250,14 @@ def transfer_through_characters(source_side_pivots: Sequence[Range], target_side
             for t in range(T):
                 out[t][sq] += pivot_given_targets[t][qt]
             sq, qt = sq + 1, qt + 1
+            continue
+        if b.size() == 0:  # a piece without surface before the end (SentencePiece's bare "▁"): its mass
+            for t in range(T):  # goes to the pivot token at its position (the reference asserts overlap
+                out[t][sq] += pivot_given_targets[t][qt]  # here, Response.cc:49, and divides by 0)
+            qt += 1
+            continue
+        if a.size() == 0:  # likewise on the first model's side: nothing to collect
+            sq += 1
             continue
         left, right = max(a.begin, b.begin), min(a.end, b.end)
         if right > left:
@@ -286,13 +288,13 @@ def remap_alignments(first: Response, second: Response) -> List[Alignment]:
         q2 = [second.source.word_as_range(sid, i) for i in range(second.source.word_count(sid))]
         remapped = np.asarray(transfer_through_characters(q1, q2, q_given_t), np.float32).reshape(len(q_given_t), len(q1))
         sq = np.asarray(s_given_q, np.float32).reshape(len(q1), -1)
-        out.append((remapped @ sq).tolist())
+        out.append(remapped @ sq)
     return out
 
 
 def combine(first: Response, second: Response) -> Response:  # Response.cc:179-191
     r = Response()
-    if first.alignments:
+    if len(first.alignments):
         r.alignments = remap_alignments(first, second)
     r.source, r.target = first.source, second.target
     return r

@@ -41,6 +41,14 @@ class Range:
         return "{%d, %d}" % (self.begin, self.end)
 
 
+class _Lazy:
+    """A sentence whose token ranges are computed when first asked for."""
+    __slots__ = ("begin", "end", "count", "resolve")
+
+    def __init__(self, begin: int, end: int, count: int, resolve):
+        self.begin, self.end, self.count, self.resolve = begin, end, count, resolve
+
+
 class AnnotatedText:
     """A text blob with sentence and (sub)word boundaries. Between two sentences lies
     a gap (whitespace the translation keeps); gap i precedes sentence i and gap
@@ -48,7 +56,9 @@ class AnnotatedText:
 
     def __init__(self, text: str | bytes = b""):
         self.data: bytes = text.encode("utf-8") if isinstance(text, str) else bytes(text)
-        self._words: List[List[int]] = []  # per sentence: token begin offsets + sentence end
+        # per sentence: token begin offsets + sentence end, or a _Lazy that produces them on
+        # first use (ranges cost a protobuf walk per piece; translating needs only the ids)
+        self._sent: List[object] = []
         self._encoding = Encoding.Byte
         self._cp: Optional[List[int]] = None
 
@@ -58,10 +68,29 @@ class AnnotatedText:
         return self.data.decode("utf-8", errors="replace")
 
     def sentence_count(self) -> int:
-        return len(self._words)
+        return len(self._sent)
+
+    @property
+    def _words(self) -> "_WordsView":
+        return _WordsView(self)
+
+    def _offsets(self, sentence_id: int) -> List[int]:
+        w = self._sent[sentence_id]
+        if isinstance(w, _Lazy):
+            offs = w.resolve()
+            if len(offs) != w.count + 1:
+                raise RuntimeError("lazy annotation resolved to a different token count")
+            offs[0], offs[-1] = w.begin, w.end  # the bounds it was recorded with (gaps depend on them)
+            self._sent[sentence_id] = w = offs
+        return w
+
+    def _bounds(self, sentence_id: int) -> Tuple[int, int]:
+        w = self._sent[sentence_id]
+        return (w.begin, w.end) if isinstance(w, _Lazy) else (w[0], w[-1])
 
     def word_count(self, sentence_id: int) -> int:
-        return len(self._words[sentence_id]) - 1
+        w = self._sent[sentence_id]
+        return w.count if isinstance(w, _Lazy) else len(w) - 1
 
     def _range(self, b: int, e: int) -> Range:
         if self._encoding == Encoding.UTF8:
@@ -70,32 +99,35 @@ class AnnotatedText:
         return Range(b, e)
 
     def word_as_range(self, sentence_id: int, word_id: int) -> Range:
-        w = self._words[sentence_id]
+        w = self._offsets(sentence_id)
         return self._range(w[word_id], w[word_id + 1])
 
     def sentence_as_range(self, sentence_id: int) -> Range:
-        w = self._words[sentence_id]
-        return self._range(w[0], w[-1])
+        return self._range(*self._bounds(sentence_id))
 
     def _gap_bytes(self, gap_id: int) -> Tuple[int, int]:
-        b = self._words[gap_id - 1][-1] if gap_id > 0 else 0
-        e = self._words[gap_id][0] if gap_id < len(self._words) else len(self.data)
+        b = self._bounds(gap_id - 1)[1] if gap_id > 0 else 0
+        e = self._bounds(gap_id)[0] if gap_id < len(self._sent) else len(self.data)
         return b, e
 
     def gap_as_range(self, gap_id: int) -> Range:
         return self._range(*self._gap_bytes(gap_id))
 
     def word(self, sentence_id: int, word_id: int) -> str:
-        w = self._words[sentence_id]
+        w = self._offsets(sentence_id)
         return self.data[w[word_id]:w[word_id + 1]].decode("utf-8", errors="replace")
 
     def sentence(self, sentence_id: int) -> str:
-        w = self._words[sentence_id]
-        return self.data[w[0]:w[-1]].decode("utf-8", errors="replace")
+        b, e = self._bounds(sentence_id)
+        return self.data[b:e].decode("utf-8", errors="replace")
 
     def gap(self, gap_id: int) -> str:
         b, e = self._gap_bytes(gap_id)
         return self.data[b:e].decode("utf-8", errors="replace")
+
+    def gap_bytes(self, gap_id: int) -> bytes:
+        b, e = self._gap_bytes(gap_id)
+        return self.data[b:e]
 
     def to(self, encoding: Encoding) -> None:
         """Ranges in bytes or in code points (Annotation.cc:87-160)."""
@@ -124,10 +156,19 @@ class AnnotatedText:
                     raise ValueError("tokens of a sentence must be contiguous")
         else:
             offs = [sentence_begin]
-        last = self._words[-1][-1] if self._words else 0
-        if offs[0] < last or offs[-1] > len(self.data):
+        self._check_order(offs[0], offs[-1])
+        self._sent.append(offs)
+
+    def record_lazy_sentence(self, begin: int, end: int, count: int, resolve) -> None:
+        """record_existing_sentence for a sentence of `count` tokens in [begin, end) whose token
+        boundaries `resolve()` returns (count + 1 ascending offsets) when somebody asks."""
+        self._check_order(begin, end)
+        self._sent.append(_Lazy(begin, end, count, resolve))
+
+    def _check_order(self, begin: int, end: int) -> None:
+        last = self._bounds(len(self._sent) - 1)[1] if self._sent else 0
+        if begin < last or end > len(self.data) or end < begin:
             raise ValueError("sentence outside the text or before the previous one")
-        self._words.append(offs)
 
     def append_sentence(self, prefix: bytes | str, tokens: Sequence[bytes]) -> None:
         """Append gap text, then a sentence given as its token strings (Annotation.cc:20-43)."""
@@ -138,12 +179,36 @@ class AnnotatedText:
             o += len(t)
         offs.append(o)
         self.data += b"".join(tokens)
-        self._words.append(offs)
+        self._sent.append(offs)
+        self._cp = None
+
+    def append_lazy_sentence(self, prefix: bytes | str, sentence: bytes, count: int, resolve) -> None:
+        """append_sentence with the sentence's text given whole; `resolve()` returns the token
+        boundaries relative to the sentence (count + 1 offsets, 0 .. len(sentence))."""
+        self.append_ending_whitespace(prefix)
+        begin = len(self.data)
+        self.data += sentence
+        self._sent.append(_Lazy(begin, begin + len(sentence), count, lambda: [begin + o for o in resolve()]))
         self._cp = None
 
     def append_ending_whitespace(self, whitespace: bytes | str) -> None:
         self.data += whitespace.encode("utf-8") if isinstance(whitespace, str) else whitespace
         self._cp = None
+
+
+class _WordsView:
+    """Read access to the resolved token boundaries of every sentence (a list of lists)."""
+
+    def __init__(self, owner: AnnotatedText):
+        self.owner = owner
+
+    def __len__(self) -> int:
+        return len(self.owner._sent)
+
+    def __getitem__(self, sentence_id: int) -> List[int]:
+        if sentence_id < 0:
+            sentence_id += len(self.owner._sent)
+        return self.owner._offsets(sentence_id)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -184,6 +249,23 @@ class Vocabulary:
         texts = [l.decode("utf-8", errors="replace") for l in lines]
         protos = self.sp.encode(texts, out_type="proto", num_threads=num_threads or None)
         return [([p.id for p in pr.pieces], [(p.begin, p.end) for p in pr.pieces]) for pr in protos]
+
+    def encode_ids_batch(self, lines: Sequence[str], num_threads: int = 0) -> List[List[int]]:
+        """ids only (no ranges): SentencePiece's batch call, one C++ pass on its thread pool."""
+        return self.sp.encode(list(lines), out_type=int, num_threads=num_threads or None)
+
+    def decode_text_batch(self, sentences: Sequence[Sequence[int]], num_threads: int = 0) -> List[str]:
+        return self.sp.decode([list(map(int, w)) for w in sentences], num_threads=num_threads or None)
+
+    def encode_boundaries(self, line: str) -> List[int]:
+        """Token boundaries (byte offsets into `line`, one more than tokens) of encode(line)."""
+        proto = self.sp.encode(line, out_type="proto")
+        return [p.begin for p in proto.pieces] + [proto.pieces[-1].end if proto.pieces else 0]
+
+    def decode_boundaries(self, words: Sequence[int]) -> List[int]:
+        """Token boundaries of decode(words) in the decoded text (the EOS piece is empty)."""
+        proto = self.sp.decode([int(w) for w in words], out_type="proto")
+        return [p.begin for p in proto.pieces] + [proto.pieces[-1].end if proto.pieces else 0]
 
     def decode(self, words: Sequence[int], ignore_eos: bool = False) -> Tuple[bytes, List[Tuple[int, int]]]:
         """Decoded text and the byte range of every piece in it; the EOS piece is an empty
@@ -335,39 +417,67 @@ class TextProcessor:
     def process(self, text: str | bytes, wrap_length: int, num_threads: int = 0) -> Tuple[AnnotatedText, List[List[int]]]:
         """Split, tokenise, wrap every sentence into segments of at most wrap_length ids
         including the EOS appended to each (TextProcessor.cc:101-163)."""
+        return self.process_many([text], wrap_length, num_threads)[0]
+
+    def process_many(self, texts: Sequence[str | bytes], wrap_length: int, num_threads: int = 0):
+        """process() of many texts with ONE SentencePiece batch call for all their sentences.
+        Token ranges of the source annotation are resolved lazily (only a wrapped sentence
+        needs them here, to find where its parts start)."""
         if wrap_length < 2:
             raise ValueError("wrap_length must leave room for one token and EOS")
-        source = AnnotatedText(text)
-        spans = list(sentence_stream(source.data, self.splitter, self.mode))
-        encoded = self.vocabulary.encode_batch([source.data[b:e] for b, e in spans], num_threads)
-        eos, step = self.vocabulary.eos_id(), wrap_length - 1
-        segments: List[List[int]] = []
-        for (b, _), (words, views) in zip(spans, encoded):
-            for off in range(0, len(words), step):  # nothing for a sentence without tokens
-                part = views[off:off + step]
-                ranges = [(b + pb, b + pe) for pb, pe in part]
-                # sentencepiece's views of one sentence are contiguous; wrapped parts start where
-                # their first token starts, and the EOS is an empty range at the end
-                ranges.append((ranges[-1][1], ranges[-1][1]))
-                source.record_existing_sentence(ranges, ranges[0][0])
-                segments.append(list(words[off:off + step]) + [eos])
-        return source, segments
+        sources = [AnnotatedText(t) for t in texts]
+        spans, lines = [], []
+        for src in sources:
+            sp = list(sentence_stream(src.data, self.splitter, self.mode))
+            spans.append(sp)
+            lines += [src.data[b:e].decode("utf-8", errors="replace") for b, e in sp]
+        encoded = self.vocabulary.encode_ids_batch(lines, num_threads) if lines else []
+        eos, step, v = self.vocabulary.eos_id(), wrap_length - 1, self.vocabulary
+        out, k = [], 0
+        for src, sp in zip(sources, spans):
+            segments: List[List[int]] = []
+            for b, e in sp:
+                words, line = encoded[k], lines[k]
+                k += 1
+                # the sentence is what its tokens cover: SentencePiece drops surrounding whitespace
+                lead = len(line) - len(line.lstrip())
+                if lead or line != line.rstrip():
+                    b += len(line[:lead].encode("utf-8"))
+                    line = line.strip()
+                    e = b + len(line.encode("utf-8"))
+                if not words:  # nothing after normalisation (TextProcessor.cc:118)
+                    continue
+                if len(words) <= step:
+                    def resolve(b=b, line=line):
+                        offs = [b + o for o in v.encode_boundaries(line)]
+                        return offs + [offs[-1]]  # the EOS: empty, at the end
+                    src.record_lazy_sentence(b, e, len(words) + 1, resolve)
+                    segments.append(list(words) + [eos])
+                    continue
+                bounds = [b + o for o in v.encode_boundaries(line)]
+                for off in range(0, len(words), step):
+                    part = bounds[off:off + step + 1]
+                    src.record_existing_sentence(list(zip(part[:-1], part[1:])) + [(part[-1], part[-1])], part[0])
+                    segments.append(list(words[off:off + step]) + [eos])
+            out.append((src, segments))
+        return out
 
     def process_annotated(self, source: AnnotatedText) -> Tuple[AnnotatedText, List[List[int]]]:
         """Re-tokenise text whose sentences are already marked (the pivot's second hop): one
         segment per sentence, no wrapping (TextProcessor.cc:165-199)."""
         out = AnnotatedText(source.data)
-        eos = self.vocabulary.eos_id()
-        spans = []
-        for s in range(source.sentence_count()):
-            w = source._words[s]
-            spans.append((w[0], w[-1]))
-        encoded = self.vocabulary.encode_batch([out.data[b:e] for b, e in spans])
+        eos, v = self.vocabulary.eos_id(), self.vocabulary
+        spans = [source._bounds(s) for s in range(source.sentence_count())]
+        lines = [out.data[b:e].decode("utf-8", errors="replace") for b, e in spans]
+        encoded = v.encode_ids_batch(lines) if lines else []
         segments = []
-        for (b, e), (words, views) in zip(spans, encoded):
-            ranges = [(b + pb, b + pe) for pb, pe in views]
-            end = ranges[-1][1] if ranges else e
-            ranges.append((end, end))
-            out.record_existing_sentence(ranges, ranges[0][0])
+        for (b, e), line, words in zip(spans, lines, encoded):
+            def resolve(b=b, e=e, line=line, n=len(words)):
+                offs = [b + o for o in v.encode_boundaries(line)] if n else [e]
+                return offs + [offs[-1]]
+            if words:
+                out.record_lazy_sentence(b, e, len(words) + 1, resolve)
+            else:
+                out.record_existing_sentence([(e, e)], e)
             segments.append(list(words) + [eos])
         return out, segments

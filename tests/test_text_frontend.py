@@ -152,6 +152,13 @@ def test_alignment_transfer_keeps_probability_mass():
     assert np.allclose(out[:, 3], p[:, 3], atol=1e-6)  # EOS meets EOS
     same = np.asarray(frontend.transfer_through_characters(q1, q1, p.tolist()))
     assert np.allclose(same, p, atol=1e-7)
+    # a surface-less piece in front (SentencePiece's bare "▁") keeps its mass
+    q3 = [R(0, 0)] + q2
+    p3 = rng.random((5, 5)).astype(np.float32)
+    p3 /= p3.sum(axis=1, keepdims=True)
+    out3 = np.asarray(frontend.transfer_through_characters(q1, q3, p3.tolist()))
+    assert np.allclose(out3.sum(axis=1), 1.0, atol=1e-6)
+    assert np.allclose(out3[:, 0], p3[:, 0] + p3[:, 1] + p3[:, 2] * 0.25, atol=1e-6)
     # no EOS on the first side: the second side's EOS mass is shared out
     out2 = np.asarray(frontend.transfer_through_characters(q1[:3], q2, p.tolist()))
     assert np.allclose(out2.sum(axis=1), 1.0, atol=1e-6)

@@ -31,10 +31,15 @@ res = {"documents": docs_n, "sentences": docs_n * 8, "chars": chars, "workers": 
        "spm_train_s": round(t_train, 1)}
 # 1. the text side alone
 t0 = time.time()
-processed = [model.processor.process(t, 128) for t in texts]
+processed = model.processor.process_many(texts, 128, workers)
 dt = time.time() - t0
 src_tokens = sum(len(s) for _, segs in processed for s in segs)
-res["text_processor"] = {"seconds": round(dt, 3), "source_tokens_per_s": round(src_tokens / dt), "threads": "sentencepiece pool"}
+res["text_processor"] = {"seconds": round(dt, 3), "source_tokens_per_s": round(src_tokens / dt),
+                         "what": "split + SentencePiece ids for the whole call (process_many), %d threads" % workers}
+t0 = time.time()
+n_ranges = sum(src.word_count(s) + 0 * src.word_as_range(s, 0).begin for src, _ in processed[:200] for s in range(src.sentence_count()))
+dt = time.time() - t0
+res["resolve_source_ranges"] = {"seconds": round(dt, 3), "tokens_per_s": round(n_ranges / dt), "what": "token byte ranges on demand (200 documents)"}
 # 2. end to end
 for max_words in (4096, 16384):
     svc = frontend.Service(workers=workers, max_words=max_words)
