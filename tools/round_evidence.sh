@@ -3,7 +3,7 @@
 # usage: tools/round_evidence.sh <tag>     (writes gpurun_out/<tag>_*)
 TAG=${1:-r02}
 mkdir -p gpurun_out
-tools/profile_round.sh $TAG || exit 1
+WITH_BASE=1 tools/profile_round.sh $TAG || exit 1
 timeout -k 10 120 python tools/decode_phases.py 256 > gpurun_out/${TAG}_phases.txt 2>&1 || exit 1
 timeout -k 10 120 python tools/decode_phases_loaded.py > gpurun_out/${TAG}_phases_loaded.txt 2>&1 || exit 1
 timeout -k 10 200 python tools/occupancy_trace.py 20 480 256 > gpurun_out/${TAG}_occupancy.txt 2>&1 || exit 1
@@ -18,3 +18,5 @@ SLIMT_BENCH_REHEARSAL=1 timeout -k 10 300 python bench.py --gpus 2 --steps 10 --
 cut -c1-300 gpurun_out/${TAG}_rehearsal_2ranks_on_1gpu.json
 for cfg in "8 32768 4096 0" "8 32768 4096 1" "6 32768 4096 0" "8 32768 0 1"; do timeout -k 10 200 python tools/async_bench.py $cfg >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err; done
 cut -c1-330 gpurun_out/${TAG}_service_bench.jsonl
+timeout -k 10 250 python tools/text_bench.py 3000 8 > gpurun_out/${TAG}_text_bench.json 2> gpurun_out/${TAG}_text_bench.err
+cut -c1-400 gpurun_out/${TAG}_text_bench.json
