@@ -818,7 +818,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           A2[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
         }
       }
-      __syncthreads();
+      lds_barrier();
       // every sentence of this tile has emitted EOS (counted in the previous step's sampling
       // phase; checked here, behind the first barrier that follows it anyway)
       if (l == 0 && flags[0] >= valid_rows) {
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       SLIMT_STAMP(sb + 1);
       // h = LN(x + relu(c')), quantised for the Q projection
 #pragma unroll
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         const int row = 16 * rr + wave;
         ln_row<KSD>(pre + row * LDF, L.rnn_ln_s, L.rnn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
       }
-      __syncthreads();
+      lds_barrier();
       SLIMT_STAMP(sb + 2);
       // ---- cross-attention (Modules.cc:287-319) --------------------------
       // Q projection -> xs (x is dead until the end of the layer)
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
                                              for (int r = 0; r < 4; ++r)
                                                xs[(16 * rt + lg * 4 + r) * LDF + col] = dequant(acc[r], cq, L.q.u, pb);
                                            });
-      __syncthreads();
+      lds_barrier();
       SLIMT_STAMP(sb + 3);
       // SDPA over the cached K/V of this wave's sentence(s); output quantised into A1
 #pragma unroll 1
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           for (int i = 0; i < KSD; ++i) A1[row * LDA + lane + 64 * i] = 0;
         }
       }
-      __syncthreads();
+      lds_barrier();
       SLIMT_STAMP(sb + 4);
       // O projection + residual h (Modules.cc:308-314)
       stream_gemm<KSD, 1, NT_D, false, RT>(A1, LDA, L.o, wave, lane,
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
                                                pre[rl * LDF + col] = v + hs[rl * LDF + col];
                                              }
                                            });
-      __syncthreads();
+      lds_barrier();
       SLIMT_STAMP(sb + 5);
 #pragma unroll
       for (int rr = 0; rr < RT; ++rr) {
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         ln_row<KSD>(pre + row * LDF, L.attn_ln_s, L.attn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA,
                     L.ffn1.a_quant, lane);
       }
-      __syncthreads();
+      lds_barrier();
       SLIMT_STAMP(sb + 6);
       // ---- FFN (Modules.cc:251-257) ----------------------------------------
       stream_gemm<KSD, NB_FFN, NT_F1, false, RT>(
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
               A3[(16 * rt + lg * 4 + r) * LDA3 + col] = (char)quantize1(v, L.ffn2.a_quant);
             }
           });
-      __syncthreads();
+      lds_barrier();
       SLIMT_STAMP(sb + 7);
       stream_gemm<KSF, NB_FFN, NT_D, false, RT>(
           A3, LDA3, L.ffn2, wave, lane, [&](int tile, int rt, const v4i &acc, int c2, float pb) {
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
               pre[rl * LDF + col] = v + hs[rl * LDF + col];
             }
           });
-      __syncthreads();
+      lds_barrier();
       SLIMT_STAMP(sb + 8);
       // next layer's input; after the last layer: quantised for the logits
 #pragma unroll
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       }
       // Between layers no barrier: the next phase (the SSRU's quantisation) reads and writes
       // only this wave's own rows; the barrier after it covers both.
-      if (l + 1 == Ld) __syncthreads();
+      if (l + 1 == Ld) lds_barrier();
       SLIMT_STAMP(sb + 9);
     }
     if (all_done) break;
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           red_i[wave * R + 16 * rt + lg * 4 + r] = bi[rt][r];
         }
       }
-    __syncthreads();
+    lds_barrier();
     SLIMT_STAMP(41);
     // wave w finishes sentences w (+ 16): reduce over the 16 waves' candidates
 #pragma unroll

@@ -144,6 +144,18 @@ __device__ __forceinline__ float half_max(float v) {
 // (Intgemm.inl.cc:29-34). max/min return the non-NaN operand,
 // so NaN quantises to -127 -- what intgemm's cvtps_epi32 (INT_MIN) + saturating
 // packs + max_epi8(-127) produce as well.
+// Workgroup barrier for phases that hand their data over through LDS only. __syncthreads()
+// is a full workgroup fence: the compiler puts s_waitcnt vmcnt(0) in front of s_barrier, which
+// also waits for every global load in flight -- a weight prefetch issued before the barrier
+// then costs its whole round trip AT the barrier. This one orders LDS traffic only
+// (s_waitcnt lgkmcnt(0); s_barrier) and leaves global loads and stores in flight. Not for data
+// that changes hands through global memory.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ int quantize1(float x, float a_quant) {
   float v = __builtin_rintf(x * a_quant);
   v = __builtin_fminf(__builtin_fmaxf(v, -127.0f), 127.0f);

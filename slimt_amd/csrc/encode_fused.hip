@@ -279,7 +279,13 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         }
       }
     }
-    __syncthreads();
+    // the O projection's fragments and epilogue constants travel under the attention (bq is
+    // dead until the next layer's prefetch)
+    load_frags<KSD>(bq, L.o, wave, 0, lane);
+    int cs_o;
+    float pb_o;
+    load_epi(L.o, wave, lr, cs_o, pb_o);
+    lds_barrier();
     SLIMT_ESTAMP(2);
     // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one
     // wave per (sentence, head). A chain of v_mfma_f32_32x32x2_f32 over ascending
@@ -376,29 +382,44 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     for (int r = rows_used + wave; r < ER; r += ENW)
 #pragma unroll
       for (int i = 0; i < KSD; ++i) Aq[r * LDA + lane + 64 * i] = 0;
-    __syncthreads();
+    lds_barrier();
     SLIMT_ESTAMP(3);
+    float lsc[KSD], lbi[KSD];
+    load_ln<KSD>(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);  // needed behind the next barrier
     {  // O projection + residual: x = x + yo (Modules.cc:308-314)
-      v4i bo[KSD];
-      load_frags<KSD>(bo, L.o, wave, 0, lane);
       v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-      tile_mma2<KSD>(Aq, LDA, bo, lr, lg, c0, c1);
+      tile_mma2<KSD>(Aq, LDA, bq, lr, lg, c0, c1);
       const int col = wave * 16 + lr;
-      int cs;
-      float pb;
-      load_epi(L.o, wave, lr, cs, pb);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float *p0 = xs + (lg * 4 + r) * LDX + col;
         float *p1 = xs + (16 + lg * 4 + r) * LDX + col;
-        *p0 = *p0 + edequant(c0[r], cs, L.o.u, pb);
-        *p1 = *p1 + edequant(c1[r], cs, L.o.u, pb);
+        *p0 = *p0 + edequant(c0[r], cs_o, L.o.u, pb_o);
+        *p1 = *p1 + edequant(c1[r], cs_o, L.o.u, pb_o);
       }
     }
-    __syncthreads();
+    // FFN1's first column tiles: requested here, used behind the LayerNorm
+    constexpr int NT1 = (KSF * 4) / ENW;  // FFN1 column tiles per wave
+    const rsrc_t r1 = make_rsrc(L.ffn1.Wp, (unsigned)L.ffn1.n_tiles * KSD * 1024u);
+    const rsrc_t r1c = make_rsrc(L.ffn1.colsum, (unsigned)L.ffn1.n_tiles * 64u);
+    const rsrc_t r1p = make_rsrc(L.ffn1.pb, (unsigned)L.ffn1.n_tiles * 64u);
+    v4i bw[3][KSD], cs4[3];
+    float4 pb4[3];
+    auto load1 = [&](int buf, int i) {
+      const int tile = wave + ENW * i;
+#pragma unroll
+      for (int ks = 0; ks < KSD; ++ks)
+        bw[buf][ks] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r1, lane * 16, (tile * KSD + ks) * 1024, 0));
+      cs4[buf] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r1c, lg * 16, tile * 64, 0));
+      pb4[buf] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1p, lg * 16, tile * 64, 0));
+    };
+#pragma unroll
+    for (int i = 0; i < 3 && i < NT1; ++i) {
+      load1(i, i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    lds_barrier();
     SLIMT_ESTAMP(4);
-    float lsc[KSD], lbi[KSD];
-    load_ln<KSD>(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);
     for (int r = wave; r < ER; r += ENW) {
       eln_row<KSD>(xs + r * LDX, lsc, lbi, a.eps, lane);
       const float4 v = *reinterpret_cast<const float4 *>(xs + r * LDX + 4 * lane);
@@ -406,7 +427,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
           pack4(quantize1(v.x, L.ffn1.a_quant), quantize1(v.y, L.ffn1.a_quant),
                 quantize1(v.z, L.ffn1.a_quant), quantize1(v.w, L.ffn1.a_quant));
     }
-    __syncthreads();
+    lds_barrier();
     SLIMT_ESTAMP(5);
     // ---- FFN (Modules.cc:326-331). The whole hidden layer (32 x F int8, 49 KiB for F = 1536)
     // lives in the dead q/k/v buffers, so the phase is two streams with ONE barrier between
@@ -420,7 +441,6 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       constexpr int LDH = 64 * KSF + 16;  // hidden row stride (bytes)
       char *Hb = reinterpret_cast<char *>(qb);
       static_assert((size_t)ER * LDH <= (size_t)ER * LDQQ * 4 + 2 * (size_t)ER * LDQ * 4, "hidden layer fits q/k/v");
-      constexpr int NT1 = (KSF * 4) / ENW;  // FFN1 column tiles per wave
       static_assert((KSF * 4) % ENW == 0 && KSF % 4 == 0, "whole tiles / whole chunks per wave");
       {
         v4i a0[KSD], a1[KSD];  // this wave's view of the 32 input rows, all of K
@@ -428,24 +448,6 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         for (int ks = 0; ks < KSD; ++ks) {
           a0[ks] = *reinterpret_cast<const v4i *>(Aq + lr * LDA + ks * 64 + lg * 16);
           a1[ks] = *reinterpret_cast<const v4i *>(Aq + (16 + lr) * LDA + ks * 64 + lg * 16);
-        }
-        const rsrc_t r1 = make_rsrc(L.ffn1.Wp, (unsigned)L.ffn1.n_tiles * KSD * 1024u);
-        const rsrc_t r1c = make_rsrc(L.ffn1.colsum, (unsigned)L.ffn1.n_tiles * 64u);
-        const rsrc_t r1p = make_rsrc(L.ffn1.pb, (unsigned)L.ffn1.n_tiles * 64u);
-        v4i bw[3][KSD], cs4[3];
-        float4 pb4[3];
-        auto load1 = [&](int buf, int i) {
-          const int tile = wave + ENW * i;
-#pragma unroll
-          for (int ks = 0; ks < KSD; ++ks)
-            bw[buf][ks] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r1, lane * 16, (tile * KSD + ks) * 1024, 0));
-          cs4[buf] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r1c, lg * 16, tile * 64, 0));
-          pb4[buf] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1p, lg * 16, tile * 64, 0));
-        };
-#pragma unroll
-        for (int i = 0; i < 3 && i < NT1; ++i) {
-          load1(i, i);
-          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < NT1; ++i) {
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         pb2v[0] = p4.x; pb2v[1] = p4.y; pb2v[2] = p4.z; pb2v[3] = p4.w;
       }
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // the hidden layer is complete
+      lds_barrier();  // the hidden layer is complete
       v4i f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
 #pragma unroll
       for (int c = 0; c < NC2; ++c) {
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         if (c + 3 < NC2) load2(buf, c + 3);
         __builtin_amdgcn_sched_barrier(0);
       }
+      load_ln<KSD>(L.ffn_ln_s, L.ffn_ln_b, lane, lsc, lbi);  // needed behind the next barrier
       // x = FFN2(...) + x: this lane's 4 columns of rows lr and 16 + lr
       const int col = wave * 16 + lg * 4;
       float4 *p0 = reinterpret_cast<float4 *>(xs + lr * LDX + col);
@@ -530,9 +533,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       *p0 = x0;
       *p1 = x1;
     }
-    __syncthreads();
+    lds_barrier();
     SLIMT_ESTAMP(6);
-    load_ln<KSD>(L.ffn_ln_s, L.ffn_ln_b, lane, lsc, lbi);
     {  // next layer's projection weights, under the LayerNorm (unconditional, so
        // that the registers are dead between the projections and here)
       const FusedEncLayerW &Ln = a.L[l + 1 < a.Le ? l + 1 : l];
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         for (int i = 0; i < KSD; ++i) dst[lane + 64 * i] = xs[r * LDX + lane + 64 * i];
       }
     }
-    __syncthreads();
+    lds_barrier();
     SLIMT_ESTAMP(7);
   }
 
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         Av[r * LDA + lane + 64 * i] = (char)quantize1(v, wv.a_quant);
       }
     }
-    __syncthreads();
+    lds_barrier();
     v4i bk[KSD], bv[KSD];
     load_frags<KSD>(bk, wk, wave, 0, lane);
     load_frags<KSD>(bv, wv, wave, 0, lane);
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
                 edequant(t ? c1[r] : c0[r], cs, wv.u, pb);
         }
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);
 }

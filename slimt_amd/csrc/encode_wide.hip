@@ -239,12 +239,12 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       for (int p = 0; p < 3; ++p) {
         SLIMT_WPHASE_LANE;
         const PreparedWeight &w = p == 0 ? L.q : (p == 1 ? L.k : L.v);
-        if (p || hr || l) __syncthreads();  // the A buffer / this round's q / k / v are free
+        if (p || hr || l) lds_barrier();  // the A buffer / this round's q / k / v are free
         if (p == 0 && hr == 1) SLIMT_WSTAMP(2);
         quantise_x(w.a_quant, lane);
         const int ct = hr * WNW + wave;
         const Epi4 e = load_epi4(w, ct, lg);
-        __syncthreads();
+        lds_barrier();
         v4i c0, c1;
         mma(Abuf, bw[0], lane, c0, c1);
         __builtin_amdgcn_sched_barrier(0);
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           dst[(16 + lr) * LDQ + col + r] = wdequant(c1[r], e.cs[r], w.u, e.pb[r]);
         }
       }
-      __syncthreads();
+      lds_barrier();
       SLIMT_WSTAMP(hr == 0 ? 1 : 3);
       // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one wave per
       // (sentence, head of the round). Same operand maps and reduction order as
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           for (int i = 0; i < RC / 64; ++i) Obuf[r * LDA + hr * RC + lane + 64 * i] = 0;
       }
     }
-    __syncthreads();  // attention of the last round is complete: q / k / v are dead
+    lds_barrier();  // attention of the last round is complete: q / k / v are dead
     SLIMT_WSTAMP(4);
     {  // O projection (Modules.cc:308-314): two column tiles per wave -> exchange tile
       SLIMT_WPHASE_LANE;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       *reinterpret_cast<float4 *>(Yb + lr * LDY + (wave + WNW) * 16 + lg * 4) = dequant4(c0, e1, L.o.u);
       *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + (wave + WNW) * 16 + lg * 4) = dequant4(c1, e1, L.o.u);
     }
-    __syncthreads();
+    lds_barrier();
     SLIMT_WSTAMP(5);
     {  // x = LN(x + O(...)); quantised for FFN1
       SLIMT_WPHASE_LANE;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         epb[t2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1p, lg * 16, (wave + WNW * t2) * 64, 0));
       }
     }
-    __syncthreads();  // the exchange tile is dead, FFN1's input is complete
+    lds_barrier();  // the exchange tile is dead, FFN1's input is complete
     SLIMT_WSTAMP(6);
     // ---- FFN (Modules.cc:326-331) ----------------------------------------------------------
     // one descriptor per FFN2 column tile, ending with the tile: a prefetch past the last chunk
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         *reinterpret_cast<int *>(Hb + (16 + lr) * LDH + col) = pack4(q1[0], q1[1], q1[2], q1[3]);
       }
     }
-    __syncthreads();  // the hidden layer is complete
+    lds_barrier();  // the hidden layer is complete
     SLIMT_WSTAMP(7);
     {  // FFN2: this wave's two column tiles over K = F, chunks of 4 k-steps, two in flight
       SLIMT_WPHASE_LANE;
@@ -480,14 +480,14 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       }
       const Epi4 e0 = load_epi4(L.ffn2, wave, lg);
       const Epi4 e1 = load_epi4(L.ffn2, wave + WNW, lg);
-      __syncthreads();  // every wave has read the hidden layer: the region becomes the exchange tile
+      lds_barrier();  // every wave has read the hidden layer: the region becomes the exchange tile
       SLIMT_WSTAMP(8);
       *reinterpret_cast<float4 *>(Yb + lr * LDY + wave * 16 + lg * 4) = dequant4(f[0][0], e0, L.ffn2.u);
       *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + wave * 16 + lg * 4) = dequant4(f[0][1], e0, L.ffn2.u);
       *reinterpret_cast<float4 *>(Yb + lr * LDY + (wave + WNW) * 16 + lg * 4) = dequant4(f[1][0], e1, L.ffn2.u);
       *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + (wave + WNW) * 16 + lg * 4) = dequant4(f[1][1], e1, L.ffn2.u);
     }
-    __syncthreads();
+    lds_barrier();
     SLIMT_WSTAMP(9);
     {  // x = LN(FFN2(...) + x)
       SLIMT_WPHASE_LANE;
@@ -529,9 +529,9 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       const PreparedWeight &w = p == 0 ? a.dec_k[l] : a.dec_v[l];
       float *out = a.kv + (size_t)(2 * l + p) * B * S * D;
       load_w(bw[1], w, wave + WNW, lane);
-      __syncthreads();
+      lds_barrier();
       quantise_x(w.a_quant, lane);
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const int ct = wave + WNW * t2;
