@@ -108,19 +108,22 @@ def algorithmic_macs_per_sentence(D, F, Le, Ld, S, T, N):
     return S * (Le * (4 * D * D + 2 * D * F) + Ld * 2 * D * D) + T * (Ld * (4 * D * D + 2 * D * F) + D * N)
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, preset="tiny11"):
     """HBM-side bytes per launch of `kernel` from the newest committed PMC pass
     (profiles/*_pmc_{FETCH,WRITE}_SIZE.json, written by tools/profile_round.sh:
-    separate rocprofv3 --pmc runs of this same workload). FETCH_SIZE is doubled
-    (gfx950 correction, MI355X_MICROARCH.md, HBM section). None if absent."""
+    separate rocprofv3 --pmc runs of this same workload; the `base` preset's passes carry
+    `_base_` in their names). FETCH_SIZE is doubled (gfx950 correction,
+    MI355X_MICROARCH.md, HBM section). None if absent."""
     import glob
     out = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{c}.json")),
-                       key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])  # r01_v9 < r01_v13
+        files = [f for f in glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{c}.json"))
+                 if ("_base_" in os.path.basename(f)) == (preset == "base")]
+        files.sort(key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])  # r01_v9 < r01_v13
         if not files:
             return None, None
-        rec = json.load(open(files[-1])).get(kernel)
+        rec = json.load(open(files[-1]))
+        rec = rec.get(kernel) or (rec.get("encode_wide") if kernel == "encode_fused" else None)
         if not rec:
             return None, None
         out[c] = (rec["avg_KB_per_launch"] * 1024.0, os.path.basename(files[-1]))
@@ -407,7 +410,9 @@ def main():
         ops = 2.0 * prof["int8_macs"] / max(1, prof["launches"])       # algorithmic int8 OPs / launch
         wbytes = prof["weight_bytes"] / max(1, prof["launches"])       # weight bytes streamed / launch
         achieved = ops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(prof_name)
+        # the committed counters are of the default workload of each preset: no figure for others
+        profiled = (args.preset in ("tiny11", "base") and B == 256 and S == 32 and n_sl == 4096 and not args.ragged)
+        traffic, traffic_src = pmc_traffic(prof_name, args.preset) if profiled else (None, None)
         cus = -(-B // 16) if prof_name == "decode_fused" else 256
         in_flight = prof["total_ms"] / (1e3 * dt) if dt > 0 else 0.0  # launches of this kernel running at once (this rank)
         # the path is a dense int8 contraction, so the bound is the int8 MFMA
