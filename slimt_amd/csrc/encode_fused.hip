@@ -149,8 +149,12 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   constexpr int D = 64 * KSD, H = D / DH;
   constexpr int LDX = D + 4;   // f32 residual rows
   constexpr int LDA = D + 16;  // int8 A rows
-  constexpr int LDQ = D + 1;   // f32 k/v rows (odd stride: row-per-lane reads are conflict-free)
-  constexpr int LDQQ = D + 4;  // f32 q rows (16-byte aligned: read as b128 broadcasts)
+  // f32 q / k / v rows. The attention's 16x16x4 MFMA operands are read by lanes (row n = lane % 16,
+  // k index g = lane / 16): q and k at [row n][d + g] -- stride = 4 mod 64 words puts the 64 lanes
+  // on 64 banks --, v at [key g][d + n] -- stride = 16 mod 64 does.
+  constexpr int LDQQ = D + 4;
+  constexpr int LDK = D + 4;
+  constexpr int LDV = D + 16;
   static_assert(D / 16 == ENW, "one 16-column tile of a D-wide GEMM per wave");
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   char *Av = Ak + ER * LDA;
   float *qb = reinterpret_cast<float *>(Av + ER * LDA);
   float *kb = qb + ER * LDQQ;
-  float *vb = kb + ER * LDQ;
+  float *vb = kb + ER * LDK;
 
   // row r of this workgroup: sentence s0 + r / S, position r % S
   auto row_sentence = [&](int r) { return s0 + r / S; };
@@ -262,8 +266,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         load_epi(L.k, wave, lr, cs, pb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          kb[(lg * 4 + r) * LDQ + col] = edequant(c0[r], cs, L.k.u, pb);
-          kb[(16 + lg * 4 + r) * LDQ + col] = edequant(c1[r], cs, L.k.u, pb);
+          kb[(lg * 4 + r) * LDK + col] = edequant(c0[r], cs, L.k.u, pb);
+          kb[(16 + lg * 4 + r) * LDK + col] = edequant(c1[r], cs, L.k.u, pb);
         }
       }
       {
@@ -274,8 +278,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         load_epi(L.v, wave, lr, cs, pb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          vb[(lg * 4 + r) * LDQ + col] = edequant(c0[r], cs, L.v.u, pb);
-          vb[(16 + lg * 4 + r) * LDQ + col] = edequant(c1[r], cs, L.v.u, pb);
+          vb[(lg * 4 + r) * LDV + col] = edequant(c0[r], cs, L.v.u, pb);
+          vb[(16 + lg * 4 + r) * LDV + col] = edequant(c1[r], cs, L.v.u, pb);
         }
       }
     }
@@ -287,94 +291,95 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     load_epi(L.o, wave, lr, cs_o, pb_o);
     lds_barrier();
     SLIMT_ESTAMP(2);
-    // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one
-    // wave per (sentence, head). A chain of v_mfma_f32_32x32x2_f32 over ascending
-    // k is bit-identical to the ascending fmaf chain the other kernels and the
-    // oracle use (tools/probe_mfma_f32.py: 65536 of 65536 elements, magnitudes
-    // 1e-38 .. 1e18), so only the instruction count changes (~3x fewer VALU
-    // instructions than the lane-per-key formulation it replaces):
-    //   S^T = K Q^T        lane (n, hh) <- key row / query row n, d = k0 + hh;
-    //                      result register r: key m = 8 (r / 4) + 4 hh + r % 4, query n
-    //   softmax over keys  the canonical 32-lane butterfly (masks 1, 2, 4, 8, 16 on
-    //                      the key index) = register pairs, one half-wave exchange,
-    //                      register pairs
-    //   O = P V            keys 2 i (lanes hh = 0) and 2 i + 1 (hh = 1) per step:
-    //                      half of P changes half-waves first (v_permlane32_swap)
+    // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one wave per
+    // (sentence, head, 16 queries) -- 16 jobs for one 32-token sentence, so all 16 waves work.
+    // A chain of v_mfma_f32_16x16x4_f32 over ascending k is bit-identical to the ascending fmaf
+    // chain the other kernels and the oracle use, like the 32x32x2 form the stage kernel keeps
+    // (tools/probe_mfma_f32.py: 16384 of 16384 elements, magnitudes 1e-38 .. 1e18):
+    //   S^T = K Q^T        two key tiles of 16; A lane (n, g) <- K[16 kt + n][d = k0 + g],
+    //                      B lane (n, g) <- Q[query n][d = k0 + g]; accumulator register r of lane
+    //                      (n, g): key 16 kt + 4 g + r, query n
+    //   softmax over keys  the canonical 32-key butterfly: masks 1, 2 inside the four registers,
+    //                      mask 4 = lanes g ^ 1 (xor 16), mask 8 = g ^ 2 (xor 32), mask 16 = the
+    //                      two key tiles
+    //   O = P V            keys 4 s + g per step s: the A operand wants P[query n][4 s + g] on lane
+    //                      (n, g), the accumulators hold P[query n][4 g + r] -- a 4 x 4 transpose
+    //                      between lane groups and registers (v_permlane16_swap, then 32)
     // Output quantised for the O projection into Aq (dead since the projections).
     {
-      typedef float v16f __attribute__((ext_vector_type(16)));
-      const int n = lane & 31, hh = lane >> 5;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const int n = lane & 15, g = lane >> 4;
       const float minus_inf = -99999999.0f;  // Input.cc:56-61
       const float lowest = -3.402823466e+38f;
-      auto tree32 = [&](const float(&x)[16], auto op, auto op_halves) -> float {
-        float t4[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)  // masks 1, 2: inside a group of four registers
-          t4[g] = op(op(x[4 * g], x[4 * g + 1]), op(x[4 * g + 2], x[4 * g + 3]));
-#pragma unroll
-        for (int g = 0; g < 4; ++g) t4[g] = op_halves(t4[g]);  // mask 4: the other half-wave
-        return op(op(t4[0], t4[1]), op(t4[2], t4[3]));          // masks 8, 16
-      };
-      auto fadd = [](float x, float y) { return x + y; };
-      auto fmax_ = [](float x, float y) { return fmaxf(x, y); };
-      auto add_halves = [](float x) { return bf_add<32>(x); };
-      auto max_halves = [](float x) { return bf_max<32>(x); };
-      for (int job = wave; job < spw * H; job += ENW) {
-        const int sl = job / H, h = job % H;
+      const int nqh = S > 16 ? 2 : 1;  // 16-query halves of a sentence
+      for (int job = wave; job < spw * H * nqh; job += ENW) {
+        const int qh = job % nqh, h = (job / nqh) % H, sl = job / (nqh * H);
         const int sb = s0 + sl;
         if (sb >= B) continue;
         const int base = sl * S;
         const int len = (int)a.lengths[sb];
-        const int rc = base + (n < S ? n : S - 1);  // this lane's key row (A) / query row (B), clamped
-        const float *kp = kb + rc * LDQ + h * DH + hh;
-        const float *qp = qb + rc * LDQQ + h * DH + hh;
-        v16f st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        const int qr = 16 * qh + n;
+        const float *qp = qb + (base + (qr < S ? qr : S - 1)) * LDQQ + h * DH + g;
+        float sc[2][4];
 #pragma unroll
-        for (int k0 = 0; k0 < DH; k0 += 2)
-          st = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[k0], qp[k0], st, 0, 0, 0);
-        float sc[16];
+        for (int kt = 0; kt < 2; ++kt) {
+          const int kr = 16 * kt + n;
+          const float *kp = kb + (base + (kr < S ? kr : S - 1)) * LDK + h * DH + g;
+          v4f st = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = 8 * (r >> 2) + 4 * hh + (r & 3);  // key of this register
-          float v = st[r];
-          if (a.alpha != 1.0f) v = a.alpha * v;
-          v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
-          if (m >= S) v = lowest;
-          sc[r] = v;
+          for (int k0 = 0; k0 < DH; k0 += 4) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[k0], qp[k0], st, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 16 * kt + 4 * g + r;  // key of this register
+            float v = st[r];
+            if (a.alpha != 1.0f) v = a.alpha * v;
+            v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
+            if (m >= S) v = lowest;
+            sc[kt][r] = v;
+          }
         }
-        const float mx = tree32(sc, fmax_, max_halves);
+        float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
+                         fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+        mx = bf_max<32>(bf_max<16>(mx));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = 8 * (r >> 2) + 4 * hh + (r & 3);
-          sc[r] = m < S ? exp_p(sc[r] - mx) : 0.0f;
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * g + r) < S ? exp_p(sc[kt][r] - mx) : 0.0f;
+        float t[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+          t[kt] = bf_add<32>(bf_add<16>((sc[kt][0] + sc[kt][1]) + (sc[kt][2] + sc[kt][3])));  // masks 1, 2 | 4 | 8
+        const float sum = t[0] + t[1];                                                          // mask 16
+        float pa[2][4];  // pa[kt][j] on lane (n, g) = P[query n][key 16 kt + 4 j + g]
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[kt][r] = sc[kt][r] / sum;  // keys >= S: exactly 0
+          // T[g][r] -> T[r][g]: registers (0, 1) and (2, 3) trade between lane groups g ^ 1,
+          // then the pairs trade between g ^ 2
+          const slimt_u2 s01 = __builtin_amdgcn_permlane16_swap(__float_as_int(sc[kt][0]), __float_as_int(sc[kt][1]), false, false);
+          const slimt_u2 s23 = __builtin_amdgcn_permlane16_swap(__float_as_int(sc[kt][2]), __float_as_int(sc[kt][3]), false, false);
+          const slimt_u2 ac = __builtin_amdgcn_permlane32_swap(s01.x, s23.x, false, false);
+          const slimt_u2 bd = __builtin_amdgcn_permlane32_swap(s01.y, s23.y, false, false);
+          pa[kt][0] = __int_as_float(ac.x);
+          pa[kt][1] = __int_as_float(bd.x);
+          pa[kt][2] = __int_as_float(ac.y);
+          pa[kt][3] = __int_as_float(bd.y);
         }
-        const float sum = tree32(sc, fadd, add_halves);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = sc[r] / sum;  // keys >= S: exactly 0
-        // P operand of step i: keys 2 i (hh = 0) / 2 i + 1 (hh = 1)
-        float pa[16];
+        for (int nt = 0; nt < DH / 16; ++nt) {
+          v4f o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const slimt_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * g + 0]),
-                                                                __float_as_int(sc[4 * g + 1]), false, false);
-          const slimt_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * g + 2]),
-                                                                __float_as_int(sc[4 * g + 3]), false, false);
-          pa[4 * g + 0] = __int_as_float(s01.x);  // keys 8 g + 0, 8 g + 1
-          pa[4 * g + 1] = __int_as_float(s23.x);  // keys 8 g + 2, 8 g + 3
-          pa[4 * g + 2] = __int_as_float(s01.y);  // keys 8 g + 4, 8 g + 5
-          pa[4 * g + 3] = __int_as_float(s23.y);  // keys 8 g + 6, 8 g + 7
-        }
-        v16f o = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+          for (int s4 = 0; s4 < 8; ++s4) {  // keys >= S contribute fma(0, v, o) == o
+            const int key = 4 * s4 + g;
+            const float vv = vb[(base + (key < S ? key : S - 1)) * LDV + h * DH + 16 * nt + n];
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4 >> 2][s4 & 3], vv, o, 0, 0, 0);
+          }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {  // keys >= S contribute fma(0, v, o) == o
-          const int key = 2 * i + hh;
-          const float vv = vb[(base + (key < S ? key : S - 1)) * LDQ + h * DH + n];
-          o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], vv, o, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = 8 * (r >> 2) + 4 * hh + (r & 3);  // query of this register
-          if (m < S) Aq[(base + m) * LDA + h * DH + n] = (char)quantize1(o[r], L.o.a_quant);
+          for (int r = 0; r < 4; ++r) {
+            const int q = 16 * qh + 4 * g + r;  // query of this register
+            if (q < S) Aq[(base + q) * LDA + h * DH + 16 * nt + n] = (char)quantize1(o[r], L.o.a_quant);
+          }
         }
       }
     }
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     {
       constexpr int LDH = 64 * KSF + 16;  // hidden row stride (bytes)
       char *Hb = reinterpret_cast<char *>(qb);
-      static_assert((size_t)ER * LDH <= (size_t)ER * LDQQ * 4 + 2 * (size_t)ER * LDQ * 4, "hidden layer fits q/k/v");
+      static_assert((size_t)ER * LDH <= (size_t)ER * (LDQQ + LDK + LDV) * 4, "hidden layer fits q/k/v");
       static_assert((KSF * 4) % ENW == 0 && KSF % 4 == 0, "whole tiles / whole chunks per wave");
       {
         v4i a0[KSD], a1[KSD];  // this wave's view of the 32 input rows, all of K
@@ -1097,8 +1102,8 @@ int fused_encode_grid(int B, int S, bool tickets) {
 }
 
 size_t fused_encode_lds_bytes(int D) {
-  return (size_t)ER * (D + 4) * 4 + 3 * (size_t)ER * (D + 16) + (size_t)ER * (D + 4) * 4 +
-         2 * (size_t)ER * (D + 1) * 4;
+  return (size_t)ER * (D + 4) * 4 + 3 * (size_t)ER * (D + 16) + 2 * (size_t)ER * (D + 4) * 4 +
+         (size_t)ER * (D + 16) * 4;
 }
 
 bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S) {

@@ -875,7 +875,9 @@ int check_batch(const slimt_hip_ctx *c, size_t B, size_t S) {
 // argument, Transformer.cc:57): the stage kernels run from there.
 int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layers,
                   const uint32_t *d_ids = nullptr, const uint32_t *d_lengths = nullptr,
-                  const PackArgs *pack = nullptr, bool embedded = false) {
+                  const PackArgs *pack = nullptr, bool embedded = false, bool keep_out = true) {
+  // keep_out = false (the translate path): the persistent encoder leaves the decoder its K/V
+  // cache only -- the encoder output itself (B S D f32, 8 MB at the headline size) is not written
   const slimt_hip_model *m = c->model;
   hipStream_t st = c->stream;
   const int M = B * S, D = m->D;
@@ -906,7 +908,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     f.lengths = d_lengths ? d_lengths : c->lengths.as<uint32_t>();
     f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
     f.kv = c->kv.as<float>();
-    f.enc_out = c->x0.as<float>();
+    f.enc_out = keep_out ? c->x0.as<float>() : nullptr;
     if (pack) {
       f.pack = *pack;
       f.pack_tiles = (pack->N + 15) / 16;
@@ -935,7 +937,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, c->dbg_embed.p, nbytes, hipMemcpyDeviceToHost, st));
     if (h_layers)
       HIPCHK(hipMemcpyAsync(h_layers, c->dbg_layers.p, nbytes * (size_t)m->Le, hipMemcpyDeviceToHost, st));
-    c->have_encoder_out = true;
+    c->have_encoder_out = keep_out;
     c->kv_ready = true;
     return 0;
   }
@@ -1225,7 +1227,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       RCCHK(prepare_affine_meta(c->out_sl, m->out_raw.as<int8_t>(), m->D, (int)n_sl, d_shortlist,
                                 m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, job));
     job.n_dev = d_n_sl;
-    RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr));
+    RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr, false, false));
     c->n_sl = (int)n_sl;
   } else {
     if (d_ids != c->ids.as<uint32_t>())

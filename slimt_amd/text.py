@@ -16,10 +16,9 @@ wheel (the reference links the same library, Vocabulary.hh:9).
 """
 from __future__ import annotations
 
-import bisect
 import enum
 from dataclasses import dataclass
-from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
+from typing import Iterator, List, Optional, Sequence, Tuple
 
 import regex
 
