@@ -390,14 +390,13 @@ def sentence_stream(text: bytes, splitter: Splitter, mode: str) -> Iterator[Tupl
             yield b, e
             continue
         para = text[b:e].decode("utf-8", errors="replace")
-        # character -> byte offsets of this paragraph
-        offs, o = [], b
-        for ch in para:
-            offs.append(o)
-            o += len(ch.encode("utf-8"))
-        offs.append(o)
-        for cb, ce in splitter.split(para):
-            yield offs[cb], offs[ce]
+        if len(para) == e - b:  # ASCII: character offsets are byte offsets
+            for cb, ce in splitter.split(para):
+                yield b + cb, b + ce
+            continue
+        for cb, ce in splitter.split(para):  # character -> byte offsets of the two cuts
+            sb = b + len(para[:cb].encode("utf-8"))
+            yield sb, sb + len(para[cb:ce].encode("utf-8"))
 
 
 # ----------------------------------------------------------------------------------------------
