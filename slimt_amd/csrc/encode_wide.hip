@@ -123,7 +123,11 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   constexpr int RC = HR * DH;        // q / k / v columns per round
   constexpr int NR = H / HR;         // rounds
   constexpr int LDA = D + 16;        // int8 A rows
-  constexpr int LDQ = RC + 1;        // f32 q / k / v rows (odd stride: row-per-lane reads are conflict-free)
+  // f32 q / k / v rows: the attention's 16x16x4 operands are read by lanes (row n = lane % 16,
+  // k index g = lane / 16) -- q, k at [row n][d + g]: stride = 4 mod 64 words is conflict-free;
+  // v at [key g][d + n]: stride = 16 mod 64 is
+  constexpr int LDQ = RC + 4;
+  constexpr int LDV = RC + 16;
   constexpr int LDY = D + 4;         // f32 exchange rows
   constexpr int LDH = F + 16;        // int8 hidden rows
   static_assert(RC / 16 == WNW, "one 16-column tile of a round's projection per wave");
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   char *region = Obuf + WR * LDA;    // q, k, v of four heads | exchange tile | hidden layer
   float *qb = reinterpret_cast<float *>(region);
   float *kb = qb + WR * LDQ;
-  float *vb = kb + WR * LDQ;
+  float *vb = kb + WR * LDQ;  // rows of LDV floats
   float *Yb = reinterpret_cast<float *>(region);
   char *Hb = region;
 
@@ -257,89 +261,94 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         const int col = wave * 16 + lg * 4;  // column inside the round
         float *dst = p == 0 ? qb : (p == 1 ? kb : vb);
+        const int ldd = p == 2 ? LDV : LDQ;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dst[lr * LDQ + col + r] = wdequant(c0[r], e.cs[r], w.u, e.pb[r]);
-          dst[(16 + lr) * LDQ + col + r] = wdequant(c1[r], e.cs[r], w.u, e.pb[r]);
+          dst[lr * ldd + col + r] = wdequant(c0[r], e.cs[r], w.u, e.pb[r]);
+          dst[(16 + lr) * ldd + col + r] = wdequant(c1[r], e.cs[r], w.u, e.pb[r]);
         }
       }
       lds_barrier();
       SLIMT_WSTAMP(hr == 0 ? 1 : 3);
       // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one wave per
-      // (sentence, head of the round). Same operand maps and reduction order as
-      // attention_mfma_kernel<64> (kernels.hip), operands read from LDS.
+      // (sentence, head of the round, 16 queries, half of the head's columns) -- 16 jobs for one
+      // 32-token sentence. v_mfma_f32_16x16x4_f32 chains over ascending k (bit-identical to the
+      // ascending fmaf chain, tools/probe_mfma_f32.py); operand maps, butterfly order and the
+      // lane-group transpose of P as in encode_fused.hip. The two waves that share a (head,
+      // query half) compute the same scores and each take 32 of the 64 output columns.
       {
         SLIMT_WPHASE_LANE;
-        typedef float v16f __attribute__((ext_vector_type(16)));
-        const int n = lane & 31, hh = lane >> 5;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const int n = lane & 15, g = lane >> 4;
         const float minus_inf = -99999999.0f;  // Input.cc:56-61
         const float lowest = -3.402823466e+38f;
-        for (int job = wave; job < spw * HR; job += WNW) {
-          const int sl = job / HR, hl = job % HR;
+        const int nqh = S > 16 ? 2 : 1;  // 16-query halves of a sentence
+        for (int job = wave; job < spw * HR * nqh * 2; job += WNW) {
+          const int dq = job & 1, qh = (job >> 1) % nqh, hl = ((job >> 1) / nqh) % HR, sl = (job >> 1) / (nqh * HR);
           const int sb = s0 + sl;
           if (sb >= B) continue;
           const int base = sl * S;
           const int len = (int)a.lengths[sb];
-          const int rc = base + (n < S ? n : S - 1);  // this lane's key row (A) / query row (B), clamped
-          const float *kp = kb + rc * LDQ + hl * DH + hh;
-          const float *qp = qb + rc * LDQ + hl * DH + hh;
-          v16f st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+          const int qr = 16 * qh + n;
+          const float *qp = qb + (base + (qr < S ? qr : S - 1)) * LDQ + hl * DH + g;
+          float sc[2][4];
 #pragma unroll
-          for (int k0 = 0; k0 < DH; k0 += 2) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[k0], qp[k0], st, 0, 0, 0);
-          float sc[16];
+          for (int kt = 0; kt < 2; ++kt) {
+            const int kr = 16 * kt + n;
+            const float *kp = kb + (base + (kr < S ? kr : S - 1)) * LDQ + hl * DH + g;
+            v4f st = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = 8 * (r >> 2) + 4 * hh + (r & 3);  // key of this register
-            float v = st[r];
-            if (a.alpha != 1.0f) v = a.alpha * v;
-            v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
-            if (m >= S) v = lowest;
-            sc[r] = v;
+            for (int k0 = 0; k0 < DH; k0 += 4) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[k0], qp[k0], st, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int m = 16 * kt + 4 * g + r;  // key of this register
+              float v = st[r];
+              if (a.alpha != 1.0f) v = a.alpha * v;
+              v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
+              if (m >= S) v = lowest;
+              sc[kt][r] = v;
+            }
           }
-          // canonical butterfly over 32 keys: masks 1, 2 = register pairs, mask 4 = the other
-          // half-wave, masks 8, 16 = register groups
-          float t4[4];
+          float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
+                           fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+          mx = bf_max<32>(bf_max<16>(mx));
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            t4[g] = bf_max<32>(fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3])));
-          const float mx = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
+          for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = 8 * (r >> 2) + 4 * hh + (r & 3);
-            sc[r] = m < S ? exp_p(sc[r] - mx) : 0.0f;
+            for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * g + r) < S ? exp_p(sc[kt][r] - mx) : 0.0f;
+          float t[2];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+            t[kt] = bf_add<32>(bf_add<16>((sc[kt][0] + sc[kt][1]) + (sc[kt][2] + sc[kt][3])));  // masks 1, 2 | 4 | 8
+          const float sum = t[0] + t[1];                                                          // mask 16
+          float pa[2][4];  // pa[kt][j] on lane (n, g) = P[query n][key 16 kt + 4 j + g]
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[kt][r] = sc[kt][r] / sum;  // keys >= S: exactly 0
+            const slimt_u2 s01 = __builtin_amdgcn_permlane16_swap(__float_as_int(sc[kt][0]), __float_as_int(sc[kt][1]), false, false);
+            const slimt_u2 s23 = __builtin_amdgcn_permlane16_swap(__float_as_int(sc[kt][2]), __float_as_int(sc[kt][3]), false, false);
+            const slimt_u2 ac = __builtin_amdgcn_permlane32_swap(s01.x, s23.x, false, false);
+            const slimt_u2 bd = __builtin_amdgcn_permlane32_swap(s01.y, s23.y, false, false);
+            pa[kt][0] = __int_as_float(ac.x);
+            pa[kt][1] = __int_as_float(bd.x);
+            pa[kt][2] = __int_as_float(ac.y);
+            pa[kt][3] = __int_as_float(bd.y);
           }
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            t4[g] = bf_add<32>((sc[4 * g] + sc[4 * g + 1]) + (sc[4 * g + 2] + sc[4 * g + 3]));
-          const float sum = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+          for (int nt = 0; nt < 2; ++nt) {
+            const int dcol = hl * DH + 32 * dq + 16 * nt + n;  // column inside the round
+            v4f o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] = sc[r] / sum;  // keys >= S: exactly 0
-          float pa[16];  // P operand of step i: keys 2 i (hh = 0) / 2 i + 1 (hh = 1)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const slimt_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * g + 0]),
-                                                                  __float_as_int(sc[4 * g + 1]), false, false);
-            const slimt_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_int(sc[4 * g + 2]),
-                                                                  __float_as_int(sc[4 * g + 3]), false, false);
-            pa[4 * g + 0] = __int_as_float(s01.x);
-            pa[4 * g + 1] = __int_as_float(s23.x);
-            pa[4 * g + 2] = __int_as_float(s01.y);
-            pa[4 * g + 3] = __int_as_float(s23.y);
-          }
-#pragma unroll
-          for (int db = 0; db < DH / 32; ++db) {
-            v16f o = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {  // keys >= S contribute fma(0, v, o) == o
-              const int key = 2 * i + hh;
-              const float vv = vb[(base + (key < S ? key : S - 1)) * LDQ + hl * DH + 32 * db + n];
-              o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], vv, o, 0, 0, 0);
+            for (int s4 = 0; s4 < 8; ++s4) {  // keys >= S contribute fma(0, v, o) == o
+              const int key = 4 * s4 + g;
+              const float vv = vb[(base + (key < S ? key : S - 1)) * LDV + dcol];
+              o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4 >> 2][s4 & 3], vv, o, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int m = 8 * (r >> 2) + 4 * hh + (r & 3);  // query of this register
-              if (m < S)
-                Obuf[(base + m) * LDA + (hr * HR + hl) * DH + 32 * db + n] = (char)quantize1(o[r], L.o.a_quant);
+            for (int r = 0; r < 4; ++r) {
+              const int q = 16 * qh + 4 * g + r;  // query of this register
+              if (q < S) Obuf[(base + q) * LDA + hr * RC + dcol] = (char)quantize1(o[r], L.o.a_quant);
             }
           }
         }
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
 
 size_t wide_encode_lds_bytes() {
   constexpr int D = 512, F = 2048, RC = 256;
-  const size_t qkv = 3 * (size_t)WR * (RC + 1) * 4;
+  const size_t qkv = 2 * (size_t)WR * (RC + 4) * 4 + (size_t)WR * (RC + 16) * 4;
   const size_t y = (size_t)WR * (D + 4) * 4, h = (size_t)WR * (F + 16);
   size_t region = qkv > y ? qkv : y;
   region = region > h ? region : h;
