@@ -130,6 +130,13 @@ int slimt_hip_model_set_decoder_budget(slimt_hip_model *model, int workgroups);
  * temporal, 2 = always non-temporal. Results do not depend on it. Needs the
  * decoder admission (budget > 0) for 0 and 2. */
 int slimt_hip_model_set_kv_cache_policy(slimt_hip_model *model, int policy);
+/* Storage format of the cross-attention K/V cache that slimt_hip_translate* keeps between
+ * its encoder and decoder launches (the reference recomputes K and V every step,
+ * slimt/Modules.cc:248-249): 0 (default) = the int8 GEMM's 24-bit shifted accumulators where
+ * the kernels support it (emb 256, head dim 32, sources of up to 32 tokens; the attention
+ * rebuilds float(acc) * unquant + bias in registers: identical floats, 25 % fewer bytes
+ * re-read per step), f32 elsewhere; 1 = always f32. Results do not depend on it. */
+int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format);
 int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
                          int32_t *dim_ffn, int32_t *vocab, int32_t *heads);
 

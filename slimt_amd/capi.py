@@ -28,6 +28,7 @@ SYMBOLS = [
     "slimt_hip_debug_decode_stamps",
     "slimt_hip_debug_occupancy_trace", "slimt_hip_model_set_decoder_budget",
     "slimt_hip_model_set_kv_cache_policy",
+    "slimt_hip_model_set_kv_cache_format",
     "slimt_hip_shortlist_create", "slimt_hip_shortlist_destroy", "slimt_hip_shortlist_info",
     "slimt_hip_shortlist_generate", "slimt_hip_shortlist_generate_device",
     "slimt_hip_translate_device_generated",
@@ -113,6 +114,7 @@ def lib():
     L.slimt_hip_debug_occupancy_trace.argtypes = [vp, sz]
     L.slimt_hip_model_set_decoder_budget.argtypes = [vp, i32]
     L.slimt_hip_model_set_kv_cache_policy.argtypes = [vp, i32]
+    L.slimt_hip_model_set_kv_cache_format.argtypes = [vp, i32]
     L.slimt_hip_ctx_create_budget.argtypes = [vp, sz, sz, sz, vp, vp]
     L.slimt_hip_shortlist_create.argtypes = [vp, sz, sz, sz, i32, i32, i32, vp]
     L.slimt_hip_shortlist_destroy.argtypes = [vp]
@@ -264,6 +266,10 @@ class Model:
     def set_kv_cache_policy(self, policy: int):
         """0 = per launch (default), 1 = temporal, 2 = non-temporal K/V cache loads in the decoder."""
         _chk(lib().slimt_hip_model_set_kv_cache_policy(self.h, policy))
+
+    def set_kv_cache_format(self, fmt: int):
+        """0 = packed 24-bit K/V cache where supported (default), 1 = always f32."""
+        _chk(lib().slimt_hip_model_set_kv_cache_format(self.h, fmt))
 
     def set_decoder_budget(self, workgroups: int):
         """Admission of persistent decoders: ~`workgroups` decoder workgroups at a time (0 = no limit)."""

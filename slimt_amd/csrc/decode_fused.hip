@@ -676,6 +676,136 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   }
 }
 
+// ---- packed K/V cache (FusedDecodeArgs::kv24): D = 256, d_head 32, S <= 32 -----------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// 12 bytes = four 24-bit accumulators accS -> float(accS) * u + pb (dequant above, operation by
+// operation). A 24-bit field moved into the HIGH three bytes of a register is accS * 256 as a
+// signed integer: one v_perm / shift per value instead of extract + sign-extend, its conversion
+// is exact (24 significant bits), and float(accS * 256) * (u / 256) is the same real product as
+// float(accS) * u, hence the same rounded float. Multiply and add stay separate roundings
+// (-ffp-contract=off), two columns per v_pk_mul_f32 / v_pk_add_f32.
+__device__ __forceinline__ f4 unpack24(int d0, int d1, int d2, float u256, f4 pb) {
+  const int y0 = d0 << 8;
+  const int y1 = (int)__builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x0504030cu);
+  const int y2 = (int)__builtin_amdgcn_perm((unsigned)d2, (unsigned)d1, 0x0403020cu);
+  const int y3 = d2 & (int)0xffffff00;
+  f2 a = {(float)y0, (float)y1}, b = {(float)y2, (float)y3};
+  const f2 uu = {u256, u256};
+  a = a * uu;
+  b = b * uu;
+  const f2 pa = {pb.x, pb.y}, pc = {pb.z, pb.w};
+  a = a + pa;
+  b = b + pc;
+  const f4 o = {a.x, a.y, b.x, b.y};
+  return o;
+}
+
+// attention_row's S <= 32, d_head 32 form over the packed cache (layout: kernels.h, kv24): same
+// passes, same order of every float operation; 16 cached values arrive as three 16-byte loads
+// (one per plane), i.e. 6 instead of 8 K loads per score pass and 3 instead of 4 V loads per
+// four keys. pbk / pbv: the K / V projections' prepared biases [D] in LDS.
+template <int KV_AUX>
+__device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256,
+                                                float uv256) {
+  constexpr int D = 256, DH = 32, H = D / DH;
+  const int S = r.S, len = r.len;
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int hh = lane >> 5, j = lane & 31;
+  const int jc = j < S ? j : S - 1;
+  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+  v4i kq[6];     // this lane's key, its head's 32 columns: two chunks of three planes
+  v4i vq[3][3];  // V rows in flight: three groups of four rows (three planes each)
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 3u);
+  // masked keys are not fetched: past the descriptors a load returns zeros, i.e. the value pb --
+  // finite, and multiplied by a probability that is exactly 0
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 3) >> 2) * 3072));
+  const int koff = j < lenf ? (hh * 6 * S + jc) * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
+  const int voff = lane * 16;                                            // [S/4][plane][D/4][16 B]
+  auto load_k = [&](int hp) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((12 * hp + i) * S) * 16, KV_AUX));
+  };
+  auto load_v = [&](v4i(&vv)[3], int g) {  // rows 4 g .. 4 g + 3
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + i) * 1024, KV_AUX));
+  };
+  // group g (12 bytes = 4 values) of the 48-byte item in planes p0, p1, p2
+  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g, float u256, f4 pb) -> f4 {
+    const int w[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+    return unpack24(w[3 * g], w[3 * g + 1], w[3 * g + 2], u256, pb);
+  };
+  load_k(0);
+  load_v(vq[0], 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int hp = 0; hp < H / 2; ++hp) {
+    const int h = 2 * hp + hh;
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = h * DH + 16 * c + 4 * g;
+        const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
+        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, uk256, *(lcf4_ptr)(pbk + d0));
+        s = __builtin_fmaf(q4.x, kk.x, s);
+        s = __builtin_fmaf(q4.y, kk.y, s);
+        s = __builtin_fmaf(q4.z, kk.z, s);
+        s = __builtin_fmaf(q4.w, kk.w, s);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // at most one chunk's q / bias reads from LDS in flight
+    }
+    if (hp + 1 < H / 2) {
+      load_k(hp + 1);
+    } else {  // the K registers are free: two more groups of V rows
+      load_v(vq[1], 1);
+      load_v(vq[2], 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (r.alpha != 1.0f) s = r.alpha * s;
+    s = s + mask;
+    if (j >= S) s = lowest;
+    const float m = half_max(s);
+    const float e = j < S ? exp_p(s - m) : 0.0f;
+    const float sum = half_sum(e);
+    const float p = e / sum;  // keys >= S: exactly 0
+    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
+    if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
+    r.pbuf[h * 32 + j] = p;
+  }
+  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
+  const int ph = (lane >> 3) * 32;
+  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  f4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    v4i(&cur)[3] = vq[g % 3];
+    const f4 p4 = *(lcf4_ptr)(r.pbuf + ph + 4 * g);
+    const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
+      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c, uv256, pv4);
+      o.x = __builtin_fmaf(pj[c], v4.x, o.x);
+      o.y = __builtin_fmaf(pj[c], v4.y, o.y);
+      o.z = __builtin_fmaf(pj[c], v4.z, o.z);
+      o.w = __builtin_fmaf(pj[c], v4.w, o.w);
+    }
+    // pin this group's sums here: the unpack + fma chains are pure arithmetic, and without a use
+    // the optimiser sinks all eight groups' work below the last load -- 96 registers of packed
+    // rows live at once (seen as 134 spilled VGPRs)
+    asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
+    if (g + 3 < 8) load_v(vq[g % 3], g + 3);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+      pack4(quantize1(o.x, r.aq_o), quantize1(o.y, r.aq_o), quantize1(o.z, r.aq_o), quantize1(o.w, r.aq_o));
+}
+
 }  // namespace
 
 // Diagnostic phase stamps (100 MHz wall clock) of workgroup 0 at one chosen
@@ -699,8 +829,9 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
 // RT = row tiles per workgroup: 1 (16 sentences) or 2 (32 sentences). Every streamed weight
 // fragment then feeds RT MFMAs (half the weight bytes per sentence and step at RT = 2), wave w
 // owns sentences w and w + 16 in the row-wise phases.
-template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1>
+template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
+  static_assert(!KV24 || (KSD == 4 && DH == 32 && !LONG), "the packed K/V cache: D = 256, d_head 32, S <= 32");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 64 * KSD, F = 64 * KSF;
   constexpr int R = 16 * RT;    // rows (sentences) per workgroup
@@ -734,6 +865,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   int *red_i = reinterpret_cast<int *>(red_v + NW * R);
   int *flags = red_i + NW * R;  // [0] = number of finished sentences of this tile
   float *pbufs = reinterpret_cast<float *>(flags + 16);  // [NW][256] attention scratch
+  float *kvpb = pbufs + NW * 256;  // KV24: [Ld][K, V][D] prepared biases of the K / V projections
 
   // Which R sentences? With a ticket counter the grid is over-subscribed and the first
   // workgroups to START claim the tiles; the rest leave at once. A workgroup needs a whole
@@ -774,6 +906,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     for (int i = tid; i < Ld * R * D; i += 1024) cs[i] = 0.0f;
   }
   if (tid == 0) flags[0] = 0;
+  if constexpr (KV24) {
+    for (int i = tid; i < Ld * 2 * D; i += 1024) kvpb[i] = a.kv_pb[i / (2 * D)][(i / D) & 1][i % D];
+  }
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     if (live[rr]) {  // outputs past a sentence's length read as zero (no memset launches)
@@ -900,8 +1035,14 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           const bool fin = rr ? finished[RT - 1] : finished[0];
           const int no = rr ? (int)n_out[RT - 1] : (int)n_out[0];
           AttnRow ar;
-          ar.kl = (gcf_ptr)(a.kv + ((size_t)(2 * l) * B + EXP_SENT(b)) * S * D);
-          ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(b)) * S * D);
+          if constexpr (KV24) {  // same planes, 3 bytes per value
+            ar.kl = (gcf_ptr)((const SLIMT_GLOBAL char *)(a.kv + (size_t)(2 * l) * B * S * D) + (size_t)EXP_SENT(b) * S * D * 3);
+            ar.vl = (gcf_ptr)((const SLIMT_GLOBAL char *)(a.kv + (size_t)(2 * l + 1) * B * S * D) +
+                              (size_t)EXP_SENT(b) * ((S + 3) & ~3) * D * 3);
+          } else {
+            ar.kl = (gcf_ptr)(a.kv + ((size_t)(2 * l) * B + EXP_SENT(b)) * S * D);
+            ar.vl = (gcf_ptr)(a.kv + ((size_t)(2 * l + 1) * B + EXP_SENT(b)) * S * D);
+          }
           ar.qrow = (lcf_ptr)(xs + row * LDF);
           ar.arow = (lc_ptr)(A1 + row * LDA);
           ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * 256);
@@ -912,7 +1053,13 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
           const bool want_align = a.align && (l + 1 == Ld) && !fin && (no < a.Tmax);
           ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + no) * S) : (gf_ptr) nullptr;
-          if (NT && l >= a.kv_temporal_layers)
+          if constexpr (KV24) {
+            const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
+            if (NT && l >= a.kv_temporal_layers)
+              attention_row24<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+            else
+              attention_row24<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+          } else if (NT && l >= a.kv_temporal_layers)
             attention_row<D, DH, LONG, 2>(ar, lane);
           else
             attention_row<D, DH, LONG, 0>(ar, lane);
@@ -1077,12 +1224,13 @@ int fused_decode_grid(int B, bool tickets, int rows) {
   return tickets ? tiles * (rows == 16 ? 2 : 4) : tiles;
 }
 
-size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows) {
+size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false) {
   // D * rows > 256 * 16: two f32 row buffers, SSRU cells in global memory (see the kernel)
   const size_t R = (size_t)rows;
   const bool lean = (size_t)D * R > 256 * 16;
   const size_t f32rows = lean ? 2 * R * (D + 4) * 4 : 3 * R * (D + 4) * 4 + (size_t)Ld * R * D * 4;
-  return f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 + NW * 256 * 4;
+  return f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 + NW * 256 * 4 +
+         (kv24 ? (size_t)Ld * 2 * D * 4 : 0);
 }
 
 bool fused_decode_supported(int D, int F, int H, int Ld) {
@@ -1112,10 +1260,21 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hi
   if (!fused_decode_supported(D, F, H, a.Ld)) return hipErrorInvalidValue;
   const int rows = fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg);
   const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, rows));
-  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows);
+  const bool kv24 = a.kv24;
+  if (kv24 && !(D == 256 && D / H == 32 && a.S <= 32)) return hipErrorInvalidValue;
+  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows, kv24);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (kv24 && rows == 16) {
+    auto k = a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true> : decode_fused_kernel<4, 24, 32, false, false, 1, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
+    return hipGetLastError();
+  }
   if (rows == 32) {
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 2>;
+    auto k = kv24 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true> : decode_fused_kernel<4, 24, 32, false, false, 2, true>)
+                  : (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 2>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -27,6 +27,16 @@ __device__ __forceinline__ float edequant(int acc, int colsum, float u, float pb
   return v + pb;
 }
 
+// four 24-bit two's-complement integers, little endian, in 12 bytes (the packed K/V cache)
+typedef int v3i __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ v3i pack24(v4i x) {
+  v3i o;
+  o.x = (x.x & 0xffffff) | (x.y << 24);
+  o.y = ((x.y >> 8) & 0xffff) | (x.z << 16);
+  o.z = ((x.z >> 16) & 0xff) | (x.w << 8);
+  return o;
+}
+
 // one 16-column tile of a weight against both row tiles of A (32 x K int8 in LDS)
 template <int KS>
 __device__ __forceinline__ void tile_mma2(const char *A, int lda, const v4i (&bf)[KS], int lr, int lg,
@@ -587,6 +597,82 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     const int col = wave * 16 + lr;
     float *kout = a.kv + (size_t)(2 * l) * B * S * D;
     float *vout = a.kv + (size_t)(2 * l + 1) * B * S * D;
+    if (a.kv24) {
+      // Packed cache (kernels.h, FusedEncodeArgs::kv24): the shifted accumulators accS = acc +
+      // 127 colsum (|accS| <= 254 * 128 * 256 < 2^23) as 24-bit integers; the decoder rebuilds
+      // float(accS) * u + pb in registers. The accumulator tiles cross to the packing threads
+      // through the (dead) q / k buffers.
+      int *stk = reinterpret_cast<int *>(qb), *stv = reinterpret_cast<int *>(kb);
+      static_assert(LDQQ == LDK, "both staging tiles use the q row stride");
+      {
+        v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+        tile_mma2<KSD>(Ak, LDA, bk, lr, lg, c0, c1);
+        int cs;
+        float pb;
+        load_epi(wk, wave, lr, cs, pb);
+        (void)pb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          stk[(lg * 4 + r) * LDQQ + col] = c0[r] + __mul24(127, cs);
+          stk[(16 + lg * 4 + r) * LDQQ + col] = c1[r] + __mul24(127, cs);
+        }
+      }
+      {
+        v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+        tile_mma2<KSD>(Av, LDA, bv, lr, lg, c0, c1);
+        int cs;
+        float pb;
+        load_epi(wv, wave, lr, cs, pb);
+        (void)pb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          stv[(lg * 4 + r) * LDQQ + col] = c0[r] + __mul24(127, cs);
+          stv[(16 + lg * 4 + r) * LDQQ + col] = c1[r] + __mul24(127, cs);
+        }
+      }
+      lds_barrier();
+      // One thread = 16 values = 48 bytes = three 16-byte stores, one per plane, so that the
+      // decoder's 16-byte loads stay contiguous across lanes:
+      //   K [sentence][column / 16][plane][key][16 B]      (consecutive lanes = consecutive keys)
+      //   V [sentence][key / 4][plane][column / 4][16 B]   (4 keys x 4 columns, key-major;
+      //                                                      consecutive lanes = consecutive columns)
+      const int Sp = (S + 3) & ~3;
+      const rsrc_t rko = make_rsrc(kout, (unsigned)((size_t)B * S * D * 3));
+      const rsrc_t rvo = make_rsrc(vout, (unsigned)((size_t)B * Sp * D * 3));
+      for (int it = tid; it < ER * (D / 16); it += 1024) {
+        const int r = it % ER, ci = it / ER;
+        if (!row_valid(r)) continue;
+        v3i w[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) w[g] = pack24(*reinterpret_cast<const v4i *>(stk + r * LDQQ + 16 * ci + 4 * g));
+        const int off = row_sentence(r) * S * D * 3 + (ci * 3 * S + r % S) * 16;
+        const v4i p0 = {w[0].x, w[0].y, w[0].z, w[1].x}, p1 = {w[1].y, w[1].z, w[2].x, w[2].y},
+                  p2 = {w[2].z, w[3].x, w[3].y, w[3].z};
+        __builtin_amdgcn_raw_buffer_store_b128(p0, rko, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(p1, rko, off + S * 16, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(p2, rko, off + 2 * S * 16, 0, 0);
+      }
+      for (int it = tid; it < spw * (Sp / 4) * 64; it += 1024) {
+        const int cl = it & 63, g = (it >> 6) % (Sp / 4), si = (it >> 6) / (Sp / 4);
+        if (s0 + si >= B) continue;
+        v3i w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // keys past the sentence: zeros (finite once unpacked, weight 0)
+          const int key = 4 * g + i;
+          const v4i x = *reinterpret_cast<const v4i *>(stv + (si * S + (key < S ? key : 0)) * LDQQ + 4 * cl);
+          const v4i z = {0, 0, 0, 0};
+          w[i] = pack24(key < S ? x : z);
+        }
+        const int off = ((s0 + si) * (Sp / 4) + g) * 3 * 64 * 16 + cl * 16;
+        const v4i p0 = {w[0].x, w[0].y, w[0].z, w[1].x}, p1 = {w[1].y, w[1].z, w[2].x, w[2].y},
+                  p2 = {w[2].z, w[3].x, w[3].y, w[3].z};
+        __builtin_amdgcn_raw_buffer_store_b128(p0, rvo, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(p1, rvo, off + 1024, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(p2, rvo, off + 2048, 0, 0);
+      }
+      lds_barrier();
+      continue;
+    }
     {
       v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
       tile_mma2<KSD>(Ak, LDA, bk, lr, lg, c0, c1);

@@ -567,6 +567,14 @@ extern "C" int slimt_hip_model_set_kv_cache_policy(slimt_hip_model *model, int p
   return 0;
 }
 
+extern "C" int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format) {
+  if (!model) return fail(-1, "model is NULL");
+  if (format < 0 || format > 1) return fail(-1, "K/V cache format %d not in 0..1", format);
+  std::lock_guard<std::mutex> lock(model->gate_mu);
+  model->kv_format = format;
+  return 0;
+}
+
 extern "C" int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
                                     int32_t *dim_ffn, int32_t *vocab, int32_t *heads) {
   if (!model) return fail(-1, "model is NULL");
@@ -875,7 +883,10 @@ int check_batch(const slimt_hip_ctx *c, size_t B, size_t S) {
 // argument, Transformer.cc:57): the stage kernels run from there.
 int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layers,
                   const uint32_t *d_ids = nullptr, const uint32_t *d_lengths = nullptr,
-                  const PackArgs *pack = nullptr, bool embedded = false, bool keep_out = true) {
+                  const PackArgs *pack = nullptr, bool embedded = false, bool keep_out = true,
+                  bool kv24 = false) {
+  // kv24 (translate_device only: the caller decodes with the persistent kernel's packed-cache
+  // variant right behind this launch): the fused encoder leaves the 24-bit K/V cache
   // keep_out = false (the translate path): the persistent encoder leaves the decoder its K/V
   // cache only -- the encoder output itself (B S D f32, 8 MB at the headline size) is not written
   const slimt_hip_model *m = c->model;
@@ -908,6 +919,8 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     f.lengths = d_lengths ? d_lengths : c->lengths.as<uint32_t>();
     f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
     f.kv = c->kv.as<float>();
+    f.kv24 = kv24;
+    if (kv24 && (size_t)M * D * 3 >= (1u << 31)) return fail(-1, "packed K/V cache: %d rows exceed a 2 GB plane", M);
     f.enc_out = keep_out ? c->x0.as<float>() : nullptr;
     if (pack) {
       f.pack = *pack;
@@ -938,7 +951,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     if (h_layers)
       HIPCHK(hipMemcpyAsync(h_layers, c->dbg_layers.p, nbytes * (size_t)m->Le, hipMemcpyDeviceToHost, st));
     c->have_encoder_out = keep_out;
-    c->kv_ready = true;
+    c->kv_ready = !kv24;  // the step-wise decoder reads the f32 form only
     return 0;
   }
   if (!embedded && c->decode_mode != 1 && long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
@@ -1213,6 +1226,11 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   const bool fused_dec = c->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld);
   const bool lean = fused_dec && (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                                   long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
+  // packed 24-bit K/V cache: fused encoder -> fused decoder, D = 256 / d_head 32 / S <= 32
+  // (V is cached in groups of four keys: S = 1, 2, 5 would not fit the f32 form's plane)
+  const bool kv24 = lean && m->kv_format == 0 && m->D == 256 && m->D / m->H == 32 && S <= 32 &&
+                    ((S + 3) & ~(size_t)3) * 3 <= S * 4 &&
+                    fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
   DecodeState ds;
   ds.prev = c->prev.as<uint32_t>();
   ds.out_ids = d_out_ids;
@@ -1227,7 +1245,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       RCCHK(prepare_affine_meta(c->out_sl, m->out_raw.as<int8_t>(), m->D, (int)n_sl, d_shortlist,
                                 m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, job));
     job.n_dev = d_n_sl;
-    RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr, false, false));
+    RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr, false, false,
+                        kv24));
     c->n_sl = (int)n_sl;
   } else {
     if (d_ids != c->ids.as<uint32_t>())
@@ -1270,6 +1289,14 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.shortlist = ds.shortlist;
     f.emb = embed_args(c);
     f.kv = c->kv.as<float>();
+    f.kv24 = kv24;
+    for (int l = 0; l < m->Ld && kv24; ++l) {
+      const AffineW &wk = m->dec[(size_t)l].attn.k, &wv = m->dec[(size_t)l].attn.v;
+      f.kv_pb[l][0] = wk.w.pb;
+      f.kv_pb[l][1] = wv.w.pb;
+      f.kv_u256[l][0] = wk.w.u * (1.0f / 256.0f);  // exact scalings: the cached integers come back
+      f.kv_u256[l][1] = wv.w.u * (1.0f / 256.0f);  // as accS * 256 (decode_fused.hip, unpack24)
+    }
     f.cells = c->state.as<float>();
     f.lengths = d_lengths;
     f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
@@ -1313,7 +1340,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       // 18.8 M, 12: 21.9 / 22.5 / 22.1, 16: 23.6 / 24.2 / 22.6, 20: 23.9 / 24.5 / 23.5;
       // B=512 full vocabulary 16.7 / 17.1 / 15.8; B=128, S=64 9.0 / 8.5 / 7.9; B=64, S=32
       // 11.9 / - / 13.6; base 6.4 / 5.9 / 5.7.
-      const double kv_bytes = (double)m->Ld * 2.0 * (double)B * (double)S * m->D * 4.0;
+      const double kv_bytes = (double)m->Ld * 2.0 * (double)B * (double)S * m->D * (kv24 ? 3.0 : 4.0);
       double pending = kv_bytes;
       size_t contexts = 1;
       bool known = false;

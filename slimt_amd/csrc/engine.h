@@ -84,6 +84,7 @@ struct slimt_hip_model {
   };
   std::vector<GateCtx> gate_ctx;
   int kv_policy = 0;  // 0 = chosen per launch, 1 = always temporal, 2 = always non-temporal K/V loads
+  int kv_format = 0;  // 0 = packed 24-bit cache where the kernels have it (kernels.h, kv24), 1 = always f32
 };
 
 struct slimt_hip_ctx {

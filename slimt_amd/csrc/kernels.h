@@ -261,6 +261,18 @@ struct FusedDecodeArgs {
   // of every launch takes one ticket; ticket - ticket_base is the tile it runs (or none).
   unsigned *ticket = nullptr;
   unsigned ticket_base = 0;
+  // Packed K/V cache (D = 256, d_head 32, S <= 32; written by encode_fused_kernel): every
+  // cached value is the int8 GEMM's shifted accumulator accS = acc + 127 colsum as a 24-bit
+  // integer (|accS| < 2^23 at K = 256); 16 values = 48 bytes = one 16-byte quad in each of
+  // three planes, so that loads stay 16 bytes per lane and contiguous across lanes:
+  //   K [B][D/16][plane][S][16 B]             (16 consecutive columns of one key)
+  //   V [B][ceil(S/4)][plane][D/4][16 B]      (4 keys x 4 consecutive columns, key-major)
+  // in the same per-layer planes as the f32 form. The attention rebuilds float(accS) * u + pb
+  // (Intgemm.inl.cc:146-153) in registers: the same floats as the f32 cache from 25 % fewer
+  // bytes, load instructions and registers in flight.
+  bool kv24 = false;
+  const float *kv_pb[4][2] = {};  // [layer][K, V]: the projections' prepared biases [D]
+  float kv_u256[4][2] = {};       // [layer][K, V]: unquantisation multiplier u / 256
   bool kv_nt = false;  // non-temporal K/V cache loads (d_head 32 / 64 shapes; see decode_fused.hip)
   int kv_temporal_layers = 0;  // with kv_nt: the first layers' caches are still read temporally
   OccTrace trace;
@@ -287,6 +299,7 @@ struct FusedEncodeArgs {
   const uint32_t *lengths = nullptr;  // [B]
   float alpha = 0.f, eps = 1e-6f;
   float *kv = nullptr;         // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]
+  bool kv24 = false;           // write the packed 24-bit form instead (FusedDecodeArgs::kv24)
   PackArgs pack;               // the batch's shortlisted output layer, packed by the
   int pack_tiles = 0;          // encoder's workgroups on the side (0 = nothing to pack)
   unsigned *ticket = nullptr;  // nullable: over-subscribed launch (see FusedDecodeArgs)

@@ -335,6 +335,41 @@ def test_kv_cache_policy_keeps_results(hip, oracle, engines, preset, B, S):
         ctx.close()
 
 
+@pytest.mark.parametrize("S", [1, 2, 3, 4, 5, 6, 7, 9, 13, 16, 21, 31, 32])
+def test_packed_kv_cache_matches_oracle_and_f32_cache(hip, oracle, engines, S):
+    """The 24-bit K/V cache (default where supported: tiny11, S <= 32) against the oracle and
+    against the f32 cache, for sentence lengths on both sides of every layout edge: several
+    sentences per encoder workgroup, a last V group of 1..4 keys, S = 1 / 2 / 5 (which fall
+    back to f32: a padded group of four keys would not fit their plane), both cache-load
+    policies and both decoder tilings (16 and 32 sentences per workgroup). Alignments are
+    the head-0 probabilities computed from the unpacked K, so they pin the floats too."""
+    from slimt_amd import synth
+    m, gm, om = engines("tiny11", 6.0)
+    B = 37
+    sl = synth.make_shortlist(m.V, 768)
+    ids, lens = synth.make_batch(m.V, B, S, seed=9100 + S, ragged=True)
+    ids, lens = ids.copy(), lens.copy()
+    lens[3] = 0  # an empty sentence: everything masked, uniform weights over real V rows
+    ids[3, :] = 0
+    oracle.set_mode(oracle.PORTABLE)
+    want = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+    oracle.set_mode(oracle.FAITHFUL)
+    ctx = hip.Context(gm, B, S)
+    try:
+        for fmt in (0, 1):
+            gm.set_kv_cache_format(fmt)
+            for policy in (2, 1):
+                gm.set_kv_cache_policy(policy)
+                for mode in (2, 3):
+                    ctx.set_decode_mode(mode)
+                    got = ctx.translate(ids, lens, sl, want_align=True)
+                    assert all(np.array_equal(a, b) for a, b in zip(got, want)), (fmt, policy, mode)
+    finally:
+        gm.set_kv_cache_format(0)
+        gm.set_kv_cache_policy(0)
+        ctx.close()
+
+
 @pytest.mark.parametrize("budget", [0, 1, 3, 1000])
 def test_decoder_admission_and_ticket_launches_keep_results(hip, oracle, engines, budget):
     """Concurrent contexts of one model under every decoder budget (0 = no limit, 1 = one
