@@ -94,17 +94,79 @@ __device__ __forceinline__ v4i load_frag(rsrc_t r, int voff, int soff) {
 // inside, it falls back to vmcnt(0) at the loop head whenever register allocation shifts.
 // RT row tiles (16 RT rows of A): every weight fragment feeds RT MFMAs; epi(tile, rt, ...)
 // runs once per finished (column tile, row tile).
+// The stream's descriptors and this lane's offsets.
+template <int KS, int NT>
+struct StreamSrc {
+  rsrc_t rw, rc, rp;
+  int voff, eoff, n_tiles;
+  __device__ __forceinline__ StreamSrc(const PreparedWeight &w, int lane) {
+    n_tiles = NT > 0 ? NT * NW : w.n_tiles;
+    rw = make_rsrc(w.Wp, (unsigned)n_tiles * KS * 1024u);
+    rc = make_rsrc(w.colsum, (unsigned)n_tiles * 64u);
+    rp = make_rsrc(w.pb, (unsigned)n_tiles * 64u);
+    voff = lane * 16;
+    eoff = (lane & 15) * 4;
+  }
+  // chunk c of wave `wave`'s stream: CH fragments + the epilogue constants of its tile(s)
+  __device__ __forceinline__ void load(Frags &bb, int c, int wave) const {
+    if constexpr (KS <= CH) {
+      constexpr int TPC = CH / KS;  // whole tiles per chunk
+#pragma unroll
+      for (int j = 0; j < TPC; ++j) {
+        const int tile = EXP_TILE(wave + NW * (c * TPC + j));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bb.f[j * KS + ks] = load_frag(rw, voff, (tile * KS + ks) * 1024);
+        bb.cs[j] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
+        bb.pb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
+      }
+    } else {
+      constexpr int CPT = KS / CH;  // chunks per tile
+      const int tile = EXP_TILE(wave + NW * (c / CPT));
+      const int ks0 = (c % CPT) * CH;
+#pragma unroll
+      for (int p = 0; p < CH; ++p) bb.f[p] = load_frag(rw, voff, (tile * KS + ks0 + p) * 1024);
+      bb.cs[0] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
+      bb.pb[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
+    }
+  }
+};
+
+// The first NB chunks of a stream, requested ahead of stream_gemm_from: weights do not depend
+// on the phase before, so a wave asks for them as soon as its own work in that phase is done
+// (or before it, where that pays) and the round trip runs under the barrier wait (lds_barrier
+// keeps global loads in flight).
+template <int KS, int NB, int NT = 0, bool PADDED = false>
+__device__ __forceinline__ void stream_prologue(const PreparedWeight &w, int wave, int lane, Frags (&b)[NB]) {
+  const StreamSrc<KS, NT> src(w, lane);
+  if constexpr (NT > 0) {
+    constexpr int NCH = KS <= CH ? (NT + CH / KS - 1) / (CH / KS) : NT * (KS / CH);
+#pragma unroll
+    for (int k = 0; k < NB && k < NCH; ++k) src.load(b[k], k, wave);
+    __builtin_amdgcn_sched_barrier(0);  // straight-line code: keep the scheduler from sinking
+  } else if constexpr (PADDED) {        // the prefetches next to their uses
+    // the chunks are requested in the same order before and inside the loop (the
+    // scheduler would otherwise regroup the prologue's loads, and the pending-load
+    // orders of the two loop entries would no longer match)
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      src.load(b[k], k, wave);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) src.load(b[k], k, wave);
+  }
+}
+
+// The stream proper; b holds the chunks stream_prologue requested.
 template <int KS, int NB, int NT = 0, bool PADDED = false, int RT = 1, class Epi>
-__device__ __forceinline__ void stream_gemm(const char *A, int lda, const PreparedWeight &w,
-                                            int wave, int lane, Epi &&epi) {
-  const int n_tiles = NT > 0 ? NT * NW : w.n_tiles;
-  const rsrc_t rw = make_rsrc(w.Wp, (unsigned)n_tiles * KS * 1024u);
-  const rsrc_t rc = make_rsrc(w.colsum, (unsigned)n_tiles * 64u);
-  const rsrc_t rp = make_rsrc(w.pb, (unsigned)n_tiles * 64u);
+__device__ __forceinline__ void stream_gemm_from(const char *A, int lda, const PreparedWeight &w, int wave,
+                                                 int lane, Frags (&b)[NB], Epi &&epi) {
+  const StreamSrc<KS, NT> src(w, lane);
+  const int n_tiles = src.n_tiles;
   const int lr = lane & 15, lg = lane >> 4;
-  const int voff = lane * 16, eoff = lr * 4;
   const int ntw = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;  // my tiles
-  Frags b[NB];
+  auto load = [&](Frags &bb, int c) { src.load(bb, c, wave); };
   if constexpr (KS <= CH) {
     constexpr int TPC = CH / KS;  // whole tiles per chunk
     v4i af[RT][KS];
@@ -114,17 +176,6 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       for (int ks = 0; ks < KS; ++ks)
         af[rt][ks] = *reinterpret_cast<const v4i *>(A + (rt * 16 + lr) * lda + ks * 64 + lg * 16);
     const int nch = (ntw + TPC - 1) / TPC;
-    auto load = [&](Frags &bb, int c) {
-#pragma unroll
-      for (int j = 0; j < TPC; ++j) {
-        const int tile = EXP_TILE(wave + NW * (c * TPC + j));
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          bb.f[j * KS + ks] = load_frag(rw, voff, (tile * KS + ks) * 1024);
-        bb.cs[j] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
-        bb.pb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
-      }
-    };
     auto tile_mma = [&](const Frags &bb, int j, int tile) {
       v4i acc[RT];
 #pragma unroll
@@ -147,9 +198,6 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
     if constexpr (NT > 0) {
       constexpr int NCH = (NT + TPC - 1) / TPC;
 #pragma unroll
-      for (int k = 0; k < NB && k < NCH; ++k) load(b[k], k);
-      __builtin_amdgcn_sched_barrier(0);  // straight-line code: keep the scheduler from sinking
-#pragma unroll                            // the prefetches next to their uses
       for (int c = 0; c < NCH; ++c) {
         compute(b[c % NB], c);
         if (c + NB < NCH) load(b[c % NB], c + NB);
@@ -157,14 +205,6 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       }
     } else if constexpr (PADDED) {
       static_assert(TPC == 1, "one tile per chunk");
-      // the chunks are requested in the same order before and inside the loop (the
-      // scheduler would otherwise regroup the prologue's loads, and the pending-load
-      // orders of the two loop entries would no longer match)
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        load(b[k], k);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       const int nchp = (nch + NB - 1) / NB * NB;
       for (int c = 0; c < nchp; c += NB) {
 #pragma unroll
@@ -175,8 +215,6 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
         }
       }
     } else {
-#pragma unroll
-      for (int k = 0; k < NB; ++k) load(b[k], k);
       for (int c = 0; c < nch; c += NB) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
@@ -189,14 +227,6 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
     constexpr int CPT = KS / CH;  // chunks per tile
     static_assert(KS % CH == 0, "K/64 must be a multiple of CH here");
     const int nch = ntw * CPT;
-    auto load = [&](Frags &bb, int c) {
-      const int tile = EXP_TILE(wave + NW * (c / CPT));
-      const int ks0 = (c % CPT) * CH;
-#pragma unroll
-      for (int p = 0; p < CH; ++p) bb.f[p] = load_frag(rw, voff, (tile * KS + ks0 + p) * 1024);
-      bb.cs[0] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
-      bb.pb[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
-    };
     v4i acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = v4i{0, 0, 0, 0};
@@ -221,9 +251,6 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
     if constexpr (NT > 0) {
       constexpr int NCH = NT * CPT;
 #pragma unroll
-      for (int k = 0; k < NB && k < NCH; ++k) load(b[k], k);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
       for (int c = 0; c < NCH; ++c) {
         chunk_mma(b[c % NB], c % CPT, wave + NW * (c / CPT));
         if (c + NB < NCH) load(b[c % NB], c + NB);
@@ -231,11 +258,6 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       }
     } else if constexpr (PADDED) {
       static_assert(NB % CPT == 0, "whole tiles per round");
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        load(b[k], k);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       const int nchp = (nch + NB - 1) / NB * NB;
       for (int c = 0; c < nchp; c += NB) {
 #pragma unroll
@@ -246,8 +268,6 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
         }
       }
     } else {
-#pragma unroll
-      for (int k = 0; k < NB; ++k) load(b[k], k);
       for (int c = 0; c < nch; c += NB) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
@@ -257,6 +277,14 @@ __device__ __forceinline__ void stream_gemm(const char *A, int lda, const Prepar
       }
     }
   }
+}
+
+template <int KS, int NB, int NT = 0, bool PADDED = false, int RT = 1, class Epi>
+__device__ __forceinline__ void stream_gemm(const char *A, int lda, const PreparedWeight &w,
+                                            int wave, int lane, Epi &&epi) {
+  Frags b[NB];
+  stream_prologue<KS, NB, NT, PADDED>(w, wave, lane, b);
+  stream_gemm_from<KS, NB, NT, PADDED, RT>(A, lda, w, wave, lane, b, epi);
 }
 
 // canonical LayerNorm of row `src` (LDS) by one wave -> dst (LDS f32) and,
@@ -1006,7 +1034,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       }
       lds_barrier();
       SLIMT_STAMP(sb + 1);
-      // h = LN(x + relu(c')), quantised for the Q projection
+      // h = LN(x + relu(c')), quantised for the Q projection (whose weight fragments are
+      // requested now: their round trip runs under the LayerNorm and the barrier)
+      Frags fq[1];
+      stream_prologue<KSD, 1, NT_D>(L.q, wave, lane, fq);
 #pragma unroll
       for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
@@ -1016,7 +1047,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       SLIMT_STAMP(sb + 2);
       // ---- cross-attention (Modules.cc:287-319) --------------------------
       // Q projection -> xs (x is dead until the end of the layer)
-      stream_gemm<KSD, 1, NT_D, false, RT>(A1, LDA, L.q, wave, lane,
+      stream_gemm_from<KSD, 1, NT_D, false, RT>(A1, LDA, L.q, wave, lane, fq,
                                            [&](int tile, int rt, const v4i &acc, int cq, float pb) {
                                              const int col = tile * 16 + lr;
 #pragma unroll
@@ -1068,10 +1099,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           for (int i = 0; i < KSD; ++i) A1[row * LDA + lane + 64 * i] = 0;
         }
       }
+      Frags fo[1];  // this wave's sentences are done: O's fragments travel under the barrier wait
+      stream_prologue<KSD, 1, NT_D>(L.o, wave, lane, fo);
       lds_barrier();
       SLIMT_STAMP(sb + 4);
       // O projection + residual h (Modules.cc:308-314)
-      stream_gemm<KSD, 1, NT_D, false, RT>(A1, LDA, L.o, wave, lane,
+      stream_gemm_from<KSD, 1, NT_D, false, RT>(A1, LDA, L.o, wave, lane, fo,
                                            [&](int tile, int rt, const v4i &acc, int co, float pb) {
                                              const int col = tile * 16 + lr;
 #pragma unroll
@@ -1102,10 +1135,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
               A3[(16 * rt + lg * 4 + r) * LDA3 + col] = (char)quantize1(v, L.ffn2.a_quant);
             }
           });
+      Frags f2[NB_FFN];  // FFN2's first chunks: requested as this wave's FFN1 tiles are done
+      stream_prologue<KSF, NB_FFN, NT_D>(L.ffn2, wave, lane, f2);
       lds_barrier();
       SLIMT_STAMP(sb + 7);
-      stream_gemm<KSF, NB_FFN, NT_D, false, RT>(
-          A3, LDA3, L.ffn2, wave, lane, [&](int tile, int rt, const v4i &acc, int c2, float pb) {
+      stream_gemm_from<KSF, NB_FFN, NT_D, false, RT>(
+          A3, LDA3, L.ffn2, wave, lane, f2, [&](int tile, int rt, const v4i &acc, int c2, float pb) {
             const int col = tile * 16 + lr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1124,13 +1159,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
                     (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
       }
       // Between layers no barrier: the next phase (the SSRU's quantisation) reads and writes
-      // only this wave's own rows; the barrier after it covers both.
-      if (l + 1 == Ld) lds_barrier();
+      // only this wave's own rows; the barrier after it covers both. (After the last layer: below.)
       SLIMT_STAMP(sb + 9);
     }
     if (all_done) break;
     // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
     SLIMT_PHASE_LANE;
+    Frags fl[NB_OUT];  // requested before the barrier that ends the last LayerNorm
+    stream_prologue<KSD, NB_OUT, 0, (KSD >= 4)>(outw, wave, lane, fl);
+    lds_barrier();
     float bv[RT][4];
     int bi[RT][4];
 #pragma unroll
@@ -1140,8 +1177,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         bv[rt][r] = -3.402823466e+38f;
         bi[rt][r] = 0x7fffffff;
       }
-    stream_gemm<KSD, NB_OUT, 0, (KSD >= 4), RT>(
-        A1, LDA, outw, wave, lane, [&](int tile, int rt, const v4i &acc, int co, float pb) {
+    stream_gemm_from<KSD, NB_OUT, 0, (KSD >= 4), RT>(
+        A1, LDA, outw, wave, lane, fl, [&](int tile, int rt, const v4i &acc, int co, float pb) {
           const int col = tile * 16 + lr;
           const bool in_range = col < outw.N;  // no branch: the streaming loop stays one block
 #pragma unroll
