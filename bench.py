@@ -433,14 +433,19 @@ def main():
         if prof_name == "decode_fused":
             # HBM view of the same kernel. SURVEY 8(d) counts the cross-attention K/V cache as
             # written once and re-read on-chip: `algorithmic_bytes_per_launch` = weights + target
-            # embedding rows + K/V once. This implementation re-reads the f32 K/V cache from the
+            # embedding rows + K/V once. This implementation re-reads the K/V cache from the
             # memory side every step (9..12 batches decode at a time: their caches exceed the
             # 256 MB Infinity Cache): `implementation_bytes_per_launch`, and its ratio.
+            # The cache the decoder re-reads is the packed 24-bit form where the kernels have it
+            # (tiny11, S <= 32, not S = 1, 2, 5: slimt_hip_model_set_kv_cache_format), f32 elsewhere;
+            # SURVEY's algorithmic K/V stays the f32 tensor it names.
             kv_once = float(B) * Ld * 2 * S * D * 4
+            kv24 = dec_fused and enc_fused and D == 256 and D // H == 32 and S <= 32 and ((S + 3) // 4 * 4) * 3 <= S * 4
+            kv_impl = kv_once * 0.75 if kv24 else kv_once
             w_once = float(Ld * (4 * D * D + 2 * D * F) + D * N_out)
             io_bytes = float(B) * T * (D + 4)
             alg_bytes = w_once + io_bytes + kv_once
-            kv_reread = kv_once * T
+            kv_reread = kv_impl * T
             impl_bytes = kv_reread + w_once * T + io_bytes
             gbs = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roofline["hbm_view"] = {
@@ -449,6 +454,7 @@ def main():
                 "implementation_bytes_per_launch": impl_bytes,
                 "implementation_over_algorithmic": impl_bytes / alg_bytes,
                 "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                "kv_cache_format": "int24 accumulators (3 bytes per value)" if kv24 else "f32",
                 "bytes_model": {"kv_cache_once": kv_once, "kv_cache_reread_every_step": kv_reread,
                                 "weights_once": w_once, "weights_once_per_step": w_once * T,
                                 "embedding_rows_and_ids": io_bytes},
