@@ -32,7 +32,7 @@ if(SLIMT_HIP_PREBUILT)
   target_include_directories(slimt_hip INTERFACE "${SLIMT_HIP_INCLUDE}")
 else()
   find_program(SLIMT_HIPCC hipcc HINTS /opt/rocm/bin ENV ROCM_PATH PATH_SUFFIXES bin REQUIRED)
-  set(SLIMT_HIP_SOURCES kernels.hip gemm_tile.hip decode_kernels.hip decode_fused.hip encode_fused.hip encode_wide.hip shortlist.hip engine.cpp)
+  set(SLIMT_HIP_SOURCES kernels.hip gemm_tile.hip decode_kernels.hip decode_fused.hip encode_fused.hip encode_wide.hip encode_tall.hip shortlist.hip engine.cpp)
   set(SLIMT_HIP_HEADERS kernels.h engine.h device_common.h)
   list(TRANSFORM SLIMT_HIP_SOURCES PREPEND "${SLIMT_HIP_CSRC}/")
   list(TRANSFORM SLIMT_HIP_HEADERS PREPEND "${SLIMT_HIP_CSRC}/")

@@ -160,6 +160,10 @@ int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
  * forced to 16 / 32 sentences per workgroup (tuning and tests; 0 picks by batch
  * size). Same results in every mode. */
 int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode);
+/* Rows (source tokens) per workgroup of the persistent encoder for emb 256 models: 0
+ * (default) = chosen per call (64-row tiles once the batch fills the device with them),
+ * 32 or 64 = forced (tuning and tests). Same results either way. */
+int slimt_hip_ctx_set_encode_rows(slimt_hip_ctx *ctx, int rows);
 /* Which kernels a translate call with source length S would use in the current
  * mode: *encoder_fused / *decoder_fused = 1 for the persistent kernels, 0 for
  * the per-stage ones. */

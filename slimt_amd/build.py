@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 # SLIMT_HIP_LIB: build/load an alternative library file (kernel experiments only)
 LIB_PATH = os.environ.get("SLIMT_HIP_LIB") or os.path.join(LIB_DIR, "libslimt_hip.so")
 
-SOURCES = ["kernels.hip", "gemm_tile.hip", "decode_kernels.hip", "decode_fused.hip", "encode_fused.hip", "encode_wide.hip", "shortlist.hip",
+SOURCES = ["kernels.hip", "gemm_tile.hip", "decode_kernels.hip", "decode_fused.hip", "encode_fused.hip", "encode_wide.hip", "encode_tall.hip", "shortlist.hip",
            "engine.cpp"]
 HEADERS = ["kernels.h", "engine.h", "device_common.h", os.path.join(ROOT, "include", "slimt_hip.h")]
 

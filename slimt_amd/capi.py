@@ -22,7 +22,7 @@ SYMBOLS = [
     "slimt_hip_softmax", "slimt_hip_highway", "slimt_hip_sdpa",
     "slimt_hip_model_create", "slimt_hip_model_destroy", "slimt_hip_model_info",
     "slimt_hip_ctx_create", "slimt_hip_ctx_create_budget", "slimt_hip_ctx_destroy", "slimt_hip_ctx_stream",
-    "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_ctx_plan", "slimt_hip_translate", "slimt_hip_translate_device",
+    "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_ctx_set_encode_rows", "slimt_hip_ctx_plan", "slimt_hip_translate", "slimt_hip_translate_device",
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
     "slimt_hip_debug_decode_stamps",
@@ -95,6 +95,7 @@ def lib():
     L.slimt_hip_ctx_stream.argtypes = [vp, vp]
     L.slimt_hip_ctx_synchronize.argtypes = [vp]
     L.slimt_hip_ctx_set_decode_mode.argtypes = [vp, i32]
+    L.slimt_hip_ctx_set_encode_rows.argtypes = [vp, i32]
     L.slimt_hip_ctx_plan.argtypes = [vp, sz, vp, vp]
     L.slimt_hip_translate.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp]
     L.slimt_hip_translate_async.argtypes = [vp, vp, vp, sz, sz, vp, sz, f32, u32, vp, vp, vp]
@@ -322,6 +323,10 @@ class Context:
     def set_decode_mode(self, mode: int):
         """0 = auto (persistent fused decoder when supported), 1 = step-wise launches."""
         _chk(lib().slimt_hip_ctx_set_decode_mode(self.h, mode))
+
+    def set_encode_rows(self, rows: int):
+        """Rows per workgroup of the persistent D = 256 encoder: 0 = auto, 32, 64."""
+        _chk(lib().slimt_hip_ctx_set_encode_rows(self.h, rows))
 
     def plan(self, S: int):
         """(encoder_fused, decoder_fused) for source length S in the current mode."""

@@ -1,0 +1,639 @@
+// Persistent fused encoder for D = 256 (tiny11: 8 heads of 32) on 64-row tiles: embedding + all
+// encoder layers + the decoder's cross-attention K/V cache in ONE launch, 64 rows
+// (= floor(64 / S) whole sentences, S <= 32) per workgroup.
+//
+// encode_fused.hip keeps 32 rows per workgroup with everything resident in LDS; every workgroup
+// then streams the layer's 1.05 MB of weights for 32 rows, and the CU's L2 path (64 B/clk) is
+// what its GEMM phases wait for. Here a weight fragment feeds FOUR row tiles: the O projection
+// and the FFN (0.85 MB of the 1.05 MB) cross the L2 path once per 64 rows. To fit 160 KiB:
+//
+//   * the residual stream lives in REGISTERS (wave w owns rows 4 w .. 4 w + 3, lane L holds
+//     columns L + 64 i -- the element-to-lane map of the canonical row sum): LayerNorm, residual
+//     adds, the embedding and every quantisation of x run on the owner without a layout change;
+//   * heads are staged in two rounds of four: q / k / v of four heads in f32 (102 KiB), attention
+//     on the f32 matrix cores, one wave per (sentence, head, 16 queries) -- 16 jobs per round for
+//     two 32-token sentences -- exactly the arithmetic of encode_fused.hip;
+//   * two int8 A-operand buffers: x quantised for Q and for K side by side, V re-uses K's
+//     (each projection has its own multiplier); a round's attention output is a third, narrow one;
+//   * GEMM outputs that meet the residual (O projection, FFN2) cross from the column-tile owner
+//     to the row owner through an f32 exchange tile that time-shares the q / k / v region with
+//     the FFN's hidden layer (64 x F int8).
+//
+// Weights are the MFMA A operand (an accumulator lane holds 4 consecutive columns of one row).
+// Arithmetic is bit-identical to encode_fused.hip, the layer-by-layer kernels and the oracle's
+// portable order. Reference: Model.cc:195-201, Transformer.cc:57-69, Modules.cc:287-334,
+// TensorOps.cc:542-580.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace slimt_hip {
+
+namespace {
+
+constexpr int TNW = 16;  // waves per workgroup
+constexpr int TR = 64;   // rows per workgroup
+constexpr int TRT = 4;   // MFMA row tiles
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t trsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ v4i tload(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// y = float(acc + 127 colsum) * u + pb   (Intgemm.inl.cc:146-153)
+__device__ __forceinline__ float tdequant(int acc, int colsum, float u, float pb) {
+  const float v = (float)(acc + __mul24(127, colsum)) * u;  // |colsum| <= 127 K < 2^23
+  return v + pb;
+}
+
+// epilogue constants of column tile `tile` for this lane's 4 columns (4 lg .. 4 lg + 3)
+struct TEpi {
+  v4i cs;
+  float4 pb;
+};
+__device__ __forceinline__ TEpi tload_epi(const PreparedWeight &w, int tile, int lg) {
+  const rsrc_t rc = trsrc(w.colsum, (unsigned)w.n_tiles * 64u), rp = trsrc(w.pb, (unsigned)w.n_tiles * 64u);
+  TEpi e;
+  e.cs = tload(rc, lg * 16, tile * 64);
+  e.pb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rp, lg * 16, tile * 64, 0));
+  return e;
+}
+__device__ __forceinline__ float4 tdequant4(const v4i &c, const TEpi &e, float u) {
+  float4 v;
+  v.x = tdequant(c[0], e.cs[0], u, e.pb.x);
+  v.y = tdequant(c[1], e.cs[1], u, e.pb.y);
+  v.z = tdequant(c[2], e.cs[2], u, e.pb.z);
+  v.w = tdequant(c[3], e.cs[3], u, e.pb.w);
+  return v;
+}
+
+// canonical LayerNorm of one row held in registers (v[i] = column lane + 64 i), in place
+__device__ __forceinline__ void tln_regs(float (&v)[4], const float (&scale)[4], const float (&bias)[4], float eps) {
+  constexpr int D = 256;
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += v[i];
+  s = wave_sum(s);
+  const float mean = s / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float d = v[i] - mean;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  const float sigma = __builtin_sqrtf(q / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t = (v[i] - mean) / sigma;
+    const float m = scale[i] * t;
+    v[i] = m + bias[i];
+  }
+}
+__device__ __forceinline__ void tload_ln(const float *scale, const float *bias, int lane, float (&sc)[4], float (&bi)[4]) {
+  const rsrc_t rs = trsrc(scale, 1024u), rb = trsrc(bias, 1024u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, i * 256, 0));
+    bi[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, i * 256, 0));
+  }
+}
+
+// four 24-bit two's-complement integers, little endian, in 12 bytes (the packed K/V cache)
+typedef int v3i __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ v3i tpack24(v4i x) {
+  v3i o;
+  o.x = (x.x & 0xffffff) | (x.y << 24);
+  o.y = ((x.y >> 8) & 0xffff) | (x.z << 16);
+  o.z = ((x.z >> 16) & 0xff) | (x.w << 8);
+  return o;
+}
+
+}  // namespace
+
+// keeps lane-derived offsets from being hoisted out of the layer loop and spilled (decode_fused.hip)
+#define SLIMT_TPHASE_LANE                               \
+  int lane = lane0;                                     \
+  asm volatile("" : "+v"(lane));                        \
+  const int lr = lane & 15, lg = lane >> 4;             \
+  (void)lr;                                             \
+  (void)lg
+
+// Diagnostic phase stamps (100 MHz wall clock) of workgroup 0 in one layer (slots 0..10).
+#define SLIMT_TSTAMP(id)                                                              \
+  do {                                                                                \
+    if (a.stamps && s0 == 0 && tid == 0 && l == a.stamp_layer)                        \
+      a.stamps[(id)] = wall_clock64();                                                \
+  } while (0)
+
+template <int KSF>
+__global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KSD = 4, D = 256, DH = 32, F = 64 * KSF;
+  constexpr int HR = 4;        // heads per round
+  constexpr int RC = HR * DH;  // q / k / v columns per round (128)
+  constexpr int NR = 2;        // rounds
+  constexpr int LDA = D + 16;  // int8 A rows
+  constexpr int LDO = RC + 16; // int8 attention output rows of one round
+  // f32 q / k / v rows: the attention's 16x16x4 operands are read by lanes (row n = lane % 16,
+  // k index g = lane / 16) -- q, k at [row n][d + g]: stride = 4 mod 64 words is conflict-free;
+  // v at [key g][d + n]: stride = 16 mod 64 is
+  constexpr int LDQ = RC + 4;
+  constexpr int LDV = RC + 16;
+  constexpr int LDY = D + 4;   // f32 exchange rows (also the int32 rows of the K/V staging tile)
+  constexpr int LDH = F + 16;  // int8 hidden rows
+  constexpr int NT1 = (F / 16) / TNW;  // FFN1 column tiles per wave
+  constexpr int NC2 = KSF / 4;         // FFN2 chunks of four k-steps
+  static_assert((F / 16) % TNW == 0 && KSF % 4 == 0, "whole tiles / whole chunks per wave");
+  static_assert(D / 16 == TNW, "one 16-column tile of a D-wide GEMM per wave");
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = a.S, B = a.B;
+  const int spw = TR / S;  // whole sentences per workgroup
+
+  __shared__ int claimed;
+  const int n_wg = (B + spw - 1) / spw;
+  int tile = blockIdx.x;
+  if (a.ticket) {  // over-subscribed launch: the first workgroups to START take the tiles
+    if (tid == 0) claimed = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
+    __syncthreads();
+    tile = claimed;
+    if ((unsigned)tile >= (unsigned)n_wg) return;
+  }
+  const int s0 = tile * spw;  // first sentence
+  const int rows_used = spw * S;
+  if (tid == 0) occ_trace_event(a.trace, 2, 0);
+
+  char *Aq = smem;                       // x quantised for Q | for FFN1 | for the decoder's K / V
+  char *Akv = Aq + TR * LDA;             // x quantised for K, then for V
+  char *Ob = Akv + TR * LDA;             // [round][TR][LDO] attention output, int8
+  char *region = Ob + NR * TR * LDO;     // q, k, v of four heads | exchange tile | hidden layer
+  float *qb = reinterpret_cast<float *>(region);
+  float *kb = qb + TR * LDQ;
+  float *vb = kb + TR * LDQ;  // rows of LDV floats
+  float *Yb = reinterpret_cast<float *>(region);
+  char *Hb = region;
+  static_assert((size_t)TR * LDY * 4 <= (size_t)TR * (2 * LDQ + LDV) * 4, "exchange tile fits q / k / v");
+  static_assert((size_t)TR * LDH <= (size_t)TR * (2 * LDQ + LDV) * 4, "hidden layer fits q / k / v");
+
+  auto row_sentence = [&](int r) { return s0 + r / S; };
+  auto row_valid = [&](int r) { return r < rows_used && row_sentence(r) < B; };
+
+  // side job: the batch's shortlisted output layer (used by the decoder launch behind this one)
+  for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+
+  // ---- embedding (Model.cc:195-197) into the owner's registers ------------------------------
+  float x[4][KSD];
+  {
+    SLIMT_TPHASE_LANE;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = 4 * wave + rr;
+      const bool ok = row_valid(r);
+      const int sb = row_sentence(r), pos = r % S;
+      const uint32_t tok = ok ? a.ids[(size_t)sb * S + pos] : 0;
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) {
+        float v = 0.0f;
+        if (ok) {
+          const float e = (float)a.emb.wemb[(size_t)tok * D + lane + 64 * i] * a.emb.inv_mult;
+          const float sc = e * a.emb.sqrt_d;
+          v = sc + a.emb.pos[(size_t)pos * D + lane + 64 * i];
+        }
+        x[rr][i] = v;
+        if (ok && a.embed_out) a.embed_out[((size_t)sb * S + pos) * D + lane + 64 * i] = v;
+      }
+    }
+  }
+  // the owner's rows, quantised for the next affine, into an A buffer
+  auto quantise_x = [&](char *A, float aq, int lane) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int i = 0; i < KSD; ++i) A[(4 * wave + rr) * LDA + lane + 64 * i] = (char)quantize1(x[rr][i], aq);
+  };
+  auto load_w = [&](v4i (&f)[KSD], const PreparedWeight &w, int ct, int lane) {
+    const rsrc_t rw = trsrc(w.Wp, (unsigned)w.n_tiles * KSD * 1024u);
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) f[ks] = tload(rw, lane * 16, (ct * KSD + ks) * 1024);
+  };
+  // one 16-column weight tile (K = D) against row tile rt of `A`: accumulator lane = row
+  // 16 rt + lr, columns 4 lg .. 4 lg + 3 of the tile
+  auto mma_rt = [&](const char *A, const v4i (&f)[KSD], int rt, int lane) {
+    const int lr = lane & 15, lg = lane >> 4;
+    v4i c = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) {
+      const v4i av = *reinterpret_cast<const v4i *>(A + (16 * rt + lr) * LDA + ks * 64 + lg * 16);
+      c = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], av, c, 0, 0, 0);
+    }
+    return c;
+  };
+
+  for (int l = 0; l < a.Le; ++l) {
+    const FusedEncLayerW &L = a.L[l];
+    SLIMT_TSTAMP(0);
+    // ---- Attention::forward (Modules.cc:287-319), four heads per round -----------------------
+    for (int hr = 0; hr < NR; ++hr) {
+      {  // x quantised for Q (once per layer) and for K
+        SLIMT_TPHASE_LANE;
+        lds_barrier();  // the A buffers and the region are free
+        if (hr == 0) quantise_x(Aq, L.q.a_quant, lane);
+        quantise_x(Akv, L.k.a_quant, lane);
+      }
+      // a round's projection is 8 column tiles x 4 row tiles: wave = (tile w % 8, row tiles
+      // 2 (w / 8), 2 (w / 8) + 1) -- its weight tile is fetched by two waves
+      const int ctl = wave & 7, rt0 = 2 * (wave >> 3);
+      const int ct = hr * (RC / 16) + ctl;
+      {  // Q and K projections
+        SLIMT_TPHASE_LANE;
+        v4i wq[KSD], wk[KSD];
+        load_w(wq, L.q, ct, lane);
+        load_w(wk, L.k, ct, lane);
+        const TEpi eq = tload_epi(L.q, ct, lg), ek = tload_epi(L.k, ct, lg);
+        lds_barrier();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int rt = rt0 + t;
+          const v4i cq = mma_rt(Aq, wq, rt, lane);
+          const v4i ck = mma_rt(Akv, wk, rt, lane);
+          *reinterpret_cast<float4 *>(qb + (16 * rt + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(cq, eq, L.q.u);
+          *reinterpret_cast<float4 *>(kb + (16 * rt + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(ck, ek, L.k.u);
+        }
+      }
+      {  // V projection: K's buffer, re-quantised with V's multiplier
+        SLIMT_TPHASE_LANE;
+        v4i wv[KSD];
+        load_w(wv, L.v, ct, lane);
+        const TEpi ev = tload_epi(L.v, ct, lg);
+        lds_barrier();  // every wave has read the K operand
+        quantise_x(Akv, L.v.a_quant, lane);
+        lds_barrier();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int rt = rt0 + t;
+          const v4i cv = mma_rt(Akv, wv, rt, lane);
+          *reinterpret_cast<float4 *>(vb + (16 * rt + lr) * LDV + ctl * 16 + lg * 4) = tdequant4(cv, ev, L.v.u);
+        }
+      }
+      lds_barrier();
+      SLIMT_TSTAMP(hr == 0 ? 1 : 3);
+      // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one wave per
+      // (sentence, head of the round, 16 queries). v_mfma_f32_16x16x4_f32 chains over ascending k
+      // (bit-identical to the ascending fmaf chain, tools/probe_mfma_f32.py); operand maps,
+      // butterfly order and the lane-group transpose of P as in encode_fused.hip.
+      {
+        SLIMT_TPHASE_LANE;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        char *Or = Ob + hr * TR * LDO;
+        const int n = lane & 15, g = lane >> 4;
+        const float minus_inf = -99999999.0f;  // Input.cc:56-61
+        const float lowest = -3.402823466e+38f;
+        const int nqh = S > 16 ? 2 : 1;  // 16-query halves of a sentence
+        for (int job = wave; job < spw * HR * nqh; job += TNW) {
+          const int qh = job % nqh, hl = (job / nqh) % HR, sl = job / (nqh * HR);
+          const int sb = s0 + sl;
+          if (sb >= B) continue;
+          const int base = sl * S;
+          const int len = (int)a.lengths[sb];
+          const int qr = 16 * qh + n;
+          const float *qp = qb + (base + (qr < S ? qr : S - 1)) * LDQ + hl * DH + g;
+          float sc[2][4];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            const int kr = 16 * kt + n;
+            const float *kp = kb + (base + (kr < S ? kr : S - 1)) * LDQ + hl * DH + g;
+            v4f st = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k0 = 0; k0 < DH; k0 += 4) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[k0], qp[k0], st, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int m = 16 * kt + 4 * g + r;  // key of this register
+              float v = st[r];
+              if (a.alpha != 1.0f) v = a.alpha * v;
+              v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
+              if (m >= S) v = lowest;
+              sc[kt][r] = v;
+            }
+          }
+          float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
+                           fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+          mx = bf_max<32>(bf_max<16>(mx));
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * g + r) < S ? exp_p(sc[kt][r] - mx) : 0.0f;
+          float t[2];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+            t[kt] = bf_add<32>(bf_add<16>((sc[kt][0] + sc[kt][1]) + (sc[kt][2] + sc[kt][3])));  // masks 1, 2 | 4 | 8
+          const float sum = t[0] + t[1];                                                          // mask 16
+          float pa[2][4];  // pa[kt][j] on lane (n, g) = P[query n][key 16 kt + 4 j + g]
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[kt][r] = sc[kt][r] / sum;  // keys >= S: exactly 0
+            const slimt_u2 s01 = __builtin_amdgcn_permlane16_swap(__float_as_int(sc[kt][0]), __float_as_int(sc[kt][1]), false, false);
+            const slimt_u2 s23 = __builtin_amdgcn_permlane16_swap(__float_as_int(sc[kt][2]), __float_as_int(sc[kt][3]), false, false);
+            const slimt_u2 ac = __builtin_amdgcn_permlane32_swap(s01.x, s23.x, false, false);
+            const slimt_u2 bd = __builtin_amdgcn_permlane32_swap(s01.y, s23.y, false, false);
+            pa[kt][0] = __int_as_float(ac.x);
+            pa[kt][1] = __int_as_float(bd.x);
+            pa[kt][2] = __int_as_float(ac.y);
+            pa[kt][3] = __int_as_float(bd.y);
+          }
+#pragma unroll
+          for (int nt = 0; nt < DH / 16; ++nt) {
+            const int dcol = hl * DH + 16 * nt + n;  // column inside the round
+            v4f o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {  // keys >= S contribute fma(0, v, o) == o
+              const int key = 4 * s4 + g;
+              const float vv = vb[(base + (key < S ? key : S - 1)) * LDV + dcol];
+              o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4 >> 2][s4 & 3], vv, o, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int q = 16 * qh + 4 * g + r;  // query of this register
+              if (q < S) Or[(base + q) * LDO + dcol] = (char)quantize1(o[r], L.o.a_quant);
+            }
+          }
+        }
+        // rows that belong to no sentence keep a defined A operand
+        for (int r = rows_used + wave; r < TR; r += TNW)
+#pragma unroll
+          for (int i = 0; i < RC / 64; ++i) Or[r * LDO + lane + 64 * i] = 0;
+      }
+      if (hr == 0) SLIMT_TSTAMP(2);
+    }
+    // ---- O projection (Modules.cc:308-314): wave = column tile, four row tiles -> exchange tile
+    {
+      SLIMT_TPHASE_LANE;
+      v4i wo[KSD];
+      load_w(wo, L.o, wave, lane);
+      const TEpi eo = tload_epi(L.o, wave, lg);
+      lds_barrier();  // attention of the last round is complete: q / k / v are dead
+      SLIMT_TSTAMP(4);
+#pragma unroll
+      for (int rt = 0; rt < TRT; ++rt) {
+        v4i c = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {  // k-steps 0, 1: round 0's heads; 2, 3: round 1's
+          const v4i av = *reinterpret_cast<const v4i *>(Ob + (ks >> 1) * TR * LDO + (16 * rt + lr) * LDO + (ks & 1) * 64 + lg * 16);
+          c = __builtin_amdgcn_mfma_i32_16x16x64_i8(wo[ks], av, c, 0, 0, 0);
+        }
+        *reinterpret_cast<float4 *>(Yb + (16 * rt + lr) * LDY + wave * 16 + lg * 4) = tdequant4(c, eo, L.o.u);
+      }
+    }
+    // FFN1's first column tiles travel under the LayerNorm
+    v4i bw[3][KSD];
+    TEpi e1[3];
+    auto load1 = [&](int buf, int i, int lane) {
+      load_w(bw[buf], L.ffn1, wave + TNW * i, lane);
+      e1[buf] = tload_epi(L.ffn1, wave + TNW * i, lane >> 4);
+    };
+    {
+      SLIMT_TPHASE_LANE;
+      float lsc[4], lbi[4];
+      tload_ln(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);
+      lds_barrier();
+      SLIMT_TSTAMP(5);
+      // x = LN(x + O(...)); quantised for FFN1
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) x[rr][i] = x[rr][i] + Yb[(4 * wave + rr) * LDY + lane + 64 * i];
+        tln_regs(x[rr], lsc, lbi, a.eps);
+      }
+      quantise_x(Aq, L.ffn1.a_quant, lane);
+#pragma unroll
+      for (int i = 0; i < 3 && i < NT1; ++i) {
+        load1(i, i, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    lds_barrier();  // the exchange tile is dead, FFN1's input is complete
+    SLIMT_TSTAMP(6);
+    // ---- FFN (Modules.cc:326-331) ----------------------------------------------------------
+    const rsrc_t r2 = trsrc(reinterpret_cast<const char *>(L.ffn2.Wp) + (size_t)wave * KSF * 1024, (unsigned)KSF * 1024u);
+    v4i b2[3][4];
+    auto load2 = [&](int buf, int c, int lane) {  // FFN2 chunk c: k-steps 4 c .. 4 c + 3 of this wave's column tile
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) b2[buf][ks] = tload(r2, lane * 16, (c * 4 + ks) * 1024);
+    };
+    {  // FFN1: NT1 column tiles per wave, three in flight; relu, requantised into the hidden layer
+      SLIMT_TPHASE_LANE;
+#pragma unroll
+      for (int i = 0; i < NT1; ++i) {
+        const int buf = i % 3, t = wave + TNW * i;
+        const TEpi e = e1[buf];
+#pragma unroll
+        for (int rt = 0; rt < TRT; ++rt) {
+          const v4i c = mma_rt(Aq, bw[buf], rt, lane);
+          int q[4];
+          const float pbv[4] = {e.pb.x, e.pb.y, e.pb.z, e.pb.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = tdequant(c[r], e.cs[r], L.ffn1.u, pbv[r]);
+            v = v > 0.0f ? v : 0.0f;
+            q[r] = quantize1(v, L.ffn2.a_quant);
+          }
+          *reinterpret_cast<int *>(Hb + (16 * rt + lr) * LDH + t * 16 + lg * 4) = pack4(q[0], q[1], q[2], q[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 3 < NT1) load1(buf, i + 3, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // FFN2's first weight chunks do not depend on the hidden layer: requested before the barrier
+#pragma unroll
+      for (int c = 0; c < 3 && c < NC2; ++c) {
+        load2(c, c, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    lds_barrier();  // the hidden layer is complete
+    SLIMT_TSTAMP(7);
+    {  // FFN2: this wave's column tile over K = F, chunks of 4 k-steps, three in flight
+      SLIMT_TPHASE_LANE;
+      v4i f[TRT];
+#pragma unroll
+      for (int rt = 0; rt < TRT; ++rt) f[rt] = v4i{0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < NC2; ++c) {
+        const int buf = c % 3;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+          for (int rt = 0; rt < TRT; ++rt) {
+            const v4i h = *reinterpret_cast<const v4i *>(Hb + (16 * rt + lr) * LDH + (c * 4 + ks) * 64 + lg * 16);
+            f[rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[buf][ks], h, f[rt], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 3 < NC2) load2(buf, c + 3, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const TEpi e2 = tload_epi(L.ffn2, wave, lg);
+      lds_barrier();  // every wave has read the hidden layer: the region becomes the exchange tile
+      SLIMT_TSTAMP(8);
+#pragma unroll
+      for (int rt = 0; rt < TRT; ++rt)
+        *reinterpret_cast<float4 *>(Yb + (16 * rt + lr) * LDY + wave * 16 + lg * 4) = tdequant4(f[rt], e2, L.ffn2.u);
+    }
+    {  // x = LN(FFN2(...) + x)
+      SLIMT_TPHASE_LANE;
+      float lsc[4], lbi[4];
+      tload_ln(L.ffn_ln_s, L.ffn_ln_b, lane, lsc, lbi);
+      lds_barrier();
+      SLIMT_TSTAMP(9);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = 4 * wave + rr;
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) x[rr][i] = Yb[r * LDY + lane + 64 * i] + x[rr][i];
+        tln_regs(x[rr], lsc, lbi, a.eps);
+        if (a.layer_out && row_valid(r)) {
+          float *dst = a.layer_out + ((size_t)l * B * S + (size_t)row_sentence(r) * S + r % S) * D;
+#pragma unroll
+          for (int i = 0; i < KSD; ++i) dst[lane + 64 * i] = x[rr][i];
+        }
+      }
+    }
+    SLIMT_TSTAMP(10);
+    // (the next phase starts with a barrier before it touches an A buffer or the region)
+  }
+
+  // ---- encoder output + decoder cross-attention K/V (Modules.cc:248-249, once per batch) ------
+  {
+    SLIMT_TPHASE_LANE;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = 4 * wave + rr;
+      if (a.enc_out && row_valid(r)) {
+        float *dst = a.enc_out + ((size_t)row_sentence(r) * S + r % S) * D;
+#pragma unroll
+        for (int i = 0; i < KSD; ++i) dst[lane + 64 * i] = x[rr][i];
+      }
+    }
+  }
+  for (int l = 0; l < a.Ld; ++l) {
+    for (int p = 0; p < 2; ++p) {
+      SLIMT_TPHASE_LANE;
+      const PreparedWeight &w = p == 0 ? a.dec_k[l] : a.dec_v[l];
+      float *out = a.kv + (size_t)(2 * l + p) * B * S * D;
+      v4i wf[KSD];
+      load_w(wf, w, wave, lane);
+      const TEpi e = tload_epi(w, wave, lg);
+      lds_barrier();  // the A buffer and the region are free
+      quantise_x(Aq, w.a_quant, lane);
+      lds_barrier();
+      const int col = wave * 16 + lg * 4;
+      int *stg = reinterpret_cast<int *>(region);  // packed cache: [TR][LDY] shifted accumulators
+#pragma unroll
+      for (int rt = 0; rt < TRT; ++rt) {
+        const v4i c = mma_rt(Aq, wf, rt, lane);
+        const int rrow = 16 * rt + lr;
+        if (a.kv24) {
+          const v4i s4 = {c[0] + __mul24(127, e.cs[0]), c[1] + __mul24(127, e.cs[1]), c[2] + __mul24(127, e.cs[2]),
+                          c[3] + __mul24(127, e.cs[3])};
+          *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = s4;
+        } else if (row_valid(rrow)) {
+          const float4 v = tdequant4(c, e, w.u);
+          if (p == 0) {  // K cache layout [sentence][head][d/4][key][4]: the lane's 4 columns are one d/4 group
+            const size_t chunk = (size_t)row_sentence(rrow) * (D / 4) + (col >> 2);
+            *reinterpret_cast<float4 *>(out + (chunk * S + rrow % S) * 4) = v;
+          } else {
+            *reinterpret_cast<float4 *>(out + ((size_t)row_sentence(rrow) * S + rrow % S) * D + col) = v;
+          }
+        }
+      }
+      if (a.kv24) {
+        // the packed cache (kernels.h, FusedDecodeArgs::kv24): one thread = 16 values = 48 bytes =
+        // three 16-byte stores, one per plane
+        lds_barrier();
+        const int Sp = (S + 3) & ~3;
+        if (p == 0) {  // K [sentence][column / 16][plane][key][16 B]: consecutive lanes = consecutive keys
+          const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * S * D * 3));
+          for (int it = tid; it < TR * (D / 16); it += 1024) {
+            const int r = it % TR, ci = it / TR;
+            if (!row_valid(r)) continue;
+            v3i wd[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wd[g] = tpack24(*reinterpret_cast<const v4i *>(stg + r * LDY + 16 * ci + 4 * g));
+            const int off = row_sentence(r) * S * D * 3 + (ci * 3 * S + r % S) * 16;
+            const v4i p0 = {wd[0].x, wd[0].y, wd[0].z, wd[1].x}, p1 = {wd[1].y, wd[1].z, wd[2].x, wd[2].y},
+                      p2 = {wd[2].z, wd[3].x, wd[3].y, wd[3].z};
+            __builtin_amdgcn_raw_buffer_store_b128(p0, ro, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, ro, off + S * 16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p2, ro, off + 2 * S * 16, 0, 0);
+          }
+        } else {  // V [sentence][key / 4][plane][column / 4][16 B]: 4 keys x 4 columns, key-major
+          const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * Sp * D * 3));
+          for (int it = tid; it < spw * (Sp / 4) * 64; it += 1024) {
+            const int cl = it & 63, g = (it >> 6) % (Sp / 4), si = (it >> 6) / (Sp / 4);
+            if (s0 + si >= B) continue;
+            v3i wd[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // keys past the sentence: zeros (finite once unpacked, weight 0)
+              const int key = 4 * g + i;
+              const v4i xv = *reinterpret_cast<const v4i *>(stg + (si * S + (key < S ? key : 0)) * LDY + 4 * cl);
+              const v4i z = {0, 0, 0, 0};
+              wd[i] = tpack24(key < S ? xv : z);
+            }
+            const int off = ((s0 + si) * (Sp / 4) + g) * 3 * 64 * 16 + cl * 16;
+            const v4i p0 = {wd[0].x, wd[0].y, wd[0].z, wd[1].x}, p1 = {wd[1].y, wd[1].z, wd[2].x, wd[2].y},
+                      p2 = {wd[2].z, wd[3].x, wd[3].y, wd[3].z};
+            __builtin_amdgcn_raw_buffer_store_b128(p0, ro, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, ro, off + 1024, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p2, ro, off + 2048, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (tid == 0) occ_trace_event(a.trace, 2, 1);
+}
+
+size_t tall_encode_lds_bytes(int F) {
+  const size_t region_qkv = (size_t)TR * (2 * (128 + 4) + (128 + 16)) * 4;
+  const size_t region_h = (size_t)TR * (F + 16);
+  const size_t region = region_qkv > region_h ? region_qkv : region_h;
+  return 2 * (size_t)TR * (256 + 16) + 2 * (size_t)TR * (128 + 16) + region;
+}
+
+bool tall_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
+  if (S < 1 || S > 32 || Le < 1 || Le > 6 || Ld < 1 || Ld > 4) return false;
+  if (D != 256 || H != 8) return false;
+  if (F != 1536 && F != 1024) return false;  // (F = 2048: the hidden layer of 64 rows does not fit the region)
+  return tall_encode_lds_bytes(F) <= 160 * 1024;
+}
+
+// workgroups launched for 64-row tiles (see fused_encode_grid)
+int tall_encode_grid(int B, int S, bool tickets) {
+  const int spw = TR / S;
+  const int tiles = (B + spw - 1) / spw;
+  if (!tickets) return tiles;
+  const int extra = tiles / 4 > 32 ? tiles / 4 : 32;
+  return (tiles + extra + 31) / 32 * 32;
+}
+
+hipError_t launch_encode_tall(const FusedEncodeArgs &a, int F, hipStream_t st) {
+  const dim3 grid(tall_encode_grid(a.B, a.S, a.ticket != nullptr));
+  const size_t lds = tall_encode_lds_bytes(F);
+  hipError_t e = hipSuccess;
+#define SLIMT_TALL_CASE(KSF_)                                                                  \
+  if (F == 64 * KSF_) {                                                                        \
+    auto k = encode_tall_kernel<KSF_>;                                                         \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                                 \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    if (e != hipSuccess) return e;                                                             \
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);                                       \
+    return hipGetLastError();                                                                  \
+  }
+  SLIMT_TALL_CASE(24) SLIMT_TALL_CASE(16)
+#undef SLIMT_TALL_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace slimt_hip

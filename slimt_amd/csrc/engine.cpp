@@ -762,6 +762,13 @@ extern "C" int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode) {
   return 0;
 }
 
+extern "C" int slimt_hip_ctx_set_encode_rows(slimt_hip_ctx *ctx, int rows) {
+  if (!ctx) return fail(-1, "ctx is NULL");
+  if (rows != 0 && rows != 32 && rows != 64) return fail(-1, "encoder rows per workgroup %d not in {0, 32, 64}", rows);
+  ctx->encode_rows = rows;
+  return 0;
+}
+
 extern "C" int slimt_hip_ctx_plan(const slimt_hip_ctx *ctx, size_t S, int *encoder_fused,
                                   int *decoder_fused) {
   if (!ctx) return fail(-1, "ctx is NULL");
@@ -941,12 +948,20 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     }
     f.ticket = c->ticket.as<unsigned>() + 1;  // over-subscribed launch, tiles claimed by ticket
     f.ticket_base = c->enc_ticket_base;
+    // D = 256: 64-row tiles (encode_tall.hip: the O projection's and the FFN's weights cross the
+    // CU's L2 path once per 64 rows) once the batch fills the chip with them -- below that, twice
+    // as many 32-row workgroups finish a lone batch sooner
+    const bool tall = tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S) &&
+                      (c->encode_rows == 64 || (c->encode_rows == 0 && tall_encode_grid(B, S, false) >= 96));
     {
       const double macs = (double)M * (m->Le * (4.0 * D * D + 2.0 * D * m->F) + m->Ld * 2.0 * D * D);
       ProfScope p(c, SLIMT_HIP_K_ENCODE_FUSED, macs, 0);
-      HIPCHK(launch_encode_fused(f, m->D, m->F, m->H, st));
+      if (tall)
+        HIPCHK(launch_encode_tall(f, m->F, st));
+      else
+        HIPCHK(launch_encode_fused(f, m->D, m->F, m->H, st));
     }
-    c->enc_ticket_base += (unsigned)fused_encode_grid(B, S, true);
+    c->enc_ticket_base += (unsigned)(tall ? tall_encode_grid(B, S, true) : fused_encode_grid(B, S, true));
     if (h_embed) HIPCHK(hipMemcpyAsync(h_embed, c->dbg_embed.p, nbytes, hipMemcpyDeviceToHost, st));
     if (h_layers)
       HIPCHK(hipMemcpyAsync(h_layers, c->dbg_layers.p, nbytes * (size_t)m->Le, hipMemcpyDeviceToHost, st));

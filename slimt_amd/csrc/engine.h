@@ -100,6 +100,7 @@ struct slimt_hip_ctx {
   bool decode_ready = false;
   bool kv_ready = false;  // cross-attention K/V already produced by the fused encoder
   slimt_hip::DevBuf dbg_embed, dbg_layers;
+  int encode_rows = 0;  // rows per workgroup of the persistent D = 256 encoder: 0 auto, 32, 64
   int decode_mode = 0;  // 0 auto (fused when supported), 1 step-wise launches, 2 / 3 fused with 16 / 32 rows per workgroup
   slimt_hip::DevBuf stamps;  // diagnostic phase stamps of the fused decoder
   int stamp_step = -1;

@@ -314,6 +314,10 @@ struct FusedEncodeArgs {
 bool fused_encode_supported(int D, int F, int H, int Le, int Ld, int S);
 hipError_t launch_encode_fused(const FusedEncodeArgs &a, int D, int F, int H, hipStream_t st);
 // D = 512 / F = 2048 / 8 heads (encode_wide.hip): same arguments, reached through launch_encode_fused
+// 64-row tiles for D = 256 (encode_tall.hip): half the weight bytes per source token
+bool tall_encode_supported(int D, int F, int H, int Le, int Ld, int S);
+int tall_encode_grid(int B, int S, bool tickets);
+hipError_t launch_encode_tall(const FusedEncodeArgs &a, int F, hipStream_t st);
 bool wide_encode_supported(int D, int F, int H, int Le, int Ld, int S);
 hipError_t launch_encode_wide(const FusedEncodeArgs &a, hipStream_t st);
 

@@ -370,6 +370,45 @@ def test_packed_kv_cache_matches_oracle_and_f32_cache(hip, oracle, engines, S):
         ctx.close()
 
 
+@pytest.mark.parametrize("B,S", [(2, 32), (7, 32), (70, 32), (9, 31), (5, 17), (23, 16), (11, 13), (40, 9),
+                                  (19, 5), (37, 4), (100, 3), (150, 1)])
+def test_tall_encoder_every_layer_and_translate_bit_exact(hip, oracle, engines, B, S):
+    """encode_tall.hip (64 rows = floor(64 / S) whole sentences per workgroup; chosen by itself
+    only for batches that fill the device): forced here on small batches -- every layer's output
+    against the oracle for 1..64 sentences per workgroup, partly filled last workgroups and
+    16-query halves (S <= 16 / > 16); then its decoder K/V cache in both storage formats
+    through translate (tokens, lengths, alignments)."""
+    from slimt_amd import synth
+    m, gm, om = engines("tiny11", 6.0)
+    ids, lens = synth.make_batch(m.V, B, S, seed=5200 + 64 * B + S, ragged=True)
+    oracle.set_mode(oracle.PORTABLE)
+    mask = oracle.make_mask(lens, S)
+    want = [om.embed(ids)]
+    for l in range(1, m.enc_layers + 1):
+        want.append(om.encoder_layer(l, want[-1], mask))
+    sl = synth.make_shortlist(m.V, 640)
+    want_t = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+    oracle.set_mode(oracle.FAITHFUL)
+    ctx = hip.Context(gm, B, S)
+    try:
+        ctx.set_encode_rows(64)
+        enc, emb, layers = ctx.encode(ids, lens, want_embed=True, want_layers=True)
+        assert np.array_equal(emb, want[0])
+        for l in range(1, m.enc_layers + 1):
+            assert np.array_equal(layers[l - 1], want[l]), (l, np.abs(layers[l - 1] - want[l]).max())
+        assert np.array_equal(enc, want[-1])
+        for fmt in (0, 1):
+            gm.set_kv_cache_format(fmt)
+            got = ctx.translate(ids, lens, sl, want_align=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want_t)), fmt
+        ctx.set_encode_rows(32)
+        got = ctx.translate(ids, lens, sl, want_align=True)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want_t))
+    finally:
+        gm.set_kv_cache_format(0)
+        ctx.close()
+
+
 @pytest.mark.parametrize("budget", [0, 1, 3, 1000])
 def test_decoder_admission_and_ticket_launches_keep_results(hip, oracle, engines, budget):
     """Concurrent contexts of one model under every decoder budget (0 = no limit, 1 = one
