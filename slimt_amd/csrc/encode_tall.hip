@@ -59,13 +59,35 @@ __device__ __forceinline__ TEpi tload_epi(const PreparedWeight &w, int tile, int
   e.pb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rp, lg * 16, tile * 64, 0));
   return e;
 }
+// Four columns at once, two per packed instruction (v_pk_mul_f32 / v_pk_add_f32 are the same
+// IEEE operations as the scalar forms: multiply and add stay separate roundings).
+typedef float tf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 tdequant4(const v4i &c, const TEpi &e, float u) {
+  tf2 lo = {(float)(c[0] + __mul24(127, e.cs[0])), (float)(c[1] + __mul24(127, e.cs[1]))};
+  tf2 hi = {(float)(c[2] + __mul24(127, e.cs[2])), (float)(c[3] + __mul24(127, e.cs[3]))};
+  const tf2 uu = {u, u};
+  lo = lo * uu;
+  hi = hi * uu;
+  const tf2 pl = {e.pb.x, e.pb.y}, ph = {e.pb.z, e.pb.w};
+  lo = lo + pl;
+  hi = hi + ph;
   float4 v;
-  v.x = tdequant(c[0], e.cs[0], u, e.pb.x);
-  v.y = tdequant(c[1], e.cs[1], u, e.pb.y);
-  v.z = tdequant(c[2], e.cs[2], u, e.pb.z);
-  v.w = tdequant(c[3], e.cs[3], u, e.pb.w);
+  v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
   return v;
+}
+// relu, then PrepareA with `aq`: four int8 in one register (the FFN's hidden layer)
+__device__ __forceinline__ int trelu_quant4(const v4i &c, const TEpi &e, float u, float aq) {
+  const float4 v = tdequant4(c, e, u);
+  tf2 lo = {v.x > 0.0f ? v.x : 0.0f, v.y > 0.0f ? v.y : 0.0f};
+  tf2 hi = {v.z > 0.0f ? v.z : 0.0f, v.w > 0.0f ? v.w : 0.0f};
+  const tf2 qq = {aq, aq};
+  lo = lo * qq;
+  hi = hi * qq;
+  float r[4] = {__builtin_rintf(lo.x), __builtin_rintf(lo.y), __builtin_rintf(hi.x), __builtin_rintf(hi.y)};
+  int q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = (int)__builtin_fminf(__builtin_fmaxf(r[i], -127.0f), 127.0f);
+  return pack4(q[0], q[1], q[2], q[3]);
 }
 
 // canonical LayerNorm of one row held in registers (v[i] = column lane + 64 i), in place
@@ -183,6 +205,24 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   // side job: the batch's shortlisted output layer (used by the decoder launch behind this one)
   for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
 
+  // A round's projection is 8 column tiles x 4 row tiles: wave = (tile w % 8, row tiles 2 (w / 8),
+  // 2 (w / 8) + 1) -- a weight tile is fetched by two waves. The Q and K tiles are requested a phase ahead: under the last
+  // LayerNorm of the layer before (round 0) or under the quantisation of x (round 1).
+  v4i wq[KSD], wk[KSD];
+  auto load_qk = [&](const FusedEncLayerW &Lw, int hr, int lane) {
+    const int ct = hr * (RC / 16) + (wave & 7);
+    const rsrc_t rq = trsrc(Lw.q.Wp, (unsigned)Lw.q.n_tiles * KSD * 1024u), rk = trsrc(Lw.k.Wp, (unsigned)Lw.k.n_tiles * KSD * 1024u);
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) {
+      wq[ks] = tload(rq, lane * 16, (ct * KSD + ks) * 1024);
+      wk[ks] = tload(rk, lane * 16, (ct * KSD + ks) * 1024);
+    }
+  };
+  {
+    SLIMT_TPHASE_LANE;
+    load_qk(a.L[0], 0, lane);
+  }
+
   // ---- embedding (Model.cc:195-197) into the owner's registers ------------------------------
   float x[4][KSD];
   {
@@ -235,23 +275,28 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     const FusedEncLayerW &L = a.L[l];
     SLIMT_TSTAMP(0);
     // ---- Attention::forward (Modules.cc:287-319), four heads per round -----------------------
+#pragma unroll
     for (int hr = 0; hr < NR; ++hr) {
       {  // x quantised for Q (once per layer) and for K
         SLIMT_TPHASE_LANE;
+        if (hr > 0) {  // (held through the attention they would spill: requested under the quantisation)
+          load_qk(L, hr, lane);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         lds_barrier();  // the A buffers and the region are free
         if (hr == 0) quantise_x(Aq, L.q.a_quant, lane);
         quantise_x(Akv, L.k.a_quant, lane);
       }
-      // a round's projection is 8 column tiles x 4 row tiles: wave = (tile w % 8, row tiles
-      // 2 (w / 8), 2 (w / 8) + 1) -- its weight tile is fetched by two waves
       const int ctl = wave & 7, rt0 = 2 * (wave >> 3);
       const int ct = hr * (RC / 16) + ctl;
-      {  // Q and K projections
+      v4i wv[KSD];
+      TEpi ev;
+      {  // Q and K projections (tiles requested a phase ago); V's tile travels under them
         SLIMT_TPHASE_LANE;
-        v4i wq[KSD], wk[KSD];
-        load_w(wq, L.q, ct, lane);
-        load_w(wk, L.k, ct, lane);
         const TEpi eq = tload_epi(L.q, ct, lg), ek = tload_epi(L.k, ct, lg);
+        load_w(wv, L.v, ct, lane);
+        ev = tload_epi(L.v, ct, lg);
+        __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -264,9 +309,6 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       }
       {  // V projection: K's buffer, re-quantised with V's multiplier
         SLIMT_TPHASE_LANE;
-        v4i wv[KSD];
-        load_w(wv, L.v, ct, lane);
-        const TEpi ev = tload_epi(L.v, ct, lg);
         lds_barrier();  // every wave has read the K operand
         quantise_x(Akv, L.v.a_quant, lane);
         lds_barrier();
@@ -431,15 +473,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
 #pragma unroll
         for (int rt = 0; rt < TRT; ++rt) {
           const v4i c = mma_rt(Aq, bw[buf], rt, lane);
-          int q[4];
-          const float pbv[4] = {e.pb.x, e.pb.y, e.pb.z, e.pb.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = tdequant(c[r], e.cs[r], L.ffn1.u, pbv[r]);
-            v = v > 0.0f ? v : 0.0f;
-            q[r] = quantize1(v, L.ffn2.a_quant);
-          }
-          *reinterpret_cast<int *>(Hb + (16 * rt + lr) * LDH + t * 16 + lg * 4) = pack4(q[0], q[1], q[2], q[3]);
+          *reinterpret_cast<int *>(Hb + (16 * rt + lr) * LDH + t * 16 + lg * 4) = trelu_quant4(c, e, L.ffn1.u, L.ffn2.a_quant);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (i + 3 < NT1) load1(buf, i + 3, lane);
@@ -475,6 +509,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       const TEpi e2 = tload_epi(L.ffn2, wave, lg);
+      // the next layer's first Q / K tiles: under the LayerNorm (unconditional, so that the
+      // registers are dead between the projections and here)
+      load_qk(a.L[l + 1 < a.Le ? l + 1 : l], 0, lane);
+      __builtin_amdgcn_sched_barrier(0);
       lds_barrier();  // every wave has read the hidden layer: the region becomes the exchange tile
       SLIMT_TSTAMP(8);
 #pragma unroll
