@@ -13,8 +13,9 @@
 //   * heads are staged in two rounds of four: q / k / v of four heads in f32 (102 KiB), attention
 //     on the f32 matrix cores, one wave per (sentence, head, 16 queries) -- 16 jobs per round for
 //     two 32-token sentences -- exactly the arithmetic of encode_fused.hip;
-//   * two int8 A-operand buffers: x quantised for Q and for K side by side, V re-uses K's
-//     (each projection has its own multiplier); a round's attention output is a third, narrow one;
+//   * three int8 A-operand buffers (x quantised with the multipliers of Q, K and V, once per
+//     layer), unpadded and XOR-swizzled instead -- with 16 pad bytes per row the third would not
+//     fit; round 0's attention output has a narrow buffer of its own, round 1's reuses Q's;
 //   * GEMM outputs that meet the residual (O projection, FFN2) cross from the column-tile owner
 //     to the row owner through an f32 exchange tile that time-shares the q / k / v region with
 //     the FFN's hidden layer (64 x F int8).
@@ -41,12 +42,6 @@ __device__ __forceinline__ rsrc_t trsrc(const void *p, unsigned bytes) {
 __device__ __forceinline__ v4i tload(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-// y = float(acc + 127 colsum) * u + pb   (Intgemm.inl.cc:146-153)
-__device__ __forceinline__ float tdequant(int acc, int colsum, float u, float pb) {
-  const float v = (float)(acc + __mul24(127, colsum)) * u;  // |colsum| <= 127 K < 2^23
-  return v + pb;
-}
-
 // epilogue constants of column tile `tile` for this lane's 4 columns (4 lg .. 4 lg + 3)
 struct TEpi {
   v4i cs;
@@ -59,7 +54,8 @@ __device__ __forceinline__ TEpi tload_epi(const PreparedWeight &w, int tile, int
   e.pb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rp, lg * 16, tile * 64, 0));
   return e;
 }
-// Four columns at once, two per packed instruction (v_pk_mul_f32 / v_pk_add_f32 are the same
+// y = float(acc + 127 colsum) * u + pb (Intgemm.inl.cc:146-153; |colsum| <= 127 K < 2^23), four
+// columns at once, two per packed instruction (v_pk_mul_f32 / v_pk_add_f32 are the same
 // IEEE operations as the scalar forms: multiply and add stay separate roundings).
 typedef float tf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 tdequant4(const v4i &c, const TEpi &e, float u) {
@@ -156,7 +152,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   constexpr int HR = 4;        // heads per round
   constexpr int RC = HR * DH;  // q / k / v columns per round (128)
   constexpr int NR = 2;        // rounds
-  constexpr int LDA = D + 16;  // int8 A rows
+  // int8 A rows: unpadded, the 16-byte chunks of a row XOR-swizzled with the row (taoff below)
+  // -- a fragment read (16 rows x one chunk) then covers all 64 banks without the 16 pad bytes
+  // per row, which is what lets THREE A buffers (x quantised for Q, K, V) fit beside the rest
+  constexpr int LDA = D;
   constexpr int LDO = RC + 16; // int8 attention output rows of one round
   // f32 q / k / v rows: the attention's 16x16x4 operands are read by lanes (row n = lane % 16,
   // k index g = lane / 16) -- q, k at [row n][d + g]: stride = 4 mod 64 words is conflict-free;
@@ -187,10 +186,13 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   const int rows_used = spw * S;
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
 
-  char *Aq = smem;                       // x quantised for Q | for FFN1 | for the decoder's K / V
-  char *Akv = Aq + TR * LDA;             // x quantised for K, then for V
-  char *Ob = Akv + TR * LDA;             // [round][TR][LDO] attention output, int8
-  char *region = Ob + NR * TR * LDO;     // q, k, v of four heads | exchange tile | hidden layer
+  char *Aq = smem;                       // x quantised for Q | round 1's attention output | for FFN1 | for the decoder's K / V
+  char *Ak = Aq + TR * LDA;              // x quantised for K
+  char *Av = Ak + TR * LDA;              // x quantised for V
+  char *Ob0 = Av + TR * LDA;             // [TR][LDO] attention output of round 0, int8
+  char *Ob1 = Aq;                        // ... of round 1: Q's operand is dead by then
+  char *region = Ob0 + TR * LDO;         // q, k, v of four heads | exchange tile | hidden layer
+  static_assert(TR * LDO <= TR * LDA, "round 1's attention output fits Q's operand buffer");
   float *qb = reinterpret_cast<float *>(region);
   float *kb = qb + TR * LDQ;
   float *vb = kb + TR * LDQ;  // rows of LDV floats
@@ -247,11 +249,13 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     }
   }
   // the owner's rows, quantised for the next affine, into an A buffer
+  // byte offset of (row, column) in an A buffer
+  auto taoff = [](int row, int col) { return row * LDA + ((((col >> 4) ^ row) & 15) << 4) + (col & 15); };
   auto quantise_x = [&](char *A, float aq, int lane) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-      for (int i = 0; i < KSD; ++i) A[(4 * wave + rr) * LDA + lane + 64 * i] = (char)quantize1(x[rr][i], aq);
+      for (int i = 0; i < KSD; ++i) A[taoff(4 * wave + rr, lane + 64 * i)] = (char)quantize1(x[rr][i], aq);
   };
   auto load_w = [&](v4i (&f)[KSD], const PreparedWeight &w, int ct, int lane) {
     const rsrc_t rw = trsrc(w.Wp, (unsigned)w.n_tiles * KSD * 1024u);
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     v4i c = {0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < KSD; ++ks) {
-      const v4i av = *reinterpret_cast<const v4i *>(A + (16 * rt + lr) * LDA + ks * 64 + lg * 16);
+      const v4i av = *reinterpret_cast<const v4i *>(A + (16 * rt + lr) * LDA + (((ks * 4 + lg) ^ lr) << 4));
       c = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], av, c, 0, 0, 0);
     }
     return c;
@@ -277,46 +281,42 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     // ---- Attention::forward (Modules.cc:287-319), four heads per round -----------------------
 #pragma unroll
     for (int hr = 0; hr < NR; ++hr) {
-      {  // x quantised for Q (once per layer) and for K
+      const int ctl = wave & 7, rt0 = 2 * (wave >> 3);
+      const int ct = hr * (RC / 16) + ctl;
+      {  // Q, K, V projections of this round's heads
         SLIMT_TPHASE_LANE;
-        if (hr > 0) {  // (held through the attention they would spill: requested under the quantisation)
+        if (hr > 0) {  // (held through the attention they would spill: requested under the barrier wait)
           load_qk(L, hr, lane);
           __builtin_amdgcn_sched_barrier(0);
         }
-        lds_barrier();  // the A buffers and the region are free
-        if (hr == 0) quantise_x(Aq, L.q.a_quant, lane);
-        quantise_x(Akv, L.k.a_quant, lane);
-      }
-      const int ctl = wave & 7, rt0 = 2 * (wave >> 3);
-      const int ct = hr * (RC / 16) + ctl;
-      v4i wv[KSD];
-      TEpi ev;
-      {  // Q and K projections (tiles requested a phase ago); V's tile travels under them
-        SLIMT_TPHASE_LANE;
-        const TEpi eq = tload_epi(L.q, ct, lg), ek = tload_epi(L.k, ct, lg);
+        v4i wv[KSD];
         load_w(wv, L.v, ct, lane);
-        ev = tload_epi(L.v, ct, lg);
+        const TEpi eq = tload_epi(L.q, ct, lg), ek = tload_epi(L.k, ct, lg), ev = tload_epi(L.v, ct, lg);
         __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int rt = rt0 + t;
-          const v4i cq = mma_rt(Aq, wq, rt, lane);
-          const v4i ck = mma_rt(Akv, wk, rt, lane);
-          *reinterpret_cast<float4 *>(qb + (16 * rt + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(cq, eq, L.q.u);
-          *reinterpret_cast<float4 *>(kb + (16 * rt + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(ck, ek, L.k.u);
+        lds_barrier();  // the region is free; round 0: so are the A buffers
+        if (hr == 0) {  // x quantised with the three projections' multipliers, once per layer
+          quantise_x(Aq, L.q.a_quant, lane);
+          quantise_x(Ak, L.k.a_quant, lane);
+          quantise_x(Av, L.v.a_quant, lane);
+          lds_barrier();
         }
-      }
-      {  // V projection: K's buffer, re-quantised with V's multiplier
-        SLIMT_TPHASE_LANE;
-        lds_barrier();  // every wave has read the K operand
-        quantise_x(Akv, L.v.a_quant, lane);
-        lds_barrier();
+        // one projection after the other: its tile and constants are dead once it is done
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const int rt = rt0 + t;
-          const v4i cv = mma_rt(Akv, wv, rt, lane);
-          *reinterpret_cast<float4 *>(vb + (16 * rt + lr) * LDV + ctl * 16 + lg * 4) = tdequant4(cv, ev, L.v.u);
+          const v4i cq = mma_rt(Aq, wq, rt0 + t, lane);
+          *reinterpret_cast<float4 *>(qb + (16 * (rt0 + t) + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(cq, eq, L.q.u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const v4i ck = mma_rt(Ak, wk, rt0 + t, lane);
+          *reinterpret_cast<float4 *>(kb + (16 * (rt0 + t) + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(ck, ek, L.k.u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const v4i cv = mma_rt(Av, wv, rt0 + t, lane);
+          *reinterpret_cast<float4 *>(vb + (16 * (rt0 + t) + lr) * LDV + ctl * 16 + lg * 4) = tdequant4(cv, ev, L.v.u);
         }
       }
       lds_barrier();
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       {
         SLIMT_TPHASE_LANE;
         typedef float v4f __attribute__((ext_vector_type(4)));
-        char *Or = Ob + hr * TR * LDO;
+        char *Or = hr == 0 ? Ob0 : Ob1;
         const int n = lane & 15, g = lane >> 4;
         const float minus_inf = -99999999.0f;  // Input.cc:56-61
         const float lowest = -3.402823466e+38f;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         v4i c = {0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KSD; ++ks) {  // k-steps 0, 1: round 0's heads; 2, 3: round 1's
-          const v4i av = *reinterpret_cast<const v4i *>(Ob + (ks >> 1) * TR * LDO + (16 * rt + lr) * LDO + (ks & 1) * 64 + lg * 16);
+          const v4i av = *reinterpret_cast<const v4i *>((ks < 2 ? Ob0 : Ob1) + (16 * rt + lr) * LDO + (ks & 1) * 64 + lg * 16);
           c = __builtin_amdgcn_mfma_i32_16x16x64_i8(wo[ks], av, c, 0, 0, 0);
         }
         *reinterpret_cast<float4 *>(Yb + (16 * rt + lr) * LDY + wave * 16 + lg * 4) = tdequant4(c, eo, L.o.u);
@@ -637,7 +637,7 @@ size_t tall_encode_lds_bytes(int F) {
   const size_t region_qkv = (size_t)TR * (2 * (128 + 4) + (128 + 16)) * 4;
   const size_t region_h = (size_t)TR * (F + 16);
   const size_t region = region_qkv > region_h ? region_qkv : region_h;
-  return 2 * (size_t)TR * (256 + 16) + 2 * (size_t)TR * (128 + 16) + region;
+  return 3 * (size_t)TR * 256 + (size_t)TR * (128 + 16) + region;
 }
 
 bool tall_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
