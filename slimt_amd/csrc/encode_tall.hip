@@ -71,19 +71,24 @@ __device__ __forceinline__ float4 tdequant4(const v4i &c, const TEpi &e, float u
   v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
   return v;
 }
-// relu, then PrepareA with `aq`: four int8 in one register (the FFN's hidden layer)
+// relu, then PrepareA with `aq` (Intgemm.inl.cc:29-34): four int8 in one register (the FFN's hidden
+// layer). For aq > 0 (a quantisation multiplier is 127 / max|x|), clamp(rint(max(v, 0) * aq), -127,
+// 127) == clamp(rint(v * aq), 0, 127) for every float v: the product keeps the sign, rint(-0) and
+// rint(+0) both convert to 0, and a NaN falls to the lower bound of either form (maxNum / minNum
+// semantics) -- so the relu rides in the clamp, and v_cvt_pk_u8_f32 converts and packs the four
+// already integral values (exact under any rounding) in one instruction each.
 __device__ __forceinline__ int trelu_quant4(const v4i &c, const TEpi &e, float u, float aq) {
   const float4 v = tdequant4(c, e, u);
-  tf2 lo = {v.x > 0.0f ? v.x : 0.0f, v.y > 0.0f ? v.y : 0.0f};
-  tf2 hi = {v.z > 0.0f ? v.z : 0.0f, v.w > 0.0f ? v.w : 0.0f};
+  tf2 lo = {v.x, v.y}, hi = {v.z, v.w};
   const tf2 qq = {aq, aq};
   lo = lo * qq;
   hi = hi * qq;
-  float r[4] = {__builtin_rintf(lo.x), __builtin_rintf(lo.y), __builtin_rintf(hi.x), __builtin_rintf(hi.y)};
-  int q[4];
+  const float r[4] = {__builtin_rintf(lo.x), __builtin_rintf(lo.y), __builtin_rintf(hi.x), __builtin_rintf(hi.y)};
+  unsigned w = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) q[i] = (int)__builtin_fminf(__builtin_fmaxf(r[i], -127.0f), 127.0f);
-  return pack4(q[0], q[1], q[2], q[3]);
+  for (int i = 0; i < 4; ++i)
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(__builtin_fmaxf(r[i], 0.0f), 127.0f), i, w);
+  return (int)w;
 }
 
 // canonical LayerNorm of one row held in registers (v[i] = column lane + 64 i), in place
