@@ -123,7 +123,7 @@ def pmc_traffic(kernel, preset="tiny11"):
         if not files:
             return None, None
         rec = json.load(open(files[-1]))
-        rec = rec.get(kernel) or (rec.get("encode_wide") if kernel == "encode_fused" else None)
+        rec = rec.get(kernel) or ((rec.get("encode_tall") or rec.get("encode_wide")) if kernel == "encode_fused" else None)
         if not rec:
             return None, None
         out[c] = (rec["avg_KB_per_launch"] * 1024.0, os.path.basename(files[-1]))

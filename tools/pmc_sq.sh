@@ -19,7 +19,7 @@ import csv, sys, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    k = "decode_fused" if "decode_fused" in n else "encode_fused" if "encode_fused" in n else None
+    k = next((x for x in ("decode_fused", "encode_fused", "encode_tall", "encode_wide") if x in n), None)
     if k: agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(agg.items()):
     print(f"{k:14s} {c:28s} launches {len(v):3d} avg {sum(v)/len(v):.5g}")

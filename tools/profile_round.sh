@@ -26,7 +26,7 @@ agg = collections.defaultdict(list)
 for r in rows:
     if r["Counter_Name"] != sys.argv[2]: continue
     name = r["Kernel_Name"]
-    key = next((k for k in ("decode_fused", "encode_fused", "encode_wide") if k in name), None)
+    key = next((k for k in ("decode_fused", "encode_fused", "encode_tall", "encode_wide") if k in name), None)
     if key: agg[key].append(float(r["Counter_Value"]))
 out = {k: {"counter": sys.argv[2], "launches": len(v), "avg_KB_per_launch": sum(v) / len(v)} for k, v in agg.items()}
 json.dump(out, open(sys.argv[3], "w"), indent=1); print(out)
