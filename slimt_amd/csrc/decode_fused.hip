@@ -834,6 +834,130 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
       pack4(quantize1(o.x, r.aq_o), quantize1(o.y, r.aq_o), quantize1(o.z, r.aq_o), quantize1(o.w, r.aq_o));
 }
 
+// The same for D = 512, d_head 64 ("base"). At K = 512 the shifted accumulator needs 25 bits, so
+// the cache holds the SIGNED one (|acc| <= 127 * 128 * 512 < 2^23) and the column's 127 colsum term
+// comes back here: c127 = float(127 colsum * 256) is exact, and so is float(acc * 256) + c127
+// (= 256 accS, |accS| < 2^24) -- from there on the operations of `dequant`.
+__device__ __forceinline__ f4 unpack24c(int d0, int d1, int d2, float u256, f4 pb, f4 c127) {
+  const int y0 = d0 << 8;
+  const int y1 = (int)__builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x0504030cu);
+  const int y2 = (int)__builtin_amdgcn_perm((unsigned)d2, (unsigned)d1, 0x0403020cu);
+  const int y3 = d2 & (int)0xffffff00;
+  f2 a = {(float)y0, (float)y1}, b = {(float)y2, (float)y3};
+  const f2 ca = {c127.x, c127.y}, cb = {c127.z, c127.w};
+  a = a + ca;
+  b = b + cb;
+  const f2 uu = {u256, u256};
+  a = a * uu;
+  b = b * uu;
+  const f2 pa = {pb.x, pb.y}, pc = {pb.z, pb.w};
+  a = a + pa;
+  b = b + pc;
+  const f4 o = {a.x, a.y, b.x, b.y};
+  return o;
+}
+
+// kc: LDS constants of this layer, [K pb | K c127 | V pb | V c127][D]
+template <int KV_AUX>
+__device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr kc, float uk256, float uv256) {
+  constexpr int D = 512, DH = 64, H = D / DH;
+  const int S = r.S, len = r.len;
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int j = lane & 31;
+  const int jc = j < S ? j : S - 1;
+  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 3u);
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 3) >> 2) * (3 * (D / 4) * 16)));
+  const int koff = j < lenf ? jc * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
+  const int voff = lane * 16;                             // [S/4][plane][D/4][16 B]: slots lane and 64 + lane
+  auto group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g, int w) -> int {
+    const int d[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+    return d[3 * g + w];
+  };
+  const lcf_ptr kpb = kc, kcs = kc + D, vpb = kc + 2 * D, vcs = kc + 3 * D;
+#pragma unroll 1
+  for (int h = 0; h < H; ++h) {
+    v4i kq[12];  // this lane's key, the head's 64 columns: four chunks of three planes
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((12 * h + i) * S) * 16, KV_AUX));
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = h * DH + 16 * c + 4 * g;
+        const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
+        const f4 kk = unpack24c(group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 0), group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 1),
+                                group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 2), uk256, *(lcf4_ptr)(kpb + d0), *(lcf4_ptr)(kcs + d0));
+        s = __builtin_fmaf(q4.x, kk.x, s);
+        s = __builtin_fmaf(q4.y, kk.y, s);
+        s = __builtin_fmaf(q4.z, kk.z, s);
+        s = __builtin_fmaf(q4.w, kk.w, s);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one chunk's q / constant reads from LDS in flight
+    }
+    if (r.alpha != 1.0f) s = r.alpha * s;
+    s = s + mask;
+    if (j >= S) s = lowest;
+    const float m = half_max(s);
+    const float e = j < S ? exp_p(s - m) : 0.0f;
+    const float sum = half_sum(e);
+    const float p = e / sum;  // keys >= S: exactly 0
+    if (lane < 32) {
+      if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
+      if (r.align && h == 0 && j < len) r.align[j] = p;
+      r.pbuf[h * 32 + j] = p;
+    }
+  }
+  v4i vq[2][6];  // V rows in flight: two groups of four rows, two column slots of three planes each
+  auto load_v = [&](v4i(&vv)[6], int g) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      vv[p] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + p) * (D / 4) * 16, KV_AUX));
+      vv[3 + p] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + p) * (D / 4) * 16 + 1024, KV_AUX));
+    }
+  };
+  load_v(vq[0], 0);
+  load_v(vq[1], 1);
+  __builtin_amdgcn_sched_barrier(0);
+  const int ph0 = (lane >> 4) * 32, ph1 = (4 + (lane >> 4)) * 32;
+  const f4 pv0 = *(lcf4_ptr)(vpb + 4 * lane), pv1 = *(lcf4_ptr)(vpb + D / 2 + 4 * lane);
+  const f4 cv0 = *(lcf4_ptr)(vcs + 4 * lane), cv1 = *(lcf4_ptr)(vcs + D / 2 + 4 * lane);
+  f4 o0 = {0.0f, 0.0f, 0.0f, 0.0f}, o1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    v4i(&cur)[6] = vq[g % 2];
+    const f4 pa4 = *(lcf4_ptr)(r.pbuf + ph0 + 4 * g), pb4 = *(lcf4_ptr)(r.pbuf + ph1 + 4 * g);
+    const float pa[4] = {pa4.x, pa4.y, pa4.z, pa4.w}, pb_[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
+      const f4 v0 = unpack24c(group(cur[0], cur[1], cur[2], c, 0), group(cur[0], cur[1], cur[2], c, 1),
+                              group(cur[0], cur[1], cur[2], c, 2), uv256, pv0, cv0);
+      const f4 v1 = unpack24c(group(cur[3], cur[4], cur[5], c, 0), group(cur[3], cur[4], cur[5], c, 1),
+                              group(cur[3], cur[4], cur[5], c, 2), uv256, pv1, cv1);
+      o0.x = __builtin_fmaf(pa[c], v0.x, o0.x);
+      o0.y = __builtin_fmaf(pa[c], v0.y, o0.y);
+      o0.z = __builtin_fmaf(pa[c], v0.z, o0.z);
+      o0.w = __builtin_fmaf(pa[c], v0.w, o0.w);
+      o1.x = __builtin_fmaf(pb_[c], v1.x, o1.x);
+      o1.y = __builtin_fmaf(pb_[c], v1.y, o1.y);
+      o1.z = __builtin_fmaf(pb_[c], v1.z, o1.z);
+      o1.w = __builtin_fmaf(pb_[c], v1.w, o1.w);
+    }
+    // pin this group's sums here (see attention_row24)
+    asm volatile("" : "+v"(o0.x), "+v"(o0.y), "+v"(o0.z), "+v"(o0.w), "+v"(o1.x), "+v"(o1.y), "+v"(o1.z), "+v"(o1.w));
+    if (g + 2 < 8) load_v(vq[g % 2], g + 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+      pack4(quantize1(o0.x, r.aq_o), quantize1(o0.y, r.aq_o), quantize1(o0.z, r.aq_o), quantize1(o0.w, r.aq_o));
+  *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) =
+      pack4(quantize1(o1.x, r.aq_o), quantize1(o1.y, r.aq_o), quantize1(o1.z, r.aq_o), quantize1(o1.w, r.aq_o));
+}
+
 }  // namespace
 
 // Diagnostic phase stamps (100 MHz wall clock) of workgroup 0 at one chosen
@@ -859,7 +983,9 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
 // owns sentences w and w + 16 in the row-wise phases.
 template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
-  static_assert(!KV24 || (KSD == 4 && DH == 32 && !LONG), "the packed K/V cache: D = 256, d_head 32, S <= 32");
+  static_assert(!KV24 || (((KSD == 4 && DH == 32) || (KSD == 8 && DH == 64)) && !LONG),
+                "the packed K/V cache: D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32");
+  constexpr int KVC = KSD == 8 ? 4 : 2;  // constant vectors per layer in LDS (see attention_row24 / _64)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 64 * KSD, F = 64 * KSF;
   constexpr int R = 16 * RT;    // rows (sentences) per workgroup
@@ -893,7 +1019,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   int *red_i = reinterpret_cast<int *>(red_v + NW * R);
   int *flags = red_i + NW * R;  // [0] = number of finished sentences of this tile
   float *pbufs = reinterpret_cast<float *>(flags + 16);  // [NW][256] attention scratch
-  float *kvpb = pbufs + NW * 256;  // KV24: [Ld][K, V][D] prepared biases of the K / V projections
+  float *kvpb = pbufs + NW * 256;  // KV24: [Ld][K pb, V pb][D], or at D = 512 [Ld][K pb, K c127, V pb, V c127][D]
 
   // Which R sentences? With a ticket counter the grid is over-subscribed and the first
   // workgroups to START claim the tiles; the rest leave at once. A workgroup needs a whole
@@ -935,7 +1061,14 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   }
   if (tid == 0) flags[0] = 0;
   if constexpr (KV24) {
-    for (int i = tid; i < Ld * 2 * D; i += 1024) kvpb[i] = a.kv_pb[i / (2 * D)][(i / D) & 1][i % D];
+    if constexpr (KVC == 2) {
+      for (int i = tid; i < Ld * 2 * D; i += 1024) kvpb[i] = a.kv_pb[i / (2 * D)][(i / D) & 1][i % D];
+    } else {
+      for (int i = tid; i < Ld * 4 * D; i += 1024) {
+        const int l = i / (4 * D), v = (i / D) & 3, d = i % D;
+        kvpb[i] = (v & 1) ? (float)(__mul24(127, a.kv_cs[l][v >> 1][d]) * 256) : a.kv_pb[l][v >> 1][d];
+      }
+    }
   }
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
@@ -1084,7 +1217,13 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
           const bool want_align = a.align && (l + 1 == Ld) && !fin && (no < a.Tmax);
           ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + no) * S) : (gf_ptr) nullptr;
-          if constexpr (KV24) {
+          if constexpr (KV24 && KVC == 4) {
+            const lcf_ptr kc = (lcf_ptr)(kvpb + (4 * l) * D);
+            if (NT && l >= a.kv_temporal_layers)
+              attention_row24_64<2>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
+            else
+              attention_row24_64<0>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
+          } else if constexpr (KV24) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
             if (NT && l >= a.kv_temporal_layers)
               attention_row24<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
@@ -1267,7 +1406,7 @@ size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false)
   const bool lean = (size_t)D * R > 256 * 16;
   const size_t f32rows = lean ? 2 * R * (D + 4) * 4 : 3 * R * (D + 4) * 4 + (size_t)Ld * R * D * 4;
   return f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 + NW * 256 * 4 +
-         (kv24 ? (size_t)Ld * 2 * D * 4 : 0);
+         (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0);
 }
 
 bool fused_decode_supported(int D, int F, int H, int Ld) {
@@ -1298,9 +1437,18 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hi
   const int rows = fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg);
   const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, rows));
   const bool kv24 = a.kv24;
-  if (kv24 && !(D == 256 && D / H == 32 && a.S <= 32)) return hipErrorInvalidValue;
+  if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= 32)) return hipErrorInvalidValue;
   const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows, kv24);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (kv24 && D == 512) {
+    if (F != 2048) return hipErrorInvalidValue;
+    auto k = a.kv_nt ? decode_fused_kernel<8, 32, 64, false, true, 1, true> : decode_fused_kernel<8, 32, 64, false, false, 1, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
+    return hipGetLastError();
+  }
   if (kv24 && rows == 16) {
     auto k = a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true> : decode_fused_kernel<4, 24, 32, false, false, 1, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),

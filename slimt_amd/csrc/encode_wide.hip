@@ -61,6 +61,16 @@ __device__ __forceinline__ Epi4 load_epi4(const PreparedWeight &w, int tile, int
   return e;
 }
 
+// four 24-bit two's-complement integers, little endian, in 12 bytes (the packed K/V cache)
+typedef int wv3i __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ wv3i wpack24(v4i x) {
+  wv3i o;
+  o.x = (x.x & 0xffffff) | (x.y << 24);
+  o.y = ((x.y >> 8) & 0xffff) | (x.z << 16);
+  o.z = ((x.z >> 16) & 0xff) | (x.w << 8);
+  return o;
+}
+
 // canonical LayerNorm of one row held in registers (v[i] = column lane + 64 i), in place
 template <int DPL>
 __device__ __forceinline__ void ln_regs(float (&v)[DPL], const float (&scale)[DPL], const float (&bias)[DPL],
@@ -556,6 +566,12 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
         const int col = ct * 16 + lg * 4;
+        if (a.kv24) {  // the packed cache: SIGNED accumulators (K = 512: acc + 127 colsum needs 25 bits), staged
+          int *stg = reinterpret_cast<int *>(region);  // [WR][LDY] int32
+          *reinterpret_cast<v4i *>(stg + lr * LDY + col) = c0;
+          *reinterpret_cast<v4i *>(stg + (16 + lr) * LDY + col) = c1;
+          continue;
+        }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           const int rrow = rt * 16 + lr;
@@ -567,6 +583,49 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
             *reinterpret_cast<float4 *>(out + (chunk * S + rrow % S) * 4) = v;
           } else {
             *reinterpret_cast<float4 *>(out + ((size_t)row_sentence(rrow) * S + rrow % S) * D + col) = v;
+          }
+        }
+      }
+      if (a.kv24) {
+        // kernels.h, FusedDecodeArgs::kv24 -- here with the signed accumulator (the decoder adds the
+        // column's 127 colsum term): one thread = 16 values = 48 bytes = three 16-byte stores
+        lds_barrier();
+        const int *stg = reinterpret_cast<const int *>(region);
+        const int Sp = (S + 3) & ~3;
+        if (p == 0) {  // K [sentence][column / 16][plane][key][16 B]
+          const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * S * D * 3));
+          for (int it = tid; it < WR * (D / 16); it += 1024) {
+            const int r = it % WR, ci = it / WR;
+            if (!row_valid(r)) continue;
+            wv3i wd[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wd[g] = wpack24(*reinterpret_cast<const v4i *>(stg + r * LDY + 16 * ci + 4 * g));
+            const int off = row_sentence(r) * S * D * 3 + (ci * 3 * S + r % S) * 16;
+            const v4i p0 = {wd[0].x, wd[0].y, wd[0].z, wd[1].x}, p1 = {wd[1].y, wd[1].z, wd[2].x, wd[2].y},
+                      p2 = {wd[2].z, wd[3].x, wd[3].y, wd[3].z};
+            __builtin_amdgcn_raw_buffer_store_b128(p0, ro, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, ro, off + S * 16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p2, ro, off + 2 * S * 16, 0, 0);
+          }
+        } else {  // V [sentence][key / 4][plane][column / 4][16 B]: 4 keys x 4 columns, key-major
+          const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * Sp * D * 3));
+          for (int it = tid; it < spw * (Sp / 4) * (D / 4); it += 1024) {
+            const int cl = it % (D / 4), g = (it / (D / 4)) % (Sp / 4), si = (it / (D / 4)) / (Sp / 4);
+            if (s0 + si >= B) continue;
+            wv3i wd[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // keys past the sentence: zeros (finite once unpacked, weight 0)
+              const int key = 4 * g + i;
+              const v4i xv = *reinterpret_cast<const v4i *>(stg + (si * S + (key < S ? key : 0)) * LDY + 4 * cl);
+              const v4i z = {0, 0, 0, 0};
+              wd[i] = wpack24(key < S ? xv : z);
+            }
+            const int off = (((s0 + si) * (Sp / 4) + g) * 3 * (D / 4) + cl) * 16;
+            const v4i p0 = {wd[0].x, wd[0].y, wd[0].z, wd[1].x}, p1 = {wd[1].y, wd[1].z, wd[2].x, wd[2].y},
+                      p2 = {wd[2].z, wd[3].x, wd[3].y, wd[3].z};
+            __builtin_amdgcn_raw_buffer_store_b128(p0, ro, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, ro, off + (D / 4) * 16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p2, ro, off + 2 * (D / 4) * 16, 0, 0);
           }
         }
       }

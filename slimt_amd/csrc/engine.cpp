@@ -1241,9 +1241,10 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   const bool fused_dec = c->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld);
   const bool lean = fused_dec && (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                                   long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
-  // packed 24-bit K/V cache: fused encoder -> fused decoder, D = 256 / d_head 32 / S <= 32
+  // packed 24-bit K/V cache: fused encoder -> fused decoder, D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32
   // (V is cached in groups of four keys: S = 1, 2, 5 would not fit the f32 form's plane)
-  const bool kv24 = lean && m->kv_format == 0 && m->D == 256 && m->D / m->H == 32 && S <= 32 &&
+  const bool kv24 = lean && m->kv_format == 0 &&
+                    ((m->D == 256 && m->D / m->H == 32) || (m->D == 512 && m->D / m->H == 64 && m->F == 2048)) && S <= 32 &&
                     ((S + 3) & ~(size_t)3) * 3 <= S * 4 &&
                     fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
   DecodeState ds;
@@ -1309,6 +1310,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       const AffineW &wk = m->dec[(size_t)l].attn.k, &wv = m->dec[(size_t)l].attn.v;
       f.kv_pb[l][0] = wk.w.pb;
       f.kv_pb[l][1] = wv.w.pb;
+      f.kv_cs[l][0] = wk.w.colsum;
+      f.kv_cs[l][1] = wv.w.colsum;
       f.kv_u256[l][0] = wk.w.u * (1.0f / 256.0f);  // exact scalings: the cached integers come back
       f.kv_u256[l][1] = wv.w.u * (1.0f / 256.0f);  // as accS * 256 (decode_fused.hip, unpack24)
     }

@@ -261,9 +261,10 @@ struct FusedDecodeArgs {
   // of every launch takes one ticket; ticket - ticket_base is the tile it runs (or none).
   unsigned *ticket = nullptr;
   unsigned ticket_base = 0;
-  // Packed K/V cache (D = 256, d_head 32, S <= 32; written by encode_fused_kernel): every
-  // cached value is the int8 GEMM's shifted accumulator accS = acc + 127 colsum as a 24-bit
-  // integer (|accS| < 2^23 at K = 256); 16 values = 48 bytes = one 16-byte quad in each of
+  // Packed K/V cache (S <= 32; D = 256 / d_head 32 written by encode_fused / encode_tall, D = 512 /
+  // d_head 64 by encode_wide): every cached value is the int8 GEMM's accumulator as a 24-bit
+  // integer -- the shifted one, accS = acc + 127 colsum, at K = 256 (|accS| < 2^23), the signed
+  // one at K = 512 (accS needs 25 bits there; the decoder adds the column's term); 16 values = 48 bytes = one 16-byte quad in each of
   // three planes, so that loads stay 16 bytes per lane and contiguous across lanes:
   //   K [B][D/16][plane][S][16 B]             (16 consecutive columns of one key)
   //   V [B][ceil(S/4)][plane][D/4][16 B]      (4 keys x 4 consecutive columns, key-major)
@@ -272,6 +273,7 @@ struct FusedDecodeArgs {
   // bytes, load instructions and registers in flight.
   bool kv24 = false;
   const float *kv_pb[4][2] = {};  // [layer][K, V]: the projections' prepared biases [D]
+  const int *kv_cs[4][2] = {};    // [layer][K, V]: their column sums [D] (D = 512: the cache holds the signed accumulator)
   float kv_u256[4][2] = {};       // [layer][K, V]: unquantisation multiplier u / 256
   bool kv_nt = false;  // non-temporal K/V cache loads (d_head 32 / 64 shapes; see decode_fused.hip)
   int kv_temporal_layers = 0;  // with kv_nt: the first layers' caches are still read temporally
