@@ -1020,6 +1020,11 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   int *flags = red_i + NW * R;  // [0] = number of finished sentences of this tile
   float *pbufs = reinterpret_cast<float *>(flags + 16);  // [NW][256] attention scratch
   float *kvpb = pbufs + NW * 256;  // KV24: [Ld][K pb, V pb][D], or at D = 512 [Ld][K pb, K c127, V pb, V c127][D]
+  // LayerNorm scale / bias of every layer in LDS ([Ld][rnn, attn, ffn][scale, bias][D]) where it fits:
+  // fetched per phase they are vector-memory loads that return IN ORDER behind whatever the wave
+  // asked for before -- a weight prefetch in front of a LayerNorm would stall it by its whole transfer
+  constexpr bool LN_LDS = KSD == 4 && RT == 1;
+  float *lnc = kvpb + (KV24 ? 4 * KVC * D : 0);  // (Ld <= 4)
 
   // Which R sentences? With a ticket counter the grid is over-subscribed and the first
   // workgroups to START claim the tiles; the rest leave at once. A workgroup needs a whole
@@ -1060,6 +1065,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     for (int i = tid; i < Ld * R * D; i += 1024) cs[i] = 0.0f;
   }
   if (tid == 0) flags[0] = 0;
+  if constexpr (LN_LDS) {
+    for (int i = tid; i < Ld * 6 * D; i += 1024) {
+      const FusedLayerW &Lw = a.L[i / (6 * D)];
+      const int v = (i / D) % 6, d = i % D;
+      const float *src = v == 0 ? Lw.rnn_ln_s : v == 1 ? Lw.rnn_ln_b : v == 2 ? Lw.attn_ln_s : v == 3 ? Lw.attn_ln_b
+                         : v == 4 ? Lw.ffn_ln_s : Lw.ffn_ln_b;
+      lnc[i] = src[d];
+    }
+  }
   if constexpr (KV24) {
     if constexpr (KVC == 2) {
       for (int i = tid; i < Ld * 2 * D; i += 1024) kvpb[i] = a.kv_pb[i / (2 * D)][(i / D) & 1][i % D];
@@ -1174,7 +1188,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
       for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
-        ln_row<KSD>(pre + row * LDF, L.rnn_ln_s, L.rnn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
+        ln_row<KSD>(pre + row * LDF, LN_LDS ? lnc + (6 * l + 0) * D : L.rnn_ln_s, LN_LDS ? lnc + (6 * l + 1) * D : L.rnn_ln_b, a.eps,
+                    hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
       }
       lds_barrier();
       SLIMT_STAMP(sb + 2);
@@ -1255,17 +1270,22 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
                                            });
       lds_barrier();
       SLIMT_STAMP(sb + 5);
+      // FFN1's first chunks: ahead of the LayerNorm where its constants live in LDS (the LayerNorm
+      // then waits for no vector-memory load), else ahead of the barrier behind it
+      Frags f1[NB_FFN];
+      if constexpr (LN_LDS) stream_prologue<KSD, NB_FFN, NT_F1>(L.ffn1, wave, lane, f1);
 #pragma unroll
       for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
-        ln_row<KSD>(pre + row * LDF, L.attn_ln_s, L.attn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA,
-                    L.ffn1.a_quant, lane);
+        ln_row<KSD>(pre + row * LDF, LN_LDS ? lnc + (6 * l + 2) * D : L.attn_ln_s, LN_LDS ? lnc + (6 * l + 3) * D : L.attn_ln_b, a.eps,
+                    hs + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
       }
+      if constexpr (!LN_LDS) stream_prologue<KSD, NB_FFN, NT_F1>(L.ffn1, wave, lane, f1);
       lds_barrier();
       SLIMT_STAMP(sb + 6);
       // ---- FFN (Modules.cc:251-257) ----------------------------------------
-      stream_gemm<KSD, NB_FFN, NT_F1, false, RT>(
-          A1, LDA, L.ffn1, wave, lane, [&](int tile, int rt, const v4i &acc, int c1, float pb) {
+      stream_gemm_from<KSD, NB_FFN, NT_F1, false, RT>(
+          A1, LDA, L.ffn1, wave, lane, f1, [&](int tile, int rt, const v4i &acc, int c1, float pb) {
             const int col = tile * 16 + lr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1294,7 +1314,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
       for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
-        ln_row<KSD>(pre + row * LDF, L.ffn_ln_s, L.ffn_ln_b, a.eps, xs + row * LDF,
+        ln_row<KSD>(pre + row * LDF, LN_LDS ? lnc + (6 * l + 4) * D : L.ffn_ln_s, LN_LDS ? lnc + (6 * l + 5) * D : L.ffn_ln_b, a.eps, xs + row * LDF,
                     (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
       }
       // Between layers no barrier: the next phase (the SSRU's quantisation) reads and writes
@@ -1401,12 +1421,14 @@ int fused_decode_grid(int B, bool tickets, int rows) {
 }
 
 size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false) {
+  const size_t ln_lds = (D == 256 && rows == 16) ? (size_t)Ld * 6 * D * 4 : 0;  // LN_LDS in the kernel
+  const size_t kv_slots = kv24 ? (size_t)4 * (D == 512 ? 4 : 2) * D * 4 : 0;     // kvpb: room for 4 layers
   // D * rows > 256 * 16: two f32 row buffers, SSRU cells in global memory (see the kernel)
   const size_t R = (size_t)rows;
   const bool lean = (size_t)D * R > 256 * 16;
   const size_t f32rows = lean ? 2 * R * (D + 4) * 4 : 3 * R * (D + 4) * 4 + (size_t)Ld * R * D * 4;
   return f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 + NW * 256 * 4 +
-         (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0);
+         (ln_lds ? kv_slots : (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0)) + ln_lds;
 }
 
 bool fused_decode_supported(int D, int F, int H, int Ld) {
