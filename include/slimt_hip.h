@@ -158,8 +158,7 @@ int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
  * them), 1 = one launch per stage (and per decode step; the kernels behind
  * slimt_hip_decode_step), 2 / 3 = automatic, but the persistent decoder is
  * forced to 16 / 32 sentences per workgroup (tuning and tests; 0 picks by batch
- * size), 4 = 16 sentences on half-size workgroups, two per compute unit (emb 256
- * models, sources of up to 32 tokens; elsewhere like 2). Same results in every mode. */
+ * size). Same results in every mode. */
 int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode);
 /* Rows (source tokens) per workgroup of the persistent encoder for emb 256 models: 0
  * (default) = chosen per call (64-row tiles once the batch fills the device with them),

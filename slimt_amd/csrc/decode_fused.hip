@@ -44,7 +44,7 @@ namespace {
 #define SLIMT_NB_OUT 4
 #endif
 
-constexpr int NW16 = 16;  // waves per workgroup (default; the half-size workgroup has 8)
+constexpr int NW = 16;   // waves per workgroup
 constexpr int CH = 4;    // weight fragments per prefetch chunk (per wave)
 
 struct Frags {
@@ -95,7 +95,7 @@ __device__ __forceinline__ v4i load_frag(rsrc_t r, int voff, int soff) {
 // RT row tiles (16 RT rows of A): every weight fragment feeds RT MFMAs; epi(tile, rt, ...)
 // runs once per finished (column tile, row tile).
 // The stream's descriptors and this lane's offsets.
-template <int KS, int NT, int NW = NW16>
+template <int KS, int NT>
 struct StreamSrc {
   rsrc_t rw, rc, rp;
   int voff, eoff, n_tiles;
@@ -135,9 +135,9 @@ struct StreamSrc {
 // on the phase before, so a wave asks for them as soon as its own work in that phase is done
 // (or before it, where that pays) and the round trip runs under the barrier wait (lds_barrier
 // keeps global loads in flight).
-template <int KS, int NB, int NT = 0, bool PADDED = false, int NW = NW16>
+template <int KS, int NB, int NT = 0, bool PADDED = false>
 __device__ __forceinline__ void stream_prologue(const PreparedWeight &w, int wave, int lane, Frags (&b)[NB]) {
-  const StreamSrc<KS, NT, NW> src(w, lane);
+  const StreamSrc<KS, NT> src(w, lane);
   if constexpr (NT > 0) {
     constexpr int NCH = KS <= CH ? (NT + CH / KS - 1) / (CH / KS) : NT * (KS / CH);
 #pragma unroll
@@ -159,10 +159,10 @@ __device__ __forceinline__ void stream_prologue(const PreparedWeight &w, int wav
 }
 
 // The stream proper; b holds the chunks stream_prologue requested.
-template <int KS, int NB, int NT = 0, bool PADDED = false, int RT = 1, int NW = NW16, class Epi>
+template <int KS, int NB, int NT = 0, bool PADDED = false, int RT = 1, class Epi>
 __device__ __forceinline__ void stream_gemm_from(const char *A, int lda, const PreparedWeight &w, int wave,
                                                  int lane, Frags (&b)[NB], Epi &&epi) {
-  const StreamSrc<KS, NT, NW> src(w, lane);
+  const StreamSrc<KS, NT> src(w, lane);
   const int n_tiles = src.n_tiles;
   const int lr = lane & 15, lg = lane >> 4;
   const int ntw = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;  // my tiles
@@ -279,12 +279,12 @@ __device__ __forceinline__ void stream_gemm_from(const char *A, int lda, const P
   }
 }
 
-template <int KS, int NB, int NT = 0, bool PADDED = false, int RT = 1, int NW = NW16, class Epi>
+template <int KS, int NB, int NT = 0, bool PADDED = false, int RT = 1, class Epi>
 __device__ __forceinline__ void stream_gemm(const char *A, int lda, const PreparedWeight &w,
                                             int wave, int lane, Epi &&epi) {
   Frags b[NB];
-  stream_prologue<KS, NB, NT, PADDED, NW>(w, wave, lane, b);
-  stream_gemm_from<KS, NB, NT, PADDED, RT, NW>(A, lda, w, wave, lane, b, epi);
+  stream_prologue<KS, NB, NT, PADDED>(w, wave, lane, b);
+  stream_gemm_from<KS, NB, NT, PADDED, RT>(A, lda, w, wave, lane, b, epi);
 }
 
 // canonical LayerNorm of row `src` (LDS) by one wave -> dst (LDS f32) and,
@@ -979,19 +979,10 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
   (void)lg
 
 // RT = row tiles per workgroup: 1 (16 sentences) or 2 (32 sentences). Every streamed weight
-// fragment then feeds RT MFMAs (half the weight bytes per sentence and step at RT = 2).
-// NW = waves per workgroup: 16, or 8 -- the half-size workgroup: 16 sentences on 512 threads with the
-// lean LDS layout (< 80 KiB), so that TWO workgroups share a CU. They run out of step with each
-// other, and one streams weights / K/V through the CU's L2 path while the other is in a VALU
-// phase (LayerNorm, softmax, unpacking, sampling) -- what the 16 waves of one workgroup, in
-// lock-step between barriers, cannot do for each other. Wave w owns sentences w + NW rr,
-// rr < RPW = 16 RT / NW, in the row-wise phases.
-template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int NW = NW16>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void decode_fused_kernel(FusedDecodeArgs a) {
-  static_assert(NW == 16 || (NW == 8 && RT == 1 && KSD == 4), "half-size workgroups: 16 sentences at D = 256");
-  constexpr int NTH = NW * 64;        // threads
-  constexpr int RPW = 16 * RT / NW;   // sentences per wave in the row-wise phases
+// fragment then feeds RT MFMAs (half the weight bytes per sentence and step at RT = 2), wave w
+// owns sentences w and w + 16 in the row-wise phases.
+template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false>
+__global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   static_assert(!KV24 || (((KSD == 4 && DH == 32) || (KSD == 8 && DH == 64)) && !LONG),
                 "the packed K/V cache: D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32");
   constexpr int KVC = KSD == 8 ? 4 : 2;  // constant vectors per layer in LDS (see attention_row24 / _64)
@@ -1016,7 +1007,7 @@ void decode_fused_kernel(FusedDecodeArgs a) {
   // pre-LN buffer then aliases hs (every pre-LN write reads at most the same element of hs,
   // LayerNorm runs from registers) and the SSRU cells live in global memory (a.cells,
   // [Ld][B][D]; 1 KiB per sentence and layer, read and written once per step).
-  constexpr bool LEAN = KSD * RT > 4 || NW == 8;
+  constexpr bool LEAN = KSD * RT > 4;
   float *xs = reinterpret_cast<float *>(smem);  // layer input rows (post-LN); reused for q
   float *hs = xs + R * LDF;                     // h / o rows (post-LN residual source)
   float *pre = LEAN ? hs : hs + R * LDF;        // pre-LN accumulation
@@ -1032,7 +1023,7 @@ void decode_fused_kernel(FusedDecodeArgs a) {
   // LayerNorm scale / bias of every layer in LDS ([Ld][rnn, attn, ffn][scale, bias][D]) where it fits:
   // fetched per phase they are vector-memory loads that return IN ORDER behind whatever the wave
   // asked for before -- a weight prefetch in front of a LayerNorm would stall it by its whole transfer
-  constexpr bool LN_LDS = KSD == 4 && RT == 1 && NW == 16;
+  constexpr bool LN_LDS = KSD == 4 && RT == 1;
   float *lnc = kvpb + (KV24 ? 4 * KVC * D : 0);  // (Ld <= 4)
 
   // Which R sentences? With a ticket counter the grid is over-subscribed and the first
@@ -1053,12 +1044,12 @@ void decode_fused_kernel(FusedDecodeArgs a) {
   if (tid == 0) occ_trace_event(a.trace, 1, 0);
 
   // per-sentence state of rows wave + 16 rr, owned by wave `wave` (uniform within the wave)
-  int bq[RPW], len[RPW];
-  bool live[RPW], finished[RPW];
-  uint32_t n_out[RPW];
+  int bq[RT], len[RT];
+  bool live[RT], finished[RT];
+  uint32_t n_out[RT];
 #pragma unroll
-  for (int rr = 0; rr < RPW; ++rr) {
-    bq[rr] = m0 + NW * rr + wave;
+  for (int rr = 0; rr < RT; ++rr) {
+    bq[rr] = m0 + 16 * rr + wave;
     live[rr] = bq[rr] < B;
     len[rr] = live[rr] ? (int)a.lengths[bq[rr]] : 0;
     finished[rr] = !live[rr];
@@ -1069,13 +1060,13 @@ void decode_fused_kernel(FusedDecodeArgs a) {
   // start_states, Transformer.cc:78-85
   if constexpr (LEAN) {
     for (int l = 0; l < Ld; ++l)
-      for (int i = tid; i < valid_rows * D; i += NTH) a.cells[((size_t)l * B + m0) * D + i] = 0.0f;
+      for (int i = tid; i < valid_rows * D; i += 1024) a.cells[((size_t)l * B + m0) * D + i] = 0.0f;
   } else {
-    for (int i = tid; i < Ld * R * D; i += NTH) cs[i] = 0.0f;
+    for (int i = tid; i < Ld * R * D; i += 1024) cs[i] = 0.0f;
   }
   if (tid == 0) flags[0] = 0;
   if constexpr (LN_LDS) {
-    for (int i = tid; i < Ld * 6 * D; i += NTH) {
+    for (int i = tid; i < Ld * 6 * D; i += 1024) {
       const FusedLayerW &Lw = a.L[i / (6 * D)];
       const int v = (i / D) % 6, d = i % D;
       const float *src = v == 0 ? Lw.rnn_ln_s : v == 1 ? Lw.rnn_ln_b : v == 2 ? Lw.attn_ln_s : v == 3 ? Lw.attn_ln_b
@@ -1085,16 +1076,16 @@ void decode_fused_kernel(FusedDecodeArgs a) {
   }
   if constexpr (KV24) {
     if constexpr (KVC == 2) {
-      for (int i = tid; i < Ld * 2 * D; i += NTH) kvpb[i] = a.kv_pb[i / (2 * D)][(i / D) & 1][i % D];
+      for (int i = tid; i < Ld * 2 * D; i += 1024) kvpb[i] = a.kv_pb[i / (2 * D)][(i / D) & 1][i % D];
     } else {
-      for (int i = tid; i < Ld * 4 * D; i += NTH) {
+      for (int i = tid; i < Ld * 4 * D; i += 1024) {
         const int l = i / (4 * D), v = (i / D) & 3, d = i % D;
         kvpb[i] = (v & 1) ? (float)(__mul24(127, a.kv_cs[l][v >> 1][d]) * 256) : a.kv_pb[l][v >> 1][d];
       }
     }
   }
 #pragma unroll
-  for (int rr = 0; rr < RPW; ++rr) {
+  for (int rr = 0; rr < RT; ++rr) {
     if (live[rr]) {  // outputs past a sentence's length read as zero (no memset launches)
       for (int i = lane; i < a.Tmax; i += 64) a.out_ids[(size_t)bq[rr] * a.Tmax + i] = 0;
       if (a.align)
@@ -1104,7 +1095,7 @@ void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
     for (int i = 0; i < KSD; ++i) {
       const float z = 0.0f * a.emb.sqrt_d;
-      xs[(NW * rr + wave) * LDF + lane + 64 * i] = live[rr] ? z + a.emb.pos[lane + 64 * i] : 0.0f;
+      xs[(16 * rr + wave) * LDF + lane + 64 * i] = live[rr] ? z + a.emb.pos[lane + 64 * i] : 0.0f;
     }
   }
   __syncthreads();
@@ -1128,8 +1119,8 @@ void decode_fused_kernel(FusedDecodeArgs a) {
       // ---- SSRU (Modules.cc:190-235) ------------------------------------
       // quantise x twice (Wf / W have their own multipliers)
 #pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = NW * rr + wave;
+      for (int rr = 0; rr < RT; ++rr) {
+        const int row = 16 * rr + wave;
 #pragma unroll
         for (int i = 0; i < KSD; ++i) {
           const float v = xs[row * LDF + lane + 64 * i];
@@ -1193,10 +1184,10 @@ void decode_fused_kernel(FusedDecodeArgs a) {
       // h = LN(x + relu(c')), quantised for the Q projection (whose weight fragments are
       // requested now: their round trip runs under the LayerNorm and the barrier)
       Frags fq[1];
-      stream_prologue<KSD, 1, NT_D, false, NW>(L.q, wave, lane, fq);
+      stream_prologue<KSD, 1, NT_D>(L.q, wave, lane, fq);
 #pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = NW * rr + wave;
+      for (int rr = 0; rr < RT; ++rr) {
+        const int row = 16 * rr + wave;
         ln_row<KSD>(pre + row * LDF, LN_LDS ? lnc + (6 * l + 0) * D : L.rnn_ln_s, LN_LDS ? lnc + (6 * l + 1) * D : L.rnn_ln_b, a.eps,
                     hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
       }
@@ -1204,7 +1195,7 @@ void decode_fused_kernel(FusedDecodeArgs a) {
       SLIMT_STAMP(sb + 2);
       // ---- cross-attention (Modules.cc:287-319) --------------------------
       // Q projection -> xs (x is dead until the end of the layer)
-      stream_gemm_from<KSD, 1, NT_D, false, RT, NW>(A1, LDA, L.q, wave, lane, fq,
+      stream_gemm_from<KSD, 1, NT_D, false, RT>(A1, LDA, L.q, wave, lane, fq,
                                            [&](int tile, int rt, const v4i &acc, int cq, float pb) {
                                              const int col = tile * 16 + lr;
 #pragma unroll
@@ -1215,13 +1206,13 @@ void decode_fused_kernel(FusedDecodeArgs a) {
       SLIMT_STAMP(sb + 3);
       // SDPA over the cached K/V of this wave's sentence(s); output quantised into A1
 #pragma unroll 1
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = NW * rr + wave;
-        const bool lv = rr ? live[RPW - 1] : live[0];
+      for (int rr = 0; rr < RT; ++rr) {
+        const int row = 16 * rr + wave;
+        const bool lv = rr ? live[RT - 1] : live[0];
         if (lv) {
-          const int b = rr ? bq[RPW - 1] : bq[0];
-          const bool fin = rr ? finished[RPW - 1] : finished[0];
-          const int no = rr ? (int)n_out[RPW - 1] : (int)n_out[0];
+          const int b = rr ? bq[RT - 1] : bq[0];
+          const bool fin = rr ? finished[RT - 1] : finished[0];
+          const int no = rr ? (int)n_out[RT - 1] : (int)n_out[0];
           AttnRow ar;
           if constexpr (KV24) {  // same planes, 3 bytes per value
             ar.kl = (gcf_ptr)((const SLIMT_GLOBAL char *)(a.kv + (size_t)(2 * l) * B * S * D) + (size_t)EXP_SENT(b) * S * D * 3);
@@ -1235,7 +1226,7 @@ void decode_fused_kernel(FusedDecodeArgs a) {
           ar.arow = (lc_ptr)(A1 + row * LDA);
           ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * 256);
           ar.S = S;
-          ar.len = rr ? len[RPW - 1] : len[0];
+          ar.len = rr ? len[RT - 1] : len[0];
           ar.alpha = a.alpha;
           ar.aq_o = L.o.a_quant;
           ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
@@ -1263,11 +1254,11 @@ void decode_fused_kernel(FusedDecodeArgs a) {
         }
       }
       Frags fo[1];  // this wave's sentences are done: O's fragments travel under the barrier wait
-      stream_prologue<KSD, 1, NT_D, false, NW>(L.o, wave, lane, fo);
+      stream_prologue<KSD, 1, NT_D>(L.o, wave, lane, fo);
       lds_barrier();
       SLIMT_STAMP(sb + 4);
       // O projection + residual h (Modules.cc:308-314)
-      stream_gemm_from<KSD, 1, NT_D, false, RT, NW>(A1, LDA, L.o, wave, lane, fo,
+      stream_gemm_from<KSD, 1, NT_D, false, RT>(A1, LDA, L.o, wave, lane, fo,
                                            [&](int tile, int rt, const v4i &acc, int co, float pb) {
                                              const int col = tile * 16 + lr;
 #pragma unroll
@@ -1282,18 +1273,18 @@ void decode_fused_kernel(FusedDecodeArgs a) {
       // FFN1's first chunks: ahead of the LayerNorm where its constants live in LDS (the LayerNorm
       // then waits for no vector-memory load), else ahead of the barrier behind it
       Frags f1[NB_FFN];
-      if constexpr (LN_LDS) stream_prologue<KSD, NB_FFN, NT_F1, false, NW>(L.ffn1, wave, lane, f1);
+      if constexpr (LN_LDS) stream_prologue<KSD, NB_FFN, NT_F1>(L.ffn1, wave, lane, f1);
 #pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = NW * rr + wave;
+      for (int rr = 0; rr < RT; ++rr) {
+        const int row = 16 * rr + wave;
         ln_row<KSD>(pre + row * LDF, LN_LDS ? lnc + (6 * l + 2) * D : L.attn_ln_s, LN_LDS ? lnc + (6 * l + 3) * D : L.attn_ln_b, a.eps,
                     hs + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
       }
-      if constexpr (!LN_LDS) stream_prologue<KSD, NB_FFN, NT_F1, false, NW>(L.ffn1, wave, lane, f1);
+      if constexpr (!LN_LDS) stream_prologue<KSD, NB_FFN, NT_F1>(L.ffn1, wave, lane, f1);
       lds_barrier();
       SLIMT_STAMP(sb + 6);
       // ---- FFN (Modules.cc:251-257) ----------------------------------------
-      stream_gemm_from<KSD, NB_FFN, NT_F1, false, RT, NW>(
+      stream_gemm_from<KSD, NB_FFN, NT_F1, false, RT>(
           A1, LDA, L.ffn1, wave, lane, f1, [&](int tile, int rt, const v4i &acc, int c1, float pb) {
             const int col = tile * 16 + lr;
 #pragma unroll
@@ -1304,10 +1295,10 @@ void decode_fused_kernel(FusedDecodeArgs a) {
             }
           });
       Frags f2[NB_FFN];  // FFN2's first chunks: requested as this wave's FFN1 tiles are done
-      stream_prologue<KSF, NB_FFN, NT_D, false, NW>(L.ffn2, wave, lane, f2);
+      stream_prologue<KSF, NB_FFN, NT_D>(L.ffn2, wave, lane, f2);
       lds_barrier();
       SLIMT_STAMP(sb + 7);
-      stream_gemm_from<KSF, NB_FFN, NT_D, false, RT, NW>(
+      stream_gemm_from<KSF, NB_FFN, NT_D, false, RT>(
           A3, LDA3, L.ffn2, wave, lane, f2, [&](int tile, int rt, const v4i &acc, int c2, float pb) {
             const int col = tile * 16 + lr;
 #pragma unroll
@@ -1321,8 +1312,8 @@ void decode_fused_kernel(FusedDecodeArgs a) {
       SLIMT_STAMP(sb + 8);
       // next layer's input; after the last layer: quantised for the logits
 #pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = NW * rr + wave;
+      for (int rr = 0; rr < RT; ++rr) {
+        const int row = 16 * rr + wave;
         ln_row<KSD>(pre + row * LDF, LN_LDS ? lnc + (6 * l + 4) * D : L.ffn_ln_s, LN_LDS ? lnc + (6 * l + 5) * D : L.ffn_ln_b, a.eps, xs + row * LDF,
                     (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
       }
@@ -1334,7 +1325,7 @@ void decode_fused_kernel(FusedDecodeArgs a) {
     // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
     SLIMT_PHASE_LANE;
     Frags fl[NB_OUT];  // requested before the barrier that ends the last LayerNorm
-    stream_prologue<KSD, NB_OUT, 0, (KSD >= 4), NW>(outw, wave, lane, fl);
+    stream_prologue<KSD, NB_OUT, 0, (KSD >= 4)>(outw, wave, lane, fl);
     lds_barrier();
     float bv[RT][4];
     int bi[RT][4];
@@ -1345,7 +1336,7 @@ void decode_fused_kernel(FusedDecodeArgs a) {
         bv[rt][r] = -3.402823466e+38f;
         bi[rt][r] = 0x7fffffff;
       }
-    stream_gemm_from<KSD, NB_OUT, 0, (KSD >= 4), RT, NW>(
+    stream_gemm_from<KSD, NB_OUT, 0, (KSD >= 4), RT>(
         A1, LDA, outw, wave, lane, fl, [&](int tile, int rt, const v4i &acc, int co, float pb) {
           const int col = tile * 16 + lr;
           const bool in_range = col < outw.N;  // no branch: the streaming loop stays one block
@@ -1372,8 +1363,8 @@ void decode_fused_kernel(FusedDecodeArgs a) {
     SLIMT_STAMP(41);
     // wave w finishes sentences w (+ 16): reduce over the 16 waves' candidates
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int row = NW * rr + wave;
+    for (int rr = 0; rr < RT; ++rr) {
+      const int row = 16 * rr + wave;
       uint32_t tok = 0;
       {
         float v = lane < NW ? red_v[lane * R + row] : -3.402823466e+38f;
@@ -1409,7 +1400,7 @@ void decode_fused_kernel(FusedDecodeArgs a) {
     if (a.stamps && m0 == 0 && tid == 0 && t == a.stamp_step) a.stamps[61] = clock64();
   }
 #pragma unroll
-  for (int rr = 0; rr < RPW; ++rr)
+  for (int rr = 0; rr < RT; ++rr)
     if (live[rr] && lane == 0) a.out_len[bq[rr]] = n_out[rr];
   if (tid == 0) occ_trace_event(a.trace, 1, 1);
 }
@@ -1429,14 +1420,14 @@ int fused_decode_grid(int B, bool tickets, int rows) {
   return tickets ? tiles * (rows == 16 ? 2 : 4) : tiles;
 }
 
-size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false, int nw = NW16) {
-  // D * rows > 256 * 16 or half-size workgroups: two f32 row buffers, SSRU cells in global memory (see the kernel)
+size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false) {
+  const size_t ln_lds = (D == 256 && rows == 16) ? (size_t)Ld * 6 * D * 4 : 0;  // LN_LDS in the kernel
+  const size_t kv_slots = kv24 ? (size_t)4 * (D == 512 ? 4 : 2) * D * 4 : 0;     // kvpb: room for 4 layers
+  // D * rows > 256 * 16: two f32 row buffers, SSRU cells in global memory (see the kernel)
   const size_t R = (size_t)rows;
-  const bool lean = (size_t)D * R > 256 * 16 || nw == 8;
-  const size_t ln_lds = (D == 256 && rows == 16 && nw == NW16) ? (size_t)Ld * 6 * D * 4 : 0;  // LN_LDS in the kernel
-  const size_t kv_slots = kv24 ? (size_t)4 * (D == 512 ? 4 : 2) * D * 4 : 0;                  // kvpb: room for 4 layers
+  const bool lean = (size_t)D * R > 256 * 16;
   const size_t f32rows = lean ? 2 * R * (D + 4) * 4 : 3 * R * (D + 4) * 4 + (size_t)Ld * R * D * 4;
-  return f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * nw * R * 4 + 64 + (size_t)nw * 256 * 4 +
+  return f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 + NW * 256 * 4 +
          (ln_lds ? kv_slots : (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0)) + ln_lds;
 }
 
@@ -1469,19 +1460,6 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hi
   const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, rows));
   const bool kv24 = a.kv24;
   if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= 32)) return hipErrorInvalidValue;
-  if (a.waves == 8) {
-    // half-size workgroups (two per CU): the tiny11 shape, short sentences, 16 rows
-    if (!(D == 256 && F == 1536 && D / H == 32 && a.S <= 32 && rows == 16)) return hipErrorInvalidValue;
-    const size_t lds8 = fused_decode_lds_bytes(D, F, a.Ld, 16, kv24, 8);
-    if (lds8 > 80 * 1024) return hipErrorInvalidValue;
-    auto k = kv24 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 8> : decode_fused_kernel<4, 24, 32, false, false, 1, true, 8>)
-                  : (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, false, 8> : decode_fused_kernel<4, 24, 32, false, false, 1, false, 8>);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, dim3(512), lds8, st, a);
-    return hipGetLastError();
-  }
   const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows, kv24);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (kv24 && D == 512) {

@@ -757,7 +757,7 @@ extern "C" int slimt_hip_ctx_stream(slimt_hip_ctx *ctx, void **stream) {
 
 extern "C" int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode) {
   if (!ctx) return fail(-1, "ctx is NULL");
-  if (mode < 0 || mode > 4) return fail(-1, "bad decode mode %d", mode);
+  if (mode < 0 || mode > 3) return fail(-1, "bad decode mode %d", mode);
   ctx->decode_mode = mode;
   return 0;
 }
@@ -1289,10 +1289,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.B = (int)B; f.S = (int)S; f.Ld = m->Ld;
     f.max_steps = steps_hint > 0 ? steps_hint : (int)(Tmax > 1 ? Tmax : 1);
     f.Tmax = (int)Tmax;
-    f.rows_per_wg = (c->decode_mode == 2 || c->decode_mode == 4) ? 16 : c->decode_mode == 3 ? 32 : 0;
-    // mode 4: half-size workgroups, two per CU (the tiny11 shape, S <= 32; elsewhere mode 2)
-    const bool half_wg = c->decode_mode == 4 && m->D == 256 && m->F == 1536 && m->D / m->H == 32 && S <= 32;
-    f.waves = half_wg ? 8 : 16;
+    f.rows_per_wg = c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : 0;
     const int rows = fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, f.rows_per_wg);
     for (int l = 0; l < m->Ld; ++l) {
       const DecLayerW &L = m->dec[(size_t)l];
@@ -1348,8 +1345,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
         HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         gm->gate_ev.push_back(ev);
       }
-      // (the budget counts CUs: a half-size workgroup takes half of one)
-      size_t n = (size_t)std::max(1, gm->decoder_budget / (half_wg ? (wgs + 1) / 2 : wgs));
+      size_t n = (size_t)std::max(1, gm->decoder_budget / wgs);
       if (n > kRing) n = kRing;
       // K/V cache policy (decode_fused.hip, KV_AUX). The caches that are being read at any
       // moment are those of the decoders that run: at most one per context (a context is a

@@ -257,7 +257,6 @@ struct FusedDecodeArgs {
   unsigned long long *stamps = nullptr;  // nullable diagnostic [64] phase stamps
   int stamp_step = 0;
   int rows_per_wg = 0;  // 0 = auto, 16 / 32 = force (32 only where supported)
-  int waves = 16;       // 8 = half-size workgroups, two per CU (decode_fused.hip; D = 256, S <= 32, 16 rows)
   // nullable: ticket counter of the over-subscribed launch (16-row kernel). Every workgroup
   // of every launch takes one ticket; ticket - ticket_base is the tile it runs (or none).
   unsigned *ticket = nullptr;
