@@ -809,7 +809,7 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
   // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
   const int ph = (lane >> 3) * 32;
   const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
-  f4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};  // columns (0, 1) and (2, 3): v_pk_fma_f32 is one fma per column
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     v4i(&cur)[3] = vq[g % 3];
@@ -818,20 +818,19 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
 #pragma unroll
     for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
       const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c, uv256, pv4);
-      o.x = __builtin_fmaf(pj[c], v4.x, o.x);
-      o.y = __builtin_fmaf(pj[c], v4.y, o.y);
-      o.z = __builtin_fmaf(pj[c], v4.z, o.z);
-      o.w = __builtin_fmaf(pj[c], v4.w, o.w);
+      const f2 pp = {pj[c], pj[c]}, va = {v4.x, v4.y}, vb = {v4.z, v4.w};
+      oa = __builtin_elementwise_fma(pp, va, oa);
+      ob = __builtin_elementwise_fma(pp, vb, ob);
     }
     // pin this group's sums here: the unpack + fma chains are pure arithmetic, and without a use
     // the optimiser sinks all eight groups' work below the last load -- 96 registers of packed
     // rows live at once (seen as 134 spilled VGPRs)
-    asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
+    asm volatile("" : "+v"(oa), "+v"(ob));
     if (g + 3 < 8) load_v(vq[g % 3], g + 3);
     __builtin_amdgcn_sched_barrier(0);
   }
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1(o.x, r.aq_o), quantize1(o.y, r.aq_o), quantize1(o.z, r.aq_o), quantize1(o.w, r.aq_o));
+      pack4(quantize1(oa.x, r.aq_o), quantize1(oa.y, r.aq_o), quantize1(ob.x, r.aq_o), quantize1(ob.y, r.aq_o));
 }
 
 // The same for D = 512, d_head 64 ("base"). At K = 512 the shifted accumulator needs 25 bits, so
@@ -926,7 +925,7 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
   const int ph0 = (lane >> 4) * 32, ph1 = (4 + (lane >> 4)) * 32;
   const f4 pv0 = *(lcf4_ptr)(vpb + 4 * lane), pv1 = *(lcf4_ptr)(vpb + D / 2 + 4 * lane);
   const f4 cv0 = *(lcf4_ptr)(vcs + 4 * lane), cv1 = *(lcf4_ptr)(vcs + D / 2 + 4 * lane);
-  f4 o0 = {0.0f, 0.0f, 0.0f, 0.0f}, o1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  f2 o0a = {0.0f, 0.0f}, o0b = {0.0f, 0.0f}, o1a = {0.0f, 0.0f}, o1b = {0.0f, 0.0f};  // column pairs: one v_pk_fma_f32 each
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     v4i(&cur)[6] = vq[g % 2];
@@ -938,24 +937,21 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
                               group(cur[0], cur[1], cur[2], c, 2), uv256, pv0, cv0);
       const f4 v1 = unpack24c(group(cur[3], cur[4], cur[5], c, 0), group(cur[3], cur[4], cur[5], c, 1),
                               group(cur[3], cur[4], cur[5], c, 2), uv256, pv1, cv1);
-      o0.x = __builtin_fmaf(pa[c], v0.x, o0.x);
-      o0.y = __builtin_fmaf(pa[c], v0.y, o0.y);
-      o0.z = __builtin_fmaf(pa[c], v0.z, o0.z);
-      o0.w = __builtin_fmaf(pa[c], v0.w, o0.w);
-      o1.x = __builtin_fmaf(pb_[c], v1.x, o1.x);
-      o1.y = __builtin_fmaf(pb_[c], v1.y, o1.y);
-      o1.z = __builtin_fmaf(pb_[c], v1.z, o1.z);
-      o1.w = __builtin_fmaf(pb_[c], v1.w, o1.w);
+      const f2 ppa = {pa[c], pa[c]}, ppb = {pb_[c], pb_[c]};
+      o0a = __builtin_elementwise_fma(ppa, f2{v0.x, v0.y}, o0a);
+      o0b = __builtin_elementwise_fma(ppa, f2{v0.z, v0.w}, o0b);
+      o1a = __builtin_elementwise_fma(ppb, f2{v1.x, v1.y}, o1a);
+      o1b = __builtin_elementwise_fma(ppb, f2{v1.z, v1.w}, o1b);
     }
     // pin this group's sums here (see attention_row24)
-    asm volatile("" : "+v"(o0.x), "+v"(o0.y), "+v"(o0.z), "+v"(o0.w), "+v"(o1.x), "+v"(o1.y), "+v"(o1.z), "+v"(o1.w));
+    asm volatile("" : "+v"(o0a), "+v"(o0b), "+v"(o1a), "+v"(o1b));
     if (g + 2 < 8) load_v(vq[g % 2], g + 2);
     __builtin_amdgcn_sched_barrier(0);
   }
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1(o0.x, r.aq_o), quantize1(o0.y, r.aq_o), quantize1(o0.z, r.aq_o), quantize1(o0.w, r.aq_o));
+      pack4(quantize1(o0a.x, r.aq_o), quantize1(o0a.y, r.aq_o), quantize1(o0b.x, r.aq_o), quantize1(o0b.y, r.aq_o));
   *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) =
-      pack4(quantize1(o1.x, r.aq_o), quantize1(o1.y, r.aq_o), quantize1(o1.z, r.aq_o), quantize1(o1.w, r.aq_o));
+      pack4(quantize1(o1a.x, r.aq_o), quantize1(o1a.y, r.aq_o), quantize1(o1b.x, r.aq_o), quantize1(o1b.y, r.aq_o));
 }
 
 }  // namespace
