@@ -212,22 +212,21 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   // side job: the batch's shortlisted output layer (used by the decoder launch behind this one)
   for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
 
-  // A round's projection is 8 column tiles x 4 row tiles: wave = (tile w % 8, row tiles 2 (w / 8),
-  // 2 (w / 8) + 1) -- a weight tile is fetched by two waves. The Q and K tiles are requested a phase ahead: under the last
-  // LayerNorm of the layer before (round 0) or under the quantisation of x (round 1).
-  v4i wq[KSD], wk[KSD];
-  auto load_qk = [&](const FusedEncLayerW &Lw, int hr, int lane) {
+  // A round's projections are 3 x 8 column tiles (Q, K, V of four heads) x 4 row tiles on 16 waves:
+  // waves 0..7 take Q tile w and V tile w, waves 8..15 K tile w - 8, all four row tiles each -- every
+  // weight tile crosses the L2 path once. The first tile (Q or K) is requested a phase ahead: under
+  // the last LayerNorm of the layer before (round 0) or at the top of round 1.
+  v4i w1[KSD];
+  auto load_first = [&](const FusedEncLayerW &Lw, int hr, int lane) {
+    const PreparedWeight &W = wave < 8 ? Lw.q : Lw.k;
     const int ct = hr * (RC / 16) + (wave & 7);
-    const rsrc_t rq = trsrc(Lw.q.Wp, (unsigned)Lw.q.n_tiles * KSD * 1024u), rk = trsrc(Lw.k.Wp, (unsigned)Lw.k.n_tiles * KSD * 1024u);
+    const rsrc_t rw = trsrc(W.Wp, (unsigned)W.n_tiles * KSD * 1024u);
 #pragma unroll
-    for (int ks = 0; ks < KSD; ++ks) {
-      wq[ks] = tload(rq, lane * 16, (ct * KSD + ks) * 1024);
-      wk[ks] = tload(rk, lane * 16, (ct * KSD + ks) * 1024);
-    }
+    for (int ks = 0; ks < KSD; ++ks) w1[ks] = tload(rw, lane * 16, (ct * KSD + ks) * 1024);
   };
   {
     SLIMT_TPHASE_LANE;
-    load_qk(a.L[0], 0, lane);
+    load_first(a.L[0], 0, lane);
   }
 
   // ---- embedding (Model.cc:195-197) into the owner's registers ------------------------------
@@ -286,17 +285,22 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     // ---- Attention::forward (Modules.cc:287-319), four heads per round -----------------------
 #pragma unroll
     for (int hr = 0; hr < NR; ++hr) {
-      const int ctl = wave & 7, rt0 = 2 * (wave >> 3);
+      const int ctl = wave & 7;
       const int ct = hr * (RC / 16) + ctl;
       {  // Q, K, V projections of this round's heads
         SLIMT_TPHASE_LANE;
-        if (hr > 0) {  // (held through the attention they would spill: requested under the barrier wait)
-          load_qk(L, hr, lane);
+        if (hr > 0) {
+          load_first(L, hr, lane);
           __builtin_amdgcn_sched_barrier(0);
         }
+        const bool qv = wave < 8;  // this wave: Q and V tiles, else the K tile
+        const PreparedWeight &W1 = qv ? L.q : L.k;
+        const TEpi e1 = tload_epi(W1, ct, lg);
+        // V's tile: loaded by every wave (an unconditional definition keeps its registers out of the
+        // K waves' way; their copy is never used, its 8 redundant fetches hit in L2)
         v4i wv[KSD];
         load_w(wv, L.v, ct, lane);
-        const TEpi eq = tload_epi(L.q, ct, lg), ek = tload_epi(L.k, ct, lg), ev = tload_epi(L.v, ct, lg);
+        const TEpi ev = tload_epi(L.v, ct, lg);
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();  // the region is free; round 0: so are the A buffers
         if (hr == 0) {  // x quantised with the three projections' multipliers, once per layer
@@ -305,23 +309,20 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           quantise_x(Av, L.v.a_quant, lane);
           lds_barrier();
         }
-        // one projection after the other: its tile and constants are dead once it is done
+        const char *A1 = qv ? Aq : Ak;
+        float *dst1 = qv ? qb : kb;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const v4i cq = mma_rt(Aq, wq, rt0 + t, lane);
-          *reinterpret_cast<float4 *>(qb + (16 * (rt0 + t) + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(cq, eq, L.q.u);
+        for (int rt = 0; rt < TRT; ++rt) {
+          const v4i c = mma_rt(A1, w1, rt, lane);
+          *reinterpret_cast<float4 *>(dst1 + (16 * rt + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(c, e1, W1.u);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (qv) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const v4i ck = mma_rt(Ak, wk, rt0 + t, lane);
-          *reinterpret_cast<float4 *>(kb + (16 * (rt0 + t) + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(ck, ek, L.k.u);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const v4i cv = mma_rt(Av, wv, rt0 + t, lane);
-          *reinterpret_cast<float4 *>(vb + (16 * (rt0 + t) + lr) * LDV + ctl * 16 + lg * 4) = tdequant4(cv, ev, L.v.u);
+          for (int rt = 0; rt < TRT; ++rt) {
+            const v4i cv = mma_rt(Av, wv, rt, lane);
+            *reinterpret_cast<float4 *>(vb + (16 * rt + lr) * LDV + ctl * 16 + lg * 4) = tdequant4(cv, ev, L.v.u);
+          }
         }
       }
       lds_barrier();
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       const TEpi e2 = tload_epi(L.ffn2, wave, lg);
       // the next layer's first Q / K tiles: under the LayerNorm (unconditional, so that the
       // registers are dead between the projections and here)
-      load_qk(a.L[l + 1 < a.Le ? l + 1 : l], 0, lane);
+      load_first(a.L[l + 1 < a.Le ? l + 1 : l], 0, lane);
       __builtin_amdgcn_sched_barrier(0);
       lds_barrier();  // every wave has read the hidden layer: the region becomes the exchange tile
       SLIMT_TSTAMP(8);
