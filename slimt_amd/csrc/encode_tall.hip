@@ -1,6 +1,6 @@
 // Persistent fused encoder for D = 256 (tiny11: 8 heads of 32) on 64-row tiles: embedding + all
 // encoder layers + the decoder's cross-attention K/V cache in ONE launch, 64 rows
-// (= floor(64 / S) whole sentences, S <= 32) per workgroup.
+// (= floor(64 / S) whole sentences for S <= 32, one sentence of 33..64 tokens) per workgroup.
 //
 // encode_fused.hip keeps 32 rows per workgroup with everything resident in LDS; every workgroup
 // then streams the layer's 1.05 MB of weights for 32 rows, and the CU's L2 path (64 B/clk) is
@@ -150,7 +150,10 @@ __device__ __forceinline__ v3i tpack24(v4i x) {
       a.stamps[(id)] = wall_clock64();                                                \
   } while (0)
 
-template <int KSF>
+// NKT = key tiles of 16 per sentence: 2 (S <= 32, floor(64 / S) sentences per workgroup) or 4
+// (33 <= S <= 64: one sentence per workgroup -- what encode_long16_kernel does through global
+// scratch tensors stays in LDS here).
+template <int KSF, int NKT = 2>
 __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KSD = 4, D = 256, DH = 32, F = 64 * KSF;
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         const int n = lane & 15, g = lane >> 4;
         const float minus_inf = -99999999.0f;  // Input.cc:56-61
         const float lowest = -3.402823466e+38f;
-        const int nqh = S > 16 ? 2 : 1;  // 16-query halves of a sentence
+        const int nqh = (S + 15) >> 4;  // 16-query tiles of a sentence
         for (int job = wave; job < spw * HR * nqh; job += TNW) {
           const int qh = job % nqh, hl = (job / nqh) % HR, sl = job / (nqh * HR);
           const int sb = s0 + sl;
@@ -347,9 +350,9 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           const int len = (int)a.lengths[sb];
           const int qr = 16 * qh + n;
           const float *qp = qb + (base + (qr < S ? qr : S - 1)) * LDQ + hl * DH + g;
-          float sc[2][4];
+          float sc[NKT][4];
 #pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
+          for (int kt = 0; kt < NKT; ++kt) {
             const int kr = 16 * kt + n;
             const float *kp = kb + (base + (kr < S ? kr : S - 1)) * LDQ + hl * DH + g;
             v4f st = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -365,21 +368,26 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
               sc[kt][r] = v;
             }
           }
-          float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
-                           fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+          float mx = lowest;
+#pragma unroll
+          for (int kt = 0; kt < NKT; ++kt)
+            mx = fmaxf(mx, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
           mx = bf_max<32>(bf_max<16>(mx));
 #pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
+          for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * g + r) < S ? exp_p(sc[kt][r] - mx) : 0.0f;
-          float t[2];
+          // the canonical butterfly over the key index 16 kt + 4 g + r: masks 1, 2 inside the four
+          // registers, 4 and 8 across lane groups, 16 and 32 across the key tiles
+          float t[NKT];
 #pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
-            t[kt] = bf_add<32>(bf_add<16>((sc[kt][0] + sc[kt][1]) + (sc[kt][2] + sc[kt][3])));  // masks 1, 2 | 4 | 8
-          const float sum = t[0] + t[1];                                                          // mask 16
-          float pa[2][4];  // pa[kt][j] on lane (n, g) = P[query n][key 16 kt + 4 j + g]
+          for (int kt = 0; kt < NKT; ++kt)
+            t[kt] = bf_add<32>(bf_add<16>((sc[kt][0] + sc[kt][1]) + (sc[kt][2] + sc[kt][3])));
+          float sum = t[0] + t[1];
+          if constexpr (NKT == 4) sum = sum + (t[2] + t[3]);
+          float pa[NKT][4];  // pa[kt][j] on lane (n, g) = P[query n][key 16 kt + 4 j + g]
 #pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
+          for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) sc[kt][r] = sc[kt][r] / sum;  // keys >= S: exactly 0
             const slimt_u2 s01 = __builtin_amdgcn_permlane16_swap(__float_as_int(sc[kt][0]), __float_as_int(sc[kt][1]), false, false);
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
             const int dcol = hl * DH + 16 * nt + n;  // column inside the round
             v4f o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4) {  // keys >= S contribute fma(0, v, o) == o
+            for (int s4 = 0; s4 < 4 * NKT; ++s4) {  // keys >= S contribute fma(0, v, o) == o
               const int key = 4 * s4 + g;
               const float vv = vb[(base + (key < S ? key : S - 1)) * LDV + dcol];
               o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4 >> 2][s4 & 3], vv, o, 0, 0, 0);
@@ -647,8 +655,8 @@ size_t tall_encode_lds_bytes(int F) {
 }
 
 bool tall_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
-  if (S < 1 || S > 32 || Le < 1 || Le > 6 || Ld < 1 || Ld > 4) return false;
-  if (D != 256 || H != 8) return false;
+  if (S < 1 || S > TR || Le < 1 || Le > 6 || Ld < 1 || Ld > 4) return false;  // S <= 32: several sentences per
+  if (D != 256 || H != 8) return false;                                      // workgroup; 33..64: one
   if (F != 1536 && F != 1024) return false;  // (F = 2048: the hidden layer of 64 rows does not fit the region)
   return tall_encode_lds_bytes(F) <= 160 * 1024;
 }
@@ -668,7 +676,7 @@ hipError_t launch_encode_tall(const FusedEncodeArgs &a, int F, hipStream_t st) {
   hipError_t e = hipSuccess;
 #define SLIMT_TALL_CASE(KSF_)                                                                  \
   if (F == 64 * KSF_) {                                                                        \
-    auto k = encode_tall_kernel<KSF_>;                                                         \
+    auto k = a.S > 32 ? encode_tall_kernel<KSF_, 4> : encode_tall_kernel<KSF_, 2>;             \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                                 \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
     if (e != hipSuccess) return e;                                                             \

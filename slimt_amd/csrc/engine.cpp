@@ -905,7 +905,10 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
   c->have_encoder_out = false;
   c->decode_ready = false;
   c->kv_ready = false;
-  if (!embedded && c->decode_mode != 1 && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
+  // sentences of 33..64 tokens: the 64-row D = 256 encoder takes one per workgroup (else the
+  // per-sentence kernel below)
+  const bool tall_mid = S > 32 && c->encode_rows != 32 && tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S);
+  if (!embedded && c->decode_mode != 1 && (tall_mid || fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S))) {
     // embedding + every encoder layer + the decoder's K/V cache in one launch
     FusedEncodeArgs f;
     f.B = B; f.S = S; f.Le = m->Le; f.Ld = m->Ld;
@@ -951,8 +954,8 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     // D = 256: 64-row tiles (encode_tall.hip: the O projection's and the FFN's weights cross the
     // CU's L2 path once per 64 rows) once the batch fills the chip with them -- below that, twice
     // as many 32-row workgroups finish a lone batch sooner
-    const bool tall = tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S) &&
-                      (c->encode_rows == 64 || (c->encode_rows == 0 && tall_encode_grid(B, S, false) >= 96));
+    const bool tall = tall_mid || (tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S) &&
+                                   (c->encode_rows == 64 || (c->encode_rows == 0 && tall_encode_grid(B, S, false) >= 96)));
     {
       const double macs = (double)M * (m->Le * (4.0 * D * D + 2.0 * D * m->F) + m->Ld * 2.0 * D * D);
       ProfScope p(c, SLIMT_HIP_K_ENCODE_FUSED, macs, 0);

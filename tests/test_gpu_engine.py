@@ -411,6 +411,38 @@ def test_tall_encoder_every_layer_and_translate_bit_exact(hip, oracle, engines, 
         ctx.close()
 
 
+@pytest.mark.parametrize("B,S", [(3, 33), (17, 40), (5, 48), (20, 49), (9, 63), (33, 64)])
+def test_tall_encoder_medium_sentences_bit_exact(hip, oracle, engines, B, S):
+    """Sentences of 33..64 tokens: one per workgroup of the 64-row encoder (four key tiles, three
+    or four 16-query tiles; the 64-column softmax in the canonical butterfly order) against the
+    oracle layer by layer and through translate; forcing 32-row tiles falls back to the
+    per-sentence kernel, with the same results."""
+    from slimt_amd import synth
+    m, gm, om = engines("tiny11", 6.0)
+    ids, lens = synth.make_batch(m.V, B, S, seed=6100 + 64 * B + S, ragged=True)
+    oracle.set_mode(oracle.PORTABLE)
+    mask = oracle.make_mask(lens, S)
+    want = [om.embed(ids)]
+    for l in range(1, m.enc_layers + 1):
+        want.append(om.encoder_layer(l, want[-1], mask))
+    sl = synth.make_shortlist(m.V, 640)
+    want_t = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+    oracle.set_mode(oracle.FAITHFUL)
+    ctx = hip.Context(gm, B, S)
+    try:
+        for rows in (0, 32):
+            ctx.set_encode_rows(rows)
+            enc, emb, layers = ctx.encode(ids, lens, want_embed=True, want_layers=True)
+            assert np.array_equal(emb, want[0]), rows
+            for l in range(1, m.enc_layers + 1):
+                assert np.array_equal(layers[l - 1], want[l]), (rows, l, np.abs(layers[l - 1] - want[l]).max())
+            assert np.array_equal(enc, want[-1]), rows
+            got = ctx.translate(ids, lens, sl, want_align=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want_t)), rows
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("budget", [0, 1, 3, 1000])
 def test_decoder_admission_and_ticket_launches_keep_results(hip, oracle, engines, budget):
     """Concurrent contexts of one model under every decoder budget (0 = no limit, 1 = one
