@@ -833,6 +833,100 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
       pack4(quantize1(oa.x, r.aq_o), quantize1(oa.y, r.aq_o), quantize1(ob.x, r.aq_o), quantize1(ob.y, r.aq_o));
 }
 
+// Sentences of 33..64 tokens over the packed cache (written by encode_tall_kernel<., 4>): lane =
+// key, one head per score pass (8 passes of 6 K loads), the 64-column softmax in the canonical
+// order (one element per lane, the 64-lane butterfly), all heads' probabilities in LDS
+// (pbuf: [H][64]), then V as whole rows, 4 keys per three loads, like the S <= 32 form.
+template <int KV_AUX>
+__device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256,
+                                                    float uv256) {
+  constexpr int D = 256, DH = 32, H = D / DH;
+  const int S = r.S, len = r.len;
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int j = lane;
+  const int jc = j < S ? j : S - 1;
+  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 3u);
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 3) >> 2) * 3072));
+  const int koff = j < lenf ? jc * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
+  const int voff = lane * 16;                             // [S/4][plane][D/4][16 B]
+  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g, float u256, f4 pb) -> f4 {
+    const int w[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+    return unpack24(w[3 * g], w[3 * g + 1], w[3 * g + 2], u256, pb);
+  };
+  v4i kq[6];
+  auto load_k = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((6 * h + i) * S) * 16, KV_AUX));
+  };
+  load_k(0);
+#pragma unroll 1
+  for (int h = 0; h < H; ++h) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = h * DH + 16 * c + 4 * g;
+        const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
+        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, uk256, *(lcf4_ptr)(pbk + d0));
+        s = __builtin_fmaf(q4.x, kk.x, s);
+        s = __builtin_fmaf(q4.y, kk.y, s);
+        s = __builtin_fmaf(q4.z, kk.z, s);
+        s = __builtin_fmaf(q4.w, kk.w, s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_k(h + 1 < H ? h + 1 : h);  // the next head's keys travel under this head's softmax
+    __builtin_amdgcn_sched_barrier(0);
+    if (r.alpha != 1.0f) s = r.alpha * s;
+    s = s + mask;
+    if (j >= S) s = lowest;
+    const float m = wave_max(s);
+    const float e = j < S ? exp_p(s - m) : 0.0f;
+    const float sum = wave_sum(e);
+    const float p = e / sum;  // keys >= S: exactly 0
+    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
+    if (r.align && h == 0 && j < len) r.align[j] = p;
+    r.pbuf[h * 64 + j] = p;
+  }
+  v4i vq[3][3];  // V rows in flight: three groups of four rows (three planes each)
+  auto load_v = [&](v4i(&vv)[3], int g) {  // rows 4 g .. 4 g + 3
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + i) * 1024, KV_AUX));
+  };
+  load_v(vq[0], 0);
+  load_v(vq[1], 1);
+  load_v(vq[2], 2);
+  __builtin_amdgcn_sched_barrier(0);
+  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
+  const int ph = (lane >> 3) * 64;
+  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    v4i(&cur)[3] = vq[g % 3];
+    const f4 p4 = *(lcf4_ptr)(r.pbuf + ph + 4 * g);
+    const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
+      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c, uv256, pv4);
+      const f2 pp = {pj[c], pj[c]}, va = {v4.x, v4.y}, vb = {v4.z, v4.w};
+      oa = __builtin_elementwise_fma(pp, va, oa);
+      ob = __builtin_elementwise_fma(pp, vb, ob);
+    }
+    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
+    if (g + 3 < 16) load_v(vq[g % 3], g + 3);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+      pack4(quantize1(oa.x, r.aq_o), quantize1(oa.y, r.aq_o), quantize1(ob.x, r.aq_o), quantize1(ob.y, r.aq_o));
+}
+
 // The same for D = 512, d_head 64 ("base"). At K = 512 the shifted accumulator needs 25 bits, so
 // the cache holds the SIGNED one (|acc| <= 127 * 128 * 512 < 2^23) and the column's 127 colsum term
 // comes back here: c127 = float(127 colsum * 256) is exact, and so is float(acc * 256) + c127
@@ -977,10 +1071,13 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
 // RT = row tiles per workgroup: 1 (16 sentences) or 2 (32 sentences). Every streamed weight
 // fragment then feeds RT MFMAs (half the weight bytes per sentence and step at RT = 2), wave w
 // owns sentences w and w + 16 in the row-wise phases.
-template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false>
+// MID: sentences of 33..64 tokens over the packed cache (D = 256; attention_row24_mid).
+template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, bool MID = false>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   static_assert(!KV24 || (((KSD == 4 && DH == 32) || (KSD == 8 && DH == 64)) && !LONG),
-                "the packed K/V cache: D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32");
+                "the packed K/V cache: D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32 (64 with MID)");
+  static_assert(!MID || (KV24 && KSD == 4 && RT == 1), "33..64-token sentences: the D = 256 packed cache, 16 rows");
+  constexpr int PBW = MID ? 512 : 256;  // floats of attention scratch per wave ([H][S])
   constexpr int KVC = KSD == 8 ? 4 : 2;  // constant vectors per layer in LDS (see attention_row24 / _64)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 64 * KSD, F = 64 * KSF;
@@ -1015,11 +1112,11 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   int *red_i = reinterpret_cast<int *>(red_v + NW * R);
   int *flags = red_i + NW * R;  // [0] = number of finished sentences of this tile
   float *pbufs = reinterpret_cast<float *>(flags + 16);  // [NW][256] attention scratch
-  float *kvpb = pbufs + NW * 256;  // KV24: [Ld][K pb, V pb][D], or at D = 512 [Ld][K pb, K c127, V pb, V c127][D]
+  float *kvpb = pbufs + NW * PBW;  // KV24: [Ld][K pb, V pb][D], or at D = 512 [Ld][K pb, K c127, V pb, V c127][D]
   // LayerNorm scale / bias of every layer in LDS ([Ld][rnn, attn, ffn][scale, bias][D]) where it fits:
   // fetched per phase they are vector-memory loads that return IN ORDER behind whatever the wave
   // asked for before -- a weight prefetch in front of a LayerNorm would stall it by its whole transfer
-  constexpr bool LN_LDS = KSD == 4 && RT == 1;
+  constexpr bool LN_LDS = KSD == 4 && RT == 1 && !MID;  // (MID: the LDS goes to the wider attention scratch)
   float *lnc = kvpb + (KV24 ? 4 * KVC * D : 0);  // (Ld <= 4)
 
   // Which R sentences? With a ticket counter the grid is over-subscribed and the first
@@ -1220,7 +1317,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           }
           ar.qrow = (lcf_ptr)(xs + row * LDF);
           ar.arow = (lc_ptr)(A1 + row * LDA);
-          ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * 256);
+          ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * PBW);
           ar.S = S;
           ar.len = rr ? len[RT - 1] : len[0];
           ar.alpha = a.alpha;
@@ -1234,6 +1331,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
               attention_row24_64<2>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_64<0>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
+          } else if constexpr (MID) {
+            const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
+            if (NT && l >= a.kv_temporal_layers)
+              attention_row24_mid<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+            else
+              attention_row24_mid<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
           } else if constexpr (KV24) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
             if (NT && l >= a.kv_temporal_layers)
@@ -1416,14 +1519,14 @@ int fused_decode_grid(int B, bool tickets, int rows) {
   return tickets ? tiles * (rows == 16 ? 2 : 4) : tiles;
 }
 
-size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false) {
-  const size_t ln_lds = (D == 256 && rows == 16) ? (size_t)Ld * 6 * D * 4 : 0;  // LN_LDS in the kernel
+size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false, bool mid = false) {
+  const size_t ln_lds = (D == 256 && rows == 16 && !mid) ? (size_t)Ld * 6 * D * 4 : 0;  // LN_LDS in the kernel
   const size_t kv_slots = kv24 ? (size_t)4 * (D == 512 ? 4 : 2) * D * 4 : 0;     // kvpb: room for 4 layers
   // D * rows > 256 * 16: two f32 row buffers, SSRU cells in global memory (see the kernel)
   const size_t R = (size_t)rows;
   const bool lean = (size_t)D * R > 256 * 16;
   const size_t f32rows = lean ? 2 * R * (D + 4) * 4 : 3 * R * (D + 4) * 4 + (size_t)Ld * R * D * 4;
-  return f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 + NW * 256 * 4 +
+  return f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 + NW * (mid ? 512 : 256) * 4 +
          (ln_lds ? kv_slots : (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0)) + ln_lds;
 }
 
@@ -1455,7 +1558,19 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hi
   const int rows = fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg);
   const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, rows));
   const bool kv24 = a.kv24;
-  if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= 32)) return hipErrorInvalidValue;
+  const bool mid = kv24 && D == 256 && a.S > 32;  // 33..64-token sentences (cache written by encode_tall_kernel<., 4>)
+  if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= (D == 256 ? 64 : 32))) return hipErrorInvalidValue;
+  if (mid) {
+    if (rows != 16 || F != 1536) return hipErrorInvalidValue;
+    const size_t ldsm = fused_decode_lds_bytes(D, F, a.Ld, 16, true, true);
+    if (ldsm > 160 * 1024) return hipErrorInvalidValue;
+    auto k = a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, true> : decode_fused_kernel<4, 24, 32, false, false, 1, true, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), ldsm, st, a);
+    return hipGetLastError();
+  }
   const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows, kv24);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (kv24 && D == 512) {

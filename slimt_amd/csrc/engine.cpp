@@ -1246,10 +1246,13 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
                                   long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
   // packed 24-bit K/V cache: fused encoder -> fused decoder, D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32
   // (V is cached in groups of four keys: S = 1, 2, 5 would not fit the f32 form's plane)
+  // ... and for 33..64-token sentences of the D = 256 / F = 1536 shape (64-row encoder, one sentence per workgroup)
+  const bool kv24_mid = S > 32 && S <= 64 && m->D == 256 && m->F == 1536 && c->encode_rows != 32 && c->decode_mode != 3 &&
+                        tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
   const bool kv24 = lean && m->kv_format == 0 &&
-                    ((m->D == 256 && m->D / m->H == 32) || (m->D == 512 && m->D / m->H == 64 && m->F == 2048)) && S <= 32 &&
-                    ((S + 3) & ~(size_t)3) * 3 <= S * 4 &&
-                    fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
+                    ((m->D == 256 && m->D / m->H == 32) || (m->D == 512 && m->D / m->H == 64 && m->F == 2048)) &&
+                    ((S <= 32 && ((S + 3) & ~(size_t)3) * 3 <= S * 4 &&
+                      fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S)) || kv24_mid);
   DecodeState ds;
   ds.prev = c->prev.as<uint32_t>();
   ds.out_ids = d_out_ids;

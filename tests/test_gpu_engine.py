@@ -335,11 +335,12 @@ def test_kv_cache_policy_keeps_results(hip, oracle, engines, preset, B, S):
         ctx.close()
 
 
-@pytest.mark.parametrize("preset,S", [("tiny11", s) for s in (1, 2, 3, 4, 5, 6, 7, 9, 13, 16, 21, 31, 32)] +
+@pytest.mark.parametrize("preset,S", [("tiny11", s) for s in (1, 2, 3, 4, 5, 6, 7, 9, 13, 16, 21, 31, 32, 33, 40, 47, 50, 63, 64)] +
                          [("base", s) for s in (3, 4, 7, 10, 16, 29, 32)])
 def test_packed_kv_cache_matches_oracle_and_f32_cache(hip, oracle, engines, preset, S):
-    """The 24-bit K/V cache (default where supported: tiny11 and base, S <= 32; base caches the
-    signed accumulator and adds the column-sum term in the attention) against the oracle and
+    """The 24-bit K/V cache (default where supported: tiny11 up to S = 64 -- 33..64 through the 64-row
+    encoder and the one-head-per-pass attention --, base up to S = 32; base caches the signed
+    accumulator and adds the column-sum term in the attention) against the oracle and
     against the f32 cache, for sentence lengths on both sides of every layout edge: several
     sentences per encoder workgroup, a last V group of 1..4 keys, S = 1 / 2 / 5 (which fall
     back to f32: a padded group of four keys would not fit their plane), both cache-load
