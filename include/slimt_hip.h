@@ -133,7 +133,8 @@ int slimt_hip_model_set_kv_cache_policy(slimt_hip_model *model, int policy);
 /* Storage format of the cross-attention K/V cache that slimt_hip_translate* keeps between
  * its encoder and decoder launches (the reference recomputes K and V every step,
  * slimt/Modules.cc:248-249): 0 (default) = the int8 GEMM's 24-bit shifted accumulators where
- * the kernels support it (emb 256, head dim 32, sources of up to 32 tokens; the attention
+ * the kernels support it (emb 256 / head dim 32 with sources of up to 64 tokens, emb 512 / head
+ * dim 64 up to 32; the attention
  * rebuilds float(acc) * unquant + bias in registers: identical floats, 25 % fewer bytes
  * re-read per step), f32 elsewhere; 1 = always f32. Results do not depend on it. */
 int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format);

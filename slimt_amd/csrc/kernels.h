@@ -261,8 +261,8 @@ struct FusedDecodeArgs {
   // of every launch takes one ticket; ticket - ticket_base is the tile it runs (or none).
   unsigned *ticket = nullptr;
   unsigned ticket_base = 0;
-  // Packed K/V cache (S <= 32; D = 256 / d_head 32 written by encode_fused / encode_tall, D = 512 /
-  // d_head 64 by encode_wide): every cached value is the int8 GEMM's accumulator as a 24-bit
+  // Packed K/V cache (D = 256 / d_head 32: S <= 32 written by encode_fused / encode_tall, 33..64 by
+  // encode_tall; D = 512 / d_head 64, S <= 32, by encode_wide): every cached value is the int8 GEMM's accumulator as a 24-bit
   // integer -- the shifted one, accS = acc + 127 colsum, at K = 256 (|accS| < 2^23), the signed
   // one at K = 512 (accS needs 25 bits there; the decoder adds the column's term); 16 values = 48 bytes = one 16-byte quad in each of
   // three planes, so that loads stay 16 bytes per lane and contiguous across lanes:
