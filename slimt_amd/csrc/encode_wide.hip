@@ -46,6 +46,37 @@ __device__ __forceinline__ float wdequant(int acc, int colsum, float u, float pb
   return v + pb;
 }
 
+// Four columns at once, two per packed instruction (v_pk_mul_f32 / v_pk_add_f32: the same IEEE
+// operations as the scalar forms, multiply and add stay separate roundings).
+typedef float wf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 wdequant4(const v4i &c, const int (&cs)[4], float u, const float (&pb)[4]) {
+  wf2 lo = {(float)(c[0] + __mul24(127, cs[0])), (float)(c[1] + __mul24(127, cs[1]))};
+  wf2 hi = {(float)(c[2] + __mul24(127, cs[2])), (float)(c[3] + __mul24(127, cs[3]))};
+  const wf2 uu = {u, u};
+  lo = lo * uu;
+  hi = hi * uu;
+  const wf2 pl = {pb[0], pb[1]}, ph = {pb[2], pb[3]};
+  lo = lo + pl;
+  hi = hi + ph;
+  float4 v;
+  v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
+  return v;
+}
+// relu, then PrepareA with `aq`, four int8 in one register (see encode_tall.hip, trelu_quant4: for a
+// positive multiplier the relu rides in the clamp, v_cvt_pk_u8_f32 converts and packs)
+__device__ __forceinline__ int wrelu_quant4(const float4 &v, float aq) {
+  wf2 lo = {v.x, v.y}, hi = {v.z, v.w};
+  const wf2 qq = {aq, aq};
+  lo = lo * qq;
+  hi = hi * qq;
+  const float r[4] = {__builtin_rintf(lo.x), __builtin_rintf(lo.y), __builtin_rintf(hi.x), __builtin_rintf(hi.y)};
+  unsigned w = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(__builtin_fmaxf(r[i], 0.0f), 127.0f), i, w);
+  return (int)w;
+}
+
 // epilogue constants of column tile `tile` for this lane's 4 columns (4 lg .. 4 lg + 3)
 struct Epi4 {
   int cs[4];
@@ -231,14 +262,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], a1, c1, 0, 0, 0);
     }
   };
-  auto dequant4 = [&](const v4i &c, const Epi4 &e, float u) {
-    float4 v;
-    v.x = wdequant(c[0], e.cs[0], u, e.pb[0]);
-    v.y = wdequant(c[1], e.cs[1], u, e.pb[1]);
-    v.z = wdequant(c[2], e.cs[2], u, e.pb[2]);
-    v.w = wdequant(c[3], e.cs[3], u, e.pb[3]);
-    return v;
-  };
+  auto dequant4 = [&](const v4i &c, const Epi4 &e, float u) { return wdequant4(c, e.cs, u, e.pb); };
   {
     SLIMT_WPHASE_LANE;
     load_w(bw[0], a.L[0].q, wave, lane);
@@ -447,19 +471,10 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           load2(buf, i + 2 - NT1, lane);  // the first two chunks of FFN2
         __builtin_amdgcn_sched_barrier(0);
         const float pbv[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
-        int q0[4], q1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v0 = wdequant(c0[r], cs4[r], L.ffn1.u, pbv[r]);
-          float v1 = wdequant(c1[r], cs4[r], L.ffn1.u, pbv[r]);
-          v0 = v0 > 0.0f ? v0 : 0.0f;
-          v1 = v1 > 0.0f ? v1 : 0.0f;
-          q0[r] = quantize1(v0, L.ffn2.a_quant);
-          q1[r] = quantize1(v1, L.ffn2.a_quant);
-        }
+        const int csv[4] = {cs4[0], cs4[1], cs4[2], cs4[3]};
         const int col = t * 16 + lg * 4;
-        *reinterpret_cast<int *>(Hb + lr * LDH + col) = pack4(q0[0], q0[1], q0[2], q0[3]);
-        *reinterpret_cast<int *>(Hb + (16 + lr) * LDH + col) = pack4(q1[0], q1[1], q1[2], q1[3]);
+        *reinterpret_cast<int *>(Hb + lr * LDH + col) = wrelu_quant4(wdequant4(c0, csv, L.ffn1.u, pbv), L.ffn2.a_quant);
+        *reinterpret_cast<int *>(Hb + (16 + lr) * LDH + col) = wrelu_quant4(wdequant4(c1, csv, L.ffn1.u, pbv), L.ffn2.a_quant);
       }
     }
     lds_barrier();  // the hidden layer is complete
