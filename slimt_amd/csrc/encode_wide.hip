@@ -7,13 +7,13 @@
 //     2 w + 1, lane L holds columns L + 64 i (the element-to-lane map of the canonical row sum),
 //     16 registers. LayerNorm, the residual adds, the embedding and every quantisation of x run
 //     on the owner from registers;
-//   * ONE int8 A-operand buffer (32 x 528 B): x is quantised with the multiplier of the
-//     projection that is about to run (Q, K, V have their own), so the three projections of a
-//     round run one after the other instead of from three buffers;
+//   * three int8 A-operand buffers (32 x 512 B each: x quantised once per layer with the
+//     multipliers of Q, K and V), unpadded with XOR-swizzled 16-byte chunks -- padded they would
+//     not fit --, so a round's three projections run back to back with no barrier in between;
 //   * heads are staged in two rounds of four: q / k / v of four heads in f32 (97 KiB), their
 //     attention on the f32 matrix cores (v_mfma_f32_32x32x2_f32 chains over ascending k, bit
 //     identical to the ascending fmaf chain; 32 + 2 x 16 MFMAs per (sentence, head)), output
-//     quantised into a second int8 buffer (the O projection's A operand);
+//     quantised into the O projection's A operand (round 0: a narrow buffer of its own, round 1: Q's);
 //   * GEMM outputs that meet the residual (O projection, FFN2) cross from the column-tile
 //     owner to the row owner through an f32 exchange tile that time-shares the q / k / v
 //     region, as does the FFN's hidden layer (32 x 2048 int8): FFN2's accumulators stay in
@@ -163,7 +163,11 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   constexpr int HR = 4;              // heads per round
   constexpr int RC = HR * DH;        // q / k / v columns per round
   constexpr int NR = H / HR;         // rounds
-  constexpr int LDA = D + 16;        // int8 A rows
+  // int8 A rows: unpadded, the 16-byte chunks of a row XOR-swizzled with the row (a fragment read
+  // of 16 rows x one chunk then covers all 64 banks without pad bytes): THREE A buffers -- x
+  // quantised once per layer with the multipliers of Q, K and V -- fit beside the rest
+  constexpr int LDA = D;
+  constexpr int LDO = RC + 16;       // int8 attention output rows of one round
   // f32 q / k / v rows: the attention's 16x16x4 operands are read by lanes (row n = lane % 16,
   // k index g = lane / 16) -- q, k at [row n][d + g]: stride = 4 mod 64 words is conflict-free;
   // v at [key g][d + n]: stride = 16 mod 64 is
@@ -192,9 +196,13 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   const int rows_used = spw * S;
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
 
-  char *Abuf = smem;                 // the projection / FFN1 input, int8
-  char *Obuf = Abuf + WR * LDA;      // attention output, int8
-  char *region = Obuf + WR * LDA;    // q, k, v of four heads | exchange tile | hidden layer
+  char *Abuf = smem;                 // x quantised for Q | round 1's attention output | FFN1 / decoder K/V input
+  char *Akb = Abuf + WR * LDA;       // x quantised for K
+  char *Avb = Akb + WR * LDA;        // x quantised for V
+  char *Ob0 = Avb + WR * LDA;        // [WR][LDO] attention output of round 0
+  char *Ob1 = Abuf;                  // ... of round 1: Q's operand is dead by then
+  char *region = Ob0 + WR * LDO;     // q, k, v of four heads | exchange tile | hidden layer
+  static_assert(WR * LDO <= WR * LDA, "round 1's attention output fits Q's operand buffer");
   float *qb = reinterpret_cast<float *>(region);
   float *kb = qb + WR * LDQ;
   float *vb = kb + WR * LDQ;  // rows of LDV floats
@@ -231,11 +239,14 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
     }
   }
   // the owner's rows, quantised for the next affine, into the A buffer
-  auto quantise_x = [&](float aq, int lane) {
+  auto quantise_x = [&](char *A, float aq, int lane) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-      for (int i = 0; i < KSD; ++i) Abuf[(2 * wave + rr) * LDA + lane + 64 * i] = (char)quantize1(x[rr][i], aq);
+      for (int i = 0; i < KSD; ++i) {
+        const int row = 2 * wave + rr, col = lane + 64 * i;
+        A[row * LDA + ((((col >> 4) ^ row) & 15) << 4 | (col & ~255)) + (col & 15)] = (char)quantize1(x[rr][i], aq);
+      }
   };
   // Weight fragments are requested one phase ahead of their use, across the barriers and the
   // LayerNorm / attention phases in between: bw[0] and bw[1] hold one 16-column tile (K = D) each,
@@ -256,8 +267,24 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
     c1 = v4i{0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < KSD; ++ks) {
-      const v4i a0 = *reinterpret_cast<const v4i *>(A + lr * LDA + ks * 64 + lg * 16);
-      const v4i a1 = *reinterpret_cast<const v4i *>(A + (16 + lr) * LDA + ks * 64 + lg * 16);
+      const int ch = ks * 4 + lg;  // 16-byte chunk of the row, swizzled
+      const int off = ((ch & 16) | ((ch ^ lr) & 15)) << 4;
+      const v4i a0 = *reinterpret_cast<const v4i *>(A + lr * LDA + off);
+      const v4i a1 = *reinterpret_cast<const v4i *>(A + (16 + lr) * LDA + off);
+      c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], a0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], a1, c1, 0, 0, 0);
+    }
+  };
+  // the same against the attention output (k-steps 0..3: round 0's heads, 4..7: round 1's; padded rows)
+  auto mma_o = [&](const v4i (&f)[KSD], int lane, v4i &c0, v4i &c1) {
+    const int lr = lane & 15, lg = lane >> 4;
+    c0 = v4i{0, 0, 0, 0};
+    c1 = v4i{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) {
+      const char *O = ks < KSD / 2 ? Ob0 : Ob1;
+      const v4i a0 = *reinterpret_cast<const v4i *>(O + lr * LDO + (ks % (KSD / 2)) * 64 + lg * 16);
+      const v4i a1 = *reinterpret_cast<const v4i *>(O + (16 + lr) * LDO + (ks % (KSD / 2)) * 64 + lg * 16);
       c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], a0, c0, 0, 0, 0);
       c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], a1, c1, 0, 0, 0);
     }
@@ -272,19 +299,25 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
     const FusedEncLayerW &L = a.L[l];
     SLIMT_WSTAMP(0);
     // ---- Attention::forward (Modules.cc:287-319), four heads per round -----------------------
+    {  // x quantised with the three projections' multipliers, once per layer
+      SLIMT_WPHASE_LANE;
+      if (l) lds_barrier();  // the A buffers and the region are free
+      quantise_x(Abuf, L.q.a_quant, lane);
+      quantise_x(Akb, L.k.a_quant, lane);
+      quantise_x(Avb, L.v.a_quant, lane);
+    }
     for (int hr = 0; hr < NR; ++hr) {
-      // Q, K, V projections of this round's heads: wave = column tile
+      // Q, K, V projections of this round's heads: wave = column tile, one after the other (their
+      // outputs are disjoint: no barrier in between)
+      lds_barrier();  // round 0: the operands are complete; round 1: round 0's attention has read q / k / v
+      if (hr == 1) SLIMT_WSTAMP(2);
       for (int p = 0; p < 3; ++p) {
         SLIMT_WPHASE_LANE;
         const PreparedWeight &w = p == 0 ? L.q : (p == 1 ? L.k : L.v);
-        if (p || hr || l) lds_barrier();  // the A buffer / this round's q / k / v are free
-        if (p == 0 && hr == 1) SLIMT_WSTAMP(2);
-        quantise_x(w.a_quant, lane);
         const int ct = hr * WNW + wave;
         const Epi4 e = load_epi4(w, ct, lg);
-        lds_barrier();
         v4i c0, c1;
-        mma(Abuf, bw[0], lane, c0, c1);
+        mma(p == 0 ? Abuf : (p == 1 ? Akb : Avb), bw[0], lane, c0, c1);
         __builtin_amdgcn_sched_barrier(0);
         if (p < 2)
           load_w(bw[0], p == 0 ? L.k : L.v, ct, lane);
@@ -296,11 +329,8 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         const int col = wave * 16 + lg * 4;  // column inside the round
         float *dst = p == 0 ? qb : (p == 1 ? kb : vb);
         const int ldd = p == 2 ? LDV : LDQ;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dst[lr * ldd + col + r] = wdequant(c0[r], e.cs[r], w.u, e.pb[r]);
-          dst[(16 + lr) * ldd + col + r] = wdequant(c1[r], e.cs[r], w.u, e.pb[r]);
-        }
+        *reinterpret_cast<float4 *>(dst + lr * ldd + col) = dequant4(c0, e, w.u);
+        *reinterpret_cast<float4 *>(dst + (16 + lr) * ldd + col) = dequant4(c1, e, w.u);
       }
       lds_barrier();
       SLIMT_WSTAMP(hr == 0 ? 1 : 3);
@@ -382,14 +412,14 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int q = 16 * qh + 4 * g + r;  // query of this register
-              if (q < S) Obuf[(base + q) * LDA + hr * RC + dcol] = (char)quantize1(o[r], L.o.a_quant);
+              if (q < S) (hr == 0 ? Ob0 : Ob1)[(base + q) * LDO + dcol] = (char)quantize1(o[r], L.o.a_quant);
             }
           }
         }
         // rows that belong to no sentence keep a defined A operand
         for (int r = rows_used + wave; r < WR; r += WNW)
 #pragma unroll
-          for (int i = 0; i < RC / 64; ++i) Obuf[r * LDA + hr * RC + lane + 64 * i] = 0;
+          for (int i = 0; i < RC / 64; ++i) (hr == 0 ? Ob0 : Ob1)[r * LDO + lane + 64 * i] = 0;
       }
     }
     lds_barrier();  // attention of the last round is complete: q / k / v are dead
@@ -401,13 +431,13 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       const Epi4 e1 = load_epi4(L.o, wave + WNW, lg);
       __builtin_amdgcn_sched_barrier(0);
       v4i c0, c1;
-      mma(Obuf, bw[0], lane, c0, c1);
+      mma_o(bw[0], lane, c0, c1);
       __builtin_amdgcn_sched_barrier(0);
       load_w(bw[0], L.ffn1, wave, lane);
       __builtin_amdgcn_sched_barrier(0);
       *reinterpret_cast<float4 *>(Yb + lr * LDY + wave * 16 + lg * 4) = dequant4(c0, e0, L.o.u);
       *reinterpret_cast<float4 *>(Yb + (16 + lr) * LDY + wave * 16 + lg * 4) = dequant4(c1, e0, L.o.u);
-      mma(Obuf, bw[1], lane, c0, c1);
+      mma_o(bw[1], lane, c0, c1);
       __builtin_amdgcn_sched_barrier(0);
       load_w(bw[1], L.ffn1, wave + WNW, lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -426,7 +456,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         for (int i = 0; i < KSD; ++i) x[rr][i] = x[rr][i] + Yb[(2 * wave + rr) * LDY + lane + 64 * i];
         ln_regs<KSD>(x[rr], lsc, lbi, a.eps);
       }
-      quantise_x(L.ffn1.a_quant, lane);
+      quantise_x(Abuf, L.ffn1.a_quant, lane);
       const rsrc_t r1c = wrsrc(L.ffn1.colsum, (unsigned)L.ffn1.n_tiles * 64u);
       const rsrc_t r1p = wrsrc(L.ffn1.pb, (unsigned)L.ffn1.n_tiles * 64u);
 #pragma unroll
@@ -564,7 +594,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       float *out = a.kv + (size_t)(2 * l + p) * B * S * D;
       load_w(bw[1], w, wave + WNW, lane);
       lds_barrier();
-      quantise_x(w.a_quant, lane);
+      quantise_x(Abuf, w.a_quant, lane);
       lds_barrier();
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
@@ -655,7 +685,7 @@ size_t wide_encode_lds_bytes() {
   const size_t y = (size_t)WR * (D + 4) * 4, h = (size_t)WR * (F + 16);
   size_t region = qkv > y ? qkv : y;
   region = region > h ? region : h;
-  return 2 * (size_t)WR * (D + 16) + region;
+  return 3 * (size_t)WR * D + (size_t)WR * (RC + 16) + region;
 }
 
 bool wide_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
