@@ -158,8 +158,8 @@ int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
  * (persistent fused encoder / decoder kernels when the model shape supports
  * them), 1 = one launch per stage (and per decode step; the kernels behind
  * slimt_hip_decode_step), 2 / 3 = automatic, but the persistent decoder is
- * forced to 16 / 32 sentences per workgroup (tuning and tests; 0 picks by batch
- * size). Same results in every mode. */
+ * forced to 16 / 32 sentences per workgroup (tuning and tests; 0 picks 32 for
+ * output layers of more than 16k columns). Same results in every mode. */
 int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode);
 /* Rows (source tokens) per workgroup of the persistent encoder for emb 256 models: 0
  * (default) = chosen per call (64-row tiles once the batch fills the device with them),

@@ -1504,8 +1504,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   if (tid == 0) occ_trace_event(a.trace, 1, 1);
 }
 
-// rows per workgroup the fused decoder uses: 32 (two row tiles) only on request (decode mode
-// 3) and only for the D = 256 shapes with short sentences
+// rows per workgroup the fused decoder uses: 32 (two row tiles) on request (decode mode 3, or the
+// engine's choice for output layers of more than 16k columns) and only for the D = 256 shapes with
+// short sentences
 int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced) {
   (void)B;
   const bool ok32 = D == 256 && F == 1536 && D / H == 32 && Ld <= 4 && S <= 32;

@@ -1295,7 +1295,11 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.B = (int)B; f.S = (int)S; f.Ld = m->Ld;
     f.max_steps = steps_hint > 0 ? steps_hint : (int)(Tmax > 1 ? Tmax : 1);
     f.Tmax = (int)Tmax;
-    f.rows_per_wg = c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : 0;
+    // 32 sentences per workgroup (where the kernel has it) once the output layer dominates the
+    // weights a step streams: with the full 32k vocabulary it is 8 of 10 MB per workgroup and step, and
+    // halving it per sentence beats the longer attention chain (B = 512, full vocabulary: 20.4 -> 23-24 M
+    // tok/s; at 16k columns the two are level, below that 16 rows win)
+    f.rows_per_wg = c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : (out.w.N > 16384 ? 32 : 0);
     const int rows = fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, f.rows_per_wg);
     for (int l = 0; l < m->Ld; ++l) {
       const DecLayerW &L = m->dec[(size_t)l];

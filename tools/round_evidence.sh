@@ -8,7 +8,7 @@ timeout -k 10 120 python tools/decode_phases.py 256 > gpurun_out/${TAG}_phases.t
 timeout -k 10 120 python tools/decode_phases_loaded.py > gpurun_out/${TAG}_phases_loaded.txt 2>&1 || exit 1
 timeout -k 10 200 python tools/occupancy_trace.py 20 480 256 > gpurun_out/${TAG}_occupancy.txt 2>&1 || exit 1
 {
-  tools/sweep.sh "--steps 20 --warmup 5" "--batch 64" "--batch 512 --shortlist 0 --workers 12" "--batch 512 --workers 12" \
+  tools/sweep.sh "--steps 20 --warmup 5" "--batch 64" "--batch 512 --shortlist 0" "--batch 512 --workers 12" \
     "--batch 128 --src-len 64" "--batch 64 --src-len 128" "--ragged" "--preset base" \
     "--total-sentences 4096 --batch 512 --steps 10" "--total-sentences 4096 --batch 256 --steps 10" \
     "--batch 4096 --workers 1 --sustained-steps 0"
