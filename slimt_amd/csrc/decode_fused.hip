@@ -1117,7 +1117,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   // fetched per phase they are vector-memory loads that return IN ORDER behind whatever the wave
   // asked for before -- a weight prefetch in front of a LayerNorm would stall it by its whole transfer
   constexpr bool LN_LDS = KSD == 4 && RT == 1 && !MID;  // (MID: the LDS goes to the wider attention scratch)
-  float *lnc = kvpb + (KV24 ? 4 * KVC * D : 0);  // (Ld <= 4)
+  float *lnc = kvpb + (KV24 ? Ld * KVC * D : 0);
+  const bool ln_lds = LN_LDS && a.ln_in_lds;  // (the launcher: only where the 160 KiB allow it)
 
   // Which R sentences? With a ticket counter the grid is over-subscribed and the first
   // workgroups to START claim the tiles; the rest leave at once. A workgroup needs a whole
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     for (int i = tid; i < Ld * R * D; i += 1024) cs[i] = 0.0f;
   }
   if (tid == 0) flags[0] = 0;
-  if constexpr (LN_LDS) {
+  if (ln_lds) {
     for (int i = tid; i < Ld * 6 * D; i += 1024) {
       const FusedLayerW &Lw = a.L[i / (6 * D)];
       const int v = (i / D) % 6, d = i % D;
@@ -1281,8 +1282,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
       for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
-        ln_row<KSD>(pre + row * LDF, LN_LDS ? lnc + (6 * l + 0) * D : L.rnn_ln_s, LN_LDS ? lnc + (6 * l + 1) * D : L.rnn_ln_b, a.eps,
-                    hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
+        if (ln_lds)
+          ln_row<KSD>(pre + row * LDF, lnc + (6 * l + 0) * D, lnc + (6 * l + 1) * D, a.eps, hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
+        else
+          ln_row<KSD>(pre + row * LDF, L.rnn_ln_s, L.rnn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
       }
       lds_barrier();
       SLIMT_STAMP(sb + 2);
@@ -1376,8 +1379,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
       for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
-        ln_row<KSD>(pre + row * LDF, LN_LDS ? lnc + (6 * l + 2) * D : L.attn_ln_s, LN_LDS ? lnc + (6 * l + 3) * D : L.attn_ln_b, a.eps,
-                    hs + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
+        if (ln_lds)
+          ln_row<KSD>(pre + row * LDF, lnc + (6 * l + 2) * D, lnc + (6 * l + 3) * D, a.eps, hs + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
+        else
+          ln_row<KSD>(pre + row * LDF, L.attn_ln_s, L.attn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
       }
       if constexpr (!LN_LDS) stream_prologue<KSD, NB_FFN, NT_F1>(L.ffn1, wave, lane, f1);
       lds_barrier();
@@ -1413,8 +1418,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
       for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
-        ln_row<KSD>(pre + row * LDF, LN_LDS ? lnc + (6 * l + 4) * D : L.ffn_ln_s, LN_LDS ? lnc + (6 * l + 5) * D : L.ffn_ln_b, a.eps, xs + row * LDF,
-                    (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
+        if (ln_lds)
+          ln_row<KSD>(pre + row * LDF, lnc + (6 * l + 4) * D, lnc + (6 * l + 5) * D, a.eps, xs + row * LDF,
+                      (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
+        else
+          ln_row<KSD>(pre + row * LDF, L.ffn_ln_s, L.ffn_ln_b, a.eps, xs + row * LDF,
+                      (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
       }
       // Between layers no barrier: the next phase (the SSRU's quantisation) reads and writes
       // only this wave's own rows; the barrier after it covers both. (After the last layer: below.)
@@ -1520,15 +1529,26 @@ int fused_decode_grid(int B, bool tickets, int rows) {
   return tickets ? tiles * (rows == 16 ? 2 : 4) : tiles;
 }
 
-size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false, bool mid = false) {
-  const size_t ln_lds = (D == 256 && rows == 16 && !mid) ? (size_t)Ld * 6 * D * 4 : 0;  // LN_LDS in the kernel
-  const size_t kv_slots = kv24 ? (size_t)4 * (D == 512 ? 4 : 2) * D * 4 : 0;     // kvpb: room for 4 layers
+// ln_in_lds (out, nullable): whether the LayerNorm constants of all layers (LN_LDS in the kernel: the
+// D = 256, 16-row, non-MID variants) still fit the 160 KiB; the returned size includes them then.
+size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false, bool mid = false,
+                              bool *ln_in_lds = nullptr) {
   // D * rows > 256 * 16: two f32 row buffers, SSRU cells in global memory (see the kernel)
   const size_t R = (size_t)rows;
   const bool lean = (size_t)D * R > 256 * 16;
   const size_t f32rows = lean ? 2 * R * (D + 4) * 4 : 3 * R * (D + 4) * 4 + (size_t)Ld * R * D * 4;
-  return f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 + NW * (mid ? 512 : 256) * 4 +
-         (ln_lds ? kv_slots : (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0)) + ln_lds;
+  const size_t base = f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 +
+                      NW * (mid ? 512 : 256) * 4 + (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0);
+  const size_t ln = (D == 256 && rows == 16 && !mid) ? (size_t)Ld * 6 * D * 4 : 0;
+  const bool fits = ln > 0 && base + ln <= 160 * 1024;
+  if (ln_in_lds) *ln_in_lds = fits;
+  return fits ? base + ln : base;
+}
+
+// sentences of 33..64 tokens over the packed cache (decode_fused_kernel<..., MID>)
+bool fused_decode_mid_supported(int D, int F, int H, int Ld) {
+  if (Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
+  return D == 256 && F == 1536 && D / H == 32 && fused_decode_lds_bytes(D, F, Ld, 16, true, true) <= 160 * 1024;
 }
 
 bool fused_decode_supported(int D, int F, int H, int Ld) {
@@ -1554,7 +1574,8 @@ static auto decode_fused_pick(bool long_sentences, bool nt) -> void (*)(FusedDec
   return decode_fused_kernel<KSD, KSF, DH, false, false>;
 }
 
-hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st) {
+hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H, hipStream_t st) {
+  FusedDecodeArgs a = a_in;
   if (!fused_decode_supported(D, F, H, a.Ld)) return hipErrorInvalidValue;
   const int rows = fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg);
   const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, rows));
@@ -1572,7 +1593,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hi
     hipLaunchKernelGGL(k, grid, dim3(1024), ldsm, st, a);
     return hipGetLastError();
   }
-  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows, kv24);
+  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows, kv24, false, &a.ln_in_lds);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (kv24 && D == 512) {
     if (F != 2048) return hipErrorInvalidValue;

@@ -1247,7 +1247,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   // packed 24-bit K/V cache: fused encoder -> fused decoder, D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32
   // (V is cached in groups of four keys: S = 1, 2, 5 would not fit the f32 form's plane)
   // ... and for 33..64-token sentences of the D = 256 / F = 1536 shape (64-row encoder, one sentence per workgroup)
-  const bool kv24_mid = S > 32 && S <= 64 && m->D == 256 && m->F == 1536 && c->encode_rows != 32 && c->decode_mode != 3 &&
+  const bool kv24_mid = S > 32 && S <= 64 && c->encode_rows != 32 && c->decode_mode != 3 &&
+                        fused_decode_mid_supported(m->D, m->F, m->H, m->Ld) &&
                         tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
   const bool kv24 = lean && m->kv_format == 0 &&
                     ((m->D == 256 && m->D / m->H == 32) || (m->D == 512 && m->D / m->H == 64 && m->F == 2048)) &&

@@ -275,6 +275,7 @@ struct FusedDecodeArgs {
   const float *kv_pb[4][2] = {};  // [layer][K, V]: the projections' prepared biases [D]
   const int *kv_cs[4][2] = {};    // [layer][K, V]: their column sums [D] (D = 512: the cache holds the signed accumulator)
   float kv_u256[4][2] = {};       // [layer][K, V]: unquantisation multiplier u / 256
+  bool ln_in_lds = false;  // set by the launcher: the LayerNorm constants of all layers fit LDS beside the rest
   bool kv_nt = false;  // non-temporal K/V cache loads (d_head 32 / 64 shapes; see decode_fused.hip)
   int kv_temporal_layers = 0;  // with kv_nt: the first layers' caches are still read temporally
   OccTrace trace;
@@ -282,6 +283,7 @@ struct FusedDecodeArgs {
 int fused_decode_grid(int B, bool tickets, int rows);
 int fused_encode_grid(int B, int S, bool tickets);
 bool fused_decode_supported(int D, int F, int H, int Ld);
+bool fused_decode_mid_supported(int D, int F, int H, int Ld);
 int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
 

@@ -444,6 +444,35 @@ def test_tall_encoder_medium_sentences_bit_exact(hip, oracle, engines, B, S):
         ctx.close()
 
 
+@pytest.mark.parametrize("Ld", [1, 3])
+def test_decoder_depths_other_than_two(hip, oracle, Ld):
+    """tiny11's shape with 1 and 3 decoder layers: the per-layer LDS tables of the persistent decoder
+    (SSRU cells, packed-cache biases, LayerNorm constants) scale with the depth -- at 3 layers the
+    LayerNorm constants no longer fit and are read from global memory, and 33..64-token sentences
+    fall back to the long-sentence path; results stay those of the oracle."""
+    from slimt_amd import synth
+    m = synth.make_model("tiny11", eos_bias=6.0, dims=(256, 1536, 8, 2, Ld, 4000))
+    gm, om = hip.Model(m), oracle.OracleModel(m)
+    try:
+        for B, S in ((21, 32), (9, 13), (7, 48)):
+            ids, lens = synth.make_batch(m.V, B, S, seed=8800 + 10 * Ld + S, ragged=True)
+            sl = synth.make_shortlist(m.V, 512)
+            oracle.set_mode(oracle.PORTABLE)
+            want = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+            oracle.set_mode(oracle.FAITHFUL)
+            ctx = hip.Context(gm, B, S)
+            try:
+                for fmt in (0, 1):
+                    gm.set_kv_cache_format(fmt)
+                    got = ctx.translate(ids, lens, sl, want_align=True)
+                    assert all(np.array_equal(a, b) for a, b in zip(got, want)), (B, S, fmt)
+            finally:
+                ctx.close()
+    finally:
+        gm.set_kv_cache_format(0)
+        gm.close()
+
+
 @pytest.mark.parametrize("budget", [0, 1, 3, 1000])
 def test_decoder_admission_and_ticket_launches_keep_results(hip, oracle, engines, budget):
     """Concurrent contexts of one model under every decoder budget (0 = no limit, 1 = one
