@@ -121,7 +121,7 @@ int slimt_hip_model_destroy(slimt_hip_model *model);
 /* Admission of the persistent decoders of all contexts of `model`: at most
  * about `workgroups` decoder workgroups (one CU each, 16 sentences) run at a
  * time, later launches wait on their own stream; the remaining CUs stay with
- * the encoders of the batches behind them. Default: 3/4 of the device's CUs;
+ * the encoders of the batches behind them. Default: 7/8 of the device's CUs;
  * 0 = no limit. Results do not depend on it. */
 int slimt_hip_model_set_decoder_budget(slimt_hip_model *model, int workgroups);
 /* Cache policy of the persistent decoder's K/V cache loads: 0 (default) = chosen

@@ -531,7 +531,7 @@ extern "C" int slimt_hip_model_create(const slimt_hip_param *params, size_t n_pa
   m->device = device;
   {  // default decoder admission: three quarters of the CUs (measured optimum)
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->decoder_budget = 3 * prop.multiProcessorCount / 4;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->decoder_budget = 7 * prop.multiProcessorCount / 8;
   }
   int rc = model_build(m, params, n_params, dims);
   if (rc) {
