@@ -11,7 +11,8 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 W = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 m = synth.make_model(preset, eos_bias=6.0)
 gm = capi.Model(m)
-B, S = 48, 24
+B = int(sys.argv[5]) if len(sys.argv) > 5 else 48
+S = int(sys.argv[6]) if len(sys.argv) > 6 else 24
 sl = synth.make_shortlist(m.V, 2048)
 jobs = [synth.make_batch(m.V, B, S, seed=1000 + i, ragged=True) for i in range(W)]
 ctxs = [capi.Context(gm, B, S) for _ in range(W)]
