@@ -68,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--decoder-budget", type=int, default=-1,
                     help="decoder workgroups admitted at a time (-1 = library default, 0 = no limit)")
     ap.add_argument("--decode-mode", type=int, default=0, help="0 = fused persistent decoder, 1 = step-wise")
+    ap.add_argument("--encode-rows", type=int, default=0,
+                    help="rows per workgroup of the emb-256 encoder: 0 = chosen per call (default), 32, 64")
     ap.add_argument("--kv-policy", type=int, default=0,
                     help="decoder K/V cache loads: 0 = chosen per launch (default), 1 = temporal, 2 = non-temporal")
     ap.add_argument("--sustained-steps", type=int, default=40,
@@ -299,6 +301,8 @@ def main():
         ctxs = [capi.Context(gm, B, S) for _ in range(W)]
         for c in ctxs:
             c.set_decode_mode(args.decode_mode)
+            if args.encode_rows:
+                c.set_encode_rows(args.encode_rows)
         dev = torch.device("cuda", local_rank)
 
         def to_dev(a):

@@ -162,7 +162,7 @@ int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
  * output layers of more than 16k columns). Same results in every mode. */
 int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode);
 /* Rows (source tokens) per workgroup of the persistent encoder for emb 256 models: 0
- * (default) = chosen per call (64-row tiles once the batch fills the device with them),
+ * (default) = chosen per call (64-row tiles from 32 of them on),
  * 32 or 64 = forced (tuning and tests). Same results either way. */
 int slimt_hip_ctx_set_encode_rows(slimt_hip_ctx *ctx, int rows);
 /* Which kernels a translate call with source length S would use in the current

@@ -952,10 +952,11 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     f.ticket = c->ticket.as<unsigned>() + 1;  // over-subscribed launch, tiles claimed by ticket
     f.ticket_base = c->enc_ticket_base;
     // D = 256: 64-row tiles (encode_tall.hip: the O projection's and the FFN's weights cross the
-    // CU's L2 path once per 64 rows) once the batch fills the chip with them -- below that, twice
-    // as many 32-row workgroups finish a lone batch sooner
+    // CU's L2 path once per 64 rows) from 32 of them on: with other batches in flight they win
+    // already there (B = 128: 23.3 -> 26.2 M tok/s, B = 64: level), a lone batch of that size pays
+    // ~0.1 ms of latency; below that twice as many 32-row workgroups (and less padding) are better
     const bool tall = tall_mid || (tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S) &&
-                                   (c->encode_rows == 64 || (c->encode_rows == 0 && tall_encode_grid(B, S, false) >= 96)));
+                                   (c->encode_rows == 64 || (c->encode_rows == 0 && tall_encode_grid(B, S, false) >= 32)));
     {
       const double macs = (double)M * (m->Le * (4.0 * D * D + 2.0 * D * m->F) + m->Ld * 2.0 * D * D);
       ProfScope p(c, SLIMT_HIP_K_ENCODE_FUSED, macs, 0);
