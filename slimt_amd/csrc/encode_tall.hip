@@ -193,6 +193,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   const int s0 = tile * spw;  // first sentence
   const int rows_used = spw * S;
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
+  // this workgroup's sentence lengths: read once (they may live in pinned host memory, and every
+  // attention job needs its sentence's; ordered by the first barrier below)
+  __shared__ int slens[TR];
+  if (tid < spw) slens[tid] = s0 + tid < B ? (int)a.lengths[s0 + tid] : 0;
 
   char *Aq = smem;                       // x quantised for Q | round 1's attention output | for FFN1 | for the decoder's K / V
   char *Ak = Aq + TR * LDA;              // x quantised for K
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           const int sb = s0 + sl;
           if (sb >= B) continue;
           const int base = sl * S;
-          const int len = (int)a.lengths[sb];
+          const int len = slens[sl];
           const int qr = 16 * qh + n;
           const float *qp = qb + (base + (qr < S ? qr : S - 1)) * LDQ + hl * DH + g;
           float sc[NKT][4];

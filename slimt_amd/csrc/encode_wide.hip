@@ -195,6 +195,9 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   const int s0 = tile * spw;  // first sentence
   const int rows_used = spw * S;
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
+  // this workgroup's sentence lengths: read once (they may live in pinned host memory)
+  __shared__ int slens[WR];
+  if (tid < spw) slens[tid] = s0 + tid < B ? (int)a.lengths[s0 + tid] : 0;
 
   char *Abuf = smem;                 // x quantised for Q | round 1's attention output | FFN1 / decoder K/V input
   char *Akb = Abuf + WR * LDA;       // x quantised for K
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           const int sb = s0 + sl;
           if (sb >= B) continue;
           const int base = sl * S;
-          const int len = (int)a.lengths[sb];
+          const int len = slens[sl];
           const int qr = 16 * qh + n;
           const float *qp = qb + (base + (qr < S ? qr : S - 1)) * LDQ + hl * DH + g;
           float sc[2][4];

@@ -621,6 +621,7 @@ void ctx_free(slimt_hip_ctx *c) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
   }
+  if (c->sync_event) (void)hipEventDestroy(c->sync_event);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -783,7 +784,13 @@ extern "C" int slimt_hip_ctx_plan(const slimt_hip_ctx *ctx, size_t S, int *encod
 
 extern "C" int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx) {
   if (!ctx) return fail(-1, "ctx is NULL");
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // A blocking-sync event, not hipStreamSynchronize: that one spins, and a host pipeline has one
+  // thread per context waiting here for milliseconds -- a dozen spinning threads take the cores
+  // the runtime's own threads and the batch builders need (the Service with 8 workers: 11.7 ->
+  // 13.3 M tok/s once the waiters sleep).
+  if (!ctx->sync_event) HIPCHK(hipEventCreateWithFlags(&ctx->sync_event, hipEventBlockingSync | hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ctx->sync_event, ctx->stream));
+  HIPCHK(hipEventSynchronize(ctx->sync_event));
   return 0;
 }
 
@@ -1484,12 +1491,44 @@ int translate_host(slimt_hip_ctx *ctx, const uint32_t *src_ids, const uint32_t *
   HIPCHK(hipSetDevice(m->device));
   hipStream_t st = ctx->stream;
   const size_t Tmax = std::max<size_t>(1, (size_t)(limit_factor * (float)S));
+  // the shortlist is read at random every step: it stays on the device, uploaded when it changes
+  if (n_shortlist && (ctx->sl_host.size() != n_shortlist ||
+                      std::memcmp(ctx->sl_host.data(), shortlist, n_shortlist * 4) != 0)) {
+    ctx->sl_host.assign(shortlist, shortlist + n_shortlist);
+    HIPCHK(hipMemcpyAsync(ctx->shortlist.p, ctx->sl_host.data(), n_shortlist * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // (sl_host is pageable: the copy is staged; done once per shortlist)
+  }
+  // Asynchronous callers with PINNED buffers (hipHostMalloc / slimt_hip_host_alloc): the persistent
+  // kernels read the ids / lengths and write tokens, lengths and alignments in host memory themselves
+  // -- no copy on either side. Copies are what a host pipeline stalls on: an asynchronous copy
+  // of stream A sits in a DMA queue behind copies that wait for stream B's kernels (measured with the
+  // Service: 12 contexts of equal batches ran strictly one after the other, 3.7 M tok/s).
+  const bool persistent = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
+                          (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
+                           long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
+  if (!wait && persistent) {
+    auto device_view = [](const void *p) -> void * {
+      hipPointerAttribute_t a;
+      if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
+      return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
+    };
+    void *v_ids = device_view(src_ids), *v_len = device_view(lengths), *v_out = device_view(out_ids),
+         *v_ol = device_view(out_len), *v_al = align ? device_view(align) : nullptr;
+    if (v_ids && v_len && v_out && v_ol && (!align || v_al)) {
+      RCCHK(translate_device(ctx, static_cast<const uint32_t *>(v_ids), static_cast<const uint32_t *>(v_len),
+                             ctx->shortlist.as<uint32_t>(), B, S, n_shortlist, limit_factor, eos_id,
+                             static_cast<uint32_t *>(v_out), static_cast<uint32_t *>(v_ol),
+                             static_cast<float *>(v_al), (int)Tmax));
+      return 0;
+    }
+  }
   HIPCHK(ctx->out_ids.reserve(B * Tmax * 4));
   if (align) HIPCHK(ctx->align.reserve(B * Tmax * S * 4));
   HIPCHK(hipMemcpyAsync(ctx->ids.p, src_ids, B * S * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->lengths.p, lengths, B * 4, hipMemcpyHostToDevice, st));
-  if (n_shortlist)
-    HIPCHK(hipMemcpyAsync(ctx->shortlist.p, shortlist, n_shortlist * 4, hipMemcpyHostToDevice, st));
   // asynchronous callers never read back inside the loop: a fixed step budget (the persistent
   // decoder still leaves its loop as soon as every sentence has emitted EOS)
   RCCHK(translate_device(ctx, ctx->ids.as<uint32_t>(), ctx->lengths.as<uint32_t>(),

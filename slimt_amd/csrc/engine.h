@@ -90,6 +90,8 @@ struct slimt_hip_model {
 struct slimt_hip_ctx {
   slimt_hip_model *model = nullptr;
   hipStream_t stream = nullptr;
+  hipEvent_t sync_event = nullptr;  // blocking-sync event of slimt_hip_ctx_synchronize (created on first use)
+  std::vector<uint32_t> sl_host;    // the shortlist last uploaded by translate_host (re-uploaded only when it changes)
   bool own_stream = false;
   size_t max_B = 0, max_S = 0;
   size_t max_M = 0;  // padded tokens (B * S) the workspace holds

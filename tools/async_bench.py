@@ -19,7 +19,8 @@ exe = B.build_host()
 with tempfile.TemporaryDirectory() as d:
     mb, cb, ob = (os.path.join(d, n) for n in ("model.bin", "case.bin", "out.bin"))
     open(mb, "wb").write(synth.write_bin(m))
-    lens = r.integers(8, 33, size=n_sent)
+    lo = int(os.environ.get("SLIMT_SERVICE_MIN_LEN", "8"))  # sentence lengths uniform in [lo, 32]
+    lens = r.integers(lo, 33, size=n_sent)
     with open(cb, "wb") as f:
         f.write(struct.pack("<7If", m.enc_layers, m.dec_layers, m.H, max_words, 128, workers, 1, 1.5))
         f.write(struct.pack("<I", n_sent))
