@@ -186,12 +186,16 @@ int slimt_hip_translate(slimt_hip_ctx *ctx, const uint32_t *src_ids,
                         const uint32_t *shortlist, size_t n_shortlist,
                         float limit_factor, uint32_t eos_id, uint32_t *out_ids,
                         uint32_t *out_len, float *align);
-/* Same without the final wait: the H2D copies, the kernels and the D2H copies are
- * queued on the ctx stream and the call returns; slimt_hip_ctx_synchronize(ctx)
- * waits for them. Every buffer must stay valid (and unchanged) until then, and
- * should be pinned (slimt_hip_host_alloc) for the copies to be truly
- * asynchronous. One call in flight per ctx: a worker that wants to assemble its
- * next batch while this one runs uses two contexts (host/Service.cc). */
+/* Same without the final wait: the work is queued on the ctx stream and the call
+ * returns; slimt_hip_ctx_synchronize(ctx) waits for it. Every buffer must stay
+ * valid (and unchanged) until then, and should be pinned (slimt_hip_host_alloc):
+ * with src_ids, lengths, out_ids, out_len (and align) all pinned the persistent
+ * kernels read and write them in host memory themselves and no copy is queued at
+ * all; otherwise H2D / D2H copies bracket the kernels (and asynchronous copies of
+ * many contexts queue behind each other's kernels). The shortlist is uploaded
+ * only when it differs from the previous call's. One call in flight per ctx: a
+ * worker that wants to assemble its next batch while this one runs uses two
+ * contexts (host/Service.cc). */
 int slimt_hip_translate_async(slimt_hip_ctx *ctx, const uint32_t *src_ids,
                               const uint32_t *lengths, size_t B, size_t S,
                               const uint32_t *shortlist, size_t n_shortlist,

@@ -85,7 +85,7 @@ struct ServiceConfig {
   size_t max_words = 8192;   // word budget of a batch: (B + 1) * S <= max_words
   size_t wrap_length = 128;  // longest sentence (slimt wraps there, Frontend.hh:27)
   float tgt_length_limit_factor = 1.5F;
-  size_t workers_per_device = 4;
+  size_t workers_per_device = 10;  // x 2 contexts each: about 20 batches in flight per GPU
   uint32_t pad_id = 0;
   bool alignments = true;
   // One shortlist policy for the service's lifetime (immutable after construction):

@@ -16,7 +16,7 @@ timeout -k 10 200 python tools/occupancy_trace.py 20 480 256 > gpurun_out/${TAG}
 cat gpurun_out/${TAG}_configs.txt
 SLIMT_BENCH_REHEARSAL=1 timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 2 --workers 8 --no-cpu-baseline --sustained-steps 0 > gpurun_out/${TAG}_rehearsal_2ranks_on_1gpu.json 2> gpurun_out/${TAG}_rehearsal.err
 cut -c1-300 gpurun_out/${TAG}_rehearsal_2ranks_on_1gpu.json
-for cfg in "8 32768 4096 0" "8 32768 4096 1" "6 32768 4096 0" "8 32768 0 1"; do timeout -k 10 200 python tools/async_bench.py $cfg >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err; done
+for cfg in "10 32768 4096 0" "10 32768 4096 1" "6 32768 4096 0" "10 32768 0 1"; do timeout -k 10 200 python tools/async_bench.py $cfg >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err; done
 cut -c1-330 gpurun_out/${TAG}_service_bench.jsonl
 timeout -k 10 250 python tools/text_bench.py 3000 8 > gpurun_out/${TAG}_text_bench.json 2> gpurun_out/${TAG}_text_bench.err
 cut -c1-400 gpurun_out/${TAG}_text_bench.json
