@@ -288,22 +288,57 @@ class Model:
             pass
 
 
+class _Pinned:
+    """A growing pinned host buffer (slimt_hip_host_alloc) seen as numpy arrays."""
+
+    def __init__(self):
+        self.ptr = C.c_void_p()
+        self.nbytes = 0
+
+    def array(self, dtype, shape):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if n > self.nbytes:
+            self.free()
+            want = max(n, 2 * self.nbytes, 4096)
+            _chk(lib().slimt_hip_host_alloc(want, C.byref(self.ptr)))
+            self.nbytes = want
+        raw = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), shape=(self.nbytes,))
+        return raw[:n].view(dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            lib().slimt_hip_host_free(self.ptr)
+            self.ptr = C.c_void_p()
+            self.nbytes = 0
+
+
 class Context:
     """One worker's stream + workspace (mirrors one slimt Async worker)."""
 
-    def __init__(self, model: Model, max_batch: int, max_source_length: int, stream: int = 0):
+    def __init__(self, model: Model, max_batch: int, max_source_length: int, stream: int = 0,
+                 max_tokens: int = 0):
+        """max_tokens > 0: a token-budget workspace (slimt_hip_ctx_create_budget): any batch with
+        B <= max_batch, S <= max_source_length and B * S <= max_tokens."""
         self.model = model
         h = C.c_void_p()
-        _chk(lib().slimt_hip_ctx_create(model.h, max_batch, max_source_length,
-                                        C.c_void_p(stream) if stream else None, C.byref(h)))
+        if max_tokens:
+            _chk(lib().slimt_hip_ctx_create_budget(model.h, max_batch, max_source_length, max_tokens,
+                                                   C.c_void_p(stream) if stream else None, C.byref(h)))
+        else:
+            _chk(lib().slimt_hip_ctx_create(model.h, max_batch, max_source_length,
+                                            C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
         self.B = self.S = 0
         self.N = model.V
+        self._pinned = {}  # name -> _Pinned (translate_pinned)
 
     def close(self):
         if getattr(self, "h", None):
             lib().slimt_hip_ctx_destroy(self.h)
             self.h = None
+            for b in getattr(self, "_pinned", {}).values():
+                b.free()
+            self._pinned = {}
 
     def __del__(self):
         try:
@@ -350,6 +385,29 @@ class Context:
                                        0 if sl is None else sl.size, limit_factor, eos_id,
                                        _p(out_ids), _p(out_len), _p(align)))
         return out_ids, out_len, align
+
+    def translate_pinned(self, ids, lengths, shortlist=None, limit_factor: float = 1.5, eos_id: int = 0,
+                         want_align: bool = False):
+        """translate() through this context's pinned staging buffers and slimt_hip_translate_async:
+        the persistent kernels then read and write host memory themselves, no copy is queued (host
+        pipelines with several contexts: copies of one stream wait behind other streams' kernels).
+        Returns copies of out_ids [B,Tmax], out_len [B], align|None."""
+        ids = np.asarray(ids)
+        B, S = ids.shape
+        T = max(int(np.float32(limit_factor) * np.float32(S)), 1)
+        pin = lambda name: self._pinned.setdefault(name, _Pinned())
+        p_ids = pin("ids").array(np.uint32, (B, S))
+        p_len = pin("len").array(np.uint32, (B,))
+        p_out = pin("out").array(np.uint32, (B, T))
+        p_ol = pin("ol").array(np.uint32, (B,))
+        p_al = pin("al").array(np.float32, (B, T, S)) if want_align else None
+        p_ids[...] = ids
+        p_len[...] = lengths
+        sl = None if shortlist is None else np.ascontiguousarray(shortlist, dtype=np.uint32)
+        _chk(lib().slimt_hip_translate_async(self.h, _p(p_ids), _p(p_len), B, S, _p(sl), 0 if sl is None else sl.size,
+                                             limit_factor, eos_id, _p(p_out), _p(p_ol), _p(p_al)))
+        self.synchronize()
+        return p_out.copy(), p_ol.copy(), (p_al.copy() if want_align else None)
 
     def translate_device(self, d_ids: int, d_lengths: int, B: int, S: int, d_shortlist: int,
                          n_shortlist: int, limit_factor: float, eos_id: int, d_out_ids: int,

@@ -153,17 +153,18 @@ class Service:
         return out
 
     def _context(self, model: Model, B: int, S: int) -> capi.Context:
+        """This thread's context for `model`: a token-budget workspace for every batch _batches can
+        form ((B + 1) * S <= max_words, S <= wrap_length), created once -- re-creating a context as
+        batches grow frees and allocates device memory, which stalls every other thread's stream."""
         key = (model.id, threading.get_ident())
         with self._lock:
-            entry = self._contexts.get(key)
-        if entry is None or entry[1] < B or entry[2] < S:
-            if entry is not None:
-                entry[0].close()
-            cap_b, cap_s = max(B, entry[1] if entry else 0), max(S, entry[2] if entry else 0)
-            entry = (capi.Context(model.engine, cap_b, cap_s), cap_b, cap_s)
+            ctx = self._contexts.get(key)
+        if ctx is None:
+            longest = 128  # the engine's limit; a pivot's second pass sees sentences longer than wrap_length
+            ctx = capi.Context(model.engine, max(self.max_words, 1), longest, max_tokens=max(self.max_words, longest))
             with self._lock:
-                self._contexts[key] = entry
-        return entry[0]
+                self._contexts[key] = ctx
+        return ctx
 
     def _run_batch(self, model: Model, batch: List[_Unit]):
         B, S = len(batch), max(len(u.words) for u in batch)
@@ -174,8 +175,8 @@ class Service:
             lens[i] = len(u.words)
         ctx = self._context(model, B, S)
         shortlist = model.shortlist_generator.generate(ids, lens) if model.shortlist_generator else None
-        out_ids, out_len, align = ctx.translate(ids, lens, shortlist, self.limit_factor,
-                                                model.vocabulary.eos_id(), want_align=True)
+        out_ids, out_len, align = ctx.translate_pinned(ids, lens, shortlist, self.limit_factor,
+                                                       model.vocabulary.eos_id(), want_align=True)
         return [(u, out_ids[i, :int(out_len[i])], align[i, :int(out_len[i]), :int(lens[i])]) for i, u in enumerate(batch)]
 
     def _translate_segments(self, model: Model, per_request: List[List[List[int]]]):
@@ -229,7 +230,7 @@ class Service:
 
     def close(self) -> None:
         self._pool.shutdown(wait=True)
-        for ctx, _, _ in self._contexts.values():
+        for ctx in self._contexts.values():
             ctx.close()
         self._contexts.clear()
 
