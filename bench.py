@@ -72,6 +72,8 @@ def parse(argv=None):
                     help="rows per workgroup of the emb-256 encoder: 0 = chosen per call (default), 32, 64")
     ap.add_argument("--kv-policy", type=int, default=0,
                     help="decoder K/V cache loads: 0 = chosen per launch (default), 1 = temporal, 2 = non-temporal")
+    ap.add_argument("--xcd-affinity", type=int, default=-1,
+                    help="home XCDs of a batch's decoder workgroups: -1 = library default, 0 = off, 1 / 2 / 4")
     ap.add_argument("--sustained-steps", type=int, default=40,
                     help="after the timed region, one longer untimed-by-the-driver region of this many steps "
                          "(reported as `sustained`; 0 = skip)")
@@ -298,6 +300,8 @@ def main():
             gm.set_decoder_budget(args.decoder_budget)
         if args.kv_policy:
             gm.set_kv_cache_policy(args.kv_policy)
+        if args.xcd_affinity >= 0:
+            gm.set_xcd_affinity(args.xcd_affinity)
         ctxs = [capi.Context(gm, B, S) for _ in range(W)]
         for c in ctxs:
             c.set_decode_mode(args.decode_mode)

@@ -130,6 +130,13 @@ int slimt_hip_model_set_decoder_budget(slimt_hip_model *model, int workgroups);
  * temporal, 2 = always non-temporal. Results do not depend on it. Needs the
  * decoder admission (budget > 0) for 0 and 2. */
 int slimt_hip_model_set_kv_cache_policy(slimt_hip_model *model, int policy);
+/* XCD-affine placement of the persistent decoder (needs the decoder admission, budget > 0):
+ * 0 (default) = a batch's workgroups run wherever the dispatcher puts them; 1 / 2 / 4 = a batch
+ * of up to 16 / 32 / 64 workgroups is over-launched on every XCD and its tiles are claimed only by
+ * workgroups that find themselves (HW_REG_XCC_ID) on the batch's one / two / four home XCDs, so that the
+ * batch's own shortlisted output layer streams through those L2s only (each MI355X XCD has a private
+ * 4 MB L2). Placement changes speed only; results do not depend on it. */
+int slimt_hip_model_set_xcd_affinity(slimt_hip_model *model, int xcds);
 /* Storage format of the cross-attention K/V cache that slimt_hip_translate* keeps between
  * its encoder and decoder launches (the reference recomputes K and V every step,
  * slimt/Modules.cc:248-249): 0 (default) = the int8 GEMM's 24-bit shifted accumulators where

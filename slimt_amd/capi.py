@@ -28,6 +28,7 @@ SYMBOLS = [
     "slimt_hip_debug_decode_stamps",
     "slimt_hip_debug_occupancy_trace", "slimt_hip_model_set_decoder_budget",
     "slimt_hip_model_set_kv_cache_policy",
+    "slimt_hip_model_set_xcd_affinity",
     "slimt_hip_model_set_kv_cache_format",
     "slimt_hip_shortlist_create", "slimt_hip_shortlist_destroy", "slimt_hip_shortlist_info",
     "slimt_hip_shortlist_generate", "slimt_hip_shortlist_generate_device",
@@ -115,6 +116,7 @@ def lib():
     L.slimt_hip_debug_occupancy_trace.argtypes = [vp, sz]
     L.slimt_hip_model_set_decoder_budget.argtypes = [vp, i32]
     L.slimt_hip_model_set_kv_cache_policy.argtypes = [vp, i32]
+    L.slimt_hip_model_set_xcd_affinity.argtypes = [vp, i32]
     L.slimt_hip_model_set_kv_cache_format.argtypes = [vp, i32]
     L.slimt_hip_ctx_create_budget.argtypes = [vp, sz, sz, sz, vp, vp]
     L.slimt_hip_shortlist_create.argtypes = [vp, sz, sz, sz, i32, i32, i32, vp]
@@ -267,6 +269,10 @@ class Model:
     def set_kv_cache_policy(self, policy: int):
         """0 = per launch (default), 1 = temporal, 2 = non-temporal K/V cache loads in the decoder."""
         _chk(lib().slimt_hip_model_set_kv_cache_policy(self.h, policy))
+
+    def set_xcd_affinity(self, xcds: int):
+        """0 = off (default); 1 / 2 / 4 = a batch's decoder tiles are claimed on that many home XCDs."""
+        _chk(lib().slimt_hip_model_set_xcd_affinity(self.h, xcds))
 
     def set_kv_cache_format(self, fmt: int):
         """0 = packed 24-bit K/V cache where supported (default), 1 = always f32."""

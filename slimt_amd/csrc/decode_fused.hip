@@ -1129,7 +1129,31 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   // independent, so who runs which changes nothing in the results.
   int tile = blockIdx.x;
   if (a.ticket) {
-    if (tid == 0) flags[1] = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
+    if (tid == 0) {
+      if (a.home_mask) {  // XCD-affine claim (kernels.h)
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+        const bool home = (a.home_mask >> (xcc & 31)) & 1u;
+        const unsigned tiles = (unsigned)((B + R - 1) / R);
+        unsigned long long seen = __hip_atomic_load(a.xstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int mine = 0x7fffffff;
+        for (;;) {  // bounded: every failed exchange is another candidate's arrival (at most xgrid of them)
+          const unsigned arrived = (unsigned)(seen >> 32) - a.xarr_base;
+          const unsigned claimed = (unsigned)seen - a.xclaim_base;
+          const unsigned to_come = a.xgrid - (arrived + 1u);
+          const unsigned open_tiles = tiles - (claimed < tiles ? claimed : tiles);
+          const bool take = open_tiles > 0 && (home || to_come < open_tiles);
+          const unsigned long long want = seen + (1ull << 32) + (take ? 1ull : 0ull);
+          if (__hip_atomic_compare_exchange_strong(a.xstate, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT)) {
+            mine = take ? (int)claimed : 0x7fffffff;
+            break;
+          }
+        }
+        flags[1] = mine;
+      } else {
+        flags[1] = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
+      }
+    }
     __syncthreads();
     tile = flags[1];
     if ((unsigned)tile >= (unsigned)((B + R - 1) / R)) return;
@@ -1578,7 +1602,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   FusedDecodeArgs a = a_in;
   if (!fused_decode_supported(D, F, H, a.Ld)) return hipErrorInvalidValue;
   const int rows = fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg);
-  const dim3 grid(fused_decode_grid(a.B, a.ticket != nullptr, rows));
+  const dim3 grid(a.home_mask ? (int)a.xgrid : fused_decode_grid(a.B, a.ticket != nullptr, rows));
   const bool kv24 = a.kv24;
   const bool mid = kv24 && D == 256 && a.S > 32;  // 33..64-token sentences (cache written by encode_tall_kernel<., 4>)
   if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= (D == 256 ? 64 : 32))) return hipErrorInvalidValue;

@@ -567,6 +567,14 @@ extern "C" int slimt_hip_model_set_kv_cache_policy(slimt_hip_model *model, int p
   return 0;
 }
 
+extern "C" int slimt_hip_model_set_xcd_affinity(slimt_hip_model *model, int xcds) {
+  if (!model) return fail(-1, "model is NULL");
+  if (xcds != 0 && xcds != 1 && xcds != 2 && xcds != 4) return fail(-1, "XCD affinity %d not in {0, 1, 2, 4}", xcds);
+  std::lock_guard<std::mutex> lock(model->gate_mu);
+  model->xcd_affinity = xcds;
+  return 0;
+}
+
 extern "C" int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format) {
   if (!model) return fail(-1, "model is NULL");
   if (format < 0 || format > 1) return fail(-1, "K/V cache format %d not in 0..1", format);
@@ -643,8 +651,8 @@ int ctx_alloc(slimt_hip_ctx *c) {
   HIPCHK(c->att.reserve(M * D * 4));
   HIPCHK(c->h8.reserve(M * F));
   HIPCHK(c->a8.reserve(M * D));
-  HIPCHK(c->ticket.reserve(8));  // [0] decoder, [1] fused encoder
-  HIPCHK(hipMemset(c->ticket.p, 0, 8));
+  HIPCHK(c->ticket.reserve(16));  // [0] decoder, [1] fused encoder, [2..3] XCD-affine claim state (64 bits)
+  HIPCHK(hipMemset(c->ticket.p, 0, 16));
   HIPCHK(c->kv.reserve((size_t)m->Ld * 2 * M * D * 4));
   HIPCHK(c->dx.reserve(B * D * 4));
   HIPCHK(c->dx_pre.reserve(B * D * 4));
@@ -1400,11 +1408,34 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       f.kv_nt = t_layers < m->Ld;
       f.kv_temporal_layers = t_layers;
       if (gm->gate_seq >= n) HIPCHK(hipStreamWaitEvent(st, gm->gate_ev[(gm->gate_seq - n) % kRing], 0));
+      const int n_home = gm->xcd_affinity;
+      const bool affine = n_home > 0 && rows == 16 && wgs <= 16 * n_home;
+      if (affine) {
+        if (gm->gate_home.size() < kRing) gm->gate_home.assign(kRing, 0u);
+        unsigned mask = gm->gate_seq >= n ? gm->gate_home[(gm->gate_seq - n) % kRing] : 0u;
+        if (!mask || __builtin_popcount(mask) != n_home) {
+          const unsigned slot = (unsigned)(gm->gate_seq % (size_t)(8 / n_home));
+          mask = n_home == 1 ? 1u << slot : n_home == 2 ? 3u << (2 * slot) : 0xfu << (4 * (slot & 1));
+        }
+        gm->gate_home[gm->gate_seq % kRing] = mask;
+        f.home_mask = mask;
+        f.xstate = reinterpret_cast<unsigned long long *>(c->ticket.as<unsigned>() + 2);
+        f.xarr_base = c->xarr_base;
+        f.xclaim_base = c->xclaim_base;
+        f.xgrid = 8u * (unsigned)((wgs + n_home - 1) / n_home);
+      } else if (!gm->gate_home.empty()) {
+        gm->gate_home[gm->gate_seq % kRing] = 0u;
+      }
       {
         ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);
         HIPCHK(launch_decode_fused(f, m->D, m->F, m->H, st));
       }
-      c->ticket_base += tickets;
+      if (affine) {
+        c->xarr_base += f.xgrid;
+        c->xclaim_base += (unsigned)wgs;
+      } else {
+        c->ticket_base += tickets;
+      }
       HIPCHK(hipEventRecord(gm->gate_ev[gm->gate_seq % kRing], st));
       gm->gate_seq += 1;
       return 0;

@@ -83,6 +83,11 @@ struct slimt_hip_model {
     double kv_bytes;
   };
   std::vector<GateCtx> gate_ctx;
+  // XCD-affine placement of a batch's decoder workgroups (kernels.h, FusedDecodeArgs::home_mask):
+  // 0 = off, 1 / 2 = a batch's tiles are claimed on one / two XCDs. Launch k takes the home of launch
+  // k - n (the one whose end admits it: its CUs are the ones that have just come free).
+  int xcd_affinity = 0;
+  std::vector<unsigned> gate_home;  // ring, parallel to gate_ev: home mask of each admitted launch
   int kv_policy = 0;  // 0 = chosen per launch, 1 = always temporal, 2 = always non-temporal K/V loads
   int kv_format = 0;  // 0 = packed 24-bit cache where the kernels have it (kernels.h, kv24), 1 = always f32
 };
@@ -113,6 +118,7 @@ struct slimt_hip_ctx {
   slimt_hip::DevBuf ticket;      // ticket counter of the over-subscribed decoder launches
   unsigned ticket_base = 0;      // tickets handed out by earlier launches
   unsigned enc_ticket_base = 0;  // the same for the fused encoder (second counter of `ticket`)
+  unsigned xarr_base = 0, xclaim_base = 0;  // XCD-affine claims (64-bit state word behind the two counters)
   slimt_hip::DevBuf kv;  // [Ld][2][B*S][D]
   // decoder workspace
   slimt_hip::DevBuf dx, dx_pre, dh, datt8, dout, df8, state;

@@ -261,6 +261,17 @@ struct FusedDecodeArgs {
   // of every launch takes one ticket; ticket - ticket_base is the tile it runs (or none).
   unsigned *ticket = nullptr;
   unsigned ticket_base = 0;
+  // XCD-affine placement (home_mask != 0; speed only, never correctness): a launch over-subscribes
+  // every XCD with candidates (workgroups are dealt round-robin over the 8 XCDs, whatever their CUs
+  // are doing) and a candidate claims a tile only on a HOME XCD of this batch (bit XCC_ID of
+  // home_mask) -- so that the batch's own shortlisted output layer (1 MB) is streamed through ONE
+  // (or two) 4 MB L2 instead of all eight -- or when fewer candidates are still to arrive than tiles
+  // are unclaimed (then anyone takes one: every tile is claimed whatever the dispatcher does).
+  // *xstate = {arrivals : 32 | claimed : 32} of all launches so far (never reset); xarr_base /
+  // xclaim_base = its halves before this launch; xgrid = candidates of this launch.
+  unsigned long long *xstate = nullptr;
+  unsigned home_mask = 0;
+  unsigned xarr_base = 0, xclaim_base = 0, xgrid = 0;
   // Packed K/V cache (D = 256 / d_head 32: S <= 32 written by encode_fused / encode_tall, 33..64 by
   // encode_tall; D = 512 / d_head 64, S <= 32, by encode_wide): every cached value is the int8 GEMM's accumulator as a 24-bit
   // integer -- the shifted one, accS = acc + 127 colsum, at K = 256 (|accS| < 2^23), the signed

@@ -13,6 +13,8 @@ B, S, n_sl = 256, 32, 4096
 dev = torch.device("cuda", 0)
 m = synth.make_model("tiny11", seed=1234, eos_bias=-100.0)
 gm = capi.Model(m)
+if os.environ.get("SLIMT_XCD_AFFINITY"):
+    gm.set_xcd_affinity(int(os.environ["SLIMT_XCD_AFFINITY"]))
 ctxs = [capi.Context(gm, B, S) for _ in range(W)]
 for c in ctxs:
     c.set_decode_mode(int(os.environ.get("SLIMT_DECODE_MODE", "0")))  # 3 = 32 sentences per workgroup

@@ -12,7 +12,7 @@ while read -r c; do
   [ -z "$c" ] && continue
   i=$((i+1))
   rm -rf gpurun_out/pmc_${TAG}_$i
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_${TAG}_$i -- python3 bench.py --batch ${BATCH:-4096} --workers 1 --steps 2 --warmup 1 --sustained-steps 0 --no-cpu-baseline --profile-kernel none > gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pmc set $i ($c) failed"; tail -3 gpurun_out/pmc_${TAG}_$i.log; continue; }
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_${TAG}_$i -- python3 bench.py ${PRESET:+--preset $PRESET} --batch ${BATCH:-4096} --workers 1 --steps 2 --warmup 1 --sustained-steps 0 --no-cpu-baseline --profile-kernel none > gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pmc set $i ($c) failed"; tail -3 gpurun_out/pmc_${TAG}_$i.log; continue; }
   f=$(ls gpurun_out/pmc_${TAG}_$i/*/*counter_collection.csv | head -1)
   python3 - "$f" <<'PY' | tee -a gpurun_out/${TAG}_sq_pmc.txt
 import csv, sys, collections
@@ -28,4 +28,6 @@ done <<'SETS'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES
 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVES SQ_INSTS_VMEM_WR
+TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU_CVT
 SETS
