@@ -310,6 +310,21 @@ int slimt_hip_translate_device_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist
                                          uint32_t *d_out_ids, uint32_t *d_out_len, float *d_align,
                                          int steps_hint);
 
+/* The same on HOST buffers -- Model::forward as the reference's workers call it (Model.cc:111-204),
+ * shortlist step included: _translate_generated waits for the result, _translate_async_generated
+ * queues the work on ctx's stream like slimt_hip_translate_async (same buffer rules: with every
+ * array pinned the kernels read ids / lengths from, and write tokens, lengths and alignment rows to,
+ * host memory themselves; nothing is copied, nothing synchronises, and no host shortlist exists at
+ * all). A handle may be shared by every context of its device. */
+int slimt_hip_translate_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *shortlist,
+                                  const uint32_t *src_ids, const uint32_t *lengths, size_t B, size_t S,
+                                  float limit_factor, uint32_t eos_id, uint32_t *out_ids,
+                                  uint32_t *out_len, float *align);
+int slimt_hip_translate_async_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *shortlist,
+                                        const uint32_t *src_ids, const uint32_t *lengths, size_t B,
+                                        size_t S, float limit_factor, uint32_t eos_id,
+                                        uint32_t *out_ids, uint32_t *out_len, float *align);
+
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, HIP events bracket every launch of kernel family `kernel_id`
  * on the ctx stream; slimt_hip_profile_read returns the number of launches

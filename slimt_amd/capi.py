@@ -32,7 +32,7 @@ SYMBOLS = [
     "slimt_hip_model_set_kv_cache_format",
     "slimt_hip_shortlist_create", "slimt_hip_shortlist_destroy", "slimt_hip_shortlist_info",
     "slimt_hip_shortlist_generate", "slimt_hip_shortlist_generate_device",
-    "slimt_hip_translate_device_generated",
+    "slimt_hip_translate_device_generated", "slimt_hip_translate_generated", "slimt_hip_translate_async_generated",
     "slimt_hip_translate_async", "slimt_hip_host_alloc", "slimt_hip_host_free",
     "slimt_hip_encode_embedded", "slimt_hip_decode_begin_from", "slimt_hip_decode_step_states",
 ]
@@ -125,6 +125,8 @@ def lib():
     L.slimt_hip_shortlist_generate.argtypes = [vp, vp, vp, sz, sz, vp, vp]
     L.slimt_hip_shortlist_generate_device.argtypes = [vp, vp, vp, vp, sz, sz, vp, vp]
     L.slimt_hip_translate_device_generated.argtypes = [vp, vp, vp, vp, sz, sz, f32, u32, vp, vp, vp, i32]
+    L.slimt_hip_translate_generated.argtypes = [vp, vp, vp, vp, sz, sz, f32, u32, vp, vp, vp]
+    L.slimt_hip_translate_async_generated.argtypes = [vp, vp, vp, vp, sz, sz, f32, u32, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("slimt_hip_abi_version",):
@@ -392,28 +394,56 @@ class Context:
                                        _p(out_ids), _p(out_len), _p(align)))
         return out_ids, out_len, align
 
+    def pinned_buffers(self, B: int, S: int, limit_factor: float = 1.5, want_align: bool = False):
+        """This context's pinned staging arrays for a [B,S] batch: (ids, lengths, out_ids, out_len, align|None)."""
+        T = max(int(np.float32(limit_factor) * np.float32(S)), 1)
+        pin = lambda name: self._pinned.setdefault(name, _Pinned())
+        return (pin("ids").array(np.uint32, (B, S)), pin("len").array(np.uint32, (B,)),
+                pin("out").array(np.uint32, (B, T)), pin("ol").array(np.uint32, (B,)),
+                pin("al").array(np.float32, (B, T, S)) if want_align else None)
+
+    def translate_async(self, bufs, shortlist=None, generator=None, limit_factor: float = 1.5, eos_id: int = 0):
+        """slimt_hip_translate_async[_generated] on arrays from pinned_buffers() (already filled);
+        synchronize() before reading the outputs. `generator`: a ShortlistGenerator -- the batch's
+        lexical shortlist is then generated on this context's stream (Model.cc:117-120)."""
+        p_ids, p_len, p_out, p_ol, p_al = bufs
+        B, S = p_ids.shape
+        if generator is not None:
+            _chk(lib().slimt_hip_translate_async_generated(self.h, generator.h, _p(p_ids), _p(p_len), B, S,
+                                                           limit_factor, eos_id, _p(p_out), _p(p_ol), _p(p_al)))
+            return
+        sl = None if shortlist is None else np.ascontiguousarray(shortlist, dtype=np.uint32)
+        _chk(lib().slimt_hip_translate_async(self.h, _p(p_ids), _p(p_len), B, S, _p(sl), 0 if sl is None else sl.size,
+                                             limit_factor, eos_id, _p(p_out), _p(p_ol), _p(p_al)))
+
     def translate_pinned(self, ids, lengths, shortlist=None, limit_factor: float = 1.5, eos_id: int = 0,
-                         want_align: bool = False):
+                         want_align: bool = False, generator=None):
         """translate() through this context's pinned staging buffers and slimt_hip_translate_async:
         the persistent kernels then read and write host memory themselves, no copy is queued (host
         pipelines with several contexts: copies of one stream wait behind other streams' kernels).
         Returns copies of out_ids [B,Tmax], out_len [B], align|None."""
         ids = np.asarray(ids)
         B, S = ids.shape
-        T = max(int(np.float32(limit_factor) * np.float32(S)), 1)
-        pin = lambda name: self._pinned.setdefault(name, _Pinned())
-        p_ids = pin("ids").array(np.uint32, (B, S))
-        p_len = pin("len").array(np.uint32, (B,))
-        p_out = pin("out").array(np.uint32, (B, T))
-        p_ol = pin("ol").array(np.uint32, (B,))
-        p_al = pin("al").array(np.float32, (B, T, S)) if want_align else None
-        p_ids[...] = ids
-        p_len[...] = lengths
-        sl = None if shortlist is None else np.ascontiguousarray(shortlist, dtype=np.uint32)
-        _chk(lib().slimt_hip_translate_async(self.h, _p(p_ids), _p(p_len), B, S, _p(sl), 0 if sl is None else sl.size,
-                                             limit_factor, eos_id, _p(p_out), _p(p_ol), _p(p_al)))
+        bufs = self.pinned_buffers(B, S, limit_factor, want_align)
+        bufs[0][...] = ids
+        bufs[1][...] = lengths
+        self.translate_async(bufs, shortlist, generator, limit_factor, eos_id)
         self.synchronize()
-        return p_out.copy(), p_ol.copy(), (p_al.copy() if want_align else None)
+        return bufs[2].copy(), bufs[3].copy(), (bufs[4].copy() if want_align else None)
+
+    def translate_generated(self, generator, ids, lengths, limit_factor: float = 1.5, eos_id: int = 0,
+                            want_align: bool = False):
+        """Model::forward with its shortlist step (slimt_hip_translate_generated): host arrays, blocking."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        B, S = ids.shape
+        T = max(int(np.float32(limit_factor) * np.float32(S)), 1)
+        out_ids = np.zeros((B, T), dtype=np.uint32)
+        out_len = np.zeros(B, dtype=np.uint32)
+        align = np.zeros((B, T, S), dtype=np.float32) if want_align else None
+        _chk(lib().slimt_hip_translate_generated(self.h, generator.h, _p(ids), _p(lengths), B, S, limit_factor,
+                                                 eos_id, _p(out_ids), _p(out_len), _p(align)))
+        return out_ids, out_len, align
 
     def translate_device(self, d_ids: int, d_lengths: int, B: int, S: int, d_shortlist: int,
                          n_shortlist: int, limit_factor: float, eos_id: int, d_out_ids: int,

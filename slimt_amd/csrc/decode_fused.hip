@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   for (int rr = 0; rr < RT; ++rr) {
     if (live[rr]) {  // outputs past a sentence's length read as zero (no memset launches)
       for (int i = lane; i < a.Tmax; i += 64) a.out_ids[(size_t)bq[rr] * a.Tmax + i] = 0;
-      if (a.align)
+      if (a.align && !a.align_out)
         for (int i = lane; i < a.Tmax * S; i += 64) a.align[(size_t)bq[rr] * a.Tmax * S + i] = 0.0f;
     }
     // step-0 embedding: zeros * sqrt(D) + pos(0)  (Transformer.cc:138-144,160)
@@ -1534,6 +1534,38 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr)
     if (live[rr] && lane == 0) a.out_len[bq[rr]] = n_out[rr];
+  if (a.align && a.align_out) {
+    // staged alignment rows -> their destination (kernels.h, align_out). This wave wrote the rows it
+    // reads (rows 0 .. n_out - 1, columns 0 .. len - 1); everything else is zero.
+#pragma unroll 1
+    for (int rr = 0; rr < RT; ++rr) {
+      if (!live[rr]) continue;
+      const size_t base = (size_t)bq[rr] * a.Tmax * S;
+      const int rows_set = (int)n_out[rr] < a.Tmax ? (int)n_out[rr] : a.Tmax;
+      const int n = a.Tmax * S, ln = len[rr];
+      if (((base | (size_t)S) & 3) == 0 && (reinterpret_cast<size_t>(a.align_out) & 15) == 0 &&
+          (reinterpret_cast<size_t>(a.align) & 15) == 0) {  // 16-byte pieces: four columns of one row
+        const f4 *src = reinterpret_cast<const f4 *>(a.align + base);
+        f4 *dst = reinterpret_cast<f4 *>(a.align_out + base);
+        for (int i = lane; i < n / 4; i += 64) {
+          const int row = (4 * i) / S, col = (4 * i) % S;
+          f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (row < rows_set && col < ln) {
+            v = src[i];
+            if (col + 1 >= ln) v.y = 0.0f;
+            if (col + 2 >= ln) v.z = 0.0f;
+            if (col + 3 >= ln) v.w = 0.0f;
+          }
+          dst[i] = v;
+        }
+      } else {
+        for (int i = lane; i < n; i += 64) {
+          const int row = i / S, col = i % S;
+          a.align_out[base + i] = (row < rows_set && col < ln) ? a.align[base + i] : 0.0f;
+        }
+      }
+    }
+  }
   if (tid == 0) occ_trace_event(a.trace, 1, 1);
 }
 

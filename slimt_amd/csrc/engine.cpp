@@ -796,6 +796,7 @@ extern "C" int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx) {
   // thread per context waiting here for milliseconds -- a dozen spinning threads take the cores
   // the runtime's own threads and the batch builders need (the Service with 8 workers: 11.7 ->
   // 13.3 M tok/s once the waiters sleep).
+  HIPCHK(hipSetDevice(ctx->model->device));  // the event is created and recorded on the context's device, whatever the caller's is
   if (!ctx->sync_event) HIPCHK(hipEventCreateWithFlags(&ctx->sync_event, hipEventBlockingSync | hipEventDisableTiming));
   HIPCHK(hipEventRecord(ctx->sync_event, ctx->stream));
   HIPCHK(hipEventSynchronize(ctx->sync_event));
@@ -1249,7 +1250,11 @@ int decoder_layers(slimt_hip_ctx *c, float *d_align, int Tmax, const uint32_t *d
 int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_lengths,
                      const uint32_t *d_shortlist, size_t B, size_t S, size_t n_sl,
                      float limit_factor, uint32_t eos_id, uint32_t *d_out_ids, uint32_t *d_out_len,
-                     float *d_align, int steps_hint, const uint32_t *d_n_sl = nullptr) {
+                     float *d_align, int steps_hint, const uint32_t *d_n_sl = nullptr,
+                     float *align_out = nullptr) {
+  // align_out != nullptr (persistent decoder only): d_align is a staging buffer in device memory and
+  // the decoder copies each sentence's rows from there to align_out when its loop ends (see
+  // FusedDecodeArgs::align_out)
   // d_n_sl != nullptr: the shortlist was generated on this stream; its size is on
   // the device and n_sl is only the capacity of d_shortlist (persistent kernels only)
   const slimt_hip_model *m = c->model;
@@ -1292,8 +1297,10 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       HIPCHK(hipMemcpyAsync(c->ids.p, d_ids, B * S * 4, hipMemcpyDeviceToDevice, st));
     if (d_lengths != c->lengths.as<uint32_t>())
       HIPCHK(hipMemcpyAsync(c->lengths.p, d_lengths, B * 4, hipMemcpyDeviceToDevice, st));
-    if (n_sl && d_shortlist != c->shortlist.as<uint32_t>())
+    if (n_sl && d_shortlist != c->shortlist.as<uint32_t>()) {
+      c->sl_host.clear();  // ctx->shortlist no longer holds what translate_host uploaded last
       HIPCHK(hipMemcpyAsync(c->shortlist.p, d_shortlist, n_sl * 4, hipMemcpyDeviceToDevice, st));
+    }
     d_lengths = c->lengths.as<uint32_t>();
     d_shortlist = c->shortlist.as<uint32_t>();
     RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr));
@@ -1349,6 +1356,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.out_ids = d_out_ids;
     f.out_len = d_out_len;
     f.align = d_align;
+    f.align_out = d_align ? align_out : nullptr;
     f.trace = g_occ_trace;
     f.ticket = c->ticket.as<unsigned>();
     f.ticket_base = c->ticket_base;  // advanced below, once the launch is in the stream
@@ -1488,6 +1496,52 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
 
 }  // namespace
 
+namespace {
+// the device view of a pinned host allocation (hipHostMalloc / slimt_hip_host_alloc), else nullptr
+void *host_device_view(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
+}
+
+void shortlist_args(const slimt_hip_shortlist *sl, const uint32_t *d_ids, const uint32_t *d_len,
+                    size_t B, size_t S, uint32_t *d_out, uint32_t *d_n, ShortlistArgs &a);
+int shortlist_scratch(DevBuf &buf, const slimt_hip_shortlist *sl, hipStream_t st);
+
+// Model::forward's order (Model.cc:117-120): the batch's shortlist first -- generated on ctx's
+// stream into ctx->shortlist -- then translate_device with it. Arrays the device can read.
+int translate_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const uint32_t *d_src_ids,
+                        const uint32_t *d_lengths, size_t B, size_t S, float limit_factor, uint32_t eos_id,
+                        uint32_t *d_out_ids, uint32_t *d_out_len, float *d_align, int steps_hint,
+                        float *align_out) {
+  const slimt_hip_model *m = ctx->model;
+  hipStream_t st = ctx->stream;
+  ctx->sl_host.clear();  // ctx->shortlist no longer holds what translate_host uploaded last
+  HIPCHK(ctx->n_sl_dev.reserve(4));
+  RCCHK(shortlist_scratch(ctx->sl_scratch, sl, st));
+  ShortlistArgs a;
+  shortlist_args(sl, d_src_ids, d_lengths, B, S, ctx->shortlist.as<uint32_t>(),
+                 ctx->n_sl_dev.as<uint32_t>(), a);
+  a.scratch = ctx->sl_scratch.as<uint32_t>();
+  HIPCHK(launch_shortlist_generate(a, st));
+  const bool lean = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
+                    (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
+                     long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
+  if (lean)  // the size stays on the device: capacity V, actual count read by the kernels
+    return translate_device(ctx, d_src_ids, d_lengths, ctx->shortlist.as<uint32_t>(), B, S,
+                            (size_t)m->V, limit_factor, eos_id, d_out_ids, d_out_len, d_align,
+                            steps_hint, ctx->n_sl_dev.as<uint32_t>(), align_out);
+  uint32_t n = 0;  // stage kernels are sized on the host: one 4-byte read-back
+  HIPCHK(hipMemcpyAsync(&n, ctx->n_sl_dev.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return translate_device(ctx, d_src_ids, d_lengths, ctx->shortlist.as<uint32_t>(), B, S, n,
+                          limit_factor, eos_id, d_out_ids, d_out_len, d_align, steps_hint);
+}
+}  // namespace
+
 extern "C" int slimt_hip_translate_device(slimt_hip_ctx *ctx, const uint32_t *d_src_ids,
                                           const uint32_t *d_lengths, size_t B, size_t S,
                                           const uint32_t *d_shortlist, size_t n_shortlist,
@@ -1525,9 +1579,10 @@ int translate_host(slimt_hip_ctx *ctx, const uint32_t *src_ids, const uint32_t *
   // the shortlist is read at random every step: it stays on the device, uploaded when it changes
   if (n_shortlist && (ctx->sl_host.size() != n_shortlist ||
                       std::memcmp(ctx->sl_host.data(), shortlist, n_shortlist * 4) != 0)) {
+    ctx->sl_host.clear();  // until the upload has succeeded the device copy is nobody's
+    HIPCHK(hipMemcpyAsync(ctx->shortlist.p, shortlist, n_shortlist * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // (the caller's array may be pageable: the copy is staged; done once per shortlist)
     ctx->sl_host.assign(shortlist, shortlist + n_shortlist);
-    HIPCHK(hipMemcpyAsync(ctx->shortlist.p, ctx->sl_host.data(), n_shortlist * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));  // (sl_host is pageable: the copy is staged; done once per shortlist)
   }
   // Asynchronous callers with PINNED buffers (hipHostMalloc / slimt_hip_host_alloc): the persistent
   // kernels read the ids / lengths and write tokens, lengths and alignments in host memory themselves
@@ -1538,21 +1593,18 @@ int translate_host(slimt_hip_ctx *ctx, const uint32_t *src_ids, const uint32_t *
                           (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                            long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
   if (!wait && persistent) {
-    auto device_view = [](const void *p) -> void * {
-      hipPointerAttribute_t a;
-      if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-      }
-      return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
-    };
-    void *v_ids = device_view(src_ids), *v_len = device_view(lengths), *v_out = device_view(out_ids),
-         *v_ol = device_view(out_len), *v_al = align ? device_view(align) : nullptr;
+    void *v_ids = host_device_view(src_ids), *v_len = host_device_view(lengths), *v_out = host_device_view(out_ids),
+         *v_ol = host_device_view(out_len), *v_al = align ? host_device_view(align) : nullptr;
     if (v_ids && v_len && v_out && v_ol && (!align || v_al)) {
+      // alignment rows (Model.cc:84-108) are staged in device memory and leave for the host once per
+      // sentence, as whole 16-byte stores when its loop ends: written row by row across PCIe from
+      // inside the step loop they cost the Service 28 % (12.9 against 17.9 M tok/s)
+      if (align) HIPCHK(ctx->align.reserve(B * Tmax * S * 4));
       RCCHK(translate_device(ctx, static_cast<const uint32_t *>(v_ids), static_cast<const uint32_t *>(v_len),
                              ctx->shortlist.as<uint32_t>(), B, S, n_shortlist, limit_factor, eos_id,
                              static_cast<uint32_t *>(v_out), static_cast<uint32_t *>(v_ol),
-                             static_cast<float *>(v_al), (int)Tmax));
+                             align ? ctx->align.as<float>() : nullptr, (int)Tmax, nullptr,
+                             static_cast<float *>(v_al)));
       return 0;
     }
   }
@@ -1670,9 +1722,11 @@ extern "C" int slimt_hip_decode_begin(slimt_hip_ctx *ctx, const uint32_t *shortl
   for (size_t i = 0; i < n_shortlist; ++i)
     if (shortlist[i] >= (uint32_t)m->V) return fail(-1, "shortlist id %u out of range", shortlist[i]);
   HIPCHK(hipSetDevice(m->device));
-  if (n_shortlist)
+  if (n_shortlist) {
+    ctx->sl_host.clear();  // ctx->shortlist no longer holds what translate_host uploaded last
     HIPCHK(hipMemcpyAsync(ctx->shortlist.p, shortlist, n_shortlist * 4, hipMemcpyHostToDevice,
                           ctx->stream));
+  }
   RCCHK(decode_setup(ctx, n_shortlist));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -1988,25 +2042,69 @@ extern "C" int slimt_hip_translate_device_generated(slimt_hip_ctx *ctx, slimt_hi
   if (sl->target_vocab != (size_t)m->V)
     return fail(-1, "shortlist target vocabulary %zu != model vocabulary %d", sl->target_vocab, m->V);
   HIPCHK(hipSetDevice(m->device));
+  return translate_generated(ctx, sl, d_src_ids, d_lengths, B, S, limit_factor, eos_id, d_out_ids, d_out_len,
+                             d_align, steps_hint, nullptr);
+}
+
+namespace {
+// Model::forward (Model.cc:111-204) on HOST buffers with the batch's lexical shortlist generated on
+// the device (Model.cc:117-120): no host shortlist, no upload, no synchronisation in the
+// asynchronous form.
+int translate_host_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const uint32_t *src_ids,
+                             const uint32_t *lengths, size_t B, size_t S, float limit_factor,
+                             uint32_t eos_id, uint32_t *out_ids, uint32_t *out_len, float *align, bool wait) {
+  if (!ctx || !sl || !src_ids || !lengths || !out_ids || !out_len) return fail(-1, "null argument");
+  RCCHK(check_batch(ctx, B, S));
+  const slimt_hip_model *m = ctx->model;
+  if (sl->device != m->device) return fail(-1, "shortlist and context are on different devices");
+  if (sl->target_vocab != (size_t)m->V)
+    return fail(-1, "shortlist target vocabulary %zu != model vocabulary %d", sl->target_vocab, m->V);
+  const uint32_t vmax = (uint32_t)std::min((size_t)m->V, sl->source_vocab);
+  for (size_t i = 0; i < B * S; ++i)
+    if (src_ids[i] >= vmax) return fail(-1, "token id %u out of range", src_ids[i]);
+  for (size_t i = 0; i < B; ++i)
+    if (lengths[i] > S) return fail(-1, "length %u > S", lengths[i]);
+  HIPCHK(hipSetDevice(m->device));
   hipStream_t st = ctx->stream;
-  // Model::forward's order (Model.cc:117-120): the batch's shortlist first
-  HIPCHK(ctx->n_sl_dev.reserve(4));
-  RCCHK(shortlist_scratch(ctx->sl_scratch, sl, st));
-  ShortlistArgs a;
-  shortlist_args(sl, d_src_ids, d_lengths, B, S, ctx->shortlist.as<uint32_t>(),
-                 ctx->n_sl_dev.as<uint32_t>(), a);
-  a.scratch = ctx->sl_scratch.as<uint32_t>();
-  HIPCHK(launch_shortlist_generate(a, st));
-  const bool lean = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
-                    (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
-                     long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
-  if (lean)  // the size stays on the device: capacity V, actual count read by the kernels
-    return translate_device(ctx, d_src_ids, d_lengths, ctx->shortlist.as<uint32_t>(), B, S,
-                            (size_t)m->V, limit_factor, eos_id, d_out_ids, d_out_len, d_align,
-                            steps_hint, ctx->n_sl_dev.as<uint32_t>());
-  uint32_t n = 0;  // stage kernels are sized on the host: one 4-byte read-back
-  HIPCHK(hipMemcpyAsync(&n, ctx->n_sl_dev.p, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  return translate_device(ctx, d_src_ids, d_lengths, ctx->shortlist.as<uint32_t>(), B, S, n,
-                          limit_factor, eos_id, d_out_ids, d_out_len, d_align, steps_hint);
+  const size_t Tmax = std::max<size_t>(1, (size_t)(limit_factor * (float)S));
+  const bool persistent = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
+                          (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
+                           long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
+  if (!wait && persistent) {  // pinned buffers: the kernels read and write host memory themselves (translate_host)
+    void *v_ids = host_device_view(src_ids), *v_len = host_device_view(lengths), *v_out = host_device_view(out_ids),
+         *v_ol = host_device_view(out_len), *v_al = align ? host_device_view(align) : nullptr;
+    if (v_ids && v_len && v_out && v_ol && (!align || v_al)) {
+      if (align) HIPCHK(ctx->align.reserve(B * Tmax * S * 4));
+      return translate_generated(ctx, sl, static_cast<const uint32_t *>(v_ids), static_cast<const uint32_t *>(v_len),
+                                 B, S, limit_factor, eos_id, static_cast<uint32_t *>(v_out),
+                                 static_cast<uint32_t *>(v_ol), align ? ctx->align.as<float>() : nullptr,
+                                 (int)Tmax, static_cast<float *>(v_al));
+    }
+  }
+  HIPCHK(ctx->out_ids.reserve(B * Tmax * 4));
+  if (align) HIPCHK(ctx->align.reserve(B * Tmax * S * 4));
+  HIPCHK(hipMemcpyAsync(ctx->ids.p, src_ids, B * S * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->lengths.p, lengths, B * 4, hipMemcpyHostToDevice, st));
+  RCCHK(translate_generated(ctx, sl, ctx->ids.as<uint32_t>(), ctx->lengths.as<uint32_t>(), B, S, limit_factor,
+                            eos_id, ctx->out_ids.as<uint32_t>(), ctx->out_len.as<uint32_t>(),
+                            align ? ctx->align.as<float>() : nullptr, wait ? 0 : (int)Tmax, nullptr));
+  HIPCHK(hipMemcpyAsync(out_ids, ctx->out_ids.p, B * Tmax * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(out_len, ctx->out_len.p, B * 4, hipMemcpyDeviceToHost, st));
+  if (align) HIPCHK(hipMemcpyAsync(align, ctx->align.p, B * Tmax * S * 4, hipMemcpyDeviceToHost, st));
+  if (wait) HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+}  // namespace
+
+extern "C" int slimt_hip_translate_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const uint32_t *src_ids,
+                                             const uint32_t *lengths, size_t B, size_t S, float limit_factor,
+                                             uint32_t eos_id, uint32_t *out_ids, uint32_t *out_len, float *align) {
+  return translate_host_generated(ctx, sl, src_ids, lengths, B, S, limit_factor, eos_id, out_ids, out_len, align, true);
+}
+
+extern "C" int slimt_hip_translate_async_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl,
+                                                   const uint32_t *src_ids, const uint32_t *lengths, size_t B,
+                                                   size_t S, float limit_factor, uint32_t eos_id,
+                                                   uint32_t *out_ids, uint32_t *out_len, float *align) {
+  return translate_host_generated(ctx, sl, src_ids, lengths, B, S, limit_factor, eos_id, out_ids, out_len, align, false);
 }

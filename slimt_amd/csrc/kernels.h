@@ -253,6 +253,12 @@ struct FusedDecodeArgs {
   uint32_t *out_ids = nullptr;  // [B][Tmax]
   uint32_t *out_len = nullptr;  // [B]
   float *align = nullptr;       // nullable [B][Tmax][S]
+  // nullable: `align` is then a staging buffer in device memory (rows written as the steps go, nothing
+  // else initialised) and each sentence's [Tmax][S] block is written HERE once, when its loop has
+  // ended -- zeros outside the recorded rows / beyond the sentence's length -- as 16-byte stores:
+  // the form for a destination in pinned host memory (one burst across PCIe per sentence instead of
+  // a 4-byte-per-lane store per step).
+  float *align_out = nullptr;
   float *attn = nullptr;        // nullable debug [B][H][S]
   unsigned long long *stamps = nullptr;  // nullable diagnostic [64] phase stamps
   int stamp_step = 0;

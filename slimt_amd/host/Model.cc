@@ -81,6 +81,14 @@ void Worker::forward_async(const uint32_t *ids, const uint32_t *lengths, size_t 
     raise("slimt_hip_translate_async");
 }
 
+void Worker::forward_async_generated(slimt_hip_shortlist *generator, const uint32_t *ids,
+                                     const uint32_t *lengths, size_t B, size_t S, float limit_factor,
+                                     uint32_t *out_ids, uint32_t *out_len, float *align) {
+  if (slimt_hip_translate_async_generated(ctx_, generator, ids, lengths, B, S, limit_factor,
+                                          model_.config().eos_id, out_ids, out_len, align))
+    raise("slimt_hip_translate_async_generated");
+}
+
 void Worker::wait() {
   if (slimt_hip_ctx_synchronize(ctx_)) raise("slimt_hip_ctx_synchronize");
 }

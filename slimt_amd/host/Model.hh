@@ -26,6 +26,7 @@ struct Hypothesis {  // slimt/Types.hh:55-61
   Words target;
   Alignment alignment;
   size_t padded_length = 0;  // diagnostic: the S of the batch this sentence was translated in
+  uint64_t batch = 0;        // diagnostic: serial number of that batch (Service: batches in launch order)
 };
 using History = std::shared_ptr<Hypothesis>;
 using Histories = std::vector<History>;
@@ -93,6 +94,11 @@ class Worker {
   void forward_async(const uint32_t *ids, const uint32_t *lengths, size_t B, size_t S,
                      const uint32_t *shortlist, size_t n_shortlist, float limit_factor,
                      uint32_t *out_ids, uint32_t *out_len, float *align);
+  // The same with the batch's lexical shortlist generated on the device, on this worker's stream,
+  // from the ids themselves (Model.cc:117-120; slimt_hip_translate_async_generated).
+  void forward_async_generated(slimt_hip_shortlist *generator, const uint32_t *ids, const uint32_t *lengths,
+                               size_t B, size_t S, float limit_factor, uint32_t *out_ids, uint32_t *out_len,
+                               float *align);
   void wait();
 
  private:

@@ -117,6 +117,7 @@ struct Service::Slot {
   Pinned<float> align;
   std::vector<Unit> batch;  // non-empty while a translate is in flight on this slot
   size_t B = 0, S = 0, T = 0;
+  uint64_t serial = 0;
 };
 
 Service::Service(const ServiceConfig &config, std::vector<const Model *> replicas)
@@ -126,9 +127,27 @@ Service::Service(const ServiceConfig &config, std::vector<const Model *> replica
       queue_(config.max_words, longest_) {
   if (replicas.empty()) throw std::invalid_argument("Service needs at least one model replica");
   if (config.workers_per_device == 0) throw std::invalid_argument("Service needs at least one worker");
-  for (const Model *model : replicas)
+  config_.lexical_shortlist = View{};  // borrowed for this constructor only
+  std::vector<slimt_hip_shortlist *> generator_of(replicas.size(), nullptr);
+  if (config.lexical_shortlist.data) {
+    std::vector<int> devices;
+    for (size_t r = 0; r < replicas.size(); ++r) {
+      const int device = replicas[r]->config().device;
+      size_t g = 0;
+      while (g < devices.size() && devices[g] != device) ++g;
+      if (g == devices.size()) {
+        devices.push_back(device);
+        generators_.push_back(std::make_unique<ShortlistGenerator>(
+            config.lexical_shortlist, config.source_vocab, config.target_vocab, config.shortlist_shared_vocab,
+            config.shortlist_check, device));
+      }
+      generator_of[r] = generators_[g]->handle();
+    }
+  }
+  live_workers_ = replicas.size() * config.workers_per_device;
+  for (size_t r = 0; r < replicas.size(); ++r)
     for (size_t w = 0; w < config.workers_per_device; ++w)
-      threads_.emplace_back([this, model]() { work(model); });
+      threads_.emplace_back([this, model = replicas[r], generator = generator_of[r]]() { work(model, generator); });
 }
 
 Service::~Service() {
@@ -154,6 +173,10 @@ std::future<Histories> Service::translate(std::vector<Words> sentences) {
   {
     std::lock_guard<std::mutex> lock(mutex_);
     if (closing_) throw std::runtime_error("Service is shutting down");
+    if (live_workers_ == 0) {  // every worker has failed: nobody would ever take this request
+      pending->fail(dead_error_);
+      return result;
+    }
     const uint64_t seq = sequence_++;
     for (size_t i = 0; i < pending->size(); ++i) {
       Unit u;
@@ -175,17 +198,31 @@ std::vector<Unit> Service::next_batch(bool may_block) {
   return queue_.take();
 }
 
-void Service::launch(Slot &slot, std::vector<Unit> batch) {
-  const size_t B = batch.size();
-  const size_t S = batch.back().length;  // lengths ascend inside a batch
+void Service::launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *generator) {
+  // the slot owns the batch from here on: whatever throws below, the caller fails slot.batch
+  slot.batch = std::move(batch);
+  batch.clear();
+  const size_t B = slot.batch.size();
+  const size_t S = slot.batch.back().length;  // lengths ascend inside a batch
   const size_t T = std::max<size_t>(1, static_cast<size_t>(config_.tgt_length_limit_factor * static_cast<float>(S)));
+  slot.B = B;
+  slot.S = S;
+  slot.T = T;
+  slot.serial = batches_.fetch_add(1, std::memory_order_relaxed);
   uint32_t *ids = slot.ids.ensure(B * S);
   uint32_t *lengths = slot.lengths.ensure(B);
   std::fill(ids, ids + B * S, config_.pad_id);
   for (size_t b = 0; b < B; ++b) {
-    const Words &w = batch[b].owner->sentence(batch[b].index);
+    const Words &w = slot.batch[b].owner->sentence(slot.batch[b].index);
     std::copy(w.begin(), w.end(), ids + b * S);
     lengths[b] = static_cast<uint32_t>(w.size());
+  }
+  uint32_t *out_ids = slot.out_ids.ensure(B * T), *out_len = slot.out_len.ensure(B);
+  float *align = config_.alignments ? slot.align.ensure(B * T * S) : nullptr;
+  if (generator) {  // the batch's own lexical shortlist, generated on the worker's stream (Model.cc:117-120)
+    slot.worker->forward_async_generated(generator, ids, lengths, B, S, config_.tgt_length_limit_factor, out_ids,
+                                         out_len, align);
+    return;
   }
   const uint32_t *sl = nullptr;
   size_t n_sl = 0;
@@ -193,26 +230,39 @@ void Service::launch(Slot &slot, std::vector<Unit> batch) {
     n_sl = config_.shortlist->size();
     sl = slot.shortlist.get();
   }
-  slot.B = B;
-  slot.S = S;
-  slot.T = T;
-  slot.batch = std::move(batch);
-  slot.worker->forward_async(ids, lengths, B, S, sl, n_sl, config_.tgt_length_limit_factor,
-                             slot.out_ids.ensure(B * T), slot.out_len.ensure(B),
-                             config_.alignments ? slot.align.ensure(B * T * S) : nullptr);
+  slot.worker->forward_async(ids, lengths, B, S, sl, n_sl, config_.tgt_length_limit_factor, out_ids, out_len, align);
 }
 
 void Service::finish(Slot &slot) {
-  std::vector<Unit> batch = std::move(slot.batch);
-  slot.batch.clear();
+  // the batch stays in the slot until its results are in hand: if the wait fails, the caller
+  // fails slot.batch with the error (its requests then see the HIP error, not a broken promise)
   slot.worker->wait();
   Histories histories = collect(slot.out_ids.get(), slot.out_len.get(),
                                 config_.alignments ? slot.align.get() : nullptr, slot.lengths.get(), slot.B,
                                 slot.S, slot.T);
-  for (size_t b = 0; b < batch.size(); ++b) batch[b].owner->deliver(batch[b].index, std::move(histories[b]));
+  std::vector<Unit> batch = std::move(slot.batch);
+  slot.batch.clear();
+  for (size_t b = 0; b < batch.size(); ++b) {
+    histories[b]->batch = slot.serial;
+    batch[b].owner->deliver(batch[b].index, std::move(histories[b]));
+  }
 }
 
-void Service::work(const Model *model) {
+// A worker that cannot run leaves: the others keep serving. Only when the LAST one has gone do
+// the waiting (and all later) requests fail, with that worker's error.
+void Service::retire(const std::exception_ptr &error) {
+  std::vector<Unit> orphans;
+  {
+    std::lock_guard<std::mutex> lock(mutex_);
+    if (--live_workers_ > 0) return;
+    dead_error_ = error;
+    for (std::vector<Unit> batch = queue_.take(); !batch.empty(); batch = queue_.take())
+      orphans.insert(orphans.end(), std::make_move_iterator(batch.begin()), std::make_move_iterator(batch.end()));
+  }
+  for (Unit &u : orphans) u.owner->fail(error);
+}
+
+void Service::work(const Model *model, slimt_hip_shortlist *generator) {
   Slot slots[2];
   size_t cur = 0;
   auto fail_batch = [](std::vector<Unit> &batch, const std::exception_ptr &error) {
@@ -220,19 +270,17 @@ void Service::work(const Model *model) {
     batch.clear();
   };
   try {
+    if (config_.fail_worker_setup) config_.fail_worker_setup(model);  // tests: a worker that cannot be built
     for (Slot &s : slots) {
       // (B + 1) * S <= max_words: at most max_words - 1 rows, at most max_words padded tokens
       s.worker = std::make_unique<Worker>(*model, config_.max_words, longest_, config_.max_words);
-      if (config_.shortlist) {
+      if (config_.shortlist && !generator) {
         uint32_t *sl = s.shortlist.ensure(config_.shortlist->size());
         std::copy(config_.shortlist->begin(), config_.shortlist->end(), sl);
       }
     }
   } catch (...) {
-    // this worker cannot run: every batch it would have taken fails instead of hanging
-    const std::exception_ptr error = std::current_exception();
-    for (std::vector<Unit> batch = next_batch(true); !batch.empty(); batch = next_batch(true))
-      fail_batch(batch, error);
+    retire(std::current_exception());
     return;
   }
   for (;;) {
@@ -249,9 +297,11 @@ void Service::work(const Model *model) {
       continue;
     }
     try {
-      launch(mine, std::move(batch));
+      launch(mine, batch, generator);
     } catch (...) {
-      fail_batch(mine.batch.empty() ? batch : mine.batch, std::current_exception());
+      const std::exception_ptr error = std::current_exception();
+      fail_batch(batch, error);
+      fail_batch(mine.batch, error);
     }
     if (!other.batch.empty()) {
       try {
@@ -260,7 +310,7 @@ void Service::work(const Model *model) {
         fail_batch(other.batch, std::current_exception());
       }
     }
-    cur ^= 1;
+    if (!mine.batch.empty()) cur ^= 1;
   }
 }
 

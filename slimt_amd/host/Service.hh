@@ -22,6 +22,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <exception>
+#include <functional>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -30,6 +31,7 @@
 #include <vector>
 
 #include "Model.hh"
+#include "Shortlist.hh"
 
 namespace slimt {
 
@@ -88,9 +90,21 @@ struct ServiceConfig {
   size_t workers_per_device = 10;  // x 2 contexts each: about 20 batches in flight per GPU
   uint32_t pad_id = 0;
   bool alignments = true;
-  // One shortlist policy for the service's lifetime (immutable after construction):
-  // sorted target ids, or nullopt for the full vocabulary.
+  // Output vocabulary of a batch, one policy for the service's lifetime:
+  //  * lexical_shortlist set: the reference's own -- ShortlistGenerator::generate on every batch's
+  //    source words (Model.cc:60-82,117-120; Shortlist.cc:115-175) -- run on the device, on the
+  //    worker's stream, from the batch's ids in pinned memory: no host shortlist, no upload, no
+  //    synchronisation. `lexical_shortlist` is the binary shortlist file (Shortlist.hh:77-84), borrowed
+  //    for the constructor; one generator per device is built from it;
+  //  * else `shortlist`: one fixed sorted id list (tests, benchmarks), or nullopt: the full vocabulary.
+  View lexical_shortlist;
+  size_t source_vocab = 0, target_vocab = 0;  // Vocabulary::size() of the two vocabularies
+  bool shortlist_shared_vocab = false;        // ShortlistGenerator's `shared` (Shortlist.hh:51)
+  bool shortlist_check = false;               // verify the file's checksum (Shortlist.cc:66-76)
   std::optional<Words> shortlist;
+  // Test hook: called by every worker before it builds its contexts; throwing from it makes that
+  // worker fail the way a failed allocation would (the others must keep serving).
+  std::function<void(const Model *)> fail_worker_setup;
 };
 
 class Service {
@@ -106,16 +120,21 @@ class Service {
 
  private:
   struct Slot;
-  void work(const Model *model);
+  void work(const Model *model, slimt_hip_shortlist *generator);
   std::vector<Unit> next_batch(bool may_block);
-  void launch(Slot &slot, std::vector<Unit> batch);
+  void launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *generator);
   void finish(Slot &slot);
+  void retire(const std::exception_ptr &error);
 
   ServiceConfig config_;
   size_t longest_;
   LengthQueue queue_;
+  std::vector<std::unique_ptr<ShortlistGenerator>> generators_;  // one per device in use (lexical shortlist)
   uint64_t sequence_ = 0;
+  std::atomic<uint64_t> batches_{0};  // batches launched so far (Hypothesis::batch)
   bool closing_ = false;
+  size_t live_workers_ = 0;          // workers that can take batches
+  std::exception_ptr dead_error_;    // set once the last of them has failed: requests fail with it
   std::mutex mutex_;
   std::condition_variable wake_;
   std::vector<std::thread> threads_;

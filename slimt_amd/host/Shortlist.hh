@@ -50,6 +50,9 @@ class ShortlistGenerator {  // slimt/Shortlist.hh:38-90
   ShortlistGenerator &operator=(const ShortlistGenerator &) = delete;
   // words: the batch's source tokens without padding (Input::words())
   Shortlist generate(const Words &words) const;
+  // the device-side generator, for Worker::forward_async_generated (one handle serves every
+  // worker of its device: the asynchronous path only reads it)
+  slimt_hip_shortlist *handle() const { return handle_; }
 
  private:
   slimt_hip_shortlist *handle_ = nullptr;

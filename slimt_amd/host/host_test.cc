@@ -6,6 +6,7 @@
 //           f32 bias[N], u32 n_idx, u32 idx[n_idx]
 // out.bin : per sentence u32 n, u32 tokens[n], f32 align[n][len];
 //           then f32 affine[M*N], f32 dot[M*N], f32 select[M*n_idx]
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -130,10 +131,37 @@ static int batching_main(int argc, char **argv) {
       if (n_sl) sc.shortlist = c.vec<uint32_t>(n_sl);
     }
     if (const char *e = std::getenv("SLIMT_SERVICE_NO_ALIGN")) sc.alignments = e[0] != '1';
+    // SLIMT_SERVICE_LEXICAL=<binary shortlist file>: every batch gets its own lexical shortlist,
+    // generated on the device (ServiceConfig::lexical_shortlist); the vocabulary sizes are the model's
+    std::vector<char> lexical;
+    if (const char *e = std::getenv("SLIMT_SERVICE_LEXICAL")) {
+      lexical = slurp(e);
+      int32_t vocab = 0;
+      if (slimt_hip_model_info(model.handle(), nullptr, nullptr, &vocab, nullptr)) throw std::runtime_error("model_info");
+      sc.lexical_shortlist = View{lexical.data(), lexical.size()};
+      sc.source_vocab = sc.target_vocab = static_cast<size_t>(vocab);
+      sc.shortlist_check = true;
+    }
+    // SLIMT_SERVICE_REPLICAS=n: n model replicas, all on device 0 (exercises the replica / worker
+    // assignment without an 8-GPU node); SLIMT_SERVICE_FAIL_WORKERS=k: the first k workers to start
+    // fail their set-up (the others must serve everything)
+    const int n_replicas = std::getenv("SLIMT_SERVICE_REPLICAS") ? std::atoi(std::getenv("SLIMT_SERVICE_REPLICAS")) : 1;
+    std::vector<std::unique_ptr<Model>> extra;
+    std::vector<const Model *> replicas{&model};
+    for (int r = 1; r < n_replicas; ++r) {
+      extra.push_back(std::make_unique<Model>(cfg, bin.data(), bin.size()));
+      replicas.push_back(extra.back().get());
+    }
+    std::atomic<int> to_fail{std::getenv("SLIMT_SERVICE_FAIL_WORKERS") ? std::atoi(std::getenv("SLIMT_SERVICE_FAIL_WORKERS")) : 0};
+    if (to_fail.load() > 0)
+      sc.fail_worker_setup = [&to_fail](const Model *) {
+        if (to_fail.fetch_sub(1) > 0) throw std::runtime_error("injected worker set-up failure");
+      };
+    const bool dump_full = std::getenv("SLIMT_SERVICE_DUMP_FULL") != nullptr;
     std::vector<std::future<Histories>> futures;
     std::vector<Histories> results;
     {
-      Service service(sc, {&model});
+      Service service(sc, replicas);
       // first request alone and untimed: worker start-up (contexts, pinned buffers)
       const auto t0 = std::chrono::steady_clock::now();
       for (auto &r : requests) futures.push_back(service.translate(r));
@@ -154,7 +182,17 @@ static int batching_main(int argc, char **argv) {
         const uint32_t S = static_cast<uint32_t>(h->padded_length), n = static_cast<uint32_t>(h->target.size());
         put(out, &S, 1);
         put(out, &n, 1);
+        if (dump_full) {  // + the batch it travelled in and its alignment rows
+          const uint32_t batch = static_cast<uint32_t>(h->batch);
+          const uint32_t rows = static_cast<uint32_t>(h->alignment.size());
+          const uint32_t len = rows ? static_cast<uint32_t>(h->alignment[0].size()) : 0;
+          put(out, &batch, 1);
+          put(out, &rows, 1);
+          put(out, &len, 1);
+        }
         put(out, h->target.data(), n);
+        if (dump_full)
+          for (const Distribution &row : h->alignment) put(out, row.data(), row.size());
       }
     }
   } catch (const std::exception &e) {

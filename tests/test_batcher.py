@@ -122,3 +122,110 @@ def test_service_rejects_bad_requests_and_survives(hip, synth_models):
     assert res.returncode == 0, res.stderr + res.stdout
     assert "rejected empty" in res.stdout and "rejected overlong" in res.stdout
     assert "worker failure reported" in res.stdout and "survived: 3 sentences" in res.stdout
+
+
+def _run_async(m, reqs, workers, max_words=96, wrap=24, env_extra=None, sl=None, expect_rc=0):
+    with tempfile.TemporaryDirectory() as d:
+        mb, cb, ob = (os.path.join(d, n) for n in ("model.bin", "case.bin", "out.bin"))
+        open(mb, "wb").write(synth.write_bin(m))
+        _case(cb, (m.enc_layers, m.dec_layers, m.H), max_words, wrap, workers, 1.5, reqs, sl)
+        env = dict(os.environ, SLIMT_SERVICE_DUMP_FULL="1")
+        extra = dict(env_extra or {})
+        if "SLIMT_SERVICE_LEXICAL_BLOB" in extra:  # bytes -> a file next to the case
+            lb = os.path.join(d, "lex.bin")
+            open(lb, "wb").write(extra.pop("SLIMT_SERVICE_LEXICAL_BLOB"))
+            extra["SLIMT_SERVICE_LEXICAL"] = lb
+        env.update(extra)
+        res = subprocess.run([_exe(), "--async", mb, cb, ob], capture_output=True, text=True, timeout=600, env=env)
+        assert res.returncode == expect_rc, res.stderr
+        raw = open(ob, "rb").read() if os.path.exists(ob) else b""
+    return res, raw
+
+
+def _parse_full(raw, reqs):
+    """-> list of (sentence, S, batch serial, tokens, alignment rows [n][len]) in request order."""
+    out, off = [], 0
+    for segs in reqs:
+        for s in segs:
+            S, n, batch, rows, ln = struct.unpack_from("<5I", raw, off)
+            off += 20
+            toks = np.frombuffer(raw, np.uint32, n, off)
+            off += 4 * n
+            al = np.frombuffer(raw, np.float32, rows * ln, off).reshape(rows, ln)
+            off += 4 * rows * ln
+            out.append((s, S, batch, toks, al))
+    assert off == len(raw)
+    return out
+
+
+def _check_batches(oracle, om, rows, shortlist_of):
+    """Rebuild every batch the Service formed (sentences grouped by batch serial, in the order it
+    padded them: ascending length, arrival order inside a length == request order here) and compare
+    tokens, lengths and alignment rows with the oracle on that batch and ITS shortlist."""
+    batches = {}
+    for i, (s, S, batch, toks, al) in enumerate(rows):
+        batches.setdefault(batch, []).append(i)
+    oracle.set_mode(oracle.PORTABLE)
+    for members in batches.values():
+        members.sort(key=lambda i: (len(rows[i][0]), i))
+        S = rows[members[0]][1]
+        assert all(rows[i][1] == S for i in members) and S == max(len(rows[i][0]) for i in members)
+        ids = np.zeros((len(members), S), np.uint32)
+        lens = np.zeros(len(members), np.uint32)
+        for b, i in enumerate(members):
+            ids[b, : len(rows[i][0])] = rows[i][0]
+            lens[b] = len(rows[i][0])
+        sl = shortlist_of(ids, lens)
+        w_out, w_ln, w_al, _ = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
+        for b, i in enumerate(members):
+            _, _, _, toks, al = rows[i]
+            n = int(w_ln[b])
+            assert len(toks) == n and np.array_equal(toks, w_out[b, :n])
+            assert al.shape == (n, int(lens[b])) and np.array_equal(al, w_al[b, :n, : int(lens[b])])
+    oracle.set_mode(oracle.FAITHFUL)
+    return len(batches)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [1, 4])
+def test_service_generates_a_lexical_shortlist_per_batch(hip, oracle, synth_models, workers):
+    """ServiceConfig::lexical_shortlist: every batch's output vocabulary is ShortlistGenerator::generate
+    of ITS source words (Model.cc:117-120), on the device; tokens and alignment rows == oracle with
+    OracleShortlist.generate of the rebuilt batch."""
+    m = synth_models("micro", 3.0)
+    blob = synth.make_lexical_shortlist(m.V, m.V, 16, 6, seed=21)
+    osl = oracle.OracleShortlist(blob, m.V, m.V)
+    reqs = _requests(m.V, 30, 50 + workers, 20)
+    res, raw = _run_async(m, reqs, workers, env_extra={"SLIMT_SERVICE_LEXICAL_BLOB": blob, "SLIMT_SERVICE_REPEAT": "1"})
+    rows = _parse_full(raw, reqs)
+    n_batches = _check_batches(oracle, oracle.OracleModel(m), rows, lambda ids, lens: osl.generate(ids, lens))
+    assert n_batches >= 3
+    # the shortlists really differ between batches (else the test would not see a frozen one)
+    seen = {tuple(osl.generate(np.asarray([s], np.uint32), np.asarray([len(s)], np.uint32))) for s, *_ in rows[:8]}
+    assert len(seen) > 1
+
+
+@pytest.mark.gpu
+def test_service_two_replicas_on_one_device(hip, oracle, synth_models):
+    """Two Model replicas (both on device 0), three workers each: the replica / worker assignment of
+    Service (slimt/Frontend.cc:207-227's workers, one set per GPU) runs before an 8-GPU node does."""
+    m = synth_models("micro", 3.0)
+    sl = synth.make_shortlist(m.V, 128, frequent=16)
+    reqs = _requests(m.V, 40, 91, 20)
+    res, raw = _run_async(m, reqs, 3, env_extra={"SLIMT_SERVICE_REPLICAS": "2", "SLIMT_SERVICE_REPEAT": "1"}, sl=sl)
+    rows = _parse_full(raw, reqs)
+    assert _check_batches(oracle, oracle.OracleModel(m), rows, lambda ids, lens: sl) >= 3
+
+
+@pytest.mark.gpu
+def test_service_survives_workers_that_cannot_start(hip, oracle, synth_models):
+    """Two of four workers fail their set-up: they retire, the other two translate everything
+    (a failed worker used to fail most of the queue). All four failing: every
+    request fails with the worker's error instead of hanging."""
+    m = synth_models("micro", 3.0)
+    reqs = _requests(m.V, 20, 17, 20)
+    res, raw = _run_async(m, reqs, 4, env_extra={"SLIMT_SERVICE_FAIL_WORKERS": "2"})
+    rows = _parse_full(raw, reqs)
+    assert _check_batches(oracle, oracle.OracleModel(m), rows, lambda ids, lens: None) >= 2
+    res, _ = _run_async(m, reqs, 4, env_extra={"SLIMT_SERVICE_FAIL_WORKERS": "4"}, expect_rc=1)
+    assert "injected worker set-up failure" in res.stderr

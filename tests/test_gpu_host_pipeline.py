@@ -1,0 +1,187 @@
+"""GPU parity of the host-side entry points of Model::forward (slimt/Model.cc:111-204) as a worker
+calls it: pinned asynchronous translate with alignment rows staged in device memory, the batch's
+lexical shortlist generated on the context's stream (Model.cc:117-120), the shortlist cache of
+slimt_hip_translate, XCD-affine decoder placement -- all against the CPU oracle (PORTABLE order:
+bit-exact tokens, lengths and alignment rows)."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines(hip, oracle, synth_models):
+    cache = {}
+
+    def get(preset, eos_bias):
+        key = (preset, eos_bias)
+        if key not in cache:
+            m = synth_models(preset, eos_bias)
+            cache[key] = (m, hip.Model(m), oracle.OracleModel(m))
+        return cache[key]
+
+    yield get
+    for _, gm, _ in cache.values():
+        gm.close()
+
+
+def _want(oracle, om, ids, lens, sl):
+    oracle.set_mode(oracle.PORTABLE)
+    out = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+    oracle.set_mode(oracle.FAITHFUL)
+    return out
+
+
+# S % 4 != 0 takes the 4-byte copy-out, S % 4 == 0 the 16-byte one; B = 45 has a partly filled tile;
+# 40 / 70 tokens: the 33..64-token and the long decoder variants write their rows the same way
+@pytest.mark.parametrize("preset,eos_bias,B,S,n_sl", [
+    ("micro", 3.0, 8, 8, 128), ("micro", 3.0, 5, 7, None), ("tiny11", 6.0, 45, 32, 2048),
+    ("tiny11", 6.0, 19, 13, 1024), ("tiny11", 6.0, 7, 40, 1024), ("tiny11", 6.0, 3, 70, 512),
+    ("base", 6.0, 19, 32, 1024), ("base", 6.0, 6, 10, 512)])
+def test_pinned_translate_stages_alignment_rows(hip, oracle, engines, preset, eos_bias, B, S, n_sl):
+    """slimt_hip_translate_async on pinned buffers: the persistent decoder stages alignment rows in
+    device memory and writes each sentence's [T][S] block to the host once (zeros outside the
+    recorded rows and beyond the sentence's length), Model.cc:84-108."""
+    from slimt_amd import synth
+    m, gm, om = engines(preset, eos_bias)
+    ids, lens = synth.make_batch(m.V, B, S, seed=31 * B + S, ragged=True)
+    sl = None if n_sl is None else synth.make_shortlist(m.V, n_sl)
+    w_out, w_ln, w_al = _want(oracle, om, ids, lens, sl)
+    ctx = hip.Context(gm, B, S)
+    for rep in range(2):  # the second pass finds the first one's rows in the staging buffer
+        bufs = ctx.pinned_buffers(B, S, 1.5, True)
+        bufs[4][...] = np.float32(7.25)  # whatever the host buffer held must be overwritten everywhere
+        out, ln, al = ctx.translate_pinned(ids, lens, sl, want_align=True)
+        assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out)
+        assert np.array_equal(al, w_al), rep
+    # a shorter batch afterwards: stale rows of the longer one stay out
+    ids2, lens2 = synth.make_batch(m.V, max(1, B // 2), S, seed=5 + B, ragged=True)
+    w2 = _want(oracle, om, ids2, lens2, sl)
+    got2 = ctx.translate_pinned(ids2, lens2, sl, want_align=True)
+    assert all(np.array_equal(a, b) for a, b in zip(got2, w2))
+    ctx.close()
+
+
+def test_shortlist_upload_cache_is_invalidated_by_other_entry_points(hip, oracle, engines):
+    """slimt_hip_translate uploads a shortlist only when it differs from the one it uploaded last;
+    every other writer of the context's device shortlist (decode_begin, the device-resident
+    translate, the generated-shortlist translate) must drop that claim."""
+    import torch
+    from slimt_amd import synth
+    m, gm, om = engines("tiny11", 6.0)
+    B, S = 9, 12
+    ids, lens = synth.make_batch(m.V, B, S, seed=77, ragged=True)
+    slA, slB = synth.make_shortlist(m.V, 1024, seed=1), synth.make_shortlist(m.V, 1024, seed=2)
+    assert not np.array_equal(slA, slB)
+    wantA = _want(oracle, om, ids, lens, slA)
+    blob = synth.make_lexical_shortlist(m.V, m.V, 100, 50, seed=4)
+    gen = hip.ShortlistGenerator(blob, m.V, m.V)
+    dev = torch.device("cuda", 0)
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    d_ids, d_lens = to_dev(ids), to_dev(lens)
+    T = int(np.float32(1.5) * np.float32(S))
+    d_out = torch.zeros((B, T), dtype=torch.int32, device=dev)
+    d_ol = torch.zeros((B,), dtype=torch.int32, device=dev)
+
+    def disturb_decode_begin(ctx):
+        ctx.encode(ids, lens)
+        ctx.decode_begin(slB)
+
+    def disturb_generated(ctx):
+        ctx.translate_device_generated(gen, d_ids.data_ptr(), d_lens.data_ptr(), B, S, 1.5, 0, d_out.data_ptr(),
+                                       d_ol.data_ptr(), 0, steps_hint=T)
+        ctx.synchronize()
+
+    def disturb_stagewise_device(ctx):  # mode 1 copies the caller's device shortlist into the context's
+        d_sl = to_dev(slB)
+        ctx.set_decode_mode(1)
+        ctx.translate_device(d_ids.data_ptr(), d_lens.data_ptr(), B, S, d_sl.data_ptr(), slB.size, 1.5, 0,
+                             d_out.data_ptr(), d_ol.data_ptr(), 0, steps_hint=T)
+        ctx.synchronize()
+        ctx.set_decode_mode(0)
+
+    def disturb_pinned_generated(ctx):
+        ctx.translate_pinned(ids, lens, generator=gen)
+
+    for disturb in (disturb_decode_begin, disturb_generated, disturb_stagewise_device, disturb_pinned_generated):
+        ctx = hip.Context(gm, B, S)
+        got = ctx.translate(ids, lens, slA, want_align=True)
+        assert all(np.array_equal(a, b) for a, b in zip(got, wantA)), disturb.__name__
+        disturb(ctx)
+        got = ctx.translate(ids, lens, slA, want_align=True)  # the same host shortlist again
+        assert all(np.array_equal(a, b) for a, b in zip(got, wantA)), disturb.__name__
+        ctx.close()
+    gen.close()
+
+
+@pytest.mark.parametrize("preset,B,S,frequent,best", [("micro", 6, 9, 16, 8), ("tiny11", 37, 21, 100, 40),
+                                                      ("tiny11", 5, 48, 100, 100), ("base", 9, 16, 100, 60)])
+def test_translate_generated_from_host_buffers(hip, oracle, engines, preset, B, S, frequent, best):
+    """Model::forward with its shortlist step (Model.cc:117-120,195-203) from HOST buffers: blocking
+    (pageable arrays, copies) and asynchronous (pinned arrays, no copy, no host shortlist) ==
+    oracle translate with OracleShortlist.generate of the same batch."""
+    from slimt_amd import synth
+    m, gm, om = engines(preset, 6.0 if preset != "micro" else 3.0)
+    blob = synth.make_lexical_shortlist(m.V, m.V, frequent, best, seed=B + S)
+    gen = hip.ShortlistGenerator(blob, m.V, m.V, check=True)
+    osl = oracle.OracleShortlist(blob, m.V, m.V)
+    ctx = hip.Context(gm, B, S)
+    for seed in (1, 2):
+        ids, lens = synth.make_batch(m.V, B, S, seed=900 + seed + S, ragged=True)
+        sl = osl.generate(ids, lens)
+        want = _want(oracle, om, ids, lens, sl)
+        got = ctx.translate_generated(gen, ids, lens, want_align=True)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), ("blocking", seed)
+        got = ctx.translate_pinned(ids, lens, want_align=True, generator=gen)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), ("pinned", seed)
+        got = ctx.translate_pinned(ids, lens, want_align=False, generator=gen)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ctx.set_decode_mode(1)  # stage kernels: the shortlist's size is read back once
+    got = ctx.translate_generated(gen, ids, lens, want_align=True)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    # errors: a token outside the source vocabulary, a generator of another vocabulary
+    bad = ids.copy()
+    bad[0, 0] = m.V
+    with pytest.raises(RuntimeError, match="out of range"):
+        ctx.translate_generated(gen, bad, lens)
+    other = hip.ShortlistGenerator(synth.make_lexical_shortlist(64, 64, 8, 4, seed=9), 64, 64)
+    with pytest.raises(RuntimeError, match="vocabulary"):
+        ctx.translate_generated(other, np.zeros((1, 4), np.uint32), np.array([4], np.uint32))
+    other.close()
+    ctx.close()
+    gen.close()
+
+
+@pytest.mark.parametrize("xcds", [1, 2, 4])
+def test_xcd_affine_decoder_placement_keeps_results(hip, oracle, engines, xcds):
+    """slimt_hip_model_set_xcd_affinity: where a batch's decoder tiles run (which XCD claims them)
+    changes nothing in the results -- concurrent contexts, partly filled tiles, B from 1 tile to
+    more tiles than the home XCDs take (then the launch is not placed at all)."""
+    from slimt_amd import synth
+    m, gm, om = engines("tiny11", 6.0)
+    S, W = 14, 3
+    sl = synth.make_shortlist(m.V, 1024)
+    jobs = [synth.make_batch(m.V, B, S, seed=8100 + i, ragged=True) for i, B in enumerate((27, 5, 200, 16, 300, 64))]
+    want = [_want(oracle, om, ids, lens, sl) for ids, lens in jobs]
+    gm.set_xcd_affinity(xcds)
+    ctxs = [hip.Context(gm, 300, S) for _ in range(W)]
+    bad = []
+
+    def work(w):
+        for rep in range(2):
+            for i in range(w, len(jobs), W):
+                got = ctxs[w].translate(jobs[i][0], jobs[i][1], sl, want_align=True)
+                if not all(np.array_equal(a, b) for a, b in zip(got, want[i])):
+                    bad.append((w, rep, i))
+
+    ts = [threading.Thread(target=work, args=(w,)) for w in range(W)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for c in ctxs:
+        c.close()
+    gm.set_xcd_affinity(0)
+    assert not bad, bad
+    with pytest.raises(RuntimeError):
+        gm.set_xcd_affinity(3)
