@@ -77,6 +77,11 @@ def parse(argv=None):
     ap.add_argument("--sustained-steps", type=int, default=40,
                     help="after the timed region, one longer untimed-by-the-driver region of this many steps "
                          "(reported as `sustained`; 0 = skip)")
+    ap.add_argument("--forward-steps", type=int, default=20,
+                    help="after the timed region: Model::forward as the reference defines it (host buffers in, "
+                         "tokens + lengths + alignment rows back in host memory; with one fixed shortlist and with "
+                         "a lexical shortlist generated per batch), this many steps each (reported as "
+                         "`model_forward*`; 0 = skip), and `single_stream` (one worker alone)")
     ap.add_argument("--all-kernels", action="store_true",
                     help="after the timed region, time every kernel family (untimed pass)")
     return ap.parse_args(argv)
@@ -392,6 +397,71 @@ def main():
         sustained = {"steps": args.sustained_steps, "batches_per_gpu": args.sustained_steps * batches_per_step,
                      "value": total_tokens_per_step * args.sustained_steps / dts, "seconds": dts}
 
+    forward = None
+    if args.forward_steps > 0 and not dry and not strong:
+        # Model::forward as the reference's workers call it (Model.cc:111-204): ids and lengths in
+        # (pinned) HOST memory, tokens, lengths and the alignment rows of every step (Model.cc:84-108)
+        # back in host memory -- slimt_hip_translate_async[_generated] on the same 20 x 256 workload.
+        from slimt_amd import capi as _capi
+        K = args.forward_steps
+        fb = []
+        for w in range(W):
+            ids_h, lens_h = synth.make_batch(model.V, B, S, seed=8000 + 97 * rank + w, ragged=args.ragged)
+            bufs = ctxs[w].pinned_buffers(B, S, 1.5, True)
+            bufs[0][...] = ids_h
+            bufs[1][...] = lens_h
+            fb.append(bufs)
+        lex = synth.make_lexical_shortlist(model.V, model.V, 100, 1, seed=11, empty_fraction=0.4, min_count=1)
+        gen = _capi.ShortlistGenerator(lex, model.V, model.V, device=local_rank)
+
+        def fregion(with_align, generator):
+            def fstep():
+                for w in range(W):
+                    bufs = fb[w] if with_align else fb[w][:4] + (None,)
+                    ctxs[w].translate_async(bufs, shortlist=None if generator else sl, generator=generator)
+            for _ in range(2):
+                fstep()
+            barrier()
+            t = time.perf_counter()
+            for _ in range(K):
+                fstep()
+            barrier()
+            d, _ = reduce_timing(dist, cpu, time.perf_counter() - t, tokens_per_step)
+            got = int(sum(int(fb[w][3].sum()) for w in range(W)))
+            if got != W * B * T:
+                raise SystemExit(f"bench: model_forward produced {got} tokens, expected {W * B * T}")
+            return {"value": total_tokens_per_step * K / d, "ms_per_step": 1e3 * d / K, "steps": K}
+
+        io = ("ids + lengths read from pinned host memory, tokens + lengths + alignment rows [B,T,S] written to "
+              "pinned host memory by the persistent kernels (no copy queued)")
+        forward = {
+            "model_forward": dict(fregion(True, None), io=io, alignments=True,
+                                  shortlist=f"one host list of {n_sl} ids (uploaded when it changes)" if n_sl else "full vocabulary"),
+            "model_forward_no_alignments": dict(fregion(False, None), alignments=False),
+        }
+        if n_sl:
+            n_gen = int(gen.generate(np.asarray(fb[0][0]), np.asarray(fb[0][1])).size)
+            forward["model_forward_per_batch_shortlist"] = dict(
+                fregion(True, gen), io=io, alignments=True,
+                shortlist=f"ShortlistGenerator::generate per batch on the device (Model.cc:117-120; synthetic "
+                          f"binary lexical shortlist, {n_gen} ids for worker 0's batch), no host shortlist")
+        gen.close()
+        # one stream alone: batches of one worker back to back
+        K1 = max(4, K // 2)
+        d_ids, d_lens, nb = batches[0]
+        def one():
+            ctxs[0].translate_device(d_ids.data_ptr(), d_lens.data_ptr(), nb, S, d_sl.data_ptr() if d_sl is not None else 0,
+                                     n_sl, 1.5, 0, d_outs[0].data_ptr(), d_lens_out[0].data_ptr(), 0, steps_hint=T)
+        one()
+        barrier()
+        t = time.perf_counter()
+        for _ in range(K1):
+            one()
+        barrier()
+        d1 = time.perf_counter() - t
+        forward["single_stream"] = {"value": nb * T * K1 / d1, "ms_per_batch": 1e3 * d1 / K1, "batches": K1,
+                                    "note": "one worker alone (one stream, batches back to back), device-resident I/O, this rank"}
+
     per_kernel = None
     if args.all_kernels and rank == 0 and not dry:
         per_kernel = {}
@@ -499,6 +569,8 @@ def main():
         }
         if sustained is not None:
             out["sustained"] = sustained
+        if forward is not None:
+            out.update(forward)
         if per_kernel is not None:
             out["per_kernel"] = per_kernel
         if world == 1 and not args.no_cpu_baseline and not dry:

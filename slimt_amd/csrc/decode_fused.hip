@@ -1643,8 +1643,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
     const size_t ldsm = fused_decode_lds_bytes(D, F, a.Ld, 16, true, true);
     if (ldsm > 160 * 1024) return hipErrorInvalidValue;
     auto k = a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, true> : decode_fused_kernel<4, 24, 32, false, false, 1, true, true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)ldsm);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(1024), ldsm, st, a);
     return hipGetLastError();
@@ -1654,16 +1653,14 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   if (kv24 && D == 512) {
     if (F != 2048) return hipErrorInvalidValue;
     auto k = a.kv_nt ? decode_fused_kernel<8, 32, 64, false, true, 1, true> : decode_fused_kernel<8, 32, 64, false, false, 1, true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
     return hipGetLastError();
   }
   if (kv24 && rows == 16) {
     auto k = a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true> : decode_fused_kernel<4, 24, 32, false, false, 1, true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
     return hipGetLastError();
@@ -1671,8 +1668,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   if (rows == 32) {
     auto k = kv24 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true> : decode_fused_kernel<4, 24, 32, false, false, 2, true>)
                   : (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 2>);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
     return hipGetLastError();
@@ -1680,8 +1676,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
 #define SLIMT_FUSED_CASE(KSD_, KSF_, DH_)                                                   \
   if (D == 64 * KSD_ && F == 64 * KSF_ && D / H == DH_) {                                    \
     auto k = decode_fused_pick<KSD_, KSF_, DH_>(a.S > 32, a.kv_nt);                           \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                    \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds); \
     if (e != hipSuccess) return e;                                                           \
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);                                     \
     return hipGetLastError();                                                                \

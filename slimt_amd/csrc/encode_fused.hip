@@ -1173,8 +1173,7 @@ hipError_t launch_encode_long(const LongEncodeArgs &a, hipStream_t st) {
   if (!long_encode_supported(a.D, a.F, a.H, a.f.Le, a.f.Ld, a.f.S)) return hipErrorInvalidValue;
   const size_t lds = long16_lds_bytes();
   auto k = a.f.S <= 64 ? encode_long16_kernel<2> : encode_long16_kernel<4>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(a.f.B), dim3(1024), lds, st, a);
   return hipGetLastError();
@@ -1211,8 +1210,7 @@ hipError_t launch_encode_fused(const FusedEncodeArgs &a, int D, int F, int H, hi
 #define SLIMT_ENC_CASE(KSF_)                                                                   \
   if (F == 64 * KSF_) {                                                                        \
     auto k = encode_fused_kernel<4, KSF_, 32>;                                                 \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                                 \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);             \
     if (e != hipSuccess) return e;                                                             \
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);                                       \
     return hipGetLastError();                                                                  \

@@ -681,8 +681,7 @@ hipError_t launch_encode_tall(const FusedEncodeArgs &a, int F, hipStream_t st) {
 #define SLIMT_TALL_CASE(KSF_)                                                                  \
   if (F == 64 * KSF_) {                                                                        \
     auto k = a.S > 32 ? encode_tall_kernel<KSF_, 4> : encode_tall_kernel<KSF_, 2>;             \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                                 \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);             \
     if (e != hipSuccess) return e;                                                             \
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);                                       \
     return hipGetLastError();                                                                  \

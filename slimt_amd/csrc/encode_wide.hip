@@ -700,8 +700,7 @@ hipError_t launch_encode_wide(const FusedEncodeArgs &a, hipStream_t st) {
   const dim3 grid(fused_encode_grid(a.B, a.S, a.ticket != nullptr));
   const size_t lds = wide_encode_lds_bytes();
   auto k = encode_wide_kernel<8, 32, 64>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds);
+  hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
   return hipGetLastError();

@@ -2,6 +2,8 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,6 +60,50 @@ void DevBuf::release() {
   p = nullptr;
   bytes = 0;
 }
+
+namespace {
+// SLIMT_HOST_TIMING=1: where a translate call's host time goes (printed when a model is destroyed)
+struct HostTiming {
+  bool on = std::getenv("SLIMT_HOST_TIMING") != nullptr;
+  std::atomic<uint64_t> ns[8] = {};
+  std::atomic<uint64_t> calls{0};
+} g_timing;
+const char *kTimingNames[8] = {"validate", "encode: prepare + launch", "submit + gate locks", "gate: wait-event call",
+                               "decoder launch call", "gate: event record", "pinned-pointer views", "other"};
+struct StageClock {
+  std::chrono::steady_clock::time_point t;
+  StageClock() { if (g_timing.on) t = std::chrono::steady_clock::now(); }
+  void lap(int stage) {
+    if (!g_timing.on) return;
+    const auto now = std::chrono::steady_clock::now();
+    g_timing.ns[stage] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t).count();
+    t = now;
+  }
+};
+void timing_report() {
+  if (!g_timing.on || g_timing.calls == 0) return;
+  std::fprintf(stderr, "host-timing: %llu translate calls; us per call:", (unsigned long long)g_timing.calls.load());
+  for (int i = 0; i < 8; ++i)
+    if (g_timing.ns[i]) std::fprintf(stderr, " [%s %.1f]", kTimingNames[i], 1e-3 * g_timing.ns[i] / g_timing.calls);
+  std::fprintf(stderr, "\n");
+}
+}  // namespace
+
+namespace slimt_hip {
+hipError_t set_dynamic_lds_once(const void *kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, int> largest;
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  int &have = largest[{device, kernel}];
+  if (bytes <= have) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
+}  // namespace slimt_hip
 
 extern "C" int slimt_hip_abi_version(void) { return SLIMT_HIP_ABI_VERSION; }
 extern "C" const char *slimt_hip_last_error(void) { return g_err; }
@@ -545,6 +591,7 @@ extern "C" int slimt_hip_model_create(const slimt_hip_param *params, size_t n_pa
 
 extern "C" int slimt_hip_model_destroy(slimt_hip_model *model) {
   if (!model) return 0;
+  timing_report();
   (void)hipSetDevice(model->device);
   model_free(model);
   delete model;
@@ -670,6 +717,7 @@ int ctx_alloc(slimt_hip_ctx *c) {
   HIPCHK(c->n_finished.reserve(16));
   HIPCHK(c->shortlist.reserve(V * 4));
   HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->n_finished_host), 16, hipHostMallocDefault));
+  std::memset(c->n_finished_host, 0, 16);  // [0] early-exit read-back, [1] size of the last generated shortlist
   return 0;
 }
 
@@ -1251,7 +1299,9 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
                      const uint32_t *d_shortlist, size_t B, size_t S, size_t n_sl,
                      float limit_factor, uint32_t eos_id, uint32_t *d_out_ids, uint32_t *d_out_len,
                      float *d_align, int steps_hint, const uint32_t *d_n_sl = nullptr,
-                     float *align_out = nullptr) {
+                     float *align_out = nullptr, size_t n_sl_hint = 0) {
+  // n_sl_hint (with d_n_sl): what the host expects the device-side shortlist size to be (the size of
+  // this context's previous generated shortlist): tuning decisions only
   // align_out != nullptr (persistent decoder only): d_align is a staging buffer in device memory and
   // the decoder copies each sentence's rows from there to align_out when its loop ends (see
   // FusedDecodeArgs::align_out)
@@ -1275,6 +1325,16 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
                     ((m->D == 256 && m->D / m->H == 32) || (m->D == 512 && m->D / m->H == 64 && m->F == 2048)) &&
                     ((S <= 32 && ((S + 3) & ~(size_t)3) * 3 <= S * 4 &&
                       fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S)) || kv24_mid);
+  // One thread at a time queues a persistent translate (a few runtime calls, ~50 us): the runtime
+  // serialises launches internally anyway, and a dozen worker threads contending inside it take
+  // far longer per call than the same calls made one after the other (Service, 10 workers: 2.1 ms
+  // per launch call against 0.05 ms with two).
+  static const bool submit_lock = !(std::getenv("SLIMT_SUBMIT_LOCK") && std::getenv("SLIMT_SUBMIT_LOCK")[0] == '0');
+  std::unique_lock<std::mutex> submit(c->model->submit_mu, std::defer_lock);
+  StageClock clk;
+  if (lean && submit_lock) submit.lock();
+  clk.lap(2);
+  if (g_timing.on) g_timing.calls += 1;
   DecodeState ds;
   ds.prev = c->prev.as<uint32_t>();
   ds.out_ids = d_out_ids;
@@ -1292,6 +1352,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr, false, false,
                         kv24));
     c->n_sl = (int)n_sl;
+    clk.lap(1);
   } else {
     if (d_ids != c->ids.as<uint32_t>())
       HIPCHK(hipMemcpyAsync(c->ids.p, d_ids, B * S * 4, hipMemcpyDeviceToDevice, st));
@@ -1323,7 +1384,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     // weights a step streams: with the full 32k vocabulary it is 8 of 10 MB per workgroup and step, and
     // halving it per sentence beats the longer attention chain (B = 512, full vocabulary: 20.4 -> 23-24 M
     // tok/s; at 16k columns the two are level, below that 16 rows win)
-    f.rows_per_wg = c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : (out.w.N > 16384 ? 32 : 0);
+    const size_t n_expected = d_n_sl && n_sl_hint ? n_sl_hint : (size_t)out.w.N;
+    f.rows_per_wg = c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : (n_expected > 16384 ? 32 : 0);
     const int rows = fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, f.rows_per_wg);
     for (int l = 0; l < m->Ld; ++l) {
       const DecLayerW &L = m->dec[(size_t)l];
@@ -1374,7 +1436,9 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     if (gm->decoder_budget > 0) {
       // decoder admission (engine.h): launch k waits for launch k - n on its own stream
       constexpr size_t kRing = 64;
+      clk.lap(7);
       std::lock_guard<std::mutex> lock(gm->gate_mu);
+      clk.lap(2);
       while (gm->gate_ev.size() < kRing) {
         hipEvent_t ev;
         HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1393,7 +1457,12 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       // 18.8 M, 12: 21.9 / 22.5 / 22.1, 16: 23.6 / 24.2 / 22.6, 20: 23.9 / 24.5 / 23.5;
       // B=512 full vocabulary 16.7 / 17.1 / 15.8; B=128, S=64 9.0 / 8.5 / 7.9; B=64, S=32
       // 11.9 / - / 13.6; base 6.4 / 5.9 / 5.7.
+      // Which contexts have a decoder pending is judged from when they launched last (a translate
+      // call takes a few milliseconds), not by asking the runtime: one hipEventQuery per context
+      // under this lock made every launch O(contexts) runtime calls, and with a dozen worker threads
+      // the launches queued behind each other (Service, 16 workers: 9.9 ms per launch call).
       const double kv_bytes = (double)m->Ld * 2.0 * (double)B * (double)S * m->D * (kv24 ? 3.0 : 4.0);
+      const auto now = std::chrono::steady_clock::now();
       double pending = kv_bytes;
       size_t contexts = 1;
       bool known = false;
@@ -1401,21 +1470,21 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
         if (g.ctx == c) {
           g.seq = gm->gate_seq;
           g.kv_bytes = kv_bytes;
+          g.when = now;
           known = true;
-        } else if (gm->gate_seq - g.seq < kRing &&
-                   hipEventQuery(gm->gate_ev[g.seq % kRing]) == hipErrorNotReady) {
+        } else if (gm->gate_seq - g.seq < kRing && now - g.when < std::chrono::milliseconds(25)) {
           pending += g.kv_bytes;
           contexts += 1;
         }
       }
-      (void)hipGetLastError();  // hipErrorNotReady is not an error here
-      if (!known) gm->gate_ctx.push_back({c, gm->gate_seq, kv_bytes});
+      if (!known) gm->gate_ctx.push_back({c, gm->gate_seq, kv_bytes, now});
       const double active = pending / (double)contexts * (double)std::min(contexts, n);
       int t_layers = gm->kv_policy == 1 ? m->Ld : gm->kv_policy == 2 ? 0
                      : (int)std::min((double)m->Ld, std::floor((double)m->Ld * 300.0e6 / active));
       f.kv_nt = t_layers < m->Ld;
       f.kv_temporal_layers = t_layers;
       if (gm->gate_seq >= n) HIPCHK(hipStreamWaitEvent(st, gm->gate_ev[(gm->gate_seq - n) % kRing], 0));
+      clk.lap(3);
       const int n_home = gm->xcd_affinity;
       const bool affine = n_home > 0 && rows == 16 && wgs <= 16 * n_home;
       if (affine) {
@@ -1438,6 +1507,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
         ProfScope p(c, SLIMT_HIP_K_DECODE_FUSED, macs, wbytes);
         HIPCHK(launch_decode_fused(f, m->D, m->F, m->H, st));
       }
+      clk.lap(4);
       if (affine) {
         c->xarr_base += f.xgrid;
         c->xclaim_base += (unsigned)wgs;
@@ -1445,6 +1515,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
         c->ticket_base += tickets;
       }
       HIPCHK(hipEventRecord(gm->gate_ev[gm->gate_seq % kRing], st));
+      clk.lap(5);
       gm->gate_seq += 1;
       return 0;
     }
@@ -1497,6 +1568,15 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
 }  // namespace
 
 namespace {
+// Staging for the alignment rows of a pinned asynchronous translate: sized ONCE for the largest batch
+// the context takes at this limit factor (a buffer that grows batch by batch frees and allocates device
+// memory under the other contexts' streams, and hipFree waits for the device).
+size_t align_staging_bytes(const slimt_hip_ctx *ctx, size_t B, size_t S, size_t Tmax, float limit_factor) {
+  const size_t t_max = (size_t)(limit_factor * (float)ctx->max_S) + 1;
+  const size_t worst = ctx->max_M * t_max * 4;
+  return std::max(worst <= ((size_t)256 << 20) ? worst : 0, B * Tmax * S * 4);
+}
+
 // the device view of a pinned host allocation (hipHostMalloc / slimt_hip_host_alloc), else nullptr
 void *host_device_view(const void *p) {
   hipPointerAttribute_t a;
@@ -1526,6 +1606,13 @@ int translate_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const uint3
   shortlist_args(sl, d_src_ids, d_lengths, B, S, ctx->shortlist.as<uint32_t>(),
                  ctx->n_sl_dev.as<uint32_t>(), a);
   a.scratch = ctx->sl_scratch.as<uint32_t>();
+  // the count also goes to a pinned word: what this context's PREVIOUS shortlist held is the host's
+  // estimate of this one's size (a batch's shortlist is sized on the device; the host only picks
+  // the decoder variant by it)
+  uint32_t *hint = reinterpret_cast<uint32_t *>(ctx->n_finished_host) + 1;
+  const size_t n_hint = *hint;
+  void *hint_dev = nullptr;
+  if (hipHostGetDevicePointer(&hint_dev, hint, 0) == hipSuccess) a.n_out_host = static_cast<uint32_t *>(hint_dev);
   HIPCHK(launch_shortlist_generate(a, st));
   const bool lean = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
                     (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
@@ -1533,7 +1620,7 @@ int translate_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const uint3
   if (lean)  // the size stays on the device: capacity V, actual count read by the kernels
     return translate_device(ctx, d_src_ids, d_lengths, ctx->shortlist.as<uint32_t>(), B, S,
                             (size_t)m->V, limit_factor, eos_id, d_out_ids, d_out_len, d_align,
-                            steps_hint, ctx->n_sl_dev.as<uint32_t>(), align_out);
+                            steps_hint, ctx->n_sl_dev.as<uint32_t>(), align_out, n_hint);
   uint32_t n = 0;  // stage kernels are sized on the host: one 4-byte read-back
   HIPCHK(hipMemcpyAsync(&n, ctx->n_sl_dev.p, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -1564,6 +1651,7 @@ int translate_host(slimt_hip_ctx *ctx, const uint32_t *src_ids, const uint32_t *
                    uint32_t eos_id, uint32_t *out_ids, uint32_t *out_len, float *align, bool wait) {
   if (!ctx || !src_ids || !lengths || !out_ids || !out_len) return fail(-1, "null argument");
   RCCHK(check_batch(ctx, B, S));
+  StageClock hclk;
   const slimt_hip_model *m = ctx->model;
   if (n_shortlist > (size_t)m->V) return fail(-1, "shortlist larger than the vocabulary");
   if (n_shortlist && !shortlist) return fail(-1, "shortlist is NULL");
@@ -1592,14 +1680,16 @@ int translate_host(slimt_hip_ctx *ctx, const uint32_t *src_ids, const uint32_t *
   const bool persistent = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
                           (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                            long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
+  hclk.lap(0);
   if (!wait && persistent) {
     void *v_ids = host_device_view(src_ids), *v_len = host_device_view(lengths), *v_out = host_device_view(out_ids),
          *v_ol = host_device_view(out_len), *v_al = align ? host_device_view(align) : nullptr;
+    hclk.lap(6);
     if (v_ids && v_len && v_out && v_ol && (!align || v_al)) {
       // alignment rows (Model.cc:84-108) are staged in device memory and leave for the host once per
       // sentence, as whole 16-byte stores when its loop ends: written row by row across PCIe from
       // inside the step loop they cost the Service 28 % (12.9 against 17.9 M tok/s)
-      if (align) HIPCHK(ctx->align.reserve(B * Tmax * S * 4));
+      if (align) HIPCHK(ctx->align.reserve(align_staging_bytes(ctx, B, S, Tmax, limit_factor)));
       RCCHK(translate_device(ctx, static_cast<const uint32_t *>(v_ids), static_cast<const uint32_t *>(v_len),
                              ctx->shortlist.as<uint32_t>(), B, S, n_shortlist, limit_factor, eos_id,
                              static_cast<uint32_t *>(v_out), static_cast<uint32_t *>(v_ol),
@@ -2074,7 +2164,7 @@ int translate_host_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const 
     void *v_ids = host_device_view(src_ids), *v_len = host_device_view(lengths), *v_out = host_device_view(out_ids),
          *v_ol = host_device_view(out_len), *v_al = align ? host_device_view(align) : nullptr;
     if (v_ids && v_len && v_out && v_ol && (!align || v_al)) {
-      if (align) HIPCHK(ctx->align.reserve(B * Tmax * S * 4));
+      if (align) HIPCHK(ctx->align.reserve(align_staging_bytes(ctx, B, S, Tmax, limit_factor)));
       return translate_generated(ctx, sl, static_cast<const uint32_t *>(v_ids), static_cast<const uint32_t *>(v_len),
                                  B, S, limit_factor, eos_id, static_cast<uint32_t *>(v_out),
                                  static_cast<uint32_t *>(v_ol), align ? ctx->align.as<float>() : nullptr,

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <string>
 #include <mutex>
 #include <vector>
@@ -71,6 +72,7 @@ struct slimt_hip_model {
   // `decoder_budget` decoder workgroups are meant to run at a time; launch k waits
   // (on its stream, not the host) for launch k - n, n = budget / its workgroups.
   // The other CUs stay with the encoders of the batches behind. 0 = no limit.
+  std::mutex submit_mu;  // held while a persistent translate is queued (translate_device)
   std::mutex gate_mu;
   std::vector<hipEvent_t> gate_ev;  // ring, created on first use
   size_t gate_seq = 0;
@@ -81,6 +83,7 @@ struct slimt_hip_model {
     const slimt_hip_ctx *ctx;
     size_t seq;
     double kv_bytes;
+    std::chrono::steady_clock::time_point when;  // host time of that launch call
   };
   std::vector<GateCtx> gate_ctx;
   // XCD-affine placement of a batch's decoder workgroups (kernels.h, FusedDecodeArgs::home_mask):

@@ -249,8 +249,7 @@ __global__ __launch_bounds__(128 * CG, 1) void gemm_tile_kernel(TileArgs ka) {
 template <int CG, int EPI>
 hipError_t launch_tile_t(const TileArgs &ka, dim3 grid, hipStream_t st) {
   auto run = [&](auto kernel) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds);
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(kernel), (int)kTileLds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, grid, dim3(128 * CG), kTileLds, st, ka);
     return hipGetLastError();

@@ -297,6 +297,10 @@ struct FusedDecodeArgs {
   int kv_temporal_layers = 0;  // with kv_nt: the first layers' caches are still read temporally
   OccTrace trace;
 };
+// hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), but only when
+// `bytes` exceeds what was already set for this kernel on the current device: the call takes
+// runtime-wide locks, and a host pipeline has a dozen threads launching at once.
+hipError_t set_dynamic_lds_once(const void *kernel, int bytes);
 int fused_decode_grid(int B, bool tickets, int rows);
 int fused_encode_grid(int B, int S, bool tickets);
 bool fused_decode_supported(int D, int F, int H, int Ld);
@@ -367,6 +371,7 @@ struct ShortlistArgs {
   int B = 0, S = 0;
   uint32_t *out = nullptr;    // [tgt_vocab] capacity
   uint32_t *n_out = nullptr;  // [1]
+  uint32_t *n_out_host = nullptr;  // nullable: a second copy of the count (pinned host memory: the host's hint for its next launch)
   uint32_t *scratch = nullptr;  // target + source bitmaps, zero on entry and on exit
 };
 size_t shortlist_lds_bytes(int src_vocab, int tgt_vocab);

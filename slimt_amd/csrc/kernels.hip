@@ -879,8 +879,7 @@ template <int DH>
 static hipError_t launch_attention_mfma(const AttnArgs &a, hipStream_t st) {
   const size_t lds = (size_t)4 * 2 * 32 * (DH + 2) * sizeof(float);
   auto k = attention_mfma_kernel<DH>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.B * a.H + 3) / 4), dim3(256), lds, st, a);
   return hipGetLastError();

@@ -156,7 +156,10 @@ __global__ __launch_bounds__(1024) void shortlist_compact_kernel(ShortlistArgs a
       ones += used;
       need -= used;
     }
-    if (lane == 0) *a.n_out = ones;
+    if (lane == 0) {
+      *a.n_out = ones;
+      if (a.n_out_host) *a.n_out_host = ones;
+    }
   }
   __syncthreads();
   cnt = 0;
@@ -196,15 +199,13 @@ hipError_t launch_shortlist_generate(const ShortlistArgs &a, hipStream_t st) {
   const size_t lds = shortlist_lds_bytes(a.src_vocab, a.tgt_vocab);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (!a.scratch) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(shortlist_compact_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(shortlist_compact_kernel), (int)lds);
   if (e != hipSuccess) return e;
   const int n_tok = a.B * a.S;
   int blocks = (n_tok + 1023) / 1024;  // 64 tokens per wave pass, 16 waves per block
   blocks = blocks < 1 ? 1 : (blocks > 16 ? 16 : blocks);
   const size_t lds1 = (size_t)((a.tgt_vocab + 31) / 32) * sizeof(uint32_t);
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(shortlist_mark_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  e = set_dynamic_lds_once(reinterpret_cast<const void *>(shortlist_mark_kernel), (int)lds1);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(shortlist_mark_kernel, dim3(blocks), dim3(1024), lds1, st, a);
   e = hipGetLastError();

@@ -1,6 +1,9 @@
 #include "Service.hh"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -28,13 +31,7 @@ void Pending::fail(const std::exception_ptr &error) {
 
 // ---- LengthQueue ---------------------------------------------------------------
 
-namespace {
-struct Later {  // std::*_heap build max-heaps: "later arrival" on top of the comparison = min-heap on order
-  bool operator()(const Unit &a, const Unit &b) const { return a.order > b.order; }
-};
-}  // namespace
-
-LengthQueue::LengthQueue(size_t max_words, size_t longest) : max_words_(max_words), heaps_(longest + 1) {
+LengthQueue::LengthQueue(size_t max_words, size_t longest) : max_words_(max_words), fifos_(longest + 1) {
   if (longest > max_words)
     throw std::invalid_argument("wrap_length > max_words: the longest sentence would not fit a batch (" +
                                 std::to_string(longest) + " > " + std::to_string(max_words) + ")");
@@ -43,10 +40,14 @@ LengthQueue::LengthQueue(size_t max_words, size_t longest) : max_words_(max_word
 
 void LengthQueue::push(Unit unit) {
   const size_t len = unit.length;
-  if (len >= heaps_.size()) throw std::invalid_argument("sentence longer than the queue accepts");
-  auto &heap = heaps_[len];
-  heap.push_back(std::move(unit));
-  std::push_heap(heap.begin(), heap.end(), Later());
+  if (len >= fifos_.size()) throw std::invalid_argument("sentence longer than the queue accepts");
+  auto &fifo = fifos_[len];
+  if (!fifo.empty() && fifo.back().order > unit.order) {  // out-of-order arrival (not the service's): keep it sorted
+    auto at = std::upper_bound(fifo.begin(), fifo.end(), unit, [](const Unit &a, const Unit &b) { return a.order < b.order; });
+    fifo.insert(at, std::move(unit));
+  } else {
+    fifo.push_back(std::move(unit));
+  }
   low_ = std::min(low_, len);
   high_ = std::max(high_, len);
   ++waiting_;
@@ -56,20 +57,19 @@ std::vector<Unit> LengthQueue::take() {
   std::vector<Unit> batch;
   if (waiting_ == 0) return batch;
   for (size_t len = low_; len <= high_; ++len) {
-    auto &heap = heaps_[len];
-    while (!heap.empty()) {
+    auto &fifo = fifos_[len];
+    while (!fifo.empty()) {
       // all rows are padded to the longest one = the one being added (lengths ascend)
       if ((batch.size() + 1) * len > max_words_) goto done;
-      std::pop_heap(heap.begin(), heap.end(), Later());
-      batch.push_back(std::move(heap.back()));
-      heap.pop_back();
+      batch.push_back(std::move(fifo.front()));
+      fifo.pop_front();
     }
   }
 done:
   waiting_ -= batch.size();
-  while (low_ <= high_ && heaps_[low_].empty()) ++low_;
+  while (low_ <= high_ && fifos_[low_].empty()) ++low_;
   if (waiting_ == 0) {
-    low_ = heaps_.size();
+    low_ = fifos_.size();
     high_ = 0;
   }
   return batch;
@@ -78,6 +78,16 @@ done:
 // ---- Service -------------------------------------------------------------------
 
 namespace {
+struct Lap {  // adds the time since construction (or the last lap) to a counter
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void to(std::atomic<uint64_t> &counter) {
+    const auto now = std::chrono::steady_clock::now();
+    counter.fetch_add(static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(now - t).count()),
+                      std::memory_order_relaxed);
+    t = now;
+  }
+};
+
 [[noreturn]] void raise(const char *what) {
   throw std::runtime_error(std::string(what) + ": " + slimt_hip_last_error());
 }
@@ -157,6 +167,14 @@ Service::~Service() {
   }
   wake_.notify_all();
   for (auto &t : threads_) t.join();
+  if (std::getenv("SLIMT_SERVICE_STATS")) {
+    const double n = static_cast<double>(batches_.load() - stats_base_), ms = 1e-6;
+    std::fprintf(stderr,
+                 "service-stats: %.0f batches, %zu workers; worker time per batch (ms): waiting for work %.3f, "
+                 "launch %.3f, waiting for the GPU %.3f, collect %.3f, deliver %.3f\n",
+                 n, threads_.size(), ms * ns_idle_ / n, ms * ns_launch_ / n, ms * ns_wait_ / n, ms * ns_collect_ / n,
+                 ms * ns_deliver_ / n);
+  }
 }
 
 std::future<Histories> Service::translate(std::vector<Words> sentences) {
@@ -193,12 +211,21 @@ std::future<Histories> Service::translate(std::vector<Words> sentences) {
 
 // The next batch, or an empty one: nothing waits (may_block false) / the service closes.
 std::vector<Unit> Service::next_batch(bool may_block) {
+  Lap lap;
   std::unique_lock<std::mutex> lock(mutex_);
   if (may_block) wake_.wait(lock, [this]() { return queue_.waiting() > 0 || closing_; });
-  return queue_.take();
+  std::vector<Unit> batch = queue_.take();
+  lap.to(ns_idle_);
+  return batch;
 }
 
 void Service::launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *generator) {
+  Lap lap;
+  struct Done {
+    Lap &lap;
+    std::atomic<uint64_t> &counter;
+    ~Done() { lap.to(counter); }
+  } done{lap, ns_launch_};
   // the slot owns the batch from here on: whatever throws below, the caller fails slot.batch
   slot.batch = std::move(batch);
   batch.clear();
@@ -236,16 +263,20 @@ void Service::launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *
 void Service::finish(Slot &slot) {
   // the batch stays in the slot until its results are in hand: if the wait fails, the caller
   // fails slot.batch with the error (its requests then see the HIP error, not a broken promise)
+  Lap lap;
   slot.worker->wait();
+  lap.to(ns_wait_);
   Histories histories = collect(slot.out_ids.get(), slot.out_len.get(),
                                 config_.alignments ? slot.align.get() : nullptr, slot.lengths.get(), slot.B,
                                 slot.S, slot.T);
+  lap.to(ns_collect_);
   std::vector<Unit> batch = std::move(slot.batch);
   slot.batch.clear();
   for (size_t b = 0; b < batch.size(); ++b) {
     histories[b]->batch = slot.serial;
     batch[b].owner->deliver(batch[b].index, std::move(histories[b]));
   }
+  lap.to(ns_deliver_);
 }
 
 // A worker that cannot run leaves: the others keep serving. Only when the LAST one has gone do
@@ -274,6 +305,15 @@ void Service::work(const Model *model, slimt_hip_shortlist *generator) {
     for (Slot &s : slots) {
       // (B + 1) * S <= max_words: at most max_words - 1 rows, at most max_words padded tokens
       s.worker = std::make_unique<Worker>(*model, config_.max_words, longest_, config_.max_words);
+      // every staging array at its largest, once: growing one later frees and allocates pinned
+      // memory, and hipHostFree waits for the whole device (B S <= max_words, T <= factor S + 1)
+      const size_t rows = config_.max_words;
+      const size_t out_tokens = static_cast<size_t>(config_.tgt_length_limit_factor * static_cast<float>(rows)) + rows + 1;
+      s.ids.ensure(rows);
+      s.lengths.ensure(rows);
+      s.out_len.ensure(rows);
+      s.out_ids.ensure(out_tokens);
+      if (config_.alignments) s.align.ensure(out_tokens * longest_);
       if (config_.shortlist && !generator) {
         uint32_t *sl = s.shortlist.ensure(config_.shortlist->size());
         std::copy(config_.shortlist->begin(), config_.shortlist->end(), sl);

@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <deque>
 #include <exception>
 #include <functional>
 #include <future>
@@ -68,18 +69,21 @@ class LengthQueue {
   // `longest` = the longest sentence accepted; the budget must hold at least one
   // such sentence (the reference's check, slimt/Batcher.cc:85-91).
   LengthQueue(size_t max_words, size_t longest);
+  // Units arrive in ascending `order` (the service numbers requests under the lock it pushes
+  // under), so every length is a FIFO: O(1) per sentence -- a request of 65,536 sentences used to
+  // hold the lock for its whole heap insertion while every worker waited.
   void push(Unit unit);
   // Next batch under the reference's rule (slimt/Batcher.cc:95-120): lengths
   // ascending, arrival order within a length, stop at the first sentence that
   // would push (count + 1) * its length over the budget. Empty when nothing waits.
   std::vector<Unit> take();
   size_t waiting() const { return waiting_; }
-  size_t longest() const { return heaps_.size() - 1; }
+  size_t longest() const { return fifos_.size() - 1; }
 
  private:
   size_t max_words_;
-  std::vector<std::vector<Unit>> heaps_;  // heaps_[len]: min-heap on Unit::order
-  size_t low_ = 0, high_ = 0;             // lengths outside [low_, high_] are empty
+  std::vector<std::deque<Unit>> fifos_;  // fifos_[len]: ascending Unit::order
+  size_t low_ = 0, high_ = 0;            // lengths outside [low_, high_] are empty
   size_t waiting_ = 0;
 };
 
@@ -117,6 +121,11 @@ class Service {
   // Queue one request. Throws std::invalid_argument for an empty sentence or one longer
   // than the service accepts; a failure on a worker arrives through the future.
   std::future<Histories> translate(std::vector<Words> sentences);
+  // restart the SLIMT_SERVICE_STATS counters (benchmarks: after the warm-up pass)
+  void stats_reset() {
+    stats_base_ = batches_.load();
+    for (auto *c : {&ns_idle_, &ns_launch_, &ns_wait_, &ns_collect_, &ns_deliver_}) c->store(0);
+  }
 
  private:
   struct Slot;
@@ -132,6 +141,9 @@ class Service {
   std::vector<std::unique_ptr<ShortlistGenerator>> generators_;  // one per device in use (lexical shortlist)
   uint64_t sequence_ = 0;
   std::atomic<uint64_t> batches_{0};  // batches launched so far (Hypothesis::batch)
+  uint64_t stats_base_ = 0;
+  // where the workers' time goes, in nanoseconds (printed by the destructor when SLIMT_SERVICE_STATS is set)
+  std::atomic<uint64_t> ns_idle_{0}, ns_launch_{0}, ns_wait_{0}, ns_collect_{0}, ns_deliver_{0};
   bool closing_ = false;
   size_t live_workers_ = 0;          // workers that can take batches
   std::exception_ptr dead_error_;    // set once the last of them has failed: requests fail with it

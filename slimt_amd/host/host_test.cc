@@ -11,12 +11,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <future>
 #include <iostream>
 #include <iterator>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "Service.hh"
@@ -165,14 +167,55 @@ static int batching_main(int argc, char **argv) {
       // first request alone and untimed: worker start-up (contexts, pinned buffers)
       const auto t0 = std::chrono::steady_clock::now();
       for (auto &r : requests) futures.push_back(service.translate(r));
-      for (auto &f : futures) results.push_back(f.get());
+      if (std::getenv("SLIMT_SERVICE_DISCARD")) {
+        // a client that consumes results as they arrive (benchmarks): count and drop, so that the
+        // allocator recycles the memory instead of faulting in 1.5 MB of fresh pages per batch
+        size_t tokens = 0;
+        for (auto &f : futures)
+          for (const auto &h : f.get()) tokens += h->target.size();
+        std::fprintf(stderr, "async-tokens: %zu\n", tokens);
+      } else {
+        for (auto &f : futures) results.push_back(f.get());
+      }
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       std::fprintf(stderr, "async: %zu requests translated in %.3f ms\n", requests.size(), ms);
       if (std::getenv("SLIMT_SERVICE_REPEAT")) {  // steady state: the same requests again, workers warm
         std::vector<std::future<Histories>> again;
+        service.stats_reset();
         const auto t1 = std::chrono::steady_clock::now();
-        for (auto &r : requests) again.push_back(service.translate(r));
-        for (auto &f : again) f.wait();
+        if (std::getenv("SLIMT_SERVICE_DISCARD")) {
+          // clients that consume (and free) their results as they arrive: request i belongs to client
+          // i mod C; one client alone would be the bottleneck once alignment rows come back (45 small
+          // vectors per sentence, Types.hh:34-36)
+          const size_t C = std::getenv("SLIMT_SERVICE_CLIENTS") ? std::max(1, std::atoi(std::getenv("SLIMT_SERVICE_CLIENTS"))) : 4;
+          std::atomic<size_t> warm_tokens{0};
+          std::vector<std::thread> clients;
+          for (size_t c = 0; c < C; ++c)
+            clients.emplace_back([&, c]() {
+              // steady state: at most `window` requests outstanding per client; the oldest is consumed
+              // (and freed) before the next one is submitted; `rounds` passes over the client's requests
+              const size_t window = std::getenv("SLIMT_SERVICE_WINDOW") ? std::max(1, std::atoi(std::getenv("SLIMT_SERVICE_WINDOW"))) : 8;
+              const size_t rounds = std::getenv("SLIMT_SERVICE_ROUNDS") ? std::max(1, std::atoi(std::getenv("SLIMT_SERVICE_ROUNDS"))) : 3;
+              std::deque<std::future<Histories>> mine;
+              size_t tokens = 0;
+              auto consume = [&]() {
+                for (const auto &h : mine.front().get()) tokens += h->target.size();
+                mine.pop_front();
+              };
+              for (size_t r = 0; r < rounds; ++r)
+                for (size_t i = c; i < requests.size(); i += C) {
+                  if (mine.size() >= window) consume();
+                  mine.push_back(service.translate(requests[i]));
+                }
+              while (!mine.empty()) consume();
+              warm_tokens += tokens;
+            });
+          for (auto &t : clients) t.join();
+          std::fprintf(stderr, "async-warm-tokens: %zu\n", warm_tokens.load());
+        } else {
+          for (auto &r : requests) again.push_back(service.translate(r));
+          for (auto &f : again) f.wait();
+        }
         const double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
         std::fprintf(stderr, "async-warm: %zu requests translated in %.3f ms\n", requests.size(), ms2);
       }

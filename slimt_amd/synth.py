@@ -183,23 +183,26 @@ def shortlist_checksum(body: bytes) -> int:
 
 
 def make_lexical_shortlist(V_src: int, V_tgt: int, frequent: int = 100, best: int = 100,
-                           seed: int = 7, empty_fraction: float = 0.1) -> bytes:
+                           seed: int = 7, empty_fraction: float = 0.1, min_count: int = 0) -> bytes:
     """A synthetic binary lexical shortlist in the layout ShortlistGenerator::load
     reads (Shortlist.hh:77-84, Shortlist.cc:41-104): header of six uint64, the
     word_to_offset table (V_src + 1 entries), then per source word a sorted list
     of <= `best` unique target ids; some words have an empty list."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    counts = rng.integers(0, best + 1, size=V_src)
+    counts = rng.integers(min(min_count, best), best + 1, size=V_src)
     counts[rng.random(V_src) < empty_fraction] = 0
     counts[-1] = max(1, min(best, V_tgt))  # content_check wants every offset but the last < size (Shortlist.cc:18-21)
     offsets = np.zeros(V_src + 1, dtype=np.uint64)
     offsets[1:] = np.cumsum(counts)
     lists = np.zeros(int(offsets[-1]), dtype=np.uint32)
-    for w in range(V_src):
-        k = int(counts[w])
-        if k:
-            lists[int(offsets[w]): int(offsets[w + 1])] = np.sort(
-                rng.choice(V_tgt, size=k, replace=False)).astype(np.uint32)
+    if best <= 1:  # one candidate per word: no sorting, no per-word draw (benchmark-sized vocabularies)
+        lists[:] = rng.integers(0, V_tgt, size=lists.size)
+    else:
+        for w in range(V_src):
+            k = int(counts[w])
+            if k:
+                lists[int(offsets[w]): int(offsets[w + 1])] = np.sort(
+                    rng.choice(V_tgt, size=k, replace=False)).astype(np.uint32)
     body = struct.pack("<4Q", frequent, best, offsets.size, lists.size) + offsets.tobytes() + lists.tobytes()
     return struct.pack("<2Q", SHORTLIST_MAGIC, shortlist_checksum(body)) + body
 
