@@ -927,6 +927,143 @@ __device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr
       pack4(quantize1(oa.x, r.aq_o), quantize1(oa.y, r.aq_o), quantize1(ob.x, r.aq_o), quantize1(ob.y, r.aq_o));
 }
 
+// Sentences of 65..128 tokens over the packed cache (written by encode_long16_kernel): lane L holds
+// keys L and L + 64 -- one head per score pass, in two half passes of 6 K loads each --, the
+// 128-column softmax in the canonical order (lane L first adds keys L and L + 64, then the 64-lane
+// butterfly, as attention_row_long and the generic form do), all heads' probabilities in LDS
+// (pbuf: [H][128]), then V as whole rows, 4 keys per three loads, key groups past the sentence skipped.
+template <int KV_AUX>
+__device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256,
+                                                     float uv256) {
+  constexpr int D = 256, DH = 32, H = D / DH;
+  const int S = __builtin_amdgcn_readfirstlane(r.S), len = __builtin_amdgcn_readfirstlane(r.len);
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int j0 = lane, j1 = lane + 64;
+  const float mask0 = (1.0f - (j0 < len ? 1.0f : 0.0f)) * minus_inf;
+  const float mask1 = (1.0f - (j1 < len ? 1.0f : 0.0f)) * minus_inf;
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 3u);
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((lenf + 3) >> 2) * 3072));
+  // masked keys are not fetched (zeros past the descriptor: the value pb, weighted by exactly 0)
+  const int koff0 = j0 < lenf ? j0 * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
+  const int koff1 = j1 < lenf ? j1 * 16 : kPastDescriptor;
+  const int voff = lane * 16;                               // [S/4][plane][D/4][16 B]
+  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g, float u256, f4 pb) -> f4 {
+    const int w[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+    return unpack24(w[3 * g], w[3 * g + 1], w[3 * g + 2], u256, pb);
+  };
+  // Two K buffers: a half pass's keys are requested one half pass ahead (keys L + 64 of head h before
+  // keys L are scored, keys L of head h + 1 before keys L + 64 are), so that a round trip to the cache
+  // runs under 64 values' worth of unpacking instead of in front of it. No store inside the loop (the
+  // probabilities leave through LDS): loads and stores share one counter, and a conditional store
+  // would make the compiler drain every load in flight at the loop head.
+  v4i ka[6], kb[6];
+  auto load_k = [&](v4i(&kq)[6], int h, int koff) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((6 * h + i) * S) * 16, KV_AUX));
+  };
+  auto score = [&](const v4i(&kq)[6], int h) -> float {  // this lane's key against head h: the ascending-column fmaf chain
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = h * DH + 16 * c + 4 * g;
+        const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
+        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, uk256, *(lcf4_ptr)(pbk + d0));
+        s = __builtin_fmaf(q4.x, kk.x, s);
+        s = __builtin_fmaf(q4.y, kk.y, s);
+        s = __builtin_fmaf(q4.z, kk.z, s);
+        s = __builtin_fmaf(q4.w, kk.w, s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return s;
+  };
+  load_k(ka, 0, koff0);
+  auto head = [&](int h, bool last) {
+    load_k(kb, h, koff1);
+    __builtin_amdgcn_sched_barrier(0);
+    float s0 = score(ka, h);
+    if (!last) load_k(ka, h + 1, koff0);  // (the last head requests nothing it would have to wait out again)
+    __builtin_amdgcn_sched_barrier(0);
+    float s1 = score(kb, h);
+    if (r.alpha != 1.0f) {
+      s0 = r.alpha * s0;
+      s1 = r.alpha * s1;
+    }
+    s0 = s0 + mask0;
+    s1 = s1 + mask1;
+    if (j0 >= S) s0 = lowest;
+    if (j1 >= S) s1 = lowest;
+    const float m = wave_max(fmaxf(s0, s1));
+    const float e0 = j0 < S ? exp_p(s0 - m) : 0.0f;
+    const float e1 = j1 < S ? exp_p(s1 - m) : 0.0f;
+    const float sum = wave_sum(e0 + e1);
+    r.pbuf[h * 128 + j0] = e0 / sum;  // keys >= S: exactly 0
+    r.pbuf[h * 128 + j1] = e1 / sum;
+  };
+#pragma unroll 1
+  for (int h = 0; h < H - 1; ++h) head(h, false);
+  head(H - 1, true);
+  constexpr int NV = 5;  // V key groups (four rows, three planes each) in flight
+  v4i vq[NV][3];
+  auto load_v = [&](v4i(&vv)[3], int g) {  // rows 4 g .. 4 g + 3 (past the descriptor: zeros)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + i) * 1024, KV_AUX));
+  };
+  if (r.align) {  // head 0 over the sentence's own keys (update_alignment, Model.cc:84-108)
+    if (j0 < len) r.align[j0] = r.pbuf[j0];
+    if (j1 < len) r.align[j1] = r.pbuf[j1];
+  }
+  if (r.attn) {
+    for (int h = 0; h < H; ++h) {
+      if (j0 < S) r.attn[(size_t)h * S + j0] = r.pbuf[h * 128 + j0];
+      if (j1 < S) r.attn[(size_t)h * S + j1] = r.pbuf[h * 128 + j1];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // the groups are requested in the order the loop re-requests them, nothing else behind them: the
+  // pending-load order at the loop head is then the same from both of its entries (exact waits)
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    load_v(vq[k], k);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
+  const int ph = (lane >> 3) * 128;
+  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
+  const int ng = (lenf + 3) >> 2;  // key groups that hold a key with a non-zero weight
+  auto group = [&](const v4i(&cur)[3], int g) {
+    if (g >= ng) return;  // (uniform) past the sentence: pbuf holds the next head's probabilities there
+    const f4 p4 = *(lcf4_ptr)(r.pbuf + ph + 4 * g);
+    const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
+      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c, uv256, pv4);
+      const f2 pp = {pj[c], pj[c]}, va = {v4.x, v4.y}, vb = {v4.z, v4.w};
+      oa = __builtin_elementwise_fma(pp, va, oa);
+      ob = __builtin_elementwise_fma(pp, vb, ob);
+    }
+    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
+  };
+#pragma unroll 1
+  for (int g = 0; g < ng; g += NV) {  // (groups past ng inside the last round are skipped; their rows: zeros)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      group(vq[k], g + k);
+      load_v(vq[k], g + k + NV);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+      pack4(quantize1(oa.x, r.aq_o), quantize1(oa.y, r.aq_o), quantize1(ob.x, r.aq_o), quantize1(ob.y, r.aq_o));
+}
+
 // The same for D = 512, d_head 64 ("base"). At K = 512 the shifted accumulator needs 25 bits, so
 // the cache holds the SIGNED one (|acc| <= 127 * 128 * 512 < 2^23) and the column's 127 colsum term
 // comes back here: c127 = float(127 colsum * 256) is exact, and so is float(acc * 256) + c127
@@ -1071,13 +1208,15 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
 // RT = row tiles per workgroup: 1 (16 sentences) or 2 (32 sentences). Every streamed weight
 // fragment then feeds RT MFMAs (half the weight bytes per sentence and step at RT = 2), wave w
 // owns sentences w and w + 16 in the row-wise phases.
-// MID: sentences of 33..64 tokens over the packed cache (D = 256; attention_row24_mid).
-template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, bool MID = false>
+// MID: 1 = sentences of 33..64 tokens over the packed cache (D = 256; attention_row24_mid), 2 = of 65..128
+// tokens (attention_row24_long; the SSRU cells then live in global memory: their 32 KB of LDS hold the
+// [H][128] probabilities of every wave's sentence).
+template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   static_assert(!KV24 || (((KSD == 4 && DH == 32) || (KSD == 8 && DH == 64)) && !LONG),
-                "the packed K/V cache: D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32 (64 with MID)");
-  static_assert(!MID || (KV24 && KSD == 4 && RT == 1), "33..64-token sentences: the D = 256 packed cache, 16 rows");
-  constexpr int PBW = MID ? 512 : 256;  // floats of attention scratch per wave ([H][S])
+                "the packed K/V cache: D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32 (64 / 128 with MID 1 / 2)");
+  static_assert(!MID || (KV24 && KSD == 4 && RT == 1), "33..128-token sentences: the D = 256 packed cache, 16 rows");
+  constexpr int PBW = MID == 2 ? 1024 : MID == 1 ? 512 : 256;  // floats of attention scratch per wave ([H][S])
   constexpr int KVC = KSD == 8 ? 4 : 2;  // constant vectors per layer in LDS (see attention_row24 / _64)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 64 * KSD, F = 64 * KSF;
@@ -1101,11 +1240,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   // LayerNorm runs from registers) and the SSRU cells live in global memory (a.cells,
   // [Ld][B][D]; 1 KiB per sentence and layer, read and written once per step).
   constexpr bool LEAN = KSD * RT > 4;
+  constexpr bool CELLS_GLOBAL = LEAN || MID == 2;  // SSRU cells in a.cells instead of LDS
   float *xs = reinterpret_cast<float *>(smem);  // layer input rows (post-LN); reused for q
   float *hs = xs + R * LDF;                     // h / o rows (post-LN residual source)
   float *pre = LEAN ? hs : hs + R * LDF;        // pre-LN accumulation
   float *cs = pre + R * LDF;                    // SSRU cells [Ld][R][D] (full layout only)
-  char *A1 = reinterpret_cast<char *>(cs + (LEAN ? 0 : (size_t)Ld * R * D));
+  char *A1 = reinterpret_cast<char *>(cs + (CELLS_GLOBAL ? 0 : (size_t)Ld * R * D));
   char *A2 = A1 + R * LDA;
   char *A3 = A2 + R * LDA;
   float *red_v = reinterpret_cast<float *>(A3 + R * LDA3);  // [NW][R]
@@ -1116,7 +1256,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   // LayerNorm scale / bias of every layer in LDS ([Ld][rnn, attn, ffn][scale, bias][D]) where it fits:
   // fetched per phase they are vector-memory loads that return IN ORDER behind whatever the wave
   // asked for before -- a weight prefetch in front of a LayerNorm would stall it by its whole transfer
-  constexpr bool LN_LDS = KSD == 4 && RT == 1 && !MID;  // (MID: the LDS goes to the wider attention scratch)
+  constexpr bool LN_LDS = KSD == 4 && RT == 1 && MID == 0;  // (MID: the LDS goes to the wider attention scratch)
   float *lnc = kvpb + (KV24 ? Ld * KVC * D : 0);
   const bool ln_lds = LN_LDS && a.ln_in_lds;  // (the launcher: only where the 160 KiB allow it)
 
@@ -1176,7 +1316,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   const int valid_rows = (B - m0) < R ? (B - m0) : R;
 
   // start_states, Transformer.cc:78-85
-  if constexpr (LEAN) {
+  if constexpr (CELLS_GLOBAL) {
     for (int l = 0; l < Ld; ++l)
       for (int i = tid; i < valid_rows * D; i += 1024) a.cells[((size_t)l * B + m0) * D + i] = 0.0f;
   } else {
@@ -1232,7 +1372,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     for (int l = 0; l < Ld; ++l) {
       SLIMT_PHASE_LANE;
       const FusedLayerW &L = a.L[l];
-      float *cl = LEAN ? a.cells + ((size_t)l * B + m0) * D : cs + (size_t)l * R * D;
+      float *cl = CELLS_GLOBAL ? a.cells + ((size_t)l * B + m0) * D : cs + (size_t)l * R * D;
       const int sb = 1 + 10 * l;
       // ---- SSRU (Modules.cc:190-235) ------------------------------------
       // quantise x twice (Wf / W have their own multipliers)
@@ -1285,7 +1425,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             const int rl = 16 * rt + lg * 4 + r;
             const float f = dequant(accf[r], csf, L.rnn_f.u, pbf);
             const float wx = dequant(accw[r], csw, L.rnn_w.u, pbw);
-            const bool cell_ok = !LEAN || rl < valid_rows;  // global cells: rows of this batch only
+            const bool cell_ok = !CELLS_GLOBAL || rl < valid_rows;  // global cells: rows of this batch only
             const float c = cell_ok ? cl[rl * D + col] : 0.0f;
             const float sg = sigmoid_p(f);  // highway(c, Wx, f), TensorOps.cc:674-678
             const float t1 = sg * c;
@@ -1333,6 +1473,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           const int b = rr ? bq[RT - 1] : bq[0];
           const bool fin = rr ? finished[RT - 1] : finished[0];
           const int no = rr ? (int)n_out[RT - 1] : (int)n_out[0];
+          // this sentence's cache of this layer: streamed past the caches (non-temporal), or kept
+          // (FusedDecodeArgs::kv_temporal_eighths: layers first, then sentences by index mod 8)
+          const bool kv_streams = 8 * l + (b & 7) >= a.kv_temporal_eighths;
           AttnRow ar;
           if constexpr (KV24) {  // same planes, 3 bytes per value
             ar.kl = (gcf_ptr)((const SLIMT_GLOBAL char *)(a.kv + (size_t)(2 * l) * B * S * D) + (size_t)EXP_SENT(b) * S * D * 3);
@@ -1354,23 +1497,29 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + no) * S) : (gf_ptr) nullptr;
           if constexpr (KV24 && KVC == 4) {
             const lcf_ptr kc = (lcf_ptr)(kvpb + (4 * l) * D);
-            if (NT && l >= a.kv_temporal_layers)
+            if (NT && kv_streams)
               attention_row24_64<2>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_64<0>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
-          } else if constexpr (MID) {
+          } else if constexpr (MID == 2) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
-            if (NT && l >= a.kv_temporal_layers)
+            if (NT && kv_streams)
+              attention_row24_long<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+            else
+              attention_row24_long<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+          } else if constexpr (MID == 1) {
+            const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
+            if (NT && kv_streams)
               attention_row24_mid<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_mid<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
           } else if constexpr (KV24) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
-            if (NT && l >= a.kv_temporal_layers)
+            if (NT && kv_streams)
               attention_row24<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-          } else if (NT && l >= a.kv_temporal_layers)
+          } else if (NT && kv_streams)
             attention_row<D, DH, LONG, 2>(ar, lane);
           else
             attention_row<D, DH, LONG, 0>(ar, lane);
@@ -1587,14 +1736,15 @@ int fused_decode_grid(int B, bool tickets, int rows) {
 
 // ln_in_lds (out, nullable): whether the LayerNorm constants of all layers (LN_LDS in the kernel: the
 // D = 256, 16-row, non-MID variants) still fit the 160 KiB; the returned size includes them then.
-size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false, bool mid = false,
+size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false, int mid = 0,
                               bool *ln_in_lds = nullptr) {
   // D * rows > 256 * 16: two f32 row buffers, SSRU cells in global memory (see the kernel)
   const size_t R = (size_t)rows;
   const bool lean = (size_t)D * R > 256 * 16;
-  const size_t f32rows = lean ? 2 * R * (D + 4) * 4 : 3 * R * (D + 4) * 4 + (size_t)Ld * R * D * 4;
+  const size_t cells = (lean || mid == 2) ? 0 : (size_t)Ld * R * D * 4;
+  const size_t f32rows = (lean ? 2 : 3) * R * (D + 4) * 4 + cells;
   const size_t base = f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 +
-                      NW * (mid ? 512 : 256) * 4 + (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0);
+                      NW * (mid == 2 ? 1024 : mid == 1 ? 512 : 256) * 4 + (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0);
   const size_t ln = (D == 256 && rows == 16 && !mid) ? (size_t)Ld * 6 * D * 4 : 0;
   const bool fits = ln > 0 && base + ln <= 160 * 1024;
   if (ln_in_lds) *ln_in_lds = fits;
@@ -1604,7 +1754,13 @@ size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false,
 // sentences of 33..64 tokens over the packed cache (decode_fused_kernel<..., MID>)
 bool fused_decode_mid_supported(int D, int F, int H, int Ld) {
   if (Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
-  return D == 256 && F == 1536 && D / H == 32 && fused_decode_lds_bytes(D, F, Ld, 16, true, true) <= 160 * 1024;
+  return D == 256 && F == 1536 && D / H == 32 && fused_decode_lds_bytes(D, F, Ld, 16, true, 1) <= 160 * 1024;
+}
+
+// sentences of 65..128 tokens over the packed cache (decode_fused_kernel<..., MID = 2>)
+bool fused_decode_long24_supported(int D, int F, int H, int Ld) {
+  if (Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
+  return D == 256 && F == 1536 && D / H == 32 && fused_decode_lds_bytes(D, F, Ld, 16, true, 2) <= 160 * 1024;
 }
 
 bool fused_decode_supported(int D, int F, int H, int Ld) {
@@ -1636,19 +1792,20 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   const int rows = fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg);
   const dim3 grid(a.home_mask ? (int)a.xgrid : fused_decode_grid(a.B, a.ticket != nullptr, rows));
   const bool kv24 = a.kv24;
-  const bool mid = kv24 && D == 256 && a.S > 32;  // 33..64-token sentences (cache written by encode_tall_kernel<., 4>)
-  if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= (D == 256 ? 64 : 32))) return hipErrorInvalidValue;
+  const int mid = (kv24 && D == 256 && a.S > 32) ? (a.S > 64 ? 2 : 1) : 0;  // 33..64 / 65..128-token sentences
+  if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= (D == 256 ? 128 : 32))) return hipErrorInvalidValue;
   if (mid) {
     if (rows != 16 || F != 1536) return hipErrorInvalidValue;
-    const size_t ldsm = fused_decode_lds_bytes(D, F, a.Ld, 16, true, true);
+    const size_t ldsm = fused_decode_lds_bytes(D, F, a.Ld, 16, true, mid);
     if (ldsm > 160 * 1024) return hipErrorInvalidValue;
-    auto k = a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, true> : decode_fused_kernel<4, 24, 32, false, false, 1, true, true>;
+    auto k = mid == 2 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 1, true, 2>)
+                      : (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 1> : decode_fused_kernel<4, 24, 32, false, false, 1, true, 1>);
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)ldsm);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(1024), ldsm, st, a);
     return hipGetLastError();
   }
-  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows, kv24, false, &a.ln_in_lds);
+  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows, kv24, 0, &a.ln_in_lds);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (kv24 && D == 512) {
     if (F != 2048) return hipErrorInvalidValue;

@@ -1146,6 +1146,58 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
                                    : make_rsrc(out + (size_t)row0 * D, sbytes);
       const int voff = which == 0 ? (((d >> 2) * S + lg * 4) * 4 + (d & 3)) * 4 : (lg * 4 * D + col) * 4;
       const int rstep = which == 0 ? 16 : D * 4;  // bytes per row
+      if (f.kv24) {
+        // The packed cache (kernels.h, FusedDecodeArgs::kv24): the shifted accumulators accS = acc +
+        // 127 colsum as 24-bit integers, 16 values = 48 bytes = one 16-byte store in each of three planes.
+        // They pass through LDS (the operand and the attention staging are free: [16 nrt][256] int32)
+        // so that a thread holds 16 columns of one key (K) or 4 keys x 4 columns (V).
+        __syncthreads();  // every wave has read its A fragments
+        int *stg = reinterpret_cast<int *>(smem);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+          if (rt < nrt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(16 * rt + lg * 4 + r) * D + col] = acc[rt][r] + __mul24(127, cs);
+          }
+        __syncthreads();
+        const int Sp = (S + 3) & ~3;
+        if (which == 0) {  // K [sentence][column / 16][plane][key][16 B]: consecutive lanes = consecutive keys
+          const rsrc_t rp = make_rsrc(reinterpret_cast<const char *>(out) + (size_t)b * S * D * 3, (unsigned)(S * D * 3));
+          for (int it = tid; it < S * (D / 16); it += 1024) {
+            const int r = it % S, ci = it / S;
+            v3i wd[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wd[g] = pack24(*reinterpret_cast<const v4i *>(stg + r * D + 16 * ci + 4 * g));
+            const int off = (ci * 3 * S + r) * 16;
+            const v4i p0 = {wd[0].x, wd[0].y, wd[0].z, wd[1].x}, p1 = {wd[1].y, wd[1].z, wd[2].x, wd[2].y},
+                      p2 = {wd[2].z, wd[3].x, wd[3].y, wd[3].z};
+            __builtin_amdgcn_raw_buffer_store_b128(p0, rp, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, rp, off + S * 16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p2, rp, off + 2 * S * 16, 0, 0);
+          }
+        } else {  // V [sentence][key / 4][plane][column / 4][16 B]: 4 keys x 4 columns, key-major
+          const rsrc_t rp = make_rsrc(reinterpret_cast<const char *>(out) + (size_t)b * Sp * D * 3, (unsigned)(Sp * D * 3));
+          for (int it = tid; it < (Sp / 4) * 64; it += 1024) {
+            const int cl = it & 63, g = it >> 6;
+            v3i wd[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // keys past the sentence: zeros (finite once unpacked, weight 0)
+              const int key = 4 * g + i;
+              const v4i xv = *reinterpret_cast<const v4i *>(stg + (key < S ? key : 0) * D + 4 * cl);
+              const v4i z = {0, 0, 0, 0};
+              wd[i] = pack24(key < S ? xv : z);
+            }
+            const int off = (g * 3 * 64 + cl) * 16;
+            const v4i p0 = {wd[0].x, wd[0].y, wd[0].z, wd[1].x}, p1 = {wd[1].y, wd[1].z, wd[2].x, wd[2].y},
+                      p2 = {wd[2].z, wd[3].x, wd[3].y, wd[3].z};
+            __builtin_amdgcn_raw_buffer_store_b128(p0, rp, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, rp, off + 1024, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p2, rp, off + 2048, 0, 0);
+          }
+        }
+        __syncthreads();
+        continue;
+      }
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt)
         if (rt < nrt) {

@@ -1059,6 +1059,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     f.lengths = d_lengths ? d_lengths : c->lengths.as<uint32_t>();
     f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
     f.kv = c->kv.as<float>();
+    f.kv24 = kv24;
     f.enc_out = c->x0.as<float>();
     if (pack) {
       f.pack = *pack;
@@ -1086,7 +1087,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     if (h_layers)
       HIPCHK(hipMemcpyAsync(h_layers, c->dbg_layers.p, nbytes * (size_t)m->Le, hipMemcpyDeviceToHost, st));
     c->have_encoder_out = true;
-    c->kv_ready = true;
+    c->kv_ready = !kv24;  // the step-wise decoder reads the f32 form only
     return 0;
   }
   float *x = c->x0.as<float>(), *y = c->x1.as<float>();
@@ -1321,10 +1322,13 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   const bool kv24_mid = S > 32 && S <= 64 && c->encode_rows != 32 && c->decode_mode != 3 &&
                         fused_decode_mid_supported(m->D, m->F, m->H, m->Ld) &&
                         tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
+  // ... and for 65..128-token sentences of that shape (the per-sentence encoder, attention_row24_long)
+  const bool kv24_long = S > 64 && S <= 128 && c->decode_mode != 3 && fused_decode_long24_supported(m->D, m->F, m->H, m->Ld) &&
+                         long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
   const bool kv24 = lean && m->kv_format == 0 &&
                     ((m->D == 256 && m->D / m->H == 32) || (m->D == 512 && m->D / m->H == 64 && m->F == 2048)) &&
                     ((S <= 32 && ((S + 3) & ~(size_t)3) * 3 <= S * 4 &&
-                      fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S)) || kv24_mid);
+                      fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S)) || kv24_mid || kv24_long);
   // One thread at a time queues a persistent translate (a few runtime calls, ~50 us): the runtime
   // serialises launches internally anyway, and a dozen worker threads contending inside it take
   // far longer per call than the same calls made one after the other (Service, 10 workers: 2.1 ms
@@ -1479,10 +1483,16 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       }
       if (!known) gm->gate_ctx.push_back({c, gm->gate_seq, kv_bytes, now});
       const double active = pending / (double)contexts * (double)std::min(contexts, n);
-      int t_layers = gm->kv_policy == 1 ? m->Ld : gm->kv_policy == 2 ? 0
-                     : (int)std::min((double)m->Ld, std::floor((double)m->Ld * 300.0e6 / active));
-      f.kv_nt = t_layers < m->Ld;
-      f.kv_temporal_layers = t_layers;
+      // ... in eighths of a layer's caches (kernels.h, kv_temporal_eighths): SLIMT_KV_BUDGET_MB /
+      // SLIMT_KV_GRAIN tune the rule (defaults: 300 MB in whole layers, the measured optimum above)
+      static const double budget = (std::getenv("SLIMT_KV_BUDGET_MB") ? std::atof(std::getenv("SLIMT_KV_BUDGET_MB")) : 300.0) * 1e6;
+      static const int grain = std::getenv("SLIMT_KV_GRAIN") ? std::max(1, std::atoi(std::getenv("SLIMT_KV_GRAIN"))) : 8;
+      const int all = 8 * m->Ld;
+      int eighths = gm->kv_policy == 1 ? all : gm->kv_policy == 2 ? 0
+                    : (int)std::min((double)all, std::floor((double)all * budget / active));
+      if (gm->kv_policy == 0) eighths = eighths / grain * grain;
+      f.kv_nt = eighths < all;
+      f.kv_temporal_eighths = eighths;
       if (gm->gate_seq >= n) HIPCHK(hipStreamWaitEvent(st, gm->gate_ev[(gm->gate_seq - n) % kRing], 0));
       clk.lap(3);
       const int n_home = gm->xcd_affinity;

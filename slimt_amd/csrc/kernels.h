@@ -294,7 +294,10 @@ struct FusedDecodeArgs {
   float kv_u256[4][2] = {};       // [layer][K, V]: unquantisation multiplier u / 256
   bool ln_in_lds = false;  // set by the launcher: the LayerNorm constants of all layers fit LDS beside the rest
   bool kv_nt = false;  // non-temporal K/V cache loads (d_head 32 / 64 shapes; see decode_fused.hip)
-  int kv_temporal_layers = 0;  // with kv_nt: the first layers' caches are still read temporally
+  // with kv_nt: which caches are still read temporally, in eighths of a layer: sentence b's cache of
+  // layer l is kept iff 8 l + (b mod 8) < kv_temporal_eighths (8 = all of layer 0, 12 = layer 0 and
+  // half the sentences' layer 1, ...)
+  int kv_temporal_eighths = 0;
   OccTrace trace;
 };
 // hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), but only when
@@ -305,6 +308,7 @@ int fused_decode_grid(int B, bool tickets, int rows);
 int fused_encode_grid(int B, int S, bool tickets);
 bool fused_decode_supported(int D, int F, int H, int Ld);
 bool fused_decode_mid_supported(int D, int F, int H, int Ld);
+bool fused_decode_long24_supported(int D, int F, int H, int Ld);
 int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
 

@@ -1,6 +1,6 @@
 """GPU box: per-phase time of one decoder workgroup (tile 0 of context 0, one step) WHILE
 the other workers run the bench load -- which phases do the neighbours stretch?
-usage: python tools/decode_phases_loaded.py [workers=20]"""
+usage: python tools/decode_phases_loaded.py [workers=20] [batch=256] [src_len=32]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
@@ -9,7 +9,9 @@ import torch
 from slimt_amd import capi, synth
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-B, S, n_sl = 256, 32, 4096
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+n_sl = 4096
 dev = torch.device("cuda", 0)
 m = synth.make_model("tiny11", seed=1234, eos_bias=-100.0)
 gm = capi.Model(m)
