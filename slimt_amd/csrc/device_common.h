@@ -162,6 +162,64 @@ __device__ __forceinline__ int quantize1(float x, float a_quant) {
   return (int)v;
 }
 
+// Correctly rounded quotients of SEVERAL numerators over ONE denominator (a LayerNorm row's sigma, a
+// softmax row's sum). The compiler expands n / d (-fhip-fp32-correctly-rounded-divide-sqrt) into
+//   v_div_scale x2, v_rcp, 2 fma (reciprocal refinement), mul, 3 fma (quotient refinement),
+//   v_div_fmas, v_div_fixup
+// and while neither operand needs scaling and nothing is special, scale / fmas / fixup are the
+// identity: the quotient IS the fma chain below, whose first three operations depend on d alone.
+// So the reciprocal is refined once per denominator and a quotient costs mul + 4 fma + its guard
+// instead of twelve instructions (one of them a quarter-rate v_rcp) -- the same bits, not an
+// approximation: tools/probes/div_probe.hip compares the two over 1.7e10 operand pairs per guard
+// range (profiles/r03_div_probe.txt: 0 mismatches inside the ranges used here, mismatches outside).
+// Outside the guard (any lane of the wave: the branch is uniform) the compiler's division runs.
+struct SharedDiv {
+  float d, r1;
+  bool d_ok;
+  __device__ __forceinline__ SharedDiv(float den, float d_lo, float d_hi) : d(den) {
+    const float r0 = __builtin_amdgcn_rcpf(den);
+    const float e = __builtin_fmaf(-den, r0, 1.0f);
+    r1 = __builtin_fmaf(e, r0, r0);
+    d_ok = den >= d_lo && den <= d_hi;
+  }
+  __device__ __forceinline__ float chain(float n) const {
+    const float q0 = n * r1;
+    const float m0 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(m0, r1, q0);
+    const float m1 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(m1, r1, q1);
+  }
+  // n_lo <= |n| <= n_hi, or n == +0 exactly where ZERO (a softmax's masked keys). Bitwise, not
+  // short-circuit: `&&` / `||` on per-lane conditions compile to nested exec-mask branches.
+  template <bool ZERO>
+  __device__ __forceinline__ unsigned inside(float n, float n_lo, float n_hi) const {
+    const float an = __builtin_fabsf(n);
+    unsigned in = (unsigned)(an >= n_lo);
+    if (ZERO) return in | (unsigned)(__float_as_uint(n) == 0u);  // (a softmax term is exp(x - max) <= 1: no upper check;
+    return in & (unsigned)(an <= n_hi);                           //  a NaN fails `>=` and takes the compiler's division)
+  }
+  // N quotients, one guard for all of them
+  template <int N, bool ZERO>
+  __device__ __forceinline__ void quot(float (&n)[N], float n_lo, float n_hi) const {
+    unsigned in = (unsigned)d_ok;
+#pragma unroll
+    for (int i = 0; i < N; ++i) in &= inside<ZERO>(n[i], n_lo, n_hi);
+    if (__builtin_amdgcn_ballot_w64(in == 0u) != 0) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) n[i] = n[i] / d;
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) n[i] = chain(n[i]);
+    }
+  }
+};
+// guard ranges verified by the probe: LayerNorm (v - mean) / sigma, sigma = sqrt(var + 1e-6) >= 2^-10;
+// softmax e / sum, e in [0, 1], sum >= 1 (the maximum's own term)
+#define SLIMT_DIV_LN_D 0x1p-12f, 0x1p20f
+#define SLIMT_DIV_LN_N 0x1p-100f, 0x1p40f
+#define SLIMT_DIV_SM_D 0x1p-1f, 0x1p12f
+#define SLIMT_DIV_SM_N 0x1p-100f, 0x1p1f
+
 __device__ __forceinline__ int pack4(int a, int b, int c, int d) {
   return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24);
 }

@@ -120,9 +120,13 @@ __device__ __forceinline__ void ln_regs(float (&v)[DPL], const float (&scale)[DP
   }
   q = wave_sum(q);
   const float sigma = __builtin_sqrtf(q / (float)D + eps);
+  float tq[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) tq[i] = v[i] - mean;
+  SharedDiv(sigma, SLIMT_DIV_LN_D).quot<DPL, false>(tq, SLIMT_DIV_LN_N);  // (v - mean) / sigma, correctly rounded
 #pragma unroll
   for (int i = 0; i < DPL; ++i) {
-    const float t = (v[i] - mean) / sigma;
+    const float t = tq[i];
     const float m = scale[i] * t;
     v[i] = m + bias[i];
   }
@@ -389,10 +393,13 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
             t[kt] = bf_add<32>(bf_add<16>((sc[kt][0] + sc[kt][1]) + (sc[kt][2] + sc[kt][3])));  // masks 1, 2 | 4 | 8
           const float sum = t[0] + t[1];                                                          // mask 16
           float pa[2][4];  // pa[kt][j] on lane (n, g) = P[query n][key 16 kt + 4 j + g]
+          {  // e / sum for this lane's eight keys: one refined reciprocal (device_common.h, SharedDiv)
+            const SharedDiv dv(sum, SLIMT_DIV_SM_D);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) dv.quot<4, true>(sc[kt], SLIMT_DIV_SM_N);  // keys >= S: exactly 0
+          }
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[kt][r] = sc[kt][r] / sum;  // keys >= S: exactly 0
             const slimt_u2 s01 = __builtin_amdgcn_permlane16_swap(__float_as_int(sc[kt][0]), __float_as_int(sc[kt][1]), false, false);
             const slimt_u2 s23 = __builtin_amdgcn_permlane16_swap(__float_as_int(sc[kt][2]), __float_as_int(sc[kt][3]), false, false);
             const slimt_u2 ac = __builtin_amdgcn_permlane32_swap(s01.x, s23.x, false, false);

@@ -139,18 +139,35 @@ class Service:
 
     # -- batching ---------------------------------------------------------------------------------
     def _batches(self, units: Sequence[_Unit]) -> List[List[_Unit]]:
-        """Longest first; a batch closes when (sentences x its longest) would pass max_words."""
-        order = sorted(units, key=lambda u: (-len(u.words), u.request, u.index))
+        """The reference's batch-forming rule (Batcher::generate, slimt/Batcher.cc:95-120), as the C++
+        Service's LengthQueue applies it: walk the lengths UPWARDS, arrival order inside a length, and
+        keep adding sentences while (count + 1) * length fits the word budget -- a batch is as wide as
+        the last sentence added, and a sentence's padding (hence its length limit floor(1.5 S)) is the
+        same here, in host/Service.cc and in the reference."""
+        order = sorted(units, key=lambda u: (len(u.words), u.request, u.index))
         out, cur = [], []
         for u in order:
-            width = len(cur[0].words) if cur else len(u.words)
-            if cur and (len(cur) + 1) * width > self.max_words:
+            if cur and (len(cur) + 1) * len(u.words) > self.max_words:
                 out.append(cur)
                 cur = []
             cur.append(u)
         if cur:
             out.append(cur)
         return out
+
+    # the engine's longest source (the reference wraps at 128, Frontend.hh:27, and its batcher leaves
+    # slack above that for the rare longer segment, Batcher.cc:83-88)
+    ENGINE_LIMIT = 128
+
+    def _split_long(self, words: List[int], eos: int) -> List[List[int]]:
+        """A segment longer than the engine takes (only a pivot's second hop can produce one: its
+        input is the first model's output re-tokenised, not wrapped text) goes through in pieces of
+        at most ENGINE_LIMIT tokens, every piece ending in EOS."""
+        if len(words) <= self.ENGINE_LIMIT:
+            return [words]
+        body = list(words[:-1]) if words and words[-1] == eos else list(words)
+        step = self.ENGINE_LIMIT - 1
+        return [body[i:i + step] + [eos] for i in range(0, len(body), step)]
 
     def _context(self, model: Model, B: int, S: int) -> capi.Context:
         """This thread's context for `model`: a token-budget workspace for every batch _batches can
@@ -180,12 +197,41 @@ class Service:
         return [(u, out_ids[i, :int(out_len[i])], align[i, :int(out_len[i]), :int(lens[i])]) for i, u in enumerate(batch)]
 
     def _translate_segments(self, model: Model, per_request: List[List[List[int]]]):
-        units = [_Unit(r, i, seg) for r, segs in enumerate(per_request) for i, seg in enumerate(segs)]
-        histories = [[None] * len(segs) for segs in per_request]
+        eos = model.vocabulary.eos_id()
+        units, pieces_of = [], {}
+        for r, segs in enumerate(per_request):
+            for i, seg in enumerate(segs):
+                pieces = self._split_long(list(seg), eos)
+                pieces_of[(r, i)] = len(pieces)
+                for k, piece in enumerate(pieces):
+                    units.append(_Unit(r, (i, k), piece))
+        parts = {}
         futures = [self._pool.submit(self._run_batch, model, b) for b in self._batches(units)]
         for f in futures:
             for u, words, alignment in f.result():
-                histories[u.request][u.index] = (words, alignment)
+                parts[(u.request, u.index)] = (words, alignment, len(u.words))
+        histories = [[None] * len(segs) for segs in per_request]
+        for (r, i), n in pieces_of.items():
+            if n == 1:
+                words, alignment, _ = parts[(r, (i, 0))]
+                histories[r][i] = (words, alignment)
+                continue
+            # a split segment: targets concatenated (inner EOS dropped), alignment rows block-diagonal
+            # over the pieces' source tokens (the pieces' inner EOS columns dropped, the last one kept)
+            got = [parts[(r, (i, k))] for k in range(n)]
+            widths = [L - 1 for _, _, L in got[:-1]] + [got[-1][2]]
+            total = sum(widths)
+            out_words, rows, col = [], [], 0
+            for k, (words, alignment, L) in enumerate(got):
+                last = k == n - 1
+                keep = len(words) if last or not len(words) or words[-1] != eos else len(words) - 1
+                for t in range(keep):
+                    row = np.zeros(total, np.float32)
+                    row[col:col + widths[k]] = np.asarray(alignment[t], np.float32)[:widths[k]]
+                    rows.append(row)
+                out_words.extend(int(w) for w in words[:keep])
+                col += widths[k]
+            histories[r][i] = (np.asarray(out_words, np.uint32), np.stack(rows) if rows else np.zeros((0, total), np.float32))
         return histories
 
     # -- the binding's calls -----------------------------------------------------------------------

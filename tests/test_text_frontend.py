@@ -173,8 +173,20 @@ def test_service_batches_by_token_budget():
         assert sorted(u.index for b in batches for u in b) == list(range(9))
         for b in batches:
             width = max(len(u.words) for u in b)
-            assert len(b) * width <= 64 and len(b[0].words) == width
-        assert [len(u.words) for u in batches[0]] == [31, 30]
+            assert len(b) * width <= 64 and len(b[-1].words) == width
+            assert [len(u.words) for u in b] == sorted(len(u.words) for u in b)
+        # the reference's walk (Batcher.cc:95-120): lengths ascending, (count + 1) * length <= max_words
+        assert [[len(u.words) for u in b] for b in batches] == [[2, 3, 5, 7, 9], [16, 16], [30, 31]]
+        # ... the same batches the C++ LengthQueue forms (oracle.batcher_generate restates the reference)
+        from oracle import oracle as O
+        want = O.batcher_generate([[len(u.words) for u in units]], 64, 32, 1.5)
+        assert [[(u.request, u.index) for u in b] for b in batches] == want
+        # a segment longer than the engine takes (a pivot's second hop) travels in pieces that end in EOS
+        long = list(range(5, 5 + 300)) + [0]
+        pieces = svc._split_long(long, 0)
+        assert [len(p) for p in pieces] == [128, 128, 47] and all(p[-1] == 0 for p in pieces)
+        assert [w for p in pieces for w in p[:-1]] == long[:-1]
+        assert svc._split_long([4, 5, 0], 0) == [[4, 5, 0]]
     finally:
         svc.close()
 
