@@ -279,12 +279,30 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   };
   // one 16-column weight tile (K = D) against row tile rt of `A`: accumulator lane = row
   // 16 rt + lr, columns 4 lg .. 4 lg + 3 of the tile
-  auto mma_rt = [&](const char *A, const v4i (&f)[KSD], int rt, int lane) {
+  // This lane's fragment offsets inside a row tile of an A buffer, one per k-step: the XOR swizzle depends
+  // on (lr, lg, ks) only, a row tile adds the constant 16 rt LDA -- computed ONCE per phase (AFrag) and
+  // pinned, the reads then carry an immediate offset. Recomputed per read (what the compiler does
+  // with the plain expression) it is three VALU instructions per fragment, 12 per (tile, row tile) next
+  // to 4 MFMAs and a 29-instruction epilogue.
+  typedef const __attribute__((address_space(3))) char *lds_cptr;
+  struct AFrag {
+    lds_cptr p[KSD];
+  };
+  auto a_frag = [&](const char *A, int lane) {
     const int lr = lane & 15, lg = lane >> 4;
+    AFrag o;
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) {
+      o.p[ks] = (lds_cptr)(A + lr * LDA + (((ks * 4 + lg) ^ lr) << 4));
+      asm volatile("" : "+v"(o.p[ks]));
+    }
+    return o;
+  };
+  auto mma_rt = [&](const v4i (&f)[KSD], int rt, const AFrag &o) {
     v4i c = {0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < KSD; ++ks) {
-      const v4i av = *reinterpret_cast<const v4i *>(A + (16 * rt + lr) * LDA + (((ks * 4 + lg) ^ lr) << 4));
+      const v4i av = *reinterpret_cast<const __attribute__((address_space(3))) v4i *>(o.p[ks] + 16 * rt * LDA);
       c = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], av, c, 0, 0, 0);
     }
     return c;
@@ -322,16 +340,18 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         }
         const char *A1 = qv ? Aq : Ak;
         float *dst1 = qv ? qb : kb;
+        const AFrag af = a_frag(A1, lane);
 #pragma unroll
         for (int rt = 0; rt < TRT; ++rt) {
-          const v4i c = mma_rt(A1, w1, rt, lane);
+          const v4i c = mma_rt(w1, rt, af);
           *reinterpret_cast<float4 *>(dst1 + (16 * rt + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(c, e1, W1.u);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (qv) {
+          const AFrag afv = a_frag(Av, lane);
 #pragma unroll
           for (int rt = 0; rt < TRT; ++rt) {
-            const v4i cv = mma_rt(Av, wv, rt, lane);
+            const v4i cv = mma_rt(wv, rt, afv);
             *reinterpret_cast<float4 *>(vb + (16 * rt + lr) * LDV + ctl * 16 + lg * 4) = tdequant4(cv, ev, L.v.u);
           }
         }
@@ -491,13 +511,14 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     };
     {  // FFN1: NT1 column tiles per wave, three in flight; relu, requantised into the hidden layer
       SLIMT_TPHASE_LANE;
+      const AFrag af = a_frag(Aq, lane);
 #pragma unroll
       for (int i = 0; i < NT1; ++i) {
         const int buf = i % 3, t = wave + TNW * i;
         const TEpi e = e1[buf];
 #pragma unroll
         for (int rt = 0; rt < TRT; ++rt) {
-          const v4i c = mma_rt(Aq, bw[buf], rt, lane);
+          const v4i c = mma_rt(bw[buf], rt, af);
           *reinterpret_cast<int *>(Hb + (16 * rt + lr) * LDH + t * 16 + lg * 4) = trelu_quant4(c, e, L.ffn1.u, L.ffn2.a_quant);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -592,10 +613,11 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       quantise_x(Aq, w.a_quant, lane);
       lds_barrier();
       const int col = wave * 16 + lg * 4;
+      const AFrag af = a_frag(Aq, lane);
       int *stg = reinterpret_cast<int *>(region);  // packed cache: [TR][LDY] shifted accumulators
 #pragma unroll
       for (int rt = 0; rt < TRT; ++rt) {
-        const v4i c = mma_rt(Aq, wf, rt, lane);
+        const v4i c = mma_rt(wf, rt, af);
         const int rrow = 16 * rt + lr;
         if (a.kv24) {
           const v4i s4 = {c[0] + __mul24(127, e.cs[0]), c[1] + __mul24(127, e.cs[1]), c[2] + __mul24(127, e.cs[2]),
