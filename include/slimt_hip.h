@@ -147,6 +147,8 @@ int slimt_hip_model_set_xcd_affinity(slimt_hip_model *model, int xcds);
 int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format);
 int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
                          int32_t *dim_ffn, int32_t *vocab, int32_t *heads);
+/* the device the model's weights live on (-1 for NULL) */
+int slimt_hip_model_device(const slimt_hip_model *model);
 
 /* stream: a hipStream_t to run on (borrowed), or NULL to create one. */
 int slimt_hip_ctx_create(slimt_hip_model *model, size_t max_batch,

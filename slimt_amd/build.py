@@ -120,6 +120,30 @@ def build_host(force: bool = False) -> str:
     return HOST_TEST
 
 
+HOST_LIB = os.path.join(LIB_DIR, "libslimt_hip_host.so")
+HOST_LIB_SOURCES = ["Io.cc", "Model.cc", "Shortlist.cc", "Service.cc", "service_capi.cc"]
+
+
+def build_host_lib(force: bool = False) -> str:
+    """libslimt_hip_host.so: the C++ Service behind include/slimt_hip_service.h (what a binding
+    links next to libslimt_hip.so)."""
+    build()
+    srcs = [os.path.join(HOST_DIR, s) for s in HOST_LIB_SOURCES]
+    deps = srcs + [os.path.join(HOST_DIR, h) for h in os.listdir(HOST_DIR)] + [
+        LIB_PATH, os.path.join(ROOT, "include", "slimt_hip_service.h")]
+    if not force and os.path.exists(HOST_LIB) and all(
+            os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps):
+        return HOST_LIB
+    rocm_lib = "/opt/rocm/lib"
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-fPIC", "-shared", "-I", HOST_DIR,
+           "-I", os.path.join(ROOT, "include")] + srcs + [
+        "-L", LIB_DIR, "-lslimt_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + rocm_lib,
+        "-Wl,-rpath," + rocm_lib, "-pthread", "-o", HOST_LIB]
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv))
+    print(build_host_lib(force="--force" in sys.argv))

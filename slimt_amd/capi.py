@@ -28,7 +28,7 @@ SYMBOLS = [
     "slimt_hip_debug_decode_stamps",
     "slimt_hip_debug_occupancy_trace", "slimt_hip_model_set_decoder_budget",
     "slimt_hip_model_set_kv_cache_policy",
-    "slimt_hip_model_set_xcd_affinity",
+    "slimt_hip_model_set_xcd_affinity", "slimt_hip_model_device",
     "slimt_hip_model_set_kv_cache_format",
     "slimt_hip_shortlist_create", "slimt_hip_shortlist_destroy", "slimt_hip_shortlist_info",
     "slimt_hip_shortlist_generate", "slimt_hip_shortlist_generate_device",
@@ -550,3 +550,139 @@ class ShortlistGenerator:
         except Exception:
             pass
 
+
+
+# ---- the batching service (include/slimt_hip_service.h, libslimt_hip_host.so) -----------------------
+_host_lib = None
+
+
+def host_lib():
+    """Load libslimt_hip_host.so (host/Service behind a C ABI; built by __graft_entry__.build())."""
+    global _host_lib
+    if _host_lib is not None:
+        return _host_lib
+    lib()  # libslimt_hip.so first: the host library links against it
+    path = _build.HOST_LIB
+    if not os.path.exists(path):
+        raise SlimtHipError(f"{path} is missing: build it with `python -m slimt_amd.build`")
+    H = C.CDLL(path)
+    vp, sz = C.c_void_p, C.c_size_t
+    H.slimt_hip_service_last_error.restype = C.c_char_p
+    H.slimt_hip_service_create.argtypes = [vp, vp, sz, vp]
+    H.slimt_hip_service_destroy.argtypes = [vp]
+    H.slimt_hip_service_translate.argtypes = [vp, vp, vp, sz, vp]
+    H.slimt_hip_result_view.argtypes = [vp] * 8
+    H.slimt_hip_result_destroy.argtypes = [vp]
+    _host_lib = H
+    return H
+
+
+class _ServiceConfig(C.Structure):
+    _fields_ = [("max_words", C.c_uint64), ("wrap_length", C.c_uint64), ("limit_factor", C.c_float),
+                ("workers_per_device", C.c_uint32), ("pad_id", C.c_uint32), ("eos_id", C.c_uint32),
+                ("alignments", C.c_int32), ("lexical_shortlist", C.c_void_p), ("lexical_shortlist_bytes", C.c_uint64),
+                ("source_vocab", C.c_uint64), ("target_vocab", C.c_uint64), ("shortlist_shared_vocab", C.c_int32),
+                ("shortlist_check", C.c_int32), ("shortlist", C.c_void_p), ("n_shortlist", C.c_uint64)]
+
+
+class ServiceResult:
+    """One request's result (slimt_hip_result): flat arrays, views valid while this object lives.
+    targets[target_offsets[i]:target_offsets[i+1]] = sentence i's target ids (EOS included);
+    alignment(i) = its [target tokens, source tokens] matrix."""
+
+    def __init__(self, handle, source_lengths):
+        self.h = handle
+        n = C.c_size_t()
+        ptrs = [C.c_void_p() for _ in range(6)]
+        rc = host_lib().slimt_hip_result_view(self.h, C.byref(n), *[C.byref(p) for p in ptrs])
+        if rc:
+            raise SlimtHipError(host_lib().slimt_hip_service_last_error().decode())
+        self.n = n.value
+
+        def arr(p, dtype, count):
+            if not count or not p.value:
+                return np.zeros(0, dtype)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(count,))
+
+        self.target_offsets = arr(ptrs[1], np.uint64, self.n + 1)
+        self.targets = arr(ptrs[0], np.uint32, int(self.target_offsets[-1]) if self.n else 0)
+        self.padded_length = arr(ptrs[2], np.uint32, self.n)
+        self.batch = arr(ptrs[3], np.uint64, self.n)
+        self.align_offsets = arr(ptrs[5], np.uint64, self.n + 1)
+        self.alignments = arr(ptrs[4], np.float32, int(self.align_offsets[-1]) if self.n else 0)
+        self.source_lengths = source_lengths
+
+    def target(self, i: int) -> np.ndarray:
+        return self.targets[int(self.target_offsets[i]):int(self.target_offsets[i + 1])]
+
+    def alignment(self, i: int) -> np.ndarray:
+        a, b = int(self.align_offsets[i]), int(self.align_offsets[i + 1])
+        rows = int(self.target_offsets[i + 1] - self.target_offsets[i])
+        return self.alignments[a:b].reshape(rows, -1) if b > a else np.zeros((rows, 0), np.float32)
+
+    def close(self):
+        if getattr(self, "h", None):
+            host_lib().slimt_hip_result_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchService:
+    """host/Service over its C ABI: tokenised sentences in, target ids + alignment rows out; token-budget
+    batches, double-buffered pinned workers, per-batch lexical shortlist on the device."""
+
+    def __init__(self, models, max_words: int = 8192, wrap_length: int = 128, limit_factor: float = 1.5,
+                 workers_per_device: int = 6, pad_id: int = 0, eos_id: int = 0, alignments: bool = True,
+                 lexical_shortlist: bytes = b"", source_vocab: int = 0, target_vocab: int = 0,
+                 shared_vocab: bool = False, check: bool = False, shortlist=None):
+        self._keep = []
+        cfg = _ServiceConfig(max_words, wrap_length, limit_factor, workers_per_device, pad_id, eos_id,
+                             1 if alignments else 0, None, 0, source_vocab, target_vocab,
+                             1 if shared_vocab else 0, 1 if check else 0, None, 0)
+        if lexical_shortlist:
+            buf = C.create_string_buffer(bytes(lexical_shortlist), len(lexical_shortlist))
+            self._keep.append(buf)
+            cfg.lexical_shortlist = C.cast(buf, C.c_void_p)
+            cfg.lexical_shortlist_bytes = len(lexical_shortlist)
+        elif shortlist is not None:
+            sl = np.ascontiguousarray(shortlist, dtype=np.uint32)
+            self._keep.append(sl)
+            cfg.shortlist = sl.ctypes.data_as(C.c_void_p)
+            cfg.n_shortlist = sl.size
+        arr = (C.c_void_p * len(models))(*[m.h for m in models])
+        self.h = C.c_void_p()
+        if host_lib().slimt_hip_service_create(C.byref(cfg), arr, len(models), C.byref(self.h)):
+            raise SlimtHipError(host_lib().slimt_hip_service_last_error().decode())
+
+    def translate_flat(self, tokens: np.ndarray, offsets: np.ndarray) -> ServiceResult:
+        """tokens uint32 (flat), offsets uint64 [n + 1]. Blocking; thread-safe."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        out = C.c_void_p()
+        if host_lib().slimt_hip_service_translate(self.h, _p(tokens), _p(offsets), offsets.size - 1, C.byref(out)):
+            raise SlimtHipError(host_lib().slimt_hip_service_last_error().decode())
+        return ServiceResult(out, np.diff(offsets).astype(np.int64))
+
+    def translate(self, sentences) -> ServiceResult:
+        lens = np.fromiter((len(s) for s in sentences), dtype=np.uint64, count=len(sentences))
+        offsets = np.zeros(len(sentences) + 1, np.uint64)
+        np.cumsum(lens, out=offsets[1:])
+        tokens = np.concatenate([np.asarray(s, dtype=np.uint32) for s in sentences]) if len(sentences) else \
+            np.zeros(0, np.uint32)
+        return self.translate_flat(tokens, offsets)
+
+    def close(self):
+        if getattr(self, "h", None):
+            host_lib().slimt_hip_service_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

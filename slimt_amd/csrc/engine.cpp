@@ -630,6 +630,8 @@ extern "C" int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int f
   return 0;
 }
 
+extern "C" int slimt_hip_model_device(const slimt_hip_model *model) { return model ? model->device : -1; }
+
 extern "C" int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
                                     int32_t *dim_ffn, int32_t *vocab, int32_t *heads) {
   if (!model) return fail(-1, "model is NULL");

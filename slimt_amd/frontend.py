@@ -10,17 +10,17 @@ addition, the `device` the model's weights live on.
     responses = service.translate(model, ["Hello world. How are you?"], html=False)
     responses[0].target.text, responses[0].alignments
 
-Text in, text out: TextProcessor (text.py) splits and tokenises, a length-sorted
-token-budget batcher (Batcher.cc:77-147 semantics: batches of at most `max_words`
-padded tokens, longest sentences first) feeds `slimt_hip_translate` on one context
-per worker, and the returned ids / alignment rows become the Response
+Text in, text out: TextProcessor (text.py) splits and tokenises, the C++ batching
+service (host/Service.{hh,cc} through include/slimt_hip_service.h: token-budget batches
+of at most `max_words` padded tokens formed by the reference's rule, Batcher.cc:95-120,
+double-buffered pinned workers, the batch's lexical shortlist generated on the device)
+translates, and the returned ids / alignment rows become the Response
 (Request.cc:136-170). The compute is the C-ABI library's; nothing here falls back
 to a CPU model.
 """
 from __future__ import annotations
 
 import threading
-from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import List, Sequence
 
@@ -103,8 +103,10 @@ class Model:
         self.engine = capi.Model(host, device)
         self.dims = (host.D, host.F, host.V)
         self.shortlist_generator = None
+        self.shortlist_blob = b""
         if package.shortlist:  # Model::make_shortlist_generator, Model.cc:60-72
-            self.shortlist_generator = capi.ShortlistGenerator(_blob(package.shortlist), host.V, host.V,
+            self.shortlist_blob = _blob(package.shortlist)
+            self.shortlist_generator = capi.ShortlistGenerator(self.shortlist_blob, host.V, host.V,
                                                                shared=True, check=False, device=device)
 
     def close(self) -> None:
@@ -112,6 +114,39 @@ class Model:
             self.shortlist_generator.close()
             self.shortlist_generator = None
         self.engine.close()
+
+
+class _LazyAlignment:
+    """One sentence's [target tokens, source tokens] matrix inside a call's block of alignment rows;
+    materialised (a reshaped view, no copy) on first use. Indexes, iterates and converts like the
+    array it stands for."""
+    __slots__ = ("_block", "_a", "_b", "_rows", "_cols", "_arr")
+
+    def __init__(self, block, a, b, rows, cols):
+        self._block, self._a, self._b, self._rows, self._cols, self._arr = block, a, b, rows, cols, None
+
+    def array(self) -> np.ndarray:
+        if self._arr is None:
+            self._arr = self._block[self._a:self._b].reshape(self._rows, self._cols) if self._b > self._a else \
+                np.zeros((self._rows, self._cols), np.float32)
+        return self._arr
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.array()
+        return a if dtype is None else a.astype(dtype)
+
+    def __len__(self):
+        return self._rows
+
+    def __getitem__(self, i):
+        return self.array()[i]
+
+    def __iter__(self):
+        return iter(self.array())
+
+    @property
+    def shape(self):
+        return (self._rows, self._cols)
 
 
 @dataclass
@@ -133,8 +168,8 @@ class Service:
         self.max_words = max_words
         self.wrap_length = wrap_length
         self.limit_factor = tgt_length_limit_factor
-        self._pool = ThreadPoolExecutor(max_workers=workers)
-        self._contexts = {}  # (model id, worker thread) -> capi.Context
+        self.pipeline_documents = 256  # translate(): documents per pipelined chunk (one chunk: no pipeline)
+        self._engines = {}  # model id -> capi.BatchService (host/Service over its C ABI)
         self._lock = threading.Lock()
 
     # -- batching ---------------------------------------------------------------------------------
@@ -169,56 +204,65 @@ class Service:
         step = self.ENGINE_LIMIT - 1
         return [body[i:i + step] + [eos] for i in range(0, len(body), step)]
 
-    def _context(self, model: Model, B: int, S: int) -> capi.Context:
-        """This thread's context for `model`: a token-budget workspace for every batch _batches can
-        form ((B + 1) * S <= max_words, S <= wrap_length), created once -- re-creating a context as
-        batches grow frees and allocates device memory, which stalls every other thread's stream."""
-        key = (model.id, threading.get_ident())
+    def _engine(self, model: Model) -> "capi.BatchService":
+        """The C++ batching service for `model` (host/Service.{hh,cc} behind include/slimt_hip_service.h):
+        token-budget batches under the rule of _batches, `workers` double-buffered workers with pinned
+        staging, the batch's lexical shortlist generated on the device (Model.cc:117-120). Units,
+        batches, padding and result routing used to be Python objects; they are C++ now, and one call
+        carries a whole translate()."""
         with self._lock:
-            ctx = self._contexts.get(key)
-        if ctx is None:
-            longest = 128  # the engine's limit; a pivot's second pass sees sentences longer than wrap_length
-            ctx = capi.Context(model.engine, max(self.max_words, 1), longest, max_tokens=max(self.max_words, longest))
-            with self._lock:
-                self._contexts[key] = ctx
-        return ctx
-
-    def _run_batch(self, model: Model, batch: List[_Unit]):
-        B, S = len(batch), max(len(u.words) for u in batch)
-        ids = np.zeros((B, S), np.uint32)
-        lens = np.zeros(B, np.uint32)
-        for i, u in enumerate(batch):
-            ids[i, :len(u.words)] = u.words
-            lens[i] = len(u.words)
-        ctx = self._context(model, B, S)
-        shortlist = model.shortlist_generator.generate(ids, lens) if model.shortlist_generator else None
-        out_ids, out_len, align = ctx.translate_pinned(ids, lens, shortlist, self.limit_factor,
-                                                       model.vocabulary.eos_id(), want_align=True)
-        return [(u, out_ids[i, :int(out_len[i])], align[i, :int(out_len[i]), :int(lens[i])]) for i, u in enumerate(batch)]
+            eng = self._engines.get(model.id)
+            if eng is None:
+                V = model.dims[2]
+                eng = capi.BatchService([model.engine], max_words=max(self.max_words, 1),
+                                        wrap_length=min(self.ENGINE_LIMIT, max(self.max_words, 1)),
+                                        limit_factor=self.limit_factor, workers_per_device=self.workers, pad_id=0,
+                                        eos_id=model.vocabulary.eos_id(), alignments=True,
+                                        lexical_shortlist=model.shortlist_blob, source_vocab=V, target_vocab=V,
+                                        shared_vocab=True, check=False)
+                self._engines[model.id] = eng
+        return eng
 
     def _translate_segments(self, model: Model, per_request: List[List[List[int]]]):
         eos = model.vocabulary.eos_id()
-        units, pieces_of = [], {}
+        flat, owner = [], []  # the sentences of the one request the C++ service gets; (request, index, piece)
+        pieces_of = {}
         for r, segs in enumerate(per_request):
             for i, seg in enumerate(segs):
+                if len(seg) <= self.ENGINE_LIMIT:
+                    flat.append(seg)
+                    owner.append((r, i, 0))
+                    continue
                 pieces = self._split_long(list(seg), eos)
                 pieces_of[(r, i)] = len(pieces)
                 for k, piece in enumerate(pieces):
-                    units.append(_Unit(r, (i, k), piece))
-        parts = {}
-        futures = [self._pool.submit(self._run_batch, model, b) for b in self._batches(units)]
-        for f in futures:
-            for u, words, alignment in f.result():
-                parts[(u.request, u.index)] = (words, alignment, len(u.words))
+                    flat.append(piece)
+                    owner.append((r, i, k))
         histories = [[None] * len(segs) for segs in per_request]
-        for (r, i), n in pieces_of.items():
-            if n == 1:
-                words, alignment, _ = parts[(r, (i, 0))]
+        if not flat:
+            return histories
+        res = self._engine(model).translate(flat)
+        targets, t_off = res.targets.copy(), res.target_offsets.astype(np.int64)
+        align, a_off = res.alignments.copy(), res.align_offsets.astype(np.int64)
+        src_len = res.source_lengths
+        res.close()
+        # per sentence: (target ids, alignment); the alignment is cut out of the call's one block when
+        # somebody asks for it (_LazyAlignment): most callers read a few, and 24,000 reshaped views
+        # per call were a tenth of a second of interpreter time
+        parts = {}
+        words_all = targets.tolist()
+        to, ao, sl = t_off.tolist(), a_off.tolist(), src_len.tolist()
+        for n, (r, i, k) in enumerate(owner):
+            words = words_all[to[n]:to[n + 1]]
+            alignment = _LazyAlignment(align, ao[n], ao[n + 1], len(words), sl[n])
+            if (r, i) in pieces_of:
+                parts[(r, i, k)] = (words, alignment.array(), sl[n])
+            else:
                 histories[r][i] = (words, alignment)
-                continue
+        for (r, i), n in pieces_of.items():
             # a split segment: targets concatenated (inner EOS dropped), alignment rows block-diagonal
             # over the pieces' source tokens (the pieces' inner EOS columns dropped, the last one kept)
-            got = [parts[(r, (i, k))] for k in range(n)]
+            got = [parts[(r, i, k)] for k in range(n)]
             widths = [L - 1 for _, _, L in got[:-1]] + [got[-1][2]]
             total = sum(widths)
             out_words, rows, col = [], [], 0
@@ -231,14 +275,14 @@ class Service:
                     rows.append(row)
                 out_words.extend(int(w) for w in words[:keep])
                 col += widths[k]
-            histories[r][i] = (np.asarray(out_words, np.uint32), np.stack(rows) if rows else np.zeros((0, total), np.float32))
+            histories[r][i] = (out_words, np.stack(rows) if rows else np.zeros((0, total), np.float32))
         return histories
 
     # -- the binding's calls -----------------------------------------------------------------------
     def _respond_many(self, model: Model, sources: Sequence[AnnotatedText], histories) -> List[Response]:
         """Request::complete (Request.cc:136-170) for a whole call: every sentence's ids decoded in
         one SentencePiece batch, the source's gaps kept, target token ranges resolved on demand."""
-        flat = [words for hist in histories for words, _ in hist]
+        flat = [words for hist in histories for words, _ in hist]  # lists of ids
         decoded = model.vocabulary.decode_text_batch(flat, self.workers) if flat else []
         out, k, v = [], 0, model.vocabulary
         for source, hist in zip(sources, histories):
@@ -256,9 +300,29 @@ class Service:
                   encoding: Encoding = Encoding.UTF8) -> List[Response]:
         if html:
             raise NotImplementedError("HTML markup transfer is outside the ported path (SURVEY.md §2)")
-        processed = model.processor.process_many(texts, self.wrap_length, self.workers)
-        histories = self._translate_segments(model, [segs for _, segs in processed])
-        out = self._respond_many(model, [src for src, _ in processed], histories)
+        # Large calls go through in chunks of documents, pipelined: while the engine translates chunk k
+        # (a C call: no interpreter lock held), this thread splits and tokenises chunk k + 1 and
+        # assembles the responses of chunk k - 1. Batches are formed per chunk (as they are per
+        # arrival window in the reference's Async service).
+        chunk = self.pipeline_documents
+        if len(texts) <= chunk:
+            processed = model.processor.process_many(texts, self.wrap_length, self.workers)
+            histories = self._translate_segments(model, [segs for _, segs in processed])
+            out = self._respond_many(model, [src for src, _ in processed], histories)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            out, pending = [], []
+            with ThreadPoolExecutor(max_workers=2) as pool:
+                def finish(item):
+                    processed, fut = item
+                    out.extend(self._respond_many(model, [src for src, _ in processed], fut.result()))
+                for k in range(0, len(texts), chunk):
+                    processed = model.processor.process_many(texts[k:k + chunk], self.wrap_length, self.workers)
+                    pending.append((processed, pool.submit(self._translate_segments, model, [segs for _, segs in processed])))
+                    while len(pending) > 2:
+                        finish(pending.pop(0))
+                while pending:
+                    finish(pending.pop(0))
         for r in out:
             r.to(encoding)
         return out
@@ -275,10 +339,9 @@ class Service:
         return [combine(r1, r2) for r1, r2 in zip(firsts, seconds)]
 
     def close(self) -> None:
-        self._pool.shutdown(wait=True)
-        for ctx in self._contexts.values():
-            ctx.close()
-        self._contexts.clear()
+        for eng in self._engines.values():
+            eng.close()
+        self._engines.clear()
 
 
 # -------------------------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
 #include "Model.hh"
 
+#include <algorithm>
 #include <cassert>
 #include <stdexcept>
 
@@ -45,7 +46,9 @@ Model::Model(const Config &config, const void *model_bin, size_t size) : config_
     raise("slimt_hip_model_create");
 }
 
-Model::~Model() { slimt_hip_model_destroy(model_); }
+Model::~Model() {
+  if (owned_) slimt_hip_model_destroy(model_);
+}
 
 Worker::Worker(const Model &model, size_t max_batch, size_t max_length, size_t max_tokens)
     : model_(model) {
@@ -94,7 +97,7 @@ void Worker::wait() {
 }
 
 Histories collect(const uint32_t *out_ids, const uint32_t *out_len, const float *align,
-                  const uint32_t *lengths, size_t B, size_t S, size_t T) {
+                  const uint32_t *lengths, size_t B, size_t S, size_t T, bool flat) {
   Histories histories;
   histories.reserve(B);
   for (size_t b = 0; b < B; ++b) {
@@ -102,7 +105,14 @@ Histories collect(const uint32_t *out_ids, const uint32_t *out_len, const float 
     hyp->padded_length = S;
     const size_t n = out_len[b] < T ? out_len[b] : T;
     hyp->target.assign(out_ids + b * T, out_ids + b * T + n);
-    if (align) {
+    if (align && flat) {
+      const size_t len = lengths[b];
+      hyp->alignment_flat.resize(n * len);
+      for (size_t t = 0; t < n; ++t) {
+        const float *row = align + (b * T + t) * S;
+        std::copy(row, row + len, hyp->alignment_flat.begin() + static_cast<std::ptrdiff_t>(t * len));
+      }
+    } else if (align) {
       const size_t len = lengths[b];
       hyp->alignment.reserve(n);
       for (size_t t = 0; t < n; ++t) {

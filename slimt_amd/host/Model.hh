@@ -25,6 +25,10 @@ using Alignment = std::vector<Distribution>;
 struct Hypothesis {  // slimt/Types.hh:55-61
   Words target;
   Alignment alignment;
+  // The same rows as ONE block, [target.size()][source tokens] row-major, filled INSTEAD of
+  // `alignment` when the producer was asked for flat rows (ServiceConfig::flat_alignments: the C ABI,
+  // whose callers want arrays -- one allocation per sentence instead of one per target token)
+  std::vector<float> alignment_flat;
   size_t padded_length = 0;  // diagnostic: the S of the batch this sentence was translated in
   uint64_t batch = 0;        // diagnostic: serial number of that batch (Service: batches in launch order)
 };
@@ -65,6 +69,13 @@ class Model {
   };
   // `model_bin`: a Marian .bin held in memory for the duration of the call.
   Model(const Config &config, const void *model_bin, size_t size);
+  // A view of weights that live elsewhere (created through the C ABI): not destroyed with the Model.
+  Model(const Config &config, slimt_hip_model *borrowed) : config_(config), model_(borrowed), owned_(false) {
+    int32_t heads = 0;
+    if (borrowed && slimt_hip_model_info(borrowed, nullptr, nullptr, nullptr, &heads) == 0 && heads > 0)
+      config_.num_heads = static_cast<size_t>(heads);
+    config_.device = slimt_hip_model_device(borrowed);
+  }
   ~Model();
   Model(const Model &) = delete;
   Model &operator=(const Model &) = delete;
@@ -74,6 +85,7 @@ class Model {
  private:
   Config config_;
   slimt_hip_model *model_ = nullptr;
+  bool owned_ = true;
 };
 
 class Worker {
@@ -109,6 +121,6 @@ class Worker {
 // Raw outputs of a pass -> Histories (targets cut at out_len, alignment rows cut at the
 // sentence's own length, slimt/Model.cc:95-106,163-176).
 Histories collect(const uint32_t *out_ids, const uint32_t *out_len, const float *align,
-                  const uint32_t *lengths, size_t B, size_t S, size_t T);
+                  const uint32_t *lengths, size_t B, size_t S, size_t T, bool flat = false);
 
 }  // namespace slimt

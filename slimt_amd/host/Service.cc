@@ -268,7 +268,7 @@ void Service::finish(Slot &slot) {
   lap.to(ns_wait_);
   Histories histories = collect(slot.out_ids.get(), slot.out_len.get(),
                                 config_.alignments ? slot.align.get() : nullptr, slot.lengths.get(), slot.B,
-                                slot.S, slot.T);
+                                slot.S, slot.T, config_.flat_alignments);
   lap.to(ns_collect_);
   std::vector<Unit> batch = std::move(slot.batch);
   slot.batch.clear();

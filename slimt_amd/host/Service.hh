@@ -94,6 +94,7 @@ struct ServiceConfig {
   size_t workers_per_device = 10;  // x 2 contexts each: about 20 batches in flight per GPU
   uint32_t pad_id = 0;
   bool alignments = true;
+  bool flat_alignments = false;  // Hypothesis::alignment_flat instead of ::alignment (one block per sentence)
   // Output vocabulary of a batch, one policy for the service's lifetime:
   //  * lexical_shortlist set: the reference's own -- ShortlistGenerator::generate on every batch's
   //    source words (Model.cc:60-82,117-120; Shortlist.cc:115-175) -- run on the device, on the

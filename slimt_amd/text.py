@@ -254,7 +254,8 @@ class Vocabulary:
         return self.sp.encode(list(lines), out_type=int, num_threads=num_threads or None)
 
     def decode_text_batch(self, sentences: Sequence[Sequence[int]], num_threads: int = 0) -> List[str]:
-        return self.sp.decode([list(map(int, w)) for w in sentences], num_threads=num_threads or None)
+        return self.sp.decode([w if type(w) is list else (w.tolist() if hasattr(w, "tolist") else list(map(int, w)))
+                               for w in sentences], num_threads=num_threads or None)
 
     def encode_boundaries(self, line: str) -> List[int]:
         """Token boundaries (byte offsets into `line`, one more than tokens) of encode(line)."""
@@ -282,6 +283,14 @@ _CANDIDATE = regex.compile(
     r"(?P<prefix>[\p{L}\p{N}]*)(?P<punct>[" + regex.escape(_EOS_MARKS) + r"]+)"
     r"(?P<tail>['\")\]’”\p{Pf}]*(?:\[\p{Nd}+[\p{Nd},\s]*\p{Nd}\])?['\")\]’”\p{Pf}]*)"
     r"(?P<ws>\s*)", regex.UNICODE)
+# the same candidate without its prefix group: `search` then jumps from mark to mark (a leading
+# [\p{L}\p{N}]* makes it try a letter run at every position of every word); the prefix -- needed only
+# for a single '.' before an upper-case letter or a digit -- is read backwards from the mark
+_MARK = regex.compile(
+    r"(?P<punct>[" + regex.escape(_EOS_MARKS) + r"]+)"
+    r"(?P<tail>['\")\]’”\p{Pf}]*(?:\[\p{Nd}+[\p{Nd},\s]*\p{Nd}\])?['\")\]’”\p{Pf}]*)"
+    r"(?P<ws>\s*)", regex.UNICODE)
+_PREFIX_CHAR = regex.compile(r"[\p{L}\p{N}]", regex.UNICODE)
 _NEXT_WORD = regex.compile(r"[^\s\p{L}\p{N}\p{M}\p{S}]*\s*(?P<lead>[\p{L}\p{M}\p{N}]*)", regex.UNICODE)
 _LOWER = regex.compile(r"\p{M}*\p{Ll}", regex.UNICODE)
 _UPPER = regex.compile(r"\p{M}*[\p{Lu}\p{Lt}]", regex.UNICODE)
@@ -329,24 +338,32 @@ class Splitter:
                 return
             start, scan, end = pos, pos, None
             while end is None:
-                m = _CANDIDATE.search(paragraph, scan)
+                floor = scan
+                m = _MARK.search(paragraph, scan)
                 if not m:
                     break
                 scan = m.end()
                 punct, ws = m.group("punct"), m.group("ws")
                 if not ws and punct not in ("。", "！", "？"):
-                    scan = m.end("punct") if m.end("punct") > m.start() else m.end()
+                    scan = m.end("punct")
                     continue
+
+                def prefix(m=m, floor=floor):  # the letters / digits right before the mark (not before `floor`:
+                    b = m.start("punct")       # where this candidate search began, as the one-regex form's match does)
+                    while b > floor and _PREFIX_CHAR.match(paragraph, b - 1):
+                        b -= 1
+                    return paragraph[b:m.start("punct")]
+
                 lead = _NEXT_WORD.match(paragraph, m.end()).group("lead")
                 if _OTHER.match(lead):
                     pass  # a letter without case (CJK, ...): break
                 elif _LOWER.match(lead):
                     continue
                 elif _UPPER.match(lead):
-                    if punct == "." and self.prefix_class(m.group("prefix")) != 0:
+                    if punct == "." and self.prefix_class(prefix()) != 0:
                         continue
                 elif _DIGIT.match(lead):
-                    if punct == "." and self.prefix_class(m.group("prefix")) == 2:
+                    if punct == "." and self.prefix_class(prefix()) == 2:
                         continue
                 else:
                     if punct == "..." and m.group("tail") == "]" and m.start("punct") > start + 1 and \

@@ -229,3 +229,34 @@ def test_service_survives_workers_that_cannot_start(hip, oracle, synth_models):
     assert _check_batches(oracle, oracle.OracleModel(m), rows, lambda ids, lens: None) >= 2
     res, _ = _run_async(m, reqs, 4, env_extra={"SLIMT_SERVICE_FAIL_WORKERS": "4"}, expect_rc=1)
     assert "injected worker set-up failure" in res.stderr
+
+
+@pytest.mark.gpu
+def test_service_c_abi_returns_flat_results(hip, oracle, synth_models):
+    """include/slimt_hip_service.h through capi.BatchService (what a binding calls): one request of
+    tokenised sentences in, flat target ids / alignment rows / batch serials out == the oracle on
+    every rebuilt batch; two replicas of the model, a lexical shortlist generated per batch."""
+    m = synth_models("micro", 3.0)
+    blob = synth.make_lexical_shortlist(m.V, m.V, 16, 6, seed=33)
+    osl = oracle.OracleShortlist(blob, m.V, m.V)
+    om = oracle.OracleModel(m)
+    gm1, gm2 = hip.Model(m), hip.Model(m)
+    svc = hip.BatchService([gm1, gm2], max_words=96, wrap_length=24, limit_factor=1.5, workers_per_device=2,
+                           eos_id=0, alignments=True, lexical_shortlist=blob, source_vocab=m.V, target_vocab=m.V,
+                           check=True)
+    try:
+        sents = [s for segs in _requests(m.V, 25, 77, 20) for s in segs]
+        res = svc.translate(sents)
+        assert res.n == len(sents)
+        rows = [(sents[i], int(res.padded_length[i]), int(res.batch[i]), res.target(i).copy(), res.alignment(i).copy())
+                for i in range(res.n)]
+        res.close()
+        assert _check_batches(oracle, om, rows, lambda ids, lens: osl.generate(ids, lens)) >= 3
+        empty = svc.translate([])
+        assert empty.n == 0
+        with pytest.raises(hip.SlimtHipError, match="longer than"):
+            svc.translate([np.ones(30, np.uint32)])
+    finally:
+        svc.close()
+        gm1.close()
+        gm2.close()

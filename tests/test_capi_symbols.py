@@ -30,6 +30,26 @@ def test_library_exports_every_declared_symbol():
     assert capi.lib().slimt_hip_abi_version() == 2
 
 
+def test_service_library_exports_every_declared_symbol():
+    """include/slimt_hip_service.h (the batching service's C ABI) against libslimt_hip_host.so; without a
+    GPU a service cannot be created (its workers need a device), but the failure is an error code."""
+    from slimt_amd import build, capi
+    path = build.build_host_lib()
+    assert os.path.exists(path)
+    text = open(os.path.join(ROOT, "include", "slimt_hip_service.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(slimt_hip_(?:service|result)_[a-z0-9_]+)\s*\(", text)))
+    assert names == ["slimt_hip_result_destroy", "slimt_hip_result_view", "slimt_hip_service_create",
+                     "slimt_hip_service_destroy", "slimt_hip_service_last_error", "slimt_hip_service_translate"]
+    dll = capi.host_lib()
+    for n in names:
+        assert hasattr(dll, n), f"{n} declared in slimt_hip_service.h but not exported"
+    out = ctypes.c_void_p()
+    assert dll.slimt_hip_service_create(None, None, 0, ctypes.byref(out)) != 0
+    assert b"null argument" in dll.slimt_hip_service_last_error()
+    assert dll.slimt_hip_result_view(None, None, None, None, None, None, None, None) != 0
+
+
 def test_no_oracle_in_product():
     """The product path must never import/link the oracle or /root/reference."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "slimt_amd")):

@@ -72,6 +72,66 @@ def test_splitter_rules():
     assert split("   ") == [] and split("") == []
 
 
+def test_splitter_mark_search_equals_the_one_regex_form():
+    """Splitter.split finds its candidates with the prefix-free _MARK pattern (linear) and reads the
+    prefix backwards; the restatement's original form, one regex with a leading [\\p{L}\\p{N}]* prefix
+    group (text._CANDIDATE), must give the same cuts on every text."""
+    import random
+    from slimt_amd import text as T
+    sp = T.Splitter()
+    sp.load_from_serialized("Mr\nDr\nNo #NUMERIC_ONLY#\nSt\nvs\ne.g\nU.S\n")
+
+    def one_regex_split(paragraph):
+        n, pos = len(paragraph), 0
+        while True:
+            while pos < n and paragraph[pos].isspace():
+                pos += 1
+            if pos >= n:
+                return
+            start, scan, end = pos, pos, None
+            while end is None:
+                m = T._CANDIDATE.search(paragraph, scan)
+                if not m:
+                    break
+                scan = m.end()
+                punct, ws = m.group("punct"), m.group("ws")
+                if not ws and punct not in ("。", "！", "？"):
+                    scan = m.end("punct")
+                    continue
+                lead = T._NEXT_WORD.match(paragraph, m.end()).group("lead")
+                if T._OTHER.match(lead):
+                    pass
+                elif T._LOWER.match(lead):
+                    continue
+                elif T._UPPER.match(lead):
+                    if punct == "." and sp.prefix_class(m.group("prefix")) != 0:
+                        continue
+                elif T._DIGIT.match(lead):
+                    if punct == "." and sp.prefix_class(m.group("prefix")) == 2:
+                        continue
+                else:
+                    if punct == "..." and m.group("tail") == "]" and m.start("punct") > start + 1 and \
+                            paragraph[m.start("punct") - 1] == "[":
+                        continue
+                end = m.start("ws")
+            if end is None:
+                end = n
+                while end > start and paragraph[end - 1].isspace():
+                    end -= 1
+                yield start, end
+                return
+            yield start, end
+            pos = end
+
+    rnd = random.Random(3)
+    atoms = ["Mr", "Dr", "No", "St", "vs", "e.g", "U.S", "Hello", "world", "x", "3", "14", "a.b", "ab", "Ünï", "日本", "γ", "Z"]
+    puncts = [".", "?", "!", "...", ".)", ".\"", "。", "！", "? ", ". ", ".  ", " ", " ", " ", "[...]", " [...] ", ".[1]",
+              ".[12, 3] ", "'", "”", ",", "\t"]
+    for _ in range(4000):
+        s = "".join(rnd.choice(atoms) + rnd.choice(puncts) for _ in range(rnd.randint(1, 14)))
+        assert list(sp.split(s)) == list(one_regex_split(s)), s
+
+
 def test_sentence_stream_modes():
     sp = text.Splitter()
     data = "Line one. Line two.\r\n\nPara two\nwrapped here. End.\n".encode()
