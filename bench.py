@@ -139,6 +139,24 @@ def pmc_traffic(kernel, preset="tiny11"):
     return 2.0 * out["FETCH_SIZE"][0] + out["WRITE_SIZE"][0], [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]
 
 
+def sq_counters(kernel, preset="tiny11"):
+    """SQ / TCC counter digest of `kernel` from the newest committed full-occupancy pass
+    (profiles/*_sq_pmc.json, tools/pmc_sq.sh: separate rocprofv3 --pmc runs, one launch with every CU
+    holding a workgroup). None if absent."""
+    import glob
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*_sq_pmc.json"))
+             if ("_base_" in os.path.basename(f)) == (preset == "base")]
+    files.sort(key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    for f in reversed(files):
+        ks = json.load(open(f)).get("kernels", {})
+        rec = ks.get(kernel) or ((ks.get("encode_tall") or ks.get("encode_wide")) if kernel == "encode_fused" else None)
+        if rec:
+            keep = ("mfma_busy_frac", "valu_busy_frac", "wave_parked_frac", "wave_issue_stall_frac", "wave_issuing_frac",
+                    "l2_hit_frac", "lds_bank_conflict_frac")
+            return {k: rec[k] for k in keep if k in rec}, os.path.basename(f)
+    return None, None
+
+
 def cpu_model_string():
     try:
         for line in open("/proc/cpuinfo"):
@@ -504,10 +522,14 @@ def main():
             "algorithmic_ops_per_launch": ops, "launches": prof["launches"], "avg_launch_us": 1e3 * avg_ms,
             "cus_per_launch": cus, "launches_in_flight": in_flight,
             "frac_of_occupied_cus": achieved / (PEAK_INT8_TOPS * cus / 256.0),
+            "counters_full_occupancy": sq_counters(prof_name, args.preset)[0] if profiled else None,
+            "counters_source": sq_counters(prof_name, args.preset)[1] if profiled else None,
             "whole_job": {"achieved": whole_job_tops / world, "frac": whole_job_tops / world / PEAK_INT8_TOPS,
                           "note": "all kernels, per GPU: algorithmic int8 OPs of every translated sentence / "
                                   "wall time of the timed region"},
         }
+        if roofline["counters_full_occupancy"]:
+            roofline["mfma_busy_frac"] = roofline["counters_full_occupancy"].get("mfma_busy_frac")
         if prof_name == "decode_fused":
             # HBM view of the same kernel. SURVEY 8(d) counts the cross-attention K/V cache as
             # written once and re-read on-chip: `algorithmic_bytes_per_launch` = weights + target

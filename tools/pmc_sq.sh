@@ -31,3 +31,36 @@ SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INST_LE
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU_CVT
 SETS
+# JSON digest: counters per kernel + busy fractions (profiles/<tag>_sq_pmc.json; bench.py's roofline.mfma_busy_frac)
+python3 - gpurun_out/${TAG}_sq_pmc.txt gpurun_out/${TAG}_sq_pmc.json <<'PY'
+import json, re, sys, collections
+k = collections.defaultdict(dict)
+for line in open(sys.argv[1]):
+    m = re.match(r"(\S+)\s+(\S+)\s+launches\s+(\d+)\s+avg\s+(\S+)", line)
+    if m:
+        k[m.group(1)][m.group(2)] = float(m.group(4))
+out = {}
+for name, c in k.items():
+    d = dict(c)
+    if "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0            # rocprofv3 sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+        simd_cycles = cyc * 256 * 4                 # 256 CUs x 4 SIMDs
+        d["kernel_cycles"] = cyc
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            d["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles       # counts cycles
+        if "SQ_ACTIVE_INST_VALU" in c:
+            d["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles      # counts quad-cycles
+        if "SQ_WAVE_CYCLES" in c:
+            for key, label in (("SQ_WAIT_ANY", "wave_parked_frac"), ("SQ_WAIT_INST_ANY", "wave_issue_stall_frac"),
+                               ("SQ_ACTIVE_INST_ANY", "wave_issuing_frac")):
+                if key in c:
+                    d[label] = c[key] / c["SQ_WAVE_CYCLES"]
+    if c.get("TCC_REQ_sum"):
+        d["l2_hit_frac"] = c.get("TCC_HIT_sum", 0.0) / (c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0))
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+    out[name] = d
+json.dump({"workload": "bench.py --batch %s --workers 1: every CU holds a workgroup of the kernel (full occupancy); one launch profiled alone" % sys.argv[1].split("/")[-1], "kernels": out}, open(sys.argv[2], "w"), indent=1)
+for name, d in out.items():
+    print(name, {x: round(d[x], 4) for x in ("mfma_busy_frac", "valu_busy_frac", "wave_parked_frac", "wave_issue_stall_frac", "wave_issuing_frac", "l2_hit_frac", "lds_bank_conflict_frac") if x in d})
+PY

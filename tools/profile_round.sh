@@ -6,7 +6,7 @@
 # Each step is bounded; a failed or timed-out step stops the chain.
 TAG=${1:-r02}
 mkdir -p gpurun_out
-timeout -k 10 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || { echo "bench failed"; tail -5 gpurun_out/${TAG}_bench.err; exit 1; }
+timeout -k 10 400 python bench.py ${NO_CPU:+--no-cpu-baseline} > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || { echo "bench failed"; tail -5 gpurun_out/${TAG}_bench.err; exit 1; }
 tail -1 gpurun_out/${TAG}_bench.json | cut -c1-400
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run through gpurun)}"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_$TAG.log 2>&1 || { echo "rocprof stats failed"; tail -5 gpurun_out/prof_$TAG.log; exit 1; }

@@ -2,6 +2,8 @@
 buffers in and out) in a loop -- slimt's own Async workers calling Model::forward (Frontend.cc:212-226).
 usage: sync_workers_bench.py [workers] [batches per worker] [batch] [src_len] [pinned 0/1]"""
 import json, os, sys, threading, time
+if not os.environ.get("SLIMT_TOOL_NO_QUEUE_DEFAULT"):  # (set: rely on the default the library sets when it is loaded)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from slimt_amd import capi, synth
