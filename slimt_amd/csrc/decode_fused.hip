@@ -719,12 +719,14 @@ __device__ __forceinline__ f4 unpack24(int d0, int d1, int d2, float u256, f4 pb
   const int y2 = (int)__builtin_amdgcn_perm((unsigned)d2, (unsigned)d1, 0x0403020cu);
   const int y3 = d2 & (int)0xffffff00;
   f2 a = {(float)y0, (float)y1}, b = {(float)y2, (float)y3};
-  const f2 uu = {u256, u256};
-  a = a * uu;
+#ifndef SLIMT_EXP_NODEQ  // timing experiment (wrong results): the unpack without its multiply and add. Alone, an
+  const f2 uu = {u256, u256};  // attention phase goes 9.84 -> 8.36 us: 256 fewer VALU instructions x 4 waves x 4 cycles
+  a = a * uu;                  // -- the phase is VALU-issue bound (prefetching K a pass ahead changed nothing)
   b = b * uu;
   const f2 pa = {pb.x, pb.y}, pc = {pb.z, pb.w};
   a = a + pa;
   b = b + pc;
+#endif
   const f4 o = {a.x, a.y, b.x, b.y};
   return o;
 }
