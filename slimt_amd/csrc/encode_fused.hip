@@ -463,7 +463,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     // columns of one row, so the requantised hidden values leave as one 4-byte LDS store per
     // row tile and the FFN2 result meets the residual as float4.
     {
-      constexpr int LDH = 64 * KSF + 16;  // hidden row stride (bytes)
+      constexpr int LDH = 64 * KSF + 32;  // hidden row stride (bytes; + 32: conflict-free FFN2 fragment reads, encode_tall.hip)
       char *Hb = reinterpret_cast<char *>(qb);
       static_assert((size_t)ER * LDH <= (size_t)ER * (LDQQ + LDK + LDV) * 4, "hidden layer fits q/k/v");
       static_assert((KSF * 4) % ENW == 0 && KSF % 4 == 0, "whole tiles / whole chunks per wave");

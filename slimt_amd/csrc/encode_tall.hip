@@ -172,10 +172,18 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   // f32 q / k / v rows: the attention's 16x16x4 operands are read by lanes (row n = lane % 16,
   // k index g = lane / 16) -- q, k at [row n][d + g]: stride = 4 mod 64 words is conflict-free;
   // v at [key g][d + n]: stride = 16 mod 64 is
-  constexpr int LDQ = RC + 4;
+  // q / k rows: + 2 floats. The attention reads them one float per lane (row n = lane % 16, k index
+  // g = lane / 16, ds_read_b32: 32 banks, half a wave per LDS cycle): 2 n + g is a different bank for every
+  // lane of a half wave; with + 4 rows n and n + 8 shared banks (every operand read 2-way conflicted).
+  // Rows are then 8-byte aligned: the projections store two float2 instead of one float4.
+  constexpr int LDQ = RC + 2;
   constexpr int LDV = RC + 16;
   constexpr int LDY = D + 4;   // f32 exchange rows (also the int32 rows of the K/V staging tile)
-  constexpr int LDH = F + 16;  // int8 hidden rows
+  // int8 hidden rows: + 32 bytes, so that an FFN2 fragment read (ds_read_b128: 16 rows x 16 B per
+  // hardware lane group) covers all 64 banks -- with + 16 the dword index 4 (lr + lg) put rows lr and lr + 1 of
+  // neighbouring lane groups on the same banks: every read 2-way conflicted (8 instead of 4 LDS cycles,
+  // 1.5 MB of such reads per layer; SQ_LDS_BANK_CONFLICT was 29 % of the kernel's LDS cycles)
+  constexpr int LDH = F + 32;
   constexpr int NT1 = (F / 16) / TNW;  // FFN1 column tiles per wave
   constexpr int NC2 = KSF / 4;         // FFN2 chunks of four k-steps
   static_assert((F / 16) % TNW == 0 && KSF % 4 == 0, "whole tiles / whole chunks per wave");
@@ -344,7 +352,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
 #pragma unroll
         for (int rt = 0; rt < TRT; ++rt) {
           const v4i c = mma_rt(w1, rt, af);
-          *reinterpret_cast<float4 *>(dst1 + (16 * rt + lr) * LDQ + ctl * 16 + lg * 4) = tdequant4(c, e1, W1.u);
+          const float4 qk = tdequant4(c, e1, W1.u);
+          float *qd = dst1 + (16 * rt + lr) * LDQ + ctl * 16 + lg * 4;
+          *reinterpret_cast<float2 *>(qd) = float2{qk.x, qk.y};
+          *reinterpret_cast<float2 *>(qd + 2) = float2{qk.z, qk.w};
         }
         __builtin_amdgcn_sched_barrier(0);
         if (qv) {
@@ -516,6 +527,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       for (int i = 0; i < NT1; ++i) {
         const int buf = i % 3, t = wave + TNW * i;
         const TEpi e = e1[buf];
+        // Measured by ablation (timing-only builds, round 3): this phase is 9.2 us = the weight stream alone
+        // (3.0: 384 KB at the CU's 64 B/clk) + the MFMAs and their A-fragment reads (3.1; 0.9 of it the LDS reads)
+        // + the epilogues (3.1) -- they add up instead of overlapping, whichever way the loop is arranged
+        // (loads before / after the epilogues, half the waves of a SIMD started late: no change).
 #pragma unroll
         for (int rt = 0; rt < TRT; ++rt) {
           const v4i c = mma_rt(bw[buf], rt, af);
@@ -681,8 +696,8 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
 }
 
 size_t tall_encode_lds_bytes(int F) {
-  const size_t region_qkv = (size_t)TR * (2 * (128 + 4) + (128 + 16)) * 4;
-  const size_t region_h = (size_t)TR * (F + 16);
+  const size_t region_qkv = (size_t)TR * (2 * (128 + 2) + (128 + 16)) * 4;
+  const size_t region_h = (size_t)TR * (F + 32);
   const size_t region = region_qkv > region_h ? region_qkv : region_h;
   return 3 * (size_t)TR * 256 + (size_t)TR * (128 + 16) + region;
 }

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   constexpr int LDQ = RC + 4;
   constexpr int LDV = RC + 16;
   constexpr int LDY = D + 4;         // f32 exchange rows
-  constexpr int LDH = F + 16;        // int8 hidden rows
+  constexpr int LDH = F + 32;        // int8 hidden rows (+ 32: an FFN2 fragment read then covers all 64 banks, encode_tall.hip)
   static_assert(RC / 16 == WNW, "one 16-column tile of a round's projection per wave");
   static_assert(D / 16 == 2 * WNW, "two 16-column tiles of a D-wide GEMM per wave");
   static_assert(DH == 64 && KSD == 8, "planned for D = 512, d_head = 64");
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
 size_t wide_encode_lds_bytes() {
   constexpr int D = 512, F = 2048, RC = 256;
   const size_t qkv = 2 * (size_t)WR * (RC + 4) * 4 + (size_t)WR * (RC + 16) * 4;
-  const size_t y = (size_t)WR * (D + 4) * 4, h = (size_t)WR * (F + 16);
+  const size_t y = (size_t)WR * (D + 4) * 4, h = (size_t)WR * (F + 32);
   size_t region = qkv > y ? qkv : y;
   region = region > h ? region : h;
   return 3 * (size_t)WR * D + (size_t)WR * (RC + 16) + region;
