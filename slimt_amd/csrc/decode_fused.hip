@@ -1224,8 +1224,11 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr int D = 64 * KSD, F = 64 * KSF;
   constexpr int R = 16 * RT;    // rows (sentences) per workgroup
   constexpr int LDF = D + 4;    // f32 row stride
-  constexpr int LDA = D + 16;   // int8 row stride (K = D)
-  constexpr int LDA3 = F + 16;  // int8 row stride (K = F)
+  // int8 operand rows: + 32 bytes -- a fragment read (ds_read_b128: 16 rows x 16 B per hardware lane group)
+  // then covers all 64 banks; with + 16, rows lr and lr + 1 of neighbouring lane groups shared banks
+  // (every A-fragment read 2-way conflicted; tools/lds_conflicts.py)
+  constexpr int LDA = D + 32;   // K = D
+  constexpr int LDA3 = F + 32;  // K = F
   // column tiles per wave where every wave has the same number (else 0: rolled loops)
   constexpr int NT_D = (D / 16) % NW == 0 ? (D / 16) / NW : 0;
   constexpr int NT_F1 = (F / 16) % NW == 0 ? (F / 16) / NW : 0;
@@ -1745,7 +1748,7 @@ size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false,
   const bool lean = (size_t)D * R > 256 * 16;
   const size_t cells = (lean || mid == 2) ? 0 : (size_t)Ld * R * D * 4;
   const size_t f32rows = (lean ? 2 : 3) * R * (D + 4) * 4 + cells;
-  const size_t base = f32rows + 2 * R * (size_t)(D + 16) + R * (size_t)(F + 16) + 2 * NW * R * 4 + 64 +
+  const size_t base = f32rows + 2 * R * (size_t)(D + 32) + R * (size_t)(F + 32) + 2 * NW * R * 4 + 64 +
                       NW * (mid == 2 ? 1024 : mid == 1 ? 512 : 256) * 4 + (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0);
   const size_t ln = (D == 256 && rows == 16 && !mid) ? (size_t)Ld * 6 * D * 4 : 0;
   const bool fits = ln > 0 && base + ln <= 160 * 1024;
