@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cassert>
 #include <stdexcept>
+#include <string>
 
 #include "Io.hh"
 
@@ -23,7 +24,9 @@ void Input::add(const Words &words) {
   lengths_.push_back(static_cast<uint32_t>(words.size()));
 }
 
-Model::Model(const Config &config, const void *model_bin, size_t size) : config_(config) {
+Model::Model(const Config &config, const void *model_bin, size_t size, const void *lexical_shortlist,
+             size_t lexical_shortlist_size)
+    : config_(config) {
   std::vector<io::Item> items = io::load_items(model_bin, size);
   std::vector<slimt_hip_param> params;
   params.reserve(items.size());
@@ -44,10 +47,73 @@ Model::Model(const Config &config, const void *model_bin, size_t size) : config_
   dims.num_heads = static_cast<int32_t>(config.num_heads);
   if (slimt_hip_model_create(params.data(), params.size(), &dims, config.device, &model_))
     raise("slimt_hip_model_create");
+  if (lexical_shortlist && lexical_shortlist_size) {
+    // both Vocabulary arguments of the reference's generator are the model's (Model.cc:73-74)
+    int32_t vocab = 0;
+    if (slimt_hip_model_info(model_, nullptr, nullptr, &vocab, nullptr) ||
+        slimt_hip_shortlist_create(lexical_shortlist, lexical_shortlist_size, static_cast<size_t>(vocab),
+                                   static_cast<size_t>(vocab), /*shared=*/0, /*check=*/0, config.device,
+                                   &generator_)) {
+      const std::string why = slimt_hip_last_error();
+      slimt_hip_model_destroy(model_);
+      throw std::runtime_error("slimt_hip_shortlist_create: " + why);
+    }
+  }
 }
 
 Model::~Model() {
+  for (Lease &l : idle_) slimt_hip_ctx_destroy(l.ctx);
+  if (generator_) slimt_hip_shortlist_destroy(generator_);
   if (owned_) slimt_hip_model_destroy(model_);
+}
+
+size_t Model::contexts_built() const {
+  std::lock_guard<std::mutex> lock(pool_mu_);
+  return built_;
+}
+
+Histories Model::forward(const Input &input) const {
+  const size_t B = input.lengths().size(), S = input.sequence_length();
+  if (B == 0) return {};
+  const size_t Tmax = static_cast<size_t>(input.limit_factor() * static_cast<float>(S));
+  const size_t T = Tmax ? Tmax : 1;
+  Lease lease;
+  {
+    std::lock_guard<std::mutex> lock(pool_mu_);
+    if (!idle_.empty()) {
+      lease = idle_.back();
+      idle_.pop_back();
+    }
+  }
+  if (lease.ctx && (B > lease.max_batch || S > lease.max_length || B * S > lease.max_tokens)) {
+    slimt_hip_ctx_destroy(lease.ctx);  // grows to the largest batch seen: at most a few rebuilds
+    lease.ctx = nullptr;
+  }
+  if (!lease.ctx) {
+    lease.max_batch = std::max(B, lease.max_batch);
+    lease.max_length = std::max(S, lease.max_length);
+    lease.max_tokens = std::max(B * S, lease.max_tokens);
+    if (slimt_hip_ctx_create_budget(model_, lease.max_batch, lease.max_length, lease.max_tokens, nullptr, &lease.ctx))
+      raise("slimt_hip_ctx_create_budget");
+    std::lock_guard<std::mutex> lock(pool_mu_);
+    ++built_;
+  }
+  std::vector<uint32_t> out_ids(B * T), out_len(B);
+  std::vector<float> align(B * T * S);  // Model::decode records alignments unconditionally (Model.cc:156,170)
+  const int rc = generator_
+                     ? slimt_hip_translate_generated(lease.ctx, generator_, input.indices().data(), input.lengths().data(),
+                                                     B, S, input.limit_factor(), config_.eos_id, out_ids.data(),
+                                                     out_len.data(), align.data())
+                     : slimt_hip_translate(lease.ctx, input.indices().data(), input.lengths().data(), B, S, nullptr, 0,
+                                           input.limit_factor(), config_.eos_id, out_ids.data(), out_len.data(),
+                                           align.data());
+  const std::string why = rc ? slimt_hip_last_error() : "";
+  {
+    std::lock_guard<std::mutex> lock(pool_mu_);
+    idle_.push_back(lease);  // a failed call leaves the context usable (arguments are checked before any launch)
+  }
+  if (rc) throw std::runtime_error((generator_ ? "slimt_hip_translate_generated: " : "slimt_hip_translate: ") + why);
+  return collect(out_ids.data(), out_len.data(), align.data(), input.lengths().data(), B, S, T);
 }
 
 Worker::Worker(const Model &model, size_t max_batch, size_t max_length, size_t max_tokens)

@@ -9,6 +9,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <string>
 #include <vector>
@@ -67,9 +68,13 @@ class Model {
     uint32_t eos_id = 0;
     int device = 0;
   };
-  // `model_bin`: a Marian .bin held in memory for the duration of the call.
-  Model(const Config &config, const void *model_bin, size_t size);
-  // A view of weights that live elsewhere (created through the C ABI): not destroyed with the Model.
+  // `model_bin`: a Marian .bin held in memory for the duration of the call. `lexical_shortlist`
+  // (optional): the binary lexical shortlist of the reference's Package (make_shortlist_generator,
+  // slimt/Model.cc:60-82), copied to the device; forward() then generates every batch's shortlist.
+  Model(const Config &config, const void *model_bin, size_t size, const void *lexical_shortlist = nullptr,
+        size_t lexical_shortlist_size = 0);
+  // A view of weights that live elsewhere (created through the C ABI): not destroyed with the Model,
+  // and they must outlive it (forward()'s pooled contexts are released by ~Model).
   Model(const Config &config, slimt_hip_model *borrowed) : config_(config), model_(borrowed), owned_(false) {
     int32_t heads = 0;
     if (borrowed && slimt_hip_model_info(borrowed, nullptr, nullptr, nullptr, &heads) == 0 && heads > 0)
@@ -81,11 +86,28 @@ class Model {
   Model &operator=(const Model &) = delete;
   slimt_hip_model *handle() const { return model_; }
   const Config &config() const { return config_; }
+  // slimt::Model::forward (slimt/Model.hh:56, Model.cc:187-204): one const, re-entrant call --
+  // the batch's shortlist (when the model has a generator), encoder, greedy decode, a Hypothesis
+  // with its alignment rows per sentence. Any number of threads may call it on one Model, like the
+  // reference's Async workers (Frontend.cc:212-226): each call borrows a device context (stream +
+  // workspace) from the model's pool, or builds one when every context is in use; a context that
+  // is too small for the batch is replaced by one that fits.
+  Histories forward(const Input &input) const;
+  // contexts forward() has built so far (at most the largest number of concurrent callers)
+  size_t contexts_built() const;
 
  private:
+  struct Lease {  // a pooled context and the batch sizes its workspace holds
+    slimt_hip_ctx *ctx = nullptr;
+    size_t max_batch = 0, max_length = 0, max_tokens = 0;
+  };
   Config config_;
   slimt_hip_model *model_ = nullptr;
   bool owned_ = true;
+  slimt_hip_shortlist *generator_ = nullptr;
+  mutable std::mutex pool_mu_;
+  mutable std::vector<Lease> idle_;
+  mutable size_t built_ = 0;
 };
 
 class Worker {

@@ -384,7 +384,68 @@ static int load_main(int argc, char **argv) {
   return 0;
 }
 
+// host_test --model-forward model.bin case.bin out.bin [lexical_shortlist.bin]
+//   slimt::Model::forward(const Input &) const (slimt/Model.hh:56) called from `threads` threads on ONE
+//   const Model, batch i by thread i % threads. case.bin: u32 {enc_layers, dec_layers, heads, threads,
+//   batches}, f32 limit_factor, then per batch u32 B, u32 S, u32 ids[B*S], u32 lengths[B].
+//   out.bin: per batch, per sentence u32 n, u32 tokens[n], f32 align[n][len]. stderr: contexts built.
+static int model_forward_main(int argc, char **argv) {
+  using namespace slimt;
+  if (argc != 5 && argc != 6) return 2;
+  std::vector<char> bin = slurp(argv[2]), cs = slurp(argv[3]);
+  std::vector<char> blob;
+  if (argc == 6) blob = slurp(argv[5]);
+  Cur c{cs.data()};
+  const uint32_t Le = c.get<uint32_t>(), Ld = c.get<uint32_t>(), H = c.get<uint32_t>();
+  const uint32_t n_threads = c.get<uint32_t>(), n_batches = c.get<uint32_t>();
+  const float limit = c.get<float>();
+  std::vector<Input> inputs;
+  for (uint32_t i = 0; i < n_batches; ++i) {
+    const uint32_t B = c.get<uint32_t>(), S = c.get<uint32_t>();
+    auto ids = c.vec<uint32_t>(size_t(B) * S);
+    auto lens = c.vec<uint32_t>(B);
+    inputs.emplace_back(B, S, /*pad_id=*/0, limit);
+    for (uint32_t b = 0; b < B; ++b)
+      inputs.back().add(Words(ids.begin() + size_t(b) * S, ids.begin() + size_t(b) * S + lens[b]));
+  }
+  try {
+    Model::Config cfg;
+    cfg.encoder_layers = Le;
+    cfg.decoder_layers = Ld;
+    cfg.num_heads = H;
+    const Model model(cfg, bin.data(), bin.size(), blob.empty() ? nullptr : blob.data(), blob.size());
+    std::vector<Histories> results(n_batches);
+    std::vector<std::string> errors(n_threads);
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < n_threads; ++t)
+      pool.emplace_back([&, t] {
+        try {
+          for (uint32_t i = t; i < n_batches; i += n_threads) results[i] = model.forward(inputs[i]);
+        } catch (const std::exception &e) {
+          errors[t] = e.what();
+        }
+      });
+    for (auto &th : pool) th.join();
+    for (const std::string &e : errors)
+      if (!e.empty()) throw std::runtime_error(e);
+    std::fprintf(stderr, "contexts-built: %zu\n", model.contexts_built());
+    std::ofstream out(argv[4], std::ios::binary);
+    for (uint32_t i = 0; i < n_batches; ++i)
+      for (const auto &h : results[i]) {
+        const uint32_t n = static_cast<uint32_t>(h->target.size());
+        put(out, &n, 1);
+        put(out, h->target.data(), n);
+        for (const auto &row : h->alignment) put(out, row.data(), row.size());
+      }
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "host_test: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc >= 2 && std::string(argv[1]) == "--model-forward") return model_forward_main(argc, argv);
   if (argc >= 2 && (std::string(argv[1]) == "--batcher" || std::string(argv[1]) == "--async"))
     return batching_main(argc, argv);
   if (argc >= 2 && std::string(argv[1]) == "--service-errors") return service_errors_main(argc, argv);

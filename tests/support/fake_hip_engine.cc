@@ -111,6 +111,11 @@ int slimt_hip_shortlist_generate(slimt_hip_shortlist *, const uint32_t *, const 
   *n = 8;
   return 0;
 }
+int slimt_hip_translate_generated(slimt_hip_ctx *c, slimt_hip_shortlist *sl, const uint32_t *ids, const uint32_t *lengths, size_t B,
+                                  size_t S, float limit, uint32_t eos, uint32_t *out_ids, uint32_t *out_len, float *align) {
+  if (!sl) return fail("shortlist is NULL");
+  return run(c, ids, lengths, B, S, limit, eos, out_ids, out_len, align, true);
+}
 int slimt_hip_translate_async_generated(slimt_hip_ctx *c, slimt_hip_shortlist *sl, const uint32_t *ids, const uint32_t *lengths,
                                         size_t B, size_t S, float limit, uint32_t eos, uint32_t *out_ids, uint32_t *out_len,
                                         float *align) {

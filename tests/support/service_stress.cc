@@ -111,6 +111,32 @@ int main(int argc, char **argv) {
     try { dead.translate({Words{3, 0}}).get(); std::printf("dead service answered\n"); } catch (const std::exception &e) { std::printf("dead service: %s\n", e.what()); }
     unsetenv("FAKE_HIP_FAIL_CTX_AFTER");
   }
+  // Model::forward(const Input &) const from several threads on one Model: the context pool
+  {
+    std::vector<std::thread> ts;
+    std::atomic<int> fwd{0};
+    for (int c = 0; c < clients; ++c)
+      ts.emplace_back([&, c]() {
+        std::mt19937 rng(700 + c);
+        for (int r = 0; r < requests; ++r) {
+          const size_t B = 1 + rng() % 6, S = 2 + rng() % 15;
+          Input in(B, S, 0, 1.5f);
+          std::vector<Words> sents(B);
+          for (auto &s : sents) {
+            s.resize(1 + rng() % S);
+            for (auto &w : s) w = 2 + rng() % 500;
+            s.back() = 0;
+            in.add(s);
+          }
+          Histories hs = static_cast<const Model &>(a).forward(in);
+          for (size_t i = 0; i < hs.size(); ++i)
+            if (!check(sents[i], *hs[i], 1.5f, true)) ++bad;
+          fwd += (int)hs.size();
+        }
+      });
+    for (auto &t : ts) t.join();
+    std::printf("Model::forward: %d sentences on %zu pooled contexts\n", fwd.load(), a.contexts_built());
+  }
   for (slimt_hip_model *h : {ha, hb, h2, h3}) slimt_hip_model_destroy(h);
   return bad.load() ? 1 : 0;
 }

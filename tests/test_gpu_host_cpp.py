@@ -177,3 +177,58 @@ def test_cpp_transformer_classes_drive_model_forward(hip, oracle, synth_models, 
         assert n == w_ln[b] and np.array_equal(toks, w_out[b, :n]), b
         assert np.array_equal(al, w_al[b, :n, :L]), b
     assert off == len(raw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,eos_bias,lexical,threads", [("micro", 3.0, False, 1), ("tiny11", 6.0, True, 4),
+                                                             ("tiny11", 6.0, False, 3), ("base", 6.0, True, 2)])
+def test_cpp_model_forward_const_is_reentrant(hip, oracle, synth_models, preset, eos_bias, lexical, threads):
+    """slimt::Model::forward(const Input &) const (slimt/Model.hh:56, Model.cc:187-204) as the
+    reference's Async workers call it: several threads on ONE const Model, batches of growing and
+    shrinking shapes (a pooled context is rebuilt when a batch outgrows it), the shortlist generated
+    per batch when the model was given a lexical shortlist -- every sentence's tokens and alignment
+    rows equal the oracle's, and no more contexts were built than threads ran."""
+    import re
+    from slimt_amd import synth
+    exe = _build_host()
+    m = synth_models(preset, eos_bias)
+    shapes = [(5, 9), (12, 21), (3, 40), (20, 16), (1, 1), (7, 33), (16, 8), (2, 70 if preset != "base" else 30)]
+    batches = [synth.make_batch(m.V, B, S, seed=600 + i, ragged=True) for i, (B, S) in enumerate(shapes)]
+    blob = synth.make_lexical_shortlist(m.V, m.V, 100 if m.V > 200 else 16, 30 if m.V > 200 else 6, seed=8) if lexical else None
+    with tempfile.TemporaryDirectory() as d:
+        mb, cb, ob, sb = (os.path.join(d, n) for n in ("model.bin", "case.bin", "out.bin", "lex.bin"))
+        open(mb, "wb").write(synth.write_bin(m))
+        with open(cb, "wb") as f:
+            f.write(struct.pack("<5If", m.enc_layers, m.dec_layers, m.H, threads, len(batches), 1.5))
+            for ids, lens in batches:
+                f.write(struct.pack("<2I", *ids.shape) + ids.tobytes() + lens.tobytes())
+        args = [exe, "--model-forward", mb, cb, ob]
+        if lexical:
+            open(sb, "wb").write(blob)
+            args.append(sb)
+        res = subprocess.run(args, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr
+        raw = open(ob, "rb").read()
+    built = int(re.search(r"contexts-built: (\d+)", res.stderr).group(1))
+    assert 1 <= built <= threads + len(shapes)  # one per concurrent caller + rebuilds for larger batches
+    osl = oracle.OracleShortlist(blob, m.V, m.V) if lexical else None
+    om = oracle.OracleModel(m)
+    oracle.set_mode(oracle.PORTABLE)
+    off = 0
+    try:
+        for ids, lens in batches:
+            sl = osl.generate(ids, lens) if lexical else None
+            w_out, w_ln, w_al, _ = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
+            for b in range(ids.shape[0]):
+                (n,) = struct.unpack_from("<I", raw, off)
+                off += 4
+                toks = np.frombuffer(raw, np.uint32, n, off)
+                off += 4 * n
+                L = int(lens[b])
+                al = np.frombuffer(raw, np.float32, n * L, off).reshape(n, L)
+                off += 4 * n * L
+                assert n == w_ln[b] and np.array_equal(toks, w_out[b, :n])
+                assert np.array_equal(al, w_al[b, :n, :L])
+    finally:
+        oracle.set_mode(oracle.FAITHFUL)
+    assert off == len(raw)
