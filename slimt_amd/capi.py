@@ -7,6 +7,7 @@ call fails, SlimtHipError is raised.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import os
 from typing import Optional, Sequence
 
@@ -672,8 +673,7 @@ class BatchService:
         lens = np.fromiter((len(s) for s in sentences), dtype=np.uint64, count=len(sentences))
         offsets = np.zeros(len(sentences) + 1, np.uint64)
         np.cumsum(lens, out=offsets[1:])
-        tokens = np.concatenate([np.asarray(s, dtype=np.uint32) for s in sentences]) if len(sentences) else \
-            np.zeros(0, np.uint32)
+        tokens = np.fromiter(itertools.chain.from_iterable(sentences), dtype=np.uint32, count=int(offsets[-1]))
         return self.translate_flat(tokens, offsets)
 
     def close(self):

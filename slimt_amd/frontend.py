@@ -20,6 +20,7 @@ to a CPU model.
 """
 from __future__ import annotations
 
+import functools
 import threading
 from dataclasses import dataclass, field
 from typing import List, Sequence
@@ -28,6 +29,7 @@ import numpy as np
 
 from . import capi, synth
 from .text import AnnotatedText, Encoding, Range, TextProcessor, Vocabulary  # noqa: F401 (API surface)
+from .text import _Lazy
 
 Alignment = np.ndarray  # [target token][source token] f32, p(source | target); indexes like a list of rows
 
@@ -72,6 +74,11 @@ class Response:  # Response.hh: source / target with sentence + token ranges, so
     def to(self, encoding: Encoding) -> None:
         self.source.to(encoding)
         self.target.to(encoding)
+
+
+def _target_boundaries(vocabulary, begin: int, words) -> List[int]:
+    """Token boundaries (byte offsets in the target text) of a decoded sentence that starts at `begin`."""
+    return [begin + o for o in vocabulary.decode_boundaries(words)]
 
 
 def _blob(x) -> bytes:
@@ -227,17 +234,21 @@ class Service:
         eos = model.vocabulary.eos_id()
         flat, owner = [], []  # the sentences of the one request the C++ service gets; (request, index, piece)
         pieces_of = {}
-        for r, segs in enumerate(per_request):
-            for i, seg in enumerate(segs):
-                if len(seg) <= self.ENGINE_LIMIT:
-                    flat.append(seg)
-                    owner.append((r, i, 0))
-                    continue
-                pieces = self._split_long(list(seg), eos)
-                pieces_of[(r, i)] = len(pieces)
-                for k, piece in enumerate(pieces):
-                    flat.append(piece)
-                    owner.append((r, i, k))
+        limit = self.ENGINE_LIMIT
+        if all(len(seg) <= limit for segs in per_request for seg in segs):  # the usual call: nothing to split
+            flat = [seg for segs in per_request for seg in segs]
+        else:
+            for r, segs in enumerate(per_request):
+                for i, seg in enumerate(segs):
+                    if len(seg) <= limit:
+                        flat.append(seg)
+                        owner.append((r, i, 0))
+                        continue
+                    pieces = self._split_long(list(seg), eos)
+                    pieces_of[(r, i)] = len(pieces)
+                    for k, piece in enumerate(pieces):
+                        flat.append(piece)
+                        owner.append((r, i, k))
         histories = [[None] * len(segs) for segs in per_request]
         if not flat:
             return histories
@@ -252,6 +263,14 @@ class Service:
         parts = {}
         words_all = targets.tolist()
         to, ao, sl = t_off.tolist(), a_off.tolist(), src_len.tolist()
+        if not pieces_of:
+            n = 0
+            for hist in histories:
+                for i in range(len(hist)):
+                    words = words_all[to[n]:to[n + 1]]
+                    hist[i] = (words, _LazyAlignment(align, ao[n], ao[n + 1], len(words), sl[n]))
+                    n += 1
+            return histories
         for n, (r, i, k) in enumerate(owner):
             words = words_all[to[n]:to[n + 1]]
             alignment = _LazyAlignment(align, ao[n], ao[n + 1], len(words), sl[n])
@@ -286,13 +305,27 @@ class Service:
         decoded = model.vocabulary.decode_text_batch(flat, self.workers) if flat else []
         out, k, v = [], 0, model.vocabulary
         for source, hist in zip(sources, histories):
+            # AnnotatedText.append_lazy_sentence per sentence, written out: the target text is joined once per
+            # response, sentences recorded directly (this loop holds the interpreter lock while the
+            # engine's threads wait for the next chunk)
             resp = Response(source=source)
+            parts, sent, alignments = [], resp.target._sent, resp.alignments
+            src_sent, data, prev_end, pos = source._sent, source.data, 0, 0
             for s, (words, alignment) in enumerate(hist):
-                resp.target.append_lazy_sentence(source.gap_bytes(s), decoded[k].encode("utf-8"), len(words),
-                                                 lambda words=words: v.decode_boundaries(words))
-                resp.alignments.append(alignment)
+                w = src_sent[s]
+                lazy = type(w) is _Lazy
+                gap = data[prev_end:(w.begin if lazy else w[0])]  # source.gap_bytes(s)
+                prev_end = w.end if lazy else w[-1]
+                text = decoded[k].encode("utf-8")
+                begin = pos + len(gap)
+                pos = begin + len(text)
+                parts.append(gap)
+                parts.append(text)
+                sent.append(_Lazy(begin, pos, len(words), functools.partial(_target_boundaries, v, begin, words)))
+                alignments.append(alignment)
                 k += 1
-            resp.target.append_ending_whitespace(source.gap_bytes(len(hist)) if hist else source.data)
+            parts.append(data[prev_end:] if hist else data)  # the gap behind the last sentence
+            resp.target.data = b"".join(parts)
             out.append(resp)
         return out
 

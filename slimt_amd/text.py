@@ -17,6 +17,7 @@ wheel (the reference links the same library, Vocabulary.hh:9).
 from __future__ import annotations
 
 import enum
+import functools
 from dataclasses import dataclass
 from typing import Iterator, List, Optional, Sequence, Tuple
 
@@ -331,6 +332,16 @@ class Splitter:
         """(begin, end) character ranges of the sentences of one paragraph."""
         n = len(paragraph)
         pos = 0
+
+        def prefix(m, floor):     # the letters / digits right before the mark (not before `floor`: where this
+            b = m.start("punct")  # candidate search began, as the one-regex form's match does)
+            while b > floor:
+                ch = paragraph[b - 1]
+                if not (ch.isalnum() if ch < "\x80" else _PREFIX_CHAR.match(ch, concurrent=False)):
+                    break
+                b -= 1
+            return paragraph[b:m.start("punct")]
+
         while True:
             while pos < n and paragraph[pos].isspace():
                 pos += 1
@@ -338,8 +349,11 @@ class Splitter:
                 return
             start, scan, end = pos, pos, None
             while end is None:
+                # concurrent=False: by default the regex module releases the interpreter lock around every
+                # match on a str; with the service's other Python threads waiting for it, getting it back cost
+                # more than the match (5.6 us per search against 1.7 us alone)
                 floor = scan
-                m = _MARK.search(paragraph, scan)
+                m = _MARK.search(paragraph, scan, concurrent=False)
                 if not m:
                     break
                 scan = m.end()
@@ -348,24 +362,28 @@ class Splitter:
                     scan = m.end("punct")
                     continue
 
-                def prefix(m=m, floor=floor):  # the letters / digits right before the mark (not before `floor`:
-                    b = m.start("punct")       # where this candidate search began, as the one-regex form's match does)
-                    while b > floor and _PREFIX_CHAR.match(paragraph, b - 1):
-                        b -= 1
-                    return paragraph[b:m.start("punct")]
-
-                lead = _NEXT_WORD.match(paragraph, m.end()).group("lead")
-                if _OTHER.match(lead):
-                    pass  # a letter without case (CJK, ...): break
-                elif _LOWER.match(lead):
+                # what the next word starts with decides (1 caseless letter, 2 lower, 3 upper / title, 4 digit,
+                # 0 anything else). ASCII letter or digit right after the whitespace: no regex needed
+                nxt = paragraph[scan] if scan < n else ""
+                if "a" <= nxt <= "z":
                     continue
-                elif _UPPER.match(lead):
-                    if punct == "." and self.prefix_class(prefix()) != 0:
-                        continue
-                elif _DIGIT.match(lead):
-                    if punct == "." and self.prefix_class(prefix()) == 2:
-                        continue
+                if "A" <= nxt <= "Z":
+                    kind = 3
+                elif "0" <= nxt <= "9":
+                    kind = 4
                 else:
+                    lead = _NEXT_WORD.match(paragraph, scan, concurrent=False).group("lead")
+                    kind = 1 if _OTHER.match(lead) else 2 if _LOWER.match(lead) else 3 if _UPPER.match(lead) else \
+                        4 if _DIGIT.match(lead) else 0
+                if kind == 2:
+                    continue
+                if kind == 3:
+                    if punct == "." and self.prefix_class(prefix(m, floor)) != 0:
+                        continue
+                elif kind == 4:
+                    if punct == "." and self.prefix_class(prefix(m, floor)) == 2:
+                        continue
+                elif kind == 0:
                     if punct == "..." and m.group("tail") == "]" and m.start("punct") > start + 1 and \
                             paragraph[m.start("punct") - 1] == "[":
                         continue
@@ -417,6 +435,12 @@ def sentence_stream(text: bytes, splitter: Splitter, mode: str) -> Iterator[Tupl
 
 
 # ----------------------------------------------------------------------------------------------
+def _source_boundaries(vocabulary, begin: int, line: str) -> List[int]:
+    """Token boundaries (byte offsets in the text) of a sentence that starts at `begin`, EOS included."""
+    offs = [begin + o for o in vocabulary.encode_boundaries(line)]
+    return offs + [offs[-1]]  # the EOS: empty, at the end
+
+
 class TextProcessor:
     """text -> (annotated source, segments of token ids ending in EOS) (TextProcessor.cc:78-199)."""
 
@@ -449,31 +473,36 @@ class TextProcessor:
         encoded = self.vocabulary.encode_ids_batch(lines, num_threads) if lines else []
         eos, step, v = self.vocabulary.eos_id(), wrap_length - 1, self.vocabulary
         out, k = [], 0
+
         for src, sp in zip(sources, spans):
             segments: List[List[int]] = []
+            sent, last, size = src._sent, 0, len(src.data)
             for b, e in sp:
                 words, line = encoded[k], lines[k]
                 k += 1
+                if not words:  # nothing after normalisation (TextProcessor.cc:118)
+                    continue
                 # the sentence is what its tokens cover: SentencePiece drops surrounding whitespace
-                lead = len(line) - len(line.lstrip())
-                if lead or line != line.rstrip():
+                if line[0].isspace() or line[-1].isspace():
+                    lead = len(line) - len(line.lstrip())
                     b += len(line[:lead].encode("utf-8"))
                     line = line.strip()
                     e = b + len(line.encode("utf-8"))
-                if not words:  # nothing after normalisation (TextProcessor.cc:118)
-                    continue
                 if len(words) <= step:
-                    def resolve(b=b, line=line):
-                        offs = [b + o for o in v.encode_boundaries(line)]
-                        return offs + [offs[-1]]  # the EOS: empty, at the end
-                    src.record_lazy_sentence(b, e, len(words) + 1, resolve)
-                    segments.append(list(words) + [eos])
+                    # record_lazy_sentence, inlined (a fifth of this loop went into its calls)
+                    if b < last or e > size or e < b:
+                        raise ValueError("sentence outside the text or before the previous one")
+                    words.append(eos)  # SentencePiece's own list: nobody else holds it
+                    sent.append(_Lazy(b, e, len(words), functools.partial(_source_boundaries, v, b, line)))
+                    last = e
+                    segments.append(words)
                     continue
                 bounds = [b + o for o in v.encode_boundaries(line)]
                 for off in range(0, len(words), step):
                     part = bounds[off:off + step + 1]
                     src.record_existing_sentence(list(zip(part[:-1], part[1:])) + [(part[-1], part[-1])], part[0])
                     segments.append(list(words[off:off + step]) + [eos])
+                last = e
             out.append((src, segments))
         return out
 

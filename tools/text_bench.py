@@ -44,11 +44,24 @@ res["resolve_source_ranges"] = {"seconds": round(dt, 3), "tokens_per_s": round(n
 for max_words in (4096, 16384):
     svc = frontend.Service(workers=workers, max_words=max_words)
     svc.translate(model, texts[:64])  # warm-up: contexts, kernels
-    t0 = time.time()
-    responses = svc.translate(model, texts)
-    dt = time.time() - t0
+    runs = []
+    for rep in range(3):  # one call each; the median is reported, every run is listed
+        prof = None
+        if os.environ.get("SLIMT_TEXT_PROFILE") and max_words == 16384 and rep == 2:  # where the calling thread spends the call
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
+        t0 = time.time()
+        responses = svc.translate(model, texts)
+        runs.append(time.time() - t0)
+        if prof:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(30)
+    dt = sorted(runs)[1]
     tgt_tokens = sum(r.target.word_count(s) for r in responses for s in range(r.target.sentence_count()))
-    res[f"end_to_end_max_words_{max_words}"] = {"seconds": round(dt, 3), "source_tokens_per_s": round(src_tokens / dt),
+    res[f"end_to_end_max_words_{max_words}"] = {"seconds": round(dt, 3), "seconds_each_run": [round(x, 3) for x in runs],
+                                                 "source_tokens_per_s": round(src_tokens / dt),
                                                  "target_tokens_per_s": round(tgt_tokens / dt),
                                                  "sentences_per_s": round(docs_n * 8 / dt)}
     svc.close()
