@@ -58,9 +58,15 @@ __device__ __forceinline__ TEpi tload_epi(const PreparedWeight &w, int tile, int
 // columns at once, two per packed instruction (v_pk_mul_f32 / v_pk_add_f32 are the same
 // IEEE operations as the scalar forms: multiply and add stay separate roundings).
 typedef float tf2 __attribute__((ext_vector_type(2)));
+// The shift 127 colsum is the accumulator's INITIAL value (tshift, once per column tile: the four row tiles of a
+// column share it) instead of an addition in every epilogue: integer arithmetic, the same sum -- `c` below is
+// already acc + 127 colsum.
+__device__ __forceinline__ v4i tshift(const TEpi &e) {
+  return v4i{__mul24(127, e.cs[0]), __mul24(127, e.cs[1]), __mul24(127, e.cs[2]), __mul24(127, e.cs[3])};
+}
 __device__ __forceinline__ float4 tdequant4(const v4i &c, const TEpi &e, float u) {
-  tf2 lo = {(float)(c[0] + __mul24(127, e.cs[0])), (float)(c[1] + __mul24(127, e.cs[1]))};
-  tf2 hi = {(float)(c[2] + __mul24(127, e.cs[2])), (float)(c[3] + __mul24(127, e.cs[3]))};
+  tf2 lo = {(float)c[0], (float)c[1]};
+  tf2 hi = {(float)c[2], (float)c[3]};
   const tf2 uu = {u, u};
   lo = lo * uu;
   hi = hi * uu;
@@ -306,8 +312,8 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     }
     return o;
   };
-  auto mma_rt = [&](const v4i (&f)[KSD], int rt, const AFrag &o) {
-    v4i c = {0, 0, 0, 0};
+  auto mma_rt = [&](const v4i (&f)[KSD], int rt, const AFrag &o, const v4i &init) {
+    v4i c = init;
 #pragma unroll
     for (int ks = 0; ks < KSD; ++ks) {
       const v4i av = *reinterpret_cast<const __attribute__((address_space(3))) v4i *>(o.p[ks] + 16 * rt * LDA);
@@ -349,9 +355,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         const char *A1 = qv ? Aq : Ak;
         float *dst1 = qv ? qb : kb;
         const AFrag af = a_frag(A1, lane);
+        const v4i s1 = tshift(e1);
 #pragma unroll
         for (int rt = 0; rt < TRT; ++rt) {
-          const v4i c = mma_rt(w1, rt, af);
+          const v4i c = mma_rt(w1, rt, af, s1);
           const float4 qk = tdequant4(c, e1, W1.u);
           float *qd = dst1 + (16 * rt + lr) * LDQ + ctl * 16 + lg * 4;
           *reinterpret_cast<float2 *>(qd) = float2{qk.x, qk.y};
@@ -360,9 +367,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (qv) {
           const AFrag afv = a_frag(Av, lane);
+          const v4i sv = tshift(ev);
 #pragma unroll
           for (int rt = 0; rt < TRT; ++rt) {
-            const v4i cv = mma_rt(wv, rt, afv);
+            const v4i cv = mma_rt(wv, rt, afv, sv);
             *reinterpret_cast<float4 *>(vb + (16 * rt + lr) * LDV + ctl * 16 + lg * 4) = tdequant4(cv, ev, L.v.u);
           }
         }
@@ -473,9 +481,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       const TEpi eo = tload_epi(L.o, wave, lg);
       lds_barrier();  // attention of the last round is complete: q / k / v are dead
       SLIMT_TSTAMP(4);
+      const v4i so = tshift(eo);
 #pragma unroll
       for (int rt = 0; rt < TRT; ++rt) {
-        v4i c = {0, 0, 0, 0};
+        v4i c = so;
 #pragma unroll
         for (int ks = 0; ks < KSD; ++ks) {  // k-steps 0, 1: round 0's heads; 2, 3: round 1's
           const v4i av = *reinterpret_cast<const v4i *>((ks < 2 ? Ob0 : Ob1) + (16 * rt + lr) * LDO + (ks & 1) * 64 + lg * 16);
@@ -527,13 +536,14 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       for (int i = 0; i < NT1; ++i) {
         const int buf = i % 3, t = wave + TNW * i;
         const TEpi e = e1[buf];
+        const v4i sh = tshift(e);
         // Measured by ablation (timing-only builds, round 3): this phase is 9.2 us = the weight stream alone
         // (3.0: 384 KB at the CU's 64 B/clk) + the MFMAs and their A-fragment reads (3.1; 0.9 of it the LDS reads)
         // + the epilogues (3.1) -- they add up instead of overlapping, whichever way the loop is arranged
         // (loads before / after the epilogues, half the waves of a SIMD started late: no change).
 #pragma unroll
         for (int rt = 0; rt < TRT; ++rt) {
-          const v4i c = mma_rt(bw[buf], rt, af);
+          const v4i c = mma_rt(bw[buf], rt, af, sh);
           *reinterpret_cast<int *>(Hb + (16 * rt + lr) * LDH + t * 16 + lg * 4) = trelu_quant4(c, e, L.ffn1.u, L.ffn2.a_quant);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -551,9 +561,13 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     SLIMT_TSTAMP(7);
     {  // FFN2: this wave's column tile over K = F, chunks of 4 k-steps, three in flight
       SLIMT_TPHASE_LANE;
+      const TEpi e2 = tload_epi(L.ffn2, wave, lg);  // its shift starts the accumulators
       v4i f[TRT];
+      {
+        const v4i s2 = tshift(e2);
 #pragma unroll
-      for (int rt = 0; rt < TRT; ++rt) f[rt] = v4i{0, 0, 0, 0};
+        for (int rt = 0; rt < TRT; ++rt) f[rt] = s2;
+      }
 #pragma unroll
       for (int c = 0; c < NC2; ++c) {
         const int buf = c % 3;
@@ -569,7 +583,6 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         if (c + 3 < NC2) load2(buf, c + 3, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
-      const TEpi e2 = tload_epi(L.ffn2, wave, lg);
       // the next layer's first Q / K tiles: under the LayerNorm (unconditional, so that the
       // registers are dead between the projections and here)
       load_first(a.L[l + 1 < a.Le ? l + 1 : l], 0, lane);
@@ -629,15 +642,14 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       lds_barrier();
       const int col = wave * 16 + lg * 4;
       const AFrag af = a_frag(Aq, lane);
+      const v4i skv = tshift(e);
       int *stg = reinterpret_cast<int *>(region);  // packed cache: [TR][LDY] shifted accumulators
 #pragma unroll
       for (int rt = 0; rt < TRT; ++rt) {
-        const v4i c = mma_rt(wf, rt, af);
+        const v4i c = mma_rt(wf, rt, af, skv);
         const int rrow = 16 * rt + lr;
         if (a.kv24) {
-          const v4i s4 = {c[0] + __mul24(127, e.cs[0]), c[1] + __mul24(127, e.cs[1]), c[2] + __mul24(127, e.cs[2]),
-                          c[3] + __mul24(127, e.cs[3])};
-          *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = s4;
+          *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = c;
         } else if (row_valid(rrow)) {
           const float4 v = tdequant4(c, e, w.u);
           if (p == 0) {  // K cache layout [sentence][head][d/4][key][4]: the lane's 4 columns are one d/4 group

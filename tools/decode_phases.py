@@ -1,11 +1,11 @@
-"""GPU box: per-phase time of the persistent decoder (workgroup 0, one step)."""
+"""GPU box: per-phase time of the persistent decoder (workgroup 0, one step). argv: B, S, shortlist size."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from slimt_amd import capi, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-n_sl = 4096
+n_sl = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 m = synth.make_model("tiny11", eos_bias=-100.0)
 gm = capi.Model(m); ctx = capi.Context(gm, B, S)
 ctx.set_decode_mode(int(os.environ.get("SLIMT_DECODE_MODE", "0")))  # 3 = 32 sentences per workgroup
@@ -27,12 +27,4 @@ for step in (5, 20):
     for i in range(1, len(idx)):
         print(f"  {names[i]:22s} {(t[i]-t[i-1])/100:7.2f} us")
 
-if S > 32:
-    sys.exit(0)  # (the encoder stamps below are those of the S <= 32 kernels)
-ctx.debug_decode_stamps(2)
-ctx.translate(ids, lens, sl)
-st = ctx.debug_decode_stamps(-1).astype(np.int64)[48:56]
-en = ["quantise", "qkv_gemm", "attention", "o_gemm", "ln+quant", "ffn", "ln"]
-print(f"--- encoder layer 2 (workgroup 0): total {(st[7]-st[0])/100:.1f} us")
-for i in range(7):
-    print(f"  {en[i]:22s} {(st[i+1]-st[i])/100:7.2f} us")
+# (encoder phases: tools/encode_wide_phases.py [batch] [tiny11 | base])
