@@ -81,20 +81,23 @@ __device__ __forceinline__ float4 tdequant4(const v4i &c, const TEpi &e, float u
 // layer). For aq > 0 (a quantisation multiplier is 127 / max|x|), clamp(rint(max(v, 0) * aq), -127,
 // 127) == clamp(rint(v * aq), 0, 127) for every float v: the product keeps the sign, rint(-0) and
 // rint(+0) both convert to 0, and a NaN falls to the lower bound of either form (maxNum / minNum
-// semantics) -- so the relu rides in the clamp, and v_cvt_pk_u8_f32 converts and packs the four
-// already integral values (exact under any rounding) in one instruction each.
+// semantics) -- so the relu rides in the clamp. v_cvt_pk_u8_f32 rounds to nearest even itself, saturates at
+// 0 and at 255 and converts a NaN to 0 (tools/probes/cvt_u8_probe.hip, all 2^32 bit patterns:
+// profiles/r03_cvt_u8_probe.txt): it is the rint, the lower clamp and the pack in one instruction per value; the
+// upper clamp 127 is taken on the four packed bytes at once (a byte >= 128 becomes 127).
 __device__ __forceinline__ int trelu_quant4(const v4i &c, const TEpi &e, float u, float aq) {
   const float4 v = tdequant4(c, e, u);
   tf2 lo = {v.x, v.y}, hi = {v.z, v.w};
   const tf2 qq = {aq, aq};
   lo = lo * qq;
   hi = hi * qq;
-  const float r[4] = {__builtin_rintf(lo.x), __builtin_rintf(lo.y), __builtin_rintf(hi.x), __builtin_rintf(hi.y)};
   unsigned w = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(__builtin_fmaxf(r[i], 0.0f), 127.0f), i, w);
-  return (int)w;
+  w = __builtin_amdgcn_cvt_pk_u8_f32(lo.x, 0, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(lo.y, 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(hi.x, 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(hi.y, 3, w);
+  const unsigned m = w & 0x80808080u;
+  return (int)((w | (m - (m >> 7))) & 0x7f7f7f7fu);
 }
 
 // canonical LayerNorm of one row held in registers (v[i] = column lane + 64 i), in place

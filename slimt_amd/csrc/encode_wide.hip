@@ -63,18 +63,20 @@ __device__ __forceinline__ float4 wdequant4(const v4i &c, const int (&cs)[4], fl
   return v;
 }
 // relu, then PrepareA with `aq`, four int8 in one register (see encode_tall.hip, trelu_quant4: for a
-// positive multiplier the relu rides in the clamp, v_cvt_pk_u8_f32 converts and packs)
+// positive multiplier the relu rides in the clamp; v_cvt_pk_u8_f32 rounds to nearest even, saturates at 0 and
+// packs; the upper clamp 127 is taken on the four packed bytes)
 __device__ __forceinline__ int wrelu_quant4(const float4 &v, float aq) {
   wf2 lo = {v.x, v.y}, hi = {v.z, v.w};
   const wf2 qq = {aq, aq};
   lo = lo * qq;
   hi = hi * qq;
-  const float r[4] = {__builtin_rintf(lo.x), __builtin_rintf(lo.y), __builtin_rintf(hi.x), __builtin_rintf(hi.y)};
   unsigned w = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(__builtin_fmaxf(r[i], 0.0f), 127.0f), i, w);
-  return (int)w;
+  w = __builtin_amdgcn_cvt_pk_u8_f32(lo.x, 0, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(lo.y, 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(hi.x, 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(hi.y, 3, w);
+  const unsigned m = w & 0x80808080u;
+  return (int)((w | (m - (m >> 7))) & 0x7f7f7f7fu);
 }
 
 // epilogue constants of column tile `tile` for this lane's 4 columns (4 lg .. 4 lg + 3)

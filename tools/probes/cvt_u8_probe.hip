@@ -22,6 +22,9 @@ __global__ void probe(unsigned long long *bad, unsigned *example) {
       const unsigned m = got & 0x80u;
       got = (got | (m - (m >> 7))) & 0x7fu;
     }
+#elif defined(SLIMT_PROBE_MED3)
+    // one v_med3_f32 clamps both ends (a NaN operand makes it MIN3 of the others: 0), then the conversion rounds
+    const unsigned got = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(x, 0.0f, 127.0f), 0, 0u) & 0xffu;
 #else
     const unsigned got = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(x, 127.0f), 0, 0u) & 0xffu;
 #endif
