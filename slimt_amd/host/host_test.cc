@@ -133,6 +133,7 @@ static int batching_main(int argc, char **argv) {
       if (n_sl) sc.shortlist = c.vec<uint32_t>(n_sl);
     }
     if (const char *e = std::getenv("SLIMT_SERVICE_NO_ALIGN")) sc.alignments = e[0] != '1';
+    if (const char *e = std::getenv("SLIMT_SERVICE_FLAT_ALIGN")) sc.flat_alignments = e[0] == '1';
     // SLIMT_SERVICE_LEXICAL=<binary shortlist file>: every batch gets its own lexical shortlist,
     // generated on the device (ServiceConfig::lexical_shortlist); the vocabulary sizes are the model's
     std::vector<char> lexical;

@@ -2,7 +2,7 @@
 token-budget batches from ragged sentences, `workers` double-buffered worker
 threads (two contexts + pinned staging each), host buffers in and out (PCIe
 included). argv: workers, sentences, shortlist size (0 = full vocabulary; "lex" = a lexical shortlist generated
-per batch on the device, ServiceConfig::lexical_shortlist), alignments (1/0)."""
+per batch on the device, ServiceConfig::lexical_shortlist), alignments (1 / 0 / "flat" = ServiceConfig::flat_alignments)."""
 import json, os, re, struct, subprocess, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +12,8 @@ workers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 n_sent = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 lexical = len(sys.argv) > 3 and sys.argv[3] == "lex"
 n_sl = 0 if lexical or len(sys.argv) <= 3 else int(sys.argv[3])
-align = (sys.argv[4] if len(sys.argv) > 4 else "1") == "1"
+align = (sys.argv[4] if len(sys.argv) > 4 else "1") in ("1", "flat")
+flat = len(sys.argv) > 4 and sys.argv[4] == "flat"  # one [T][len] block per sentence instead of T small vectors
 max_words = 8192 + 32  # 256 sentences of 32 tokens: (B + 1) * S <= max_words
 m = synth.make_model("tiny11", eos_bias=-100.0)  # nobody emits EOS: floor(1.5 * S) tokens per sentence
 r = np.random.Generator(np.random.PCG64(5))
@@ -34,7 +35,8 @@ with tempfile.TemporaryDirectory() as d:
             sl = synth.make_shortlist(m.V, n_sl)
             f.write(struct.pack("<I", sl.size) + sl.tobytes())
     env = dict(os.environ, GPU_MAX_HW_QUEUES="32", SLIMT_SERVICE_REPEAT="1",
-               SLIMT_SERVICE_NO_ALIGN="0" if align else "1", SLIMT_SERVICE_STATS="1", SLIMT_SERVICE_DISCARD="1")
+               SLIMT_SERVICE_NO_ALIGN="0" if align else "1", SLIMT_SERVICE_STATS="1", SLIMT_SERVICE_DISCARD="1",
+               SLIMT_SERVICE_FLAT_ALIGN="1" if flat else "0")
     if lexical:  # about 4000 ids for a batch of 256 x 32 tokens, different for every batch
         lb = os.path.join(d, "lex.bin")
         open(lb, "wb").write(synth.make_lexical_shortlist(m.V, m.V, 100, 1, seed=11, empty_fraction=0.4, min_count=1))
@@ -50,7 +52,7 @@ with tempfile.TemporaryDirectory() as d:
     toks = int(re.search(r"async-warm-tokens: (\d+)", res.stderr).group(1))  # the warm, timed pass: clients x rounds
 print(json.dumps({"workload": f"Service, tiny11 {'lexical shortlist generated per batch on the device' if lexical else 'shortlist ' + str(n_sl) if n_sl else 'full vocabulary'}, {n_sent} ragged "
                               f"sentences (8..32 tokens), max_words={max_words}, workers={workers} x 2 contexts, "
-                              f"pinned host buffers{' + alignments' if align else ''}",
+                              f"pinned host buffers{' + alignments' if align else ''}{' (one block per sentence)' if flat else ''}",
                   "target_tokens_per_s": toks / ms * 1e3,
                   "ms": ms, "ms_first_pass_with_worker_startup": ms_cold, "target_tokens": toks,
                   "service_stats": stats.group(1) if stats else None,

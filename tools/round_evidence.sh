@@ -42,7 +42,7 @@ cat gpurun_out/${TAG}_configs.txt
 SLIMT_BENCH_REHEARSAL=1 timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 2 --workers 8 --no-cpu-baseline --sustained-steps 0 --forward-steps 0 > gpurun_out/${TAG}_rehearsal_2ranks_on_1gpu.json 2> gpurun_out/${TAG}_rehearsal.err
 cut -c1-200 gpurun_out/${TAG}_rehearsal_2ranks_on_1gpu.json
 rm -f gpurun_out/${TAG}_service_bench.jsonl
-for cfg in "10 32768 4096 0" "10 32768 4096 1" "10 32768 lex 0" "10 32768 lex 1" "6 32768 4096 1" "10 32768 0 1"; do
+for cfg in "10 32768 4096 0" "10 32768 4096 1" "10 32768 4096 flat" "10 32768 lex 0" "10 32768 lex 1" "6 32768 4096 1" "10 32768 0 1"; do
   timeout -k 10 200 python tools/async_bench.py $cfg >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err || { echo "service bench $cfg failed"; exit 1; }
 done
 SLIMT_SERVICE_REPLICAS=2 timeout -k 10 200 python tools/async_bench.py 5 32768 4096 1 >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err
@@ -51,6 +51,6 @@ import json, sys
 for l in open(sys.argv[1]):
     d = json.loads(l); print(f"{d['target_tokens_per_s']/1e6:6.2f} M tok/s  {d['workload'][:120]}")
 PY
-timeout -k 10 250 python tools/text_bench.py 3000 6 > gpurun_out/${TAG}_text_bench.json 2> gpurun_out/${TAG}_text_bench.err
+timeout -k 10 250 python tools/text_bench.py 3000 8 > gpurun_out/${TAG}_text_bench.json 2> gpurun_out/${TAG}_text_bench.err
 cut -c1-600 gpurun_out/${TAG}_text_bench.json
 timeout -k 10 100 python tools/sync_workers_bench.py > gpurun_out/${TAG}_sync_workers.jsonl 2>/dev/null; cut -c1-300 gpurun_out/${TAG}_sync_workers.jsonl

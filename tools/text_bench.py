@@ -2,7 +2,7 @@
 Where the time goes once the model runs at > 1 M tok/s: sentence splitting + SentencePiece
 (host), batching, the engine, decoding ids back to text.
 usage: python tools/text_bench.py [documents] [workers]"""
-import io, json, os, random, sys, time
+import gc, io, json, os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sentencepiece
 from slimt_amd import frontend, synth
@@ -44,8 +44,10 @@ res["resolve_source_ranges"] = {"seconds": round(dt, 3), "tokens_per_s": round(n
 for max_words in (4096, 16384):
     svc = frontend.Service(workers=workers, max_words=max_words)
     svc.translate(model, texts[:64])  # warm-up: contexts, kernels
-    runs = []
+    runs, responses = [], None
     for rep in range(3):  # one call each; the median is reported, every run is listed
+        responses = None  # the previous call's 24,000 sentences: freed (and collected) outside the timed call
+        gc.collect()
         prof = None
         if os.environ.get("SLIMT_TEXT_PROFILE") and max_words == 16384 and rep == 2:  # where the calling thread spends the call
             import cProfile
