@@ -95,17 +95,46 @@ __device__ __forceinline__ v4i load_frag(rsrc_t r, int voff, int soff) {
 // RT row tiles (16 RT rows of A): every weight fragment feeds RT MFMAs; epi(tile, rt, ...)
 // runs once per finished (column tile, row tile).
 // The stream's descriptors and this lane's offsets.
-template <int KS, int NT>
+template <int KS, int NT, bool PAIRED = false>
 struct StreamSrc {
   rsrc_t rw, rc, rp;
   int voff, eoff, n_tiles;
   __device__ __forceinline__ StreamSrc(const PreparedWeight &w, int lane) {
     n_tiles = NT > 0 ? NT * NW : w.n_tiles;
     rw = make_rsrc(w.Wp, (unsigned)n_tiles * KS * 1024u);
-    rc = make_rsrc(w.colsum, (unsigned)n_tiles * 64u);
-    rp = make_rsrc(w.pb, (unsigned)n_tiles * 64u);
+    if constexpr (PAIRED) {  // pair constants (kernels.h, PreparedWeight::cp4): one descriptor, 16 bytes per lane
+      rc = make_rsrc(w.cp4, (unsigned)(16 * ((n_tiles + 31) / 32)) * 256u);
+      rp = rc;
+      eoff = (lane & 15) * 16;
+    } else {
+      rc = make_rsrc(w.colsum, (unsigned)n_tiles * 64u);
+      rp = make_rsrc(w.pb, (unsigned)n_tiles * 64u);
+      eoff = (lane & 15) * 4;
+    }
     voff = lane * 16;
-    eoff = (lane & 15) * 4;
+  }
+  // K = 256 (one tile per chunk): chunk c's four fragments; the ODD chunk of a pair (2 p, 2 p + 1) -- or an even
+  // last chunk without a partner -- also fetches the pair's epilogue constants as one quad: cs[0], pb[0] = the even
+  // chunk's, cs[1], pb[1] = the odd one's (HOLD). With the odd chunk because both chunks' constants are then dead
+  // when its buffer is requested again: fetched with the even chunk, the odd chunk's would have to be copied across
+  // the loop's back edge, and the copy waits for the load (measured: one drained round trip per round).
+  template <bool HOLD>
+  __device__ __forceinline__ void load_paired(Frags &bb, int c, int wave) const {
+    static_assert(KS == CH && PAIRED, "one tile per chunk");
+    const int tile = wave + NW * c;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bb.f[ks] = load_frag(rw, voff, (tile * KS + ks) * 1024);
+#ifndef SLIMT_EXP_NOEPI
+    if constexpr (HOLD) {
+      const v4i q = load_frag(rc, eoff, (NW * (c >> 1) + wave) * 256);
+      // (__int_as_float on a copy: __builtin_bit_cast(float, q.y) of a vector ELEMENT reads element 0 with this compiler)
+      const int y = q.y, w4 = q.w;
+      bb.cs[0] = q.x;
+      bb.pb[0] = __int_as_float(y);
+      bb.cs[1] = q.z;
+      bb.pb[1] = __int_as_float(w4);
+    }
+#endif
   }
   // chunk c of wave `wave`'s stream: CH fragments + the epilogue constants of its tile(s)
   __device__ __forceinline__ void load(Frags &bb, int c, int wave) const {
@@ -116,8 +145,13 @@ struct StreamSrc {
         const int tile = EXP_TILE(wave + NW * (c * TPC + j));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bb.f[j * KS + ks] = load_frag(rw, voff, (tile * KS + ks) * 1024);
+#ifdef SLIMT_EXP_NOEPI  // timing experiment: the stream without its epilogue-constant loads (results are wrong)
+        bb.cs[j] = tile;
+        bb.pb[j] = 0.5f;
+#else
         bb.cs[j] = __builtin_amdgcn_raw_buffer_load_b32(rc, eoff, tile * 64, 0);
         bb.pb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, eoff, tile * 64, 0));
+#endif
       }
     } else {
       constexpr int CPT = KS / CH;  // chunks per tile
@@ -137,11 +171,21 @@ struct StreamSrc {
 // keeps global loads in flight).
 template <int KS, int NB, int NT = 0, bool PADDED = false>
 __device__ __forceinline__ void stream_prologue(const PreparedWeight &w, int wave, int lane, Frags (&b)[NB]) {
-  const StreamSrc<KS, NT> src(w, lane);
+  constexpr bool PAIRED = KS == CH && (NT > 0 || (PADDED && NB % 2 == 0));  // epilogue constants fetched per two chunks
+  const StreamSrc<KS, NT, PAIRED> src(w, lane);
   if constexpr (NT > 0) {
     constexpr int NCH = KS <= CH ? (NT + CH / KS - 1) / (CH / KS) : NT * (KS / CH);
 #pragma unroll
-    for (int k = 0; k < NB && k < NCH; ++k) src.load(b[k], k, wave);
+    for (int k = 0; k < NB && k < NCH; ++k) {
+      if constexpr (PAIRED) {
+        if (k % 2 == 1 || k + 1 >= NCH)
+          src.template load_paired<true>(b[k], k, wave);
+        else
+          src.template load_paired<false>(b[k], k, wave);
+      } else {
+        src.load(b[k], k, wave);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);  // straight-line code: keep the scheduler from sinking
   } else if constexpr (PADDED) {        // the prefetches next to their uses
     // the chunks are requested in the same order before and inside the loop (the
@@ -149,7 +193,14 @@ __device__ __forceinline__ void stream_prologue(const PreparedWeight &w, int wav
     // orders of the two loop entries would no longer match)
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-      src.load(b[k], k, wave);
+      if constexpr (PAIRED) {
+        if (k % 2 == 1)
+          src.template load_paired<true>(b[k], k, wave);
+        else
+          src.template load_paired<false>(b[k], k, wave);
+      } else {
+        src.load(b[k], k, wave);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -162,7 +213,8 @@ __device__ __forceinline__ void stream_prologue(const PreparedWeight &w, int wav
 template <int KS, int NB, int NT = 0, bool PADDED = false, int RT = 1, class Epi>
 __device__ __forceinline__ void stream_gemm_from(const char *A, int lda, const PreparedWeight &w, int wave,
                                                  int lane, Frags (&b)[NB], Epi &&epi) {
-  const StreamSrc<KS, NT> src(w, lane);
+  constexpr bool PAIRED = KS == CH && (NT > 0 || (PADDED && NB % 2 == 0));
+  const StreamSrc<KS, NT, PAIRED> src(w, lane);
   const int n_tiles = src.n_tiles;
   const int lr = lane & 15, lg = lane >> 4;
   const int ntw = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;  // my tiles
@@ -176,7 +228,7 @@ __device__ __forceinline__ void stream_gemm_from(const char *A, int lda, const P
       for (int ks = 0; ks < KS; ++ks)
         af[rt][ks] = *reinterpret_cast<const v4i *>(A + (rt * 16 + lr) * lda + ks * 64 + lg * 16);
     const int nch = (ntw + TPC - 1) / TPC;
-    auto tile_mma = [&](const Frags &bb, int j, int tile) {
+    auto tile_mma_c = [&](const Frags &bb, int j, int tile, int cs, float pb) {
       v4i acc[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt] = v4i{0, 0, 0, 0};
@@ -186,8 +238,9 @@ __device__ __forceinline__ void stream_gemm_from(const char *A, int lda, const P
         for (int rt = 0; rt < RT; ++rt)
           acc[rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rt][ks], bb.f[j * KS + ks], acc[rt], 0, 0, 0);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) epi(tile, rt, acc[rt], bb.cs[j], bb.pb[j]);
+      for (int rt = 0; rt < RT; ++rt) epi(tile, rt, acc[rt], cs, pb);
     };
+    auto tile_mma = [&](const Frags &bb, int j, int tile) { tile_mma_c(bb, j, tile, bb.cs[j], bb.pb[j]); };
     auto compute = [&](const Frags &bb, int c) {
 #pragma unroll
       for (int j = 0; j < TPC; ++j) {
@@ -195,12 +248,26 @@ __device__ __forceinline__ void stream_gemm_from(const char *A, int lda, const P
         if (i < ntw) tile_mma(bb, j, wave + NW * i);
       }
     };
+    // PAIRED: a pair's constants live in the buffer of its odd chunk (StreamSrc::load_paired)
     if constexpr (NT > 0) {
       constexpr int NCH = (NT + TPC - 1) / TPC;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        compute(b[c % NB], c);
-        if (c + NB < NCH) load(b[c % NB], c + NB);
+        if constexpr (PAIRED) {
+          Frags &bb = b[c % NB];
+          const bool own = c % 2 == 1 || c + 1 >= NCH;  // this chunk's buffer holds the pair's constants
+          const Frags &hold = own ? bb : b[(c + 1) % NB];
+          tile_mma_c(bb, 0, wave + NW * c, hold.cs[c % 2], hold.pb[c % 2]);
+          if (c + NB < NCH) {
+            if ((c + NB) % 2 == 1 || c + NB + 1 >= NCH)
+              src.template load_paired<true>(bb, c + NB, wave);
+            else
+              src.template load_paired<false>(bb, c + NB, wave);
+          }
+        } else {
+          compute(b[c % NB], c);
+          if (c + NB < NCH) load(b[c % NB], c + NB);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     } else if constexpr (PADDED) {
@@ -209,8 +276,18 @@ __device__ __forceinline__ void stream_gemm_from(const char *A, int lda, const P
       for (int c = 0; c < nchp; c += NB) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-          tile_mma(b[k], 0, wave + NW * (c + k));
-          load(b[k], c + k + NB);
+          if constexpr (PAIRED) {
+            if (k % 2 == 0) {
+              tile_mma_c(b[k], 0, wave + NW * (c + k), b[k + 1].cs[0], b[k + 1].pb[0]);
+              src.template load_paired<false>(b[k], c + k + NB, wave);
+            } else {
+              tile_mma_c(b[k], 0, wave + NW * (c + k), b[k].cs[1], b[k].pb[1]);
+              src.template load_paired<true>(b[k], c + k + NB, wave);
+            }
+          } else {
+            tile_mma(b[k], 0, wave + NW * (c + k));
+            load(b[k], c + k + NB);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1613,6 +1690,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     Frags fl[NB_OUT];  // requested before the barrier that ends the last LayerNorm
     stream_prologue<KSD, NB_OUT, 0, (KSD >= 4)>(outw, wave, lane, fl);
     lds_barrier();
+    SLIMT_STAMP(43);
     float bv[RT][4];
     int bi[RT][4];
 #pragma unroll
@@ -1635,6 +1713,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             bi[rt][r] = better ? col : bi[rt][r];
           }
         });
+    SLIMT_STAMP(44);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -1645,6 +1724,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           red_i[wave * R + 16 * rt + lg * 4 + r] = bi[rt][r];
         }
       }
+    SLIMT_STAMP(45);
     lds_barrier();
     SLIMT_STAMP(41);
     // wave w finishes sentences w (+ 16): reduce over the 16 waves' candidates

@@ -311,6 +311,15 @@ __device__ __forceinline__ void pack_weight_tile(const PackArgs &a, int ntile, i
       }
       a.colsum[n] = s;
       a.pb[n] = pbv;
+      // the pair form (kernels.h, PreparedWeight::cp4); a tile without a partner zeroes the partner's half
+      int *quad = a.colsum + epi_pair_offset_ints(a.N) + ((size_t)(16 * (ntile >> 5) + (ntile & 15)) * 16 + r) * 4;
+      const int half = (ntile >> 4) & 1;
+      quad[2 * half] = s;
+      quad[2 * half + 1] = __float_as_int(pbv);
+      if (half == 0 && (ntile + 16) * 16 >= a.N) {
+        quad[2] = 0;
+        quad[3] = 0;
+      }
     }
   }
 }

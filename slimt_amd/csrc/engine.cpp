@@ -179,13 +179,14 @@ int prepare_affine_meta(AffineW &aw, const int8_t *dW, int K, int N, const uint3
                         const float *d_bias, float a_quant, float b_quant, PackArgs &job) {
   const int n_tiles = (N + 15) / 16;
   HIPCHK(aw.Wp.reserve(packed_weight_bytes(K, N)));
-  HIPCHK(aw.colsum.reserve((size_t)n_tiles * 16 * sizeof(int)));
+  HIPCHK(aw.colsum.reserve(colsum_alloc_bytes(N)));
   HIPCHK(aw.pb.reserve((size_t)n_tiles * 16 * sizeof(float)));
   job.W = dW; job.K = K; job.N = N; job.idx = d_idx; job.bias = d_bias;
   job.mult = pack_mult(a_quant, b_quant);
   job.Wp = aw.Wp.p; job.colsum = aw.colsum.as<int>(); job.pb = aw.pb.as<float>();
   aw.w.Wp = aw.Wp.p;
   aw.w.colsum = aw.colsum.as<int>();
+  aw.w.cp4 = aw.colsum.as<int>() + epi_pair_offset_ints(N);
   aw.w.pb = aw.pb.as<float>();
   aw.w.u = 1.0f / (a_quant * b_quant);  // Intgemm.inl.cc:146
   aw.w.a_quant = a_quant;
@@ -200,12 +201,13 @@ int prepare_affine(AffineW &aw, const int8_t *dW, int K, int N, const uint32_t *
                    const float *d_bias, float a_quant, float b_quant, hipStream_t st) {
   const int n_tiles = (N + 15) / 16;
   HIPCHK(aw.Wp.reserve(packed_weight_bytes(K, N)));
-  HIPCHK(aw.colsum.reserve((size_t)n_tiles * 16 * sizeof(int)));
+  HIPCHK(aw.colsum.reserve(colsum_alloc_bytes(N)));
   HIPCHK(aw.pb.reserve((size_t)n_tiles * 16 * sizeof(float)));
   HIPCHK(launch_pack_weight(dW, K, N, d_idx, d_bias, a_quant, b_quant, aw.Wp.p,
                             aw.colsum.as<int>(), aw.pb.as<float>(), st));
   aw.w.Wp = aw.Wp.p;
   aw.w.colsum = aw.colsum.as<int>();
+  aw.w.cp4 = aw.colsum.as<int>() + epi_pair_offset_ints(N);
   aw.w.pb = aw.pb.as<float>();
   aw.w.u = 1.0f / (a_quant * b_quant);  // Intgemm.inl.cc:146
   aw.w.a_quant = a_quant;

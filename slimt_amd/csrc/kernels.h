@@ -17,6 +17,12 @@ struct PreparedWeight {
   const void *Wp = nullptr;
   const int *colsum = nullptr;
   const float *pb = nullptr;
+  // The same epilogue constants once more, laid out for a wave that streams tiles t, t + 16, t + 32, ... (the
+  // persistent decoder): per PAIR of such tiles and column one 16-byte quad {colsum(t), pb(t), colsum(t + 16),
+  // pb(t + 16)}, pair (t, t + 16) at index 16 (t / 32) + t % 16 -- one load instruction per two tiles where colsum
+  // and pb cost two per tile (a 64-byte load occupies the CU's address path like a 1 KiB one: the output layer's
+  // stream ran 15 % faster without them). Lives behind the colsum array (epi_pair_offset_ints).
+  const int *cp4 = nullptr;
   float u = 0.f;
   float a_quant = 0.f;
   float b_quant = 0.f;
@@ -26,6 +32,10 @@ struct PreparedWeight {
 };
 
 size_t packed_weight_bytes(int K, int N);
+// the colsum allocation: [n_tiles * 16] column sums, then (256-byte aligned) the pair constants
+__host__ __device__ inline size_t epi_pair_offset_ints(int N) { return ((size_t)((N + 15) / 16) * 16 + 63) / 64 * 64; }
+__host__ __device__ inline size_t epi_pair_count(int N) { return (size_t)16 * (((N + 15) / 16 + 31) / 32); }
+inline size_t colsum_alloc_bytes(int N) { return (epi_pair_offset_ints(N) + epi_pair_count(N) * 64) * sizeof(int); }
 
 // Diagnostic occupancy trace (tools/occupancy_trace.py): when buf != nullptr,
 // thread 0 of every workgroup of the persistent kernels appends a begin and an

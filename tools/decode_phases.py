@@ -15,8 +15,8 @@ names = ["step_start"]
 for l in range(2):
     names += [f"L{l}.ssru_quant", f"L{l}.ssru_gemm", f"L{l}.ln_h", f"L{l}.q_gemm", f"L{l}.attention",
               f"L{l}.o_gemm", f"L{l}.ln_o", f"L{l}.ffn1", f"L{l}.ffn2", f"L{l}.ln_x"]
-idx = list(range(21)) + [41, 42]
-names += ["logits+argmax", "sample/record/embed"]
+idx = list(range(21)) + [43, 44, 45, 41, 42]
+names += ["  logits: barrier", "  logits: stream", "  logits: wave arg-max", "  logits: barrier", "sample/record/embed"]
 for step in (5, 20):
     ctx.debug_decode_stamps(step)
     ctx.translate(ids, lens, sl)
