@@ -41,10 +41,6 @@ __device__ __forceinline__ rsrc_t wrsrc(const void *p, unsigned bytes) {
 __device__ __forceinline__ v4i wload(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-__device__ __forceinline__ float wdequant(int acc, int colsum, float u, float pb) {
-  const float v = (float)(acc + __mul24(127, colsum)) * u;  // |colsum| <= 127 K < 2^23
-  return v + pb;
-}
 
 // Four columns at once, two per packed instruction (v_pk_mul_f32 / v_pk_add_f32: the same IEEE
 // operations as the scalar forms, multiply and add stay separate roundings).
