@@ -239,6 +239,29 @@ def test_translate_edge_shapes(hip, oracle, engines, preset, B, S, n_sl):
     ctx.close()
 
 
+@pytest.mark.parametrize("n_sl", [16, 24, 136, 264, 504, 520, 1000, 1032, 4104])
+def test_output_layer_tile_counts(hip, oracle, engines, n_sl):
+    """Shortlists whose tile counts are odd, not a multiple of the 16 waves or of the 32-tile period of the
+    paired epilogue constants (kernels.h, PreparedWeight::cp4): tiles without a partner, a last tile of 8
+    columns, fewer tiles than waves -- and one context that sees all of them in turn (the pair array of a
+    larger shortlist is reused by a smaller one). Persistent decoder with 16 and 32 sentences per workgroup."""
+    from slimt_amd import synth
+    m, gm, om = engines("tiny11", 6.0)
+    B, S = 5, 9
+    ids, lens = synth.make_batch(m.V, B, S, seed=n_sl, ragged=True)
+    ctx = hip.Context(gm, B, S)
+    for n in (4104, n_sl, 8):  # large first: its constants stay behind in the buffers
+        sl = synth.make_shortlist(m.V, n, frequent=min(100, n))
+        oracle.set_mode(oracle.PORTABLE)
+        w_out, w_ln, w_al, _ = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
+        oracle.set_mode(oracle.FAITHFUL)
+        for mode in (0, 3):
+            ctx.set_decode_mode(mode)
+            out, ln, al = ctx.translate(ids, lens, sl, want_align=True)
+            assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out) and np.array_equal(al, w_al), (n, mode)
+    ctx.close()
+
+
 def test_translate_everything_finishes_at_step_one(hip, oracle, engines):
     """EOS bias so large that every sentence emits EOS first: the persistent
     decoder leaves its loop early and the remaining output stays zero."""
