@@ -7,6 +7,9 @@ import threading
 
 import numpy as np
 import pytest
+import torch  # noqa: F401 -- at collection time, BEFORE libslimt_hip.so is loaded: PyTorch's wheel bundles its own HIP
+#               runtime, and a process gets the one that is loaded first (with the system's loaded first, torch finds
+#               "No HIP GPUs"; two tests below hand torch tensors to the device-resident entry points)
 
 pytestmark = pytest.mark.gpu
 
