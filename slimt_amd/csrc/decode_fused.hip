@@ -1737,6 +1737,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         int ix = lane < NW ? red_i[lane * R + row] : 0x7fffffff;
         row16_argmax(v, ix);
         ix = __builtin_amdgcn_readfirstlane(ix);
+        // no column beat the start value (every logit NaN or -inf): class 0, where the reference's scan
+        // starts and stays (Transformer.cc:287-298) -- and never an index past the shortlist
+        ix = ix == 0x7fffffff ? 0 : ix;
         if (live[rr]) tok = a.shortlist ? a.shortlist[ix] : (uint32_t)ix;
       }
       if (live[rr] && !finished[rr]) {  // record(), Model.cc:127-137

@@ -605,6 +605,7 @@ __global__ __launch_bounds__(64) void decode_begin_step_kernel(EmbedArgs e, Deco
         bi = part_idx[(size_t)b * n_parts + p];
       }
     }
+    if (bi == 0x7fffffff) bi = 0;  // every logit NaN or -inf: class 0 (Transformer.cc:287-298), never out of range
     const uint32_t tok = s.shortlist ? s.shortlist[bi] : (uint32_t)bi;
     s.prev[b] = tok;
     if (!s.finished[b]) {  // record(), Model.cc:127-137

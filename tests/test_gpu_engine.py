@@ -262,6 +262,32 @@ def test_output_layer_tile_counts(hip, oracle, engines, n_sl):
     ctx.close()
 
 
+@pytest.mark.parametrize("poison", ["nan", "-inf"])
+def test_logits_without_a_maximum_sample_class_zero(hip, oracle, synth_models, poison):
+    """Every logit NaN (or -inf): nothing beats the arg-max's start value. The reference's scan starts at class 0
+    and stays there (Transformer.cc:287-298); the kernels must do the same -- and must not index the shortlist or
+    the embedding with their "no column yet" marker. All decoder variants."""
+    import copy
+    from slimt_amd import synth
+    m = copy.deepcopy(synth_models("tiny11", 6.0))
+    bias = m.params["decoder_ff_logit_out_b"]
+    bias.data[...] = np.float32(np.nan) if poison == "nan" else np.float32(-np.inf)
+    gm, om = hip.Model(m), oracle.OracleModel(m)
+    B, S = 19, 11
+    ids, lens = synth.make_batch(m.V, B, S, seed=4, ragged=True)
+    for sl in (synth.make_shortlist(m.V, 1024), None):
+        oracle.set_mode(oracle.PORTABLE)
+        w_out, w_ln, _, _ = om.translate(ids, lens, sl, 1.5, 0)
+        oracle.set_mode(oracle.FAITHFUL)
+        ctx = hip.Context(gm, B, S)
+        for mode in (0, 1, 3):
+            ctx.set_decode_mode(mode)
+            out, ln, _ = ctx.translate(ids, lens, sl)
+            assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out), (poison, mode, sl is None)
+        ctx.close()
+    gm.close()
+
+
 def test_translate_everything_finishes_at_step_one(hip, oracle, engines):
     """EOS bias so large that every sentence emits EOS first: the persistent
     decoder leaves its loop early and the remaining output stays zero."""
