@@ -25,12 +25,29 @@
 extern "C" {
 #endif
 
-#define SLIMT_HIP_ABI_VERSION 2
+#define SLIMT_HIP_ABI_VERSION 3
 
 /* ---- status -------------------------------------------------------------- */
 int slimt_hip_abi_version(void);
 const char *slimt_hip_last_error(void); /* thread-local, never NULL */
 int slimt_hip_device_count(int *count);
+
+/* ---- process-wide setup (optional) ---------------------------------------
+ * The library itself never reads or writes the environment when it is loaded.
+ * One HIP stream per translate worker: the HIP runtime multiplexes streams onto
+ * FOUR hardware queues unless GPU_MAX_HW_QUEUES says otherwise, which caps the
+ * batches really in flight (20 blocking workers: 10.4 M tok/s with 4 queues,
+ * 26.5 M with 32). The runtime reads that variable once, at ITS first call from
+ * anywhere in the process. _request_hw_queues(n) sets it (only if the process
+ * has not chosen a value) and returns 0, or returns 1 -- changing nothing -- when
+ * this library has already called into HIP (too late). It calls setenv: call it
+ * from main() before threads start and before any model is created, or set the
+ * variable in the launcher instead (bench.py, slimt_amd.frontend and host_test
+ * do one of the two; host/Service warns once when it is started with more than
+ * two workers per device and fewer than 8 queues). _hw_queues() returns the
+ * value the environment holds now (0 = unset). */
+int slimt_hip_request_hw_queues(int n);
+int slimt_hip_hw_queues(void);
 
 /* ---- op level: slimt::qmm::* (slimt/QMM.hh:48-63) ------------------------ */
 /* Host pointers in, host pointers out (H2D, kernels, D2H on `device` 0
@@ -117,6 +134,13 @@ typedef struct slimt_hip_dims { /* Model::Config (Model.hh:33-51) */
 int slimt_hip_model_create(const slimt_hip_param *params, size_t n_params,
                            const slimt_hip_dims *dims, int device,
                            slimt_hip_model **out);
+/* The same from the Marian .bin container itself (the `View model` that
+ * Transformer::Transformer receives, Transformer.cc:87-94; format Io.cc:114-161):
+ * the items are located inside `bin` (bounds-checked, nothing is copied on the
+ * host) and handed to slimt_hip_model_create. */
+int slimt_hip_model_create_from_bin(const void *bin, size_t size,
+                                    const slimt_hip_dims *dims, int device,
+                                    slimt_hip_model **out);
 int slimt_hip_model_destroy(slimt_hip_model *model);
 /* Admission of the persistent decoders of all contexts of `model`: at most
  * about `workgroups` decoder workgroups (one CU each, 16 sentences) run at a

@@ -21,6 +21,7 @@ SYMBOLS = [
     "slimt_hip_affine_acc_i32", "slimt_hip_prepare_weight_transposed",
     "slimt_hip_prepare_weight_quantized_transposed", "slimt_hip_layer_norm",
     "slimt_hip_softmax", "slimt_hip_highway", "slimt_hip_sdpa",
+    "slimt_hip_request_hw_queues", "slimt_hip_hw_queues", "slimt_hip_model_create_from_bin",
     "slimt_hip_model_create", "slimt_hip_model_destroy", "slimt_hip_model_info",
     "slimt_hip_ctx_create", "slimt_hip_ctx_create_budget", "slimt_hip_ctx_destroy", "slimt_hip_ctx_stream",
     "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_ctx_set_encode_rows", "slimt_hip_ctx_plan", "slimt_hip_translate", "slimt_hip_translate_device",
@@ -64,6 +65,31 @@ def library_path() -> str:
     return _build.LIB_PATH
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process, whatever the import order. libslimt_hip.so NEEDs `libamdhip64.so.7` by
+    SONAME: the dynamic loader binds that to a copy the process has mapped already (PyTorch imported first: its
+    bundled one), else to ROCm's through the RUNPATH. PyTorch's own libraries ask for theirs by FILE, so with
+    ROCm's copy mapped first a later `import torch` maps a second runtime next to it (and finds no GPU). When no
+    runtime is mapped yet and an installed PyTorch bundles one, map that one now: a later `import torch` then
+    finds its own file already loaded, and both sides share it. Nothing is imported, no HIP call is made."""
+    try:
+        with open("/proc/self/maps") as f:
+            if any("libamdhip64" in line for line in f):
+                return
+    except OSError:
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for d in (spec.submodule_search_locations or []) if spec else []:
+        cand = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return
+
+
 def lib():
     """Load libslimt_hip.so (must have been built: __graft_entry__.build())."""
     global _lib
@@ -74,6 +100,7 @@ def lib():
         raise SlimtHipError(
             f"{path} is missing: build it with `python -m slimt_amd.build` "
             "(there is no CPU fallback)")
+    _preload_hip_runtime()
     L = C.CDLL(path)
     vp, f32, sz, i32, u32 = C.c_void_p, C.c_float, C.c_size_t, C.c_int, C.c_uint32
     L.slimt_hip_abi_version.restype = i32
@@ -90,6 +117,9 @@ def lib():
     L.slimt_hip_highway.argtypes = [vp, vp, vp, sz, vp]
     L.slimt_hip_sdpa.argtypes = [vp, vp, vp, vp, sz, sz, sz, sz, sz, vp, vp]
     L.slimt_hip_model_create.argtypes = [vp, sz, vp, i32, vp]
+    L.slimt_hip_model_create_from_bin.argtypes = [vp, sz, vp, i32, vp]
+    L.slimt_hip_request_hw_queues.argtypes = [i32]
+    L.slimt_hip_hw_queues.restype = i32
     L.slimt_hip_model_destroy.argtypes = [vp]
     L.slimt_hip_model_info.argtypes = [vp, vp, vp, vp, vp]
     L.slimt_hip_ctx_create.argtypes = [vp, sz, sz, vp, vp]
@@ -134,6 +164,16 @@ def lib():
             fn.restype = C.c_int
     _lib = L
     return L
+
+
+def request_hw_queues(n: int = 32) -> bool:
+    """slimt_hip_request_hw_queues: ask the HIP runtime for `n` hardware queues (GPU_MAX_HW_QUEUES, unless the
+    process has set it) -- one per concurrent translate worker's stream; the default of four makes 20 workers
+    take turns. Only before the library's first HIP call: returns False when it came too late."""
+    rc = lib().slimt_hip_request_hw_queues(int(n))
+    if rc < 0:
+        raise SlimtHipError(lib().slimt_hip_last_error().decode())
+    return rc == 0
 
 
 def _chk(rc: int) -> None:
@@ -268,6 +308,23 @@ class Model:
         self.device = device
         self.D, self.F, self.H, self.V = model.D, model.F, model.H, model.V
         self.Le, self.Ld = model.enc_layers, model.dec_layers
+
+    @classmethod
+    def from_bin(cls, blob: bytes, enc_layers: int, dec_layers: int, heads: int, device: int = 0) -> "Model":
+        """slimt_hip_model_create_from_bin: the Marian .bin container as Transformer::Transformer receives it
+        (Transformer.cc:87-94); the library locates the items itself."""
+        self = cls.__new__(cls)
+        buf = bytes(blob)
+        dims = _Dims(enc_layers, dec_layers, heads)
+        h = C.c_void_p()
+        _chk(lib().slimt_hip_model_create_from_bin(buf, len(buf), C.byref(dims), device, C.byref(h)))
+        self.h = h
+        self.device = device
+        d, f, v, hh = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _chk(lib().slimt_hip_model_info(h, C.byref(d), C.byref(f), C.byref(v), C.byref(hh)))
+        self.D, self.F, self.V, self.H = d.value, f.value, v.value, hh.value
+        self.Le, self.Ld = enc_layers, dec_layers
+        return self
 
     def set_kv_cache_policy(self, policy: int):
         """0 = per launch (default), 1 = temporal, 2 = non-temporal K/V cache loads in the decoder."""

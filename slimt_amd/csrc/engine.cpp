@@ -28,6 +28,11 @@ static int fail(int code, const char *fmt, ...) {
   return code ? code : -1;
 }
 
+// Set on this library's first call into the HIP runtime (every path to the device goes through one of
+// DevBuf::reserve, slimt_hip_device_count, slimt_hip_set_device, slimt_hip_host_alloc): the runtime reads
+// GPU_MAX_HW_QUEUES once, when it initialises, so slimt_hip_request_hw_queues is of no use afterwards.
+static std::atomic<bool> g_hip_called{false};
+
 #define HIPCHK(expr)                                                                    \
   do {                                                                                  \
     hipError_t e_ = (expr);                                                             \
@@ -43,6 +48,7 @@ static int fail(int code, const char *fmt, ...) {
 
 hipError_t DevBuf::reserve(size_t n) {
   if (n <= bytes && p) return hipSuccess;
+  g_hip_called.store(true, std::memory_order_relaxed);
   if (p) {
     hipError_t e = hipFree(p);
     if (e != hipSuccess) return e;
@@ -89,11 +95,20 @@ void timing_report() {
 }
 }  // namespace
 
-// One HIP stream per translate worker; the runtime multiplexes streams onto FOUR hardware queues
-// unless GPU_MAX_HW_QUEUES says otherwise, which caps the batches really in flight (20 blocking
-// workers: 10.4 M tok/s with the default, 26.5 M with 32). Read when the runtime initialises: set
-// here, when the library is loaded, unless the process has chosen a value itself.
-__attribute__((constructor)) static void slimt_hip_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "32", 0); }
+// Nothing here runs when the library is loaded, and nothing but this function writes the environment.
+extern "C" int slimt_hip_request_hw_queues(int n) {
+  if (n < 1 || n > 1024) return fail(-1, "hardware queues %d not in 1..1024", n);
+  if (g_hip_called.load(std::memory_order_relaxed)) return 1;
+  char value[16];
+  snprintf(value, sizeof value, "%d", n);
+  if (setenv("GPU_MAX_HW_QUEUES", value, /*overwrite=*/0)) return fail(-1, "setenv failed");
+  return 0;
+}
+
+extern "C" int slimt_hip_hw_queues(void) {
+  const char *v = getenv("GPU_MAX_HW_QUEUES");
+  return v ? atoi(v) : 0;
+}
 
 namespace slimt_hip {
 hipError_t set_dynamic_lds_once(const void *kernel, int bytes) {
@@ -117,6 +132,7 @@ extern "C" const char *slimt_hip_last_error(void) { return g_err; }
 extern "C" int slimt_hip_device_count(int *count) {
   if (!count) return fail(-1, "count is NULL");
   int n = 0;
+  g_hip_called.store(true, std::memory_order_relaxed);
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) {
     *count = 0;
@@ -127,6 +143,7 @@ extern "C" int slimt_hip_device_count(int *count) {
 }
 
 extern "C" int slimt_hip_set_device(int device) {
+  g_hip_called.store(true, std::memory_order_relaxed);
   HIPCHK(hipSetDevice(device));
   return 0;
 }
@@ -595,6 +612,78 @@ extern "C" int slimt_hip_model_create(const slimt_hip_param *params, size_t n_pa
   }
   *out = m;
   return 0;
+}
+
+// The Marian .bin container (slimt/Io.cc:114-161): version, item count, headers, names, shapes,
+// padding to a 256-byte boundary, payloads. Only views are taken; every read is bounds-checked.
+extern "C" int slimt_hip_model_create_from_bin(const void *bin, size_t size, const slimt_hip_dims *dims,
+                                               int device, slimt_hip_model **out) {
+  if (!bin || !dims || !out) return fail(-1, "null argument");
+  *out = nullptr;
+  const char *p = static_cast<const char *>(bin), *const end = p + size;
+  auto take = [&](size_t n) -> const char * {
+    if ((size_t)(end - p) < n) return nullptr;
+    const char *q = p;
+    p += n;
+    return q;
+  };
+  auto u64 = [&](uint64_t *v) -> bool {
+    const char *q = take(8);
+    if (q) memcpy(v, q, 8);
+    return q != nullptr;
+  };
+  uint64_t version = 0, n = 0;
+  if (!u64(&version) || !u64(&n)) return fail(-1, "truncated Marian .bin");
+  if (version != 1) return fail(-1, "Marian .bin version %llu != 1", (unsigned long long)version);
+  if (n > (1u << 20)) return fail(-1, "implausible item count %llu", (unsigned long long)n);
+  struct Header { uint64_t name_length, type, shape_length, data_length; };  // slimt/Io.hh:24-29
+  std::vector<Header> headers((size_t)n);
+  for (Header &h : headers) {
+    const char *q = take(sizeof(Header));
+    if (!q) return fail(-1, "truncated Marian .bin");
+    memcpy(&h, q, sizeof(Header));
+  }
+  std::vector<std::string> names((size_t)n);
+  for (size_t i = 0; i < n; ++i) {
+    const char *q = take(headers[i].name_length);
+    if (!q) return fail(-1, "truncated Marian .bin");
+    names[i].assign(q, headers[i].name_length ? headers[i].name_length - 1 : 0);
+  }
+  std::vector<slimt_hip_param> params;
+  params.reserve((size_t)n);
+  std::vector<size_t> which;
+  for (size_t i = 0; i < n; ++i) {
+    if (headers[i].shape_length > 8) return fail(-1, "item %s: %llu dimensions", names[i].c_str(), (unsigned long long)headers[i].shape_length);
+    int32_t rows = 1, cols = 1;
+    for (uint64_t d = 0; d < headers[i].shape_length; ++d) {
+      const char *q = take(4);
+      if (!q) return fail(-1, "truncated Marian .bin");
+      int32_t v;
+      memcpy(&v, q, 4);
+      if (d + 2 == headers[i].shape_length) rows = v;
+      if (d + 1 == headers[i].shape_length) cols = v;
+    }
+    const int type = headers[i].type == 0x0404 ? 0 : headers[i].type == 0x4101 ? 1 : -1;  // f32 / intgemm8 (Io.cc:37-84)
+    if (type < 0) continue;  // e.g. special:model.yml
+    slimt_hip_param q;
+    q.name = names[i].c_str();
+    q.type = type;
+    q.rows = rows;
+    q.cols = cols;
+    q.data = nullptr;
+    q.bytes = headers[i].data_length;
+    params.push_back(q);
+    which.push_back(i);
+  }
+  uint64_t pad = 0;
+  if (!u64(&pad) || !take(pad)) return fail(-1, "truncated Marian .bin");  // Io.cc:151-153
+  size_t k = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const char *q = take(headers[i].data_length);
+    if (!q) return fail(-1, "truncated Marian .bin (payload of %s)", names[i].c_str());
+    if (k < which.size() && which[k] == i) params[k++].data = q;
+  }
+  return slimt_hip_model_create(params.data(), params.size(), dims, device, out);  // checks shapes against bytes
 }
 
 extern "C" int slimt_hip_model_destroy(slimt_hip_model *model) {
@@ -1757,6 +1846,7 @@ extern "C" int slimt_hip_translate_async(slimt_hip_ctx *ctx, const uint32_t *src
 extern "C" int slimt_hip_host_alloc(size_t bytes, void **out) {
   if (!out) return fail(-1, "null argument");
   *out = nullptr;
+  g_hip_called.store(true, std::memory_order_relaxed);
   HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
   return 0;
 }

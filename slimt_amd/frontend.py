@@ -107,14 +107,16 @@ class Model:
             raise ValueError("vocabulary has %d pieces, the model's embedding %d rows"
                              % (self.vocabulary.size(), host.V))
         self.device = device
+        capi.request_hw_queues(32)  # a Service runs `workers` x 2 streams on this device (no-op once HIP is up)
         self.engine = capi.Model(host, device)
         self.dims = (host.D, host.F, host.V)
         self.shortlist_generator = None
         self.shortlist_blob = b""
         if package.shortlist:  # Model::make_shortlist_generator, Model.cc:60-72
             self.shortlist_blob = _blob(package.shortlist)
+            # ShortlistGenerator(view, source, target): shared = false, check = false (Model.cc:73-80, Shortlist.hh:47-52)
             self.shortlist_generator = capi.ShortlistGenerator(self.shortlist_blob, host.V, host.V,
-                                                               shared=True, check=False, device=device)
+                                                               shared=False, check=False, device=device)
 
     def close(self) -> None:
         if self.shortlist_generator is not None:
@@ -226,7 +228,7 @@ class Service:
                                         limit_factor=self.limit_factor, workers_per_device=self.workers, pad_id=0,
                                         eos_id=model.vocabulary.eos_id(), alignments=True,
                                         lexical_shortlist=model.shortlist_blob, source_vocab=V, target_vocab=V,
-                                        shared_vocab=True, check=False)
+                                        shared_vocab=False, check=False)  # as Model.cc:73-80 constructs it
                 self._engines[model.id] = eng
         return eng
 

@@ -154,6 +154,17 @@ Service::Service(const ServiceConfig &config, std::vector<const Model *> replica
       generator_of[r] = generators_[g]->handle();
     }
   }
+  // One stream per context, two contexts per worker: with the HIP runtime's default of four hardware queues most of
+  // them would take turns (include/slimt_hip.h, slimt_hip_request_hw_queues). The models exist already, so it is too
+  // late to ask for more here; say so once.
+  if (config.warn_hw_queues && config.workers_per_device > 2 && slimt_hip_hw_queues() < 8) {
+    static std::atomic<bool> warned{false};
+    if (!warned.exchange(true))
+      std::fprintf(stderr,
+                   "slimt::Service: %zu workers per device but GPU_MAX_HW_QUEUES is %d: batches will queue behind each "
+                   "other; call slimt_hip_request_hw_queues(32) (or set the variable) before the first HIP call\n",
+                   config.workers_per_device, slimt_hip_hw_queues());
+  }
   live_workers_ = replicas.size() * config.workers_per_device;
   for (size_t r = 0; r < replicas.size(); ++r)
     for (size_t w = 0; w < config.workers_per_device; ++w)

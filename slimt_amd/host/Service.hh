@@ -93,6 +93,7 @@ struct ServiceConfig {
   float tgt_length_limit_factor = 1.5F;
   size_t workers_per_device = 10;  // x 2 contexts each: about 20 batches in flight per GPU
   uint32_t pad_id = 0;
+  bool warn_hw_queues = true;  // one line on stderr when started with > 2 workers per device and < 8 hardware queues
   bool alignments = true;
   bool flat_alignments = false;  // Hypothesis::alignment_flat instead of ::alignment (one block per sentence)
   // Output vocabulary of a batch, one policy for the service's lifetime:

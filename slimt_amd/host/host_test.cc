@@ -446,6 +446,7 @@ static int model_forward_main(int argc, char **argv) {
 }
 
 int main(int argc, char **argv) {
+  slimt_hip_request_hw_queues(32);  // before the first HIP call of the process (include/slimt_hip.h)
   if (argc >= 2 && std::string(argv[1]) == "--model-forward") return model_forward_main(argc, argv);
   if (argc >= 2 && (std::string(argv[1]) == "--batcher" || std::string(argv[1]) == "--async"))
     return batching_main(argc, argv);

@@ -27,7 +27,70 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(dll, n), f"{n} declared in slimt_hip.h but not exported"
     assert sorted(capi.SYMBOLS) == names
-    assert capi.lib().slimt_hip_abi_version() == 2
+    assert capi.lib().slimt_hip_abi_version() == 3
+
+
+_CHILD_ENV = r"""
+import ctypes, os, sys
+sys.path.insert(0, sys.argv[1])
+libc = ctypes.CDLL(None)
+libc.getenv.restype = ctypes.c_char_p
+libc.getenv.argtypes = [ctypes.c_char_p]
+assert libc.getenv(b"GPU_MAX_HW_QUEUES") is None
+from slimt_amd import capi
+L = capi.lib()
+# loading the library runs nothing that writes the environment (it used to setenv in a constructor)
+assert libc.getenv(b"GPU_MAX_HW_QUEUES") is None and "GPU_MAX_HW_QUEUES" not in os.environ
+assert L.slimt_hip_hw_queues() == 0
+assert L.slimt_hip_request_hw_queues(0) < 0 and b"not in 1..1024" in L.slimt_hip_last_error()
+assert capi.request_hw_queues(16) is True
+assert libc.getenv(b"GPU_MAX_HW_QUEUES") == b"16" and L.slimt_hip_hw_queues() == 16
+assert capi.request_hw_queues(32) is True and L.slimt_hip_hw_queues() == 16  # a value already chosen stays
+capi.device_count()                                                          # the library's first HIP call
+assert capi.request_hw_queues(32) is False                                   # too late: says so, changes nothing
+assert L.slimt_hip_hw_queues() == 16
+print("ok")
+"""
+
+_CHILD_ORDER = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+def runtimes():
+    return sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+from slimt_amd import capi
+if sys.argv[2] == "torch_first":
+    import torch
+    capi.lib()
+else:
+    capi.lib()
+    import torch
+r = runtimes()
+assert len(r) == 1, r
+print("ok", r[0])
+"""
+
+
+def _run_child(code, *args):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    return subprocess.run([sys.executable, "-c", code, ROOT, *args], capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_library_leaves_the_environment_alone():
+    """No load-time side effects: GPU_MAX_HW_QUEUES is written by slimt_hip_request_hw_queues only, only when
+    the process has not chosen a value, and not after the library's first HIP call."""
+    r = _run_child(_CHILD_ENV)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("order", ["torch_first", "ours_first"])
+def test_one_hip_runtime_in_either_import_order(order):
+    """PyTorch bundles a HIP runtime; the process must end up with exactly one mapped whichever of
+    `import torch` / loading libslimt_hip.so comes first (capi._preload_hip_runtime)."""
+    pytest.importorskip("torch")
+    r = _run_child(_CHILD_ORDER, order)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_service_library_exports_every_declared_symbol():
@@ -147,3 +210,23 @@ def test_loader_rejects_malformed_bins(tmp_path):
     struct.pack_into("<%di" % headers[i][2], bad, soff, *dims)
     r = run(bytes(bad))
     assert r.returncode == 1 and "non-positive" in r.stderr, r.stderr
+
+
+def test_model_create_from_bin_parses_before_it_needs_a_device():
+    """slimt_hip_model_create_from_bin (the `View model` of Transformer::Transformer, Transformer.cc:87-94):
+    a malformed container is refused by the parser; a good one gets as far as the device check."""
+    import struct
+    from slimt_amd import capi, synth
+    m = synth.make_model("micro", eos_bias=0.0)
+    good = synth.write_bin(m)
+    for blob, why in ((good[:40], "truncated"), (good[: len(good) // 2], "truncated"),
+                      (struct.pack("<Q", 2) + good[8:], "version"),
+                      (good[:8] + struct.pack("<Q", 1 << 30) + good[16:], "implausible")):
+        with pytest.raises(capi.SlimtHipError) as e:
+            capi.Model.from_bin(blob, m.enc_layers, m.dec_layers, m.H)
+        assert why in str(e.value), str(e.value)
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present: the good container loads (tests/test_gpu_engine.py covers it)")
+    with pytest.raises(capi.SlimtHipError) as e:
+        capi.Model.from_bin(good, m.enc_layers, m.dec_layers, m.H)
+    assert "no HIP device" in str(e.value) or "device" in str(e.value).lower()  # past the parser: the device check

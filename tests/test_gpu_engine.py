@@ -645,3 +645,28 @@ def test_model_create_checks_payload_sizes(hip, synth_models):
     m.params["encoder_l1_ffn_W1"] = Short()
     with pytest.raises(hip.SlimtHipError, match="bytes, its shape"):
         hip.Model(m)
+
+
+def test_model_from_bin_container_equals_model_from_params(hip, oracle, engines):
+    """slimt_hip_model_create_from_bin (what the Transformer::Transformer hook calls with its `View model`,
+    integration/): same tokens, lengths and alignment rows as the model built from the parameter list."""
+    from slimt_amd import synth
+    m, gm, om = engines("tiny11", 6.0)
+    gb = hip.Model.from_bin(synth.write_bin(m), m.enc_layers, m.dec_layers, m.H)
+    try:
+        assert (gb.D, gb.F, gb.V, gb.H) == (m.D, m.F, m.V, m.H)
+        ids, lens = synth.make_batch(m.V, 21, 17, ragged=True, seed=11)
+        sl = synth.make_shortlist(m.V, 1000)
+        got = []
+        for model in (gm, gb):
+            ctx = hip.Context(model, 21, 17)
+            got.append(ctx.translate(ids, lens, sl, want_align=True))
+            ctx.close()
+        for a, b in zip(got[0], got[1]):
+            assert np.array_equal(a, b)
+        oracle.set_mode(oracle.PORTABLE)
+        w_out, w_len, w_al, _ = om.translate(ids, lens, sl, want_align=True)
+        oracle.set_mode(oracle.FAITHFUL)
+        assert np.array_equal(got[1][0], w_out) and np.array_equal(got[1][1], w_len) and np.array_equal(got[1][2], w_al)
+    finally:
+        gb.close()

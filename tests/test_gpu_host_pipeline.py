@@ -7,9 +7,8 @@ import threading
 
 import numpy as np
 import pytest
-import torch  # noqa: F401 -- at collection time, BEFORE libslimt_hip.so is loaded: PyTorch's wheel bundles its own HIP
-#               runtime, and a process gets the one that is loaded first (with the system's loaded first, torch finds
-#               "No HIP GPUs"; two tests below hand torch tensors to the device-resident entry points)
+import torch  # noqa: F401 (two tests below hand torch tensors to the device-resident entry points; the import order
+#               no longer matters: test_torch_after_the_library_still_sees_the_gpu)
 
 pytestmark = pytest.mark.gpu
 
@@ -188,3 +187,40 @@ def test_xcd_affine_decoder_placement_keeps_results(hip, oracle, engines, xcds):
     assert not bad, bad
     with pytest.raises(RuntimeError):
         gm.set_xcd_affinity(3)
+
+
+_CHILD_LIBRARY_FIRST = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from slimt_amd import capi, synth
+assert capi.request_hw_queues(32)
+m = synth.make_model("micro", eos_bias=3.0)
+gm = capi.Model(m)                      # the library's first HIP calls: before torch is imported
+ctx = capi.Context(gm, 4, 6)
+ids, lens = synth.make_batch(m.V, 4, 6, ragged=True)
+out, ln, _ = ctx.translate(ids, lens, None)
+import torch                            # ... and PyTorch afterwards
+assert torch.cuda.is_available(), "torch finds no GPU after libslimt_hip.so was loaded first"
+x = torch.arange(8, device="cuda", dtype=torch.float32)
+assert float((x * 2).sum().item()) == 56.0
+out2, ln2, _ = ctx.translate(ids, lens, None)
+assert np.array_equal(out, out2) and np.array_equal(ln, ln2)
+mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+assert len(mapped) == 1, mapped
+ctx.close(); gm.close()
+print("ok", mapped[0])
+"""
+
+
+def test_torch_after_the_library_still_sees_the_gpu():
+    """One HIP runtime per process in EITHER import order (capi._preload_hip_runtime): a fresh process loads
+    libslimt_hip.so and translates first, imports torch afterwards, and both use the device."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run([sys.executable, "-c", _CHILD_LIBRARY_FIRST, root], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
