@@ -26,7 +26,6 @@ CPU port of the reference path, timed on this box's host cores, N=1 only).
 import argparse
 import json
 import os
-import re
 import socket
 import subprocess
 import sys
@@ -117,44 +116,56 @@ def algorithmic_macs_per_sentence(D, F, Le, Ld, S, T, N):
     return S * (Le * (4 * D * D + 2 * D * F) + Ld * 2 * D * D) + T * (Ld * (4 * D * D + 2 * D * F) + D * N)
 
 
+def evidence_manifest():
+    """profiles/CURRENT: the ONE evidence set this line cites, written by tools/round_evidence.sh after its
+    counter passes ({"tag": ..., "tiny11": {"FETCH_SIZE": file, "WRITE_SIZE": file, "sq_pmc": file}, "base": {...}},
+    file names relative to profiles/). No manifest, or a file it names missing: no counter figures (null) --
+    nothing is guessed from file names."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "CURRENT")))
+    except (OSError, ValueError):
+        return {}
+
+
+def _evidence(preset, key):
+    name = (evidence_manifest().get(preset) or {}).get(key)
+    if not name:
+        return None, None
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))), name
+    except (OSError, ValueError):
+        return None, None
+
+
 def pmc_traffic(kernel, preset="tiny11"):
-    """HBM-side bytes per launch of `kernel` from the newest committed PMC pass
-    (profiles/*_pmc_{FETCH,WRITE}_SIZE.json, written by tools/profile_round.sh:
-    separate rocprofv3 --pmc runs of this same workload; the `base` preset's passes carry
-    `_base_` in their names). FETCH_SIZE is doubled (gfx950 correction,
-    MI355X_MICROARCH.md, HBM section). None if absent."""
-    import glob
+    """HBM-side bytes per launch of `kernel` from the PMC passes profiles/CURRENT names
+    (tools/profile_round.sh: separate rocprofv3 --pmc runs of this same workload). FETCH_SIZE is doubled
+    (gfx950 correction, MI355X_MICROARCH.md, HBM section). None if absent."""
     out = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = [f for f in glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{c}.json"))
-                 if ("_base_" in os.path.basename(f)) == (preset == "base")]
-        files.sort(key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])  # r01_v9 < r01_v13
-        if not files:
+        rec, name = _evidence(preset, c)
+        if rec is None:
             return None, None
-        rec = json.load(open(files[-1]))
         rec = rec.get(kernel) or ((rec.get("encode_tall") or rec.get("encode_wide")) if kernel == "encode_fused" else None)
         if not rec:
             return None, None
-        out[c] = (rec["avg_KB_per_launch"] * 1024.0, os.path.basename(files[-1]))
+        out[c] = (rec["avg_KB_per_launch"] * 1024.0, name)
     return 2.0 * out["FETCH_SIZE"][0] + out["WRITE_SIZE"][0], [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]
 
 
 def sq_counters(kernel, preset="tiny11"):
-    """SQ / TCC counter digest of `kernel` from the newest committed full-occupancy pass
-    (profiles/*_sq_pmc.json, tools/pmc_sq.sh: separate rocprofv3 --pmc runs, one launch with every CU
-    holding a workgroup). None if absent."""
-    import glob
-    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*_sq_pmc.json"))
-             if ("_base_" in os.path.basename(f)) == (preset == "base")]
-    files.sort(key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
-    for f in reversed(files):
-        ks = json.load(open(f)).get("kernels", {})
-        rec = ks.get(kernel) or ((ks.get("encode_tall") or ks.get("encode_wide")) if kernel == "encode_fused" else None)
-        if rec:
-            keep = ("mfma_busy_frac", "valu_busy_frac", "wave_parked_frac", "wave_issue_stall_frac", "wave_issuing_frac",
-                    "l2_hit_frac", "lds_bank_conflict_frac")
-            return {k: rec[k] for k in keep if k in rec}, os.path.basename(f)
-    return None, None
+    """SQ / TCC counter digest of `kernel` from the full-occupancy pass profiles/CURRENT names
+    (tools/pmc_sq.sh: separate rocprofv3 --pmc runs, one launch with every CU holding a workgroup). None if absent."""
+    doc, name = _evidence(preset, "sq_pmc")
+    if doc is None:
+        return None, None
+    ks = doc.get("kernels", {})
+    rec = ks.get(kernel) or ((ks.get("encode_tall") or ks.get("encode_wide")) if kernel == "encode_fused" else None)
+    if not rec:
+        return None, None
+    keep = ("mfma_busy_frac", "valu_busy_frac", "wave_parked_frac", "wave_issue_stall_frac", "wave_issuing_frac",
+            "l2_hit_frac", "lds_bank_conflict_frac")
+    return {k: rec[k] for k in keep if k in rec}, name
 
 
 def cpu_model_string():
@@ -521,6 +532,10 @@ def main():
             "frac": achieved / PEAK_INT8_TOPS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_ops_per_launch": ops, "launches": prof["launches"], "avg_launch_us": 1e3 * avg_ms,
             "cus_per_launch": cus, "launches_in_flight": in_flight,
+            # `frac` prices ONE launch (16 CUs for a batch of 256) against the whole chip; the launches of this
+            # kernel that run at once, together, against the same peak:
+            "frac_chip": achieved * in_flight / PEAK_INT8_TOPS,
+            "evidence_tag": evidence_manifest().get("tag") if profiled else None,
             "frac_of_occupied_cus": achieved / (PEAK_INT8_TOPS * cus / 256.0),
             "counters_full_occupancy": sq_counters(prof_name, args.preset)[0] if profiled else None,
             "counters_source": sq_counters(prof_name, args.preset)[1] if profiled else None,

@@ -2,8 +2,8 @@
 # GPU box: everything DESIGN.md / profiles/ quote for a round, in one call.
 # usage: tools/round_evidence.sh <tag>     (writes gpurun_out/<tag>_*; copy what is quoted into profiles/)
 # Order matters: the PMC passes come first and their digests are copied into profiles/ (of this
-# box's copy of the repo) BEFORE the final bench.py run, so that the bench line's `traffic` and
-# `mfma_busy_frac` cite files of the same tag.
+# box's copy of the repo) and named in the manifest profiles/CURRENT BEFORE the final bench.py run, so that the
+# bench line's `traffic` and `mfma_busy_frac` cite files of the same tag (copy gpurun_out/CURRENT to profiles/ too).
 TAG=${1:-r03}
 mkdir -p gpurun_out
 NO_CPU=1 WITH_BASE=1 tools/profile_round.sh $TAG || exit 1
@@ -12,6 +12,16 @@ PRESET=base BATCH=2048 tools/pmc_sq.sh ${TAG}_base > gpurun_out/${TAG}_base_sq_r
 tail -3 gpurun_out/${TAG}_sq_run.log; tail -3 gpurun_out/${TAG}_base_sq_run.log
 cp gpurun_out/${TAG}_pmc_FETCH_SIZE.json gpurun_out/${TAG}_pmc_WRITE_SIZE.json gpurun_out/${TAG}_base_pmc_FETCH_SIZE.json \
    gpurun_out/${TAG}_base_pmc_WRITE_SIZE.json gpurun_out/${TAG}_sq_pmc.json gpurun_out/${TAG}_base_sq_pmc.json profiles/ || exit 1
+# the manifest bench.py reads: ONE evidence set, named (no "newest by file name")
+python - $TAG <<'PY' || exit 1
+import json, sys
+t = sys.argv[1]
+m = {"tag": t,
+     "tiny11": {"FETCH_SIZE": f"{t}_pmc_FETCH_SIZE.json", "WRITE_SIZE": f"{t}_pmc_WRITE_SIZE.json", "sq_pmc": f"{t}_sq_pmc.json"},
+     "base": {"FETCH_SIZE": f"{t}_base_pmc_FETCH_SIZE.json", "WRITE_SIZE": f"{t}_base_pmc_WRITE_SIZE.json", "sq_pmc": f"{t}_base_sq_pmc.json"}}
+for name in ("profiles/CURRENT", "gpurun_out/CURRENT"):
+    json.dump(m, open(name, "w"), indent=1)
+PY
 # the bench line of record for this tag (with cpu_baseline), citing the counters above
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || { echo "bench failed"; tail -5 gpurun_out/${TAG}_bench.err; exit 1; }
 python - gpurun_out/${TAG}_bench.json <<'PY'
