@@ -73,6 +73,9 @@ def parse(argv=None):
                     help="decoder K/V cache loads: 0 = chosen per launch (default), 1 = temporal, 2 = non-temporal")
     ap.add_argument("--xcd-affinity", type=int, default=-1,
                     help="home XCDs of a batch's decoder workgroups: -1 = library default, 0 = off, 1 / 2 / 4")
+    ap.add_argument("--adaptive-rows", type=int, default=-1,
+                    help="decoder sentences per workgroup by occupancy (8 or 4 while CUs would idle): -1 = library "
+                         "default (on), 0 = always 16, 1 = on")
     ap.add_argument("--sustained-steps", type=int, default=40,
                     help="after the timed region, one longer untimed-by-the-driver region of this many steps "
                          "(reported as `sustained`; 0 = skip)")
@@ -336,6 +339,8 @@ def main():
             gm.set_kv_cache_policy(args.kv_policy)
         if args.xcd_affinity >= 0:
             gm.set_xcd_affinity(args.xcd_affinity)
+        if args.adaptive_rows >= 0:
+            gm.set_adaptive_decoder_rows(bool(args.adaptive_rows))
         ctxs = [capi.Context(gm, B, S) for _ in range(W)]
         for c in ctxs:
             c.set_decode_mode(args.decode_mode)

@@ -169,6 +169,12 @@ int slimt_hip_model_set_xcd_affinity(slimt_hip_model *model, int xcds);
  * rebuilds float(acc) * unquant + bias in registers: identical floats, 25 % fewer bytes
  * re-read per step), f32 elsewhere; 1 = always f32. Results do not depend on it. */
 int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format);
+/* Sentences per workgroup of the persistent decoder in decode mode 0 (needs the decoder admission,
+ * budget > 0): on (default) = a launch uses 8 or 4 sentences per workgroup instead of 16 while the
+ * decoders of all contexts with one pending still fit the budget at that size -- a batch of 256 alone
+ * then runs on 64 CUs instead of 16 (the reference's default is ONE worker, slimt/Frontend.hh:25) --,
+ * off = always 16. Results do not depend on it. */
+int slimt_hip_model_set_adaptive_decoder_rows(slimt_hip_model *model, int on);
 int slimt_hip_model_info(const slimt_hip_model *model, int32_t *dim_emb,
                          int32_t *dim_ffn, int32_t *vocab, int32_t *heads);
 /* the device the model's weights live on (-1 for NULL) */
@@ -190,9 +196,11 @@ int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
 /* Execution strategy of slimt_hip_translate* / slimt_hip_encode: 0 = automatic
  * (persistent fused encoder / decoder kernels when the model shape supports
  * them), 1 = one launch per stage (and per decode step; the kernels behind
- * slimt_hip_decode_step), 2 / 3 = automatic, but the persistent decoder is
- * forced to 16 / 32 sentences per workgroup (tuning and tests; 0 picks 32 for
- * output layers of more than 16k columns). Same results in every mode. */
+ * slimt_hip_decode_step), 2 / 3 / 4 / 5 = automatic, but the persistent decoder
+ * is forced to 16 / 32 / 8 / 4 sentences per workgroup where it has that
+ * variant (tuning and tests; 0 picks 32 for output layers of more than 16k
+ * columns, and 8 or 4 while CUs would idle: slimt_hip_model_set_adaptive_decoder_rows).
+ * Same results in every mode. */
 int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode);
 /* Rows (source tokens) per workgroup of the persistent encoder for emb 256 models: 0
  * (default) = chosen per call (64-row tiles from 32 of them on),

@@ -31,7 +31,7 @@ SYMBOLS = [
     "slimt_hip_debug_occupancy_trace", "slimt_hip_model_set_decoder_budget",
     "slimt_hip_model_set_kv_cache_policy",
     "slimt_hip_model_set_xcd_affinity", "slimt_hip_model_device",
-    "slimt_hip_model_set_kv_cache_format",
+    "slimt_hip_model_set_kv_cache_format", "slimt_hip_model_set_adaptive_decoder_rows",
     "slimt_hip_shortlist_create", "slimt_hip_shortlist_destroy", "slimt_hip_shortlist_info",
     "slimt_hip_shortlist_generate", "slimt_hip_shortlist_generate_device",
     "slimt_hip_translate_device_generated", "slimt_hip_translate_generated", "slimt_hip_translate_async_generated",
@@ -149,6 +149,7 @@ def lib():
     L.slimt_hip_model_set_kv_cache_policy.argtypes = [vp, i32]
     L.slimt_hip_model_set_xcd_affinity.argtypes = [vp, i32]
     L.slimt_hip_model_set_kv_cache_format.argtypes = [vp, i32]
+    L.slimt_hip_model_set_adaptive_decoder_rows.argtypes = [vp, i32]
     L.slimt_hip_ctx_create_budget.argtypes = [vp, sz, sz, sz, vp, vp]
     L.slimt_hip_shortlist_create.argtypes = [vp, sz, sz, sz, i32, i32, i32, vp]
     L.slimt_hip_shortlist_destroy.argtypes = [vp]
@@ -337,6 +338,10 @@ class Model:
     def set_kv_cache_format(self, fmt: int):
         """0 = packed 24-bit K/V cache where supported (default), 1 = always f32."""
         _chk(lib().slimt_hip_model_set_kv_cache_format(self.h, fmt))
+
+    def set_adaptive_decoder_rows(self, on: bool):
+        """Decode mode 0: 8 or 4 sentences per decoder workgroup while CUs would idle (default on)."""
+        _chk(lib().slimt_hip_model_set_adaptive_decoder_rows(self.h, 1 if on else 0))
 
     def set_decoder_budget(self, workgroups: int):
         """Admission of persistent decoders: ~`workgroups` decoder workgroups at a time (0 = no limit)."""

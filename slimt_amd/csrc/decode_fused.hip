@@ -1290,8 +1290,15 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
 // MID: 1 = sentences of 33..64 tokens over the packed cache (D = 256; attention_row24_mid), 2 = of 65..128
 // tokens (attention_row24_long; the SSRU cells then live in global memory: their 32 KB of LDS hold the
 // [H][128] probabilities of every wave's sentence).
-template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0>
+// SPW: sentences per workgroup, 16 (a full MFMA row tile), 8 or 4 -- for launches that would leave most of the
+// chip idle (one batch of 256 at 16 sentences per workgroup runs on 16 of 256 CUs). The row tile stays 16 rows
+// (rows SPW.. are zero operands whose results nobody reads: the matrix pipe is 6 % busy), every wave still
+// streams its share of every weight, and only waves 0 .. SPW - 1 own a sentence in the row-wise phases
+// (LayerNorm, attention, sampling), which then have a SIMD to themselves or share it with one wave instead of
+// three. A sentence's arithmetic does not depend on which rows surround it, so results are identical.
+template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0, int SPW = 16>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
+  static_assert(SPW == 16 || ((SPW == 8 || SPW == 4) && RT == 1 && KV24), "fewer sentences per workgroup: the packed-cache, 16-row variants");
   static_assert(!KV24 || (((KSD == 4 && DH == 32) || (KSD == 8 && DH == 64)) && !LONG),
                 "the packed K/V cache: D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32 (64 / 128 with MID 1 / 2)");
   static_assert(!MID || (KV24 && KSD == 4 && RT == 1), "33..128-token sentences: the D = 256 packed cache, 16 rows");
@@ -1299,7 +1306,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr int KVC = KSD == 8 ? 4 : 2;  // constant vectors per layer in LDS (see attention_row24 / _64)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 64 * KSD, F = 64 * KSF;
-  constexpr int R = 16 * RT;    // rows (sentences) per workgroup
+  constexpr int R = 16 * RT;    // rows of the operand tiles per workgroup
+  constexpr int RS = SPW < 16 ? SPW : R;  // sentences per workgroup
   constexpr int LDF = D + 4;    // f32 row stride
   // int8 operand rows: + 32 bytes -- a fragment read (ds_read_b128: 16 rows x 16 B per hardware lane group)
   // then covers all 64 banks; with + 16, rows lr and lr + 1 of neighbouring lane groups shared banks
@@ -1316,6 +1324,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
+  const bool row_wave = SPW == 16 || wave < SPW;  // this wave owns a sentence in the row-wise phases
 
   // 16 rows x 512 ("base") or 32 rows x 256 do not fit the full layout in 160 KiB: the
   // pre-LN buffer then aliases hs (every pre-LN write reads at most the same element of hs,
@@ -1355,7 +1364,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       if (a.home_mask) {  // XCD-affine claim (kernels.h)
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
         const bool home = (a.home_mask >> (xcc & 31)) & 1u;
-        const unsigned tiles = (unsigned)((B + R - 1) / R);
+        const unsigned tiles = (unsigned)((B + RS - 1) / RS);
         unsigned long long seen = __hip_atomic_load(a.xstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int mine = 0x7fffffff;
         for (;;) {  // bounded: every failed exchange is another candidate's arrival (at most xgrid of them)
@@ -1378,9 +1387,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     }
     __syncthreads();
     tile = flags[1];
-    if ((unsigned)tile >= (unsigned)((B + R - 1) / R)) return;
+    if ((unsigned)tile >= (unsigned)((B + RS - 1) / RS)) return;
   }
-  const int m0 = tile * R;
+  const int m0 = tile * RS;
   if (tid == 0) occ_trace_event(a.trace, 1, 0);
 
   // per-sentence state of rows wave + 16 rr, owned by wave `wave` (uniform within the wave)
@@ -1390,12 +1399,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     bq[rr] = m0 + 16 * rr + wave;
-    live[rr] = bq[rr] < B;
+    live[rr] = row_wave && bq[rr] < B;
     len[rr] = live[rr] ? (int)a.lengths[bq[rr]] : 0;
     finished[rr] = !live[rr];
     n_out[rr] = 0;
   }
-  const int valid_rows = (B - m0) < R ? (B - m0) : R;
+  const int valid_rows = (B - m0) < RS ? (B - m0) : RS;
 
   // start_states, Transformer.cc:78-85
   if constexpr (CELLS_GLOBAL) {
@@ -1405,6 +1414,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     for (int i = tid; i < Ld * R * D; i += 1024) cs[i] = 0.0f;
   }
   if (tid == 0) flags[0] = 0;
+  if constexpr (SPW < 16) {  // operand rows no wave owns: defined (zero) for the whole loop
+    for (int i = tid; i < (2 * R * LDA + R * LDA3) / 4; i += 1024) reinterpret_cast<int *>(A1)[i] = 0;
+  }
   if (ln_lds) {
     for (int i = tid; i < Ld * 6 * D; i += 1024) {
       const FusedLayerW &Lw = a.L[i / (6 * D)];
@@ -1458,14 +1470,16 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       const int sb = 1 + 10 * l;
       // ---- SSRU (Modules.cc:190-235) ------------------------------------
       // quantise x twice (Wf / W have their own multipliers)
+      if (row_wave) {
 #pragma unroll
-      for (int rr = 0; rr < RT; ++rr) {
-        const int row = 16 * rr + wave;
+        for (int rr = 0; rr < RT; ++rr) {
+          const int row = 16 * rr + wave;
 #pragma unroll
-        for (int i = 0; i < KSD; ++i) {
-          const float v = xs[row * LDF + lane + 64 * i];
-          A1[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_f.a_quant);
-          A2[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
+          for (int i = 0; i < KSD; ++i) {
+            const float v = xs[row * LDF + lane + 64 * i];
+            A1[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_f.a_quant);
+            A2[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
+          }
         }
       }
       lds_barrier();
@@ -1525,13 +1539,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       // requested now: their round trip runs under the LayerNorm and the barrier)
       Frags fq[1];
       stream_prologue<KSD, 1, NT_D>(L.q, wave, lane, fq);
+      if (row_wave) {
 #pragma unroll
-      for (int rr = 0; rr < RT; ++rr) {
-        const int row = 16 * rr + wave;
-        if (ln_lds)
-          ln_row<KSD>(pre + row * LDF, lnc + (6 * l + 0) * D, lnc + (6 * l + 1) * D, a.eps, hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
-        else
-          ln_row<KSD>(pre + row * LDF, L.rnn_ln_s, L.rnn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
+        for (int rr = 0; rr < RT; ++rr) {
+          const int row = 16 * rr + wave;
+          if (ln_lds)
+            ln_row<KSD>(pre + row * LDF, lnc + (6 * l + 0) * D, lnc + (6 * l + 1) * D, a.eps, hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
+          else
+            ln_row<KSD>(pre + row * LDF, L.rnn_ln_s, L.rnn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA, L.q.a_quant, lane);
+        }
       }
       lds_barrier();
       SLIMT_STAMP(sb + 2);
@@ -1605,7 +1621,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             attention_row<D, DH, LONG, 2>(ar, lane);
           else
             attention_row<D, DH, LONG, 0>(ar, lane);
-        } else {
+        } else if (row_wave) {
 #pragma unroll
           for (int i = 0; i < KSD; ++i) A1[row * LDA + lane + 64 * i] = 0;
         }
@@ -1631,13 +1647,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       // then waits for no vector-memory load), else ahead of the barrier behind it
       Frags f1[NB_FFN];
       if constexpr (LN_LDS) stream_prologue<KSD, NB_FFN, NT_F1>(L.ffn1, wave, lane, f1);
+      if (row_wave) {
 #pragma unroll
-      for (int rr = 0; rr < RT; ++rr) {
-        const int row = 16 * rr + wave;
-        if (ln_lds)
-          ln_row<KSD>(pre + row * LDF, lnc + (6 * l + 2) * D, lnc + (6 * l + 3) * D, a.eps, hs + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
-        else
-          ln_row<KSD>(pre + row * LDF, L.attn_ln_s, L.attn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
+        for (int rr = 0; rr < RT; ++rr) {
+          const int row = 16 * rr + wave;
+          if (ln_lds)
+            ln_row<KSD>(pre + row * LDF, lnc + (6 * l + 2) * D, lnc + (6 * l + 3) * D, a.eps, hs + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
+          else
+            ln_row<KSD>(pre + row * LDF, L.attn_ln_s, L.attn_ln_b, a.eps, hs + row * LDF, A1 + row * LDA, L.ffn1.a_quant, lane);
+        }
       }
       if constexpr (!LN_LDS) stream_prologue<KSD, NB_FFN, NT_F1>(L.ffn1, wave, lane, f1);
       lds_barrier();
@@ -1670,15 +1688,17 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       lds_barrier();
       SLIMT_STAMP(sb + 8);
       // next layer's input; after the last layer: quantised for the logits
+      if (row_wave) {
 #pragma unroll
-      for (int rr = 0; rr < RT; ++rr) {
-        const int row = 16 * rr + wave;
-        if (ln_lds)
-          ln_row<KSD>(pre + row * LDF, lnc + (6 * l + 4) * D, lnc + (6 * l + 5) * D, a.eps, xs + row * LDF,
-                      (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
-        else
-          ln_row<KSD>(pre + row * LDF, L.ffn_ln_s, L.ffn_ln_b, a.eps, xs + row * LDF,
-                      (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
+        for (int rr = 0; rr < RT; ++rr) {
+          const int row = 16 * rr + wave;
+          if (ln_lds)
+            ln_row<KSD>(pre + row * LDF, lnc + (6 * l + 4) * D, lnc + (6 * l + 5) * D, a.eps, xs + row * LDF,
+                        (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
+          else
+            ln_row<KSD>(pre + row * LDF, L.ffn_ln_s, L.ffn_ln_b, a.eps, xs + row * LDF,
+                        (l + 1 == Ld) ? A1 + row * LDA : nullptr, a.out.a_quant, lane);
+        }
       }
       // Between layers no barrier: the next phase (the SSRU's quantisation) reads and writes
       // only this wave's own rows; the barrier after it covers both. (After the last layer: below.)
@@ -1730,6 +1750,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     // wave w finishes sentences w (+ 16): reduce over the 16 waves' candidates
 #pragma unroll
     for (int rr = 0; rr < RT; ++rr) {
+      if (!row_wave) break;
       const int row = 16 * rr + wave;
       uint32_t tok = 0;
       {
@@ -1806,20 +1827,25 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   if (tid == 0) occ_trace_event(a.trace, 1, 1);
 }
 
-// rows per workgroup the fused decoder uses: 32 (two row tiles) on request (decode mode 3, or the
+// sentences per workgroup the fused decoder uses: 32 (two row tiles) on request (decode mode 3, or the
 // engine's choice for output layers of more than 16k columns) and only for the D = 256 shapes with
-// short sentences
-int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced) {
+// short sentences; 8 or 4 (decode_fused_kernel, SPW) on request where the packed K/V cache variants exist
+// (the engine asks for them when a launch at 16 would leave most CUs idle); else 16.
+int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced, bool kv24) {
   (void)B;
   const bool ok32 = D == 256 && F == 1536 && D / H == 32 && Ld <= 4 && S <= 32;
-  return (forced == 32 && ok32) ? 32 : 16;
+  if (forced == 32 && ok32) return 32;
+  const bool small = kv24 && Ld <= 4 &&
+                     ((D == 256 && F == 1536 && D / H == 32 && S <= 128) || (D == 512 && F == 2048 && D / H == 64 && S <= 32));
+  if ((forced == 8 || forced == 4) && small) return forced;
+  return 16;
 }
 
-// workgroups launched for B sentences: with tickets 2 x the tiles (16 rows) / 4 x (32 rows),
+// workgroups launched for B sentences: with tickets 2 x the tiles (up to 16 sentences each) / 4 x (32),
 // i.e. one candidate per shader engine of every XCD for a batch of 256
 int fused_decode_grid(int B, bool tickets, int rows) {
   const int tiles = (B + rows - 1) / rows;
-  return tickets ? tiles * (rows == 16 ? 2 : 4) : tiles;
+  return tickets ? tiles * (rows <= 16 ? 2 : 4) : tiles;
 }
 
 // ln_in_lds (out, nullable): whether the LayerNorm constants of all layers (LN_LDS in the kernel: the
@@ -1877,46 +1903,44 @@ static auto decode_fused_pick(bool long_sentences, bool nt) -> void (*)(FusedDec
 hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H, hipStream_t st) {
   FusedDecodeArgs a = a_in;
   if (!fused_decode_supported(D, F, H, a.Ld)) return hipErrorInvalidValue;
-  const int rows = fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg);
-  const dim3 grid(a.home_mask ? (int)a.xgrid : fused_decode_grid(a.B, a.ticket != nullptr, rows));
   const bool kv24 = a.kv24;
+  const int rows = fused_decode_rows(D, F, H, a.Ld, a.S, a.B, a.rows_per_wg, kv24);
+  const dim3 grid(a.home_mask ? (int)a.xgrid : fused_decode_grid(a.B, a.ticket != nullptr, rows));
   const int mid = (kv24 && D == 256 && a.S > 32) ? (a.S > 64 ? 2 : 1) : 0;  // 33..64 / 65..128-token sentences
   if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= (D == 256 ? 128 : 32))) return hipErrorInvalidValue;
+  if (a.home_mask && rows != 16) return hipErrorInvalidValue;  // the XCD-affine claim counts 16-sentence tiles
+  auto go = [&](void (*k)(FusedDecodeArgs), size_t lds) -> hipError_t {
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
+    return hipGetLastError();
+  };
+  // the variants over the packed cache: <KSD, KSF, DH, MID> x non-temporal K/V loads x sentences per workgroup
+#define SLIMT_KV24_PICK(KSD_, KSF_, DH_, MID_)                                                                  \
+  (rows == 4   ? (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_, 4>                 \
+                          : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_, 4>)               \
+   : rows == 8 ? (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_, 8>                 \
+                          : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_, 8>)               \
+               : (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_>                    \
+                          : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_>))
   if (mid) {
-    if (rows != 16 || F != 1536) return hipErrorInvalidValue;
+    if (rows > 16 || F != 1536) return hipErrorInvalidValue;
     const size_t ldsm = fused_decode_lds_bytes(D, F, a.Ld, 16, true, mid);
     if (ldsm > 160 * 1024) return hipErrorInvalidValue;
-    auto k = mid == 2 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 1, true, 2>)
-                      : (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 1> : decode_fused_kernel<4, 24, 32, false, false, 1, true, 1>);
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)ldsm);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, dim3(1024), ldsm, st, a);
-    return hipGetLastError();
+    return go(mid == 2 ? SLIMT_KV24_PICK(4, 24, 32, 2) : SLIMT_KV24_PICK(4, 24, 32, 1), ldsm);
   }
-  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows, kv24, 0, &a.ln_in_lds);
+  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows <= 16 ? 16 : rows, kv24, 0, &a.ln_in_lds);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (kv24 && D == 512) {
     if (F != 2048) return hipErrorInvalidValue;
-    auto k = a.kv_nt ? decode_fused_kernel<8, 32, 64, false, true, 1, true> : decode_fused_kernel<8, 32, 64, false, false, 1, true>;
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
-    return hipGetLastError();
+    return go(SLIMT_KV24_PICK(8, 32, 64, 0), lds);
   }
-  if (kv24 && rows == 16) {
-    auto k = a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true> : decode_fused_kernel<4, 24, 32, false, false, 1, true>;
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
-    return hipGetLastError();
-  }
+  if (kv24 && rows <= 16) return go(SLIMT_KV24_PICK(4, 24, 32, 0), lds);
+#undef SLIMT_KV24_PICK
   if (rows == 32) {
     auto k = kv24 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true> : decode_fused_kernel<4, 24, 32, false, false, 2, true>)
                   : (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 2>);
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);
-    return hipGetLastError();
+    return go(k, lds);
   }
 #define SLIMT_FUSED_CASE(KSD_, KSF_, DH_)                                                   \
   if (D == 64 * KSD_ && F == 64 * KSF_ && D / H == DH_) {                                    \

@@ -719,6 +719,13 @@ extern "C" int slimt_hip_model_set_xcd_affinity(slimt_hip_model *model, int xcds
   return 0;
 }
 
+extern "C" int slimt_hip_model_set_adaptive_decoder_rows(slimt_hip_model *model, int on) {
+  if (!model) return fail(-1, "model is NULL");
+  std::lock_guard<std::mutex> lock(model->gate_mu);
+  model->adaptive_rows = on != 0;
+  return 0;
+}
+
 extern "C" int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format) {
   if (!model) return fail(-1, "model is NULL");
   if (format < 0 || format > 1) return fail(-1, "K/V cache format %d not in 0..1", format);
@@ -913,7 +920,7 @@ extern "C" int slimt_hip_ctx_stream(slimt_hip_ctx *ctx, void **stream) {
 
 extern "C" int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode) {
   if (!ctx) return fail(-1, "ctx is NULL");
-  if (mode < 0 || mode > 3) return fail(-1, "bad decode mode %d", mode);
+  if (mode < 0 || mode > 5) return fail(-1, "bad decode mode %d", mode);
   ctx->decode_mode = mode;
   return 0;
 }
@@ -1488,8 +1495,11 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     // halving it per sentence beats the longer attention chain (B = 512, full vocabulary: 20.4 -> 23-24 M
     // tok/s; at 16k columns the two are level, below that 16 rows win)
     const size_t n_expected = d_n_sl && n_sl_hint ? n_sl_hint : (size_t)out.w.N;
-    f.rows_per_wg = c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : (n_expected > 16384 ? 32 : 0);
-    const int rows = fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, f.rows_per_wg);
+    // ... and 8 or 4 (decode_fused.hip, SPW) when the decoders in flight would leave most of the chip idle:
+    // decided below, under the admission lock, from the contexts that have a decoder pending
+    f.rows_per_wg = c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : c->decode_mode == 4 ? 8 : c->decode_mode == 5 ? 4
+                    : (n_expected > 16384 ? 32 : 0);
+    int rows = fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, f.rows_per_wg, kv24);
     for (int l = 0; l < m->Ld; ++l) {
       const DecLayerW &L = m->dec[(size_t)l];
       FusedLayerW &fl = f.L[l];
@@ -1525,17 +1535,17 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.trace = g_occ_trace;
     f.ticket = c->ticket.as<unsigned>();
     f.ticket_base = c->ticket_base;  // advanced below, once the launch is in the stream
-    const unsigned tickets = (unsigned)fused_decode_grid((int)B, true, rows);
+    unsigned tickets = (unsigned)fused_decode_grid((int)B, true, rows);
     if (c->stamp_step >= 0 && c->stamps.p) {
       f.stamps = c->stamps.as<unsigned long long>();
       f.stamp_step = c->stamp_step;
     }
     const double macs = (double)B * f.max_steps *
                         (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.N);
-    const double wbytes = (double)f.max_steps * ((B + rows - 1) / rows) *
-                          (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.n_tiles * 16);
+    double wbytes = (double)f.max_steps * ((B + rows - 1) / rows) *
+                    (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.n_tiles * 16);
     slimt_hip_model *gm = c->model;
-    const int wgs = ((int)B + rows - 1) / rows;
+    int wgs = ((int)B + rows - 1) / rows;
     if (gm->decoder_budget > 0) {
       // decoder admission (engine.h): launch k waits for launch k - n on its own stream
       constexpr size_t kRing = 64;
@@ -1547,8 +1557,6 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
         HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         gm->gate_ev.push_back(ev);
       }
-      size_t n = (size_t)std::max(1, gm->decoder_budget / wgs);
-      if (n > kRing) n = kRing;
       // K/V cache policy (decode_fused.hip, KV_AUX). The caches that are being read at any
       // moment are those of the decoders that run: at most one per context (a context is a
       // stream) and at most n by admission. While they fit the 256 MB Infinity Cache every
@@ -1581,6 +1589,27 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
         }
       }
       if (!known) gm->gate_ctx.push_back({c, gm->gate_seq, kv_bytes, now});
+      // Sentences per workgroup (decode mode 0): the fewest of 16 / 8 / 4 with which the decoders of the
+      // contexts that have one pending (this launch's shape taken for all of them) still fit the budget --
+      // one batch of 256 alone runs on 64 CUs instead of 16, twenty batches of 64 on 160 instead of 80, and
+      // the headline's twenty batches of 256 stay at 16 (a workgroup of fewer sentences streams the same
+      // weights for them: worth it only for CUs that would idle). Results do not depend on it.
+      if (c->decode_mode == 0 && f.rows_per_wg == 0 && gm->adaptive_rows) {
+        for (int spw : {4, 8}) {
+          if (fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, spw, kv24) != spw) break;
+          if (contexts * (size_t)(((int)B + spw - 1) / spw) <= (size_t)gm->decoder_budget) {
+            f.rows_per_wg = spw;
+            rows = spw;
+            tickets = (unsigned)fused_decode_grid((int)B, true, rows);
+            wgs = ((int)B + rows - 1) / rows;
+            wbytes = (double)f.max_steps * wgs *
+                     (m->Ld * (4.0 * m->D * m->D + 2.0 * m->D * m->F) + (double)m->D * out.w.n_tiles * 16);
+            break;
+          }
+        }
+      }
+      size_t n = (size_t)std::max(1, gm->decoder_budget / wgs);
+      if (n > kRing) n = kRing;
       const double active = pending / (double)contexts * (double)std::min(contexts, n);
       // ... in eighths of a layer's caches (kernels.h, kv_temporal_eighths): SLIMT_KV_BUDGET_MB /
       // SLIMT_KV_GRAIN tune the rule (defaults: 300 MB in whole layers, the measured optimum above)

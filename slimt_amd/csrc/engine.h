@@ -92,6 +92,7 @@ struct slimt_hip_model {
   int xcd_affinity = 0;
   std::vector<unsigned> gate_home;  // ring, parallel to gate_ev: home mask of each admitted launch
   int kv_policy = 0;  // 0 = chosen per launch, 1 = always temporal, 2 = always non-temporal K/V loads
+  bool adaptive_rows = true;  // decode mode 0: 8 or 4 sentences per decoder workgroup while CUs would idle (engine.cpp)
   int kv_format = 0;  // 0 = packed 24-bit cache where the kernels have it (kernels.h, kv24), 1 = always f32
 };
 

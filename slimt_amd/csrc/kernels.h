@@ -272,7 +272,7 @@ struct FusedDecodeArgs {
   float *attn = nullptr;        // nullable debug [B][H][S]
   unsigned long long *stamps = nullptr;  // nullable diagnostic [64] phase stamps
   int stamp_step = 0;
-  int rows_per_wg = 0;  // 0 = auto, 16 / 32 = force (32 only where supported)
+  int rows_per_wg = 0;  // sentences per workgroup: 0 / 16 = a full row tile, 32 / 8 / 4 where supported (fused_decode_rows)
   // nullable: ticket counter of the over-subscribed launch (16-row kernel). Every workgroup
   // of every launch takes one ticket; ticket - ticket_base is the tile it runs (or none).
   unsigned *ticket = nullptr;
@@ -319,7 +319,7 @@ int fused_encode_grid(int B, int S, bool tickets);
 bool fused_decode_supported(int D, int F, int H, int Ld);
 bool fused_decode_mid_supported(int D, int F, int H, int Ld);
 bool fused_decode_long24_supported(int D, int F, int H, int Ld);
-int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced);
+int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced, bool kv24);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
 
 // ---- persistent fused encoder (encode_fused.hip) ------------------------------

@@ -126,6 +126,17 @@ def test_baseline_config_full_size_bit_exact(hip, oracle, engines, name, preset,
             ctx.set_decode_mode(3)  # 32 sentences per decoder workgroup
             out_3, ln_3, _ = ctx.translate(ids, lens, sl)
             assert np.array_equal(out_3, out) and np.array_equal(ln_3, ln)
+        # mode 0 above chose by occupancy (one context alone: 4 sentences per workgroup where the variant exists);
+        # every tiling forced: 16, 8, 4 sentences per workgroup -- tokens, lengths AND alignment rows
+        for mode in (2, 4, 5):
+            ctx.set_decode_mode(mode)
+            out_m, ln_m, al_m = ctx.translate(ids, lens, sl, want_align=True)
+            assert np.array_equal(out_m, w_out) and np.array_equal(ln_m, w_ln) and np.array_equal(al_m, w_al), (name, mode)
+        gm.set_adaptive_decoder_rows(False)  # mode 0 with the adaptive choice off: always 16
+        ctx.set_decode_mode(0)
+        out_m, ln_m, al_m = ctx.translate(ids, lens, sl, want_align=True)
+        gm.set_adaptive_decoder_rows(True)
+        assert np.array_equal(out_m, w_out) and np.array_equal(ln_m, w_ln) and np.array_equal(al_m, w_al), name
     finally:
         ctx.close()
 

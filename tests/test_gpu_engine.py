@@ -116,9 +116,9 @@ def test_translate_tokens_lengths_alignments(hip, oracle, engines, preset, eos_b
     w_out, w_ln, w_al, steps = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
     oracle.set_mode(oracle.FAITHFUL)
     # mode 0: persistent fused decoder (when the shape supports it);
-    # mode 1: one launch per stage and step; modes 2 / 3: the persistent decoder
-    # with 16 / 32 sentences per workgroup. Same tokens every way.
-    for mode in (0, 1, 2, 3):
+    # mode 1: one launch per stage and step; modes 2 / 3 / 4 / 5: the persistent decoder
+    # with 16 / 32 / 8 / 4 sentences per workgroup. Same tokens every way.
+    for mode in (0, 1, 2, 3, 4, 5):
         ctx.set_decode_mode(mode)
         out, ln, al = ctx.translate(ids, lens, sl, limit_factor=1.5, eos_id=0, want_align=True)
         assert np.array_equal(ln, w_ln), (mode, ln, w_ln)
@@ -232,7 +232,7 @@ def test_translate_edge_shapes(hip, oracle, engines, preset, B, S, n_sl):
     oracle.set_mode(oracle.PORTABLE)
     w_out, w_ln, w_al, _ = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
     oracle.set_mode(oracle.FAITHFUL)
-    for mode in (0, 1, 3):
+    for mode in (0, 1, 2, 3, 5):
         ctx.set_decode_mode(mode)
         out, ln, al = ctx.translate(ids, lens, sl, want_align=True)
         assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out) and np.array_equal(al, w_al), mode
@@ -255,7 +255,7 @@ def test_output_layer_tile_counts(hip, oracle, engines, n_sl):
         oracle.set_mode(oracle.PORTABLE)
         w_out, w_ln, w_al, _ = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
         oracle.set_mode(oracle.FAITHFUL)
-        for mode in (0, 3):
+        for mode in (0, 2, 3, 4):
             ctx.set_decode_mode(mode)
             out, ln, al = ctx.translate(ids, lens, sl, want_align=True)
             assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out) and np.array_equal(al, w_al), (n, mode)
@@ -395,7 +395,7 @@ def test_packed_kv_cache_matches_oracle_and_f32_cache(hip, oracle, engines, pres
     against the f32 cache, for sentence lengths on both sides of every layout edge: several
     sentences per encoder workgroup, a last V group of 1..4 keys, S = 1 / 2 / 5 (which fall
     back to f32: a padded group of four keys would not fit their plane), both cache-load
-    policies and both decoder tilings (16 and 32 sentences per workgroup). Alignments are
+    policies and every decoder tiling (16, 32, 8 and 4 sentences per workgroup). Alignments are
     the head-0 probabilities computed from the unpacked K, so they pin the floats too."""
     from slimt_amd import synth
     m, gm, om = engines(preset, 6.0)
@@ -414,7 +414,9 @@ def test_packed_kv_cache_matches_oracle_and_f32_cache(hip, oracle, engines, pres
             gm.set_kv_cache_format(fmt)
             for policy in (2, 1):
                 gm.set_kv_cache_policy(policy)
-                for mode in ((2, 3) if preset == "tiny11" else (0,)):
+                # 16 / 32 / 8 / 4 sentences per decoder workgroup (32: tiny11's short sentences only; 8 and 4: the
+                # packed-cache variants, else they fall back to 16)
+                for mode in ((2, 3, 4, 5) if preset == "tiny11" else (2, 4, 5)):
                     ctx.set_decode_mode(mode)
                     got = ctx.translate(ids, lens, sl, want_align=True)
                     assert all(np.array_equal(a, b) for a, b in zip(got, want)), (fmt, policy, mode)
@@ -543,7 +545,9 @@ def test_decoder_admission_and_ticket_launches_keep_results(hip, oracle, engines
     bad = []
 
     def work(w):
-        for rep in range(2):
+        # automatic (8 or 4 sentences per workgroup while they fit the budget), then 16 / 8 / 4 forced
+        for rep, mode in enumerate((0, 2, 4, 5)):
+            ctxs[w].set_decode_mode(mode)
             for i in range(w, len(jobs), W):
                 got = ctxs[w].translate(jobs[i][0], jobs[i][1], sl, want_align=True)
                 if not all(np.array_equal(a, b) for a, b in zip(got, want[i])):
