@@ -547,6 +547,10 @@ struct so_model {
   int threads;
   /* per-batch caches for reference_cost == 0 (not thread safe; test infra) */
   float *kv_cache;
+  int32_t *kv_acc; /* PORTABLE: the K / V projections' shifted accumulators, [Ld][K,V][B*S][D] */
+  const float *kv_acc_src;
+  size_t kv_acc_B, kv_acc_S;
+  float kv_acc_probe[4];
   size_t kv_B, kv_S;
   const float *kv_src;
   float kv_probe[4]; /* first/last values of the cached encoder_out: a recycled
@@ -708,6 +712,7 @@ void so_model_destroy(so_model *m) {
   }
   free_affine_cache(&m->output);
   free(m->kv_cache);
+  free(m->kv_acc);
   free(m->enc);
   free(m->dec);
   free(m->embedding);
@@ -906,6 +911,101 @@ static const float *kv_for(const so_model *m_, int layer, int which,
   return m->kv_cache + (size_t)(2 * layer + which) * per;
 }
 
+/* PORTABLE order of the decoder's cross-attention (Attention::forward, Modules.cc:287-319, over the
+ * K / V projections of the encoder output, which do not change between steps). The reference
+ * dequantises every K / V element (y = float(accS) * u + pb, Intgemm.inl.cc:146-153) and then runs the
+ * float attention (Modules.cc:24-86). The GPU keeps the projections' int32 accumulators between steps;
+ * rebuilding u * acc + pb per cached element and step is two thirds of its attention arithmetic, so the
+ * PORTABLE order applies the (per column constant) u and pb AFTER the sums -- the same real numbers,
+ * other roundings; FAITHFUL stays the literal sequence:
+ *   scores   t_j = fmaf chain over the head's columns d (ascending, from 0) of q_d * float(accK[j][d])
+ *            c_h = row sum (PORTABLE row order) of the products q_d * pbK[d] over the head's columns
+ *            s_j = alpha * fmaf(t_j, uK, c_h) + mask_j       (alpha, mask, softmax as Modules.cc:45-75)
+ *   context  w_d = fmaf chain over the keys j (ascending, from 0) of p_j * float(accV[j][d])
+ *            P_h = row sum (PORTABLE row order) of the head's probabilities
+ *            o_d = fmaf(w_d, uV, pbV[d] * P_h)
+ * float(acc) is exact (|acc| <= 254 * 127 * K < 2^24 for K <= 512). */
+static const int32_t *kv_acc_for(const so_model *m_, int layer, int which,
+                                 const float *encoder_out, size_t B, size_t S) {
+  so_model *m = (so_model *)m_;
+  size_t D = (size_t)m->D, per = B * S * D;
+  const float probe[4] = {encoder_out[0], encoder_out[per / 2], encoder_out[per - 1],
+                          encoder_out[per / 3]};
+  if (m->kv_acc_src != encoder_out || m->kv_acc_B != B || m->kv_acc_S != S || !m->kv_acc ||
+      memcmp(probe, m->kv_acc_probe, sizeof probe) != 0) {
+    free(m->kv_acc);
+    m->kv_acc = (int32_t *)malloc(per * 2 * (size_t)m->Ld * sizeof(int32_t));
+    for (int l = 0; l < m->Ld; l++) {
+      const so_affine_p *k = &m->dec[l].attn.k, *v = &m->dec[l].attn.v;
+      so_affine_acc(encoder_out, B * S, D, k->W, D, k->a_quant, m->kv_acc + (size_t)(2 * l) * per);
+      so_affine_acc(encoder_out, B * S, D, v->W, D, v->a_quant, m->kv_acc + (size_t)(2 * l + 1) * per);
+    }
+    m->kv_acc_src = encoder_out;
+    m->kv_acc_B = B;
+    m->kv_acc_S = S;
+    memcpy(m->kv_acc_probe, probe, sizeof probe);
+  }
+  return m->kv_acc + (size_t)(2 * layer + which) * per;
+}
+
+/* out [B][D] (heads joined), attn [B][H][S] */
+static void cross_attention_portable(const so_model *m, const so_attn_p *a, int layer, const float *yq,
+                                     const float *encoder_out, const float *mask, size_t B, size_t S,
+                                     float *out, float *attn) {
+  size_t D = (size_t)m->D, H = (size_t)m->H, dh = D / H;
+  const int32_t *accK = kv_acc_for(m, layer, 0, encoder_out, B, S);
+  const int32_t *accV = kv_acc_for(m, layer, 1, encoder_out, B, S);
+  float *pbK = (float *)malloc(D * sizeof(float)), *pbV = (float *)malloc(D * sizeof(float));
+  prepare_bias(a->k.W, D, D, a->k.b, a->k.a_quant, a->k.b_quant, pbK);
+  prepare_bias(a->v.W, D, D, a->v.b, a->v.a_quant, a->v.b_quant, pbV);
+  const float uK = 1.0f / (a->k.a_quant * a->k.b_quant), uV = 1.0f / (a->v.a_quant * a->v.b_quant);
+  const float alpha = 1.0f / sqrtf((float)dh);
+  float *sc = (float *)malloc(S * sizeof(float)), *prod = (float *)malloc(dh * sizeof(float));
+  for (size_t b = 0; b < B; b++)
+    for (size_t h = 0; h < H; h++) {
+      const float *q = yq + b * D + h * dh;
+      for (size_t d = 0; d < dh; d++) prod[d] = q[d] * pbK[h * dh + d];
+      const float c = so_row_sum(prod, dh);
+      for (size_t j = 0; j < S; j++) {
+        const int32_t *k = accK + (b * S + j) * D + h * dh;
+        float t = 0.0f;
+        for (size_t d = 0; d < dh; d++) t = fmaf(q[d], (float)k[d], t);
+        float s = fmaf(t, uK, c);
+        if (alpha != 1.0f) s = alpha * s;
+        sc[j] = s + mask[b * S + j];
+      }
+      float *p = attn + (b * H + h) * S;
+      so_softmax(sc, 1, S, p);
+      const float P = so_row_sum(p, S);
+      for (size_t d = 0; d < dh; d++) {
+        float w = 0.0f;
+        for (size_t j = 0; j < S; j++) w = fmaf(p[j], (float)accV[(b * S + j) * D + h * dh + d], w);
+        const float pbP = pbV[h * dh + d] * P;
+        out[b * D + h * dh + d] = fmaf(w, uV, pbP);
+      }
+    }
+  free(prod); free(sc); free(pbV); free(pbK);
+}
+
+/* Attention::forward (Modules.cc:287-319) for the decoder's cross-attention in the PORTABLE order:
+ * q projection, the attention above, then the output projection, residual and LayerNorm as
+ * attention_forward. q [B,D] (Tq = 1), y [B,D], attn [B,H,S]. */
+static void cross_attention_forward_portable(const so_model *m, const so_attn_p *a, int layer,
+                                             const float *q, const float *encoder_out, const float *mask,
+                                             size_t B, size_t S, float *y, float *attn) {
+  size_t D = (size_t)m->D;
+  float *yq = (float *)malloc(B * D * sizeof(float));
+  float *joined = (float *)malloc(B * D * sizeof(float));
+  float *yo = (float *)malloc(B * D * sizeof(float));
+  float *xpy = (float *)malloc(B * D * sizeof(float));
+  apply_affine(m, &a->q, q, B, yq);
+  cross_attention_portable(m, a, layer, yq, encoder_out, mask, B, S, joined, attn);
+  apply_affine(m, &a->o, joined, B, yo);
+  so_add(q, yo, B * D, xpy); /* Modules.cc:314 */
+  apply_ln(&a->ln, xpy, B, D, y);
+  free(xpy); free(yo); free(joined); free(yq);
+}
+
 /* Decoder::step (Transformer.cc:120-183) with DecoderLayer::forward
  * (Modules.cc:237-259). */
 void so_decode_step(const so_model *m, const float *encoder_out,
@@ -927,12 +1027,16 @@ void so_decode_step(const so_model *m, const float *encoder_out,
   for (int l = 0; l < m->Ld; l++) {
     const so_dec_layer *L = &m->dec[l];
     ssru_forward(m, L, states + (size_t)l * n, x, B, h);
-    const float *pk = NULL, *pv = NULL;
-    if (!m->reference_cost) {
-      pk = kv_for(m, l, 0, encoder_out, B, S);
-      pv = kv_for(m, l, 1, encoder_out, B, S);
+    if (g_mode == SO_PORTABLE) {
+      cross_attention_forward_portable(m, &L->attn, l, h, encoder_out, mask, B, S, a, attn_l);
+    } else {
+      const float *pk = NULL, *pv = NULL;
+      if (!m->reference_cost) {
+        pk = kv_for(m, l, 0, encoder_out, B, S);
+        pv = kv_for(m, l, 1, encoder_out, B, S);
+      }
+      attention_forward(m, &L->attn, h, encoder_out, mask, B, 1, S, pk, pv, a, attn_l);
     }
-    attention_forward(m, &L->attn, h, encoder_out, mask, B, 1, S, pk, pv, a, attn_l);
     ffn_block(m, &L->ffn1, &L->ffn2, &L->ffn_ln, a, B, x);
     /* :165-174: alignment = attention of the LAST layer */
     if (attn && l + 1 == m->Ld) memcpy(attn, attn_l, B * H * S * sizeof(float));
@@ -975,6 +1079,7 @@ size_t so_translate(const so_model *m, const uint32_t *src_ids,
   size_t D = (size_t)m->D, H = (size_t)m->H;
   size_t N = shortlist ? n_sl : (size_t)m->V;
   ((so_model *)m)->kv_src = NULL; /* new batch: the cross-attention K/V cache is stale */
+  ((so_model *)m)->kv_acc_src = NULL;
   float *mask = (float *)malloc(B * S * sizeof(float));
   so_make_mask(lengths, B, S, mask);
   float *emb = (float *)malloc(B * S * D * sizeof(float));

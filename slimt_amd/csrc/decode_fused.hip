@@ -410,10 +410,13 @@ typedef const SLIMT_LDS f4 *lcf4_ptr;
 typedef SLIMT_LDS char *lc_ptr;
 
 struct AttnRow {
-  gcf_ptr kl, vl;  // this sentence's cached K / V [S][D]
+  gcf_ptr kl, vl;  // this sentence's cached K / V [S][D]: float(accS) in the f32 form (see unpack24f below)
+  gcf_ptr pbk, pbv;  // f32 form: the K / V projections' prepared biases [D] (global memory)
+  float uk, uv;      // f32 form: their unquantisation multipliers
   lcf_ptr qrow;    // LDS: q [D]
   lc_ptr arow;     // LDS: int8 output row [D] (A operand of the O projection)
   SLIMT_LDS float *pbuf;  // LDS: 64 floats of per-wave scratch
+  SLIMT_LDS float *hsum;  // LDS: 16 floats of per-wave scratch (the heads' probability sums P_h)
   int S, len;
   float alpha, aq_o;
   gf_ptr attn;   // nullable [H][S]
@@ -463,6 +466,9 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
     // in the lane, the 32-lane butterfly on both, and their sum.
     const int hh = lane >> 5, j = lane & 31;
     const int ng = (S + 31) >> 5;
+    const float uk = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r.uk)));
+    const float uv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r.uv)));
+    const float *pbk = uniform_ptr((const float *)r.pbk), *pbv = uniform_ptr((const float *)r.pbv);
     const rsrc_t rk = make_rsrc(uniform_ptr((const float *)r.kl), (unsigned)(S * D) * 4u);
     const rsrc_t rv = make_rsrc(uniform_ptr((const float *)r.vl), (unsigned)(lenf * D) * 4u);  // padding is
     const int koff = ((hh * (DH / 4) * S + j) * 4) * 4;                                        // not fetched
@@ -480,6 +486,8 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
       float sc[4];
       f4 ka[8], kb[8];
       load_k(ka, 0);
+      // c_h (the hoisted order, unpack24f below): column lane + 64 hp belongs to head 2 hp + (lane >> 5) = h
+      const float ch = half_sum(r.qrow[lane + 64 * hp] * pbk[lane + 64 * hp]);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f4(&cur)[8] = (g & 1) ? kb : ka;
@@ -497,6 +505,7 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
             s = __builtin_fmaf(q4.z, cur[i].z, s);
             s = __builtin_fmaf(q4.w, cur[i].w, s);
           }
+          s = __builtin_fmaf(s, uk, ch);
           if (r.alpha != 1.0f) s = r.alpha * s;
           s = s + (1.0f - (key < len ? 1.0f : 0.0f)) * minus_inf;
           if (key >= S) s = lowest;
@@ -508,9 +517,12 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
       for (int g = 0; g < 4; ++g) sc[g] = (32 * g + j) < S ? exp_p(sc[g] - m) : 0.0f;
       const float sum = half_sum(sc[0] + sc[2]) + half_sum(sc[1] + sc[3]);
 #pragma unroll
+      for (int g = 0; g < 4; ++g) sc[g] = sc[g] / sum;  // keys >= S: exactly 0
+      const float P = half_sum(sc[0] + sc[2]) + half_sum(sc[1] + sc[3]);  // P_h in the same canonical order
+#pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int key = 32 * g + j;
-        const float p = sc[g] / sum;  // keys >= S: exactly 0
+        const float p = sc[g];
         if (g < ng) {
           if (r.attn && key < S) r.attn[(size_t)h * S + key] = p;
           if (r.align && hp == 0 && hh == 0 && key < len) r.align[key] = p;
@@ -543,6 +555,7 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
           }
         }
       }
+      o = __builtin_fmaf(o, uv, pbv[2 * hp * DH + lane] * P);
       r.arow[2 * hp * DH + lane] = (char)quantize1(o, r.aq_o);
     }
   }
@@ -600,6 +613,9 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
     load_k(0);
     load_v(vq[0], 0);  // needed only after the last score pass: a long head start
     __builtin_amdgcn_sched_barrier(0);
+    float ck[4];  // the hoisted order (unpack24f below): c_h of this lane's head in pass hp
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ck[i] = half_sum(r.qrow[lane + 64 * i] * r.pbk[lane + 64 * i]);
 #pragma unroll
     for (int hp = 0; hp < H / 2; ++hp) {
       const int h = 2 * hp + hh;
@@ -619,6 +635,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
         load_v(vq[2], 2);
       }
       __builtin_amdgcn_sched_barrier(0);
+      s = __builtin_fmaf(s, r.uk, ck[hp]);
       if (r.alpha != 1.0f) s = r.alpha * s;
       s = s + mask;
       if (j >= S) s = lowest;
@@ -626,12 +643,16 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       const float e = j < S ? exp_p(s - m) : 0.0f;
       const float sum = half_sum(e);  // canonical order: masks 1..16; the mask-32 step would add +0
       const float p = e / sum;        // keys >= S: exactly 0
+      const float ps = half_sum(p);   // P_h
       if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
       if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
       r.pbuf[h * 32 + j] = p;
+      if (j == 0) r.hsum[h] = ps;
     }
     // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
     const int ph = (lane >> 3) * 32;
+    const float P = r.hsum[lane >> 3];
+    const f4 pv4 = *(gcf4_ptr)(r.pbv + 4 * lane);
     f4 o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -649,6 +670,10 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       if (g + 3 < 8) load_v(vq[g % 3], g + 3);
       __builtin_amdgcn_sched_barrier(0);
     }
+    o.x = __builtin_fmaf(o.x, r.uv, pv4.x * P);
+    o.y = __builtin_fmaf(o.y, r.uv, pv4.y * P);
+    o.z = __builtin_fmaf(o.z, r.uv, pv4.z * P);
+    o.w = __builtin_fmaf(o.w, r.uv, pv4.w * P);
     *(SLIMT_LDS int *)(r.arow + 4 * lane) =
         pack4(quantize1(o.x, r.aq_o), quantize1(o.y, r.aq_o), quantize1(o.z, r.aq_o), quantize1(o.w, r.aq_o));
   } else if (LONG && DH == 32 && S <= 128) {
@@ -683,6 +708,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       for (int i = 0; i < 16; ++i)
         k4[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
                                            rk, koff, ((h * (DH / 4) + i) * S * 4) * 4, KV_AUX));
+      const float ch = wave_sum(r.qrow[h * DH + lane] * r.pbk[h * DH + lane]);  // c_h (the hoisted order, unpack24f below)
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -692,6 +718,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
         s = __builtin_fmaf(q4.z, k4[i].z, s);
         s = __builtin_fmaf(q4.w, k4[i].w, s);
       }
+      s = __builtin_fmaf(s, r.uk, ch);
       if (r.alpha != 1.0f) s = r.alpha * s;
       s = s + mask;
       if (j >= S) s = lowest;
@@ -699,10 +726,12 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       const float e = j < S ? exp_p(s - m) : 0.0f;
       const float sum = half_sum(e);
       const float p = e / sum;  // keys >= S: exactly 0
+      const float ps = half_sum(p);  // P_h
       if (lane < 32) {
         if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
         if (r.align && h == 0 && j < len) r.align[j] = p;
         r.pbuf[h * 32 + j] = p;
+        if (lane == 0) r.hsum[h] = ps;
       }
     }
     load_v(vq[0], 0);  // (held across the head loop, a group of V rows would be spilled)
@@ -730,6 +759,18 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       if (g + 3 < 16) load_v(vq[g % 3], g + 3);
       __builtin_amdgcn_sched_barrier(0);
     }
+    {
+      const float P0 = r.hsum[lane >> 4], P1 = r.hsum[4 + (lane >> 4)];
+      const f4 pv0 = *(gcf4_ptr)(r.pbv + 4 * lane), pv1 = *(gcf4_ptr)(r.pbv + D / 2 + 4 * lane);
+      o0.x = __builtin_fmaf(o0.x, r.uv, pv0.x * P0);
+      o0.y = __builtin_fmaf(o0.y, r.uv, pv0.y * P0);
+      o0.z = __builtin_fmaf(o0.z, r.uv, pv0.z * P0);
+      o0.w = __builtin_fmaf(o0.w, r.uv, pv0.w * P0);
+      o1.x = __builtin_fmaf(o1.x, r.uv, pv1.x * P1);
+      o1.y = __builtin_fmaf(o1.y, r.uv, pv1.y * P1);
+      o1.z = __builtin_fmaf(o1.z, r.uv, pv1.z * P1);
+      o1.w = __builtin_fmaf(o1.w, r.uv, pv1.w * P1);
+    }
     *(SLIMT_LDS int *)(r.arow + 4 * lane) =
         pack4(quantize1(o0.x, r.aq_o), quantize1(o0.y, r.aq_o), quantize1(o0.z, r.aq_o), quantize1(o0.w, r.aq_o));
     *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) =
@@ -742,6 +783,8 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
     const float mask0 = (1.0f - (lane < len ? 1.0f : 0.0f)) * minus_inf;
     const float mask1 = (1.0f - ((lane + 64) < len ? 1.0f : 0.0f)) * minus_inf;
     for (int h = 0; h < H; ++h) {
+      // c_h: one column of the head per lane, the canonical butterfly (lanes past the head hold +0)
+      const float ch = wave_sum(lane < DH ? r.qrow[h * DH + dc] * r.pbk[h * DH + dc] : 0.0f);
       float s0 = 0.0f, s1 = 0.0f;
       for (int k = 0; k < DH; ++k) {
         const float qk = r.qrow[h * DH + k];
@@ -749,6 +792,8 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
         s0 = __builtin_fmaf(qk, kc[(size_t)j0 * 4], s0);
         s1 = __builtin_fmaf(qk, kc[(size_t)j1 * 4], s1);
       }
+      s0 = __builtin_fmaf(s0, r.uk, ch);
+      s1 = __builtin_fmaf(s1, r.uk, ch);
       if (r.alpha != 1.0f) {
         s0 = r.alpha * s0;
         s1 = r.alpha * s1;
@@ -762,6 +807,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       const float e1 = (lane + 64) < S ? exp_p(s1 - m) : 0.0f;
       const float sum = wave_sum(e0 + e1);
       const float p0 = e0 / sum, p1 = e1 / sum;
+      const float P = wave_sum(p0 + p1);  // P_h
       if (r.attn) {
         gf_ptr ap = r.attn + (size_t)h * S;
         if (lane < S) ap[lane] = p0;
@@ -776,6 +822,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
         const float pj = __shfl(jj < 64 ? p0 : p1, jj & 63, 64);
         o = __builtin_fmaf(pj, r.vl[(size_t)jj * D + h * DH + dc], o);
       }
+      o = __builtin_fmaf(o, r.uv, r.pbv[h * DH + dc] * P);
       if (lane < DH) r.arow[h * DH + lane] = (char)quantize1(o, r.aq_o);
     }
   }
@@ -784,28 +831,34 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
 // ---- packed K/V cache (FusedDecodeArgs::kv24): D = 256, d_head 32, S <= 32 -----------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// 12 bytes = four 24-bit accumulators accS -> float(accS) * u + pb (dequant above, operation by
-// operation). A 24-bit field moved into the HIGH three bytes of a register is accS * 256 as a
-// signed integer: one v_perm / shift per value instead of extract + sign-extend, its conversion
-// is exact (24 significant bits), and float(accS * 256) * (u / 256) is the same real product as
-// float(accS) * u, hence the same rounded float. Multiply and add stay separate roundings
-// (-ffp-contract=off), two columns per v_pk_mul_f32 / v_pk_add_f32.
-__device__ __forceinline__ f4 unpack24(int d0, int d1, int d2, float u256, f4 pb) {
+// The cached cross-attention in the hoisted (PORTABLE) order -- oracle/slimt_oracle.c, cross_attention_portable:
+// the projections' unquantisation multiplier u and prepared bias pb are per-column constants, so they are
+// applied AFTER the sums instead of to every cached value in every step:
+//   t_j = fmaf chain over the head's columns of q_d * float(accK[j][d]);  c_h = row sum of q_d * pbK[d]
+//   s_j = alpha * fmaf(t_j, uK, c_h) + mask_j;   p = softmax(s);   P_h = row sum of p
+//   w_d = fmaf chain over the keys of p_j * float(accV[j][d]);            o_d = fmaf(w_d, uV, pbV[d] * P_h)
+// (the reference dequantises first, Intgemm.inl.cc:146-153 / Modules.cc:24-86: same reals, other roundings;
+// per value the unpack was extract + convert + half a packed multiply + half a packed add, now extract + convert).
+//
+// 12 bytes = four 24-bit accumulators accS -> float(accS * 256). A 24-bit field moved into the HIGH three bytes
+// of a register is accS * 256 as a signed integer: one v_perm / shift per value instead of extract + sign-extend,
+// and its conversion is exact (24 significant bits). The fmaf chains over 256 accS are 256 times those over accS
+// (a power of two scales every partial sum exactly), and u / 256 takes the factor out again.
+__device__ __forceinline__ f4 unpack24f(int d0, int d1, int d2) {
   const int y0 = d0 << 8;
   const int y1 = (int)__builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x0504030cu);
   const int y2 = (int)__builtin_amdgcn_perm((unsigned)d2, (unsigned)d1, 0x0403020cu);
   const int y3 = d2 & (int)0xffffff00;
-  f2 a = {(float)y0, (float)y1}, b = {(float)y2, (float)y3};
-#ifndef SLIMT_EXP_NODEQ  // timing experiment (wrong results): the unpack without its multiply and add. Alone, an
-  const f2 uu = {u256, u256};  // attention phase goes 9.84 -> 8.36 us: 256 fewer VALU instructions x 4 waves x 4 cycles
-  a = a * uu;                  // -- the phase is VALU-issue bound (prefetching K a pass ahead changed nothing)
-  b = b * uu;
-  const f2 pa = {pb.x, pb.y}, pc = {pb.z, pb.w};
-  a = a + pa;
-  b = b + pc;
-#endif
-  const f4 o = {a.x, a.y, b.x, b.y};
+  const f4 o = {(float)y0, (float)y1, (float)y2, (float)y3};
   return o;
+}
+
+// c_h = row sum (canonical order) of q_d * pbK[d] over head h's DH columns, for the heads this lane meets in the
+// score passes. DH = 32, D = 256: lane l holds column l + 64 i of head 2 i + (l >> 5) -- the head of pass i in
+// the two-heads-per-pass forms, whose lanes of half hh score head 2 i + hh: no shuffle at all.
+__device__ __forceinline__ void head_constants32(lcf_ptr q, lcf_ptr pbk, int lane, float (&c)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = half_sum(q[lane + 64 * i] * pbk[lane + 64 * i]);
 }
 
 // attention_row's S <= 32, d_head 32 form over the packed cache (layout: kernels.h, kv24): same
@@ -826,8 +879,8 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
   v4i kq[6];     // this lane's key, its head's 32 columns: two chunks of three planes
   v4i vq[3][3];  // V rows in flight: three groups of four rows (three planes each)
   const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 3u);
-  // masked keys are not fetched: past the descriptors a load returns zeros, i.e. the value pb --
-  // finite, and multiplied by a probability that is exactly 0
+  // masked keys are not fetched: past the descriptors a load returns zeros -- a score that the mask
+  // overrides, a value weighted by a probability that is exactly 0
   const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 3) >> 2) * 3072));
   const int koff = j < lenf ? (hh * 6 * S + jc) * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
   const int voff = lane * 16;                                            // [S/4][plane][D/4][16 B]
@@ -842,30 +895,32 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
       vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + i) * 1024, KV_AUX));
   };
   // group g (12 bytes = 4 values) of the 48-byte item in planes p0, p1, p2
-  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g, float u256, f4 pb) -> f4 {
+  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g) -> f4 {
     const int w[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-    return unpack24(w[3 * g], w[3 * g + 1], w[3 * g + 2], u256, pb);
+    return unpack24f(w[3 * g], w[3 * g + 1], w[3 * g + 2]);
   };
   load_k(0);
   load_v(vq[0], 0);
   __builtin_amdgcn_sched_barrier(0);
+  float ck[4];  // c_h of this lane's head in pass hp (under the first loads' round trip)
+  head_constants32(r.qrow, pbk, lane, ck);
 #pragma unroll
   for (int hp = 0; hp < H / 2; ++hp) {
     const int h = 2 * hp + hh;
-    float s = 0.0f;
+    float t = 0.0f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = h * DH + 16 * c + 4 * g;
         const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
-        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, uk256, *(lcf4_ptr)(pbk + d0));
-        s = __builtin_fmaf(q4.x, kk.x, s);
-        s = __builtin_fmaf(q4.y, kk.y, s);
-        s = __builtin_fmaf(q4.z, kk.z, s);
-        s = __builtin_fmaf(q4.w, kk.w, s);
+        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g);
+        t = __builtin_fmaf(q4.x, kk.x, t);
+        t = __builtin_fmaf(q4.y, kk.y, t);
+        t = __builtin_fmaf(q4.z, kk.z, t);
+        t = __builtin_fmaf(q4.w, kk.w, t);
       }
-      __builtin_amdgcn_sched_barrier(0);  // at most one chunk's q / bias reads from LDS in flight
+      __builtin_amdgcn_sched_barrier(0);  // at most one chunk's q reads from LDS in flight
     }
     if (hp + 1 < H / 2) {
       load_k(hp + 1);
@@ -874,6 +929,7 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
       load_v(vq[2], 2);
     }
     __builtin_amdgcn_sched_barrier(0);
+    float s = __builtin_fmaf(t, uk256, ck[hp]);
     if (r.alpha != 1.0f) s = r.alpha * s;
     s = s + mask;
     if (j >= S) s = lowest;
@@ -881,13 +937,16 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
     const float e = j < S ? exp_p(s - m) : 0.0f;
     const float sum = half_sum(e);
     const float p = e / sum;  // keys >= S: exactly 0
+    const float ps = half_sum(p);  // P_h
     if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
     if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
     r.pbuf[h * 32 + j] = p;
+    if (j == 0) r.hsum[h] = ps;
   }
   // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
   const int ph = (lane >> 3) * 32;
   const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  const float P = r.hsum[lane >> 3];
   f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};  // columns (0, 1) and (2, 3): v_pk_fma_f32 is one fma per column
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
@@ -896,7 +955,7 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
     const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
-      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c, uv256, pv4);
+      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c);
       const f2 pp = {pj[c], pj[c]}, va = {v4.x, v4.y}, vb = {v4.z, v4.w};
       oa = __builtin_elementwise_fma(pp, va, oa);
       ob = __builtin_elementwise_fma(pp, vb, ob);
@@ -908,8 +967,10 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
     if (g + 3 < 8) load_v(vq[g % 3], g + 3);
     __builtin_amdgcn_sched_barrier(0);
   }
+  const float o0 = __builtin_fmaf(oa.x, uv256, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv256, pv4.y * P);
+  const float o2 = __builtin_fmaf(ob.x, uv256, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv256, pv4.w * P);
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1(oa.x, r.aq_o), quantize1(oa.y, r.aq_o), quantize1(ob.x, r.aq_o), quantize1(ob.y, r.aq_o));
+      pack4(quantize1(o0, r.aq_o), quantize1(o1, r.aq_o), quantize1(o2, r.aq_o), quantize1(o3, r.aq_o));
 }
 
 // Sentences of 33..64 tokens over the packed cache (written by encode_tall_kernel<., 4>): lane =
@@ -931,9 +992,9 @@ __device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr
   const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 3) >> 2) * 3072));
   const int koff = j < lenf ? jc * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
   const int voff = lane * 16;                             // [S/4][plane][D/4][16 B]
-  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g, float u256, f4 pb) -> f4 {
+  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g) -> f4 {
     const int w[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-    return unpack24(w[3 * g], w[3 * g + 1], w[3 * g + 2], u256, pb);
+    return unpack24f(w[3 * g], w[3 * g + 1], w[3 * g + 2]);
   };
   v4i kq[6];
   auto load_k = [&](int h) {
@@ -942,25 +1003,34 @@ __device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr
       kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((6 * h + i) * S) * 16, KV_AUX));
   };
   load_k(0);
+  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
+    float ck[4];
+    head_constants32(r.qrow, pbk, lane, ck);
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ck[i];
+    }
+  }
 #pragma unroll 1
   for (int h = 0; h < H; ++h) {
-    float s = 0.0f;
+    float t = 0.0f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = h * DH + 16 * c + 4 * g;
         const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
-        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, uk256, *(lcf4_ptr)(pbk + d0));
-        s = __builtin_fmaf(q4.x, kk.x, s);
-        s = __builtin_fmaf(q4.y, kk.y, s);
-        s = __builtin_fmaf(q4.z, kk.z, s);
-        s = __builtin_fmaf(q4.w, kk.w, s);
+        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g);
+        t = __builtin_fmaf(q4.x, kk.x, t);
+        t = __builtin_fmaf(q4.y, kk.y, t);
+        t = __builtin_fmaf(q4.z, kk.z, t);
+        t = __builtin_fmaf(q4.w, kk.w, t);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     load_k(h + 1 < H ? h + 1 : h);  // the next head's keys travel under this head's softmax
     __builtin_amdgcn_sched_barrier(0);
+    float s = __builtin_fmaf(t, uk256, r.hsum[8 + h]);
     if (r.alpha != 1.0f) s = r.alpha * s;
     s = s + mask;
     if (j >= S) s = lowest;
@@ -968,9 +1038,11 @@ __device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr
     const float e = j < S ? exp_p(s - m) : 0.0f;
     const float sum = wave_sum(e);
     const float p = e / sum;  // keys >= S: exactly 0
+    const float ps = wave_sum(p);  // P_h
     if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
     if (r.align && h == 0 && j < len) r.align[j] = p;
     r.pbuf[h * 64 + j] = p;
+    if (lane == 0) r.hsum[h] = ps;
   }
   v4i vq[3][3];  // V rows in flight: three groups of four rows (three planes each)
   auto load_v = [&](v4i(&vv)[3], int g) {  // rows 4 g .. 4 g + 3
@@ -985,6 +1057,7 @@ __device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr
   // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
   const int ph = (lane >> 3) * 64;
   const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  const float P = r.hsum[lane >> 3];
   f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
@@ -993,7 +1066,7 @@ __device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr
     const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
-      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c, uv256, pv4);
+      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c);
       const f2 pp = {pj[c], pj[c]}, va = {v4.x, v4.y}, vb = {v4.z, v4.w};
       oa = __builtin_elementwise_fma(pp, va, oa);
       ob = __builtin_elementwise_fma(pp, vb, ob);
@@ -1002,8 +1075,10 @@ __device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr
     if (g + 3 < 16) load_v(vq[g % 3], g + 3);
     __builtin_amdgcn_sched_barrier(0);
   }
+  const float o0 = __builtin_fmaf(oa.x, uv256, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv256, pv4.y * P);
+  const float o2 = __builtin_fmaf(ob.x, uv256, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv256, pv4.w * P);
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1(oa.x, r.aq_o), quantize1(oa.y, r.aq_o), quantize1(ob.x, r.aq_o), quantize1(ob.y, r.aq_o));
+      pack4(quantize1(o0, r.aq_o), quantize1(o1, r.aq_o), quantize1(o2, r.aq_o), quantize1(o3, r.aq_o));
 }
 
 // Sentences of 65..128 tokens over the packed cache (written by encode_long16_kernel): lane L holds
@@ -1028,9 +1103,9 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
   const int koff0 = j0 < lenf ? j0 * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
   const int koff1 = j1 < lenf ? j1 * 16 : kPastDescriptor;
   const int voff = lane * 16;                               // [S/4][plane][D/4][16 B]
-  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g, float u256, f4 pb) -> f4 {
+  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g) -> f4 {
     const int w[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-    return unpack24(w[3 * g], w[3 * g + 1], w[3 * g + 2], u256, pb);
+    return unpack24f(w[3 * g], w[3 * g + 1], w[3 * g + 2]);
   };
   // Two K buffers: a half pass's keys are requested one half pass ahead (keys L + 64 of head h before
   // keys L are scored, keys L of head h + 1 before keys L + 64 are), so that a round trip to the cache
@@ -1043,7 +1118,7 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
     for (int i = 0; i < 6; ++i)
       kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((6 * h + i) * S) * 16, KV_AUX));
   };
-  auto score = [&](const v4i(&kq)[6], int h) -> float {  // this lane's key against head h: the ascending-column fmaf chain
+  auto score = [&](const v4i(&kq)[6], int h) -> float {  // this lane's key against head h: the ascending-column fmaf chain t_j
     float s = 0.0f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -1051,7 +1126,7 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
       for (int g = 0; g < 4; ++g) {
         const int d0 = h * DH + 16 * c + 4 * g;
         const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
-        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, uk256, *(lcf4_ptr)(pbk + d0));
+        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g);
         s = __builtin_fmaf(q4.x, kk.x, s);
         s = __builtin_fmaf(q4.y, kk.y, s);
         s = __builtin_fmaf(q4.z, kk.z, s);
@@ -1062,6 +1137,14 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
     return s;
   };
   load_k(ka, 0, koff0);
+  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
+    float ck[4];
+    head_constants32(r.qrow, pbk, lane, ck);
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ck[i];
+    }
+  }
   auto head = [&](int h, bool last) {
     load_k(kb, h, koff1);
     __builtin_amdgcn_sched_barrier(0);
@@ -1069,6 +1152,9 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
     if (!last) load_k(ka, h + 1, koff0);  // (the last head requests nothing it would have to wait out again)
     __builtin_amdgcn_sched_barrier(0);
     float s1 = score(kb, h);
+    const float ch = r.hsum[8 + h];
+    s0 = __builtin_fmaf(s0, uk256, ch);
+    s1 = __builtin_fmaf(s1, uk256, ch);
     if (r.alpha != 1.0f) {
       s0 = r.alpha * s0;
       s1 = r.alpha * s1;
@@ -1081,8 +1167,11 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
     const float e0 = j0 < S ? exp_p(s0 - m) : 0.0f;
     const float e1 = j1 < S ? exp_p(s1 - m) : 0.0f;
     const float sum = wave_sum(e0 + e1);
-    r.pbuf[h * 128 + j0] = e0 / sum;  // keys >= S: exactly 0
-    r.pbuf[h * 128 + j1] = e1 / sum;
+    const float p0 = e0 / sum, p1 = e1 / sum;  // keys >= S: exactly 0
+    r.pbuf[h * 128 + j0] = p0;
+    r.pbuf[h * 128 + j1] = p1;
+    const float ps = wave_sum(p0 + p1);  // P_h: lane L adds keys L and L + 64, then the butterfly
+    if (lane == 0) r.hsum[h] = ps;
   };
 #pragma unroll 1
   for (int h = 0; h < H - 1; ++h) head(h, false);
@@ -1115,6 +1204,7 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
   // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
   const int ph = (lane >> 3) * 128;
   const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  const float P = r.hsum[lane >> 3];
   f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
   const int ng = (lenf + 3) >> 2;  // key groups that hold a key with a non-zero weight
   auto group = [&](const v4i(&cur)[3], int g) {
@@ -1123,7 +1213,7 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
     const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
-      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c, uv256, pv4);
+      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c);
       const f2 pp = {pj[c], pj[c]}, va = {v4.x, v4.y}, vb = {v4.z, v4.w};
       oa = __builtin_elementwise_fma(pp, va, oa);
       ob = __builtin_elementwise_fma(pp, vb, ob);
@@ -1139,15 +1229,17 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  const float o0 = __builtin_fmaf(oa.x, uv256, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv256, pv4.y * P);
+  const float o2 = __builtin_fmaf(ob.x, uv256, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv256, pv4.w * P);
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1(oa.x, r.aq_o), quantize1(oa.y, r.aq_o), quantize1(ob.x, r.aq_o), quantize1(ob.y, r.aq_o));
+      pack4(quantize1(o0, r.aq_o), quantize1(o1, r.aq_o), quantize1(o2, r.aq_o), quantize1(o3, r.aq_o));
 }
 
 // The same for D = 512, d_head 64 ("base"). At K = 512 the shifted accumulator needs 25 bits, so
 // the cache holds the SIGNED one (|acc| <= 127 * 128 * 512 < 2^23) and the column's 127 colsum term
 // comes back here: c127 = float(127 colsum * 256) is exact, and so is float(acc * 256) + c127
-// (= 256 accS, |accS| < 2^24) -- from there on the operations of `dequant`.
-__device__ __forceinline__ f4 unpack24c(int d0, int d1, int d2, float u256, f4 pb, f4 c127) {
+// (= 256 accS, |accS| < 2^24): float(accS * 256) as unpack24f gives it, at one exact add per value.
+__device__ __forceinline__ f4 unpack24cf(int d0, int d1, int d2, f4 c127) {
   const int y0 = d0 << 8;
   const int y1 = (int)__builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x0504030cu);
   const int y2 = (int)__builtin_amdgcn_perm((unsigned)d2, (unsigned)d1, 0x0403020cu);
@@ -1156,12 +1248,6 @@ __device__ __forceinline__ f4 unpack24c(int d0, int d1, int d2, float u256, f4 p
   const f2 ca = {c127.x, c127.y}, cb = {c127.z, c127.w};
   a = a + ca;
   b = b + cb;
-  const f2 uu = {u256, u256};
-  a = a * uu;
-  b = b * uu;
-  const f2 pa = {pb.x, pb.y}, pc = {pb.z, pb.w};
-  a = a + pa;
-  b = b + pc;
   const f4 o = {a.x, a.y, b.x, b.y};
   return o;
 }
@@ -1192,22 +1278,25 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
 #pragma unroll
     for (int i = 0; i < 12; ++i)
       kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((12 * h + i) * S) * 16, KV_AUX));
-    float s = 0.0f;
+    // c_h = row sum of q_d * pbK[d] over the head's 64 columns (one per lane, the canonical 64-lane butterfly)
+    const float ch = wave_sum(r.qrow[h * DH + lane] * kpb[h * DH + lane]);
+    float t = 0.0f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = h * DH + 16 * c + 4 * g;
         const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
-        const f4 kk = unpack24c(group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 0), group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 1),
-                                group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 2), uk256, *(lcf4_ptr)(kpb + d0), *(lcf4_ptr)(kcs + d0));
-        s = __builtin_fmaf(q4.x, kk.x, s);
-        s = __builtin_fmaf(q4.y, kk.y, s);
-        s = __builtin_fmaf(q4.z, kk.z, s);
-        s = __builtin_fmaf(q4.w, kk.w, s);
+        const f4 kk = unpack24cf(group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 0), group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 1),
+                                 group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 2), *(lcf4_ptr)(kcs + d0));
+        t = __builtin_fmaf(q4.x, kk.x, t);
+        t = __builtin_fmaf(q4.y, kk.y, t);
+        t = __builtin_fmaf(q4.z, kk.z, t);
+        t = __builtin_fmaf(q4.w, kk.w, t);
       }
       __builtin_amdgcn_sched_barrier(0);  // one chunk's q / constant reads from LDS in flight
     }
+    float s = __builtin_fmaf(t, uk256, ch);
     if (r.alpha != 1.0f) s = r.alpha * s;
     s = s + mask;
     if (j >= S) s = lowest;
@@ -1215,10 +1304,12 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
     const float e = j < S ? exp_p(s - m) : 0.0f;
     const float sum = half_sum(e);
     const float p = e / sum;  // keys >= S: exactly 0
+    const float ps = half_sum(p);  // P_h
     if (lane < 32) {
       if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
       if (r.align && h == 0 && j < len) r.align[j] = p;
       r.pbuf[h * 32 + j] = p;
+      if (lane == 0) r.hsum[h] = ps;
     }
   }
   v4i vq[2][6];  // V rows in flight: two groups of four rows, two column slots of three planes each
@@ -1235,6 +1326,7 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
   const int ph0 = (lane >> 4) * 32, ph1 = (4 + (lane >> 4)) * 32;
   const f4 pv0 = *(lcf4_ptr)(vpb + 4 * lane), pv1 = *(lcf4_ptr)(vpb + D / 2 + 4 * lane);
   const f4 cv0 = *(lcf4_ptr)(vcs + 4 * lane), cv1 = *(lcf4_ptr)(vcs + D / 2 + 4 * lane);
+  const float P0 = r.hsum[lane >> 4], P1 = r.hsum[4 + (lane >> 4)];
   f2 o0a = {0.0f, 0.0f}, o0b = {0.0f, 0.0f}, o1a = {0.0f, 0.0f}, o1b = {0.0f, 0.0f};  // column pairs: one v_pk_fma_f32 each
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
@@ -1243,10 +1335,10 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
     const float pa[4] = {pa4.x, pa4.y, pa4.z, pa4.w}, pb_[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
-      const f4 v0 = unpack24c(group(cur[0], cur[1], cur[2], c, 0), group(cur[0], cur[1], cur[2], c, 1),
-                              group(cur[0], cur[1], cur[2], c, 2), uv256, pv0, cv0);
-      const f4 v1 = unpack24c(group(cur[3], cur[4], cur[5], c, 0), group(cur[3], cur[4], cur[5], c, 1),
-                              group(cur[3], cur[4], cur[5], c, 2), uv256, pv1, cv1);
+      const f4 v0 = unpack24cf(group(cur[0], cur[1], cur[2], c, 0), group(cur[0], cur[1], cur[2], c, 1),
+                               group(cur[0], cur[1], cur[2], c, 2), cv0);
+      const f4 v1 = unpack24cf(group(cur[3], cur[4], cur[5], c, 0), group(cur[3], cur[4], cur[5], c, 1),
+                               group(cur[3], cur[4], cur[5], c, 2), cv1);
       const f2 ppa = {pa[c], pa[c]}, ppb = {pb_[c], pb_[c]};
       o0a = __builtin_elementwise_fma(ppa, f2{v0.x, v0.y}, o0a);
       o0b = __builtin_elementwise_fma(ppa, f2{v0.z, v0.w}, o0b);
@@ -1258,10 +1350,14 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
     if (g + 2 < 8) load_v(vq[g % 2], g + 2);
     __builtin_amdgcn_sched_barrier(0);
   }
+  const float a0 = __builtin_fmaf(o0a.x, uv256, pv0.x * P0), a1 = __builtin_fmaf(o0a.y, uv256, pv0.y * P0);
+  const float a2 = __builtin_fmaf(o0b.x, uv256, pv0.z * P0), a3 = __builtin_fmaf(o0b.y, uv256, pv0.w * P0);
+  const float b0 = __builtin_fmaf(o1a.x, uv256, pv1.x * P1), b1 = __builtin_fmaf(o1a.y, uv256, pv1.y * P1);
+  const float b2 = __builtin_fmaf(o1b.x, uv256, pv1.z * P1), b3 = __builtin_fmaf(o1b.y, uv256, pv1.w * P1);
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1(o0a.x, r.aq_o), quantize1(o0a.y, r.aq_o), quantize1(o0b.x, r.aq_o), quantize1(o0b.y, r.aq_o));
+      pack4(quantize1(a0, r.aq_o), quantize1(a1, r.aq_o), quantize1(a2, r.aq_o), quantize1(a3, r.aq_o));
   *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) =
-      pack4(quantize1(o1a.x, r.aq_o), quantize1(o1a.y, r.aq_o), quantize1(o1b.x, r.aq_o), quantize1(o1b.y, r.aq_o));
+      pack4(quantize1(b0, r.aq_o), quantize1(b1, r.aq_o), quantize1(b2, r.aq_o), quantize1(b3, r.aq_o));
 }
 
 }  // namespace
@@ -1586,6 +1682,11 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           ar.qrow = (lcf_ptr)(xs + row * LDF);
           ar.arow = (lc_ptr)(A1 + row * LDA);
           ar.pbuf = (SLIMT_LDS float *)(pbufs + wave * PBW);
+          ar.hsum = (SLIMT_LDS float *)(red_v + wave * R);  // (the arg-max scratch: idle until the output layer)
+          ar.pbk = (gcf_ptr)a.kv_pb[l][0];
+          ar.pbv = (gcf_ptr)a.kv_pb[l][1];
+          ar.uk = a.kv_u[l][0];
+          ar.uv = a.kv_u[l][1];
           ar.S = S;
           ar.len = rr ? len[RT - 1] : len[0];
           ar.alpha = a.alpha;

@@ -504,8 +504,11 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
   __syncthreads();
   if (!live) return;
 
-  // 4. scores: alpha * (k-ascending fmaf chain), + mask (Modules.cc:45-67)
+  // 4. scores in the hoisted (PORTABLE) order (decode_fused.hip, unpack24f; oracle cross_attention_portable):
+  // the cache holds float(accS); t_j = k-ascending fmaf chain, s_j = alpha * fmaf(t_j, uK, c_h) + mask with
+  // c_h = canonical row sum of q_d * pbK[d] over the head's columns (one per lane; lanes past the head hold +0)
   const float *qrow = qbuf + wave * DH;
+  const float ch = wave_sum(lane < DH ? qrow[dc] * a.pbk[h * DH + dc] : 0.0f);
   float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
   for (int i = 0; i < DH / 4; ++i) {
@@ -531,6 +534,8 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
       s1 = __builtin_fmaf(q4.w, k4.w, s1);
     }
   }
+  s0 = __builtin_fmaf(s0, a.uk, ch);
+  s1 = __builtin_fmaf(s1, a.uk, ch);
   if (a.alpha != 1.0f) {
     s0 = a.alpha * s0;
     s1 = a.alpha * s1;
@@ -547,6 +552,7 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
   const float e1 = (lane + 64) < S ? exp_p(s1 - m) : 0.0f;
   const float sum = wave_sum(e0 + e1);
   const float p0 = e0 / sum, p1 = e1 / sum;
+  const float P = wave_sum(p0 + p1);  // P_h
   if (a.attn) {
     float *ap = a.attn + ((size_t)b * a.H + h) * S;
     if (lane < S) ap[lane] = p0;
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
       if (lane + 64 < len) al[lane + 64] = p1;
     }
   }
-  // 5. out[d] = key-ascending fmaf chain of p[j] * V[j][d]
+  // 5. out[d] = fmaf(w_d, uV, pbV[d] * P_h), w_d = key-ascending fmaf chain of p[j] * float(accV[j][d])
   float o = 0.0f;
 #pragma unroll
   for (int j = 0; j < VPF; ++j) {
@@ -594,6 +600,7 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
       }
     }
   }
+  o = __builtin_fmaf(o, a.uv, a.pbv[h * DH + dc] * P);
   if (lane < DH) {
     if (a.out_i8)
       a.out_i8[(size_t)b * D + h * DH + lane] = (int8_t)quantize1(o, a.a_quant_out);

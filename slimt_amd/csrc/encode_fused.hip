@@ -697,7 +697,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
           const int rr = t * 16 + lg * 4 + r;
           if (row_valid(rr)) {  // K cache layout [sentence][head][d/4][key][4]
             const size_t chunk = ((size_t)row_sentence(rr) * H + hh) * (DH / 4) + (d >> 2);
-            kout[(chunk * S + rr % S) * 4 + (d & 3)] = edequant(t ? c1[r] : c0[r], cs, wk.u, pb);
+            // the cache holds float(accS), exact; the decoder applies u and pb after its sums (kernels.h, kv24)
+            kout[(chunk * S + rr % S) * 4 + (d & 3)] = (float)((t ? c1[r] : c0[r]) + __mul24(127, cs));
           }
         }
     }
@@ -713,8 +714,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int rr = t * 16 + lg * 4 + r;
           if (row_valid(rr))
-            vout[((size_t)row_sentence(rr) * S + rr % S) * D + col] =
-                edequant(t ? c1[r] : c0[r], cs, wv.u, pb);
+            vout[((size_t)row_sentence(rr) * S + rr % S) * D + col] = (float)((t ? c1[r] : c0[r]) + __mul24(127, cs));
         }
     }
     lds_barrier();
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * rt + lg * 4 + r;
-            if (row < S) bstore(ro, voff, (16 * rt + r) * rstep, edequant(acc[rt][r], cs, W.u, pb));
+            if (row < S) bstore(ro, voff, (16 * rt + r) * rstep, (float)(acc[rt][r] + __mul24(127, cs)));  // float(accS): kernels.h, kv24
           }
         }
       __syncthreads();

@@ -654,7 +654,8 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         if (a.kv24) {
           *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = c;
         } else if (row_valid(rrow)) {
-          const float4 v = tdequant4(c, e, w.u);
+          // c is the shifted accumulator accS: the cache holds float(accS), exact (kernels.h, kv24)
+          const float4 v = {(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
           if (p == 0) {  // K cache layout [sentence][head][d/4][key][4]: the lane's 4 columns are one d/4 group
             const size_t chunk = (size_t)row_sentence(rrow) * (D / 4) + (col >> 2);
             *reinterpret_cast<float4 *>(out + (chunk * S + rrow % S) * 4) = v;

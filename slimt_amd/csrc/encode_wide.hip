@@ -629,7 +629,10 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         for (int rt = 0; rt < 2; ++rt) {
           const int rrow = rt * 16 + lr;
           if (!row_valid(rrow)) continue;
-          const float4 v = dequant4(rt ? c1 : c0, e, w.u);
+          // the f32 form holds float(accS) = float(acc + 127 colsum), exact (kernels.h, kv24)
+          const v4i &cc = rt ? c1 : c0;
+          const float4 v = {(float)(cc[0] + __mul24(127, e.cs[0])), (float)(cc[1] + __mul24(127, e.cs[1])),
+                            (float)(cc[2] + __mul24(127, e.cs[2])), (float)(cc[3] + __mul24(127, e.cs[3]))};
           if (p == 0) {  // K cache layout [sentence][head][d/4][key][4]: the lane's 4 columns are one d/4 group
             const int hh = col / DH, d = col % DH;
             const size_t chunk = ((size_t)row_sentence(rrow) * H + hh) * (DH / 4) + (d >> 2);

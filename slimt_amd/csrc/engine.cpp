@@ -975,10 +975,11 @@ EmbedArgs embed_args(const slimt_hip_ctx *c) {
 
 // affine on M rows, f32 in -> f32 out
 int run_affine_f32(slimt_hip_ctx *c, int family, const AffineW &w, const float *x, int M, float *y,
-                   int rows_per_block, int kc_S = 0, int kc_dh = 0) {
+                   int rows_per_block, int kc_S = 0, int kc_dh = 0, bool raw_acc = false) {
   GemmArgs g;
   g.kc_S = kc_S;
   g.kc_dh = kc_dh;
+  g.raw_acc = raw_acc;
   g.x_f32 = x;
   g.lda = w.w.K;
   g.M = M;
@@ -1261,11 +1262,12 @@ int decode_setup(slimt_hip_ctx *c, size_t n_sl) {
   float *kv = c->kv.as<float>();
   for (int l = 0; l < m->Ld && !c->kv_ready; ++l) {
     const DecLayerW &L = m->dec[(size_t)l];
-    // K in the coalescing-friendly cache layout [sentence][head][d/4][key][4]
+    // K in the coalescing-friendly cache layout [sentence][head][d/4][key][4]; both as float(accS): the
+    // attention applies the projections' u and pb after its sums (kernels.h, kv24)
     RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.k, c->x0.as<float>(), M,
-                         kv + (size_t)(2 * l) * M * D, rpb, S, D / m->H));
+                         kv + (size_t)(2 * l) * M * D, rpb, S, D / m->H, true));
     RCCHK(run_affine_f32(c, SLIMT_HIP_K_GEMM_ENC, L.attn.v, c->x0.as<float>(), M,
-                         kv + (size_t)(2 * l + 1) * M * D, rpb));
+                         kv + (size_t)(2 * l + 1) * M * D, rpb, 0, 0, true));
   }
   c->n_sl = (int)n_sl;
   if (n_sl) {
@@ -1337,6 +1339,10 @@ int decoder_layers(slimt_hip_ctx *c, float *d_align, int Tmax, const uint32_t *d
     a.k = kv + (size_t)(2 * l) * M * D;
     a.v = kv + (size_t)(2 * l + 1) * M * D;
     a.ldv = D;
+    a.uk = L.attn.k.w.u;
+    a.uv = L.attn.v.w.u;
+    a.pbk = L.attn.k.w.pb;
+    a.pbv = L.attn.v.w.pb;
     a.lengths = c->lengths.as<uint32_t>();
     a.alpha = 1.0f / std::sqrt(static_cast<float>(D / m->H));
     a.out_i8 = c->datt8.as<int8_t>();
@@ -1515,14 +1521,16 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.emb = embed_args(c);
     f.kv = c->kv.as<float>();
     f.kv24 = kv24;
-    for (int l = 0; l < m->Ld && kv24; ++l) {
+    for (int l = 0; l < m->Ld; ++l) {  // the projections' constants, applied after the attention's sums (kernels.h, kv24)
       const AffineW &wk = m->dec[(size_t)l].attn.k, &wv = m->dec[(size_t)l].attn.v;
       f.kv_pb[l][0] = wk.w.pb;
       f.kv_pb[l][1] = wv.w.pb;
       f.kv_cs[l][0] = wk.w.colsum;
       f.kv_cs[l][1] = wv.w.colsum;
-      f.kv_u256[l][0] = wk.w.u * (1.0f / 256.0f);  // exact scalings: the cached integers come back
-      f.kv_u256[l][1] = wv.w.u * (1.0f / 256.0f);  // as accS * 256 (decode_fused.hip, unpack24)
+      f.kv_u[l][0] = wk.w.u;
+      f.kv_u[l][1] = wv.w.u;
+      f.kv_u256[l][0] = wk.w.u * (1.0f / 256.0f);  // exact scalings: the packed integers come back
+      f.kv_u256[l][1] = wv.w.u * (1.0f / 256.0f);  // as accS * 256 (decode_fused.hip, unpack24f)
     }
     f.cells = c->state.as<float>();
     f.lengths = d_lengths;

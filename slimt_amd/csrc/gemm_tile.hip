@@ -271,7 +271,7 @@ bool gemm_tile_supported(const GemmArgs &a, int epilogue) {
   if (epilogue == EPI_PLAIN) {
     if (a.ldy % 4 != 0 || (reinterpret_cast<uintptr_t>(a.y) & 15)) return false;
     if (a.res && (a.ldres % 4 != 0 || (reinterpret_cast<uintptr_t>(a.res) & 15))) return false;
-    if (a.kc_S) return false;  // the K-cache layout store stays with gemm_rows_kernel
+    if (a.kc_S || a.raw_acc) return false;  // the K/V-cache stores stay with gemm_rows_kernel
   } else {
     if (a.ldy8 % 16 != 0 || (reinterpret_cast<uintptr_t>(a.y_i8) & 15)) return false;
   }

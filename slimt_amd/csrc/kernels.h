@@ -98,6 +98,9 @@ struct GemmArgs {
   //   [sentence][head][d/4][key][4]  (row = sentence*kc_S + key, col = head*kc_dh + d)
   // so that a wave reading one head's keys issues fully coalesced 16-byte loads.
   int kc_S = 0, kc_dh = 0;
+  // EPI_PLAIN only: store float(accS) (exact) instead of the dequantised value -- the decoder's cross-attention
+  // K / V cache, whose consumer applies u and pb after its sums (FusedDecodeArgs::kv24)
+  bool raw_acc = false;
   // EPI_RES_LN; EPI_PLAIN: nullable residual added to the output
   const float *res = nullptr;
   int ldres = 0;
@@ -222,9 +225,12 @@ struct DQAttnArgs {
   int B = 0, D = 0, H = 0, S = 0;
   RowSrc x;            // decoder state rows (pre-LN of the SSRU block)
   PreparedWeight wq;
-  const float *k = nullptr;  // cached K, layout [B][H][dh/4][S][4]
-  const float *v = nullptr;  // cached V [B*S][ldv]
+  const float *k = nullptr;  // cached K, layout [B][H][dh/4][S][4]; values float(accS) (FusedDecodeArgs::kv24)
+  const float *v = nullptr;  // cached V [B*S][ldv], likewise
   int ldv = 0;
+  // the K / V projections' unquantisation multipliers and prepared biases [D]: applied after the sums
+  float uk = 0.f, uv = 0.f;
+  const float *pbk = nullptr, *pbv = nullptr;
   const uint32_t *lengths = nullptr;
   float alpha = 0.f, eps = 1e-6f;
   int8_t *out_i8 = nullptr;  // joined heads, quantised for the O projection
@@ -255,7 +261,7 @@ struct FusedDecodeArgs {
   const uint32_t *out_n_dev = nullptr;  // nullable: number of output columns, on the device
   const uint32_t *shortlist = nullptr;  // nullable: column -> vocabulary id
   EmbedArgs emb;
-  const float *kv = nullptr;            // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]
+  const float *kv = nullptr;            // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]; values float(accS)
   float *cells = nullptr;               // [Ld][B][D] SSRU cells, used (and zeroed) when D > 256
   const uint32_t *lengths = nullptr;
   float alpha = 0.f, eps = 1e-6f;
@@ -295,13 +301,15 @@ struct FusedDecodeArgs {
   // three planes, so that loads stay 16 bytes per lane and contiguous across lanes:
   //   K [B][D/16][plane][S][16 B]             (16 consecutive columns of one key)
   //   V [B][ceil(S/4)][plane][D/4][16 B]      (4 keys x 4 consecutive columns, key-major)
-  // in the same per-layer planes as the f32 form. The attention rebuilds float(accS) * u + pb
-  // (Intgemm.inl.cc:146-153) in registers: the same floats as the f32 cache from 25 % fewer
-  // bytes, load instructions and registers in flight.
+  // in the same per-layer planes as the f32 form. BOTH forms cache the accumulator, not the dequantised
+  // value (the f32 form as float(accS), exact): the decoder's attention applies the projections' u and pb
+  // after its sums (decode_fused.hip, unpack24f: the hoisted PORTABLE order of the oracle), the same
+  // arithmetic from either form, the packed one from 25 % fewer bytes, load instructions and registers in flight.
   bool kv24 = false;
-  const float *kv_pb[4][2] = {};  // [layer][K, V]: the projections' prepared biases [D]
+  const float *kv_pb[4][2] = {};  // [layer][K, V]: the projections' prepared biases [D] (both forms)
   const int *kv_cs[4][2] = {};    // [layer][K, V]: their column sums [D] (D = 512: the cache holds the signed accumulator)
-  float kv_u256[4][2] = {};       // [layer][K, V]: unquantisation multiplier u / 256
+  float kv_u[4][2] = {};          // [layer][K, V]: unquantisation multiplier u (f32 form)
+  float kv_u256[4][2] = {};       // [layer][K, V]: u / 256 (packed form: the integers come back as accS * 256)
   bool ln_in_lds = false;  // set by the launcher: the LayerNorm constants of all layers fit LDS beside the rest
   bool kv_nt = false;  // non-temporal K/V cache loads (d_head 32 / 64 shapes; see decode_fused.hip)
   // with kv_nt: which caches are still read temporally, in eighths of a layer: sentence b's cache of

@@ -279,6 +279,7 @@ __device__ __forceinline__ void gemm_rows_body(const GemmKArgs &ka, int bx, int 
             float v = (float)accS * u;
             v = v + pb;
             if constexpr (EPI == EPI_PLAIN) {
+              if (a.raw_acc) v = (float)accS;
               if (a.kc_S) {
                 const int sb = row / a.kc_S, j = row - sb * a.kc_S;
                 const int h = col / a.kc_dh, d = col - h * a.kc_dh;
