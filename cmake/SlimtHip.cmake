@@ -33,7 +33,7 @@ if(SLIMT_HIP_PREBUILT)
 else()
   find_program(SLIMT_HIPCC hipcc HINTS /opt/rocm/bin ENV ROCM_PATH PATH_SUFFIXES bin REQUIRED)
   set(SLIMT_HIP_SOURCES kernels.hip gemm_tile.hip decode_kernels.hip decode_fused.hip encode_fused.hip encode_wide.hip encode_tall.hip shortlist.hip engine.cpp)
-  set(SLIMT_HIP_HEADERS kernels.h engine.h device_common.h)
+  set(SLIMT_HIP_HEADERS kernels.h engine.h device_common.h shortlist_device.h)
   list(TRANSFORM SLIMT_HIP_SOURCES PREPEND "${SLIMT_HIP_CSRC}/")
   list(TRANSFORM SLIMT_HIP_HEADERS PREPEND "${SLIMT_HIP_CSRC}/")
   set(SLIMT_HIP_SO "${CMAKE_CURRENT_BINARY_DIR}/libslimt_hip.so")

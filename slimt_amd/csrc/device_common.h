@@ -316,7 +316,9 @@ __device__ __forceinline__ void pack_weight_tile(const PackArgs &a, int ntile, i
       const int half = (ntile >> 4) & 1;
       quad[2 * half] = s;
       quad[2 * half + 1] = __float_as_int(pbv);
-      if (half == 0 && (ntile + 16) * 16 >= a.N) {
+      // (N: the matrix's real column count -- with a device-side count the partner tile past it returns
+      // early above and never writes its half, which an earlier, larger batch may have left behind)
+      if (half == 0 && (ntile + 16) * 16 >= N) {
         quad[2] = 0;
         quad[3] = 0;
       }

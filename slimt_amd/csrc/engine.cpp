@@ -774,7 +774,7 @@ void ctx_free(slimt_hip_ctx *c) {
                     &c->h8, &c->a8, &c->ticket, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
                     &c->state, &c->part_val, &c->part_idx, &c->prev, &c->out_ids, &c->out_len,
                     &c->finished, &c->n_finished, &c->align, &c->shortlist, &c->logits,
-                    &c->attn_dbg, &c->stamps, &c->dbg_embed, &c->dbg_layers, &c->sl_scratch, &c->n_sl_dev};
+                    &c->attn_dbg, &c->stamps, &c->dbg_embed, &c->dbg_layers, &c->sl_scratch, &c->n_sl_dev, &c->gen_flag};
   for (auto *b : bufs) b->release();
   free_affine(c->out_sl);
   if (c->n_finished_host) (void)hipHostFree(c->n_finished_host);
@@ -1059,10 +1059,24 @@ int check_batch(const slimt_hip_ctx *c, size_t B, size_t S) {
 // ctx->ids / ctx->lengths. Result in ctx->x0.
 // embedded: ctx->x0 already holds the transformed embedding [B,S,D] (Encoder::forward's
 // argument, Transformer.cc:57): the stage kernels run from there.
+// D = 256: 64-row tiles (encode_tall.hip: the O projection's and the FFN's weights cross the
+// CU's L2 path once per 64 rows) from 32 of them on: with other batches in flight they win
+// already there (B = 128: 23.3 -> 26.2 M tok/s, B = 64: level), a lone batch of that size pays
+// ~0.1 ms of latency; below that twice as many 32-row workgroups (and less padding) are better
+bool tall_encoder_chosen(const slimt_hip_ctx *c, int B, int S) {
+  const slimt_hip_model *m = c->model;
+  const bool tall_mid = S > 32 && c->encode_rows != 32 && tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S);
+  if (c->decode_mode == 1 || !(tall_mid || fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S))) return false;
+  return tall_mid || (tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S) &&
+                      (c->encode_rows == 64 || (c->encode_rows == 0 && tall_encode_grid(B, S, false) >= 32)));
+}
+
+// gen (nullable; only where tall_encoder_chosen): the batch's shortlist is generated inside the encoder launch
+// (kernels.h, FusedEncodeArgs::gen) -- its ids / count are pack->idx / pack->n_dev.
 int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layers,
                   const uint32_t *d_ids = nullptr, const uint32_t *d_lengths = nullptr,
                   const PackArgs *pack = nullptr, bool embedded = false, bool keep_out = true,
-                  bool kv24 = false) {
+                  bool kv24 = false, const ShortlistArgs *gen = nullptr) {
   // kv24 (translate_device only: the caller decodes with the persistent kernel's packed-cache
   // variant right behind this launch): the fused encoder leaves the 24-bit K/V cache
   // keep_out = false (the translate path): the persistent encoder leaves the decoder its K/V
@@ -1122,12 +1136,16 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     }
     f.ticket = c->ticket.as<unsigned>() + 1;  // over-subscribed launch, tiles claimed by ticket
     f.ticket_base = c->enc_ticket_base;
-    // D = 256: 64-row tiles (encode_tall.hip: the O projection's and the FFN's weights cross the
-    // CU's L2 path once per 64 rows) from 32 of them on: with other batches in flight they win
-    // already there (B = 128: 23.3 -> 26.2 M tok/s, B = 64: level), a lone batch of that size pays
-    // ~0.1 ms of latency; below that twice as many 32-row workgroups (and less padding) are better
-    const bool tall = tall_mid || (tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S) &&
-                                   (c->encode_rows == 64 || (c->encode_rows == 0 && tall_encode_grid(B, S, false) >= 32)));
+    const bool tall = tall_encoder_chosen(c, B, S);
+    if (gen) {
+      if (!tall || !pack) return fail(-1, "in-launch shortlist generation needs the 64-row encoder and a packing job");
+      HIPCHK(c->gen_flag.reserve(64));
+      if (c->gen_epoch == 0) HIPCHK(hipMemsetAsync(c->gen_flag.p, 0, 64, st));
+      f.gen = *gen;
+      f.gen_flag = c->gen_flag.as<unsigned>();
+      f.gen_epoch = ++c->gen_epoch;
+      if (c->gen_epoch == 0xffffffffu) c->gen_epoch = 0;  // (the flag is cleared again before epoch 1 is reused)
+    }
     {
       const double macs = (double)M * (m->Le * (4.0 * D * D + 2.0 * D * m->F) + m->Ld * 2.0 * D * D);
       ProfScope p(c, SLIMT_HIP_K_ENCODE_FUSED, macs, 0);
@@ -1412,7 +1430,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
                      const uint32_t *d_shortlist, size_t B, size_t S, size_t n_sl,
                      float limit_factor, uint32_t eos_id, uint32_t *d_out_ids, uint32_t *d_out_len,
                      float *d_align, int steps_hint, const uint32_t *d_n_sl = nullptr,
-                     float *align_out = nullptr, size_t n_sl_hint = 0) {
+                     float *align_out = nullptr, size_t n_sl_hint = 0, const ShortlistArgs *gen = nullptr) {
+  // gen (with d_n_sl, lean path, 64-row encoder): the shortlist is generated inside the encoder launch
   // n_sl_hint (with d_n_sl): what the host expects the device-side shortlist size to be (the size of
   // this context's previous generated shortlist): tuning decisions only
   // align_out != nullptr (persistent decoder only): d_align is a staging buffer in device memory and
@@ -1466,7 +1485,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
                                 m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, job));
     job.n_dev = d_n_sl;
     RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr, false, false,
-                        kv24));
+                        kv24, gen));
     c->n_sl = (int)n_sl;
     clk.lap(1);
   } else {
@@ -1759,14 +1778,20 @@ int translate_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const uint3
   const size_t n_hint = *hint;
   void *hint_dev = nullptr;
   if (hipHostGetDevicePointer(&hint_dev, hint, 0) == hipSuccess) a.n_out_host = static_cast<uint32_t *>(hint_dev);
-  HIPCHK(launch_shortlist_generate(a, st));
   const bool lean = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
                     (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                      long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
+  // With the 64-row encoder the generator runs INSIDE the encoder launch, by the workgroup that starts first
+  // (encode_tall.hip): as a launch of its own -- one workgroup -- it waited ~0.5 ms for a CU behind the
+  // other batches' persistent kernels (47 us alone). Same ids, same count, same consumers.
+  static const bool fold = !(std::getenv("SLIMT_SHORTLIST_FOLD") && std::getenv("SLIMT_SHORTLIST_FOLD")[0] == '0');
+  const bool in_launch = fold && lean && tall_encoder_chosen(ctx, (int)B, (int)S) &&
+                         ((size_t)(a.tgt_vocab + 31) / 32 + (size_t)(a.src_vocab + 31) / 32 + 1024) * 4 <= 64 * 1024;
+  if (!in_launch) HIPCHK(launch_shortlist_generate(a, st));
   if (lean)  // the size stays on the device: capacity V, actual count read by the kernels
     return translate_device(ctx, d_src_ids, d_lengths, ctx->shortlist.as<uint32_t>(), B, S,
                             (size_t)m->V, limit_factor, eos_id, d_out_ids, d_out_len, d_align,
-                            steps_hint, ctx->n_sl_dev.as<uint32_t>(), align_out, n_hint);
+                            steps_hint, ctx->n_sl_dev.as<uint32_t>(), align_out, n_hint, in_launch ? &a : nullptr);
   uint32_t n = 0;  // stage kernels are sized on the host: one 4-byte read-back
   HIPCHK(hipMemcpyAsync(&n, ctx->n_sl_dev.p, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

@@ -99,6 +99,8 @@ struct slimt_hip_model {
 struct slimt_hip_ctx {
   slimt_hip_model *model = nullptr;
   hipStream_t stream = nullptr;
+  slimt_hip::DevBuf gen_flag;         // in-launch shortlist generation: the word its publisher sets to gen_epoch (kernels.h, FusedEncodeArgs::gen)
+  unsigned gen_epoch = 0;
   hipEvent_t sync_event = nullptr;  // blocking-sync event of slimt_hip_ctx_synchronize (created on first use)
   std::vector<uint32_t> sl_host;    // the shortlist last uploaded by translate_host (re-uploaded only when it changes)
   bool own_stream = false;

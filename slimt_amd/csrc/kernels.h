@@ -330,6 +330,25 @@ bool fused_decode_long24_supported(int D, int F, int H, int Ld);
 int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced, bool kv24);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
 
+// ---- lexical shortlist generation (shortlist.hip) -------------------------------
+struct ShortlistArgs {
+  const unsigned long long *w2o = nullptr;  // [src_vocab + 1] offsets into lists
+  const uint32_t *lists = nullptr;          // sorted target ids per source word
+  unsigned long long frequent = 0;
+  int shared = 0;
+  int src_vocab = 0, tgt_vocab = 0;
+  const uint32_t *ids = nullptr;      // [B][S] padded source tokens
+  const uint32_t *lengths = nullptr;  // [B]
+  int B = 0, S = 0;
+  uint32_t *out = nullptr;    // [tgt_vocab] capacity
+  uint32_t *n_out = nullptr;  // [1]
+  uint32_t *n_out_host = nullptr;  // nullable: a second copy of the count (pinned host memory: the host's hint for its next launch)
+  uint32_t *scratch = nullptr;  // target + source bitmaps, zero on entry and on exit
+};
+size_t shortlist_lds_bytes(int src_vocab, int tgt_vocab);
+size_t shortlist_scratch_bytes(int src_vocab, int tgt_vocab);
+hipError_t launch_shortlist_generate(const ShortlistArgs &a, hipStream_t st);
+
 // ---- persistent fused encoder (encode_fused.hip) ------------------------------
 struct FusedEncLayerW {
   PreparedWeight q, k, v, o, ffn1, ffn2;
@@ -349,6 +368,14 @@ struct FusedEncodeArgs {
   bool kv24 = false;           // write the packed 24-bit form instead (FusedDecodeArgs::kv24)
   PackArgs pack;               // the batch's shortlisted output layer, packed by the
   int pack_tiles = 0;          // encoder's workgroups on the side (0 = nothing to pack)
+  // ShortlistGenerator::generate inside this launch (64-row encoder only; gen.w2o != nullptr): the workgroup
+  // that claims tile 0 generates the batch's shortlist (gen.out / gen.n_out = pack.idx / pack.n_dev) before its
+  // encoder work and publishes *gen_flag = gen_epoch; every workgroup packs its share of the output layer at
+  // the END of its encoder work, behind that flag (the publisher is running before any waiter can start:
+  // tiles are claimed in start order, and it waits for nobody).
+  ShortlistArgs gen;
+  unsigned *gen_flag = nullptr;
+  unsigned gen_epoch = 0;
   unsigned *ticket = nullptr;  // nullable: over-subscribed launch (see FusedDecodeArgs)
   unsigned ticket_base = 0;
   OccTrace trace;
@@ -380,25 +407,6 @@ hipError_t launch_highway(const float *x, const float *y, const float *g, size_t
 // [B,H,T,dh] <-> [B,T,H*dh] helpers for the op-level sdpa API
 hipError_t launch_transpose_heads(const float *in, int B, int d2, int d1, int d0, float *out,
                                   hipStream_t st);
-
-// ---- lexical shortlist generation (shortlist.hip) -------------------------------
-struct ShortlistArgs {
-  const unsigned long long *w2o = nullptr;  // [src_vocab + 1] offsets into lists
-  const uint32_t *lists = nullptr;          // sorted target ids per source word
-  unsigned long long frequent = 0;
-  int shared = 0;
-  int src_vocab = 0, tgt_vocab = 0;
-  const uint32_t *ids = nullptr;      // [B][S] padded source tokens
-  const uint32_t *lengths = nullptr;  // [B]
-  int B = 0, S = 0;
-  uint32_t *out = nullptr;    // [tgt_vocab] capacity
-  uint32_t *n_out = nullptr;  // [1]
-  uint32_t *n_out_host = nullptr;  // nullable: a second copy of the count (pinned host memory: the host's hint for its next launch)
-  uint32_t *scratch = nullptr;  // target + source bitmaps, zero on entry and on exit
-};
-size_t shortlist_lds_bytes(int src_vocab, int tgt_vocab);
-size_t shortlist_scratch_bytes(int src_vocab, int tgt_vocab);
-hipError_t launch_shortlist_generate(const ShortlistArgs &a, hipStream_t st);
 
 // ---- persistent per-sentence encoder for 32 < S <= 128 (kernels.hip) -----------
 // One workgroup owns one sentence for the whole encoder: the stages of the

@@ -1,0 +1,171 @@
+// Device-side pieces of the lexical shortlist generator (shortlist.hip): shared by its two kernels and by
+// the 64-row encoder, whose first workgroup generates the batch's shortlist inside the encoder launch
+// (encode_tall.hip) -- a one-workgroup kernel of its own waited about 0.5 ms for a free CU behind the
+// persistent kernels of the other batches.
+#pragma once
+#include "device_common.h"
+#include "kernels.h"
+
+namespace slimt_hip {
+
+// Pass 1 by `n_waves` waves (this one is `wave`): every source token ORs its aligned target ids into the
+// target bitmap `lb` (LDS), first occurrence of a source word only (claimed in the source bitmap `sb`, LDS
+// or global). A wave takes 64 tokens at a time, one per lane: the lane claims its source word and fetches
+// the word's list bounds -- three memory round trips for 64 tokens. The wave then walks the claimed tokens,
+// all lanes ORing 64 list entries per step into LDS, the next token's entries already in flight.
+__device__ __forceinline__ void shortlist_mark(const ShortlistArgs &a, uint32_t *lb, uint32_t *sb, int lane, int wave,
+                                               int n_waves) {
+  const int n_tok = a.B * a.S;
+  const uint32_t kNone = 0xffffffffu;
+  for (int base = wave * 64; base < n_tok; base += n_waves * 64) {
+    const int idx = base + lane;
+    unsigned long long begin = 0, end = 0;
+    if (idx < n_tok) {
+      const int b = idx / a.S, j = idx - b * a.S;
+      if (j < (int)a.lengths[b]) {  // padding is not a word (Input::words())
+        const uint32_t w = a.ids[idx];
+        if (w < (uint32_t)a.src_vocab) {  // out of range: undefined in the reference; ignored
+          if (a.shared && w < (uint32_t)a.tgt_vocab) atomicOr(&lb[w >> 5], 1u << (w & 31));
+          const uint32_t bit = 1u << (w & 31);
+          if (!(atomicOr(&sb[w >> 5], bit) & bit)) {
+            begin = a.w2o[w];
+            end = a.w2o[w + 1];
+          }
+        }
+      }
+    }
+    unsigned long long todo = __ballot(end > begin);
+    auto fetch = [&](int l) -> uint32_t {  // first 64 entries of lane l's list
+      const unsigned long long bl = __shfl(begin, l, 64), el = __shfl(end, l, 64);
+      return bl + lane < el ? a.lists[bl + lane] : kNone;
+    };
+    int cur_l = -1;
+    uint32_t cur = kNone;
+    if (todo) {
+      cur_l = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      cur = fetch(cur_l);
+    }
+    while (cur_l >= 0) {
+      int nxt_l = -1;
+      uint32_t nxt = kNone;
+      if (todo) {
+        nxt_l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        nxt = fetch(nxt_l);
+      }
+      if (cur != kNone) atomicOr(&lb[cur >> 5], 1u << (cur & 31));  // < tgt_vocab: checked at load
+      const unsigned long long bl = __shfl(begin, cur_l, 64), el = __shfl(end, cur_l, 64);
+      for (unsigned long long k = bl + 64 + lane; k < el; k += 64) {  // lists longer than 64
+        const uint32_t t = a.lists[k];
+        atomicOr(&lb[t >> 5], 1u << (t & 31));
+      }
+      cur_l = nxt_l;
+      cur = nxt;
+    }
+  }
+}
+
+// Pass 2 by one workgroup of 1024 threads over the complete target bitmap `tb` (LDS, TW words) with `scan`
+// (LDS, 1024 words): adds the `frequent` ids, counts, applies the multiple-of-eight patch and emits the set
+// bits in ascending order through a prefix sum of per-word popcounts. The caller has synchronised before.
+__device__ __forceinline__ void shortlist_compact(const ShortlistArgs &a, uint32_t *tb, uint32_t *scan, int tid) {
+  const int TW = (a.tgt_vocab + 31) / 32;
+  const unsigned long long nf = a.frequent < (unsigned long long)a.tgt_vocab
+                                    ? a.frequent : (unsigned long long)a.tgt_vocab;
+  for (int i = tid; i < (int)nf; i += 1024) atomicOr(&tb[i >> 5], 1u << (i & 31));
+  __syncthreads();
+  // contiguous words per thread, so that offsets follow the id order
+  const int wpt = (TW + 1023) / 1024;
+  const int w0 = tid * wpt, w1 = (w0 + wpt) < TW ? (w0 + wpt) : TW;
+  auto valid_mask = [&](int w) -> uint32_t {  // bits of word w that are real vocabulary ids
+    const int rem = a.tgt_vocab - 32 * w;
+    return rem >= 32 ? 0xffffffffu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+  };
+  uint32_t cnt = 0;
+  for (int w = w0; w < w1; ++w) cnt += __popc(tb[w] & valid_mask(w));
+  {  // total over the workgroup: per-wave shuffles, then 16 partial sums
+    uint32_t t = cnt;
+    for (int x = 32; x >= 1; x >>= 1) t += __shfl_xor(t, x, 64);
+    if ((tid & 63) == 0) scan[tid >> 6] = t;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // multiple-of-eight patch (Shortlist.cc:148-165): the lowest unset ids >=
+    // frequent, found by one wave 64 bitmap words at a time (the reference's
+    // id-by-id scan is O(V) when the table is nearly full)
+    const int lane = tid;
+    uint32_t ones = 0;
+    for (int i = 0; i < 16; ++i) ones += scan[i];
+    uint32_t need = (8u - ones % 8u) % 8u;
+    const unsigned long long f = a.frequent;
+    const int fw = f < (unsigned long long)a.tgt_vocab ? (int)(f >> 5) : TW;
+    for (int base = fw; base < TW && need > 0; base += 64) {
+      const int w = base + lane;
+      uint32_t z = 0;
+      if (w < TW) {
+        z = ~tb[w] & valid_mask(w);
+        if (w == fw) z &= ~((1u << (f & 31)) - 1u);
+      }
+      const uint32_t c = (uint32_t)__popc(z);
+      uint32_t inc = c;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += v;
+      }
+      const uint32_t exc = inc - c;
+      uint32_t take = exc < need ? (c < need - exc ? c : need - exc) : 0u;
+      uint32_t add = 0;
+      for (; take > 0; --take) {
+        const uint32_t low = z & (0u - z);
+        add |= low;
+        z ^= low;
+      }
+      if (add) tb[w] |= add;
+      const uint32_t total = __shfl(inc, 63, 64);
+      const uint32_t used = total < need ? total : need;
+      ones += used;
+      need -= used;
+    }
+    if (lane == 0) {
+      *a.n_out = ones;
+      if (a.n_out_host) *a.n_out_host = ones;
+    }
+  }
+  __syncthreads();
+  cnt = 0;
+  for (int w = w0; w < w1; ++w) cnt += __popc(tb[w] & valid_mask(w));
+  __syncthreads();
+  scan[tid] = cnt;
+  __syncthreads();
+  // inclusive Hillis-Steele scan over the 1024 per-thread counts
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t v = tid >= d ? scan[tid - d] : 0u;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  uint32_t off = scan[tid] - cnt;  // exclusive
+  // bucket sort (Shortlist.cc:168-173)
+  for (int w = w0; w < w1; ++w) {
+    uint32_t bits = tb[w] & valid_mask(w);
+    while (bits) {
+      const int bpos = __ffs((int)bits) - 1;
+      a.out[off++] = (uint32_t)(32 * w + bpos);
+      bits &= bits - 1;
+    }
+  }
+}
+
+// Both passes by ONE workgroup of 1024 threads, bitmaps in LDS (lds: TW + SW + 1024 words); no global scratch.
+__device__ __forceinline__ void shortlist_generate_block(const ShortlistArgs &a, uint32_t *lds, int tid) {
+  const int TW = (a.tgt_vocab + 31) / 32, SW = (a.src_vocab + 31) / 32;
+  uint32_t *tb = lds, *sb = tb + TW, *scan = sb + SW;
+  for (int i = tid; i < TW + SW; i += 1024) tb[i] = 0;
+  __syncthreads();
+  shortlist_mark(a, tb, sb, tid & 63, tid >> 6, 16);
+  __syncthreads();
+  shortlist_compact(a, tb, scan, tid);
+}
+
+}  // namespace slimt_hip
