@@ -831,7 +831,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
 // ---- packed K/V cache (FusedDecodeArgs::kv24): D = 256, d_head 32, S <= 32 -----------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// The cached cross-attention in the hoisted (PORTABLE) order -- oracle/slimt_oracle.c, cross_attention_portable:
+// The cached cross-attention in the hoisted (PORTABLE) order -- the CPU checker under oracle/ restates it as cross_attention_portable:
 // the projections' unquantisation multiplier u and prepared bias pb are per-column constants, so they are
 // applied AFTER the sums instead of to every cached value in every step:
 //   t_j = fmaf chain over the head's columns of q_d * float(accK[j][d]);  c_h = row sum of q_d * pbK[d]
@@ -1469,7 +1469,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           const unsigned to_come = a.xgrid - (arrived + 1u);
           const unsigned open_tiles = tiles - (claimed < tiles ? claimed : tiles);
           const bool take = open_tiles > 0 && (home || to_come < open_tiles);
-          const unsigned long long want = seen + (1ull << 32) + (take ? 1ull : 0ull);
+          // the two halves are counters of their own (modulo 2^32 each, like their bases): composed, not added as
+          // one 64-bit number, so that the claimed count's wrap-around never carries into the arrivals
+          const unsigned long long want =
+              ((unsigned long long)((unsigned)(seen >> 32) + 1u) << 32) | (unsigned long long)((unsigned)seen + (take ? 1u : 0u));
           if (__hip_atomic_compare_exchange_strong(a.xstate, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT)) {
             mine = take ? (int)claimed : 0x7fffffff;

@@ -108,9 +108,14 @@ Histories Model::forward(const Input &input) const {
                                            input.limit_factor(), config_.eos_id, out_ids.data(), out_len.data(),
                                            align.data());
   const std::string why = rc ? slimt_hip_last_error() : "";
-  {
+  if (rc && why.find("hip") != std::string::npos) {
+    // a HIP error (the library reports them as "file:line hipCall -> message") can come after part of the call
+    // has been queued: that context is not returned to the pool; an argument check fails before any launch
+    slimt_hip_ctx_destroy(lease.ctx);
+    lease.ctx = nullptr;
+  } else {
     std::lock_guard<std::mutex> lock(pool_mu_);
-    idle_.push_back(lease);  // a failed call leaves the context usable (arguments are checked before any launch)
+    idle_.push_back(lease);
   }
   if (rc) throw std::runtime_error((generator_ ? "slimt_hip_translate_generated: " : "slimt_hip_translate: ") + why);
   return collect(out_ids.data(), out_len.data(), align.data(), input.lengths().data(), B, S, T);

@@ -353,6 +353,13 @@ void Service::work(const Model *model, slimt_hip_shortlist *generator) {
       const std::exception_ptr error = std::current_exception();
       fail_batch(batch, error);
       fail_batch(mine.batch, error);
+      // a launch that failed half way (a HIP error behind the argument checks) may have queued work that still
+      // reads this slot's pinned ids / lengths or writes its outputs: drain the slot's stream before the next
+      // batch refills them (whatever the drain itself reports; the batch has failed already)
+      try {
+        mine.worker->wait();
+      } catch (...) {
+      }
     }
     if (!other.batch.empty()) {
       try {

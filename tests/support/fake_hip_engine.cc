@@ -35,6 +35,8 @@ int slimt_hip_model_create(const slimt_hip_param *, size_t, const slimt_hip_dims
 }
 int slimt_hip_model_destroy(slimt_hip_model *m) { delete m; return 0; }
 int slimt_hip_model_device(const slimt_hip_model *m) { return m ? m->device : -1; }
+int slimt_hip_hw_queues(void) { return 32; }
+int slimt_hip_request_hw_queues(int) { return 0; }
 int slimt_hip_model_info(const slimt_hip_model *m, int32_t *d, int32_t *f, int32_t *v, int32_t *h) {
   if (!m) return fail("model is NULL");
   if (d) *d = 64; if (f) *f = 128; if (v) *v = 512; if (h) *h = m->heads;
