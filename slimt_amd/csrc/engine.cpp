@@ -1624,7 +1624,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       if (c->decode_mode == 0 && f.rows_per_wg == 0 && gm->adaptive_rows) {
         for (int spw : {4, 8}) {
           if (fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, spw, kv24) != spw) break;
-          if (contexts * (size_t)(((int)B + spw - 1) / spw) <= (size_t)gm->decoder_budget) {
+          static const double oversub = std::getenv("SLIMT_ROWS_OVERSUB") ? std::atof(std::getenv("SLIMT_ROWS_OVERSUB")) : 1.0;
+          if ((double)(contexts * (size_t)(((int)B + spw - 1) / spw)) <= oversub * (double)gm->decoder_budget) {
             f.rows_per_wg = spw;
             rows = spw;
             tickets = (unsigned)fused_decode_grid((int)B, true, rows);

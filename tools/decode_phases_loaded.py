@@ -15,6 +15,8 @@ n_sl = 4096
 dev = torch.device("cuda", 0)
 m = synth.make_model("tiny11", seed=1234, eos_bias=-100.0)
 gm = capi.Model(m)
+if os.environ.get("SLIMT_DECODER_BUDGET"):
+    gm.set_decoder_budget(int(os.environ["SLIMT_DECODER_BUDGET"]))
 if os.environ.get("SLIMT_XCD_AFFINITY"):
     gm.set_xcd_affinity(int(os.environ["SLIMT_XCD_AFFINITY"]))
 ctxs = [capi.Context(gm, B, S) for _ in range(W)]
