@@ -88,6 +88,7 @@ def lib():
         L.so_encode.argtypes = [vp, vp, vp, sz, sz, vp]
         L.so_encoder_layer.argtypes = [vp, i32, vp, vp, sz, sz, vp, vp]
         L.so_decode_step.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp, sz, vp, vp]
+        L.so_cross_attention.argtypes = [vp, i32, vp, vp, vp, sz, sz, vp, vp]
         L.so_shortlist_checksum.restype = C.c_uint64
         L.so_shortlist_checksum.argtypes = [vp, sz]
         L.so_shortlist_parse.restype = i32
@@ -273,6 +274,16 @@ class OracleModel:
         out = np.empty_like(x)
         lib().so_encode(self.h, _p(x), _p(mask), B, S, _p(out))
         return out
+
+    def cross_attention(self, layer, yq, encoder_out, mask):
+        """The attention proper of decoder layer `layer` (0-based) on a projected query yq [B,D]: joined heads
+        [B,D] (before the output projection) and probabilities [B,H,S], in the current float order."""
+        yq, encoder_out, mask = _f32(yq), _f32(encoder_out), _f32(mask)
+        B, S, _ = encoder_out.shape
+        out = np.empty((B, self.D), dtype=np.float32)
+        attn = np.empty((B, self.H, S), dtype=np.float32)
+        lib().so_cross_attention(self.h, layer, _p(yq), _p(encoder_out), _p(mask), B, S, _p(out), _p(attn))
+        return out, attn
 
     def decode_step(self, encoder_out, mask, states, prev, shortlist):
         """states: f32 [Ld,B,D], updated in place. Returns logits, attn."""

@@ -1006,6 +1006,34 @@ static void cross_attention_forward_portable(const so_model *m, const so_attn_p 
   free(xpy); free(yo); free(joined); free(yq);
 }
 
+/* The attention proper of a decoder layer's cross-attention, as an op of its own (tests: the PORTABLE
+ * order against the FAITHFUL one on the same projected query): yq [B,D] = the Q projection's output,
+ * out [B,D] = the joined heads BEFORE the output projection, attn [B,H,S]. FAITHFUL: K / V dequantised
+ * element by element, then scaled_dot_product_attention (Modules.cc:24-86, 287-306); PORTABLE: the
+ * hoisted order above. */
+void so_cross_attention(const so_model *m, int layer, const float *yq, const float *encoder_out,
+                        const float *mask, size_t B, size_t S, float *out, float *attn) {
+  use_model_threads(m);
+  const so_attn_p *a = &m->dec[layer].attn;
+  if (g_mode == SO_PORTABLE) {
+    ((so_model *)m)->kv_acc_src = NULL;
+    cross_attention_portable(m, a, layer, yq, encoder_out, mask, B, S, out, attn);
+    return;
+  }
+  size_t D = (size_t)m->D, H = (size_t)m->H, dh = D / H;
+  float *yk = (float *)malloc(B * S * D * sizeof(float)), *yv = (float *)malloc(B * S * D * sizeof(float));
+  float *sk = (float *)malloc(B * S * D * sizeof(float)), *sv = (float *)malloc(B * S * D * sizeof(float));
+  float *sq = (float *)malloc(B * D * sizeof(float)), *ao = (float *)malloc(B * D * sizeof(float));
+  apply_affine(m, &a->k, encoder_out, B * S, yk);
+  apply_affine(m, &a->v, encoder_out, B * S, yv);
+  so_transpose_3120(yq, B, 1, H, dh, sq);
+  so_transpose_3120(yk, B, S, H, dh, sk);
+  so_transpose_3120(yv, B, S, H, dh, sv);
+  so_sdpa(sq, sk, sv, mask, B, H, 1, S, dh, ao, attn);
+  so_transpose_3120(ao, B, H, 1, dh, out);
+  free(ao); free(sq); free(sv); free(sk); free(yv); free(yk);
+}
+
 /* Decoder::step (Transformer.cc:120-183) with DecoderLayer::forward
  * (Modules.cc:237-259). */
 void so_decode_step(const so_model *m, const float *encoder_out,

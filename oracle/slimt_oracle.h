@@ -132,6 +132,10 @@ void so_encoder_layer(const so_model *m, int layer, const float *x,
                       float *attn /* nullable [B,H,S,S] */);
 /* Transformer.cc:120-183. states [Ld][B,D] in/out; prev NULL => step 0;
  * shortlist NULL => full vocab. logits [B,N]; attn [B,H,1,S] (last layer) */
+/* the attention proper of decoder layer `layer`'s cross-attention (0-based) on an already projected query:
+ * FAITHFUL = dequantised K / V + scaled_dot_product_attention, PORTABLE = the hoisted order (slimt_oracle.c) */
+void so_cross_attention(const so_model *m, int layer, const float *yq, const float *encoder_out,
+                        const float *mask, size_t B, size_t S, float *out, float *attn);
 void so_decode_step(const so_model *m, const float *encoder_out,
                     const float *mask, size_t B, size_t S, float *states,
                     const uint32_t *prev, const uint32_t *shortlist,

@@ -294,3 +294,38 @@ def test_oracle_model_is_stateless_across_batches(oracle, synth_models):
         for a, b in zip(got[:3], fresh[:3]):
             assert np.array_equal(a, b), seed
     oracle.set_mode(oracle.FAITHFUL)
+
+
+@pytest.mark.parametrize("preset,B,S", [("mini", 5, 23), ("tiny11", 6, 32), ("tiny11", 3, 100), ("base", 4, 17)])
+def test_hoisted_cross_attention_within_tolerance_of_the_literal_order(oracle, synth_models, preset, B, S):
+    """The PORTABLE order of the decoder's cross-attention applies the K / V projections' unquantisation
+    multiplier and prepared bias AFTER the attention's sums (oracle/slimt_oracle.c, cross_attention_portable);
+    the reference dequantises every element first (Intgemm.inl.cc:146-153, Modules.cc:24-86 = FAITHFUL). Same
+    real numbers, other roundings: on the same projected query both the probabilities and the context vectors
+    agree within north_star's 1e-4 (measured ~1e-6 relative), masked keys are exactly 0 in both, rows sum to 1.
+    (An all-masked row is compared like any other: its scores sit next to -1e8, where both orders round alike.)"""
+    from slimt_amd import synth
+    m = synth_models(preset, eos_bias=1.0)
+    om = oracle.OracleModel(m)
+    ids, lens = synth.make_batch(m.V, B, S, ragged=True, seed=77)
+    lens = lens.copy()
+    lens[1] = 0  # an empty sentence: everything masked, uniform weights
+    mask = oracle.make_mask(lens, S)
+    oracle.set_mode(oracle.FAITHFUL)
+    enc = om.encode(om.embed(ids), mask)
+    r = np.random.Generator(np.random.PCG64(5))
+    yq = r.normal(0, 1.5, size=(B, m.D)).astype(np.float32)
+    for layer in range(m.dec_layers):
+        oracle.set_mode(oracle.FAITHFUL)
+        f_out, f_attn = om.cross_attention(layer, yq, enc, mask)
+        oracle.set_mode(oracle.PORTABLE)
+        p_out, p_attn = om.cross_attention(layer, yq, enc, mask)
+        oracle.set_mode(oracle.FAITHFUL)
+        assert np.abs(p_attn - f_attn).max() <= 1e-4
+        scale = max(1.0, float(np.abs(f_out).max()))
+        assert np.abs(p_out - f_out).max() <= 1e-4 * scale, (np.abs(p_out - f_out).max(), scale)
+        assert np.median(np.abs(p_out - f_out)) <= 2e-6 * scale
+        for b in range(B):
+            if lens[b] > 0:  # (the empty sentence: every key carries the mask, the weights are whatever survives next to -1e8)
+                assert not p_attn[b, :, lens[b]:].any() and not f_attn[b, :, lens[b]:].any()
+        assert np.allclose(p_attn.sum(axis=2), 1.0, atol=1e-5)
