@@ -4,8 +4,12 @@
 # Order matters: the PMC passes come first and their digests are copied into profiles/ (of this
 # box's copy of the repo) and named in the manifest profiles/CURRENT BEFORE the final bench.py run, so that the
 # bench line's `traffic` and `mfma_busy_frac` cite files of the same tag (copy gpurun_out/CURRENT to profiles/ too).
+# Stage (2nd argument): a = counters, bench line of record, phases, occupancy; b = the other shapes, the 2-rank
+# rehearsal, service and text benches; all (default) = both (more than one gpurun call's 20 minutes).
 TAG=${1:-r03}
+STAGE=${2:-all}
 mkdir -p gpurun_out
+if [ "$STAGE" != "b" ]; then
 NO_CPU=1 WITH_BASE=1 tools/profile_round.sh $TAG || exit 1
 tools/pmc_sq.sh $TAG > gpurun_out/${TAG}_sq_run.log 2>&1 || { echo "pmc_sq failed"; tail -5 gpurun_out/${TAG}_sq_run.log; exit 1; }
 PRESET=base BATCH=2048 tools/pmc_sq.sh ${TAG}_base > gpurun_out/${TAG}_base_sq_run.log 2>&1 || { echo "pmc_sq base failed"; exit 1; }
@@ -34,15 +38,18 @@ for k in ("model_forward", "model_forward_no_alignments", "model_forward_per_bat
 print(f"  cpu_baseline: {d['cpu_baseline']['value']:.0f} tok/s on {d['cpu_baseline']['cores']} cores")
 PY
 timeout -k 10 300 python bench.py --preset base --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_base_bench.json 2> gpurun_out/${TAG}_base_bench.err || exit 1
-timeout -k 10 120 python tools/decode_phases.py 256 > gpurun_out/${TAG}_phases.txt 2>&1 || exit 1
+SLIMT_DECODE_MODE=2 timeout -k 10 120 python tools/decode_phases.py 256 > gpurun_out/${TAG}_phases.txt 2>&1 || exit 1  # 16 sentences per workgroup (the loaded tiling)
+for mode in 4 5; do SLIMT_DECODE_MODE=$mode timeout -k 10 120 python tools/decode_phases.py 256 > gpurun_out/${TAG}_phases_mode$mode.txt 2>&1 || exit 1; done
 timeout -k 10 120 python tools/decode_phases_loaded.py > gpurun_out/${TAG}_phases_loaded.txt 2>&1 || exit 1
 timeout -k 10 120 python tools/decode_phases_loaded.py 20 64 128 > gpurun_out/${TAG}_phases_loaded_S128.txt 2>&1 || exit 1
 timeout -k 10 120 python tools/encode_wide_phases.py 256 tiny11 > gpurun_out/${TAG}_encoder_phases.txt 2>&1 || exit 1
 timeout -k 10 120 python tools/encode_wide_phases.py 256 base > gpurun_out/${TAG}_base_encoder_phases.txt 2>&1 || exit 1
 timeout -k 10 200 python tools/occupancy_trace.py 20 480 256 > gpurun_out/${TAG}_occupancy.txt 2>&1 || exit 1
 grep -E "total" gpurun_out/${TAG}_phases_loaded.txt gpurun_out/${TAG}_encoder_phases.txt
+fi
+[ "$STAGE" = "a" ] && exit 0
 {
-  tools/sweep.sh "--forward-steps 0" "--forward-steps 0 --batch 64" "--forward-steps 0 --batch 512 --shortlist 0" \
+  tools/sweep.sh "--forward-steps 0" "--forward-steps 0 --batch 64" "--forward-steps 0 --batch 64 --adaptive-rows 0" "--forward-steps 0 --batch 512 --shortlist 0" \
     "--forward-steps 0 --batch 512 --workers 12" "--forward-steps 0 --batch 128 --src-len 64" "--forward-steps 0 --batch 64 --src-len 96" \
     "--forward-steps 0 --batch 64 --src-len 128" "--forward-steps 0 --ragged" "--forward-steps 0 --preset base" \
     "--total-sentences 4096 --batch 512 --steps 10" "--total-sentences 4096 --batch 256 --steps 10" \
