@@ -9,6 +9,7 @@
 // weights stream from L2 in MFMA-fragment order. Arithmetic is bit-identical
 // to the layer-by-layer kernels (kernels.hip).
 #include "device_common.h"
+#include "shortlist_device.h"
 #include "kernels.h"
 
 namespace slimt_hip {
@@ -232,7 +233,12 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
 
   // ---- side job: the batch's shortlisted output layer (used by the decoder
   // launch that follows this one in the stream; independent of the encoder) ----
-  for (int pt = tile; pt < a.pack_tiles; pt += n_tiles) pack_weight_tile(a.pack, pt, tid, 1024);
+  const bool gen_here = a.gen.w2o != nullptr;  // the batch's shortlist is generated in this launch (encode_tall.hip): packed at the end
+  if (!gen_here) {
+    for (int pt = tile; pt < a.pack_tiles; pt += n_tiles) pack_weight_tile(a.pack, pt, tid, 1024);
+  } else if (tile == 0) {
+    shortlist_publish_in_launch(a.gen, reinterpret_cast<uint32_t *>(smem), a.gen_flag, a.gen_epoch, tid);
+  }
 
   // ---- embedding (Model.cc:195-197) ----------------------------------------
   for (int r = wave; r < ER; r += ENW) {
@@ -718,6 +724,10 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         }
     }
     lds_barrier();
+  }
+  if (gen_here) {
+    shortlist_await_in_launch(a.gen_flag, a.gen_epoch, tid);
+    for (int pt = tile; pt < a.pack_tiles; pt += n_tiles) pack_weight_tile(a.pack, pt, tid, 1024);
   }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);
 }
@@ -1269,6 +1279,9 @@ hipError_t launch_encode_fused(const FusedEncodeArgs &a, int D, int F, int H, hi
   if (wide_encode_supported(D, F, H, a.Le, a.Ld, a.S)) return launch_encode_wide(a, st);
   const dim3 grid(fused_encode_grid(a.B, a.S, a.ticket != nullptr));
   const size_t lds = fused_encode_lds_bytes(D);
+  if (a.gen.w2o && (!a.ticket || !a.gen_flag || !a.pack_tiles ||
+                    shortlist_in_launch_lds_bytes(a.gen.src_vocab, a.gen.tgt_vocab) > lds))
+    return hipErrorInvalidValue;  // (in-launch shortlist generation: see launch_encode_tall)
   hipError_t e = hipSuccess;
 #define SLIMT_ENC_CASE(KSF_)                                                                   \
   if (F == 64 * KSF_) {                                                                        \

@@ -244,17 +244,8 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
   } else if (tile == 0) {
     // ShortlistGenerator::generate (Shortlist.cc:115-175; Model.cc:117-120) by the workgroup that started first,
-    // in the still unused LDS, then published for the others (kernels.h, FusedEncodeArgs::gen): plain stores,
-    // every storing wave drained, the workgroup's barrier, ONE agent-scope release, the flag.
-    shortlist_generate_block(a.gen, reinterpret_cast<uint32_t *>(smem), tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.gen_flag, a.gen_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();  // the LDS is the encoder's from here
+    // in the still unused LDS, then published for the others (shortlist_device.h)
+    shortlist_publish_in_launch(a.gen, reinterpret_cast<uint32_t *>(smem), a.gen_flag, a.gen_epoch, tid);
   }
 
   // A round's projections are 3 x 8 column tiles (Q, K, V of four heads) x 4 row tiles on 16 waves:
@@ -727,17 +718,8 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   }
   if (gen_here) {
     // the shortlist of this launch: wait for its publisher (running since before this workgroup started, and
-    // waiting for nobody: ~40 us of work against this workgroup's ~250), one relaxed poll loop by one lane,
-    // ONE agent-scope acquire, the barrier; then this workgroup's share of the output layer
-    if (tid == 0) {
-      // (bounded like every spin: ~2 s; unreachable while the launch is ticketed, see launch_encode_tall)
-      for (unsigned spin = 0; spin < (1u << 24) &&
-                              __hip_atomic_load(a.gen_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.gen_epoch; ++spin)
-        __builtin_amdgcn_s_sleep(8);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
+    // waiting for nobody: ~40 us of work against this workgroup's ~250); then this workgroup's share of the output layer
+    shortlist_await_in_launch(a.gen_flag, a.gen_epoch, tid);
     for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
   }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);
@@ -770,7 +752,7 @@ hipError_t launch_encode_tall(const FusedEncodeArgs &a, int F, hipStream_t st) {
   // in-launch shortlist generation: tiles must be claimed in START order (the publisher is then running before
   // any waiter exists), and the two bitmaps + the scan array must fit the LDS the encoder is not using yet
   if (a.gen.w2o && (!a.ticket || !a.gen_flag || !a.pack_tiles ||
-                    ((size_t)(a.gen.tgt_vocab + 31) / 32 + (size_t)(a.gen.src_vocab + 31) / 32 + 1024) * 4 > tall_encode_lds_bytes(F)))
+                    shortlist_in_launch_lds_bytes(a.gen.src_vocab, a.gen.tgt_vocab) > tall_encode_lds_bytes(F)))
     return hipErrorInvalidValue;
   const dim3 grid(tall_encode_grid(a.B, a.S, a.ticket != nullptr));
   const size_t lds = tall_encode_lds_bytes(F);

@@ -25,6 +25,7 @@
 // to the layer-by-layer kernels (kernels.hip) and to the oracle's portable order.
 // Reference: Model.cc:195-201, Transformer.cc:57-69, Modules.cc:287-334, TensorOps.cc:542-580.
 #include "device_common.h"
+#include "shortlist_device.h"
 #include "kernels.h"
 
 namespace slimt_hip {
@@ -218,7 +219,12 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   auto row_valid = [&](int r) { return r < rows_used && row_sentence(r) < B; };
 
   // side job: the batch's shortlisted output layer (used by the decoder launch behind this one)
-  for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+  const bool gen_here = a.gen.w2o != nullptr;  // the batch's shortlist is generated in this launch (encode_tall.hip): packed at the end
+  if (!gen_here) {
+    for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+  } else if (tile == 0) {
+    shortlist_publish_in_launch(a.gen, reinterpret_cast<uint32_t *>(smem), a.gen_flag, a.gen_epoch, tid);
+  }
 
   // ---- embedding (Model.cc:195-197) into the owner's registers ------------------------------
   float x[2][KSD];
@@ -687,6 +693,10 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       }
     }
   }
+  if (gen_here) {
+    shortlist_await_in_launch(a.gen_flag, a.gen_epoch, tid);
+    for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+  }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);
 }
 
@@ -705,6 +715,9 @@ bool wide_encode_supported(int D, int F, int H, int Le, int Ld, int S) {
 }
 
 hipError_t launch_encode_wide(const FusedEncodeArgs &a, hipStream_t st) {
+  if (a.gen.w2o && (!a.ticket || !a.gen_flag || !a.pack_tiles ||
+                    shortlist_in_launch_lds_bytes(a.gen.src_vocab, a.gen.tgt_vocab) > wide_encode_lds_bytes()))
+    return hipErrorInvalidValue;  // (in-launch shortlist generation: see launch_encode_tall)
   const dim3 grid(fused_encode_grid(a.B, a.S, a.ticket != nullptr));
   const size_t lds = wide_encode_lds_bytes();
   auto k = encode_wide_kernel<8, 32, 64>;

@@ -1071,7 +1071,15 @@ bool tall_encoder_chosen(const slimt_hip_ctx *c, int B, int S) {
                       (c->encode_rows == 64 || (c->encode_rows == 0 && tall_encode_grid(B, S, false) >= 32)));
 }
 
-// gen (nullable; only where tall_encoder_chosen): the batch's shortlist is generated inside the encoder launch
+// embedding + every encoder layer + the decoder's K/V cache in one launch of encode_tall / encode_fused / encode_wide
+bool fused_encoder_chosen(const slimt_hip_ctx *c, int B, int S) {
+  (void)B;
+  const slimt_hip_model *m = c->model;
+  const bool tall_mid = S > 32 && c->encode_rows != 32 && tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S);
+  return c->decode_mode != 1 && (tall_mid || fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S));
+}
+
+// gen (nullable; only where fused_encoder_chosen): the batch's shortlist is generated inside the encoder launch
 // (kernels.h, FusedEncodeArgs::gen) -- its ids / count are pack->idx / pack->n_dev.
 int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layers,
                   const uint32_t *d_ids = nullptr, const uint32_t *d_lengths = nullptr,
@@ -1138,7 +1146,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     f.ticket_base = c->enc_ticket_base;
     const bool tall = tall_encoder_chosen(c, B, S);
     if (gen) {
-      if (!tall || !pack) return fail(-1, "in-launch shortlist generation needs the 64-row encoder and a packing job");
+      if (!pack) return fail(-1, "in-launch shortlist generation needs a packing job");
       HIPCHK(c->gen_flag.reserve(64));
       if (c->gen_epoch == 0) HIPCHK(hipMemsetAsync(c->gen_flag.p, 0, 64, st));
       f.gen = *gen;
@@ -1786,8 +1794,10 @@ int translate_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const uint3
   // (encode_tall.hip): as a launch of its own -- one workgroup -- it waited ~0.5 ms for a CU behind the
   // other batches' persistent kernels (47 us alone). Same ids, same count, same consumers.
   static const bool fold = !(std::getenv("SLIMT_SHORTLIST_FOLD") && std::getenv("SLIMT_SHORTLIST_FOLD")[0] == '0');
-  const bool in_launch = fold && lean && tall_encoder_chosen(ctx, (int)B, (int)S) &&
-                         ((size_t)(a.tgt_vocab + 31) / 32 + (size_t)(a.src_vocab + 31) / 32 + 1024) * 4 <= 64 * 1024;
+  // (the persistent encoders of sentences up to 64 tokens: 64-row / 32-row tiles at D = 256, D = 512; the
+  // per-sentence kernel for 65..128 tokens keeps the two-kernel generator)
+  const bool in_launch = fold && lean && fused_encoder_chosen(ctx, (int)B, (int)S) &&
+                         shortlist_in_launch_lds_bytes(a.src_vocab, a.tgt_vocab) <= 64 * 1024;
   if (!in_launch) HIPCHK(launch_shortlist_generate(a, st));
   if (lean)  // the size stays on the device: capacity V, actual count read by the kernels
     return translate_device(ctx, d_src_ids, d_lengths, ctx->shortlist.as<uint32_t>(), B, S,

@@ -346,6 +346,10 @@ struct ShortlistArgs {
   uint32_t *scratch = nullptr;  // target + source bitmaps, zero on entry and on exit
 };
 size_t shortlist_lds_bytes(int src_vocab, int tgt_vocab);
+// LDS of the one-workgroup form (both bitmaps + the scan array), and whether an encoder launch can host it
+inline size_t shortlist_in_launch_lds_bytes(int src_vocab, int tgt_vocab) {
+  return ((size_t)(tgt_vocab + 31) / 32 + (size_t)(src_vocab + 31) / 32 + 1024) * sizeof(uint32_t);
+}
 size_t shortlist_scratch_bytes(int src_vocab, int tgt_vocab);
 hipError_t launch_shortlist_generate(const ShortlistArgs &a, hipStream_t st);
 
@@ -368,7 +372,7 @@ struct FusedEncodeArgs {
   bool kv24 = false;           // write the packed 24-bit form instead (FusedDecodeArgs::kv24)
   PackArgs pack;               // the batch's shortlisted output layer, packed by the
   int pack_tiles = 0;          // encoder's workgroups on the side (0 = nothing to pack)
-  // ShortlistGenerator::generate inside this launch (64-row encoder only; gen.w2o != nullptr): the workgroup
+  // ShortlistGenerator::generate inside this launch (the S <= 64 encoders; gen.w2o != nullptr): the workgroup
   // that claims tile 0 generates the batch's shortlist (gen.out / gen.n_out = pack.idx / pack.n_dev) before its
   // encoder work and publishes *gen_flag = gen_epoch; every workgroup packs its share of the output layer at
   // the END of its encoder work, behind that flag (the publisher is running before any waiter can start:

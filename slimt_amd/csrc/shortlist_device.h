@@ -168,4 +168,35 @@ __device__ __forceinline__ void shortlist_generate_block(const ShortlistArgs &a,
   shortlist_compact(a, tb, scan, tid);
 }
 
+// ---- ShortlistGenerator::generate inside an encoder launch (kernels.h, FusedEncodeArgs::gen) ------------------
+// The workgroup that claims tile 0 -- the first to START: tiles are claimed by ticket, so it is running before any
+// waiter exists, and it waits for nobody -- generates the batch's shortlist in the LDS the encoder is not using yet
+// and publishes it: plain stores, every storing wave drained, the workgroup's barrier, ONE agent-scope release, the
+// flag. `lds`: shortlist_in_launch_lds_bytes() of dynamic LDS. Ends with a barrier: the LDS is the caller's again.
+__device__ __forceinline__ void shortlist_publish_in_launch(const ShortlistArgs &a, uint32_t *lds, unsigned *flag,
+                                                            unsigned epoch, int tid) {
+  shortlist_generate_block(a, lds, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+}
+
+// Every workgroup, at the end of its encoder work and before it packs its share of the shortlisted output layer:
+// one relaxed poll loop by one lane (bounded like every spin: ~2 s; unreachable while the launch is ticketed), ONE
+// agent-scope acquire, the barrier; plain loads of the ids / the count behind it.
+__device__ __forceinline__ void shortlist_await_in_launch(unsigned *flag, unsigned epoch, int tid) {
+  if (tid == 0) {
+    for (unsigned spin = 0; spin < (1u << 24) && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin)
+      __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
 }  // namespace slimt_hip

@@ -10,4 +10,11 @@ for fold in 0 1 0 1; do
   echo -n "fold=$fold "
   SLIMT_SHORTLIST_FOLD=$fold tools/sweep.sh "--forward-steps 20 --sustained-steps 0 --steps 10" || exit 1
 done > gpurun_out/${TAG}_forward.txt 2>&1
+for fold in 0 1; do
+  echo -n "base fold=$fold "
+  SLIMT_SHORTLIST_FOLD=$fold tools/sweep.sh "--preset base --forward-steps 12 --sustained-steps 0 --steps 8" || exit 1
+done >> gpurun_out/${TAG}_forward.txt 2>&1
 cat gpurun_out/${TAG}_forward.txt
+timeout -k 10 300 python tools/stress_generated.py 6 4 > gpurun_out/${TAG}_stress.txt 2>&1 || { echo "stress failed"; tail -5 gpurun_out/${TAG}_stress.txt; exit 1; }
+timeout -k 10 300 python tools/stress_generated.py 4 3 base >> gpurun_out/${TAG}_stress.txt 2>&1 || { echo "stress (base) failed"; tail -5 gpurun_out/${TAG}_stress.txt; exit 1; }
+grep mismatches gpurun_out/${TAG}_stress.txt

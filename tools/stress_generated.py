@@ -2,7 +2,7 @@
 others acquire) under uneven load -- W contexts translate batches of different sizes back to back, each batch with its
 own lexical shortlist, half of them while a neighbour keeps every CU busy with a larger batch; every result is compared
 with the CPU checker (its generator + its translation, PORTABLE order), every word of it.
-usage: python tools/stress_generated.py [contexts=6] [repeats=6]"""
+usage: python tools/stress_generated.py [contexts=6] [repeats=6] [preset=tiny11]   (base: the D = 512 encoder)"""
 import os, sys, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
@@ -12,13 +12,17 @@ from slimt_amd import capi, synth
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-m = synth.make_model("tiny11", eos_bias=6.0)
+preset = sys.argv[3] if len(sys.argv) > 3 else "tiny11"
+m = synth.make_model(preset, eos_bias=6.0)
 gm = capi.Model(m)
 om = O.OracleModel(m)
 blob = synth.make_lexical_shortlist(m.V, m.V, 100, 1, seed=11, empty_fraction=0.4, min_count=1)
 gen = capi.ShortlistGenerator(blob, m.V, m.V)
 osl = O.OracleShortlist(blob, m.V, m.V)
-shapes = [(64, 32), (96, 32), (256, 32), (128, 16), (70, 31), (200, 20)]  # all take the 64-row encoder (>= 32 tiles)
+# tiny11: the 64-row encoder (>= 32 tiles of it) and, for the small batches, the 32-row one; base: the D = 512 encoder
+shapes = [(64, 32), (96, 32), (256, 32), (128, 16), (70, 31), (200, 20), (20, 32), (30, 12)]
+if preset == "base":
+    shapes = [(64, 32), (40, 17), (96, 32), (21, 9)]
 jobs = []
 O.set_mode(O.PORTABLE)
 for i, (B, S) in enumerate(shapes):
@@ -43,7 +47,7 @@ def work(w):
 ts = [threading.Thread(target=work, args=(w,)) for w in range(W)]
 [t.start() for t in ts]
 [t.join() for t in ts]
-print(f"shortlist sizes {[j[3] for j in jobs]}; {len(bad)} mismatches in {W * reps * len(jobs)} generated translates on {W} concurrent contexts")
+print(f"{preset}: shortlist sizes {[j[3] for j in jobs]}; {len(bad)} mismatches in {W * reps * len(jobs)} generated translates on {W} concurrent contexts")
 for b in bad[:10]:
     print("  ", b)
 sys.exit(1 if bad else 0)
