@@ -1557,6 +1557,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     outw.N = (int)*a.out_n_dev;
     outw.n_tiles = (outw.N + 15) / 16;
   }
+  // logit[0] NaN for every row (a NaN in column 0's prepared bias or in the multiplier): the reference's scan starts
+  // from logits[0] and only moves on `value > max`, so it stays at class 0 (Transformer.cc:287-298); the arg-max
+  // below skips NaNs, so the rule is applied where the token is taken
+  const bool nan0 = outw.pb[0] != outw.pb[0] || a.out.u != a.out.u;
   const int max_steps = a.max_steps;
   bool all_done = false;
   for (int t = 0; t < max_steps; ++t) {
@@ -1864,7 +1868,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         ix = __builtin_amdgcn_readfirstlane(ix);
         // no column beat the start value (every logit NaN or -inf): class 0, where the reference's scan
         // starts and stays (Transformer.cc:287-298) -- and never an index past the shortlist
-        ix = ix == 0x7fffffff ? 0 : ix;
+        ix = (ix == 0x7fffffff || nan0) ? 0 : ix;
         if (live[rr]) tok = a.shortlist ? a.shortlist[ix] : (uint32_t)ix;
       }
       if (live[rr] && !finished[rr]) {  // record(), Model.cc:127-137

@@ -1517,6 +1517,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   }
   ds.shortlist = n_sl ? d_shortlist : nullptr;
   const AffineW &out = output_layer(c);
+  ds.pb0 = out.w.pb;
+  ds.u_out = out.w.u;
   if (c->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld)) {
     // the whole greedy loop in one persistent launch (decode_fused.hip)
     FusedDecodeArgs f;

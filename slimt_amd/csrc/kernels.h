@@ -152,6 +152,11 @@ struct DecodeState {
   const uint32_t *shortlist = nullptr;  // nullable
   int Tmax = 0;
   uint32_t eos = 0;
+  // the output layer's prepared bias of column 0 and its multiplier: a NaN there makes logit[0] NaN for every
+  // row, and the reference's scan, which starts from logits[0] and only moves on `value > max`, then stays at
+  // class 0 (Transformer.cc:287-298) -- the arg-max kernels skip NaNs, so the rule is applied where a token is taken
+  const float *pb0 = nullptr;
+  float u_out = 1.0f;
 };
 // Reduce the argmax partials of the previous step (if first == 0), record the
 // tokens (Model.cc:127-137) and build the next decoder input embedding

@@ -607,6 +607,7 @@ __global__ __launch_bounds__(64) void decode_begin_step_kernel(EmbedArgs e, Deco
       }
     }
     if (bi == 0x7fffffff) bi = 0;  // every logit NaN or -inf: class 0 (Transformer.cc:287-298), never out of range
+    if (s.pb0 && (*s.pb0 != *s.pb0 || s.u_out != s.u_out)) bi = 0;  // logit[0] is NaN: the reference's scan never leaves class 0
     const uint32_t tok = s.shortlist ? s.shortlist[bi] : (uint32_t)bi;
     s.prev[b] = tok;
     if (!s.finished[b]) {  // record(), Model.cc:127-137

@@ -262,27 +262,38 @@ def test_output_layer_tile_counts(hip, oracle, engines, n_sl):
     ctx.close()
 
 
-@pytest.mark.parametrize("poison", ["nan", "-inf"])
+@pytest.mark.parametrize("poison", ["nan", "-inf", "nan-in-column-0"])
 def test_logits_without_a_maximum_sample_class_zero(hip, oracle, synth_models, poison):
     """Every logit NaN (or -inf): nothing beats the arg-max's start value. The reference's scan starts at class 0
     and stays there (Transformer.cc:287-298); the kernels must do the same -- and must not index the shortlist or
-    the embedding with their "no column yet" marker. All decoder variants."""
+    the embedding with their "no column yet" marker. And a NaN in column 0's logit ALONE: `value > NaN` is never
+    true, so the reference stays at class 0 as well, whatever the other columns hold (the kernels' arg-max skips
+    NaNs; the rule is applied where the token is taken). All decoder variants; EOS is another id than class 0's,
+    so the loop runs its full length on class 0."""
     import copy
     from slimt_amd import synth
     m = copy.deepcopy(synth_models("tiny11", 6.0))
     bias = m.params["decoder_ff_logit_out_b"]
-    bias.data[...] = np.float32(np.nan) if poison == "nan" else np.float32(-np.inf)
-    gm, om = hip.Model(m), oracle.OracleModel(m)
     B, S = 19, 11
     ids, lens = synth.make_batch(m.V, B, S, seed=4, ragged=True)
-    for sl in (synth.make_shortlist(m.V, 1024), None):
+    shortlists = (synth.make_shortlist(m.V, 1024), None)
+    if poison == "nan-in-column-0":
+        assert shortlists[0][0] == 0  # column 0 of both output layers is vocabulary id 0
+        bias.data.reshape(-1)[0] = np.float32(np.nan)
+    else:
+        bias.data[...] = np.float32(np.nan) if poison == "nan" else np.float32(-np.inf)
+    gm, om = hip.Model(m), oracle.OracleModel(m)
+    eos = 0 if poison != "nan-in-column-0" else 7
+    for sl in shortlists:
         oracle.set_mode(oracle.PORTABLE)
-        w_out, w_ln, _, _ = om.translate(ids, lens, sl, 1.5, 0)
+        w_out, w_ln, _, _ = om.translate(ids, lens, sl, 1.5, eos)
         oracle.set_mode(oracle.FAITHFUL)
+        if poison == "nan-in-column-0":
+            assert not w_out.any() and (w_ln == int(np.float32(1.5) * np.float32(S))).all()  # class 0 at every step
         ctx = hip.Context(gm, B, S)
-        for mode in (0, 1, 3):
+        for mode in (0, 1, 2, 3, 5):
             ctx.set_decode_mode(mode)
-            out, ln, _ = ctx.translate(ids, lens, sl)
+            out, ln, _ = ctx.translate(ids, lens, sl, eos_id=eos)
             assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out), (poison, mode, sl is None)
         ctx.close()
     gm.close()
