@@ -31,6 +31,8 @@ def main():
     sl = synth.make_shortlist(model.V, n_sl)
     gm = capi.Model(model, device=0)
     ctxs = [capi.Context(gm, B, S) for _ in range(W)]
+    for c in ctxs:
+        c.set_decode_mode(int(os.environ.get("SLIMT_DECODE_MODE", "0")))  # 3 = 32 sentences per decoder workgroup
     T = int(np.float32(1.5) * np.float32(S))
 
     def to_dev(a):
@@ -50,7 +52,7 @@ def main():
     for i in range(W):
         step(i)
     torch.cuda.synchronize()
-    wgs_per_step = -(-B // 16) + -(-B * S // 32)
+    wgs_per_step = -(-B // 4) + -(-B * S // 32)
     cap = 2 * wgs_per_step * steps + 1024
     buf = torch.zeros(1 + 3 * cap, dtype=torch.int64, device=dev)
     capi._chk(capi.lib().slimt_hip_debug_occupancy_trace(buf.data_ptr(), cap))
