@@ -1657,6 +1657,22 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       int eighths = gm->kv_policy == 1 ? all : gm->kv_policy == 2 ? 0
                     : (int)std::min((double)all, std::floor((double)all * budget / active));
       if (gm->kv_policy == 0) eighths = eighths / grain * grain;
+      // Round 4: WHICH caches stay temporal. "Layer 0 of every decoder" (the rule above) makes every workgroup pay one
+      // cached and one streamed attention per step; keeping BOTH layers of k of every 8 launches (by admission order)
+      // and streaming both layers of the others holds the same bytes but lets the kept decoders run their whole step
+      // at the cached speed (and finish together, so no CU idles inside a launch): 32.35 -> 33.05-33.26 M tok/s at
+      // k = 6, 32.5-32.9 at k = 5, 32.3-32.6 at k = 7, 31.7 all temporal (profiles/r04_v3_kv_by_launch.txt).
+      // k = as many eighths of the pending decoders as SLIMT_KV_LAUNCH_BUDGET_MB (default 270) covers;
+      // SLIMT_KV_BY_LAUNCH: 0 = the per-layer rule, 1..8 = that k.
+      static const int by_launch = std::getenv("SLIMT_KV_BY_LAUNCH") ? std::atoi(std::getenv("SLIMT_KV_BY_LAUNCH")) : -1;
+      static const double launch_budget =
+          (std::getenv("SLIMT_KV_LAUNCH_BUDGET_MB") ? std::atof(std::getenv("SLIMT_KV_LAUNCH_BUDGET_MB")) : 270.0) * 1e6;
+      // (sentences of up to 32 tokens; longer ones measured 2-3 % slower this way and keep the per-layer rule:
+      // S = 64 18.5 -> 17.9 M, S = 128 8.2 -> 8.0 M)
+      if (gm->kv_policy == 0 && by_launch != 0 && eighths < all && S <= 32) {
+        const int k = by_launch > 0 ? std::min(by_launch, 8) : (int)std::min(8.0, std::floor(8.0 * launch_budget / active));
+        eighths = (int)(gm->gate_seq % 8) < k ? all : 0;
+      }
       f.kv_nt = eighths < all;
       f.kv_temporal_eighths = eighths;
       if (gm->gate_seq >= n) HIPCHK(hipStreamWaitEvent(st, gm->gate_ev[(gm->gate_seq - n) % kRing], 0));
