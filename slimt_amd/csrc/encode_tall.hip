@@ -688,9 +688,15 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
             const int off = row_sentence(r) * S * D * 3 + (ci * 3 * S + r % S) * 16;
             const v4i p0 = {wd[0].x, wd[0].y, wd[0].z, wd[1].x}, p1 = {wd[1].y, wd[1].z, wd[2].x, wd[2].y},
                       p2 = {wd[2].z, wd[3].x, wd[3].y, wd[3].z};
-            __builtin_amdgcn_raw_buffer_store_b128(p0, ro, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(p1, ro, off + S * 16, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(p2, ro, off + 2 * S * 16, 0, 0);
+            if (a.kv_store_nt) {  // this batch's decoder will stream its cache past the Infinity Cache: so do the stores
+              __builtin_amdgcn_raw_buffer_store_b128(p0, ro, off, 0, 2);
+              __builtin_amdgcn_raw_buffer_store_b128(p1, ro, off + S * 16, 0, 2);
+              __builtin_amdgcn_raw_buffer_store_b128(p2, ro, off + 2 * S * 16, 0, 2);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(p0, ro, off, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(p1, ro, off + S * 16, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(p2, ro, off + 2 * S * 16, 0, 0);
+            }
           }
         } else {  // V [sentence][key / 4][plane][column / 4][16 B]: 4 keys x 4 columns, key-major
           const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * Sp * D * 3));
@@ -708,9 +714,15 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
             const int off = ((s0 + si) * (Sp / 4) + g) * 3 * 64 * 16 + cl * 16;
             const v4i p0 = {wd[0].x, wd[0].y, wd[0].z, wd[1].x}, p1 = {wd[1].y, wd[1].z, wd[2].x, wd[2].y},
                       p2 = {wd[2].z, wd[3].x, wd[3].y, wd[3].z};
-            __builtin_amdgcn_raw_buffer_store_b128(p0, ro, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(p1, ro, off + 1024, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(p2, ro, off + 2048, 0, 0);
+            if (a.kv_store_nt) {
+              __builtin_amdgcn_raw_buffer_store_b128(p0, ro, off, 0, 2);
+              __builtin_amdgcn_raw_buffer_store_b128(p1, ro, off + 1024, 0, 2);
+              __builtin_amdgcn_raw_buffer_store_b128(p2, ro, off + 2048, 0, 2);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(p0, ro, off, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(p1, ro, off + 1024, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(p2, ro, off + 2048, 0, 0);
+            }
           }
         }
       }

@@ -1084,7 +1084,7 @@ bool fused_encoder_chosen(const slimt_hip_ctx *c, int B, int S) {
 int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layers,
                   const uint32_t *d_ids = nullptr, const uint32_t *d_lengths = nullptr,
                   const PackArgs *pack = nullptr, bool embedded = false, bool keep_out = true,
-                  bool kv24 = false, const ShortlistArgs *gen = nullptr) {
+                  bool kv24 = false, const ShortlistArgs *gen = nullptr, bool kv_store_nt = false) {
   // kv24 (translate_device only: the caller decodes with the persistent kernel's packed-cache
   // variant right behind this launch): the fused encoder leaves the 24-bit K/V cache
   // keep_out = false (the translate path): the persistent encoder leaves the decoder its K/V
@@ -1123,6 +1123,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
     f.kv = c->kv.as<float>();
     f.kv24 = kv24;
+    f.kv_store_nt = kv_store_nt;
     if (kv24 && (size_t)M * D * 3 >= (1u << 31)) return fail(-1, "packed K/V cache: %d rows exceed a 2 GB plane", M);
     f.enc_out = keep_out ? c->x0.as<float>() : nullptr;
     if (pack) {
@@ -1478,6 +1479,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   if (lean && submit_lock) submit.lock();
   clk.lap(2);
   if (g_timing.on) g_timing.calls += 1;
+  unsigned long long call_slot = 0;
+  int call_k = 8;
   DecodeState ds;
   ds.prev = c->prev.as<uint32_t>();
   ds.out_ids = d_out_ids;
@@ -1492,8 +1495,13 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       RCCHK(prepare_affine_meta(c->out_sl, m->out_raw.as<int8_t>(), m->D, (int)n_sl, d_shortlist,
                                 m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, job));
     job.n_dev = d_n_sl;
+    // the decoder's cache policy of THIS call (decided further down, under the admission lock, from the same two
+    // numbers): will its caches be kept in the Infinity Cache, or streamed? Streamed ones are also WRITTEN past it
+    call_slot = c->model->kv_call_seq.fetch_add(1, std::memory_order_relaxed);
+    call_k = c->model->kv_k_last.load(std::memory_order_relaxed);
+    static const bool store_nt = std::getenv("SLIMT_KV_STORE_NT") && std::getenv("SLIMT_KV_STORE_NT")[0] == '1';
     RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr, false, false,
-                        kv24, gen));
+                        kv24, gen, store_nt && kv24 && call_k < 8 && (int)(call_slot % 8) >= call_k));
     c->n_sl = (int)n_sl;
     clk.lap(1);
   } else {
@@ -1664,6 +1672,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       // k = 6, 32.5-32.9 at k = 5, 32.3-32.6 at k = 7, 31.7 all temporal (profiles/r04_v3_kv_by_launch.txt).
       // k = as many eighths of the pending decoders as SLIMT_KV_LAUNCH_BUDGET_MB (default 270) covers;
       // SLIMT_KV_BY_LAUNCH: 0 = the per-layer rule, 1..8 = that k.
+      static const bool store_nt_rule = std::getenv("SLIMT_KV_STORE_NT") && std::getenv("SLIMT_KV_STORE_NT")[0] == '1';
       static const int by_launch = std::getenv("SLIMT_KV_BY_LAUNCH") ? std::atoi(std::getenv("SLIMT_KV_BY_LAUNCH")) : -1;
       static const double launch_budget =
           (std::getenv("SLIMT_KV_LAUNCH_BUDGET_MB") ? std::atof(std::getenv("SLIMT_KV_LAUNCH_BUDGET_MB")) : 270.0) * 1e6;
@@ -1673,7 +1682,12 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       // "all of it" thrashes where "its layer 0" fits (29.8 -> 27.2 M tok/s)
       if (gm->kv_policy == 0 && by_launch != 0 && eighths < all && S <= 32 && 4.0 * kv_bytes <= launch_budget) {
         const int k = by_launch > 0 ? std::min(by_launch, 8) : (int)std::min(8.0, std::floor(8.0 * launch_budget / active));
-        eighths = (int)(gm->gate_seq % 8) < k ? all : 0;
+        // (the slot was drawn when the call started, with the k of the admission before it: the encoder of a call
+        // whose cache will be streamed can then write it non-temporally, SLIMT_KV_STORE_NT=1)
+        eighths = (int)(call_slot % 8) < (store_nt_rule ? call_k : k) ? all : 0;
+        gm->kv_k_last.store(k, std::memory_order_relaxed);
+      } else {
+        gm->kv_k_last.store(8, std::memory_order_relaxed);
       }
       f.kv_nt = eighths < all;
       f.kv_temporal_eighths = eighths;

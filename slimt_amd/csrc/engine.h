@@ -2,6 +2,7 @@
 // Mirrors slimt::Transformer / Encoder / Decoder (slimt/Transformer.hh:15-72)
 // and the loop of slimt::Model::forward/decode (slimt/Model.cc:111-204).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -92,6 +93,8 @@ struct slimt_hip_model {
   int xcd_affinity = 0;
   std::vector<unsigned> gate_home;  // ring, parallel to gate_ev: home mask of each admitted launch
   int kv_policy = 0;  // 0 = chosen per launch, 1 = always temporal, 2 = always non-temporal K/V loads
+  std::atomic<unsigned long long> kv_call_seq{0};  // K/V cache policy per launch (engine.cpp): a slot per translate call,
+  std::atomic<int> kv_k_last{8};                   // and the k (kept launches of every 8) of the last admission
   bool adaptive_rows = true;  // decode mode 0: 8 or 4 sentences per decoder workgroup while CUs would idle (engine.cpp)
   int kv_format = 0;  // 0 = packed 24-bit cache where the kernels have it (kernels.h, kv24), 1 = always f32
 };

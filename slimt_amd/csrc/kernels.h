@@ -375,6 +375,7 @@ struct FusedEncodeArgs {
   float alpha = 0.f, eps = 1e-6f;
   float *kv = nullptr;         // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]
   bool kv24 = false;           // write the packed 24-bit form instead (FusedDecodeArgs::kv24)
+  bool kv_store_nt = false;    // 64-row encoder, packed form: non-temporal cache stores (the decoder of this batch will stream it)
   PackArgs pack;               // the batch's shortlisted output layer, packed by the
   int pack_tiles = 0;          // encoder's workgroups on the side (0 = nothing to pack)
   // ShortlistGenerator::generate inside this launch (the S <= 64 encoders; gen.w2o != nullptr): the workgroup
