@@ -54,7 +54,7 @@ for ks in range(4):
     print("A frag read ks", ks, cycles_b128(lambda l: (l & 15) * LDA + ((((ks * 4 + (l >> 4)) ^ (l & 15)) & 15) << 4)))
 LDO = 144
 print("O-proj read", cycles_b128(lambda l: (l & 15) * LDO + (l >> 4) * 16))
-LDQ, LDV, LDY = 132, 144, 260
+LDQ, LDV, LDY = 130, 144, 260  # encode_tall.hip (q / k rows: + 2 floats)
 print("q/k f32 store (b128 write)", cycles_w128(lambda l: ((l & 15) * LDQ + (l >> 4) * 4) * 4))
 print("v f32 store (b128 write)", cycles_w128(lambda l: ((l & 15) * LDV + (l >> 4) * 4) * 4))
 print("Y store (b128 write)", cycles_w128(lambda l: ((l & 15) * LDY + (l >> 4) * 4) * 4))
