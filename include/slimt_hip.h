@@ -249,6 +249,9 @@ int slimt_hip_host_free(void *p);
  * the ctx stream when `steps_hint` > 0 (runs exactly that many decode steps,
  * no early-exit read-back), otherwise syncs every few steps to stop as soon
  * as every sentence has emitted EOS. */
+/* Device arrays cannot be checked by the host: a token or shortlist id >= the vocabulary reads the table's last
+ * row instead of faulting -- that sentence's result is undefined (as in the reference, which does not check
+ * either), the other sentences' results are not affected. */
 int slimt_hip_translate_device(slimt_hip_ctx *ctx, const uint32_t *d_src_ids,
                                const uint32_t *d_lengths, size_t B, size_t S,
                                const uint32_t *d_shortlist, size_t n_shortlist,

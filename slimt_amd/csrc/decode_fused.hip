@@ -1885,7 +1885,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         for (int i = 0; i < KSD; ++i) {
           float v = 0.0f;
           if (live[rr]) {
-            const float e = (float)a.emb.wemb[(size_t)tok * D + lane + 64 * i] * a.emb.inv_mult;
+            const float e = (float)a.emb.wemb[(size_t)embed_row(a.emb, tok) * D + lane + 64 * i] * a.emb.inv_mult;
             const float sc = e * a.emb.sqrt_d;
             v = sc + a.emb.pos[lane + 64 * i];
           }

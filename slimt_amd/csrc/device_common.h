@@ -279,7 +279,8 @@ __device__ __forceinline__ void pack_weight_tile(const PackArgs &a, int ntile, i
     const int n = ntile * 16 + r;
     v4i v = {0, 0, 0, 0};
     if (n < N) {
-      const size_t src = a.idx ? (size_t)a.idx[n] : (size_t)n;
+      size_t src = a.idx ? (size_t)a.idx[n] : (size_t)n;
+      if (a.n_src > 0 && src >= (size_t)a.n_src) src = (size_t)a.n_src - 1;
       v = *reinterpret_cast<const v4i *>(a.W + src * a.K + (size_t)ch * 16);
     }
     const int ks = ch >> 2, kg = ch & 3;
@@ -292,6 +293,7 @@ __device__ __forceinline__ void pack_weight_tile(const PackArgs &a, int ntile, i
     size_t src = 0;
     if (n < N) {
       src = a.idx ? (size_t)a.idx[n] : (size_t)n;
+      if (a.n_src > 0 && src >= (size_t)a.n_src) src = (size_t)a.n_src - 1;
       for (int ch = sub; ch < chunks; ch += 16) {
         v4i v = *reinterpret_cast<const v4i *>(a.W + src * a.K + (size_t)ch * 16);
         s += sum_bytes(v.x) + sum_bytes(v.y) + sum_bytes(v.z) + sum_bytes(v.w);

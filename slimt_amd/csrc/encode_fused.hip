@@ -244,7 +244,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   for (int r = wave; r < ER; r += ENW) {
     const bool ok = row_valid(r);
     const int sb = row_sentence(r), pos = r % S;
-    const uint32_t tok = ok ? a.ids[(size_t)sb * S + pos] : 0;
+    const uint32_t tok = ok ? embed_row(a.emb, a.ids[(size_t)sb * S + pos]) : 0;
 #pragma unroll
     for (int i = 0; i < KSD; ++i) {
       float v = 0.0f;
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
 
   // ---- embedding (Model.cc:195-197) ----------------------------------------
   for (int r = wave; r < S; r += ENW) {
-    const uint32_t tok = f.ids[(size_t)row0 + r];
+    const uint32_t tok = embed_row(f.emb, f.ids[(size_t)row0 + r]);
 #pragma unroll
     for (int i = 0; i < KSD; ++i) {
       const float e = (float)f.emb.wemb[(size_t)tok * D + lane + 64 * i] * f.emb.inv_mult;

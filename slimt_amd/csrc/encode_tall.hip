@@ -274,7 +274,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       const int r = 4 * wave + rr;
       const bool ok = row_valid(r);
       const int sb = row_sentence(r), pos = r % S;
-      const uint32_t tok = ok ? a.ids[(size_t)sb * S + pos] : 0;
+      const uint32_t tok = ok ? embed_row(a.emb, a.ids[(size_t)sb * S + pos]) : 0;
 #pragma unroll
       for (int i = 0; i < KSD; ++i) {
         float v = 0.0f;

@@ -193,12 +193,13 @@ struct TmpAffine {  // device temporaries of one stateless qmm call
 
 // buffers + descriptor of a prepared weight; the packing itself is a PackArgs job
 int prepare_affine_meta(AffineW &aw, const int8_t *dW, int K, int N, const uint32_t *d_idx,
-                        const float *d_bias, float a_quant, float b_quant, PackArgs &job) {
+                        const float *d_bias, float a_quant, float b_quant, PackArgs &job, int n_src = 0) {
   const int n_tiles = (N + 15) / 16;
   HIPCHK(aw.Wp.reserve(packed_weight_bytes(K, N)));
   HIPCHK(aw.colsum.reserve(colsum_alloc_bytes(N)));
   HIPCHK(aw.pb.reserve((size_t)n_tiles * 16 * sizeof(float)));
   job.W = dW; job.K = K; job.N = N; job.idx = d_idx; job.bias = d_bias;
+  job.n_src = n_src;
   job.mult = pack_mult(a_quant, b_quant);
   job.Wp = aw.Wp.p; job.colsum = aw.colsum.as<int>(); job.pb = aw.pb.as<float>();
   aw.w.Wp = aw.Wp.p;
@@ -970,6 +971,7 @@ EmbedArgs embed_args(const slimt_hip_ctx *c) {
   e.sqrt_d = std::sqrt(static_cast<float>(m->D));  // Transformer.cc:34
   e.pos = c->pos.as<float>();
   e.D = m->D;
+  e.V = m->V;
   return e;
 }
 
@@ -1493,7 +1495,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     PackArgs job;
     if (n_sl)
       RCCHK(prepare_affine_meta(c->out_sl, m->out_raw.as<int8_t>(), m->D, (int)n_sl, d_shortlist,
-                                m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, job));
+                                m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, job, m->V));
     job.n_dev = d_n_sl;
     // the decoder's cache policy of THIS call (decided further down, under the admission lock, from the same two
     // numbers): will its caches be kept in the Infinity Cache, or streamed? Streamed ones are also WRITTEN past it

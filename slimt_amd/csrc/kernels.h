@@ -58,6 +58,7 @@ struct PackArgs {
   int *colsum = nullptr;
   float *pb = nullptr;
   const uint32_t *n_dev = nullptr;  // nullable: the actual N lives on the device (N is then an upper bound)
+  int n_src = 0;  // rows of W (0 = not stated): a gathered index past it reads the last row instead of faulting
 };
 inline float pack_mult(float a_quant, float b_quant) {
   const float a_alpha = 127.0f / a_quant;
@@ -138,7 +139,13 @@ struct EmbedArgs {
   float inv_mult = 0.f, sqrt_d = 0.f;
   const float *pos = nullptr;    // [max_S][D] sinusoid table
   int D = 0;
+  // rows of wemb: an id past the table (only device-resident inputs can carry one: host entry points check) reads the
+  // last row instead of faulting -- the result of that sentence is undefined, as in the reference; the others' are not
+  int V = 0;
 };
+__host__ __device__ inline uint32_t embed_row(const EmbedArgs &e, uint32_t tok) {
+  return tok < (uint32_t)e.V ? tok : (uint32_t)(e.V - 1);
+}
 hipError_t launch_embed_encoder(const EmbedArgs &e, const uint32_t *ids, int B, int S, float *x,
                                 hipStream_t st);
 

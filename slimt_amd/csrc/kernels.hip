@@ -566,7 +566,7 @@ hipError_t launch_ssru(const SsruArgs &a, hipStream_t st) {
 // E[tok][d] = float(q) * (1/mult)   (Io.cc:275-283), then * sqrt(D), then
 // + pos[s][d]  (Transformer.cc:24-49). Separate roundings, as in the reference.
 __device__ __forceinline__ float embed1(const EmbedArgs &e, uint32_t tok, int d, const float *pos) {
-  const float v = (float)e.wemb[(size_t)tok * e.D + d] * e.inv_mult;
+  const float v = (float)e.wemb[(size_t)embed_row(e, tok) * e.D + d] * e.inv_mult;
   const float s = v * e.sqrt_d;
   return s + pos[d];
 }
@@ -574,7 +574,7 @@ __device__ __forceinline__ float embed1(const EmbedArgs &e, uint32_t tok, int d,
 __global__ void embed_encoder_kernel(EmbedArgs e, const uint32_t *ids, int S, float *x) {
   const int row = blockIdx.x;  // b * S + s
   const int s = row % S;
-  const uint32_t tok = ids[row];
+  const uint32_t tok = embed_row(e, ids[row]);
   for (int d = threadIdx.x; d < e.D; d += blockDim.x)
     x[(size_t)row * e.D + d] = embed1(e, tok, d, e.pos + (size_t)s * e.D);
 }
