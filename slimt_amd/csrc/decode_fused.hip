@@ -1499,7 +1499,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   for (int rr = 0; rr < RT; ++rr) {
     bq[rr] = m0 + 16 * rr + wave;
     live[rr] = row_wave && bq[rr] < B;
-    len[rr] = live[rr] ? (int)a.lengths[bq[rr]] : 0;
+    len[rr] = live[rr] ? checked_length(a.lengths[bq[rr]], S) : 0;
     finished[rr] = !live[rr];
     n_out[rr] = 0;
   }

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
     s0 = a.alpha * s0;
     s1 = a.alpha * s1;
   }
-  const int len = (int)a.lengths[b];
+  const int len = checked_length(a.lengths[b], S);
   const float minus_inf = -99999999.0f;  // Input.cc:56-61
   s0 = s0 + (1.0f - (lane < len ? 1.0f : 0.0f)) * minus_inf;
   s1 = s1 + (1.0f - ((lane + 64) < len ? 1.0f : 0.0f)) * minus_inf;

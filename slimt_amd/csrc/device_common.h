@@ -20,6 +20,10 @@
 
 namespace slimt_hip {
 
+// a sentence length as the kernels use it: device-resident arrays cannot be checked by the host, and a length past the
+// padded width S would size cache descriptors past the sentence's block
+__device__ __forceinline__ int checked_length(uint32_t len, int S) { return len < (uint32_t)S ? (int)len : S; }
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float exp_p(float x) {

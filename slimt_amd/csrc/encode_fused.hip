@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
   // this workgroup's sentence lengths: read once (they may live in pinned host memory)
   __shared__ int slens[ER];
-  if (tid < spw) slens[tid] = s0 + tid < B ? (int)a.lengths[s0 + tid] : 0;
+  if (tid < spw) slens[tid] = s0 + tid < B ? checked_length(a.lengths[s0 + tid], S) : 0;
 
   float *xs = reinterpret_cast<float *>(smem);
   char *Aq = reinterpret_cast<char *>(xs + ER * LDX);
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
   const int b = blockIdx.x, S = f.S;
   const int row0 = b * S;
   const int nrt = (S + 15) >> 4;  // row tiles in use (uniform)
-  const int len = (int)f.lengths[b];
+  const int len = checked_length(f.lengths[b], S);
 
   char *A = smem;                                          // [128][272] int8
   char *H0 = A + LR * LDA, *H1 = H0 + LR * LDA;            // FFN hidden chunks

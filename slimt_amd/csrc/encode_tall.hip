@@ -218,7 +218,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   // this workgroup's sentence lengths: read once (they may live in pinned host memory, and every
   // attention job needs its sentence's; ordered by the first barrier below)
   __shared__ int slens[TR];
-  if (tid < spw) slens[tid] = s0 + tid < B ? (int)a.lengths[s0 + tid] : 0;
+  if (tid < spw) slens[tid] = s0 + tid < B ? checked_length(a.lengths[s0 + tid], S) : 0;
 
   char *Aq = smem;                       // x quantised for Q | round 1's attention output | for FFN1 | for the decoder's K / V
   char *Ak = Aq + TR * LDA;              // x quantised for K

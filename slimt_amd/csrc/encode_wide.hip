@@ -200,7 +200,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
   // this workgroup's sentence lengths: read once (they may live in pinned host memory)
   __shared__ int slens[WR];
-  if (tid < spw) slens[tid] = s0 + tid < B ? (int)a.lengths[s0 + tid] : 0;
+  if (tid < spw) slens[tid] = s0 + tid < B ? checked_length(a.lengths[s0 + tid], S) : 0;
 
   char *Abuf = smem;                 // x quantised for Q | round 1's attention output | FFN1 / decoder K/V input
   char *Akb = Abuf + WR * LDA;       // x quantised for K

@@ -689,7 +689,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, int b, int h, 
       mask0 = j0 < S ? a.mask[(size_t)b * S + j0] : 0.0f;
       mask1 = j1 < S ? a.mask[(size_t)b * S + j1] : 0.0f;
     } else {
-      const int len = (int)a.lengths[b];
+      const int len = checked_length(a.lengths[b], S);
       const float minus_inf = -99999999.0f;
       mask0 = (1.0f - (j0 < len ? 1.0f : 0.0f)) * minus_inf;
       mask1 = (1.0f - (j1 < len ? 1.0f : 0.0f)) * minus_inf;
@@ -726,7 +726,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, int b, int h, 
       if (lane + 64 < S) ap[lane + 64] = p1;
     }
     if (a.align && h == 0 && !a.finished[b]) {  // update_alignment, Model.cc:84-108
-      const int len = (int)a.lengths[b];
+      const int len = checked_length(a.lengths[b], S);
       const uint32_t t = a.out_len[b];
       if ((int)t < a.Tmax) {
         float *al = a.align + ((size_t)b * a.Tmax + t) * S;
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     for (int k0 = 0; k0 < DH; k0 += 2)
       st = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[k0], qp[k0], st, 0, 0, 0);
   }
-  const int len = a.mask ? 0 : (int)a.lengths[b];
+  const int len = a.mask ? 0 : checked_length(a.lengths[b], S);
   float sc[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {

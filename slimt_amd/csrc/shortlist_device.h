@@ -22,7 +22,7 @@ __device__ __forceinline__ void shortlist_mark(const ShortlistArgs &a, uint32_t 
     unsigned long long begin = 0, end = 0;
     if (idx < n_tok) {
       const int b = idx / a.S, j = idx - b * a.S;
-      if (j < (int)a.lengths[b]) {  // padding is not a word (Input::words())
+      if ((uint32_t)j < a.lengths[b]) {  // padding is not a word (Input::words()); a length past S is S
         const uint32_t w = a.ids[idx];
         if (w < (uint32_t)a.src_vocab) {  // out of range: undefined in the reference; ignored
           if (a.shared && w < (uint32_t)a.tgt_vocab) atomicOr(&lb[w >> 5], 1u << (w & 31));

@@ -690,28 +690,34 @@ def test_model_from_bin_container_equals_model_from_params(hip, oracle, engines)
 def test_device_resident_ids_out_of_range_do_not_fault(hip, oracle, engines):
     """slimt_hip_translate_device cannot validate arrays that live on the device: a source id (or a shortlist id) past the
     vocabulary must not fault -- it reads the table's last row -- and must not disturb the OTHER sentences of the batch
-    (sentences are independent: they still equal the oracle)."""
+    (sentences are independent: they still equal the oracle); a sentence length past the padded width S is S."""
     import torch
     from slimt_amd import synth
     m, gm, om = engines("tiny11", 6.0)
     B, S = 70, 32
     ids, lens = synth.make_batch(m.V, B, S, seed=66, ragged=True)
     sl = synth.make_shortlist(m.V, 1024)
+    # a length past the padded width means the padded width: sentences 17 and 63 are checked against the oracle at len = S
+    full = lens.copy()
+    full[[17, 63]] = S
     oracle.set_mode(oracle.PORTABLE)
-    w_out, w_ln, _, _ = om.translate(ids, lens, sl, 1.5, 0)
+    w_out, w_ln, _, _ = om.translate(ids, full, sl, 1.5, 0)
     oracle.set_mode(oracle.FAITHFUL)
     bad = ids.copy()
     bad[5, 0] = np.uint32(m.V + 12345)
     bad[41, min(3, int(lens[41]) - 1)] = np.uint32(0xFFFFFFF0)
+    bad_lens = lens.copy()
+    bad_lens[17] = np.uint32(S + 100)
+    bad_lens[63] = np.uint32(0xFFFFFFFF)
     dev = torch.device("cuda", 0)
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
     T = int(np.float32(1.5) * np.float32(S))
-    d_ids, d_len, d_sl = to_dev(bad), to_dev(lens), to_dev(sl)
+    d_ids, d_len, d_sl = to_dev(bad), to_dev(bad_lens), to_dev(sl)
     d_out = torch.zeros((B, T), dtype=torch.int32, device=dev)
     d_ol = torch.zeros((B,), dtype=torch.int32, device=dev)
     ctx = hip.Context(gm, B, S)
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 3):
             ctx.set_decode_mode(mode)
             ctx.translate_device(d_ids.data_ptr(), d_len.data_ptr(), B, S, d_sl.data_ptr(), sl.size, 1.5, 0,
                                  d_out.data_ptr(), d_ol.data_ptr(), 0)
