@@ -174,7 +174,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   constexpr int HR = 4;        // heads per round
   constexpr int RC = HR * DH;  // q / k / v columns per round (128)
   constexpr int NR = 2;        // rounds
-  // int8 A rows: unpadded, the 16-byte chunks of a row XOR-swizzled with the row (taoff below)
+  // int8 A rows: unpadded, the 16-byte chunks of a row XOR-swizzled with the row (quantise_x below)
   // -- a fragment read (16 rows x one chunk) then covers all 64 banks without the 16 pad bytes
   // per row, which is what lets THREE A buffers (x quantised for Q, K, V) fit beside the rest
   constexpr int LDA = D;
@@ -288,14 +288,33 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       }
     }
   }
-  // the owner's rows, quantised for the next affine, into an A buffer
-  // byte offset of (row, column) in an A buffer
-  auto taoff = [](int row, int col) { return row * LDA + ((((col >> 4) ^ row) & 15) << 4) + (col & 15); };
-  auto quantise_x = [&](char *A, float aq, int lane) {
+  // the owner's rows, quantised for the next affine, into an A buffer.
+  // Byte offset of (row, column): row LDA + (((column / 16) ^ f(row)) << 4) + column % 16 with f(r) = the two 2-bit
+  // halves of r & 15 swapped -- any bijection of the row's low four bits makes a fragment read (16 rows x one chunk)
+  // cover all 64 banks; THIS one puts the owner's stores at one lane-dependent address plus compile-time offsets:
+  // row 4 w + rr, column L + 64 i -> chunk ((L / 16) ^ (w & 3)) | ((i ^ rr) << 2), i.e.
+  //   A + 1024 w + (((L / 16) ^ (w & 3)) << 4) + L % 16   (tq_base: one register per phase)   + 256 rr + ((i ^ rr) << 6).
+  // (With f = identity the i-term was (i ^ (w & 3)) << 6: two to three address instructions in front of every byte store.)
+  typedef __attribute__((address_space(3))) char *lds_bptr;
+  auto tq_base = [&](int lane) {
+    lds_bptr p = (lds_bptr)(smem + 1024 * wave + ((((lane >> 4) ^ wave) & 3) << 4) + (lane & 15));
+    asm volatile("" : "+v"(p));
+    return p;
+  };
+  // PrepareA (Intgemm.inl.cc:29-34) for a BYTE store: clamp(rint(x aq), -127, 127) == rint(clamp(x aq, -127, 127)) (the bounds
+  // are integers, rint is monotonic), and adding 1.5 * 2^23 rounds to nearest even and leaves the integer's two's complement
+  // in the low mantissa bits: multiply, v_med3 (a NaN product -> -127, like the max / min pair), add -- the store takes
+  // the low byte. (quantize1: multiply, v_rndne, v_med3, v_cvt_i32.)
+  auto quant_byte = [](float v, float aq) {
+    const float t = __builtin_amdgcn_fmed3f(v * aq, -127.0f, 127.0f);
+    return __float_as_int(t + 12582912.0f);
+  };
+  // aoff: the A buffer's byte offset in smem (a constant at every call)
+  auto quantise_x = [&](int aoff, float aq, lds_bptr qb0) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-      for (int i = 0; i < KSD; ++i) A[taoff(4 * wave + rr, lane + 64 * i)] = (char)quantize1(x[rr][i], aq);
+      for (int i = 0; i < KSD; ++i) qb0[aoff + 256 * rr + ((i ^ rr) << 6)] = (char)quant_byte(x[rr][i], aq);
   };
   auto load_w = [&](v4i (&f)[KSD], const PreparedWeight &w, int ct, int lane) {
     const rsrc_t rw = trsrc(w.Wp, (unsigned)w.n_tiles * KSD * 1024u);
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     AFrag o;
 #pragma unroll
     for (int ks = 0; ks < KSD; ++ks) {
-      o.p[ks] = (lds_cptr)(A + lr * LDA + (((ks * 4 + lg) ^ lr) << 4));
+      o.p[ks] = (lds_cptr)(A + lr * LDA + (((ks * 4 + lg) ^ (((lr & 3) << 2) | (lr >> 2))) << 4));
       asm volatile("" : "+v"(o.p[ks]));
     }
     return o;
@@ -358,9 +377,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();  // the region is free; round 0: so are the A buffers
         if (hr == 0) {  // x quantised with the three projections' multipliers, once per layer
-          quantise_x(Aq, L.q.a_quant, lane);
-          quantise_x(Ak, L.k.a_quant, lane);
-          quantise_x(Av, L.v.a_quant, lane);
+          const lds_bptr qb0 = tq_base(lane);
+          quantise_x(0, L.q.a_quant, qb0);
+          quantise_x(TR * LDA, L.k.a_quant, qb0);
+          quantise_x(2 * TR * LDA, L.v.a_quant, qb0);
           lds_barrier();
         }
         const char *A1 = qv ? Aq : Ak;
@@ -473,7 +493,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int q = 16 * qh + 4 * g + r;  // query of this register
-              if (q < S) Or[(base + q) * LDO + dcol] = (char)quantize1(o[r], L.o.a_quant);
+              if (q < S) Or[(base + q) * LDO + dcol] = (char)quant_byte(o[r], L.o.a_quant);
             }
           }
         }
@@ -524,7 +544,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         for (int i = 0; i < KSD; ++i) x[rr][i] = x[rr][i] + Yb[(4 * wave + rr) * LDY + lane + 64 * i];
         tln_regs(x[rr], lsc, lbi, a.eps);
       }
-      quantise_x(Aq, L.ffn1.a_quant, lane);
+      quantise_x(0, L.ffn1.a_quant, tq_base(lane));
 #pragma unroll
       for (int i = 0; i < 3 && i < NT1; ++i) {
         load1(i, i, lane);
@@ -649,7 +669,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       load_w(wf, w, wave, lane);
       const TEpi e = tload_epi(w, wave, lg);
       lds_barrier();  // the A buffer and the region are free
-      quantise_x(Aq, w.a_quant, lane);
+      quantise_x(0, w.a_quant, tq_base(lane));
       lds_barrier();
       const int col = wave * 16 + lg * 4;
       const AFrag af = a_frag(Aq, lane);
