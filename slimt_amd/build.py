@@ -76,7 +76,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
     extra = os.environ.get("SLIMT_HIPCC_EXTRA", "").split()  # experiments only
-    tag = ("_" + str(abs(hash(" ".join(extra))) % 10**8)) if extra else ""
+    # (a stable tag: the interpreter's string hash changes per process and left one set of objects per build behind)
+    import zlib
+    tag = ("_x%08x" % zlib.crc32(" ".join(extra).encode())) if extra else ""
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     cflags = [f for f in FLAGS if f != "-shared"]

@@ -44,6 +44,27 @@ __device__ __forceinline__ float exp_p(float x) {
   return y * __int_as_float((ni + 127) << 23);
 }
 
+// exp_p without its two early exits: the polynomial runs for every input and the special cases are selected
+// afterwards -- the same bits for every float (below -86 the discarded product may be anything; a NaN takes the
+// polynomial path in both forms), no exec-mask branches around a dozen instructions.
+__device__ __forceinline__ float exp_p_select(float x) {
+  const float xc = x > 88.0f ? 88.0f : x;
+  float n = __builtin_rintf(xc * 1.44269504088896341f);
+  float r = __builtin_fmaf(n, -0.693359375f, xc);
+  r = __builtin_fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  float r2 = r * r;
+  float y = __builtin_fmaf(p, r2, r) + 1.0f;
+  const int ni = (int)n;
+  const float v = y * __int_as_float((ni + 127) << 23);
+  return x < -86.0f ? 0.0f : v;
+}
+
 // TensorOps.cc:33-36
 __device__ __forceinline__ float sigmoid_p(float x) {
   if (x > 0) return 1.0f / (1.0f + exp_p(-x));

@@ -289,15 +289,17 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     }
   }
   // the owner's rows, quantised for the next affine, into an A buffer.
-  // Byte offset of (row, column): row LDA + (((column / 16) ^ f(row)) << 4) + column % 16 with f(r) = the two 2-bit
-  // halves of r & 15 swapped -- any bijection of the row's low four bits makes a fragment read (16 rows x one chunk)
-  // cover all 64 banks; THIS one puts the owner's stores at one lane-dependent address plus compile-time offsets:
-  // row 4 w + rr, column L + 64 i -> chunk ((L / 16) ^ (w & 3)) | ((i ^ rr) << 2), i.e.
-  //   A + 1024 w + (((L / 16) ^ (w & 3)) << 4) + L % 16   (tq_base: one register per phase)   + 256 rr + ((i ^ rr) << 6).
-  // (With f = identity the i-term was (i ^ (w & 3)) << 6: two to three address instructions in front of every byte store.)
+  // Byte offset of (row, column): row LDA + (((column / 16) ^ f(row)) << 4) + column % 16 with
+  //   f(r) = ((r & 3) << 2) | (((r >> 2) + 1) & 3)   (r = row & 15: the 2-bit halves swapped, the upper one + 1).
+  // A fragment read (ds_read_b128, serviced in the hardware's four groups of 16 lanes: tools/lds_conflicts.py) must find 16
+  // different chunks per group; of the bijections that do, this one ALSO puts the owner's stores at one lane-dependent
+  // address plus compile-time offsets: row 4 w + rr, column L + 64 i -> chunk ((L / 16) ^ ((w + 1) & 3)) | ((i ^ rr) << 2), i.e.
+  //   A + 1024 w + (((L / 16) ^ ((w + 1) & 3)) << 4) + L % 16   (tq_base: one register per phase)   + 256 rr + ((i ^ rr) << 6).
+  // (f = identity: the i-term is (i ^ (w & 3)) << 6, two to three address instructions in front of every byte store; the plain
+  // swap of the halves: every fragment read 2-way conflicted, SQ_LDS_BANK_CONFLICT 15 -> 35 % of the LDS cycles.)
   typedef __attribute__((address_space(3))) char *lds_bptr;
   auto tq_base = [&](int lane) {
-    lds_bptr p = (lds_bptr)(smem + 1024 * wave + ((((lane >> 4) ^ wave) & 3) << 4) + (lane & 15));
+    lds_bptr p = (lds_bptr)(smem + 1024 * wave + ((((lane >> 4) ^ (wave + 1)) & 3) << 4) + (lane & 15));
     asm volatile("" : "+v"(p));
     return p;
   };
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     AFrag o;
 #pragma unroll
     for (int ks = 0; ks < KSD; ++ks) {
-      o.p[ks] = (lds_cptr)(A + lr * LDA + (((ks * 4 + lg) ^ (((lr & 3) << 2) | (lr >> 2))) << 4));
+      o.p[ks] = (lds_cptr)(A + lr * LDA + (((ks * 4 + lg) ^ (((lr & 3) << 2) | (((lr >> 2) + 1) & 3))) << 4));
       asm volatile("" : "+v"(o.p[ks]));
     }
     return o;
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
             for (int r = 0; r < 4; ++r) {
               const int m = 16 * kt + 4 * g + r;  // key of this register
               float v = st[r];
-              if (a.alpha != 1.0f) v = a.alpha * v;
+              v = a.alpha * v;  // (alpha == 1: the product is v itself, bit for bit -- no select per score)
               v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
               if (m >= S) v = lowest;
               sc[kt][r] = v;
@@ -454,7 +456,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
 #pragma unroll
           for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * g + r) < S ? exp_p(sc[kt][r] - mx) : 0.0f;
+            for (int r = 0; r < 4; ++r) {
+              const float e = exp_p_select(sc[kt][r] - mx);
+              sc[kt][r] = (16 * kt + 4 * g + r) < S ? e : 0.0f;
+            }
           // the canonical butterfly over the key index 16 kt + 4 g + r: masks 1, 2 inside the four
           // registers, 4 and 8 across lane groups, 16 and 32 across the key tiles
           float t[NKT];

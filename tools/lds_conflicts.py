@@ -52,6 +52,9 @@ print("--- other encode_tall patterns (conflict-free: b128 read 4, b32 2, b128 w
 LDA = 256
 for ks in range(4):
     print("A frag read ks", ks, cycles_b128(lambda l: (l & 15) * LDA + ((((ks * 4 + (l >> 4)) ^ (l & 15)) & 15) << 4)))
+tf = lambda r: ((r & 3) << 2) | (((r >> 2) + 1) & 3)  # encode_tall.hip's row swizzle (store-friendly; the plain swap of the halves: 8)
+for ks in range(4):
+    print("A frag read, swizzle f, ks", ks, cycles_b128(lambda l: (l & 15) * LDA + ((((ks * 4 + (l >> 4)) ^ tf(l & 15)) & 15) << 4)))
 LDO = 144
 print("O-proj read", cycles_b128(lambda l: (l & 15) * LDO + (l >> 4) * 16))
 LDQ, LDV, LDY = 130, 144, 260  # encode_tall.hip (q / k rows: + 2 floats)
