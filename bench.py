@@ -69,6 +69,9 @@ def parse(argv=None):
     ap.add_argument("--decode-mode", type=int, default=0, help="0 = fused persistent decoder, 1 = step-wise")
     ap.add_argument("--encode-rows", type=int, default=0,
                     help="rows per workgroup of the emb-256 encoder: 0 = chosen per call (default), 32, 64")
+    ap.add_argument("--kv-format", type=int, default=0,
+                    help="decoder K/V cache: 0 = packed 24-bit accumulators where the shape has that form (default), 1 = f32 "
+                         "(slimt_hip_model_set_kv_cache_format; same results, tuning)")
     ap.add_argument("--kv-policy", type=int, default=0,
                     help="decoder K/V cache loads: 0 = chosen per launch (default), 1 = temporal, 2 = non-temporal")
     ap.add_argument("--xcd-affinity", type=int, default=-1,
@@ -337,6 +340,8 @@ def main():
             gm.set_decoder_budget(args.decoder_budget)
         if args.kv_policy:
             gm.set_kv_cache_policy(args.kv_policy)
+        if args.kv_format:
+            gm.set_kv_cache_format(args.kv_format)
         if args.xcd_affinity >= 0:
             gm.set_xcd_affinity(args.xcd_affinity)
         if args.adaptive_rows >= 0:

@@ -386,13 +386,16 @@ __device__ __forceinline__ void ln_row(const float *src, const float *scale, con
   }
   q = wave_sum(q);
   const float sigma = __builtin_sqrtf(q / (float)D + eps);
+  float tq[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) tq[i] = v[i] - mean;
+  SharedDiv(sigma, SLIMT_DIV_LN_D).quot<DPL, false>(tq, SLIMT_DIV_LN_N);  // (v - mean) / sigma, correctly rounded (device_common.h)
 #pragma unroll
   for (int i = 0; i < DPL; ++i) {
-    const float t = (v[i] - mean) / sigma;
-    const float m = scale[lane + 64 * i] * t;
+    const float m = scale[lane + 64 * i] * tq[i];
     const float y = m + bias[lane + 64 * i];
     dst[lane + 64 * i] = y;
-    if (A) A[lane + 64 * i] = (char)quantize1(y, aq);
+    if (A) A[lane + 64 * i] = (char)quantize1_byte(y, aq);
   }
 }
 
@@ -556,7 +559,7 @@ __device__ __noinline__ void attention_row_long(AttnRow r, int lane) {
         }
       }
       o = __builtin_fmaf(o, uv, pbv[2 * hp * DH + lane] * P);
-      r.arow[2 * hp * DH + lane] = (char)quantize1(o, r.aq_o);
+      r.arow[2 * hp * DH + lane] = (char)quantize1_byte(o, r.aq_o);
     }
   }
 }
@@ -675,7 +678,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
     o.z = __builtin_fmaf(o.z, r.uv, pv4.z * P);
     o.w = __builtin_fmaf(o.w, r.uv, pv4.w * P);
     *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-        pack4(quantize1(o.x, r.aq_o), quantize1(o.y, r.aq_o), quantize1(o.z, r.aq_o), quantize1(o.w, r.aq_o));
+        pack4(quantize1_byte(o.x, r.aq_o), quantize1_byte(o.y, r.aq_o), quantize1_byte(o.z, r.aq_o), quantize1_byte(o.w, r.aq_o));
   } else if (LONG && DH == 32 && S <= 128) {
     attention_row_long<D, DH, KV_AUX>(r, lane);
   } else if (DH == 64 && S <= 32) {
@@ -772,9 +775,9 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
       o1.w = __builtin_fmaf(o1.w, r.uv, pv1.w * P1);
     }
     *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-        pack4(quantize1(o0.x, r.aq_o), quantize1(o0.y, r.aq_o), quantize1(o0.z, r.aq_o), quantize1(o0.w, r.aq_o));
+        pack4(quantize1_byte(o0.x, r.aq_o), quantize1_byte(o0.y, r.aq_o), quantize1_byte(o0.z, r.aq_o), quantize1_byte(o0.w, r.aq_o));
     *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) =
-        pack4(quantize1(o1.x, r.aq_o), quantize1(o1.y, r.aq_o), quantize1(o1.z, r.aq_o), quantize1(o1.w, r.aq_o));
+        pack4(quantize1_byte(o1.x, r.aq_o), quantize1_byte(o1.y, r.aq_o), quantize1_byte(o1.z, r.aq_o), quantize1_byte(o1.w, r.aq_o));
   } else {
     // generic: one head per pass, keys lane and lane + 64
     const int j0 = lane < S ? lane : S - 1;
@@ -823,7 +826,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
         o = __builtin_fmaf(pj, r.vl[(size_t)jj * D + h * DH + dc], o);
       }
       o = __builtin_fmaf(o, r.uv, r.pbv[h * DH + dc] * P);
-      if (lane < DH) r.arow[h * DH + lane] = (char)quantize1(o, r.aq_o);
+      if (lane < DH) r.arow[h * DH + lane] = (char)quantize1_byte(o, r.aq_o);
     }
   }
 }
@@ -970,7 +973,7 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
   const float o0 = __builtin_fmaf(oa.x, uv256, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv256, pv4.y * P);
   const float o2 = __builtin_fmaf(ob.x, uv256, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv256, pv4.w * P);
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1(o0, r.aq_o), quantize1(o1, r.aq_o), quantize1(o2, r.aq_o), quantize1(o3, r.aq_o));
+      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
 }
 
 // Sentences of 33..64 tokens over the packed cache (written by encode_tall_kernel<., 4>): lane =
@@ -1078,7 +1081,7 @@ __device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr
   const float o0 = __builtin_fmaf(oa.x, uv256, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv256, pv4.y * P);
   const float o2 = __builtin_fmaf(ob.x, uv256, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv256, pv4.w * P);
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1(o0, r.aq_o), quantize1(o1, r.aq_o), quantize1(o2, r.aq_o), quantize1(o3, r.aq_o));
+      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
 }
 
 // Sentences of 65..128 tokens over the packed cache (written by encode_long16_kernel): lane L holds
@@ -1232,7 +1235,7 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
   const float o0 = __builtin_fmaf(oa.x, uv256, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv256, pv4.y * P);
   const float o2 = __builtin_fmaf(ob.x, uv256, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv256, pv4.w * P);
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1(o0, r.aq_o), quantize1(o1, r.aq_o), quantize1(o2, r.aq_o), quantize1(o3, r.aq_o));
+      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
 }
 
 // The same for D = 512, d_head 64 ("base"). At K = 512 the shifted accumulator needs 25 bits, so
@@ -1355,9 +1358,9 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
   const float b0 = __builtin_fmaf(o1a.x, uv256, pv1.x * P1), b1 = __builtin_fmaf(o1a.y, uv256, pv1.y * P1);
   const float b2 = __builtin_fmaf(o1b.x, uv256, pv1.z * P1), b3 = __builtin_fmaf(o1b.y, uv256, pv1.w * P1);
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1(a0, r.aq_o), quantize1(a1, r.aq_o), quantize1(a2, r.aq_o), quantize1(a3, r.aq_o));
+      pack4(quantize1_byte(a0, r.aq_o), quantize1_byte(a1, r.aq_o), quantize1_byte(a2, r.aq_o), quantize1_byte(a3, r.aq_o));
   *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) =
-      pack4(quantize1(b0, r.aq_o), quantize1(b1, r.aq_o), quantize1(b2, r.aq_o), quantize1(b3, r.aq_o));
+      pack4(quantize1_byte(b0, r.aq_o), quantize1_byte(b1, r.aq_o), quantize1_byte(b2, r.aq_o), quantize1_byte(b3, r.aq_o));
 }
 
 }  // namespace
@@ -1580,8 +1583,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
           for (int i = 0; i < KSD; ++i) {
             const float v = xs[row * LDF + lane + 64 * i];
-            A1[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_f.a_quant);
-            A2[row * LDA + lane + 64 * i] = (char)quantize1(v, L.rnn_w.a_quant);
+            A1[row * LDA + lane + 64 * i] = (char)quantize1_byte(v, L.rnn_f.a_quant);
+            A2[row * LDA + lane + 64 * i] = (char)quantize1_byte(v, L.rnn_w.a_quant);
           }
         }
       }
@@ -1626,7 +1629,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             const float wx = dequant(accw[r], csw, L.rnn_w.u, pbw);
             const bool cell_ok = !CELLS_GLOBAL || rl < valid_rows;  // global cells: rows of this batch only
             const float c = cell_ok ? cl[rl * D + col] : 0.0f;
-            const float sg = sigmoid_p(f);  // highway(c, Wx, f), TensorOps.cc:674-678
+            const float sg = sigmoid_p_select(f);  // highway(c, Wx, f), TensorOps.cc:674-678
             const float t1 = sg * c;
             const float t2 = (1.0f - sg) * wx;
             const float cn = t1 + t2;
@@ -1774,9 +1777,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             const int col = tile * 16 + lr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float v = dequant(acc[r], c1, L.ffn1.u, pb);
-              v = v > 0.0f ? v : 0.0f;
-              A3[(16 * rt + lg * 4 + r) * LDA3 + col] = (char)quantize1(v, L.ffn2.a_quant);
+              // relu, then PrepareA: for aq > 0, clamp(rint(max(v, 0) aq), -127, 127) == rint(clamp(v aq, 0, 127)) for every
+              // float v (the product keeps the sign; a NaN falls to the lower bound of either form) -- the relu rides in the
+              // clamp, the rounding in the magic add (quantize1_byte)
+              const float v = dequant(acc[r], c1, L.ffn1.u, pb);
+              const float tq = __builtin_amdgcn_fmed3f(v * L.ffn2.a_quant, 0.0f, 127.0f);
+              A3[(16 * rt + lg * 4 + r) * LDA3 + col] = (char)__float_as_int(tq + 12582912.0f);
             }
           });
       Frags f2[NB_FFN];  // FFN2's first chunks: requested as this wave's FFN1 tiles are done

@@ -71,6 +71,14 @@ __device__ __forceinline__ float sigmoid_p(float x) {
   float e = exp_p(x);
   return e / (1.0f + e);
 }
+// The same without divergent branches: both arms are exp of the non-positive argument over 1 + that, only the numerator
+// differs -- one exponential and one division per value whatever the signs in the wave (same bits: same operations on
+// the same operands; a NaN compares false and takes the second arm in both forms).
+__device__ __forceinline__ float sigmoid_p_select(float x) {
+  const bool pos = x > 0;
+  const float t = exp_p_select(pos ? -x : x);
+  return (pos ? 1.0f : t) / (1.0f + t);
+}
 
 // Butterfly partners. The canonical reduction is the xor butterfly with masks
 // ascending (1, 2, 4, ..., 32): at step M every lane combines its value with
@@ -185,6 +193,14 @@ __device__ __forceinline__ int quantize1(float x, float a_quant) {
   float v = __builtin_rintf(x * a_quant);
   v = __builtin_fminf(__builtin_fmaxf(v, -127.0f), 127.0f);
   return (int)v;
+}
+// quantize1 for a BYTE store (the low byte of the result is the int8): clamp(rint(t), -127, 127) == rint(clamp(t, -127, 127))
+// (integer bounds, rint is monotonic), and adding 1.5 * 2^23 rounds to nearest even and leaves the integer's two's
+// complement in the low mantissa bits -- multiply, v_med3 (a NaN product -> -127, like the max / min pair), add
+// instead of multiply, v_rndne, v_med3, v_cvt_i32.
+__device__ __forceinline__ int quantize1_byte(float x, float a_quant) {
+  const float t = __builtin_amdgcn_fmed3f(x * a_quant, -127.0f, 127.0f);
+  return __float_as_int(t + 12582912.0f);
 }
 
 // Correctly rounded quotients of SEVERAL numerators over ONE denominator (a LayerNorm row's sigma, a
