@@ -221,14 +221,14 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   auto quantise_row = [&](int r, const FusedEncLayerW &L) {
     const float4 v = *reinterpret_cast<const float4 *>(xs + r * LDX + 4 * lane);
     *reinterpret_cast<int *>(Aq + r * LDA + 4 * lane) =
-        pack4(quantize1(v.x, L.q.a_quant), quantize1(v.y, L.q.a_quant), quantize1(v.z, L.q.a_quant),
-              quantize1(v.w, L.q.a_quant));
+        pack4(quantize1_byte(v.x, L.q.a_quant), quantize1_byte(v.y, L.q.a_quant), quantize1_byte(v.z, L.q.a_quant),
+              quantize1_byte(v.w, L.q.a_quant));
     *reinterpret_cast<int *>(Ak + r * LDA + 4 * lane) =
-        pack4(quantize1(v.x, L.k.a_quant), quantize1(v.y, L.k.a_quant), quantize1(v.z, L.k.a_quant),
-              quantize1(v.w, L.k.a_quant));
+        pack4(quantize1_byte(v.x, L.k.a_quant), quantize1_byte(v.y, L.k.a_quant), quantize1_byte(v.z, L.k.a_quant),
+              quantize1_byte(v.w, L.k.a_quant));
     *reinterpret_cast<int *>(Av + r * LDA + 4 * lane) =
-        pack4(quantize1(v.x, L.v.a_quant), quantize1(v.y, L.v.a_quant), quantize1(v.z, L.v.a_quant),
-              quantize1(v.w, L.v.a_quant));
+        pack4(quantize1_byte(v.x, L.v.a_quant), quantize1_byte(v.y, L.v.a_quant), quantize1_byte(v.z, L.v.a_quant),
+              quantize1_byte(v.w, L.v.a_quant));
   };
 
   // ---- side job: the batch's shortlisted output layer (used by the decoder
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
           for (int r = 0; r < 4; ++r) {
             const int m = 16 * kt + 4 * g + r;  // key of this register
             float v = st[r];
-            if (a.alpha != 1.0f) v = a.alpha * v;
+            v = a.alpha * v;  // (alpha == 1: the product is v, bit for bit)
             v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
             if (m >= S) v = lowest;
             sc[kt][r] = v;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * g + r) < S ? exp_p(sc[kt][r] - mx) : 0.0f;
+          for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * g + r) < S ? exp_p_select(sc[kt][r] - mx) : 0.0f;
         float t[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = 16 * qh + 4 * g + r;  // query of this register
-            if (q < S) Aq[(base + q) * LDA + h * DH + 16 * nt + n] = (char)quantize1(o[r], L.o.a_quant);
+            if (q < S) Aq[(base + q) * LDA + h * DH + 16 * nt + n] = (char)quantize1_byte(o[r], L.o.a_quant);
           }
         }
       }
@@ -455,8 +455,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       eln_row<KSD>(xs + r * LDX, lsc, lbi, a.eps, lane);
       const float4 v = *reinterpret_cast<const float4 *>(xs + r * LDX + 4 * lane);
       *reinterpret_cast<int *>(Aq + r * LDA + 4 * lane) =
-          pack4(quantize1(v.x, L.ffn1.a_quant), quantize1(v.y, L.ffn1.a_quant),
-                quantize1(v.z, L.ffn1.a_quant), quantize1(v.w, L.ffn1.a_quant));
+          pack4(quantize1_byte(v.x, L.ffn1.a_quant), quantize1_byte(v.y, L.ffn1.a_quant),
+                quantize1_byte(v.z, L.ffn1.a_quant), quantize1_byte(v.w, L.ffn1.a_quant));
     }
     lds_barrier();
     SLIMT_ESTAMP(5);
@@ -497,8 +497,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
             float v1 = edequant(c1[r], cs4[buf][r], L.ffn1.u, pbv[r]);
             v0 = v0 > 0.0f ? v0 : 0.0f;
             v1 = v1 > 0.0f ? v1 : 0.0f;
-            q0[r] = quantize1(v0, L.ffn2.a_quant);
-            q1[r] = quantize1(v1, L.ffn2.a_quant);
+            q0[r] = quantize1_byte(v0, L.ffn2.a_quant);
+            q1[r] = quantize1_byte(v1, L.ffn2.a_quant);
           }
           const int col = (wave + ENW * i) * 16 + lg * 4;
           *reinterpret_cast<int *>(Hb + lr * LDH + col) = pack4(q0[0], q0[1], q0[2], q0[3]);
@@ -602,8 +602,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
 #pragma unroll
       for (int i = 0; i < KSD; ++i) {
         const float v = xs[r * LDX + lane + 64 * i];
-        Ak[r * LDA + lane + 64 * i] = (char)quantize1(v, wk.a_quant);
-        Av[r * LDA + lane + 64 * i] = (char)quantize1(v, wv.a_quant);
+        Ak[r * LDA + lane + 64 * i] = (char)quantize1_byte(v, wk.a_quant);
+        Av[r * LDA + lane + 64 * i] = (char)quantize1_byte(v, wv.a_quant);
       }
     }
     lds_barrier();
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
 #pragma unroll
       for (int i = 0; i < KSD; ++i) {
         const float v = r < S ? src[(size_t)r * D + lane + 64 * i] : 0.0f;
-        A[r * LDA + lane + 64 * i] = (char)quantize1(v, aq);
+        A[r * LDA + lane + 64 * i] = (char)quantize1_byte(v, aq);
       }
     }
   };
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
             for (int r = 0; r < 16; ++r) {
               const int key = 32 * g + 8 * (r >> 2) + 4 * hv + (r & 3);
               float v = st[r];
-              if (f.alpha != 1.0f) v = f.alpha * v;
+              v = f.alpha * v;  // (alpha == 1: the product is v, bit for bit)
               v = v + (1.0f - (key < len ? 1.0f : 0.0f)) * minus_inf;
               if (key >= S) v = lowest;
               sc[r] = v;
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                   const int key = 32 * g + 8 * (r >> 2) + 4 * hv + (r & 3);
-                  const float e = key < S ? exp_p(sc[r] - m) : 0.0f;
+                  const float e = key < S ? exp_p_select(sc[r] - m) : 0.0f;
                   u[g & 1][r] = u[g & 1][r] + e;
                 }
               }
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int key = 32 * g + 8 * (r >> 2) + 4 * hv + (r & 3);
-                const float e = key < S ? exp_p(sc[r] - m) : 0.0f;
+                const float e = key < S ? exp_p_select(sc[r] - m) : 0.0f;
                 sc[r] = e / sum;  // keys >= S: exactly 0
               }
 #pragma unroll
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int qi = qt * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
-            if (qi < S) A[qi * LDA + h * DH + n] = (char)quantize1(o[r], L.o.a_quant);
+            if (qi < S) A[qi * LDA + h * DH + n] = (char)quantize1_byte(o[r], L.o.a_quant);
           }
         }
         __syncthreads();
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
 #pragma unroll
       for (int i = 0; i < KSD; ++i) {
         if (r < S) X[(size_t)r * D + lane + 64 * i] = v[i];
-        A[r * LDA + lane + 64 * i] = r < S ? (char)quantize1(v[i], L.ffn1.a_quant) : (char)0;
+        A[r * LDA + lane + 64 * i] = r < S ? (char)quantize1_byte(v[i], L.ffn1.a_quant) : (char)0;
       }
     }
     __syncthreads();
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
             for (int r = 0; r < 4; ++r) {
               float v = edequant(c1[rt][r], cs, L.ffn1.u, pb);
               v = v > 0.0f ? v : 0.0f;
-              Hb[(16 * rt + lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1(v, L.ffn2.a_quant);
+              Hb[(16 * rt + lg * 4 + r) * LDA + wave * 16 + lr] = (char)quantize1_byte(v, L.ffn2.a_quant);
             }
           }
       };

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
 #pragma unroll
       for (int i = 0; i < KSD; ++i) {
         const int row = 2 * wave + rr, col = lane + 64 * i;
-        A[row * LDA + ((((col >> 4) ^ row) & 15) << 4 | (col & ~255)) + (col & 15)] = (char)quantize1(x[rr][i], aq);
+        A[row * LDA + ((((col >> 4) ^ row) & 15) << 4 | (col & ~255)) + (col & 15)] = (char)quantize1_byte(x[rr][i], aq);
       }
   };
   // Weight fragments are requested one phase ahead of their use, across the barriers and the
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
             for (int r = 0; r < 4; ++r) {
               const int m = 16 * kt + 4 * g + r;  // key of this register
               float v = st[r];
-              if (a.alpha != 1.0f) v = a.alpha * v;
+              v = a.alpha * v;  // (alpha == 1: the product is v, bit for bit)
               v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
               if (m >= S) v = lowest;
               sc[kt][r] = v;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * g + r) < S ? exp_p(sc[kt][r] - mx) : 0.0f;
+            for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * g + r) < S ? exp_p_select(sc[kt][r] - mx) : 0.0f;
           float t[2];
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt)
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int q = 16 * qh + 4 * g + r;  // query of this register
-              if (q < S) (hr == 0 ? Ob0 : Ob1)[(base + q) * LDO + dcol] = (char)quantize1(o[r], L.o.a_quant);
+              if (q < S) (hr == 0 ? Ob0 : Ob1)[(base + q) * LDO + dcol] = (char)quantize1_byte(o[r], L.o.a_quant);
             }
           }
         }
