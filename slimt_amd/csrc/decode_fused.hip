@@ -57,9 +57,29 @@ struct Frags {
 };
 
 // y = float(acc + 127 colsum) * u + pb   (Intgemm.inl.cc:146-153)
-__device__ __forceinline__ float dequant(int acc, int colsum, float u, float pb) {
-  const float v = (float)(acc + __mul24(127, colsum)) * u;  // |colsum| <= 127 K < 2^23
-  return v + pb;
+// y = float(acc + 127 colsum) * u + pb (Intgemm.inl.cc:146-153; |colsum| <= 127 K < 2^23) for the four rows an accumulator
+// lane holds -- they share their column: one shift, two packed multiplies and two packed adds (v_pk_mul_f32 / v_pk_add_f32:
+// the same IEEE operations as the scalar forms, multiply and add stay separate roundings).
+typedef float dq2 __attribute__((ext_vector_type(2)));
+struct Dequant4 {
+  float v[4];
+};
+__device__ __forceinline__ Dequant4 dequant4(const int (&acc)[4], int colsum, float u, float pb) {
+  const int sh = __mul24(127, colsum);
+  dq2 lo = {(float)(acc[0] + sh), (float)(acc[1] + sh)};
+  dq2 hi = {(float)(acc[2] + sh), (float)(acc[3] + sh)};
+  const dq2 uu = {u, u}, pp = {pb, pb};
+  lo = lo * uu;
+  hi = hi * uu;
+  lo = lo + pp;
+  hi = hi + pp;
+  Dequant4 o;
+  o.v[0] = lo.x; o.v[1] = lo.y; o.v[2] = hi.x; o.v[3] = hi.y;
+  return o;
+}
+__device__ __forceinline__ Dequant4 dequant4(const v4i &acc, int colsum, float u, float pb) {
+  const int a[4] = {acc[0], acc[1], acc[2], acc[3]};
+  return dequant4(a, colsum, u, pb);
 }
 
 // Weight streams go through buffer loads: the descriptor and the tile offset
@@ -1622,11 +1642,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             accf = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[ks], accf, 0, 0, 0);
             accw = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw, bw[ks], accw, 0, 0, 0);
           }
+          const Dequant4 f4v = dequant4(accf, csf, L.rnn_f.u, pbf), w4v = dequant4(accw, csw, L.rnn_w.u, pbw);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int rl = 16 * rt + lg * 4 + r;
-            const float f = dequant(accf[r], csf, L.rnn_f.u, pbf);
-            const float wx = dequant(accw[r], csw, L.rnn_w.u, pbw);
+            const float f = f4v.v[r];
+            const float wx = w4v.v[r];
             const bool cell_ok = !CELLS_GLOBAL || rl < valid_rows;  // global cells: rows of this batch only
             const float c = cell_ok ? cl[rl * D + col] : 0.0f;
             const float sg = sigmoid_p_select(f);  // highway(c, Wx, f), TensorOps.cc:674-678
@@ -1662,9 +1683,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       stream_gemm_from<KSD, 1, NT_D, false, RT>(A1, LDA, L.q, wave, lane, fq,
                                            [&](int tile, int rt, const v4i &acc, int cq, float pb) {
                                              const int col = tile * 16 + lr;
+                                             const Dequant4 q4v = dequant4(acc, cq, L.q.u, pb);
 #pragma unroll
                                              for (int r = 0; r < 4; ++r)
-                                               xs[(16 * rt + lg * 4 + r) * LDF + col] = dequant(acc[r], cq, L.q.u, pb);
+                                               xs[(16 * rt + lg * 4 + r) * LDF + col] = q4v.v[r];
                                            });
       lds_barrier();
       SLIMT_STAMP(sb + 3);
@@ -1745,11 +1767,11 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       stream_gemm_from<KSD, 1, NT_D, false, RT>(A1, LDA, L.o, wave, lane, fo,
                                            [&](int tile, int rt, const v4i &acc, int co, float pb) {
                                              const int col = tile * 16 + lr;
+                                             const Dequant4 o4v = dequant4(acc, co, L.o.u, pb);
 #pragma unroll
                                              for (int r = 0; r < 4; ++r) {
                                                const int rl = 16 * rt + lg * 4 + r;
-                                               const float v = dequant(acc[r], co, L.o.u, pb);
-                                               pre[rl * LDF + col] = v + hs[rl * LDF + col];
+                                               pre[rl * LDF + col] = o4v.v[r] + hs[rl * LDF + col];
                                              }
                                            });
       lds_barrier();
@@ -1775,12 +1797,13 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       stream_gemm_from<KSD, NB_FFN, NT_F1, false, RT>(
           A1, LDA, L.ffn1, wave, lane, f1, [&](int tile, int rt, const v4i &acc, int c1, float pb) {
             const int col = tile * 16 + lr;
+            const Dequant4 h4v = dequant4(acc, c1, L.ffn1.u, pb);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               // relu, then PrepareA: for aq > 0, clamp(rint(max(v, 0) aq), -127, 127) == rint(clamp(v aq, 0, 127)) for every
               // float v (the product keeps the sign; a NaN falls to the lower bound of either form) -- the relu rides in the
               // clamp, the rounding in the magic add (quantize1_byte)
-              const float v = dequant(acc[r], c1, L.ffn1.u, pb);
+              const float v = h4v.v[r];
               const float tq = __builtin_amdgcn_fmed3f(v * L.ffn2.a_quant, 0.0f, 127.0f);
               A3[(16 * rt + lg * 4 + r) * LDA3 + col] = (char)__float_as_int(tq + 12582912.0f);
             }
@@ -1792,11 +1815,11 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       stream_gemm_from<KSF, NB_FFN, NT_D, false, RT>(
           A3, LDA3, L.ffn2, wave, lane, f2, [&](int tile, int rt, const v4i &acc, int c2, float pb) {
             const int col = tile * 16 + lr;
+            const Dequant4 y4v = dequant4(acc, c2, L.ffn2.u, pb);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int rl = 16 * rt + lg * 4 + r;
-              const float v = dequant(acc[r], c2, L.ffn2.u, pb);
-              pre[rl * LDF + col] = v + hs[rl * LDF + col];
+              pre[rl * LDF + col] = y4v.v[r] + hs[rl * LDF + col];
             }
           });
       lds_barrier();
@@ -1838,9 +1861,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         A1, LDA, outw, wave, lane, fl, [&](int tile, int rt, const v4i &acc, int co, float pb) {
           const int col = tile * 16 + lr;
           const bool in_range = col < outw.N;  // no branch: the streaming loop stays one block
+          const Dequant4 l4v = dequant4(acc, co, a.out.u, pb);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = dequant(acc[r], co, a.out.u, pb);
+            const float v = l4v.v[r];
             // a lane's columns only grow, so strict > keeps its first maximum
             const bool better = in_range && v > bv[rt][r];
             bv[rt][r] = better ? v : bv[rt][r];
