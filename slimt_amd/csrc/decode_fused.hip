@@ -32,6 +32,10 @@
 #define EXP_SENT(b) (b)
 #endif
 
+#ifndef SLIMT_KV_AUX_NT
+#define SLIMT_KV_AUX_NT 2  // cache-policy bits of the "streamed" K/V loads (experiments: -DSLIMT_KV_AUX_NT=...)
+#endif
+
 namespace slimt_hip {
 
 namespace {
@@ -1747,7 +1751,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           } else if constexpr (KV24) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
             if (NT && kv_streams)
-              attention_row24<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+              attention_row24<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
           } else if (NT && kv_streams)
