@@ -35,6 +35,9 @@
 #ifndef SLIMT_KV_AUX_NT
 #define SLIMT_KV_AUX_NT 2  // cache-policy bits of the "streamed" K/V loads (experiments: -DSLIMT_KV_AUX_NT=...)
 #endif
+#ifndef SLIMT_KV_AUX_KEEP
+#define SLIMT_KV_AUX_KEEP 0  // ... of the "kept" ones
+#endif
 
 namespace slimt_hip {
 
@@ -1753,7 +1756,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             if (NT && kv_streams)
               attention_row24<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
-              attention_row24<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+              attention_row24<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
           } else if (NT && kv_streams)
             attention_row<D, DH, LONG, 2>(ar, lane);
           else
