@@ -354,6 +354,29 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     return c;
   };
 
+  // One weight tile against every row tile of `A`, epi(rt, c) per row tile: a row tile's four fragments are requested
+  // together, the next row tile's right behind this one's MFMAs (their round trip runs under this one's epilogue).
+  // Written out because the plain loop (mma_rt per row tile) compiles to read -> wait -> MFMA, fragment by fragment.
+  auto gemm_rts = [&](const v4i (&f)[KSD], const AFrag &o, const v4i &init, auto &&epi) {
+    typedef const __attribute__((address_space(3))) v4i *lds_v4i;
+    v4i A[KSD];
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) A[ks] = *(lds_v4i)(o.p[ks]);
+#pragma unroll
+    for (int rt = 0; rt < TRT; ++rt) {
+      v4i c = init;
+#pragma unroll
+      for (int ks = 0; ks < KSD; ++ks) c = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], A[ks], c, 0, 0, 0);
+      if (rt + 1 < TRT) {
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) A[ks] = *(lds_v4i)(o.p[ks] + 16 * (rt + 1) * LDA);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      epi(rt, c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   for (int l = 0; l < a.Le; ++l) {
     const FusedEncLayerW &L = a.L[l];
     SLIMT_TSTAMP(0);
@@ -389,23 +412,19 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         float *dst1 = qv ? qb : kb;
         const AFrag af = a_frag(A1, lane);
         const v4i s1 = tshift(e1);
-#pragma unroll
-        for (int rt = 0; rt < TRT; ++rt) {
-          const v4i c = mma_rt(w1, rt, af, s1);
+        gemm_rts(w1, af, s1, [&](int rt, const v4i &c) {
           const float4 qk = tdequant4(c, e1, W1.u);
           float *qd = dst1 + (16 * rt + lr) * LDQ + ctl * 16 + lg * 4;
           *reinterpret_cast<float2 *>(qd) = float2{qk.x, qk.y};
           *reinterpret_cast<float2 *>(qd + 2) = float2{qk.z, qk.w};
-        }
+        });
         __builtin_amdgcn_sched_barrier(0);
         if (qv) {
           const AFrag afv = a_frag(Av, lane);
           const v4i sv = tshift(ev);
-#pragma unroll
-          for (int rt = 0; rt < TRT; ++rt) {
-            const v4i cv = mma_rt(wv, rt, afv, sv);
+          gemm_rts(wv, afv, sv, [&](int rt, const v4i &cv) {
             *reinterpret_cast<float4 *>(vb + (16 * rt + lr) * LDV + ctl * 16 + lg * 4) = tdequant4(cv, ev, L.v.u);
-          }
+          });
         }
       }
       lds_barrier();
@@ -531,15 +550,29 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     }
     // FFN1's first column tiles travel under the LayerNorm
     v4i bw[3][KSD];
-    TEpi e1[3];
-    auto load1 = [&](int buf, int i, int lane) {
-      load_w(bw[buf], L.ffn1, wave + TNW * i, lane);
-      e1[buf] = tload_epi(L.ffn1, wave + TNW * i, lane >> 4);
-    };
+    auto load1 = [&](int buf, int i, int lane) { load_w(bw[buf], L.ffn1, wave + TNW * i, lane); };
+    // FFN1's epilogue constants (column sums and prepared biases of its F columns, 8 F bytes) wait in LDS -- K's operand
+    // buffer is idle from the last projection round to the next layer -- instead of in 24 registers per wave (three tiles
+    // in flight): those registers hold a row tile's four A fragments, requested at once and one row tile ahead (below)
+    int *ecs = reinterpret_cast<int *>(Ak);
+    float *epb = reinterpret_cast<float *>(Ak + F * 4);
+    static_assert((size_t)F * 8 <= (size_t)TR * LDA, "FFN1's epilogue constants fit K's operand buffer");
     {
       SLIMT_TPHASE_LANE;
       float lsc[4], lbi[4];
       tload_ln(L.attn_ln_s, L.attn_ln_b, lane, lsc, lbi);
+      // (F / 1024 words of each array per thread; requested here, stored behind the LayerNorm)
+      constexpr int EPT = (F + 1023) / 1024;
+      int ecv[EPT];
+      float epv[EPT];
+      {
+        const rsrc_t rc = trsrc(L.ffn1.colsum, (unsigned)F * 4u), rp = trsrc(L.ffn1.pb, (unsigned)F * 4u);
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+          ecv[i] = __builtin_amdgcn_raw_buffer_load_b32(rc, (tid + 1024 * i) * 4, 0, 0);  // (past F: zeros nobody reads)
+          epv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (tid + 1024 * i) * 4, 0, 0));
+        }
+      }
       lds_barrier();
       SLIMT_TSTAMP(5);
       // x = LN(x + O(...)); quantised for FFN1
@@ -550,6 +583,12 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         tln_regs(x[rr], lsc, lbi, a.eps);
       }
       quantise_x(0, L.ffn1.a_quant, tq_base(lane));
+#pragma unroll
+      for (int i = 0; i < EPT; ++i)
+        if (tid + 1024 * i < F) {
+          ecs[tid + 1024 * i] = ecv[i];
+          epb[tid + 1024 * i] = epv[i];
+        }
 #pragma unroll
       for (int i = 0; i < 3 && i < NT1; ++i) {
         load1(i, i, lane);
@@ -568,21 +607,37 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     {  // FFN1: NT1 column tiles per wave, three in flight; relu, requantised into the hidden layer
       SLIMT_TPHASE_LANE;
       const AFrag af = a_frag(Aq, lane);
+      typedef const __attribute__((address_space(3))) v4i *lds_v4i;
+      // Measured by ablation (timing-only builds, round 3): this phase was 9.2 us = the weight stream alone
+      // (3.0: 384 KB at the CU's 64 B/clk) + the MFMAs and their A-fragment reads (3.1) + the epilogues (3.1). The ISA showed why
+      // they added up: with 3 x 8 registers of epilogue constants held per wave, the compiler had two register quads for A
+      // fragments and serialised read -> wait -> MFMA three times per row tile, then the epilogue, then the next row tile's reads.
+      // Now a row tile's four fragments are requested together, the next row tile's right behind this one's MFMAs: their
+      // round trip runs under this one's epilogue.
+      v4i A[KSD];
+#pragma unroll
+      for (int ks = 0; ks < KSD; ++ks) A[ks] = *(lds_v4i)(af.p[ks]);
 #pragma unroll
       for (int i = 0; i < NT1; ++i) {
         const int buf = i % 3, t = wave + TNW * i;
-        const TEpi e = e1[buf];
+        TEpi e;
+        e.cs = *(lds_v4i)((lds_cptr)(ecs + t * 16 + lg * 4));
+        e.pb = __builtin_bit_cast(float4, *(lds_v4i)((lds_cptr)(epb + t * 16 + lg * 4)));
         const v4i sh = tshift(e);
-        // Measured by ablation (timing-only builds, round 3): this phase is 9.2 us = the weight stream alone
-        // (3.0: 384 KB at the CU's 64 B/clk) + the MFMAs and their A-fragment reads (3.1; 0.9 of it the LDS reads)
-        // + the epilogues (3.1) -- they add up instead of overlapping, whichever way the loop is arranged
-        // (loads before / after the epilogues, half the waves of a SIMD started late: no change).
 #pragma unroll
         for (int rt = 0; rt < TRT; ++rt) {
-          const v4i c = mma_rt(bw[buf], rt, af, sh);
+          v4i c = sh;
+#pragma unroll
+          for (int ks = 0; ks < KSD; ++ks) c = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[buf][ks], A[ks], c, 0, 0, 0);
+          // the next row tile's fragments (the next column tile starts over at row tile 0)
+          if (rt + 1 < TRT || i + 1 < NT1) {
+#pragma unroll
+            for (int ks = 0; ks < KSD; ++ks) A[ks] = *(lds_v4i)(af.p[ks] + 16 * ((rt + 1) % TRT) * LDA);
+          }
+          __builtin_amdgcn_sched_barrier(0);
           *reinterpret_cast<int *>(Hb + (16 * rt + lr) * LDH + t * 16 + lg * 4) = trelu_quant4(c, e, L.ffn1.u, L.ffn2.a_quant);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         if (i + 3 < NT1) load1(buf, i + 3, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -604,18 +659,28 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
 #pragma unroll
         for (int rt = 0; rt < TRT; ++rt) f[rt] = s2;
       }
+      // A k-step's four hidden-layer fragments (one per row tile) are requested together, the next k-step's right behind this
+      // one's four MFMAs (independent accumulators: they issue back to back). The plain loop compiled to read -> wait -> MFMA
+      // 96 times per wave: the phase WAS the LDS round trip (4.4 us of a layer).
+      typedef const __attribute__((address_space(3))) v4i *lds_v4i;
+      typedef const __attribute__((address_space(3))) char *lds_c;
+      const lds_c hrow = (lds_c)(Hb + lr * LDH + lg * 16);
+      v4i H[TRT];
+#pragma unroll
+      for (int rt = 0; rt < TRT; ++rt) H[rt] = *(lds_v4i)(hrow + 16 * rt * LDH);
 #pragma unroll
       for (int c = 0; c < NC2; ++c) {
         const int buf = c % 3;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-          for (int rt = 0; rt < TRT; ++rt) {
-            const v4i h = *reinterpret_cast<const v4i *>(Hb + (16 * rt + lr) * LDH + (c * 4 + ks) * 64 + lg * 16);
-            f[rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[buf][ks], h, f[rt], 0, 0, 0);
+          for (int rt = 0; rt < TRT; ++rt) f[rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[buf][ks], H[rt], f[rt], 0, 0, 0);
+          if (c * 4 + ks + 1 < KSF) {
+#pragma unroll
+            for (int rt = 0; rt < TRT; ++rt) H[rt] = *(lds_v4i)(hrow + 16 * rt * LDH + (c * 4 + ks + 1) * 64);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         if (c + 3 < NC2) load2(buf, c + 3, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
