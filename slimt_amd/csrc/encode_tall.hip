@@ -448,12 +448,12 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           const int base = sl * S;
           const int len = slens[sl];
           const int qr = 16 * qh + n;
-          const float *qp = qb + (base + (qr < S ? qr : S - 1)) * LDQ + hl * DH + g;
+          const float *qp = qb + __mul24(base + (qr < S ? qr : S - 1), LDQ) + hl * DH + g;
           float sc[NKT][4];
 #pragma unroll
           for (int kt = 0; kt < NKT; ++kt) {
             const int kr = 16 * kt + n;
-            const float *kp = kb + (base + (kr < S ? kr : S - 1)) * LDQ + hl * DH + g;
+            const float *kp = kb + __mul24(base + (kr < S ? kr : S - 1), LDQ) + hl * DH + g;
             v4f st = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int k0 = 0; k0 < DH; k0 += 4) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[k0], qp[k0], st, 0, 0, 0);
@@ -504,20 +504,31 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
             pa[kt][2] = __int_as_float(ac.y);
             pa[kt][3] = __int_as_float(bd.y);
           }
+          // V operands: this lane's key rows (4 s4 + g), both column tiles, requested before the first MFMA -- with the row
+          // address inside the chain the compiler put a quarter-rate 32-bit multiply, a read and its wait in front of every MFMA
+          // (rows are < 2^24: 24-bit multiplies, full rate)
+          typedef const __attribute__((address_space(3))) float *lds_fp;
+          const lds_fp vcol = (lds_fp)(vb + hl * DH + n);
+          float vv[DH / 16][4 * NKT];
+#pragma unroll
+          for (int s4 = 0; s4 < 4 * NKT; ++s4) {  // keys >= S contribute fma(0, v, o) == o
+            const int key = 4 * s4 + g;
+            const int off = __mul24(base + (key < S ? key : S - 1), LDV);
+#pragma unroll
+            for (int nt = 0; nt < DH / 16; ++nt) vv[nt][s4] = vcol[off + 16 * nt];
+          }
+          const float aq_o = L.o.a_quant;
+          typedef __attribute__((address_space(3))) char *lds_wp;
+          const lds_wp orow = (lds_wp)(Or + hl * DH + n);
 #pragma unroll
           for (int nt = 0; nt < DH / 16; ++nt) {
-            const int dcol = hl * DH + 16 * nt + n;  // column inside the round
             v4f o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int s4 = 0; s4 < 4 * NKT; ++s4) {  // keys >= S contribute fma(0, v, o) == o
-              const int key = 4 * s4 + g;
-              const float vv = vb[(base + (key < S ? key : S - 1)) * LDV + dcol];
-              o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4 >> 2][s4 & 3], vv, o, 0, 0, 0);
-            }
+            for (int s4 = 0; s4 < 4 * NKT; ++s4) o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4 >> 2][s4 & 3], vv[nt][s4], o, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int q = 16 * qh + 4 * g + r;  // query of this register
-              if (q < S) Or[(base + q) * LDO + dcol] = (char)quant_byte(o[r], L.o.a_quant);
+              if (q < S) orow[__mul24(base + q, LDO) + 16 * nt] = (char)quant_byte(o[r], aq_o);
             }
           }
         }
