@@ -442,7 +442,18 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         const float lowest = -3.402823466e+38f;
         const int nqh = (S + 15) >> 4;  // 16-query tiles of a sentence
         for (int job = wave; job < spw * HR * nqh; job += TNW) {
-          const int qh = job % nqh, hl = (job / nqh) % HR, sl = job / (nqh * HR);
+          // job = (sl HR + hl) nqh + qh without a division: nqh is 1 or 2 (S <= 32), 3 or 4 (one sentence per workgroup) --
+          // the general form kept a dozen reciprocal constants in scalar registers that spilled into this loop
+          int qh, rest;
+          if constexpr (NKT == 2) {
+            qh = nqh == 2 ? (job & 1) : 0;
+            rest = nqh == 2 ? (job >> 1) : job;
+          } else {
+            rest = nqh == 4 ? (job >> 2) : (job * 11) >> 5;  // job / 3 for job < 16
+            qh = job - rest * nqh;
+          }
+          const int hl = rest & (HR - 1), sl = rest / HR;
+          static_assert(HR == 4, "hl = rest & 3");
           const int sb = s0 + sl;
           if (sb >= B) continue;
           const int base = sl * S;
