@@ -400,7 +400,11 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         load_w(wv, L.v, ct, lane);
         const TEpi ev = tload_epi(L.v, ct, lg);
         __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();  // the region is free; round 0: so are the A buffers
+        // round 1: the region is free (round 0's attention has read its q / k / v). Round 0 of a later layer needs no barrier
+        // here: the A buffers were last read by FFN1 (two barriers ago), and nothing below touches the region -- still the
+        // exchange tile the LayerNorm before read -- until the barrier behind the quantisation. (Layer 0: the in-launch
+        // shortlist generation used this memory.)
+        if (hr > 0 || l == 0) lds_barrier();
         if (hr == 0) {  // x quantised with the three projections' multipliers, once per layer
           const lds_bptr qb0 = tq_base(lane);
           quantise_x(0, L.q.a_quant, qb0);
@@ -760,7 +764,9 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       v4i wf[KSD];
       load_w(wf, w, wave, lane);
       const TEpi e = tload_epi(w, wave, lg);
-      lds_barrier();  // the A buffer and the region are free
+      // (packed cache: no barrier here -- every wave's reads of the A buffer lie in front of the barrier between the products and
+      // the packing loop of the projection before, or of FFN1's; the staging tile is not written until the barrier below)
+      if (!a.kv24) lds_barrier();  // the A buffer and the region are free
       quantise_x(0, w.a_quant, tq_base(lane));
       lds_barrier();
       const int col = wave * 16 + lg * 4;
