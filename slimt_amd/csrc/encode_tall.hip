@@ -381,19 +381,28 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     const FusedEncLayerW &L = a.L[l];
     SLIMT_TSTAMP(0);
     // ---- Attention::forward (Modules.cc:287-319), four heads per round -----------------------
+    // (24 registers across an attention round: with four key tiles -- sentences of 33..64 tokens -- they spill)
+    constexpr bool R1_AHEAD = NKT == 2;
+    TEpi e1_next;
 #pragma unroll
     for (int hr = 0; hr < NR; ++hr) {
       const int ctl = wave & 7;
       const int ct = hr * (RC / 16) + ctl;
       {  // Q, K, V projections of this round's heads
         SLIMT_TPHASE_LANE;
-        if (hr > 0) {
+        const bool qv = wave < 8;  // this wave: Q and V tiles, else the K tile
+        const PreparedWeight &W1 = qv ? L.q : L.k;
+        // round 1's first tile and its epilogue constants were requested before round 0's attention where the registers
+        // allow it (R1_AHEAD); else here, at the top of the round
+        if (hr > 0 && !R1_AHEAD) {
           load_first(L, hr, lane);
           __builtin_amdgcn_sched_barrier(0);
         }
-        const bool qv = wave < 8;  // this wave: Q and V tiles, else the K tile
-        const PreparedWeight &W1 = qv ? L.q : L.k;
-        const TEpi e1 = tload_epi(W1, ct, lg);
+        TEpi e1;
+        if (hr > 0 && R1_AHEAD)
+          e1 = e1_next;
+        else
+          e1 = tload_epi(W1, ct, lg);
         // V's tile: loaded by every wave (an unconditional definition keeps its registers out of the
         // K waves' way; their copy is never used, its 8 redundant fetches hit in L2)
         v4i wv[KSD];
@@ -430,6 +439,12 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
             *reinterpret_cast<float4 *>(vb + (16 * rt + lr) * LDV + ctl * 16 + lg * 4) = tdequant4(cv, ev, L.v.u);
           });
         }
+      }
+      if (hr == 0 && R1_AHEAD) {  // their round trip runs under round 0's attention instead of in front of round 1's first MFMA
+        SLIMT_TPHASE_LANE;
+        load_first(L, 1, lane);
+        e1_next = tload_epi(wave < 8 ? L.q : L.k, (RC / 16) + (wave & 7), lg);
+        __builtin_amdgcn_sched_barrier(0);
       }
       lds_barrier();
       SLIMT_TSTAMP(hr == 0 ? 1 : 3);
