@@ -446,6 +446,12 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         e1_next = tload_epi(wave < 8 ? L.q : L.k, (RC / 16) + (wave & 7), lg);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (hr == 1 && R1_AHEAD) {  // ... and the O projection's tile (the same registers) under round 1's
+        SLIMT_TPHASE_LANE;
+        load_w(w1, L.o, wave, lane);
+        e1_next = tload_epi(L.o, wave, lg);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       lds_barrier();
       SLIMT_TSTAMP(hr == 0 ? 1 : 3);
       // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one wave per
@@ -572,9 +578,15 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     // ---- O projection (Modules.cc:308-314): wave = column tile, four row tiles -> exchange tile
     {
       SLIMT_TPHASE_LANE;
-      v4i wo[KSD];
-      load_w(wo, L.o, wave, lane);
-      const TEpi eo = tload_epi(L.o, wave, lg);
+      v4i wo_here[KSD];
+      TEpi eo;
+      if (!R1_AHEAD) {
+        load_w(wo_here, L.o, wave, lane);
+        eo = tload_epi(L.o, wave, lg);
+      } else {
+        eo = e1_next;
+      }
+      const v4i(&wo)[KSD] = R1_AHEAD ? w1 : wo_here;
       lds_barrier();  // attention of the last round is complete: q / k / v are dead
       SLIMT_TSTAMP(4);
       const v4i so = tshift(eo);
