@@ -312,7 +312,8 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
     // ---- Attention::forward (Modules.cc:287-319), four heads per round -----------------------
     {  // x quantised with the three projections' multipliers, once per layer
       SLIMT_WPHASE_LANE;
-      if (l) lds_barrier();  // the A buffers and the region are free
+      // (no barrier: the A buffers were last read by FFN1 and round 1's projections, barriers ago; the region -- still the
+      // exchange tile the LayerNorm before read -- is not written until the barrier below; encode_tall.hip)
       quantise_x(Abuf, L.q.a_quant, lane);
       quantise_x(Akb, L.k.a_quant, lane);
       quantise_x(Avb, L.v.a_quant, lane);
