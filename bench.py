@@ -276,13 +276,19 @@ def main():
     # SLIMT_BENCH_REHEARSAL=1: every rank on GPU 0 -- exercises the N-rank path
     # (rendezvous, barriers, max/sum reduction, rank-0 JSON) on a one-GPU box.
     rehearsal = os.environ.get("SLIMT_BENCH_REHEARSAL") == "1"
+    # One process per GPU: each rank keeps to its own host cores (a disjoint, equal share of the cores this job may
+    # use, by LOCAL_RANK), set before anything touches the GPU or starts a thread. SLIMT_BENCH_PIN=0: leave it alone.
+    cpus = None
+    if world > 1 and os.environ.get("SLIMT_BENCH_PIN", "1") != "0":
+        from slimt_amd.sharding import pin_rank
+        cpus = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if rehearsal:
         local_rank = 0
 
     import numpy as np
     import torch
     from slimt_amd import synth
-    from slimt_amd.sharding import plan_shards, reduce_timing
+    from slimt_amd.sharding import count_ranks, device_identity, plan_shards, reduce_timing
 
     dist = None
     if world > 1:
@@ -424,6 +430,12 @@ def main():
 
     cpu = torch.device("cpu")
     dt_max, total_tokens_per_step = reduce_timing(dist, cpu, dt, tokens_per_step)
+    n_ranks_seen = count_ranks(dist, cpu)  # every rank that took part adds one: N on an N-GPU run, whatever n_gpus says
+    if world > 1:  # which device and which cores this rank ran on (stderr: stdout is the JSON line's)
+        who = {"rank": rank, "local_rank": local_rank, "world": world, "cpus": cpus,
+               "tokens_per_step": tokens_per_step, "ms_per_step": 1e3 * dt / args.steps}
+        who.update({"device": None, "pci_bus_id": None, "numa_node": None} if dry else device_identity(local_rank))
+        print("bench-rank " + json.dumps(who), file=sys.stderr, flush=True)
 
     sustained = None
     if args.sustained_steps > 0 and not dry:
@@ -590,7 +602,7 @@ def main():
             }
         out = {
             "metric": "target tokens/sec, en-de tiny11 int8 greedy, batch=256",
-            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "value": value, "unit": "tokens/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps,
             "warmup": max(1, args.warmup), "ms_per_step": 1e3 * dt_max / args.steps,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int8", "data": "dry-run: no device work (SLIMT_BENCH_DRY)" if dry else "synthetic",

@@ -2,7 +2,10 @@
  * slimt_hip.h -- C ABI of the MI355X (gfx950) backend for slimt's int8
  * transformer-NMT hot path. Plain pointers and sizes only; every function
  * returns 0 on success or a non-zero status (slimt_hip_last_error() gives the
- * message). No exceptions cross this boundary; nothing here falls back to a
+ * message): a POSITIVE status is the hipError_t of a failed runtime call -- work
+ * may already be queued on the context's stream, so synchronise or destroy the
+ * context before freeing the buffers the call was given --, a NEGATIVE one is a
+ * check of the library's own (arguments, sizes, state). No exceptions cross this boundary; nothing here falls back to a
  * CPU implementation -- without a HIP device the compute entry points fail.
  *
  * Citations are file:line in the reference checkout (jerinphilip/slimt).
@@ -163,11 +166,18 @@ int slimt_hip_model_set_kv_cache_policy(slimt_hip_model *model, int policy);
 int slimt_hip_model_set_xcd_affinity(slimt_hip_model *model, int xcds);
 /* Storage format of the cross-attention K/V cache that slimt_hip_translate* keeps between
  * its encoder and decoder launches (the reference recomputes K and V every step,
- * slimt/Modules.cc:248-249): 0 (default) = the int8 GEMM's 24-bit shifted accumulators where
- * the kernels support it (emb 256 / head dim 32 with sources of up to 64 tokens, emb 512 / head
- * dim 64 up to 32; the attention
- * rebuilds float(acc) * unquant + bias in registers: identical floats, 25 % fewer bytes
- * re-read per step), f32 elsewhere; 1 = always f32. Results do not depend on it. */
+ * slimt/Modules.cc:248-249). Every format caches the int8 GEMM's ACCUMULATORS, and the
+ * attention applies the projections' unquantisation multiplier and prepared bias after its
+ * sums (the same real numbers as the reference's dequantise-then-attend, other
+ * roundings, <= 2.5e-5 apart; every format gives the same floats as every other):
+ *   0 (default) = packed integers where the kernels support it (emb 256 / head dim 32 with
+ *       sources of up to 128 tokens, emb 512 / head dim 64 up to 32), f32 elsewhere. Packed
+ *       means 24 bits per value, or -- emb 256, sources of up to 32 tokens -- 20 bits for
+ *       every sentence and layer whose accumulators all lie in [-2^19, 2^19), decided by the
+ *       encoder per batch (the 24-bit form holds any accumulator and is the fallback);
+ *   1 = always f32 (float(acc), exact);
+ *   2 = packed, always 24 bits.
+ * Results do not depend on it. */
 int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format);
 /* Sentences per workgroup of the persistent decoder in decode mode 0 (needs the decoder admission,
  * budget > 0): on (default) = a launch uses 8 or 4 sentences per workgroup instead of 16 while the
@@ -191,6 +201,13 @@ int slimt_hip_ctx_create_budget(slimt_hip_model *model, size_t max_batch,
                                 size_t max_source_length, size_t max_tokens, void *stream,
                                 slimt_hip_ctx **out);
 int slimt_hip_ctx_destroy(slimt_hip_ctx *ctx);
+/* Contexts alive on `device` in this process. A context is a stream; past 22 of
+ * them on one device the hardware queues are time-sliced whatever
+ * GPU_MAX_HW_QUEUES says (20 contexts 33 M tok/s, 24: 23.8 M, 32: 20.4 M on the
+ * headline workload), so the library says so once on stderr when the 23rd is
+ * created (SLIMT_HIP_QUIET=1 silences it). slimt runs `workers` Async threads
+ * (Frontend.hh:25), one context each: keep workers <= 22 per device and process. */
+int slimt_hip_contexts_on_device(int device, int *count);
 int slimt_hip_ctx_stream(slimt_hip_ctx *ctx, void **stream);
 int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
 /* Execution strategy of slimt_hip_translate* / slimt_hip_encode: 0 = automatic
@@ -389,6 +406,14 @@ int slimt_hip_profile_reset(slimt_hip_ctx *ctx);
  * call (step < 0 disables stamping). */
 int slimt_hip_debug_decode_stamps(slimt_hip_ctx *ctx, int step, uint64_t *out,
                                   size_t n);
+/* Diagnostic: which form each sentence-layer of ctx's last batch was cached in -- out[l * B + b],
+ * 0 = 20-bit, 1 = 24-bit; *batch = B, or 0 when the batch's caches are all in one form (f32 or
+ * 24-bit: formats 1 / 2, or a shape without the narrow form). Waits for ctx's stream. */
+int slimt_hip_debug_kv_formats(slimt_hip_ctx *ctx, uint8_t *out, size_t n, size_t *batch);
+/* Diagnostic: accumulators must lie in [-limit, limit) for the 20-bit form (default and
+ * maximum 2^19, what 20 bits hold). Tests lower it so that some sentences of a batch take the
+ * 24-bit form next to narrow ones. Results do not depend on it. */
+int slimt_hip_debug_kv_narrow_limit(slimt_hip_model *model, int limit);
 /* Diagnostic (process-wide): while device_buf != NULL, thread 0 of every
  * workgroup of the persistent encoder / decoder appends a begin and an end
  * event to it: device_buf[0] = event counter (zero it first), then 3 uint64

@@ -4,8 +4,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
-#include <map>
 #include <memory>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -18,34 +18,60 @@ namespace {
   std::abort();
 }
 
-// One device context per (thread, model): slimt's Async workers each call Model::forward from
-// their own thread (slimt/Frontend.cc:212-226).
-struct Lease {
-  slimt_hip_ctx* ctx = nullptr;
-  size_t batch = 0, length = 0, tokens = 0;
-  ~Lease() { slimt_hip_ctx_destroy(ctx); }
+}  // namespace
+
+struct ModelHandle::State {
+  slimt_hip_model* model = nullptr;
+  std::mutex mutex;
+  std::vector<Lease> idle;
+  ~State() {  // contexts first: slimt_hip_ctx_destroy reads the model they were built on
+    for (Lease& lease : idle) slimt_hip_ctx_destroy(lease.ctx);
+    slimt_hip_model_destroy(model);
+  }
 };
 
-Lease& lease_for(slimt_hip_model* model, size_t batch, size_t length) {
-  thread_local std::map<slimt_hip_model*, std::unique_ptr<Lease>> leases;
-  std::unique_ptr<Lease>& slot = leases[model];
-  if (!slot) slot = std::make_unique<Lease>();
-  Lease& lease = *slot;
-  if (lease.ctx == nullptr || batch > lease.batch || length > lease.length ||
-      batch * length > lease.tokens) {
-    slimt_hip_ctx_destroy(lease.ctx);
+ModelHandle::ModelHandle() = default;
+ModelHandle::ModelHandle(slimt_hip_model* model) : state_(std::make_unique<State>()) {
+  state_->model = model;
+}
+ModelHandle::ModelHandle(ModelHandle&& other) noexcept = default;
+ModelHandle& ModelHandle::operator=(ModelHandle&& other) noexcept = default;
+ModelHandle::~ModelHandle() = default;
+
+slimt_hip_model* ModelHandle::get() const { return state_ ? state_->model : nullptr; }
+
+ModelHandle::Lease ModelHandle::acquire(size_t batch, size_t length) const {
+  if (!state_) die("forward on an empty model handle");
+  Lease lease;
+  {
+    std::lock_guard<std::mutex> lock(state_->mutex);
+    if (!state_->idle.empty()) {
+      lease = state_->idle.back();
+      state_->idle.pop_back();
+    }
+  }
+  if (lease.ctx != nullptr &&
+      (batch > lease.batch || length > lease.length || batch * length > lease.tokens)) {
+    slimt_hip_ctx_destroy(lease.ctx);  // grows to the largest batch seen: a few rebuilds at most
     lease.ctx = nullptr;
+  }
+  if (lease.ctx == nullptr) {
     lease.batch = std::max(lease.batch, batch);
     lease.length = std::max(lease.length, length);
     lease.tokens = std::max(lease.tokens, batch * length);
-    if (slimt_hip_ctx_create_budget(model, lease.batch, lease.length,
-                                    lease.tokens, nullptr, &lease.ctx) != 0)
+    if (slimt_hip_ctx_create_budget(state_->model, lease.batch, lease.length, lease.tokens,
+                                    nullptr, &lease.ctx) != 0)
       die("slimt_hip_ctx_create_budget");
   }
   return lease;
 }
 
-}  // namespace
+void ModelHandle::release(Lease lease) const {
+  std::lock_guard<std::mutex> lock(state_->mutex);
+  state_->idle.push_back(lease);
+}
+
+void ModelHandle::discard(Lease lease) const { slimt_hip_ctx_destroy(lease.ctx); }
 
 ModelHandle create_model(View model, size_t encoder_layers, size_t decoder_layers,
                          size_t num_heads, int device) {
@@ -94,7 +120,7 @@ Words generate(slimt_hip_shortlist* generator, const Words& words,
   return indices;
 }
 
-Histories forward(slimt_hip_model* model, slimt_hip_shortlist* generator,
+Histories forward(const ModelHandle& model, slimt_hip_shortlist* generator,
                   const Input& input, uint32_t eos_id) {
   const std::vector<size_t>& source_lengths = input.lengths();
   const size_t batch = source_lengths.size();  // rows in use (Input::add calls)
@@ -107,7 +133,7 @@ Histories forward(slimt_hip_model* model, slimt_hip_shortlist* generator,
   std::vector<uint32_t> lengths(source_lengths.begin(), source_lengths.end());
   std::vector<uint32_t> tokens(batch * steps), produced(batch);
   std::vector<float> rows(batch * steps * length);  // Model::decode records alignments always
-  Lease& lease = lease_for(model, batch, length);
+  ModelHandle::Lease lease = model.acquire(batch, length);
   const uint32_t* ids = input.indices().data<uint32_t>();
   const int rc =
       generator != nullptr
@@ -117,7 +143,11 @@ Histories forward(slimt_hip_model* model, slimt_hip_shortlist* generator,
           : slimt_hip_translate(lease.ctx, ids, lengths.data(), batch, length,
                                 nullptr, 0, input.limit_factor(), eos_id,
                                 tokens.data(), produced.data(), rows.data());
-  if (rc != 0) die(generator != nullptr ? "slimt_hip_translate_generated" : "slimt_hip_translate");
+  if (rc != 0) {  // part of the call may be queued on the context's stream: it is not reused
+    model.discard(lease);
+    die(generator != nullptr ? "slimt_hip_translate_generated" : "slimt_hip_translate");
+  }
+  model.release(lease);
   histories.reserve(batch);
   for (size_t b = 0; b < batch; b++) {
     const size_t n = std::min<size_t>(produced[b], steps);

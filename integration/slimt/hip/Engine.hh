@@ -15,14 +15,43 @@
 
 namespace slimt::hip {
 
-// Owning handles (movable, not copyable; an empty handle is a null pointer).
-struct ModelDeleter {
-  void operator()(slimt_hip_model* model) const { slimt_hip_model_destroy(model); }
+// The device copy of a model and the device contexts (stream + workspace) that run on it. The
+// contexts point into the model, so they live and die with it: ~ModelHandle destroys them before
+// the model (a per-thread cache keyed by the raw model pointer would outlive it: a worker
+// thread that exits after its Model would free contexts of a freed model, and a new model at the
+// same address would inherit them). Movable, not copyable; an empty handle holds nothing.
+class ModelHandle {
+ public:
+  ModelHandle();
+  explicit ModelHandle(slimt_hip_model* model);
+  ModelHandle(ModelHandle&& other) noexcept;
+  ModelHandle& operator=(ModelHandle&& other) noexcept;
+  ModelHandle(const ModelHandle&) = delete;
+  ModelHandle& operator=(const ModelHandle&) = delete;
+  ~ModelHandle();
+
+  slimt_hip_model* get() const;
+  explicit operator bool() const { return get() != nullptr; }
+
+  // A context for a batch of `batch` rows of `length` tokens, taken from the idle ones (grown
+  // when the batch outgrows it) or built; one per concurrent caller ends up in the pool.
+  // Thread-safe: Model::forward is const and runs on every Async worker (Frontend.cc:212-226).
+  struct Lease {
+    slimt_hip_ctx* ctx = nullptr;
+    size_t batch = 0, length = 0, tokens = 0;
+  };
+  Lease acquire(size_t batch, size_t length) const;
+  void release(Lease lease) const;   // back to the pool
+  void discard(Lease lease) const;   // after a failed call: never reused
+
+ private:
+  struct State;
+  std::unique_ptr<State> state_;
 };
+
 struct ShortlistDeleter {
   void operator()(slimt_hip_shortlist* shortlist) const { slimt_hip_shortlist_destroy(shortlist); }
 };
-using ModelHandle = std::unique_ptr<slimt_hip_model, ModelDeleter>;
 using ShortlistHandle = std::unique_ptr<slimt_hip_shortlist, ShortlistDeleter>;
 
 // Transformer::Transformer (slimt/Transformer.cc:87-94): the weights of the Marian .bin `model`
@@ -43,9 +72,9 @@ Words generate(slimt_hip_shortlist* generator, const Words& words,
 
 // Model::forward (slimt/Model.cc:187-204) = embedding + Encoder::forward + the greedy loop of
 // Model::decode (:111-185), the per-batch shortlist (:117-120) included when `generator` is
-// not null. Re-entrant like the const method it replaces: every calling thread keeps its own
-// device context (stream + workspace) per model, built on first use and grown on demand.
-Histories forward(slimt_hip_model* model, slimt_hip_shortlist* generator,
+// not null. Re-entrant like the const method it replaces: every concurrent call borrows a
+// device context from the model's own pool.
+Histories forward(const ModelHandle& model, slimt_hip_shortlist* generator,
                   const Input& input, uint32_t eos_id);
 
 }  // namespace slimt::hip

@@ -23,11 +23,11 @@ SYMBOLS = [
     "slimt_hip_softmax", "slimt_hip_highway", "slimt_hip_sdpa",
     "slimt_hip_request_hw_queues", "slimt_hip_hw_queues", "slimt_hip_model_create_from_bin",
     "slimt_hip_model_create", "slimt_hip_model_destroy", "slimt_hip_model_info",
-    "slimt_hip_ctx_create", "slimt_hip_ctx_create_budget", "slimt_hip_ctx_destroy", "slimt_hip_ctx_stream",
+    "slimt_hip_ctx_create", "slimt_hip_ctx_create_budget", "slimt_hip_ctx_destroy", "slimt_hip_contexts_on_device", "slimt_hip_ctx_stream",
     "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_ctx_set_encode_rows", "slimt_hip_ctx_plan", "slimt_hip_translate", "slimt_hip_translate_device",
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
-    "slimt_hip_debug_decode_stamps",
+    "slimt_hip_debug_decode_stamps", "slimt_hip_debug_kv_formats", "slimt_hip_debug_kv_narrow_limit",
     "slimt_hip_debug_occupancy_trace", "slimt_hip_model_set_decoder_budget",
     "slimt_hip_model_set_kv_cache_policy",
     "slimt_hip_model_set_xcd_affinity", "slimt_hip_model_device",
@@ -124,6 +124,7 @@ def lib():
     L.slimt_hip_model_info.argtypes = [vp, vp, vp, vp, vp]
     L.slimt_hip_ctx_create.argtypes = [vp, sz, sz, vp, vp]
     L.slimt_hip_ctx_destroy.argtypes = [vp]
+    L.slimt_hip_contexts_on_device.argtypes = [i32, vp]
     L.slimt_hip_ctx_stream.argtypes = [vp, vp]
     L.slimt_hip_ctx_synchronize.argtypes = [vp]
     L.slimt_hip_ctx_set_decode_mode.argtypes = [vp, i32]
@@ -145,6 +146,8 @@ def lib():
     L.slimt_hip_profile_reset.argtypes = [vp]
     L.slimt_hip_debug_decode_stamps.argtypes = [vp, i32, vp, sz]
     L.slimt_hip_debug_occupancy_trace.argtypes = [vp, sz]
+    L.slimt_hip_debug_kv_formats.argtypes = [vp, vp, sz, vp]
+    L.slimt_hip_debug_kv_narrow_limit.argtypes = [vp, i32]
     L.slimt_hip_model_set_decoder_budget.argtypes = [vp, i32]
     L.slimt_hip_model_set_kv_cache_policy.argtypes = [vp, i32]
     L.slimt_hip_model_set_xcd_affinity.argtypes = [vp, i32]
@@ -165,6 +168,15 @@ def lib():
             fn.restype = C.c_int
     _lib = L
     return L
+
+
+def contexts_on_device(device: int = 0) -> int:
+    """slimt_hip_contexts_on_device: contexts (streams) this process holds on `device`; past 22 the device's hardware
+    queues are time-sliced and the library says so once on stderr."""
+    n = C.c_int(0)
+    if lib().slimt_hip_contexts_on_device(int(device), C.byref(n)):
+        raise SlimtHipError(lib().slimt_hip_last_error().decode())
+    return int(n.value)
 
 
 def request_hw_queues(n: int = 32) -> bool:
@@ -336,8 +348,13 @@ class Model:
         _chk(lib().slimt_hip_model_set_xcd_affinity(self.h, xcds))
 
     def set_kv_cache_format(self, fmt: int):
-        """0 = packed 24-bit K/V cache where supported (default), 1 = always f32."""
+        """0 = packed K/V cache where supported, 20 bits per value where a sentence's accumulators fit and 24 elsewhere
+        (default); 1 = always f32; 2 = packed, always 24 bits."""
         _chk(lib().slimt_hip_model_set_kv_cache_format(self.h, fmt))
+
+    def debug_kv_narrow_limit(self, limit: int):
+        """Accumulators must lie in [-limit, limit) for the 20-bit cache form (default and maximum 2**19)."""
+        _chk(lib().slimt_hip_debug_kv_narrow_limit(self.h, int(limit)))
 
     def set_adaptive_decoder_rows(self, on: bool):
         """Decode mode 0: 8 or 4 sentences per decoder workgroup while CUs would idle (default on)."""
@@ -559,6 +576,16 @@ class Context:
         out = np.zeros(64, dtype=np.uint64)
         _chk(lib().slimt_hip_debug_decode_stamps(self.h, step, _p(out), 64))
         return out
+
+    def debug_kv_formats(self, layers: int, max_batch: int):
+        """[layers][B] uint8 of the last batch: 0 = its cache is in the 20-bit form, 1 = 24-bit; None when the batch's
+        caches are all in one form."""
+        out = np.zeros(layers * max_batch, dtype=np.uint8)
+        b = C.c_size_t(0)
+        _chk(lib().slimt_hip_debug_kv_formats(self.h, _p(out), out.size, C.byref(b)))
+        if b.value == 0:
+            return None
+        return out[: layers * b.value].reshape(layers, b.value).copy()
 
     def profile_enable(self, kernel_id: int):
         _chk(lib().slimt_hip_profile_enable(self.h, kernel_id))

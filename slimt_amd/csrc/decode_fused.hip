@@ -916,13 +916,21 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
   const int voff = lane * 16;                                            // [S/4][plane][D/4][16 B]
   auto load_k = [&](int hp) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 6; ++i) {
+#ifdef SLIMT_EXP_KV56  // bandwidth experiment only (wrong results): 5 of 6 quads, the bytes of a 20-bit cache
+      if (i == 5) { kq[5] = kq[4]; continue; }
+#endif
       kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((12 * hp + i) * S) * 16, KV_AUX));
+    }
   };
   auto load_v = [&](v4i(&vv)[3], int g) {  // rows 4 g .. 4 g + 3
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) {
+#ifdef SLIMT_EXP_KV56
+      if (i == 2 && (g & 1)) { vv[2] = vv[1]; continue; }
+#endif
       vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + i) * 1024, KV_AUX));
+    }
   };
   // group g (12 bytes = 4 values) of the 48-byte item in planes p0, p1, p2
   auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g) -> f4 {
@@ -999,6 +1007,157 @@ __device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk
   }
   const float o0 = __builtin_fmaf(oa.x, uv256, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv256, pv4.y * P);
   const float o2 = __builtin_fmaf(ob.x, uv256, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv256, pv4.w * P);
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
+}
+
+// attention_row24 out of line: where the narrow form below is the expected one, the 24-bit form is the fallback of the
+// rare sentence-layer with an accumulator past 2^19 -- as a second inlined copy of the attention it costs every
+// sentence registers (the kernel's allocation is the maximum over both paths); as a call it costs the rare one a few
+// saved registers.
+template <int KV_AUX>
+__device__ __noinline__ void attention_row24_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256, float uv256) {
+  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
+  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
+  r.S = __builtin_amdgcn_readfirstlane(r.S);
+  r.len = __builtin_amdgcn_readfirstlane(r.len);
+  attention_row24<KV_AUX>(r, lane, pbk, pbv, uk256, uv256);
+}
+
+// ---- the narrow form of the packed cache: 20 bits per value (kernels.h, FusedDecodeArgs::kv_fmt) -------------------
+// A sentence-layer whose K and V accumulators all lie in [-2^19, 2^19) is cached as hi = accS >> 4 (16 bits) and
+// lo = accS & 15 (4 bits): 2.5 instead of 3 bytes per value, 5 instead of 6 sixteen-byte loads per 32 values -- the
+// K/V stream is what a loaded decoder step waits for (timing-only build with 5 of 6 quads: + 5 % tokens/s). Eight
+// values = one quad of hi halves + one dword of lo nibbles (device_common.h, pack20). Three bit operations per EIGHT
+// values move the nibbles into the high halves of bytes (f0: even values, f1: odd ones); then one v_perm per value
+// builds {hi byte 1, hi byte 0, lo << 4, 0} = accS << 12, whose conversion is exact (20 significant bits) -- the
+// 24-bit form's one extract per value, + 3/8 of an instruction. The chains run 4096 times the accumulators' (exact,
+// a power of two), and u / 4096 takes the factor out: the same floats as from the 24-bit and the f32 form.
+struct Lo20 {
+  unsigned f0, f1;
+};
+__device__ __forceinline__ Lo20 expand20(int lo) {
+  Lo20 e;
+  e.f1 = (unsigned)lo & 0xf0f0f0f0u;
+  e.f0 = ((unsigned)lo << 4) & 0xf0f0f0f0u;
+  return e;
+}
+template <int C>  // value C (0..7) of a quad
+__device__ __forceinline__ float unpack20(const v4i &hi, const Lo20 &e) {
+  constexpr int k = C >> 1, n = C & 1;
+  const unsigned hw = (unsigned)(k == 0 ? hi.x : k == 1 ? hi.y : k == 2 ? hi.z : hi.w);
+  constexpr unsigned sel = ((4u + 2 * n + 1) << 24) | ((4u + 2 * n) << 16) | ((unsigned)k << 8) | 0x0cu;
+  return (float)(int)__builtin_amdgcn_perm(hw, n ? e.f1 : e.f0, sel);
+}
+
+// attention_row24 over the narrow form (S <= 32, d_head 32, D = 256): the same passes and the same order of every
+// float operation. Layouts (per sentence, in the slot the 24-bit form would take):
+//   K [head][plane 0..4][S][16 B]         planes 0..3: hi halves of the head's columns 8 p .. 8 p + 7 of one key,
+//                                          plane 4: the lo nibbles of all 32 (dword p belongs to plane p)
+//   V [ceil(S / 8)][plane 0..4][D/4][16 B] planes 0..3: keys 8 g + 2 p, 8 g + 2 p + 1 x 4 consecutive columns
+//                                          (key-major), plane 4: their lo nibbles (dword p belongs to plane p)
+template <int KV_AUX>
+__device__ __forceinline__ void attention_row20(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096,
+                                                float uv4096) {
+  constexpr int D = 256, DH = 32, H = D / DH;
+  const int S = r.S, len = r.len;
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int hh = lane >> 5, j = lane & 31;
+  const int jc = j < S ? j : S - 1;
+  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+  v4i kq[5];     // this lane's key, its head's 32 columns
+  v4i vq[2][5];  // V rows in flight: two groups of eight rows
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 640));
+  // masked keys are not fetched: past the descriptors a load returns zeros -- a score that the mask
+  // overrides, a value weighted by a probability that is exactly 0
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 5120));
+  const int koff = j < lenf ? (hh * 5 * S + jc) * 16 : kPastDescriptor;
+  const int voff = lane * 16;
+  auto load_k = [&](int hp) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((10 * hp + i) * S) * 16, KV_AUX));
+  };
+  auto load_v = [&](v4i(&vv)[5], int g) {  // rows 8 g .. 8 g + 7
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (5 * g + i) * 1024, KV_AUX));
+  };
+  load_k(0);
+  load_v(vq[0], 0);
+  __builtin_amdgcn_sched_barrier(0);
+  float ck[4];  // c_h of this lane's head in pass hp (under the first loads' round trip)
+  head_constants32(r.qrow, pbk, lane, ck);
+#pragma unroll
+  for (int hp = 0; hp < H / 2; ++hp) {
+    const int h = 2 * hp + hh;
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d0 = h * DH + 8 * i;
+      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
+      const int lo[4] = {kq[4].x, kq[4].y, kq[4].z, kq[4].w};
+      const Lo20 e = expand20(lo[i]);
+      t = __builtin_fmaf(qa.x, unpack20<0>(kq[i], e), t);
+      t = __builtin_fmaf(qa.y, unpack20<1>(kq[i], e), t);
+      t = __builtin_fmaf(qa.z, unpack20<2>(kq[i], e), t);
+      t = __builtin_fmaf(qa.w, unpack20<3>(kq[i], e), t);
+      t = __builtin_fmaf(qb.x, unpack20<4>(kq[i], e), t);
+      t = __builtin_fmaf(qb.y, unpack20<5>(kq[i], e), t);
+      t = __builtin_fmaf(qb.z, unpack20<6>(kq[i], e), t);
+      t = __builtin_fmaf(qb.w, unpack20<7>(kq[i], e), t);
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);  // at most sixteen q values from LDS in flight
+    }
+    if (hp + 1 < H / 2) {
+      load_k(hp + 1);
+    } else {  // the K registers are free: the second group of V rows
+      load_v(vq[1], 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float s = __builtin_fmaf(t, uk4096, ck[hp]);
+    if (r.alpha != 1.0f) s = r.alpha * s;
+    s = s + mask;
+    if (j >= S) s = lowest;
+    const float m = half_max(s);
+    const float e = j < S ? exp_p(s - m) : 0.0f;
+    const float sum = half_sum(e);
+    const float p = e / sum;  // keys >= S: exactly 0
+    const float ps = half_sum(p);  // P_h
+    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
+    if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
+    r.pbuf[h * 32 + j] = p;
+    if (j == 0) r.hsum[h] = ps;
+  }
+  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
+  const int ph = (lane >> 3) * 32;
+  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  const float P = r.hsum[lane >> 3];
+  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};  // columns (0, 1) and (2, 3): v_pk_fma_f32 is one fma per column
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    v4i(&cur)[5] = vq[g & 1];
+    const int lo[4] = {cur[4].x, cur[4].y, cur[4].z, cur[4].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
+      const Lo20 e = expand20(lo[c]);
+      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);  // (two at a time: eight would be eight registers)
+      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
+      const f2 va0 = {unpack20<0>(cur[c], e), unpack20<1>(cur[c], e)}, vb0 = {unpack20<2>(cur[c], e), unpack20<3>(cur[c], e)};
+      const f2 va1 = {unpack20<4>(cur[c], e), unpack20<5>(cur[c], e)}, vb1 = {unpack20<6>(cur[c], e), unpack20<7>(cur[c], e)};
+      oa = __builtin_elementwise_fma(p0, va0, oa);
+      ob = __builtin_elementwise_fma(p0, vb0, ob);
+      oa = __builtin_elementwise_fma(p1, va1, oa);
+      ob = __builtin_elementwise_fma(p1, vb1, ob);
+    }
+    // pin this group's sums here (attention_row24: without a use the optimiser sinks every group's work below the last load)
+    asm volatile("" : "+v"(oa), "+v"(ob));
+    if (g + 2 < 4) load_v(vq[g & 1], g + 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float o0 = __builtin_fmaf(oa.x, uv4096, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv4096, pv4.y * P);
+  const float o2 = __builtin_fmaf(ob.x, uv4096, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv4096, pv4.w * P);
   *(SLIMT_LDS int *)(r.arow + 4 * lane) =
       pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
 }
@@ -1534,6 +1693,19 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     n_out[rr] = 0;
   }
   const int valid_rows = (B - m0) < RS ? (B - m0) : RS;
+  // the form of this wave's sentences' caches, one bit per layer: 1 = 24-bit, 0 = narrow (kernels.h, kv_fmt)
+  unsigned kv_wide[RT];
+#pragma unroll
+  for (int rr = 0; rr < RT; ++rr) {
+    kv_wide[rr] = ~0u;
+    if constexpr (KV24 && MID == 0 && KSD == 4) {
+      if (a.kv_fmt && live[rr]) {
+        unsigned w = 0;
+        for (int l = 0; l < Ld; ++l) w |= (unsigned)(a.kv_fmt[(size_t)l * B + bq[rr]] != 0) << l;
+        kv_wide[rr] = __builtin_amdgcn_readfirstlane(w);
+      }
+    }
+  }
 
   // start_states, Transformer.cc:78-85
   if constexpr (CELLS_GLOBAL) {
@@ -1753,10 +1925,23 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
               attention_row24_mid<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
           } else if constexpr (KV24) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
+#ifdef SLIMT_EXP_NO_KV20  // A/B builds: the kernel as it was before the narrow form (engine.cpp then never records forms)
             if (NT && kv_streams)
               attention_row24<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+#else
+            const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
+            if (!wide) {
+              if (NT && kv_streams)
+                attention_row20<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+              else
+                attention_row20<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+            } else if (NT && kv_streams)
+              attention_row24_cold<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+            else
+              attention_row24_cold<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+#endif
           } else if (NT && kv_streams)
             attention_row<D, DH, LONG, 2>(ar, lane);
           else

@@ -26,6 +26,32 @@ __device__ __forceinline__ int checked_length(uint32_t len, int S) { return len 
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+// ---- the narrow (20-bit) form of the packed K/V cache (kernels.h, FusedDecodeArgs::kv_fmt) ----------------------
+// Eight accumulators x[0..7], each in [-2^19, 2^19): x = 16 hi + lo with hi = x >> 4 (a signed 16-bit integer) and
+// lo = x & 15. The eight hi halves are one 16-byte quad (little endian, value c in the low / high half of dword c / 2),
+// the eight lo nibbles one dword (value c at bits 4 c .. 4 c + 3). The decoder rebuilds x << 12 with ONE v_perm per
+// value: bytes {hi's two, lo << 4, 0} (decode_fused.hip, unpack20).
+struct Packed20 {
+  v4i hi;
+  int lo;
+};
+__device__ __forceinline__ Packed20 pack20(const v4i &a, const v4i &b) {
+  const int x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  Packed20 o;
+  int h[4];
+  o.lo = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    h[c] = ((x[2 * c] >> 4) & 0xffff) | ((x[2 * c + 1] << 12) & (int)0xffff0000);
+    o.lo |= ((x[2 * c] & 15) << (8 * c)) | ((x[2 * c + 1] & 15) << (8 * c + 4));
+  }
+  o.hi = v4i{h[0], h[1], h[2], h[3]};
+  return o;
+}
+// does x fit the narrow form?
+__device__ __forceinline__ bool fits20(int x) { return (unsigned)(x + (1 << 19)) < (1u << 20); }
+constexpr int kKvNarrowMin = -(1 << 19), kKvNarrowMax = (1 << 19) - 1;
+
 __device__ __forceinline__ float exp_p(float x) {
   if (x < -86.0f) return 0.0f;
   if (x > 88.0f) x = 88.0f;

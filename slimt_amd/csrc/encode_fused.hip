@@ -194,6 +194,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
   // this workgroup's sentence lengths: read once (they may live in pinned host memory)
   __shared__ int slens[ER];
+  __shared__ int kv_wide_flag;  // the narrow cache form does not hold this workgroup's accumulators (kernels.h, kv_fmt)
   if (tid < spw) slens[tid] = s0 + tid < B ? checked_length(a.lengths[s0 + tid], S) : 0;
 
   float *xs = reinterpret_cast<float *>(smem);
@@ -606,6 +607,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         Av[r * LDA + lane + 64 * i] = (char)quantize1_byte(v, wv.a_quant);
       }
     }
+    if (tid == 0) kv_wide_flag = 0;  // (raised behind this barrier, read behind the staging barrier, by every thread)
     lds_barrier();
     v4i bk[KSD], bv[KSD];
     load_frags<KSD>(bk, wk, wave, 0, lane);
@@ -620,6 +622,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       // through the (dead) q / k buffers.
       int *stk = reinterpret_cast<int *>(qb), *stv = reinterpret_cast<int *>(kb);
       static_assert(LDQQ == LDK, "both staging tiles use the q row stride");
+      unsigned outside = 0;  // an accumulator of a valid row outside the narrow form's [-limit, limit)
+      const unsigned lim = a.kv_fmt ? (unsigned)a.kv_narrow_limit : 0x40000000u;
       {
         v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
         tile_mma2<KSD>(Ak, LDA, bk, lr, lg, c0, c1);
@@ -629,8 +633,11 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         (void)pb;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          stk[(lg * 4 + r) * LDQQ + col] = c0[r] + __mul24(127, cs);
-          stk[(16 + lg * 4 + r) * LDQQ + col] = c1[r] + __mul24(127, cs);
+          const int s0v = c0[r] + __mul24(127, cs), s1v = c1[r] + __mul24(127, cs);
+          stk[(lg * 4 + r) * LDQQ + col] = s0v;
+          stk[(16 + lg * 4 + r) * LDQQ + col] = s1v;
+          if (row_valid(lg * 4 + r)) outside |= (unsigned)((unsigned)s0v + lim >= 2u * lim);
+          if (row_valid(16 + lg * 4 + r)) outside |= (unsigned)((unsigned)s1v + lim >= 2u * lim);
         }
       }
       {
@@ -642,11 +649,62 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         (void)pb;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          stv[(lg * 4 + r) * LDQQ + col] = c0[r] + __mul24(127, cs);
-          stv[(16 + lg * 4 + r) * LDQQ + col] = c1[r] + __mul24(127, cs);
+          const int s0v = c0[r] + __mul24(127, cs), s1v = c1[r] + __mul24(127, cs);
+          stv[(lg * 4 + r) * LDQQ + col] = s0v;
+          stv[(16 + lg * 4 + r) * LDQQ + col] = s1v;
+          if (row_valid(lg * 4 + r)) outside |= (unsigned)((unsigned)s0v + lim >= 2u * lim);
+          if (row_valid(16 + lg * 4 + r)) outside |= (unsigned)((unsigned)s1v + lim >= 2u * lim);
         }
       }
+      if (outside) kv_wide_flag = 1;
       lds_barrier();
+      // The form of this workgroup's caches of this layer (kernels.h, FusedDecodeArgs::kv_fmt): the narrow one, 20 bits
+      // per value, when every K and V accumulator of its valid rows lies in [-limit, limit) -- both tiles are staged, so
+      // the choice is made before anything is written --, else 24 bits. The same integers either way.
+      const bool wide = !a.kv_fmt || kv_wide_flag != 0;
+      if (a.kv_fmt && tid < spw && s0 + tid < B) a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
+      if (!wide) {
+        // decode_fused.hip, attention_row20: one thread = 32 values = four quads of hi halves + one quad of lo nibbles
+        //   K [sentence][head][plane 0..4][key][16 B],  V [sentence][key / 8][plane 0..4][column / 4][16 B]
+        const int Sp = (S + 3) & ~3, G = (S + 7) >> 3;
+        const rsrc_t rko = make_rsrc(kout, (unsigned)((size_t)B * S * D * 3));
+        const rsrc_t rvo = make_rsrc(vout, (unsigned)((size_t)B * Sp * D * 3));
+        for (int it = tid; it < ER * (D / 32); it += 1024) {
+          const int r = it % ER, h = it / ER;
+          if (!row_valid(r)) continue;
+          const int off = row_sentence(r) * S * D * 3 + (h * 5 * S + r % S) * 16;
+          int lo[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const Packed20 pk = pack20(*reinterpret_cast<const v4i *>(stk + r * LDQQ + 32 * h + 8 * q),
+                                       *reinterpret_cast<const v4i *>(stk + r * LDQQ + 32 * h + 8 * q + 4));
+            lo[q] = pk.lo;
+            __builtin_amdgcn_raw_buffer_store_b128(pk.hi, rko, off + q * S * 16, 0, 0);
+          }
+          const v4i lq = {lo[0], lo[1], lo[2], lo[3]};
+          __builtin_amdgcn_raw_buffer_store_b128(lq, rko, off + 4 * S * 16, 0, 0);
+        }
+        for (int it = tid; it < spw * G * 64; it += 1024) {
+          const int cl = it & 63, g = (it >> 6) % G, si = (it >> 6) / G;
+          if (s0 + si >= B) continue;
+          const int off = (s0 + si) * Sp * D * 3 + (g * 5 * 64 + cl) * 16;
+          int lo[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {  // keys past the sentence: zeros (finite once unpacked, weight 0)
+            const int k0 = 8 * g + 2 * q, k1 = k0 + 1;
+            const v4i z = {0, 0, 0, 0};
+            const v4i x0 = *reinterpret_cast<const v4i *>(stv + (si * S + (k0 < S ? k0 : 0)) * LDQQ + 4 * cl);
+            const v4i x1 = *reinterpret_cast<const v4i *>(stv + (si * S + (k1 < S ? k1 : 0)) * LDQQ + 4 * cl);
+            const Packed20 pk = pack20(k0 < S ? x0 : z, k1 < S ? x1 : z);
+            lo[q] = pk.lo;
+            __builtin_amdgcn_raw_buffer_store_b128(pk.hi, rvo, off + q * 1024, 0, 0);
+          }
+          const v4i lq = {lo[0], lo[1], lo[2], lo[3]};
+          __builtin_amdgcn_raw_buffer_store_b128(lq, rvo, off + 4 * 1024, 0, 0);
+        }
+        lds_barrier();
+        continue;
+      }
       // One thread = 16 values = 48 bytes = three 16-byte stores, one per plane, so that the
       // decoder's 16-byte loads stay contiguous across lanes:
       //   K [sentence][column / 16][plane][key][16 B]      (consecutive lanes = consecutive keys)

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   // this workgroup's sentence lengths: read once (they may live in pinned host memory, and every
   // attention job needs its sentence's; ordered by the first barrier below)
   __shared__ int slens[TR];
+  __shared__ int kv_wide_flag;  // the narrow cache form does not hold this workgroup's accumulators (the K/V phase at the end)
   if (tid < spw) slens[tid] = s0 + tid < B ? checked_length(a.lengths[s0 + tid], S) : 0;
 
   char *Aq = smem;                       // x quantised for Q | round 1's attention output | for FFN1 | for the decoder's K / V
@@ -783,45 +784,116 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       }
     }
   }
+  // The packed cache takes one of two forms per workgroup and layer (kernels.h, FusedDecodeArgs::kv_fmt): the narrow one,
+  // 20 bits per value, when every K and V accumulator of this workgroup's rows lies in [-limit, limit), else 24 bits.
+  // The narrow form is tried first; an accumulator that does not fit (seen by its lane while the tile is staged) raises
+  // kv_wide_flag, every thread reads it behind the staging barrier, and the layer's K and V are produced again in the
+  // 24-bit form over whatever the narrow attempt wrote. Both forms hold the same integers.
+  const bool try_narrow = NKT == 2 && a.kv24 && a.kv_fmt != nullptr;
   for (int l = 0; l < a.Ld; ++l) {
-    for (int p = 0; p < 2; ++p) {
-      SLIMT_TPHASE_LANE;
-      const PreparedWeight &w = p == 0 ? a.dec_k[l] : a.dec_v[l];
-      float *out = a.kv + (size_t)(2 * l + p) * B * S * D;
-      v4i wf[KSD];
-      load_w(wf, w, wave, lane);
-      const TEpi e = tload_epi(w, wave, lg);
-      // (packed cache: no barrier here -- every wave's reads of the A buffer lie in front of the barrier between the products and
-      // the packing loop of the projection before, or of FFN1's; the staging tile is not written until the barrier below)
-      if (!a.kv24) lds_barrier();  // the A buffer and the region are free
-      quantise_x(0, w.a_quant, tq_base(lane));
-      lds_barrier();
-      const int col = wave * 16 + lg * 4;
-      const AFrag af = a_frag(Aq, lane);
-      const v4i skv = tshift(e);
-      int *stg = reinterpret_cast<int *>(region);  // packed cache: [TR][LDY] shifted accumulators
+    bool wide = !try_narrow;
+    for (int attempt = 0; attempt < (NKT == 2 ? 2 : 1); ++attempt) {
+      bool redo = false;
+      for (int p = 0; p < 2; ++p) {
+        SLIMT_TPHASE_LANE;
+        const PreparedWeight &w = p == 0 ? a.dec_k[l] : a.dec_v[l];
+        float *out = a.kv + (size_t)(2 * l + p) * B * S * D;
+        v4i wf[KSD];
+        load_w(wf, w, wave, lane);
+        const TEpi e = tload_epi(w, wave, lg);
+        // (packed cache: no barrier here -- every wave's reads of the A buffer lie in front of the barrier between the products and
+        // the packing loop of the projection before, or of FFN1's; the staging tile is not written until the barrier below)
+        if (!a.kv24) lds_barrier();  // the A buffer and the region are free
+        quantise_x(0, w.a_quant, tq_base(lane));
+        // (the flag is raised behind the barrier below only; it can still be 1 from the layer before, whose narrow attempt
+        // was then followed by a whole 24-bit one: every thread has read it long ago)
+        if (!wide && p == 0 && tid == 0) kv_wide_flag = 0;
+        lds_barrier();
+        const int col = wave * 16 + lg * 4;
+        const AFrag af = a_frag(Aq, lane);
+        const v4i skv = tshift(e);
+        int *stg = reinterpret_cast<int *>(region);  // packed cache: [TR][LDY] shifted accumulators
+        unsigned outside = 0;  // narrow attempt: an accumulator of a valid row outside [-limit, limit)
+        const unsigned lim = (unsigned)a.kv_narrow_limit;
 #pragma unroll
-      for (int rt = 0; rt < TRT; ++rt) {
-        const v4i c = mma_rt(wf, rt, af, skv);
-        const int rrow = 16 * rt + lr;
-        if (a.kv24) {
-          *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = c;
-        } else if (row_valid(rrow)) {
-          // c is the shifted accumulator accS: the cache holds float(accS), exact (kernels.h, kv24)
-          const float4 v = {(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
-          if (p == 0) {  // K cache layout [sentence][head][d/4][key][4]: the lane's 4 columns are one d/4 group
-            const size_t chunk = (size_t)row_sentence(rrow) * (D / 4) + (col >> 2);
-            *reinterpret_cast<float4 *>(out + (chunk * S + rrow % S) * 4) = v;
-          } else {
-            *reinterpret_cast<float4 *>(out + ((size_t)row_sentence(rrow) * S + rrow % S) * D + col) = v;
+        for (int rt = 0; rt < TRT; ++rt) {
+          const v4i c = mma_rt(wf, rt, af, skv);
+          const int rrow = 16 * rt + lr;
+          if (a.kv24) {
+            *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = c;
+            if (!wide && row_valid(rrow)) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) outside |= (unsigned)((unsigned)c[i] + lim >= 2u * lim);
+            }
+          } else if (row_valid(rrow)) {
+            // c is the shifted accumulator accS: the cache holds float(accS), exact (kernels.h, kv24)
+            const float4 v = {(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
+            if (p == 0) {  // K cache layout [sentence][head][d/4][key][4]: the lane's 4 columns are one d/4 group
+              const size_t chunk = (size_t)row_sentence(rrow) * (D / 4) + (col >> 2);
+              *reinterpret_cast<float4 *>(out + (chunk * S + rrow % S) * 4) = v;
+            } else {
+              *reinterpret_cast<float4 *>(out + ((size_t)row_sentence(rrow) * S + rrow % S) * D + col) = v;
+            }
           }
         }
-      }
-      if (a.kv24) {
-        // the packed cache (kernels.h, FusedDecodeArgs::kv24): one thread = 16 values = 48 bytes =
-        // three 16-byte stores, one per plane
+        if (!a.kv24) continue;
+        if (outside) kv_wide_flag = 1;
         lds_barrier();
+        if (!wide && kv_wide_flag) {  // uniform: read by every thread behind the barrier
+          redo = true;
+          break;
+        }
         const int Sp = (S + 3) & ~3;
+        if (!wide) {
+          // the narrow form (decode_fused.hip, attention_row20): one thread = 32 values = four quads of hi halves + one
+          // quad of lo nibbles
+          if (p == 0) {  // K [sentence][head][plane 0..4][key][16 B]: consecutive lanes = consecutive keys
+            const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * S * D * 3));
+            for (int it = tid; it < TR * (D / 32); it += 1024) {
+              const int r = it % TR, h = it / TR;
+              if (!row_valid(r)) continue;
+              const int off = row_sentence(r) * S * D * 3 + (h * 5 * S + r % S) * 16;
+              int lo[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const Packed20 pk = pack20(*reinterpret_cast<const v4i *>(stg + r * LDY + 32 * h + 8 * q),
+                                           *reinterpret_cast<const v4i *>(stg + r * LDY + 32 * h + 8 * q + 4));
+                lo[q] = pk.lo;
+                if (a.kv_store_nt) __builtin_amdgcn_raw_buffer_store_b128(pk.hi, ro, off + q * S * 16, 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(pk.hi, ro, off + q * S * 16, 0, 0);
+              }
+              const v4i lq = {lo[0], lo[1], lo[2], lo[3]};
+              if (a.kv_store_nt) __builtin_amdgcn_raw_buffer_store_b128(lq, ro, off + 4 * S * 16, 0, 2);
+              else __builtin_amdgcn_raw_buffer_store_b128(lq, ro, off + 4 * S * 16, 0, 0);
+            }
+          } else {  // V [sentence][key / 8][plane 0..4][column / 4][16 B]: key pairs x 4 columns, key-major
+            const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * Sp * D * 3));
+            const int G = (S + 7) >> 3;
+            for (int it = tid; it < spw * G * 64; it += 1024) {
+              const int cl = it & 63, g = (it >> 6) % G, si = (it >> 6) / G;
+              if (s0 + si >= B) continue;
+              const int off = (s0 + si) * Sp * D * 3 + (g * 5 * 64 + cl) * 16;
+              int lo[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {  // keys past the sentence: zeros (finite once unpacked, weight 0)
+                const int k0 = 8 * g + 2 * q, k1 = k0 + 1;
+                const v4i z = {0, 0, 0, 0};
+                const v4i x0 = *reinterpret_cast<const v4i *>(stg + (si * S + (k0 < S ? k0 : 0)) * LDY + 4 * cl);
+                const v4i x1 = *reinterpret_cast<const v4i *>(stg + (si * S + (k1 < S ? k1 : 0)) * LDY + 4 * cl);
+                const Packed20 pk = pack20(k0 < S ? x0 : z, k1 < S ? x1 : z);
+                lo[q] = pk.lo;
+                if (a.kv_store_nt) __builtin_amdgcn_raw_buffer_store_b128(pk.hi, ro, off + q * 1024, 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(pk.hi, ro, off + q * 1024, 0, 0);
+              }
+              const v4i lq = {lo[0], lo[1], lo[2], lo[3]};
+              if (a.kv_store_nt) __builtin_amdgcn_raw_buffer_store_b128(lq, ro, off + 4 * 1024, 0, 2);
+              else __builtin_amdgcn_raw_buffer_store_b128(lq, ro, off + 4 * 1024, 0, 0);
+            }
+          }
+          continue;
+        }
+        // the 24-bit form (kernels.h, FusedDecodeArgs::kv24): one thread = 16 values = 48 bytes =
+        // three 16-byte stores, one per plane
         if (p == 0) {  // K [sentence][column / 16][plane][key][16 B]: consecutive lanes = consecutive keys
           const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * S * D * 3));
           for (int it = tid; it < TR * (D / 16); it += 1024) {
@@ -871,6 +943,11 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           }
         }
       }
+      if (!redo) break;
+      wide = true;
+    }
+    if constexpr (NKT == 2) {  // (33..64-token sentences: always the 24-bit form, nothing recorded)
+      if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
     }
   }
   if (gen_here) {

@@ -729,9 +729,30 @@ extern "C" int slimt_hip_model_set_adaptive_decoder_rows(slimt_hip_model *model,
 
 extern "C" int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format) {
   if (!model) return fail(-1, "model is NULL");
-  if (format < 0 || format > 1) return fail(-1, "K/V cache format %d not in 0..1", format);
+  if (format < 0 || format > 2) return fail(-1, "K/V cache format %d not in 0..2", format);
   std::lock_guard<std::mutex> lock(model->gate_mu);
   model->kv_format = format;
+  return 0;
+}
+
+extern "C" int slimt_hip_debug_kv_narrow_limit(slimt_hip_model *model, int limit) {
+  if (!model) return fail(-1, "model is NULL");
+  if (limit < 1 || limit > (1 << 19)) return fail(-1, "narrow-form limit %d not in 1..2^19 (20 bits hold [-2^19, 2^19))", limit);
+  std::lock_guard<std::mutex> lock(model->gate_mu);
+  model->kv_narrow_limit = limit;
+  return 0;
+}
+
+extern "C" int slimt_hip_debug_kv_formats(slimt_hip_ctx *ctx, uint8_t *out, size_t n, size_t *batch) {
+  if (!ctx || !out || !batch) return fail(-1, "null argument");
+  HIPCHK(hipSetDevice(ctx->model->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *batch = 0;
+  if (!ctx->kv_fmt_valid) return 0;  // the last batch's caches are all in one form (24-bit or f32)
+  const size_t have = (size_t)ctx->model->Ld * (size_t)ctx->kv_fmt_B;
+  if (n < have) return fail(-1, "kv formats: %zu bytes for %zu", n, have);
+  HIPCHK(hipMemcpy(out, ctx->kv_fmt.p, have, hipMemcpyDeviceToHost));
+  *batch = (size_t)ctx->kv_fmt_B;
   return 0;
 }
 
@@ -858,6 +879,36 @@ double gemm_bytes(const PreparedWeight &w) { return (double)w.K * w.n_tiles * 16
 
 }  // namespace
 
+// Contexts alive per device in this process. Every context is a stream, and past ~22 of them the device's
+// hardware queues are time-sliced whatever GPU_MAX_HW_QUEUES says: 21 / 22 workers 32.5 / 32.1 M tok/s, 24 workers
+// 23.8 M, 32 workers 20.4 M (profiles/r04_v1_budget_workers_sweep.txt). Said once, on stderr, when it happens
+// (SLIMT_HIP_QUIET=1: not said); slimt_hip_contexts_on_device reports the count.
+static constexpr int kMaxDevices = 64;
+static constexpr int kContextCliff = 22;
+static std::atomic<int> g_live_ctx[kMaxDevices];
+
+static void count_context(int device, int delta) {
+  if (device < 0 || device >= kMaxDevices) return;
+  const int now = g_live_ctx[device].fetch_add(delta, std::memory_order_relaxed) + delta;
+  if (delta > 0 && now > kContextCliff) {
+    static std::atomic<bool> warned{false};
+    const char *quiet = std::getenv("SLIMT_HIP_QUIET");
+    if (!(quiet && quiet[0] == '1') && !warned.exchange(true))
+      std::fprintf(stderr,
+                   "slimt_hip: %d contexts on device %d in one process: past %d the device's hardware queues are "
+                   "time-sliced (24 contexts measured 30 %% below 20); use fewer workers with larger batches, or one "
+                   "process per device\n",
+                   now, device, kContextCliff);
+  }
+}
+
+extern "C" int slimt_hip_contexts_on_device(int device, int *count) {
+  if (!count) return fail(-1, "null argument");
+  if (device < 0 || device >= kMaxDevices) return fail(-1, "device %d out of range", device);
+  *count = g_live_ctx[device].load(std::memory_order_relaxed);
+  return 0;
+}
+
 extern "C" int slimt_hip_ctx_create(slimt_hip_model *model, size_t max_batch,
                                     size_t max_source_length, void *stream, slimt_hip_ctx **out) {
   return slimt_hip_ctx_create_budget(model, max_batch, max_source_length,
@@ -894,12 +945,14 @@ extern "C" int slimt_hip_ctx_create_budget(slimt_hip_model *model, size_t max_ba
     delete c;
     return rc;
   }
+  count_context(model->device, +1);
   *out = c;
   return 0;
 }
 
 extern "C" int slimt_hip_ctx_destroy(slimt_hip_ctx *ctx) {
   if (!ctx) return 0;
+  count_context(ctx->model->device, -1);
   (void)hipSetDevice(ctx->model->device);
   (void)hipStreamSynchronize(ctx->stream);
   {
@@ -1095,6 +1148,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
   hipStream_t st = c->stream;
   const int M = B * S, D = m->D;
   const size_t nbytes = (size_t)M * D * 4;
+  c->kv_fmt_valid = false;  // set below by the one path that records the forms of a packed cache
   c->B = B;
   c->S = S;
   c->have_encoder_out = false;
@@ -1127,6 +1181,19 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     f.kv24 = kv24;
     f.kv_store_nt = kv_store_nt;
     if (kv24 && (size_t)M * D * 3 >= (1u << 31)) return fail(-1, "packed K/V cache: %d rows exceed a 2 GB plane", M);
+    // the narrow (20-bit) form where the writer and the reader have it -- D = 256, S <= 32 -- and where a
+    // sentence's V block (groups of eight keys) fits the slot of its 24-bit form (groups of four): not S = 1..4, 9..12
+    c->kv_fmt_valid = kv24 && m->kv_format == 0 && D == 256 && S <= 32 &&
+                      ((S + 7) / 8) * 5120 <= ((S + 3) / 4) * 3072;
+#ifdef SLIMT_EXP_NO_KV20  // A/B builds (decode_fused.hip)
+    c->kv_fmt_valid = false;
+#endif
+    if (c->kv_fmt_valid) {
+      HIPCHK(c->kv_fmt.reserve((size_t)m->Ld * c->max_B));
+      f.kv_fmt = c->kv_fmt.as<unsigned char>();
+      f.kv_narrow_limit = std::min(m->kv_narrow_limit, 1 << 19);
+      c->kv_fmt_B = B;
+    }
     f.enc_out = keep_out ? c->x0.as<float>() : nullptr;
     if (pack) {
       f.pack = *pack;
@@ -1560,6 +1627,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.emb = embed_args(c);
     f.kv = c->kv.as<float>();
     f.kv24 = kv24;
+    if (kv24 && c->kv_fmt_valid && c->kv_fmt_B == (int)B) f.kv_fmt = c->kv_fmt.as<unsigned char>();
     for (int l = 0; l < m->Ld; ++l) {  // the projections' constants, applied after the attention's sums (kernels.h, kv24)
       const AffineW &wk = m->dec[(size_t)l].attn.k, &wv = m->dec[(size_t)l].attn.v;
       f.kv_pb[l][0] = wk.w.pb;
@@ -1570,6 +1638,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       f.kv_u[l][1] = wv.w.u;
       f.kv_u256[l][0] = wk.w.u * (1.0f / 256.0f);  // exact scalings: the packed integers come back
       f.kv_u256[l][1] = wv.w.u * (1.0f / 256.0f);  // as accS * 256 (decode_fused.hip, unpack24f)
+      f.kv_u4096[l][0] = wk.w.u * (1.0f / 4096.0f);  // ... as accS * 4096 from the narrow form (unpack20)
+      f.kv_u4096[l][1] = wv.w.u * (1.0f / 4096.0f);
     }
     f.cells = c->state.as<float>();
     f.lengths = d_lengths;
@@ -1619,7 +1689,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       // call takes a few milliseconds), not by asking the runtime: one hipEventQuery per context
       // under this lock made every launch O(contexts) runtime calls, and with a dozen worker threads
       // the launches queued behind each other (Service, 16 workers: 9.9 ms per launch call).
-      const double kv_bytes = (double)m->Ld * 2.0 * (double)B * (double)S * m->D * (kv24 ? 3.0 : 4.0);
+      // (the narrow form is what the model's sentences are expected to take where the kernels have it: 2.5 bytes per value)
+      const double kv_bytes = (double)m->Ld * 2.0 * (double)B * (double)S * m->D * (f.kv_fmt ? 2.5 : kv24 ? 3.0 : 4.0);
       const auto now = std::chrono::steady_clock::now();
       double pending = kv_bytes;
       size_t contexts = 1;

@@ -96,7 +96,10 @@ struct slimt_hip_model {
   std::atomic<unsigned long long> kv_call_seq{0};  // K/V cache policy per launch (engine.cpp): a slot per translate call,
   std::atomic<int> kv_k_last{8};                   // and the k (kept launches of every 8) of the last admission
   bool adaptive_rows = true;  // decode mode 0: 8 or 4 sentences per decoder workgroup while CUs would idle (engine.cpp)
-  int kv_format = 0;  // 0 = packed 24-bit cache where the kernels have it (kernels.h, kv24), 1 = always f32
+  // 0 = the packed cache where the kernels have it (kernels.h, kv24), 20 bits per value for the sentence-layers whose
+  // accumulators fit (kv_fmt) and 24 for the others; 1 = always f32; 2 = packed, always 24 bits
+  int kv_format = 0;
+  int kv_narrow_limit = 1 << 19;  // accumulators in [-limit, limit) take the narrow form (slimt_hip_debug_kv_narrow_limit)
 };
 
 struct slimt_hip_ctx {
@@ -129,6 +132,9 @@ struct slimt_hip_ctx {
   unsigned enc_ticket_base = 0;  // the same for the fused encoder (second counter of `ticket`)
   unsigned xarr_base = 0, xclaim_base = 0;  // XCD-affine claims (64-bit state word behind the two counters)
   slimt_hip::DevBuf kv;  // [Ld][2][B*S][D]
+  slimt_hip::DevBuf kv_fmt;  // [Ld][B] bytes: the form of each sentence-layer's packed cache (kernels.h, FusedDecodeArgs::kv_fmt)
+  bool kv_fmt_valid = false;  // the encoder of the current batch recorded kv_fmt (else every cache is in the 24-bit form)
+  int kv_fmt_B = 0;           // the batch size kv_fmt was recorded for
   // decoder workspace
   slimt_hip::DevBuf dx, dx_pre, dh, datt8, dout, df8, state;
   slimt_hip::DevBuf part_val, part_idx;

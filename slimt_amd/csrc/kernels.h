@@ -318,6 +318,14 @@ struct FusedDecodeArgs {
   // after its sums (decode_fused.hip, unpack24f: the hoisted PORTABLE order of the oracle), the same
   // arithmetic from either form, the packed one from 25 % fewer bytes, load instructions and registers in flight.
   bool kv24 = false;
+  // The NARROW form of the packed cache (D = 256, S <= 32): a sentence-layer whose K and V accumulators all lie in
+  // [-2^19, 2^19) is cached in 20 bits per value -- accS >> 4 as a signed 16-bit plane, accS & 15 as a nibble plane
+  // (decode_fused.hip, attention_row20: layouts and the unpack) -- in the slot its 24-bit form would take; any other
+  // keeps the 24-bit form, which holds every accumulator K = 256 can produce. kv_fmt[l * B + b] (written by the
+  // encoder that filled the cache, FusedEncodeArgs::kv_fmt) says which: 0 = narrow, 1 = 24-bit; nullptr = all 24-bit.
+  // Both forms give back the same integers, so results do not depend on it: 17 % fewer K/V bytes per step.
+  const unsigned char *kv_fmt = nullptr;
+  float kv_u4096[4][2] = {};      // [layer][K, V]: u / 4096 (narrow form: the integers come back as accS * 4096)
   const float *kv_pb[4][2] = {};  // [layer][K, V]: the projections' prepared biases [D] (both forms)
   const int *kv_cs[4][2] = {};    // [layer][K, V]: their column sums [D] (D = 512: the cache holds the signed accumulator)
   float kv_u[4][2] = {};          // [layer][K, V]: unquantisation multiplier u (f32 form)
@@ -383,6 +391,13 @@ struct FusedEncodeArgs {
   float *kv = nullptr;         // [Ld][2][B*S*D]: K as [B][H][dh/4][S][4], V as [B*S][D]
   bool kv24 = false;           // write the packed 24-bit form instead (FusedDecodeArgs::kv24)
   bool kv_store_nt = false;    // 64-row encoder, packed form: non-temporal cache stores (the decoder of this batch will stream it)
+  // packed form, S <= 32, D = 256: [Ld][B] bytes; the encoder writes a sentence-layer's cache in the narrow 20-bit form
+  // when every K and V accumulator of its workgroup's rows fits (FusedDecodeArgs::kv_fmt) and records 0, else the
+  // 24-bit form and 1. nullptr: always the 24-bit form. kv_narrow_limit: accumulators must lie in
+  // [-limit, limit) for the narrow form -- 2^19, what 20 bits hold; tests lower it to force the 24-bit form on
+  // some sentences of a batch (never above 2^19)
+  unsigned char *kv_fmt = nullptr;
+  int kv_narrow_limit = 1 << 19;
   PackArgs pack;               // the batch's shortlisted output layer, packed by the
   int pack_tiles = 0;          // encoder's workgroups on the side (0 = nothing to pack)
   // ShortlistGenerator::generate inside this launch (the S <= 64 encoders; gen.w2o != nullptr): the workgroup

@@ -108,9 +108,10 @@ Histories Model::forward(const Input &input) const {
                                            input.limit_factor(), config_.eos_id, out_ids.data(), out_len.data(),
                                            align.data());
   const std::string why = rc ? slimt_hip_last_error() : "";
-  if (rc && why.find("hip") != std::string::npos) {
-    // a HIP error (the library reports them as "file:line hipCall -> message") can come after part of the call
-    // has been queued: that context is not returned to the pool; an argument check fails before any launch
+  if (rc) {
+    // whatever failed (rc > 0: a hipError_t from the runtime, rc < 0: one of the library's own checks), part of the
+    // call may already be queued on this context's stream while the host vectors above are about to be freed:
+    // the context is destroyed (which drains its stream), never pooled
     slimt_hip_ctx_destroy(lease.ctx);
     lease.ctx = nullptr;
   } else {

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <utility>
 
 namespace slimt {
 
@@ -164,6 +165,26 @@ Service::Service(const ServiceConfig &config, std::vector<const Model *> replica
                    "slimt::Service: %zu workers per device but GPU_MAX_HW_QUEUES is %d: batches will queue behind each "
                    "other; call slimt_hip_request_hw_queues(32) (or set the variable) before the first HIP call\n",
                    config.workers_per_device, slimt_hip_hw_queues());
+  }
+  // ... and two contexts per worker are streams too: past 22 contexts on one device in one process the hardware
+  // queues are time-sliced whatever that variable says (24: -30 %); the library says so as well when the
+  // 23rd context is built, this says it before any is, with the setting that causes it
+  if (config.warn_hw_queues) {
+    std::vector<std::pair<int, size_t>> per_device;
+    for (const Model *m : replicas) {
+      auto it = std::find_if(per_device.begin(), per_device.end(), [&](auto &p) { return p.first == m->config().device; });
+      if (it == per_device.end()) per_device.emplace_back(m->config().device, 1); else it->second += 1;
+    }
+    for (auto &[device, n] : per_device) {
+      const size_t contexts = 2 * n * config.workers_per_device;
+      static std::atomic<bool> warned{false};
+      if (contexts > kContextsPerDeviceCliff && !warned.exchange(true))
+        std::fprintf(stderr,
+                     "slimt::Service: %zu replicas x %zu workers x 2 contexts = %zu streams on device %d: past %zu the "
+                     "device's hardware queues are time-sliced (24 measured 30 %% below 20); use at most %zu workers per "
+                     "device and process\n",
+                     n, config.workers_per_device, contexts, device, kContextsPerDeviceCliff, kContextsPerDeviceCliff / 2);
+    }
   }
   live_workers_ = replicas.size() * config.workers_per_device;
   for (size_t r = 0; r < replicas.size(); ++r)

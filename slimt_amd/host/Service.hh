@@ -87,13 +87,18 @@ class LengthQueue {
   size_t waiting_ = 0;
 };
 
+// Contexts (streams) one process can hold on one device before its hardware queues are time-sliced.
+constexpr size_t kContextsPerDeviceCliff = 22;
+
 struct ServiceConfig {
   size_t max_words = 8192;   // word budget of a batch: (B + 1) * S <= max_words
   size_t wrap_length = 128;  // longest sentence (slimt wraps there, Frontend.hh:27)
   float tgt_length_limit_factor = 1.5F;
   size_t workers_per_device = 10;  // x 2 contexts each: about 20 batches in flight per GPU
   uint32_t pad_id = 0;
-  bool warn_hw_queues = true;  // one line on stderr when started with > 2 workers per device and < 8 hardware queues
+  // one line on stderr when started with > 2 workers per device and < 8 hardware queues, or with more than
+  // kContextsPerDeviceCliff contexts (2 per worker) on one device
+  bool warn_hw_queues = true;
   bool alignments = true;
   bool flat_alignments = false;  // Hypothesis::alignment_flat instead of ::alignment (one block per sentence)
   // Output vocabulary of a batch, one policy for the service's lifetime:

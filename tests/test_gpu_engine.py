@@ -421,7 +421,7 @@ def test_packed_kv_cache_matches_oracle_and_f32_cache(hip, oracle, engines, pres
     oracle.set_mode(oracle.FAITHFUL)
     ctx = hip.Context(gm, B, S)
     try:
-        for fmt in (0, 1):
+        for fmt in (0, 2, 1):  # packed (20 bits where a sentence's accumulators fit) / packed 24-bit only / f32
             gm.set_kv_cache_format(fmt)
             for policy in (2, 1):
                 gm.set_kv_cache_policy(policy)
@@ -464,7 +464,7 @@ def test_tall_encoder_every_layer_and_translate_bit_exact(hip, oracle, engines, 
         for l in range(1, m.enc_layers + 1):
             assert np.array_equal(layers[l - 1], want[l]), (l, np.abs(layers[l - 1] - want[l]).max())
         assert np.array_equal(enc, want[-1])
-        for fmt in (0, 1):
+        for fmt in (0, 2, 1):
             gm.set_kv_cache_format(fmt)
             got = ctx.translate(ids, lens, sl, want_align=True)
             assert all(np.array_equal(a, b) for a, b in zip(got, want_t)), fmt
@@ -526,7 +526,7 @@ def test_decoder_depths_other_than_two(hip, oracle, Ld):
             oracle.set_mode(oracle.FAITHFUL)
             ctx = hip.Context(gm, B, S)
             try:
-                for fmt in (0, 1):
+                for fmt in (0, 2, 1):
                     gm.set_kv_cache_format(fmt)
                     got = ctx.translate(ids, lens, sl, want_align=True)
                     assert all(np.array_equal(a, b) for a, b in zip(got, want)), (B, S, fmt)

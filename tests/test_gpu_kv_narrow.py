@@ -1,0 +1,184 @@
+"""The narrow (20-bit) form of the packed cross-attention K/V cache and its 24-bit fallback
+(include/slimt_hip.h, slimt_hip_model_set_kv_cache_format; kernels.h, FusedDecodeArgs::kv_fmt).
+
+What the cache holds is the K / V projections' shifted accumulators accS of the encoder output
+(/root/reference/slimt/Modules.cc:248-249 recomputes them every step; qmm/Intgemm.inl.cc:146-153 is
+where an accumulator becomes a float). The encoder stores a workgroup's sentences of a layer in 20
+bits per value when EVERY accumulator of their K and V lies in [-2^19, 2^19), else in 24 bits. Either
+form gives back the same integers, so every result must stay what the checker (oracle/, PORTABLE order)
+computes -- and WHICH form each sentence got is itself predictable from the checker's own accumulators,
+which pins the boundary: a sentence with one accumulator at or past the limit must take the 24-bit
+form next to narrow ones in the same decoder workgroup."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def kv_accumulators(oracle, m, om, ids, lens):
+    """accS of every decoder layer's K and V projection for every row of the batch: [Ld][2][B][S][D] (int32), from the
+    checker's encoder output (bit-identical to the device's, tests/test_gpu_engine.py)."""
+    B, S = ids.shape
+    oracle.set_mode(oracle.PORTABLE)
+    enc = om.encode(om.embed(ids), oracle.make_mask(lens, S))
+    oracle.set_mode(oracle.FAITHFUL)
+    rows = np.ascontiguousarray(enc.reshape(B * S, m.D), dtype=np.float32)
+    acc = np.zeros((m.dec_layers, 2, B, S, m.D), dtype=np.int32)
+    for l in range(m.dec_layers):
+        for t, name in enumerate("kv"):
+            W = m.params[f"decoder_l{l + 1}_context_W{name}"]
+            aq = float(np.asarray(m.params[f"decoder_l{l + 1}_context_W{name}_QuantMultA"].data).ravel()[0])
+            acc[l, t] = oracle.affine_acc(rows, np.ascontiguousarray(W.data).reshape(m.D, m.D), aq).reshape(B, S, m.D)
+    return acc
+
+
+def expected_forms(acc, limit, group):
+    """1 = 24-bit: some accumulator of the workgroup's sentences (`group` consecutive ones; every row, padding included)
+    outside [-limit, limit)."""
+    Ld, _, B = acc.shape[:3]
+    outside = ((acc < -limit) | (acc >= limit)).any(axis=(1, 3, 4))  # [Ld][B]
+    want = np.zeros((Ld, B), dtype=np.uint8)
+    for s0 in range(0, B, group):
+        want[:, s0:s0 + group] = outside[:, s0:s0 + group].any(axis=1, keepdims=True)
+    return want
+
+
+@pytest.mark.parametrize("B,S,rows", [(37, 32, 64), (37, 32, 32), (41, 16, 64), (23, 21, 32), (50, 7, 64), (19, 29, 64),
+                                       (9, 8, 32), (30, 13, 64)])
+def test_forms_follow_the_accumulators_and_results_do_not(hip, oracle, synth_models, B, S, rows):
+    from slimt_amd import synth
+    m = synth_models("tiny11", 6.0)
+    gm, om = hip.Model(m), oracle.OracleModel(m)
+    ctx = hip.Context(gm, B, S)
+    try:
+        ids, lens = synth.make_batch(m.V, B, S, seed=4400 + 64 * B + S, ragged=True)
+        sl = synth.make_shortlist(m.V, 640)
+        oracle.set_mode(oracle.PORTABLE)
+        want = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+        oracle.set_mode(oracle.FAITHFUL)
+        acc = kv_accumulators(oracle, m, om, ids, lens)
+        peak = np.abs(acc.astype(np.int64)).max(axis=(1, 3, 4))  # [Ld][B]
+        assert peak.max() < 2 ** 19  # the synthetic model: every sentence fits the narrow form
+        ctx.set_encode_rows(rows)
+        group = rows // S
+        # limits: the real one, and three that split this batch's sentences (the median peak, its neighbours)
+        order = np.sort(peak.ravel())
+        limits = [2 ** 19, int(order[len(order) // 2]), int(order[len(order) // 4]) + 1, int(order[-1]), int(order[-1]) + 1, 1]
+        for limit in limits:
+            gm.debug_kv_narrow_limit(limit)
+            forms = expected_forms(acc, limit, group)
+            for mode in (2, 3, 4, 5):  # 16 / 32 / 8 / 4 sentences per decoder workgroup
+                ctx.set_decode_mode(mode)
+                got = ctx.translate(ids, lens, sl, want_align=True)
+                assert all(np.array_equal(a, b) for a, b in zip(got, want)), (limit, mode)
+                seen = ctx.debug_kv_formats(m.dec_layers, B)
+                assert seen is not None and np.array_equal(seen, forms), (limit, mode, seen, forms)
+        assert expected_forms(acc, limits[1], group).any() and not expected_forms(acc, 2 ** 19, group).any()
+        # the other cache formats record nothing and give the same results
+        for fmt in (2, 1):
+            gm.set_kv_cache_format(fmt)
+            got = ctx.translate(ids, lens, sl, want_align=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), fmt
+            assert ctx.debug_kv_formats(m.dec_layers, B) is None
+    finally:
+        ctx.close()
+        gm.close()
+
+
+@pytest.mark.parametrize("rows", [64, 32])
+def test_an_accumulator_past_2_19_sends_its_sentences_to_the_24_bit_form(hip, oracle, rows):
+    """A model whose first K column of decoder layer 1 and first V column of layer 2 sum weights of one sign: 127 colsum
+    alone is close to 2^19 there, and the data-dependent part decides sentence by sentence. The checker's accumulators say
+    which sentences cross the limit; the device must agree, keep the others narrow, and translate all of them exactly."""
+    from slimt_amd import synth
+    B, S = 41, 32
+    m = synth.make_model("tiny11", seed=1234, eos_bias=6.0)
+    ids, lens = synth.make_batch(m.V, B, S, seed=777, ragged=True)
+    om0 = oracle.OracleModel(m)
+    base = kv_accumulators(oracle, m, om0, ids, lens)
+    del om0
+    # column 0 <- `k1` weights of +127 in front (the rest as drawn): accS[.., 0] ~ 127 * 127 * k1 + data; pick k1 so that
+    # some but not all groups of sentences cross 2^19 (the encoder output does not depend on these weights)
+    group = rows // S
+    picked = {}
+    oracle.set_mode(oracle.PORTABLE)
+    om_enc = oracle.OracleModel(m)
+    enc = np.ascontiguousarray(om_enc.encode(om_enc.embed(ids), oracle.make_mask(lens, S)).reshape(B * S, m.D), dtype=np.float32)
+    del om_enc
+    oracle.set_mode(oracle.FAITHFUL)
+    for l, t, name in ((0, 0, "k"), (1, 1, "v")):
+        W = m.params[f"decoder_l{l + 1}_context_W{name}"]
+        data = np.ascontiguousarray(W.data).reshape(m.D, m.D).copy()  # payload [N][K]
+        aq = float(np.asarray(m.params[f"decoder_l{l + 1}_context_W{name}_QuantMultA"].data).ravel()[0])
+        best = None
+        for k1 in range(16, 64):
+            col = data[0].copy()
+            col[:k1] = 127
+            a0 = oracle.affine_acc(enc, col[None, :].copy(), aq).reshape(B, S).astype(np.int64)
+            over = ((a0 < -2 ** 19) | (a0 >= 2 ** 19)).any(axis=1)
+            frac = np.mean([over[s:s + group].any() for s in range(0, B, group)])
+            if 0.15 <= frac <= 0.85 and (best is None or abs(frac - 0.5) < abs(best[1] - 0.5)):
+                best = (k1, frac, col)
+        assert best is not None, "no prefix length splits this batch"
+        picked[(l, t)] = best[:2]
+        data[0] = best[2]
+        W.data = data.astype(np.int8)
+    gm, om = hip.Model(m), oracle.OracleModel(m)
+    ctx = hip.Context(gm, B, S)
+    try:
+        acc = kv_accumulators(oracle, m, om, ids, lens)
+        assert np.array_equal(acc[:, :, :, :, 1:], base[:, :, :, :, 1:])  # only column 0 moved
+        forms = expected_forms(acc, 2 ** 19, group)
+        assert forms.any() and not forms.all(), picked
+        assert np.abs(acc.astype(np.int64)).max() < 2 ** 23
+        sl = synth.make_shortlist(m.V, 640)
+        oracle.set_mode(oracle.PORTABLE)
+        want = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+        oracle.set_mode(oracle.FAITHFUL)
+        ctx.set_encode_rows(rows)
+        for mode in (2, 3, 4, 5):
+            ctx.set_decode_mode(mode)
+            for policy in (1, 2):
+                gm.set_kv_cache_policy(policy)
+                got = ctx.translate(ids, lens, sl, want_align=True)
+                assert all(np.array_equal(a, b) for a, b in zip(got, want)), (mode, policy)
+                assert np.array_equal(ctx.debug_kv_formats(m.dec_layers, B), forms), (mode, policy)
+    finally:
+        ctx.close()
+        gm.close()
+
+
+def test_narrow_limit_is_bounded(hip, synth_models):
+    m = synth_models("tiny11", 6.0)
+    gm = hip.Model(m)
+    try:
+        for bad in (0, -1, 2 ** 19 + 1, 2 ** 23):
+            with pytest.raises(hip.SlimtHipError):
+                gm.debug_kv_narrow_limit(bad)
+        gm.debug_kv_narrow_limit(2 ** 19)
+    finally:
+        gm.close()
+
+
+@pytest.mark.parametrize("B,S", [(20, 9), (33, 4), (18, 12), (25, 3)])
+def test_lengths_whose_narrow_v_block_would_not_fit_keep_the_24_bit_form(hip, oracle, synth_models, B, S):
+    """V is cached in groups of eight keys in the narrow form and of four in the 24-bit one: for S = 1..4 and 9..12 a
+    sentence's narrow block would be larger than its slot, so those lengths keep the 24-bit form (nothing is recorded)."""
+    from slimt_amd import synth
+    m = synth_models("tiny11", 6.0)
+    gm, om = hip.Model(m), oracle.OracleModel(m)
+    ctx = hip.Context(gm, B, S)
+    try:
+        ids, lens = synth.make_batch(m.V, B, S, seed=5100 + S, ragged=True)
+        sl = synth.make_shortlist(m.V, 640)
+        oracle.set_mode(oracle.PORTABLE)
+        want = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+        oracle.set_mode(oracle.FAITHFUL)
+        for rows in (64, 32):
+            ctx.set_encode_rows(rows)
+            got = ctx.translate(ids, lens, sl, want_align=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), rows
+            assert ctx.debug_kv_formats(m.dec_layers, B) is None
+    finally:
+        ctx.close()
+        gm.close()

@@ -145,9 +145,85 @@ def test_engine_hooks_compile_against_the_reference_headers(patched):
 
 def test_call_sites_use_what_engine_hh_declares(patched):
     header = (patched / "slimt" / "hip" / "Engine.hh").read_text()
-    declared = set(re.findall(r"^\w[\w:<>\* ]*?\b(\w+)\(", header, flags=re.M)) | set(re.findall(r"using (\w+) =", header))
+    declared = (set(re.findall(r"^\w[\w:<>\*& ]*?\b(\w+)\(", header, flags=re.M)) | set(re.findall(r"using (\w+) =", header))
+                | set(re.findall(r"^class (\w+) \{", header, flags=re.M)))
     used = set()
     for name in ("Transformer.hh", "Transformer.cc", "Model.hh", "Model.cc", "Shortlist.hh", "Shortlist.cc"):
         used |= set(re.findall(r"\bhip::(\w+)", (patched / "slimt" / name).read_text()))
     assert used == {"create_model", "create_shortlist", "generate", "forward", "ModelHandle", "ShortlistHandle"}
     assert used <= declared, (used, declared)
+
+
+def test_contexts_die_with_their_model_not_with_the_thread(patched, tmp_path):
+    """ADVICE r04: the contexts Model::forward runs on point into the model, so the handle that owns the model
+    owns them too. A recording double of the C ABI (test code: counts and orders the calls, computes nothing)
+    is linked with the real Engine.cc: a worker thread that outlives the model must destroy nothing afterwards,
+    every context must go before its model, and concurrent callers end with one context each."""
+    double = tmp_path / "abi_double.cc"
+    double.write_text(r"""
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "slimt/hip/Engine.hh"
+struct slimt_hip_model { std::atomic<int> live_ctx{0}; bool alive = true; };
+struct slimt_hip_ctx { slimt_hip_model* model; };
+static std::atomic<int> g_ctx_built{0}, g_ctx_destroyed{0}, g_bad{0};
+extern "C" {
+const char* slimt_hip_last_error(void) { return ""; }
+int slimt_hip_model_create_from_bin(const void*, size_t, const slimt_hip_dims*, int, slimt_hip_model** out) { *out = new slimt_hip_model; return 0; }
+int slimt_hip_model_destroy(slimt_hip_model* m) { if (!m) return 0; if (m->live_ctx.load() != 0) g_bad++; m->alive = false; return 0; }
+int slimt_hip_ctx_create_budget(slimt_hip_model* m, size_t, size_t, size_t, void*, slimt_hip_ctx** out) {
+  if (!m->alive) g_bad++; m->live_ctx++; g_ctx_built++; *out = new slimt_hip_ctx{m}; return 0; }
+int slimt_hip_ctx_destroy(slimt_hip_ctx* c) { if (!c) return 0; if (!c->model->alive) g_bad++; c->model->live_ctx--; g_ctx_destroyed++; delete c; return 0; }
+int slimt_hip_translate(slimt_hip_ctx* c, const uint32_t*, const uint32_t*, size_t B, size_t, const uint32_t*, size_t, float, uint32_t,
+                        uint32_t*, uint32_t* out_len, float*) { if (!c->model->alive) g_bad++; for (size_t b = 0; b < B; ++b) out_len[b] = 0; return 0; }
+int slimt_hip_translate_generated(slimt_hip_ctx*, slimt_hip_shortlist*, const uint32_t*, const uint32_t*, size_t, size_t, float, uint32_t,
+                                  uint32_t*, uint32_t*, float*) { return -1; }
+int slimt_hip_shortlist_create(const void*, size_t, size_t, size_t, int, int, int, slimt_hip_shortlist**) { return -1; }
+int slimt_hip_shortlist_destroy(slimt_hip_shortlist*) { return 0; }
+int slimt_hip_shortlist_generate(slimt_hip_shortlist*, const uint32_t*, const uint32_t*, size_t, size_t, uint32_t*, size_t*) { return -1; }
+}
+int main() {
+  using namespace slimt;
+  std::atomic<bool> go_on{true};
+  std::atomic<int> ready{0};
+  {
+    hip::ModelHandle model = hip::create_model(View{nullptr, 0}, 6, 2, 8);
+    std::vector<std::thread> workers;
+    for (int w = 0; w < 4; ++w)
+      workers.emplace_back([&] {
+        auto lease = model.acquire(8, 16);  // four concurrent callers
+        ready++;
+        while (ready.load() < 4) std::this_thread::yield();
+        model.release(lease);
+        auto again = model.acquire(16, 16);  // a larger batch: the pooled context is rebuilt, not leaked
+        model.release(again);
+      });
+    for (auto& t : workers) t.join();
+    // a thread that is still alive when the model goes
+    std::thread late([&] { while (go_on.load()) std::this_thread::yield(); });
+    hip::ModelHandle moved = std::move(model);
+    if (model || !moved) g_bad++;
+    {
+      hip::ModelHandle gone = std::move(moved);
+    }  // model destroyed here, with every pooled context before it
+    if (g_ctx_built.load() != g_ctx_destroyed.load()) g_bad++;
+    go_on = false;
+    late.join();
+  }
+  std::printf("built %d destroyed %d bad %d\n", g_ctx_built.load(), g_ctx_destroyed.load(), g_bad.load());
+  return g_bad.load() == 0 && g_ctx_built.load() >= 4 ? 0 : 1;
+}
+""")
+    # Engine.cc's forward() also references Input / Tensor (slimt/Tensor.cc pulls in TensorOps.cc: cblas or ruy, absent):
+    # nothing of that is called here, so those references stay unresolved at link time
+    r = subprocess.run(["g++", "-std=c++20", "-O1", "-DSLIMT_HAS_HIP", "-pthread", "-I", str(patched), "-I",
+                        os.path.join(ROOT, "include"), str(patched / "slimt" / "hip" / "Engine.cc"), str(double),
+                        "-Wl,--unresolved-symbols=ignore-all", "-o", str(tmp_path / "lifetime")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-4000:]
+    run = subprocess.run([str(tmp_path / "lifetime")], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0, run.stdout + run.stderr

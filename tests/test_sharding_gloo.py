@@ -82,6 +82,7 @@ def _run_bench(extra, env_extra=None, timeout=300):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
+    _run_bench.stderr = p.stderr
     return lines
 
 
@@ -131,3 +132,49 @@ def test_bench_under_a_launcher_environment():
     assert outs[1][0].strip() == ""  # only rank 0 prints
     d = json.loads(outs[0][0].strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["config"]["sentences_per_step_all_gpus"] == 2 * 2 * 256
+
+
+def test_cpu_sets_are_disjoint_equal_and_cover_ranks():
+    from slimt_amd.sharding import cpu_set_for_rank
+    avail = [3, 0, 1, 2, 8, 9, 10, 11, 16, 17]
+    for world in (1, 2, 3, 4, 5, 8, 10):
+        sets = [cpu_set_for_rank(r, world, avail) for r in range(world)]
+        assert all(len(s) == len(avail) // world for s in sets)
+        flat = [c for s in sets for c in s]
+        assert len(flat) == len(set(flat)) and set(flat) <= set(avail)
+        assert all(s == sorted(s) for s in sets)
+    # more ranks than cores: one core each, shared round-robin
+    assert [cpu_set_for_rank(r, 4, [5, 7]) for r in range(4)] == [[5], [7], [5], [7]]
+    with pytest.raises(ValueError):
+        cpu_set_for_rank(2, 2, avail)
+    with pytest.raises(ValueError):
+        cpu_set_for_rank(0, 1, [])
+
+
+def test_four_dry_ranks_pin_disjoint_cores_and_all_report():
+    """Readiness for the 8-GPU node without one: four ranks (no device work) each pin themselves to a disjoint share of
+    this container's cores before anything else, say on stderr which device / bus / cores they ran on, and the one JSON
+    line carries n_ranks_seen = the SUM of ones over the process group -- so the driver's N-GPU run proves N ranks
+    reported (/root/reference/slimt/Frontend.cc:207-227 is the worker model mapped one thread per GPU here)."""
+    import json
+    lines = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--workers", "2"])
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["n_ranks_seen"] == 4
+    assert d["config"]["sentences_per_step_all_gpus"] == 4 * 2 * 256
+    reports = [json.loads(l[len("bench-rank "):]) for l in _run_bench.stderr.splitlines() if l.startswith("bench-rank ")]
+    assert sorted(r["rank"] for r in reports) == [0, 1, 2, 3]
+    allowed = sorted(os.sched_getaffinity(0))
+    per = len(allowed) // 4
+    seen = []
+    for r in sorted(reports, key=lambda r: r["rank"]):
+        assert r["world"] == 4 and r["local_rank"] == r["rank"]
+        assert len(r["cpus"]) == max(per, 1) and set(r["cpus"]) <= set(allowed)
+        assert r["tokens_per_step"] == 2 * 256 * 48
+        seen += r["cpus"]
+    if per >= 1:
+        assert len(seen) == len(set(seen)), reports  # disjoint
+    # a single process sees itself only, and pins nothing
+    one = json.loads(_run_bench(["--steps", "2", "--workers", "2"])[0])
+    assert one["n_gpus"] == 1 and one["n_ranks_seen"] == 1
+    assert "bench-rank" not in _run_bench.stderr

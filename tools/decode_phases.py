@@ -8,6 +8,8 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 n_sl = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 m = synth.make_model("tiny11", eos_bias=-100.0)
 gm = capi.Model(m); ctx = capi.Context(gm, B, S)
+if os.environ.get("SLIMT_KV_FORMAT"):  # 0 = packed, 20 bits where the accumulators fit (default); 2 = packed 24-bit; 1 = f32
+    gm.set_kv_cache_format(int(os.environ["SLIMT_KV_FORMAT"]))
 ctx.set_decode_mode(int(os.environ.get("SLIMT_DECODE_MODE", "0")))  # 3 = 32 sentences per workgroup
 ids, lens = synth.make_batch(m.V, B, S); sl = synth.make_shortlist(m.V, n_sl)
 ctx.translate(ids, lens, sl)

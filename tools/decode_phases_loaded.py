@@ -15,6 +15,8 @@ n_sl = 4096
 dev = torch.device("cuda", 0)
 m = synth.make_model("tiny11", seed=1234, eos_bias=-100.0)
 gm = capi.Model(m)
+if os.environ.get("SLIMT_KV_FORMAT"):  # 0 = packed, 20 bits where the accumulators fit (default); 2 = packed 24-bit; 1 = f32
+    gm.set_kv_cache_format(int(os.environ["SLIMT_KV_FORMAT"]))
 if os.environ.get("SLIMT_DECODER_BUDGET"):
     gm.set_decoder_budget(int(os.environ["SLIMT_DECODER_BUDGET"]))
 if os.environ.get("SLIMT_XCD_AFFINITY"):
