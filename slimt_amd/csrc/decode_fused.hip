@@ -1549,6 +1549,131 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
       pack4(quantize1_byte(b0, r.aq_o), quantize1_byte(b1, r.aq_o), quantize1_byte(b2, r.aq_o), quantize1_byte(b3, r.aq_o));
 }
 
+// attention_row24_64 out of line (see attention_row24_cold): the fallback of the narrow form at D = 512.
+template <int KV_AUX>
+__device__ __noinline__ void attention_row24_64_cold(AttnRow r, int lane, lcf_ptr kc, float uk256, float uv256) {
+  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
+  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
+  r.S = __builtin_amdgcn_readfirstlane(r.S);
+  r.len = __builtin_amdgcn_readfirstlane(r.len);
+  attention_row24_64<KV_AUX>(r, lane, kc, uk256, uv256);
+}
+
+// The narrow form at D = 512 / d_head 64 (S <= 32). Unlike the 24-bit form of this shape it caches the SHIFTED
+// accumulator accS = acc + 127 colsum -- 20 bits hold it where they hold anything (|accS| < 2^19), and the attention then
+// needs no per-value column term: one v_perm + one conversion per value (+ 3/8 for the nibbles) instead of extract +
+// conversion + half a packed add, from 17 % fewer bytes. Two heads per score pass (lanes 0..31 / 32..63: the 24-bit form
+// of this shape scores one head on both halves). Same floats: float(accS) is what every form multiplies.
+//   K [head][plane 0..9][S][16 B]            planes 0..7: hi halves of the head's columns 8 p .. 8 p + 7 of one key,
+//                                             planes 8, 9: the lo nibbles of columns 0..31 / 32..63 (dword i <-> plane i / 4 + i)
+//   V [ceil(S / 8)][plane 0..4][D/4][16 B]    as at D = 256, 128 column quads per plane (a lane owns quads lane, 64 + lane)
+// kc: LDS constants of this layer, [K pb | K c127 | V pb | V c127][D] (the c127 vectors serve the 24-bit form only)
+template <int KV_AUX>
+__device__ __forceinline__ void attention_row20_64(AttnRow r, int lane, lcf_ptr kc, float uk4096, float uv4096) {
+  constexpr int D = 512, DH = 64, H = D / DH;
+  const int S = r.S, len = r.len;
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int hh = lane >> 5, j = lane & 31;
+  const int jc = j < S ? j : S - 1;
+  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 1280));
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 10240));
+  const int koff = j < lenf ? (hh * 10 * S + jc) * 16 : kPastDescriptor;
+  const lcf_ptr kpb = kc, vpb = kc + 2 * D;
+#pragma unroll 1
+  for (int hp = 0; hp < H / 2; ++hp) {
+    const int h = 2 * hp + hh;
+    v4i kq[10];  // this lane's key, its head's 64 columns
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((20 * hp + i) * S) * 16, KV_AUX));
+    // c_h = row sum of q_d * pbK[d] over the 64 columns of this lane's head (one per lane, the canonical 64-lane
+    // butterfly; both heads of the pass, under the loads' round trip)
+    const float c0 = wave_sum(r.qrow[(2 * hp) * DH + lane] * kpb[(2 * hp) * DH + lane]);
+    const float c1 = wave_sum(r.qrow[(2 * hp + 1) * DH + lane] * kpb[(2 * hp + 1) * DH + lane]);
+    const float ch = hh ? c1 : c0;
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d0 = h * DH + 8 * i;
+      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
+      const v4i &lq = kq[8 + (i >> 2)];
+      const int lo[4] = {lq.x, lq.y, lq.z, lq.w};
+      const Lo20 e = expand20(lo[i & 3]);
+      t = __builtin_fmaf(qa.x, unpack20<0>(kq[i], e), t);
+      t = __builtin_fmaf(qa.y, unpack20<1>(kq[i], e), t);
+      t = __builtin_fmaf(qa.z, unpack20<2>(kq[i], e), t);
+      t = __builtin_fmaf(qa.w, unpack20<3>(kq[i], e), t);
+      t = __builtin_fmaf(qb.x, unpack20<4>(kq[i], e), t);
+      t = __builtin_fmaf(qb.y, unpack20<5>(kq[i], e), t);
+      t = __builtin_fmaf(qb.z, unpack20<6>(kq[i], e), t);
+      t = __builtin_fmaf(qb.w, unpack20<7>(kq[i], e), t);
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);  // at most sixteen q values from LDS in flight
+    }
+    float s = __builtin_fmaf(t, uk4096, ch);
+    if (r.alpha != 1.0f) s = r.alpha * s;
+    s = s + mask;
+    if (j >= S) s = lowest;
+    const float m = half_max(s);
+    const float e = j < S ? exp_p(s - m) : 0.0f;
+    const float sum = half_sum(e);
+    const float p = e / sum;  // keys >= S: exactly 0
+    const float ps = half_sum(p);  // P_h
+    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
+    if (r.align && h == 0 && j < len) r.align[j] = p;
+    r.pbuf[h * 32 + j] = p;
+    if (j == 0) r.hsum[h] = ps;
+  }
+  // V: a lane owns column quads `lane` (head lane / 16) and 64 + lane (head 4 + lane / 16): two independent passes over
+  // the keys, each with two groups of eight rows in flight
+  int packed[2];
+#pragma unroll
+  for (int slot = 0; slot < 2; ++slot) {
+    const int voff = (slot * 64 + lane) * 16;
+    v4i vq[2][5];
+    auto load_v = [&](v4i(&vv)[5], int g) {  // rows 8 g .. 8 g + 7
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (5 * g + i) * 2048, KV_AUX));
+    };
+    load_v(vq[0], 0);
+    load_v(vq[1], 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int head = 4 * slot + (lane >> 4);
+    const int ph = head * 32;
+    const f4 pv4 = *(lcf4_ptr)(vpb + slot * (D / 2) + 4 * lane);
+    const float P = r.hsum[head];
+    f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      v4i(&cur)[5] = vq[g & 1];
+      const int lo[4] = {cur[4].x, cur[4].y, cur[4].z, cur[4].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
+        const Lo20 e = expand20(lo[c]);
+        const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
+        const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
+        const f2 va0 = {unpack20<0>(cur[c], e), unpack20<1>(cur[c], e)}, vb0 = {unpack20<2>(cur[c], e), unpack20<3>(cur[c], e)};
+        const f2 va1 = {unpack20<4>(cur[c], e), unpack20<5>(cur[c], e)}, vb1 = {unpack20<6>(cur[c], e), unpack20<7>(cur[c], e)};
+        oa = __builtin_elementwise_fma(p0, va0, oa);
+        ob = __builtin_elementwise_fma(p0, vb0, ob);
+        oa = __builtin_elementwise_fma(p1, va1, oa);
+        ob = __builtin_elementwise_fma(p1, vb1, ob);
+      }
+      asm volatile("" : "+v"(oa), "+v"(ob));  // (attention_row24: keeps a group's work next to its loads)
+      if (g + 2 < 4) load_v(vq[g & 1], g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float o0 = __builtin_fmaf(oa.x, uv4096, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv4096, pv4.y * P);
+    const float o2 = __builtin_fmaf(ob.x, uv4096, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv4096, pv4.w * P);
+    packed[slot] = pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
+  }
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) = packed[0];
+  *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) = packed[1];
+}
+
 }  // namespace
 
 // Diagnostic phase stamps (100 MHz wall clock) of workgroup 0 at one chosen
@@ -1698,7 +1823,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     kv_wide[rr] = ~0u;
-    if constexpr (KV24 && MID == 0 && KSD == 4) {
+    if constexpr (KV24 && MID == 0) {
       if (a.kv_fmt && live[rr]) {
         unsigned w = 0;
         for (int l = 0; l < Ld; ++l) w |= (unsigned)(a.kv_fmt[(size_t)l * B + bq[rr]] != 0) << l;
@@ -1907,10 +2032,23 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + no) * S) : (gf_ptr) nullptr;
           if constexpr (KV24 && KVC == 4) {
             const lcf_ptr kc = (lcf_ptr)(kvpb + (4 * l) * D);
+#ifdef SLIMT_EXP_NO_KV20
             if (NT && kv_streams)
               attention_row24_64<2>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_64<0>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
+#else
+            const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
+            if (!wide) {
+              if (NT && kv_streams)
+                attention_row20_64<2>(ar, lane, kc, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+              else
+                attention_row20_64<0>(ar, lane, kc, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+            } else if (NT && kv_streams)
+              attention_row24_64_cold<2>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
+            else
+              attention_row24_64_cold<0>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
+#endif
           } else if constexpr (MID == 2) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
             if (NT && kv_streams)

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
   // this workgroup's sentence lengths: read once (they may live in pinned host memory)
   __shared__ int slens[WR];
+  __shared__ int kv_wide_flag;  // the narrow cache form does not hold this workgroup's accumulators (the K/V phase at the end)
   if (tid < spw) slens[tid] = s0 + tid < B ? checked_length(a.lengths[s0 + tid], S) : 0;
 
   char *Abuf = smem;                 // x quantised for Q | round 1's attention output | FFN1 / decoder K/V input
@@ -602,59 +603,129 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       }
     }
   }
+  // The packed cache takes one of two forms per workgroup and layer (kernels.h, FusedDecodeArgs::kv_fmt; encode_tall.hip
+  // has the same scheme): the narrow one -- 20 bits per value, the SHIFTED accumulator accS = acc + 127 colsum -- when every
+  // accS of this workgroup's rows lies in [-limit, limit), else 24 bits holding the signed accumulator (accS needs 25 bits
+  // at K = 512). Narrow first; an accumulator that does not fit raises kv_wide_flag and the layer is done again.
+  const bool try_narrow = a.kv24 && a.kv_fmt != nullptr;
   for (int l = 0; l < a.Ld; ++l) {
-    for (int p = 0; p < 2; ++p) {
-      SLIMT_WPHASE_LANE;
-      const PreparedWeight &w = p == 0 ? a.dec_k[l] : a.dec_v[l];
-      float *out = a.kv + (size_t)(2 * l + p) * B * S * D;
-      load_w(bw[1], w, wave + WNW, lane);
-      lds_barrier();
-      quantise_x(Abuf, w.a_quant, lane);
-      lds_barrier();
+    bool wide = !try_narrow;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      bool redo = false;
+      for (int p = 0; p < 2; ++p) {
+        SLIMT_WPHASE_LANE;
+        const PreparedWeight &w = p == 0 ? a.dec_k[l] : a.dec_v[l];
+        float *out = a.kv + (size_t)(2 * l + p) * B * S * D;
+        load_w(bw[1], w, wave + WNW, lane);
+        lds_barrier();
+        quantise_x(Abuf, w.a_quant, lane);
+        if (!wide && p == 0 && tid == 0) kv_wide_flag = 0;  // (raised behind the barrier below only; encode_tall.hip)
+        lds_barrier();
+        unsigned outside = 0;  // narrow attempt: an accS of a valid row outside [-limit, limit)
+        const unsigned lim = (unsigned)a.kv_narrow_limit;
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const int ct = wave + WNW * t2;
-        const Epi4 e = load_epi4(w, ct, lg);
-        v4i c0, c1;
-        mma(Abuf, bw[t2], lane, c0, c1);
-        if (t2 == 0) {  // the next projection's first tile
-          __builtin_amdgcn_sched_barrier(0);
-          if (p == 0)
-            load_w(bw[0], a.dec_v[l], wave, lane);
-          else if (l + 1 < a.Ld)
-            load_w(bw[0], a.dec_k[l + 1], wave, lane);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        const int col = ct * 16 + lg * 4;
-        if (a.kv24) {  // the packed cache: SIGNED accumulators (K = 512: acc + 127 colsum needs 25 bits), staged
-          int *stg = reinterpret_cast<int *>(region);  // [WR][LDY] int32
-          *reinterpret_cast<v4i *>(stg + lr * LDY + col) = c0;
-          *reinterpret_cast<v4i *>(stg + (16 + lr) * LDY + col) = c1;
-          continue;
-        }
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const int ct = wave + WNW * t2;
+          const Epi4 e = load_epi4(w, ct, lg);
+          v4i c0, c1;
+          mma(Abuf, bw[t2], lane, c0, c1);
+          if (t2 == 0) {  // the next projection's first tile
+            __builtin_amdgcn_sched_barrier(0);
+            if (p == 0)
+              load_w(bw[0], a.dec_v[l], wave, lane);
+            else if (l + 1 < a.Ld)
+              load_w(bw[0], a.dec_k[l + 1], wave, lane);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const int col = ct * 16 + lg * 4;
+          if (a.kv24) {  // staged: the signed accumulators (24-bit form), or accS (narrow form)
+            int *stg = reinterpret_cast<int *>(region);  // [WR][LDY] int32
+            if (!wide) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const int rrow = rt * 16 + lr;
-          if (!row_valid(rrow)) continue;
-          // the f32 form holds float(accS) = float(acc + 127 colsum), exact (kernels.h, kv24)
-          const v4i &cc = rt ? c1 : c0;
-          const float4 v = {(float)(cc[0] + __mul24(127, e.cs[0])), (float)(cc[1] + __mul24(127, e.cs[1])),
-                            (float)(cc[2] + __mul24(127, e.cs[2])), (float)(cc[3] + __mul24(127, e.cs[3]))};
-          if (p == 0) {  // K cache layout [sentence][head][d/4][key][4]: the lane's 4 columns are one d/4 group
-            const int hh = col / DH, d = col % DH;
-            const size_t chunk = ((size_t)row_sentence(rrow) * H + hh) * (DH / 4) + (d >> 2);
-            *reinterpret_cast<float4 *>(out + (chunk * S + rrow % S) * 4) = v;
-          } else {
-            *reinterpret_cast<float4 *>(out + ((size_t)row_sentence(rrow) * S + rrow % S) * D + col) = v;
+              for (int i = 0; i < 4; ++i) {
+                c0[i] += __mul24(127, e.cs[i]);
+                c1[i] += __mul24(127, e.cs[i]);
+                if (row_valid(lr)) outside |= (unsigned)((unsigned)c0[i] + lim >= 2u * lim);
+                if (row_valid(16 + lr)) outside |= (unsigned)((unsigned)c1[i] + lim >= 2u * lim);
+              }
+            }
+            *reinterpret_cast<v4i *>(stg + lr * LDY + col) = c0;
+            *reinterpret_cast<v4i *>(stg + (16 + lr) * LDY + col) = c1;
+            continue;
+          }
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            const int rrow = rt * 16 + lr;
+            if (!row_valid(rrow)) continue;
+            // the f32 form holds float(accS) = float(acc + 127 colsum), exact (kernels.h, kv24)
+            const v4i &cc = rt ? c1 : c0;
+            const float4 v = {(float)(cc[0] + __mul24(127, e.cs[0])), (float)(cc[1] + __mul24(127, e.cs[1])),
+                              (float)(cc[2] + __mul24(127, e.cs[2])), (float)(cc[3] + __mul24(127, e.cs[3]))};
+            if (p == 0) {  // K cache layout [sentence][head][d/4][key][4]: the lane's 4 columns are one d/4 group
+              const int hh = col / DH, d = col % DH;
+              const size_t chunk = ((size_t)row_sentence(rrow) * H + hh) * (DH / 4) + (d >> 2);
+              *reinterpret_cast<float4 *>(out + (chunk * S + rrow % S) * 4) = v;
+            } else {
+              *reinterpret_cast<float4 *>(out + ((size_t)row_sentence(rrow) * S + rrow % S) * D + col) = v;
+            }
           }
         }
-      }
-      if (a.kv24) {
-        // kernels.h, FusedDecodeArgs::kv24 -- here with the signed accumulator (the decoder adds the
-        // column's 127 colsum term): one thread = 16 values = 48 bytes = three 16-byte stores
+        if (!a.kv24) continue;
+        if (outside) kv_wide_flag = 1;
         lds_barrier();
+        if (!wide && kv_wide_flag) {  // uniform: read by every thread behind the barrier
+          redo = true;
+          break;
+        }
         const int *stg = reinterpret_cast<const int *>(region);
         const int Sp = (S + 3) & ~3;
+        if (!wide) {
+          // the narrow form (decode_fused.hip, attention_row20_64): one thread = 32 values = four quads of hi halves +
+          // one quad of lo nibbles
+          if (p == 0) {  // K [sentence][head][plane 0..9][key][16 B]
+            const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * S * D * 3));
+            for (int it = tid; it < WR * (D / 32); it += 1024) {
+              const int r = it % WR, hf = it / WR;  // hf: half a head (32 columns)
+              if (!row_valid(r)) continue;
+              const int h = hf >> 1, half = hf & 1;
+              const int off = row_sentence(r) * S * D * 3 + (h * 10 * S + r % S) * 16;
+              int lo[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const Packed20 pk = pack20(*reinterpret_cast<const v4i *>(stg + r * LDY + 32 * hf + 8 * q),
+                                           *reinterpret_cast<const v4i *>(stg + r * LDY + 32 * hf + 8 * q + 4));
+                lo[q] = pk.lo;
+                __builtin_amdgcn_raw_buffer_store_b128(pk.hi, ro, off + (4 * half + q) * S * 16, 0, 0);
+              }
+              const v4i lq = {lo[0], lo[1], lo[2], lo[3]};
+              __builtin_amdgcn_raw_buffer_store_b128(lq, ro, off + (8 + half) * S * 16, 0, 0);
+            }
+          } else {  // V [sentence][key / 8][plane 0..4][column / 4][16 B]
+            const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * Sp * D * 3));
+            const int G = (S + 7) >> 3;
+            for (int it = tid; it < spw * G * (D / 4); it += 1024) {
+              const int cl = it % (D / 4), g = (it / (D / 4)) % G, si = (it / (D / 4)) / G;
+              if (s0 + si >= B) continue;
+              const int off = (s0 + si) * Sp * D * 3 + (g * 5 * (D / 4) + cl) * 16;
+              int lo[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {  // keys past the sentence: zeros (finite once unpacked, weight 0)
+                const int k0 = 8 * g + 2 * q, k1 = k0 + 1;
+                const v4i z = {0, 0, 0, 0};
+                const v4i x0 = *reinterpret_cast<const v4i *>(stg + (si * S + (k0 < S ? k0 : 0)) * LDY + 4 * cl);
+                const v4i x1 = *reinterpret_cast<const v4i *>(stg + (si * S + (k1 < S ? k1 : 0)) * LDY + 4 * cl);
+                const Packed20 pk = pack20(k0 < S ? x0 : z, k1 < S ? x1 : z);
+                lo[q] = pk.lo;
+                __builtin_amdgcn_raw_buffer_store_b128(pk.hi, ro, off + q * (D / 4) * 16, 0, 0);
+              }
+              const v4i lq = {lo[0], lo[1], lo[2], lo[3]};
+              __builtin_amdgcn_raw_buffer_store_b128(lq, ro, off + 4 * (D / 4) * 16, 0, 0);
+            }
+          }
+          continue;
+        }
+        // kernels.h, FusedDecodeArgs::kv24 -- here with the signed accumulator (the decoder adds the
+        // column's 127 colsum term): one thread = 16 values = 48 bytes = three 16-byte stores
         if (p == 0) {  // K [sentence][column / 16][plane][key][16 B]
           const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * S * D * 3));
           for (int it = tid; it < WR * (D / 16); it += 1024) {
@@ -692,7 +763,14 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           }
         }
       }
+      if (!redo) break;
+      wide = true;
+      {  // bw[0] holds the tile of whatever came next: back to this layer's K
+        SLIMT_WPHASE_LANE;
+        load_w(bw[0], a.dec_k[l], wave, lane);
+      }
     }
+    if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
   }
   if (gen_here) {
     shortlist_await_in_launch(a.gen_flag, a.gen_epoch, tid);

@@ -1181,9 +1181,9 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     f.kv24 = kv24;
     f.kv_store_nt = kv_store_nt;
     if (kv24 && (size_t)M * D * 3 >= (1u << 31)) return fail(-1, "packed K/V cache: %d rows exceed a 2 GB plane", M);
-    // the narrow (20-bit) form where the writer and the reader have it -- D = 256, S <= 32 -- and where a
+    // the narrow (20-bit) form where the writer and the reader have it -- D = 256 or 512, S <= 32 -- and where a
     // sentence's V block (groups of eight keys) fits the slot of its 24-bit form (groups of four): not S = 1..4, 9..12
-    c->kv_fmt_valid = kv24 && m->kv_format == 0 && D == 256 && S <= 32 &&
+    c->kv_fmt_valid = kv24 && m->kv_format == 0 && (D == 256 || D == 512) && S <= 32 &&
                       ((S + 7) / 8) * 5120 <= ((S + 3) / 4) * 3072;
 #ifdef SLIMT_EXP_NO_KV20  // A/B builds (decode_fused.hip)
     c->kv_fmt_valid = false;
@@ -1743,12 +1743,14 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       // and streaming both layers of the others holds the same bytes but lets the kept decoders run their whole step
       // at the cached speed (and finish together, so no CU idles inside a launch): 32.35 -> 33.05-33.26 M tok/s at
       // k = 6, 32.5-32.9 at k = 5, 32.3-32.6 at k = 7, 31.7 all temporal (profiles/r04_v3_kv_by_launch.txt).
-      // k = as many eighths of the pending decoders as SLIMT_KV_LAUNCH_BUDGET_MB (default 270) covers;
+      // k = as many eighths of the pending decoders as SLIMT_KV_LAUNCH_BUDGET_MB covers (round 4: 270, the 24-bit form;
+      // round 5: 300 -- with the narrow form the headline's decoders hold 232 MB, k = 6 / 7 / 8 measure the same
+      // (35.8 / 35.7 / 35.6 M tok/s, profiles/r05_kv_keep_sweep.txt), and every launch then runs the kept instantiation);
       // SLIMT_KV_BY_LAUNCH: 0 = the per-layer rule, 1..8 = that k.
       static const bool store_nt_rule = std::getenv("SLIMT_KV_STORE_NT") && std::getenv("SLIMT_KV_STORE_NT")[0] == '1';
       static const int by_launch = std::getenv("SLIMT_KV_BY_LAUNCH") ? std::atoi(std::getenv("SLIMT_KV_BY_LAUNCH")) : -1;
       static const double launch_budget =
-          (std::getenv("SLIMT_KV_LAUNCH_BUDGET_MB") ? std::atof(std::getenv("SLIMT_KV_LAUNCH_BUDGET_MB")) : 270.0) * 1e6;
+          (std::getenv("SLIMT_KV_LAUNCH_BUDGET_MB") ? std::atof(std::getenv("SLIMT_KV_LAUNCH_BUDGET_MB")) : 300.0) * 1e6;
       // (sentences of up to 32 tokens; longer ones measured 2-3 % slower this way and keep the per-layer rule:
       // S = 64 18.5 -> 17.9 M, S = 128 8.2 -> 8.0 M)
       // ... and launches of which at least four fit the budget: ONE batch of 4096 holds 400 MB by itself, and keeping

@@ -168,6 +168,18 @@ void Worker::wait() {
   if (slimt_hip_ctx_synchronize(ctx_)) raise("slimt_hip_ctx_synchronize");
 }
 
+void expand_alignment(Hypothesis &h) {
+  const size_t n = h.target.size();
+  if (n == 0 || !h.alignment.empty()) return;
+  const size_t len = h.alignment_flat.size() / n;  // (an empty source sentence: n empty rows, as collect() builds them)
+  h.alignment.reserve(n);
+  for (size_t t = 0; t < n; ++t) {
+    const float *row = h.alignment_flat.data() + t * len;
+    h.alignment.emplace_back(row, row + len);
+  }
+  std::vector<float>().swap(h.alignment_flat);
+}
+
 Histories collect(const uint32_t *out_ids, const uint32_t *out_len, const float *align,
                   const uint32_t *lengths, size_t B, size_t S, size_t T, bool flat) {
   Histories histories;

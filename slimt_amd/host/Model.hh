@@ -34,6 +34,8 @@ struct Hypothesis {  // slimt/Types.hh:55-61
   uint64_t batch = 0;        // diagnostic: serial number of that batch (Service: batches in launch order)
 };
 using History = std::shared_ptr<Hypothesis>;
+// alignment_flat -> alignment: target.size() rows of equal length (the sentence's source tokens), then the block is released
+void expand_alignment(Hypothesis &hypothesis);
 using Histories = std::vector<History>;
 
 // Padded batch (slimt/Input.cc:20-63): indices [B,S], lengths, limit factor.
