@@ -215,9 +215,12 @@ int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx);
  * them), 1 = one launch per stage (and per decode step; the kernels behind
  * slimt_hip_decode_step), 2 / 3 / 4 / 5 = automatic, but the persistent decoder
  * is forced to 16 / 32 / 8 / 4 sentences per workgroup where it has that
- * variant (tuning and tests; 0 picks 32 for output layers of more than 16k
- * columns, and 8 or 4 while CUs would idle: slimt_hip_model_set_adaptive_decoder_rows).
- * Same results in every mode. */
+ * variant, 6 = automatic, but output layers are shared by clusters of four
+ * 16-sentence workgroups where the kernel has that (emb 256, sources of up to 32
+ * tokens, decoder admission on) (tuning and tests; 0 picks 32 for output layers
+ * of more than 16k columns -- clusters measured 6 % below it on the full
+ * vocabulary --, and 8 or 4 while CUs would idle:
+ * slimt_hip_model_set_adaptive_decoder_rows). Same results in every mode. */
 int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode);
 /* Rows (source tokens) per workgroup of the persistent encoder for emb 256 models: 0
  * (default) = chosen per call (64-row tiles from 32 of them on),
@@ -406,6 +409,13 @@ int slimt_hip_profile_reset(slimt_hip_ctx *ctx);
  * call (step < 0 disables stamping). */
 int slimt_hip_debug_decode_stamps(slimt_hip_ctx *ctx, int step, uint64_t *out,
                                   size_t n);
+/* Diagnostic: break (broken != 0) or restore the hand-over of a shortlist generated inside the
+ * encoder launch (slimt_hip_translate*_generated): the waiting workgroups then look for a
+ * publication that never comes and give up after `poll_limit` polls (1..2^24; the default 2^24
+ * is about two seconds). A waiter that gives up packs nothing and the context's next wait --
+ * slimt_hip_ctx_synchronize, or the blocking translate calls -- FAILS: the batch's results are
+ * not to be used. Tests use it to reach that path. */
+int slimt_hip_debug_break_shortlist_handoff(slimt_hip_ctx *ctx, int broken, unsigned poll_limit);
 /* Diagnostic: which form each sentence-layer of ctx's last batch was cached in -- out[l * B + b],
  * 0 = 20-bit, 1 = 24-bit; *batch = B, or 0 when the batch's caches are all in one form (f32 or
  * 24-bit: formats 1 / 2, or a shape without the narrow form). Waits for ctx's stream. */

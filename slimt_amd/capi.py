@@ -27,7 +27,7 @@ SYMBOLS = [
     "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_ctx_set_encode_rows", "slimt_hip_ctx_plan", "slimt_hip_translate", "slimt_hip_translate_device",
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
-    "slimt_hip_debug_decode_stamps", "slimt_hip_debug_kv_formats", "slimt_hip_debug_kv_narrow_limit",
+    "slimt_hip_debug_decode_stamps", "slimt_hip_debug_kv_formats", "slimt_hip_debug_kv_narrow_limit", "slimt_hip_debug_break_shortlist_handoff",
     "slimt_hip_debug_occupancy_trace", "slimt_hip_model_set_decoder_budget",
     "slimt_hip_model_set_kv_cache_policy",
     "slimt_hip_model_set_xcd_affinity", "slimt_hip_model_device",
@@ -148,6 +148,7 @@ def lib():
     L.slimt_hip_debug_occupancy_trace.argtypes = [vp, sz]
     L.slimt_hip_debug_kv_formats.argtypes = [vp, vp, sz, vp]
     L.slimt_hip_debug_kv_narrow_limit.argtypes = [vp, i32]
+    L.slimt_hip_debug_break_shortlist_handoff.argtypes = [vp, i32, u32]
     L.slimt_hip_model_set_decoder_budget.argtypes = [vp, i32]
     L.slimt_hip_model_set_kv_cache_policy.argtypes = [vp, i32]
     L.slimt_hip_model_set_xcd_affinity.argtypes = [vp, i32]
@@ -576,6 +577,10 @@ class Context:
         out = np.zeros(64, dtype=np.uint64)
         _chk(lib().slimt_hip_debug_decode_stamps(self.h, step, _p(out), 64))
         return out
+
+    def debug_break_shortlist_handoff(self, broken: bool, poll_limit: int = 1 << 24):
+        """The waiters of an in-launch shortlist look for a publication that never comes (tests: the timeout path)."""
+        _chk(lib().slimt_hip_debug_break_shortlist_handoff(self.h, 1 if broken else 0, int(poll_limit)))
 
     def debug_kv_formats(self, layers: int, max_batch: int):
         """[layers][B] uint8 of the last batch: 0 = its cache is in the 20-bit form, 1 = 24-bit; None when the batch's

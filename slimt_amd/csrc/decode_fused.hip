@@ -860,6 +860,7 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
 
 // ---- packed K/V cache (FusedDecodeArgs::kv24): D = 256, d_head 32, S <= 32 -----------------
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 // The cached cross-attention in the hoisted (PORTABLE) order -- the CPU checker under oracle/ restates it as cross_attention_portable:
 // the projections' unquantisation multiplier u and prepared bias pb are per-column constants, so they are
@@ -1706,8 +1707,17 @@ __device__ __forceinline__ void attention_row20_64(AttnRow r, int lane, lcf_ptr 
 // streams its share of every weight, and only waves 0 .. SPW - 1 own a sentence in the row-wise phases
 // (LayerNorm, attention, sampling), which then have a SIMD to themselves or share it with one wave instead of
 // three. A sentence's arithmetic does not depend on which rows surround it, so results are identical.
-template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0, int SPW = 16>
+// CL: cluster logits (output layers of 16k columns and more: the full vocabulary). With CL = 1 every workgroup streams the
+// WHOLE output layer for its 16 sentences every step -- 8.2 MB at 32,000 columns, 76 of a loaded step's 134 us, sixteen
+// times per batch of 256. With CL > 1, CL consecutive tiles (workgroups) form a cluster that shares it: each member takes
+// 1 / CL of the column tiles for ALL the cluster's sentences, and two hand-overs through global memory per step carry the
+// quantised input rows out (256 bytes per sentence) and each member's best (logit, column) per sentence back; the
+// sentence's owner then takes the first maximum over the members' candidates -- columns ascend with the member index, so it
+// is the reference's scan (Transformer.cc:287-298) whatever the split. The members wait for each other: the engine uses
+// clusters only under the decoder admission (every admitted workgroup gets a CU without waiting for another decoder).
+template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0, int SPW = 16, int CL = 1>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
+  static_assert(CL == 1 || (CL <= 4 && RT == 1 && SPW == 16 && MID == 0 && !LONG), "cluster logits: the 16-sentence tilings");
   static_assert(SPW == 16 || ((SPW == 8 || SPW == 4) && RT == 1 && KV24), "fewer sentences per workgroup: the packed-cache, 16-row variants");
   static_assert(!KV24 || (((KSD == 4 && DH == 32) || (KSD == 8 && DH == 64)) && !LONG),
                 "the packed K/V cache: D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32 (64 / 128 with MID 1 / 2)");
@@ -1804,6 +1814,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   }
   const int m0 = tile * RS;
   if (tid == 0) occ_trace_event(a.trace, 1, 0);
+  // my cluster (CL > 1): tiles cl_first .. cl_first + cl_n - 1 (the last cluster of a batch may be short), me = member cl_m
+  const int n_tiles_b = (B + RS - 1) / RS;
+  const int cl_first = tile / CL * CL;
+  const int cl_n = CL == 1 ? 1 : (n_tiles_b - cl_first < CL ? n_tiles_b - cl_first : CL);
+  const int cl_m = tile - cl_first;
+  if (CL > 1 && tid == 0) flags[2] = 0;  // every member of my cluster has finished all its sentences
 
   // per-sentence state of rows wave + 16 rr, owned by wave `wave` (uniform within the wave)
   int bq[RT], len[RT];
@@ -1915,7 +1931,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       lds_barrier();
       // every sentence of this tile has emitted EOS (counted in the previous step's sampling
       // phase; checked here, behind the first barrier that follows it anyway)
-      if (l == 0 && flags[0] >= valid_rows) {
+      // (a cluster leaves together: its members need each other's share of the output layer until the last sentence ends)
+      if (l == 0 && (CL > 1 ? flags[2] != 0 : flags[0] >= valid_rows)) {
         all_done = true;
         break;
       }
@@ -2174,6 +2191,191 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     if (all_done) break;
     // ---- output layer + greedy sample (Transformer.cc:176-182,279-339) ----
     SLIMT_PHASE_LANE;
+    int cl_ix[RT];  // CL > 1: the sampled column of this wave's sentence, from the cluster's candidates
+#pragma unroll
+    for (int rr = 0; rr < RT; ++rr) cl_ix[rr] = 0x7fffffff;
+    if constexpr (CL > 1) {
+      constexpr int CR = 16 * CL;         // sentences (rows) of a full cluster
+      constexpr int kCoh = 17;            // sc0 | sc1: exchanged data is written through and read past the caches
+      char *CA = reinterpret_cast<char *>(xs);  // [CR][LDA] int8: the cluster's input rows (x / h / pre-LN rows are dead here)
+      float *cred_v = reinterpret_cast<float *>(CA + CR * LDA);  // [NW][CR] every wave's candidates
+      int *cred_i = reinterpret_cast<int *>(cred_v + NW * CR);
+      static_assert((size_t)CR * LDA + 2 * NW * CR * 4 <= (LEAN ? 2 : 3) * (size_t)R * LDF * 4, "the cluster's rows + candidates fit the f32 row buffers");
+      const rsrc_t ract = make_rsrc(a.cl_act, (unsigned)n_tiles_b * 16u * (unsigned)D);
+      const rsrc_t rpart = make_rsrc(a.cl_part, (unsigned)n_tiles_b * (unsigned)(CR + 1) * 8u);
+      // a cluster barrier: every wave's stores are out, one release, one arrival; then a bounded wait for the others'
+      auto cluster_sync = [&](unsigned target) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          unsigned *ctr = a.cl_sync + tile / CL;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned spin = 0;
+          while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spin > (1u << 22)) {  // ~2 s: a member never arrived (it cannot under the admission the engine asks for)
+              if (a.dev_error) __hip_atomic_store(a.dev_error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+      };
+      lds_barrier();  // the last LayerNorm's quantised rows are in A1
+      SLIMT_STAMP(43);
+      // (1) my 16 rows out
+      for (int i = tid; i < 16 * (D / 16); i += 1024) {
+        const int row = i / (D / 16), ch = i % (D / 16);
+        const v4i v = *reinterpret_cast<const v4i *>(A1 + row * LDA + ch * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ract, row * D + ch * 16, tile * 16 * D, kCoh);
+      }
+      SLIMT_STAMP(56);
+      cluster_sync((unsigned)(2 * t + 1) * (unsigned)cl_n);
+      SLIMT_STAMP(57);
+      // (2) the cluster's rows in (rows of absent members: zeros, their results are never read)
+      for (int i = tid; i < CR * (D / 16); i += 1024) {
+        const int row = i / (D / 16), ch = i % (D / 16);
+        v4i v = {0, 0, 0, 0};
+        if (row < 16 * cl_n) v = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(ract, row * D + ch * 16, cl_first * 16 * D, kCoh));
+        *reinterpret_cast<v4i *>(CA + row * LDA + ch * 16) = v;
+      }
+      // (3) my share of the column tiles against all of them. The weights are the MFMA's A operand: an accumulator lane
+      // holds FOUR consecutive columns (16 tile + 4 lg ..) of ONE sentence (16 st + lr), so the running maximum is one
+      // (value, column) pair per sentence tile; a lane's columns only grow, strict > keeps its first maximum.
+      const int tpm = (outw.n_tiles + cl_n - 1) / cl_n;
+      const int tile0 = cl_m * tpm, tile1 = tile0 + tpm < outw.n_tiles ? tile0 + tpm : outw.n_tiles;
+      const rsrc_t rw = make_rsrc(outw.Wp, (unsigned)outw.n_tiles * KSD * 1024u);
+      const rsrc_t rc = make_rsrc(outw.colsum, (unsigned)outw.n_tiles * 64u), rp = make_rsrc(outw.pb, (unsigned)outw.n_tiles * 64u);
+      struct WTile {
+        v4i f[KSD];
+        v4i cs;
+        f4 pb;
+      };
+      constexpr int NBC = 3;
+      WTile wt[NBC];
+      auto loadw = [&](WTile &x, int tl) {  // (past the last tile of the layer: zeros)
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) x.f[ks] = load_frag(rw, lane * 16, (tl * KSD + ks) * 1024);
+        x.cs = load_frag(rc, lg * 16, tl * 64);
+        x.pb = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rp, lg * 16, tl * 64, 0));
+      };
+#pragma unroll
+      for (int k = 0; k < NBC; ++k) {
+        loadw(wt[k], tile0 + wave + NW * k);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      lds_barrier();  // CA is complete
+      SLIMT_STAMP(58);
+      float cbv[CL];
+      int cbi[CL];
+#pragma unroll
+      for (int st = 0; st < CL; ++st) {
+        cbv[st] = -3.402823466e+38f;
+        cbi[st] = 0x7fffffff;
+      }
+      const int mine = tile1 > tile0 + wave ? (tile1 - tile0 - wave + NW - 1) / NW : 0;
+      const int rounds = (mine + NBC - 1) / NBC;
+      for (int c = 0; c < rounds * NBC; c += NBC) {
+#pragma unroll
+        for (int k = 0; k < NBC; ++k) {
+          const int tl = tile0 + wave + NW * (c + k);
+          const bool in_slice = tl < tile1;
+          const WTile &x = wt[k];
+          const int col0 = tl * 16 + lg * 4;
+          // The phase is bound by the issue slots of this epilogue (500 logits per lane and step whatever the split), so
+          // per logit: the shift 127 colsum STARTS the accumulator (integer arithmetic: the same sum as adding it after),
+          // conversion, half a packed multiply, half a packed add, compare, two selects. Columns outside my share or past
+          // the layer's last one get a NaN bias instead of a predicate: their logit is NaN and never "greater".
+          const v4i sh = {__mul24(127, x.cs[0]), __mul24(127, x.cs[1]), __mul24(127, x.cs[2]), __mul24(127, x.cs[3])};
+          const int left = in_slice ? outw.N - col0 : 0;  // columns of mine in this lane's four
+          const float qnan = __int_as_float(0x7fc00000);
+          const f2 pb01 = {left > 0 ? x.pb.x : qnan, left > 1 ? x.pb.y : qnan}, pb23 = {left > 2 ? x.pb.z : qnan, left > 3 ? x.pb.w : qnan};
+          const f2 uu = {a.out.u, a.out.u};
+#pragma unroll
+          for (int st = 0; st < CL; ++st) {
+            v4i acc = sh;
+#pragma unroll
+            for (int ks = 0; ks < KSD; ++ks) {
+              const v4i af = *reinterpret_cast<const v4i *>(CA + (16 * st + lr) * LDA + ks * 64 + lg * 16);
+              acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(x.f[ks], af, acc, 0, 0, 0);
+            }
+            // y = float(acc + 127 colsum) * u + pb (Intgemm.inl.cc:146-153): dequant4's operations
+            f2 lo = {(float)acc[0], (float)acc[1]}, hi = {(float)acc[2], (float)acc[3]};
+            lo = lo * uu;
+            hi = hi * uu;
+            lo = lo + pb01;
+            hi = hi + pb23;
+            const float vv[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const bool better = vv[i] > cbv[st];
+              cbv[st] = better ? vv[i] : cbv[st];
+              cbi[st] = better ? col0 + i : cbi[st];
+            }
+          }
+          loadw(wt[k], tl + NW * NBC);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      SLIMT_STAMP(44);
+      // this wave's best per sentence: over the four lane groups (larger value, then smaller column)
+      auto lane_step = [&](float &v, int &ix, int m) {
+        const float ov = __shfl_xor(v, m, 64);
+        const int o = __shfl_xor(ix, m, 64);
+        const bool take = ov > v || (ov == v && o < ix);
+        v = take ? ov : v;
+        ix = take ? o : ix;
+      };
+#pragma unroll
+      for (int st = 0; st < CL; ++st) {
+        lane_step(cbv[st], cbi[st], 16);
+        lane_step(cbv[st], cbi[st], 32);
+        if (lg == 0) {
+          cred_v[wave * CR + 16 * st + lr] = cbv[st];
+          cred_i[wave * CR + 16 * st + lr] = cbi[st];
+        }
+      }
+      SLIMT_STAMP(45);
+      lds_barrier();
+      // (4) my share's best per sentence, over the 16 waves, out to the sentence's owner
+      for (int srow = wave; srow < CR; srow += NW) {
+        float v = lane < NW ? cred_v[lane * CR + srow] : -3.402823466e+38f;
+        int ix = lane < NW ? cred_i[lane * CR + srow] : 0x7fffffff;
+        row16_argmax(v, ix);
+        if (lane == 0) {
+          const v2i rec = {__float_as_int(v), ix};
+          __builtin_amdgcn_raw_buffer_store_b64(rec, rpart, srow * 8, tile * (CR + 1) * 8, kCoh);
+        }
+      }
+      if (tid == 0) {  // ... and whether every sentence of mine has ended (as of the step before)
+        const v2i rec = {flags[0] >= valid_rows ? 1 : 0, 0};
+        __builtin_amdgcn_raw_buffer_store_b64(rec, rpart, CR * 8, tile * (CR + 1) * 8, kCoh);
+      }
+      SLIMT_STAMP(59);
+      cluster_sync((unsigned)(2 * t + 2) * (unsigned)cl_n);
+      SLIMT_STAMP(41);
+      // (5) the owner: first maximum over the members' candidates (member = lane; columns ascend with it)
+      if (row_wave) {
+        float v = -3.402823466e+38f;
+        int ix = 0x7fffffff;
+        int done = 1;
+        if (lane < cl_n) {
+          const int member = (cl_first + lane) * (CR + 1) * 8;  // (lane-dependent: in the vector offset)
+          const v2i rec = __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(rpart, member + (16 * cl_m + wave) * 8, 0, kCoh));
+          const int rv = rec.x;  // (a copy first: bit casts of vector elements read element 0 with this compiler)
+          v = __int_as_float(rv);
+          ix = rec.y;
+          const v2i drec = __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(rpart, member + CR * 8, 0, kCoh));
+          done = drec.x;
+        }
+        row16_argmax(v, ix);
+        cl_ix[0] = __builtin_amdgcn_readfirstlane(ix);
+        const bool all = __builtin_amdgcn_ballot_w64(done != 0) == ~0ull;
+        if (wave == 0 && lane == 0) flags[2] = all ? 1 : 0;
+      }
+    } else {
     Frags fl[NB_OUT];  // requested before the barrier that ends the last LayerNorm
     stream_prologue<KSD, NB_OUT, 0, (KSD >= 4)>(outw, wave, lane, fl);
     lds_barrier();
@@ -2215,6 +2417,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     SLIMT_STAMP(45);
     lds_barrier();
     SLIMT_STAMP(41);
+    }
     // wave w finishes sentences w (+ 16): reduce over the 16 waves' candidates
 #pragma unroll
     for (int rr = 0; rr < RT; ++rr) {
@@ -2222,10 +2425,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       const int row = 16 * rr + wave;
       uint32_t tok = 0;
       {
-        float v = lane < NW ? red_v[lane * R + row] : -3.402823466e+38f;
-        int ix = lane < NW ? red_i[lane * R + row] : 0x7fffffff;
-        row16_argmax(v, ix);
-        ix = __builtin_amdgcn_readfirstlane(ix);
+        int ix;
+        if constexpr (CL > 1) {
+          ix = cl_ix[rr];
+        } else {
+          float v = lane < NW ? red_v[lane * R + row] : -3.402823466e+38f;
+          ix = lane < NW ? red_i[lane * R + row] : 0x7fffffff;
+          row16_argmax(v, ix);
+          ix = __builtin_amdgcn_readfirstlane(ix);
+        }
         // no column beat the start value (every logit NaN or -inf): class 0, where the reference's scan
         // starts and stays (Transformer.cc:287-298) -- and never an index past the shortlist
         ix = (ix == 0x7fffffff || nan0) ? 0 : ix;
@@ -2402,6 +2610,11 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   if (kv24 && D == 512) {
     if (F != 2048) return hipErrorInvalidValue;
     return go(SLIMT_KV24_PICK(8, 32, 64, 0), lds);
+  }
+  if (a.cluster > 1) {  // cluster logits: the 16-sentence tiling of the D = 256 packed-cache shape
+    if (!(kv24 && D == 256 && F == 1536 && rows == 16 && a.cluster == 4 && a.cl_act && a.cl_part && a.cl_sync)) return hipErrorInvalidValue;
+    return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 0, 16, 4>
+                      : decode_fused_kernel<4, 24, 32, false, false, 1, true, 0, 16, 4>, lds);
   }
   if (kv24 && rows <= 16) return go(SLIMT_KV24_PICK(4, 24, 32, 0), lds);
 #undef SLIMT_KV24_PICK

@@ -953,8 +953,8 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   if (gen_here) {
     // the shortlist of this launch: wait for its publisher (running since before this workgroup started, and
     // waiting for nobody: ~40 us of work against this workgroup's ~250); then this workgroup's share of the output layer
-    shortlist_await_in_launch(a.gen_flag, a.gen_epoch, tid);
-    for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+    if (shortlist_await_in_launch(a.gen_flag, a.gen_epoch ^ a.gen_wait_xor, tid, a.dev_error, a.gen_spin_limit))  // (never published: nothing to pack from)
+      for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
   }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);
 }

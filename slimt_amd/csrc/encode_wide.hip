@@ -773,8 +773,8 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
     if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
   }
   if (gen_here) {
-    shortlist_await_in_launch(a.gen_flag, a.gen_epoch, tid);
-    for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+    if (shortlist_await_in_launch(a.gen_flag, a.gen_epoch ^ a.gen_wait_xor, tid, a.dev_error, a.gen_spin_limit))  // (never published: nothing to pack from)
+      for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
   }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);
 }

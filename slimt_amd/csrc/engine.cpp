@@ -735,6 +735,14 @@ extern "C" int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int f
   return 0;
 }
 
+extern "C" int slimt_hip_debug_break_shortlist_handoff(slimt_hip_ctx *ctx, int broken, unsigned poll_limit) {
+  if (!ctx) return fail(-1, "ctx is NULL");
+  if (poll_limit == 0 || poll_limit > (1u << 24)) return fail(-1, "poll limit %u not in 1..2^24", poll_limit);
+  ctx->gen_break = broken != 0;
+  ctx->gen_spin_limit = poll_limit;
+  return 0;
+}
+
 extern "C" int slimt_hip_debug_kv_narrow_limit(slimt_hip_model *model, int limit) {
   if (!model) return fail(-1, "model is NULL");
   if (limit < 1 || limit > (1 << 19)) return fail(-1, "narrow-form limit %d not in 1..2^19 (20 bits hold [-2^19, 2^19))", limit);
@@ -793,7 +801,7 @@ void sinusoid_table(int S, int D, std::vector<float> &out) {
 
 void ctx_free(slimt_hip_ctx *c) {
   DevBuf *bufs[] = {&c->pos, &c->ids, &c->lengths, &c->x0, &c->x1, &c->q, &c->k, &c->v, &c->att,
-                    &c->h8, &c->a8, &c->ticket, &c->kv, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
+                    &c->h8, &c->a8, &c->ticket, &c->kv, &c->kv_fmt, &c->cl_act, &c->cl_part, &c->cl_sync, &c->dx, &c->dx_pre, &c->dh, &c->datt8, &c->dout, &c->df8,
                     &c->state, &c->part_val, &c->part_idx, &c->prev, &c->out_ids, &c->out_len,
                     &c->finished, &c->n_finished, &c->align, &c->shortlist, &c->logits,
                     &c->attn_dbg, &c->stamps, &c->dbg_embed, &c->dbg_layers, &c->sl_scratch, &c->n_sl_dev, &c->gen_flag};
@@ -974,7 +982,7 @@ extern "C" int slimt_hip_ctx_stream(slimt_hip_ctx *ctx, void **stream) {
 
 extern "C" int slimt_hip_ctx_set_decode_mode(slimt_hip_ctx *ctx, int mode) {
   if (!ctx) return fail(-1, "ctx is NULL");
-  if (mode < 0 || mode > 5) return fail(-1, "bad decode mode %d", mode);
+  if (mode < 0 || mode > 6) return fail(-1, "bad decode mode %d", mode);
   ctx->decode_mode = mode;
   return 0;
 }
@@ -998,6 +1006,28 @@ extern "C" int slimt_hip_ctx_plan(const slimt_hip_ctx *ctx, size_t S, int *encod
   return 0;
 }
 
+// A word of pinned host memory per context that kernels set when one of their bounded waits ran out (a member of a
+// logits cluster that never arrived: 2; the in-launch shortlist's publisher never published: 1). Read where the host
+// waits for the context's stream; the word is cleared and the call fails -- the batch's results are not to be used.
+static unsigned *dev_error_word(slimt_hip_ctx *ctx) { return reinterpret_cast<unsigned *>(ctx->n_finished_host) + 2; }
+static unsigned *dev_error_device_view(slimt_hip_ctx *ctx) {
+  void *p = nullptr;
+  if (!ctx->n_finished_host || hipHostGetDevicePointer(&p, dev_error_word(ctx), 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return static_cast<unsigned *>(p);
+}
+static int check_dev_error(slimt_hip_ctx *ctx) {
+  if (!ctx->n_finished_host) return 0;
+  volatile unsigned *w = dev_error_word(ctx);
+  const unsigned e = *w;
+  if (!e) return 0;
+  *w = 0;
+  return fail(-1, e == 1 ? "the batch's shortlist was never published inside the encoder launch (bounded wait ran out): results discarded"
+                         : "a workgroup of a logits cluster never arrived (bounded wait ran out): results discarded");
+}
+
 extern "C" int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx) {
   if (!ctx) return fail(-1, "ctx is NULL");
   // A blocking-sync event, not hipStreamSynchronize: that one spins, and a host pipeline has one
@@ -1008,7 +1038,7 @@ extern "C" int slimt_hip_ctx_synchronize(slimt_hip_ctx *ctx) {
   if (!ctx->sync_event) HIPCHK(hipEventCreateWithFlags(&ctx->sync_event, hipEventBlockingSync | hipEventDisableTiming));
   HIPCHK(hipEventRecord(ctx->sync_event, ctx->stream));
   HIPCHK(hipEventSynchronize(ctx->sync_event));
-  return 0;
+  return check_dev_error(ctx);
 }
 
 // ---------------------------------------------------------------------------
@@ -1222,6 +1252,9 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.gen = *gen;
       f.gen_flag = c->gen_flag.as<unsigned>();
       f.gen_epoch = ++c->gen_epoch;
+      f.dev_error = dev_error_device_view(c);
+      f.gen_spin_limit = c->gen_spin_limit;
+      if (c->gen_break) f.gen_wait_xor = 0x40000000u;  // (debug: the waiters look for an epoch nobody publishes)
       if (c->gen_epoch == 0xffffffffu) c->gen_epoch = 0;  // (the flag is cleared again before epoch 1 is reused)
     }
     {
@@ -1609,9 +1642,32 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     const size_t n_expected = d_n_sl && n_sl_hint ? n_sl_hint : (size_t)out.w.N;
     // ... and 8 or 4 (decode_fused.hip, SPW) when the decoders in flight would leave most of the chip idle:
     // decided below, under the admission lock, from the contexts that have a decoder pending
-    f.rows_per_wg = c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : c->decode_mode == 4 ? 8 : c->decode_mode == 5 ? 4
+    // Round 5: where the kernel has it, output layers that wide are SHARED by clusters of four 16-sentence workgroups
+    // instead (decode_fused.hip, CL: each member streams a quarter of the columns for all 64 sentences) -- under the
+    // decoder admission only: the members wait for each other, and the admission is what guarantees every admitted
+    // workgroup a CU without waiting for another decoder (decode mode 6 forces clusters, 3 the 32-sentence tiling)
+    const bool cluster_ok = kv24 && m->D == 256 && m->F == 1536 && S <= 32 && c->model->decoder_budget > 0;
+    // Measured on config 4 (B = 512, 32,000 columns, 20 workers; profiles/r05_cluster_logits.txt): clusters 23.4 M tok/s,
+    // the 32-sentence tiling 24.9 M, the 16-sentence one 22.0 M -- a member's quarter of the columns takes 27 us + 14 us of
+    // skew between its waves + 6 us of hand-overs where the whole layer took 70, but the 32-sentence tiling's per-sentence
+    // cost is lower still: the phase is bound by the arg-max epilogue's issue slots and the address path's load
+    // instructions (six per column tile here, four and a half there), not by the bytes the split saves. So: on request only.
+    const bool clusters = cluster_ok && c->decode_mode == 6;
+    f.rows_per_wg = clusters ? 16 : c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : c->decode_mode == 4 ? 8 : c->decode_mode == 5 ? 4
                     : (n_expected > 16384 ? 32 : 0);
     int rows = fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, f.rows_per_wg, kv24);
+    if (clusters) {
+      const size_t tiles = (B + 15) / 16, n_clusters = (tiles + 3) / 4;
+      HIPCHK(c->cl_act.reserve(tiles * 16 * (size_t)m->D));
+      HIPCHK(c->cl_part.reserve(tiles * (16 * 4 + 1) * 8));
+      HIPCHK(c->cl_sync.reserve(n_clusters * 4));
+      HIPCHK(hipMemsetAsync(c->cl_sync.p, 0, n_clusters * 4, st));
+      f.cluster = 4;
+      f.cl_act = c->cl_act.as<unsigned char>();
+      f.cl_part = c->cl_part.as<int>();
+      f.cl_sync = c->cl_sync.as<unsigned>();
+      f.dev_error = dev_error_device_view(c);
+    }
     for (int l = 0; l < m->Ld; ++l) {
       const DecLayerW &L = m->dec[(size_t)l];
       FusedLayerW &fl = f.L[l];

@@ -107,6 +107,9 @@ struct slimt_hip_ctx {
   hipStream_t stream = nullptr;
   slimt_hip::DevBuf gen_flag;         // in-launch shortlist generation: the word its publisher sets to gen_epoch (kernels.h, FusedEncodeArgs::gen)
   unsigned gen_epoch = 0;
+  // slimt_hip_debug_break_shortlist_handoff: the waiters of the next launches poll a word the publisher never sets, `limit` times
+  bool gen_break = false;
+  unsigned gen_spin_limit = 1u << 24;
   hipEvent_t sync_event = nullptr;  // blocking-sync event of slimt_hip_ctx_synchronize (created on first use)
   std::vector<uint32_t> sl_host;    // the shortlist last uploaded by translate_host (re-uploaded only when it changes)
   bool own_stream = false;
@@ -132,6 +135,7 @@ struct slimt_hip_ctx {
   unsigned enc_ticket_base = 0;  // the same for the fused encoder (second counter of `ticket`)
   unsigned xarr_base = 0, xclaim_base = 0;  // XCD-affine claims (64-bit state word behind the two counters)
   slimt_hip::DevBuf kv;  // [Ld][2][B*S][D]
+  slimt_hip::DevBuf cl_act, cl_part, cl_sync;  // cluster logits (kernels.h, FusedDecodeArgs::cluster): the members' hand-over buffers
   slimt_hip::DevBuf kv_fmt;  // [Ld][B] bytes: the form of each sentence-layer's packed cache (kernels.h, FusedDecodeArgs::kv_fmt)
   bool kv_fmt_valid = false;  // the encoder of the current batch recorded kv_fmt (else every cache is in the 24-bit form)
   int kv_fmt_B = 0;           // the batch size kv_fmt was recorded for

@@ -330,6 +330,16 @@ struct FusedDecodeArgs {
   const int *kv_cs[4][2] = {};    // [layer][K, V]: their column sums [D] (D = 512: the cache holds the signed accumulator)
   float kv_u[4][2] = {};          // [layer][K, V]: unquantisation multiplier u (f32 form)
   float kv_u256[4][2] = {};       // [layer][K, V]: u / 256 (packed form: the integers come back as accS * 256)
+  // Cluster logits (decode_fused.hip, CL; output layers of 16k columns and more): `cluster` consecutive 16-sentence tiles
+  // share the output layer, each member computing 1 / cluster of its columns for all of them. cl_act [tiles][16][D] int8:
+  // every tile's quantised input rows of the current step; cl_part [tiles][16 cluster + 1][2]: per member and cluster
+  // sentence its best (logit bits, column), then {all my sentences ended, 0}; cl_sync [clusters]: arrivals, ZERO at launch.
+  // dev_error (nullable, pinned host memory): set non-zero when a bounded wait inside a launch ran out.
+  int cluster = 0;
+  unsigned char *cl_act = nullptr;
+  int *cl_part = nullptr;
+  unsigned *cl_sync = nullptr;
+  unsigned *dev_error = nullptr;
   bool ln_in_lds = false;  // set by the launcher: the LayerNorm constants of all layers fit LDS beside the rest
   bool kv_nt = false;  // non-temporal K/V cache loads (d_head 32 / 64 shapes; see decode_fused.hip)
   // with kv_nt: which caches are still read temporally, in eighths of a layer: sentence b's cache of
@@ -408,6 +418,9 @@ struct FusedEncodeArgs {
   ShortlistArgs gen;
   unsigned *gen_flag = nullptr;
   unsigned gen_epoch = 0;
+  unsigned gen_spin_limit = 1u << 24;  // polls a waiter makes before it gives up (tests shorten it)
+  unsigned gen_wait_xor = 0;           // debug: the waiters look for gen_epoch ^ this -- non-zero = a publisher that never comes
+  unsigned *dev_error = nullptr;       // nullable, pinned host memory: set to 1 when a waiter gave up (FusedDecodeArgs::dev_error)
   unsigned *ticket = nullptr;  // nullable: over-subscribed launch (see FusedDecodeArgs)
   unsigned ticket_base = 0;
   OccTrace trace;

@@ -187,16 +187,31 @@ __device__ __forceinline__ void shortlist_publish_in_launch(const ShortlistArgs 
 }
 
 // Every workgroup, at the end of its encoder work and before it packs its share of the shortlisted output layer:
-// one relaxed poll loop by one lane (bounded like every spin: ~2 s; unreachable while the launch is ticketed), ONE
-// agent-scope acquire, the barrier; plain loads of the ids / the count behind it.
-__device__ __forceinline__ void shortlist_await_in_launch(unsigned *flag, unsigned epoch, int tid) {
+// one relaxed poll loop by one lane, ONE agent-scope acquire, the barrier; plain loads of the ids / the count behind it.
+// The poll is bounded like every spin (`limit` polls, ~2 s by default; unreachable while the launch is ticketed: the
+// publisher started first and waits for nobody). When it does run out the ids and the count were never published:
+// returns false -- the caller must NOT pack from them -- and sets *error (pinned host memory, nullable) so that the
+// host fails the batch instead of returning translations made from a stale or partial shortlist.
+__device__ __forceinline__ bool shortlist_await_in_launch(unsigned *flag, unsigned epoch, int tid, unsigned *error,
+                                                          unsigned limit = 1u << 24) {
+  __shared__ int published;
   if (tid == 0) {
-    for (unsigned spin = 0; spin < (1u << 24) && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin)
+    unsigned spin = 0;
+    bool ok = true;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      if (++spin >= limit) {
+        ok = false;
+        break;
+      }
       __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok && error) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    published = ok ? 1 : 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+  return published != 0;
 }
 
 }  // namespace slimt_hip

@@ -128,7 +128,7 @@ def test_baseline_config_full_size_bit_exact(hip, oracle, engines, name, preset,
             assert np.array_equal(out_3, out) and np.array_equal(ln_3, ln)
         # mode 0 above chose by occupancy (one context alone: 4 sentences per workgroup where the variant exists);
         # every tiling forced: 16, 8, 4 sentences per workgroup -- tokens, lengths AND alignment rows
-        for mode in (2, 4, 5):
+        for mode in (2, 4, 5, 6):  # (6: the output layer shared by clusters of four 16-sentence workgroups, tiny11)
             ctx.set_decode_mode(mode)
             out_m, ln_m, al_m = ctx.translate(ids, lens, sl, want_align=True)
             assert np.array_equal(out_m, w_out) and np.array_equal(ln_m, w_ln) and np.array_equal(al_m, w_al), (name, mode)

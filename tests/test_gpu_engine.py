@@ -291,7 +291,7 @@ def test_logits_without_a_maximum_sample_class_zero(hip, oracle, synth_models, p
         if poison == "nan-in-column-0":
             assert not w_out.any() and (w_ln == int(np.float32(1.5) * np.float32(S))).all()  # class 0 at every step
         ctx = hip.Context(gm, B, S)
-        for mode in (0, 1, 2, 3, 5):
+        for mode in (0, 1, 2, 3, 5, 6):
             ctx.set_decode_mode(mode)
             out, ln, _ = ctx.translate(ids, lens, sl, eos_id=eos)
             assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out), (poison, mode, sl is None)

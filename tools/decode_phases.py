@@ -11,7 +11,7 @@ gm = capi.Model(m); ctx = capi.Context(gm, B, S)
 if os.environ.get("SLIMT_KV_FORMAT"):  # 0 = packed, 20 bits where the accumulators fit (default); 2 = packed 24-bit; 1 = f32
     gm.set_kv_cache_format(int(os.environ["SLIMT_KV_FORMAT"]))
 ctx.set_decode_mode(int(os.environ.get("SLIMT_DECODE_MODE", "0")))  # 3 = 32 sentences per workgroup
-ids, lens = synth.make_batch(m.V, B, S); sl = synth.make_shortlist(m.V, n_sl)
+ids, lens = synth.make_batch(m.V, B, S); sl = synth.make_shortlist(m.V, n_sl) if n_sl else None  # 0 = the full vocabulary
 ctx.translate(ids, lens, sl)
 names = ["step_start"]
 for l in range(2):
@@ -28,5 +28,9 @@ for step in (5, 20):
     print(f"--- B={B} step {step}: total {(t[-1]-t[0])/100:.1f} us   (shader clock ~{mhz:.0f} MHz)")
     for i in range(1, len(idx)):
         print(f"  {names[i]:22s} {(t[i]-t[i-1])/100:7.2f} us")
+    if os.environ.get("SLIMT_DECODE_MODE") == "6":  # cluster logits: 43 rows ready | 56 published | 57 all arrived | 58 gathered | 44 my columns done | 45 | 59 candidates out | 41 all arrived
+        c = st[[43, 56, 57, 58, 44, 45, 59, 41]]
+        for nm, a0, a1 in zip(["publish rows", "wait for the cluster", "gather rows", "my column tiles", "lane-group reduce", "wave reduce + candidates out", "wait for the cluster"], c[:-1], c[1:]):
+            print(f"    cluster: {nm:28s} {(a1-a0)/100:7.2f} us")
 
 # (encoder phases: tools/encode_wide_phases.py [batch] [tiny11 | base])

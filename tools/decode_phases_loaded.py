@@ -1,6 +1,6 @@
 """GPU box: per-phase time of one decoder workgroup (tile 0 of context 0, one step) WHILE
 the other workers run the bench load -- which phases do the neighbours stretch?
-usage: python tools/decode_phases_loaded.py [workers=20] [batch=256] [src_len=32]"""
+usage: python tools/decode_phases_loaded.py [workers=20] [batch=256] [src_len=32] [shortlist=4096]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
@@ -11,7 +11,7 @@ from slimt_amd import capi, synth
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-n_sl = 4096
+n_sl = int(sys.argv[4]) if len(sys.argv) > 4 else 4096  # 0 = the full vocabulary
 dev = torch.device("cuda", 0)
 m = synth.make_model("tiny11", seed=1234, eos_bias=-100.0)
 gm = capi.Model(m)
@@ -27,14 +27,14 @@ for c in ctxs:
 T = int(np.float32(1.5) * np.float32(S))
 to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
 ids, lens = (to_dev(x) for x in synth.make_batch(m.V, B, S))
-d_sl = to_dev(synth.make_shortlist(m.V, n_sl))
+d_sl = to_dev(synth.make_shortlist(m.V, n_sl)) if n_sl else None
 outs = [torch.zeros((B, T), dtype=torch.int32, device=dev) for _ in range(W)]
 olen = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(W)]
 
 
 def step(i):
     w = i % W
-    ctxs[w].translate_device(ids.data_ptr(), lens.data_ptr(), B, S, d_sl.data_ptr(), n_sl, 1.5, 0,
+    ctxs[w].translate_device(ids.data_ptr(), lens.data_ptr(), B, S, d_sl.data_ptr() if n_sl else 0, n_sl, 1.5, 0,
                              outs[w].data_ptr(), olen[w].data_ptr(), 0, steps_hint=T)
 
 
