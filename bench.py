@@ -41,6 +41,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_INT8_TOPS = 5000.0  # dense int8 MFMA, 2x the ~2.5 PF bf16 (MI355X_MICROARCH.md, Matrix cores)
 PEAK_HBM_GBS = 8000.0    # HBM3E spec (MI355X_MICROARCH.md, Chip-level parameters)
+# what a register-resident loop of v_mfma_i32_16x16x64_i8 sustains on the chip (profiles/archive/r02_mfma_i8_rate_probe.jsonl,
+# tools/probe_mfma.py: 4.24 POP/s): SURVEY 8(d) asks for the fraction against the nominal AND the measured peak
+MEASURED_INT8_TOPS = 4240.0
 
 
 def parse(argv=None):
@@ -557,11 +560,14 @@ def main():
             # `frac` prices ONE launch (16 CUs for a batch of 256) against the whole chip; the launches of this
             # kernel that run at once, together, against the same peak:
             "frac_chip": achieved * in_flight / PEAK_INT8_TOPS,
+            "measured_peak": MEASURED_INT8_TOPS, "frac_measured_peak": achieved / MEASURED_INT8_TOPS,
+            "frac_chip_measured_peak": achieved * in_flight / MEASURED_INT8_TOPS,
             "evidence_tag": evidence_manifest().get("tag") if profiled else None,
             "frac_of_occupied_cus": achieved / (PEAK_INT8_TOPS * cus / 256.0),
             "counters_full_occupancy": sq_counters(prof_name, args.preset)[0] if profiled else None,
             "counters_source": sq_counters(prof_name, args.preset)[1] if profiled else None,
             "whole_job": {"achieved": whole_job_tops / world, "frac": whole_job_tops / world / PEAK_INT8_TOPS,
+                          "frac_measured_peak": whole_job_tops / world / MEASURED_INT8_TOPS,
                           "note": "all kernels, per GPU: algorithmic int8 OPs of every translated sentence / "
                                   "wall time of the timed region"},
         }
@@ -577,8 +583,13 @@ def main():
             # (tiny11, S <= 32, not S = 1, 2, 5: slimt_hip_model_set_kv_cache_format), f32 elsewhere;
             # SURVEY's algorithmic K/V stays the f32 tensor it names.
             kv_once = float(B) * Ld * 2 * S * D * 4
-            kv24 = dec_fused and enc_fused and D == 256 and D // H == 32 and S <= 32 and ((S + 3) // 4 * 4) * 3 <= S * 4
-            kv_impl = kv_once * 0.75 if kv24 else kv_once
+            kv24 = (dec_fused and enc_fused and args.kv_format in (0, 2) and ((S + 3) // 4 * 4) * 3 <= S * 4 and
+                    ((D == 256 and D // H == 32 and S <= 128) or (D == 512 and D // H == 64 and S <= 32)))
+            # ... 20 bits per value where the kernels have the narrow form and the accumulators fit it (every sentence of
+            # the synthetic models does: tests/test_gpu_kv_narrow.py)
+            kv20 = (kv24 and args.kv_format == 0 and ((D == 256 and S <= 64) or (D == 512 and S <= 32)) and
+                    ((S + 7) // 8) * 5120 <= ((S + 3) // 4) * 3072)
+            kv_impl = kv_once * (0.625 if kv20 else 0.75 if kv24 else 1.0)
             w_once = float(Ld * (4 * D * D + 2 * D * F) + D * N_out)
             io_bytes = float(B) * T * (D + 4)
             alg_bytes = w_once + io_bytes + kv_once
@@ -591,12 +602,16 @@ def main():
                 "implementation_bytes_per_launch": impl_bytes,
                 "implementation_over_algorithmic": impl_bytes / alg_bytes,
                 "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
-                "kv_cache_format": "int24 accumulators (3 bytes per value)" if kv24 else "f32",
+                "kv_cache_format": ("int20 accumulators (2.5 bytes per value; 24-bit fallback per sentence and layer)" if kv20
+                                    else "int24 accumulators (3 bytes per value)" if kv24 else "f32"),
                 "bytes_model": {"kv_cache_once": kv_once, "kv_cache_reread_every_step": kv_reread,
                                 "weights_once": w_once, "weights_once_per_step": w_once * T,
                                 "embedding_rows_and_ids": io_bytes},
                 "implementation_GBs_per_launch": impl_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                 "implementation_GBs_chip": impl_bytes / (avg_ms * 1e-3) / 1e9 * in_flight if avg_ms > 0 else 0.0,
+                # the PMC figure (bytes that missed the 4 MB L2s, Infinity-Cache hits included) of one launch, as a rate over
+                # the launches in flight together: what the fabric side carries for this kernel
+                "fabric_GBs_chip": (traffic / (avg_ms * 1e-3) / 1e9 * in_flight) if traffic and avg_ms > 0 else None,
                 "l2_stream_bytes_per_launch": wbytes + kv_reread,  # weights per workgroup and step + K/V
                 "l2_stream_GBs_per_cu": (wbytes + kv_reread) / (avg_ms * 1e-3) / 1e9 / cus if avg_ms > 0 else 0.0,
             }

@@ -176,8 +176,14 @@ int slimt_hip_model_set_xcd_affinity(slimt_hip_model *model, int xcds);
  *       every sentence and layer whose accumulators all lie in [-2^19, 2^19), decided by the
  *       encoder per batch (the 24-bit form holds any accumulator and is the fallback);
  *   1 = always f32 (float(acc), exact);
- *   2 = packed, always 24 bits.
- * Results do not depend on it. */
+ *   2 = packed, always 24 bits;
+ *   3 = f32, and the attention in the reference's LITERAL sequence: every cached value
+ *       dequantised first (k = float(acc) * unquant + bias, Intgemm.inl.cc:146-153), then
+ *       Modules.cc:24-86 on those floats. Runs the decoder one launch per stage (the
+ *       persistent decoder has the hoisted order only): for checking, not for speed.
+ * Formats 0 / 1 / 2 give the same floats as each other; format 3 differs from them by
+ * roundings only (<= 2.5e-5 of the context vectors' scale), which can move an arg-max on a
+ * near-tie: see DESIGN 2 for what that means for translate output. */
 int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format);
 /* Sentences per workgroup of the persistent decoder in decode mode 0 (needs the decoder admission,
  * budget > 0): on (default) = a launch uses 8 or 4 sentences per workgroup instead of 16 while the
@@ -409,6 +415,14 @@ int slimt_hip_profile_reset(slimt_hip_ctx *ctx);
  * call (step < 0 disables stamping). */
 int slimt_hip_debug_decode_stamps(slimt_hip_ctx *ctx, int step, uint64_t *out,
                                   size_t n);
+/* Diagnostic: the decoder's cross-attention proper (Modules.cc:24-86 as Attention::forward calls it,
+ * Modules.cc:287-306) of decoder layer `layer` on the caller's projected queries yq [B][D], over
+ * the f32 K/V cache of ctx's current batch (slimt_hip_decode_begin[_from] first): joined [B][D] =
+ * the joined heads before the output projection, attn (nullable) [B][H][S] = the probabilities.
+ * literal = 0: the hoisted order every decoder here runs; 1: the reference's literal sequence
+ * (K/V cache format 3). Tests bound one against the other and both against the checker. */
+int slimt_hip_debug_cross_attention(slimt_hip_ctx *ctx, int layer, int literal, const float *yq,
+                                    float *joined, float *attn);
 /* Diagnostic: break (broken != 0) or restore the hand-over of a shortlist generated inside the
  * encoder launch (slimt_hip_translate*_generated): the waiting workgroups then look for a
  * publication that never comes and give up after `poll_limit` polls (1..2^24; the default 2^24

@@ -27,7 +27,7 @@ SYMBOLS = [
     "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_ctx_set_encode_rows", "slimt_hip_ctx_plan", "slimt_hip_translate", "slimt_hip_translate_device",
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
-    "slimt_hip_debug_decode_stamps", "slimt_hip_debug_kv_formats", "slimt_hip_debug_kv_narrow_limit", "slimt_hip_debug_break_shortlist_handoff",
+    "slimt_hip_debug_decode_stamps", "slimt_hip_debug_kv_formats", "slimt_hip_debug_kv_narrow_limit", "slimt_hip_debug_break_shortlist_handoff", "slimt_hip_debug_cross_attention",
     "slimt_hip_debug_occupancy_trace", "slimt_hip_model_set_decoder_budget",
     "slimt_hip_model_set_kv_cache_policy",
     "slimt_hip_model_set_xcd_affinity", "slimt_hip_model_device",
@@ -65,18 +65,62 @@ def library_path() -> str:
     return _build.LIB_PATH
 
 
+def _elf_soname(path: str):
+    """DT_SONAME of a 64-bit little-endian ELF shared object (None when it has none or is not one)."""
+    import struct
+    try:
+        with open(path, "rb") as f:
+            head = f.read(64)
+            if len(head) < 64 or head[:4] != b"\x7fELF" or head[4] != 2 or head[5] != 1:
+                return None
+            e_shoff, = struct.unpack_from("<Q", head, 0x28)
+            e_shentsize, e_shnum = struct.unpack_from("<HH", head, 0x3A)
+            sections = []
+            for i in range(e_shnum):
+                f.seek(e_shoff + i * e_shentsize)
+                sh = f.read(e_shentsize)
+                sh_type, = struct.unpack_from("<I", sh, 4)
+                sh_offset, sh_size, sh_link = struct.unpack_from("<QQI", sh, 0x18)
+                sections.append((sh_type, sh_offset, sh_size, sh_link))
+            for sh_type, off, size, link in sections:
+                if sh_type != 6:  # SHT_DYNAMIC
+                    continue
+                f.seek(off)
+                dyn = f.read(size)
+                for j in range(0, len(dyn) - 15, 16):
+                    tag, val = struct.unpack_from("<qQ", dyn, j)
+                    if tag == 14:  # DT_SONAME: offset into the linked string table
+                        f.seek(sections[link][1] + val)
+                        return f.read(256).split(b"\0", 1)[0].decode()
+                    if tag == 0:
+                        break
+    except (OSError, struct.error, IndexError, UnicodeDecodeError):
+        return None
+    return None
+
+
+def mapped_hip_runtimes():
+    """Paths of the libamdhip64 images this process has mapped (one, unless something loaded a second runtime)."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    except OSError:
+        return []
+
+
+HIP_RUNTIME_SONAME = "libamdhip64.so.7"  # what libslimt_hip.so NEEDs
+
+
 def _preload_hip_runtime() -> None:
     """One HIP runtime per process, whatever the import order. libslimt_hip.so NEEDs `libamdhip64.so.7` by
     SONAME: the dynamic loader binds that to a copy the process has mapped already (PyTorch imported first: its
     bundled one), else to ROCm's through the RUNPATH. PyTorch's own libraries ask for theirs by FILE, so with
     ROCm's copy mapped first a later `import torch` maps a second runtime next to it (and finds no GPU). When no
-    runtime is mapped yet and an installed PyTorch bundles one, map that one now: a later `import torch` then
-    finds its own file already loaded, and both sides share it. Nothing is imported, no HIP call is made."""
-    try:
-        with open("/proc/self/maps") as f:
-            if any("libamdhip64" in line for line in f):
-                return
-    except OSError:
+    runtime is mapped yet and an installed PyTorch bundles one WITH THAT SONAME (a PyTorch built against another ROCm
+    major would be a second runtime, the very thing this avoids), map that one now: a later `import torch` then finds
+    its own file already loaded, and both sides share it. Nothing is imported, no HIP call is made.
+    SLIMT_HIP_NO_PRELOAD=1 switches this off (processes that never import torch)."""
+    if os.environ.get("SLIMT_HIP_NO_PRELOAD") == "1" or mapped_hip_runtimes():
         return
     import importlib.util
     try:
@@ -85,7 +129,7 @@ def _preload_hip_runtime() -> None:
         spec = None
     for d in (spec.submodule_search_locations or []) if spec else []:
         cand = os.path.join(d, "lib", "libamdhip64.so")
-        if os.path.exists(cand):
+        if os.path.exists(cand) and _elf_soname(cand) == HIP_RUNTIME_SONAME:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
             return
 
@@ -102,6 +146,10 @@ def lib():
             "(there is no CPU fallback)")
     _preload_hip_runtime()
     L = C.CDLL(path)
+    if len(mapped_hip_runtimes()) > 1:  # (someone mapped another copy by file name before or behind us)
+        import warnings
+        warnings.warn("two HIP runtimes are mapped in this process (%s): the GPU may be invisible to one of them"
+                      % ", ".join(mapped_hip_runtimes()), RuntimeWarning, stacklevel=2)
     vp, f32, sz, i32, u32 = C.c_void_p, C.c_float, C.c_size_t, C.c_int, C.c_uint32
     L.slimt_hip_abi_version.restype = i32
     L.slimt_hip_last_error.restype = C.c_char_p
@@ -149,6 +197,7 @@ def lib():
     L.slimt_hip_debug_kv_formats.argtypes = [vp, vp, sz, vp]
     L.slimt_hip_debug_kv_narrow_limit.argtypes = [vp, i32]
     L.slimt_hip_debug_break_shortlist_handoff.argtypes = [vp, i32, u32]
+    L.slimt_hip_debug_cross_attention.argtypes = [vp, i32, i32, vp, vp, vp]
     L.slimt_hip_model_set_decoder_budget.argtypes = [vp, i32]
     L.slimt_hip_model_set_kv_cache_policy.argtypes = [vp, i32]
     L.slimt_hip_model_set_xcd_affinity.argtypes = [vp, i32]
@@ -350,7 +399,8 @@ class Model:
 
     def set_kv_cache_format(self, fmt: int):
         """0 = packed K/V cache where supported, 20 bits per value where a sentence's accumulators fit and 24 elsewhere
-        (default); 1 = always f32; 2 = packed, always 24 bits."""
+        (default); 1 = always f32; 2 = packed, always 24 bits; 3 = f32 and the reference's literal dequantise-then-attend
+        sequence (stage-wise decoder: for checking)."""
         _chk(lib().slimt_hip_model_set_kv_cache_format(self.h, fmt))
 
     def debug_kv_narrow_limit(self, limit: int):
@@ -577,6 +627,15 @@ class Context:
         out = np.zeros(64, dtype=np.uint64)
         _chk(lib().slimt_hip_debug_decode_stamps(self.h, step, _p(out), 64))
         return out
+
+    def debug_cross_attention(self, layer: int, yq, B: int, S: int, heads: int, literal: bool = False):
+        """The decoder's cross-attention proper on projected queries yq [B, D] over the current batch's f32 K/V cache
+        (decode_begin first): (joined heads [B, D], probabilities [B, H, S]); literal = the reference's own sequence."""
+        yq = np.ascontiguousarray(yq, dtype=np.float32)
+        out = np.empty_like(yq)
+        attn = np.empty((B, heads, S), dtype=np.float32)
+        _chk(lib().slimt_hip_debug_cross_attention(self.h, layer, 1 if literal else 0, _p(yq), _p(out), _p(attn)))
+        return out, attn
 
     def debug_break_shortlist_handoff(self, broken: bool, poll_limit: int = 1 << 24):
         """The waiters of an in-launch shortlist look for a publication that never comes (tests: the timeout path)."""

@@ -1271,6 +1271,124 @@ __device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr
       pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
 }
 
+// attention_row24_mid out of line (see attention_row24_cold): the fallback of the narrow form for 33..64-token sentences.
+template <int KV_AUX>
+__device__ __noinline__ void attention_row24_mid_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256, float uv256) {
+  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
+  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
+  r.S = __builtin_amdgcn_readfirstlane(r.S);
+  r.len = __builtin_amdgcn_readfirstlane(r.len);
+  attention_row24_mid<KV_AUX>(r, lane, pbk, pbv, uk256, uv256);
+}
+
+// attention_row24_mid over the narrow form (33..64-token sentences, written by encode_tall_kernel<., 4>): the layouts of
+// attention_row20 (K [head][plane 0..4][S][16 B], V [ceil(S / 8)][plane 0..4][D/4][16 B]), the passes of the 24-bit
+// mid form: lane = key, one head per score pass, the 64-column softmax in the canonical order, V as whole rows.
+template <int KV_AUX>
+__device__ __forceinline__ void attention_row20_mid(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096,
+                                                    float uv4096) {
+  constexpr int D = 256, DH = 32, H = D / DH;
+  const int S = r.S, len = r.len;
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int j = lane;
+  const int jc = j < S ? j : S - 1;
+  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 640));
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 5120));
+  const int koff = j < lenf ? jc * 16 : kPastDescriptor;
+  const int voff = lane * 16;
+  v4i kq[5];
+  auto load_k = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((5 * h + i) * S) * 16, KV_AUX));
+  };
+  load_k(0);
+  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
+    float ck[4];
+    head_constants32(r.qrow, pbk, lane, ck);
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ck[i];
+    }
+  }
+#pragma unroll 1
+  for (int h = 0; h < H; ++h) {
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d0 = h * DH + 8 * i;
+      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
+      const int lo[4] = {kq[4].x, kq[4].y, kq[4].z, kq[4].w};
+      const Lo20 e = expand20(lo[i]);
+      t = __builtin_fmaf(qa.x, unpack20<0>(kq[i], e), t);
+      t = __builtin_fmaf(qa.y, unpack20<1>(kq[i], e), t);
+      t = __builtin_fmaf(qa.z, unpack20<2>(kq[i], e), t);
+      t = __builtin_fmaf(qa.w, unpack20<3>(kq[i], e), t);
+      t = __builtin_fmaf(qb.x, unpack20<4>(kq[i], e), t);
+      t = __builtin_fmaf(qb.y, unpack20<5>(kq[i], e), t);
+      t = __builtin_fmaf(qb.z, unpack20<6>(kq[i], e), t);
+      t = __builtin_fmaf(qb.w, unpack20<7>(kq[i], e), t);
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    load_k(h + 1 < H ? h + 1 : h);  // the next head's keys travel under this head's softmax
+    __builtin_amdgcn_sched_barrier(0);
+    float s = __builtin_fmaf(t, uk4096, r.hsum[8 + h]);
+    if (r.alpha != 1.0f) s = r.alpha * s;
+    s = s + mask;
+    if (j >= S) s = lowest;
+    const float m = wave_max(s);
+    const float e = j < S ? exp_p(s - m) : 0.0f;
+    const float sum = wave_sum(e);
+    const float p = e / sum;  // keys >= S: exactly 0
+    const float ps = wave_sum(p);  // P_h
+    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
+    if (r.align && h == 0 && j < len) r.align[j] = p;
+    r.pbuf[h * 64 + j] = p;
+    if (lane == 0) r.hsum[h] = ps;
+  }
+  v4i vq[2][5];  // V rows in flight: two groups of eight rows
+  auto load_v = [&](v4i(&vv)[5], int g) {  // rows 8 g .. 8 g + 7
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (5 * g + i) * 1024, KV_AUX));
+  };
+  load_v(vq[0], 0);
+  load_v(vq[1], 1);
+  __builtin_amdgcn_sched_barrier(0);
+  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
+  const int ph = (lane >> 3) * 64;
+  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  const float P = r.hsum[lane >> 3];
+  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    v4i(&cur)[5] = vq[g & 1];
+    const int lo[4] = {cur[4].x, cur[4].y, cur[4].z, cur[4].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
+      const Lo20 e = expand20(lo[c]);
+      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
+      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
+      const f2 va0 = {unpack20<0>(cur[c], e), unpack20<1>(cur[c], e)}, vb0 = {unpack20<2>(cur[c], e), unpack20<3>(cur[c], e)};
+      const f2 va1 = {unpack20<4>(cur[c], e), unpack20<5>(cur[c], e)}, vb1 = {unpack20<6>(cur[c], e), unpack20<7>(cur[c], e)};
+      oa = __builtin_elementwise_fma(p0, va0, oa);
+      ob = __builtin_elementwise_fma(p0, vb0, ob);
+      oa = __builtin_elementwise_fma(p1, va1, oa);
+      ob = __builtin_elementwise_fma(p1, vb1, ob);
+    }
+    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
+    if (g + 2 < 8) load_v(vq[g & 1], g + 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float o0 = __builtin_fmaf(oa.x, uv4096, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv4096, pv4.y * P);
+  const float o2 = __builtin_fmaf(ob.x, uv4096, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv4096, pv4.w * P);
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
+}
+
 // Sentences of 65..128 tokens over the packed cache (written by encode_long16_kernel): lane L holds
 // keys L and L + 64 -- one head per score pass, in two half passes of 6 K loads each --, the
 // 128-column softmax in the canonical order (lane L first adds keys L and L + 64, then the 64-lane
@@ -1839,7 +1957,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     kv_wide[rr] = ~0u;
-    if constexpr (KV24 && MID == 0) {
+    if constexpr (KV24 && MID != 2) {
       if (a.kv_fmt && live[rr]) {
         unsigned w = 0;
         for (int l = 0; l < Ld; ++l) w |= (unsigned)(a.kv_fmt[(size_t)l * B + bq[rr]] != 0) << l;
@@ -2074,10 +2192,23 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
               attention_row24_long<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
           } else if constexpr (MID == 1) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
+#ifdef SLIMT_EXP_NO_KV20
             if (NT && kv_streams)
               attention_row24_mid<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_mid<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+#else
+            const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
+            if (!wide) {
+              if (NT && kv_streams)
+                attention_row20_mid<2>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+              else
+                attention_row20_mid<0>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+            } else if (NT && kv_streams)
+              attention_row24_mid_cold<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+            else
+              attention_row24_mid_cold<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+#endif
           } else if constexpr (KV24) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
 #ifdef SLIMT_EXP_NO_KV20  // A/B builds: the kernel as it was before the narrow form (engine.cpp then never records forms)

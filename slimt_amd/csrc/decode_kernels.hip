@@ -488,7 +488,9 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
   if (a.x.ln_scale) rows_layer_norm<1>(x, a.x.ln_scale, a.x.ln_bias, a.eps, D, lane);
   rows_quantize_to_lds<1>(x, a.wq.a_quant, A_lds, lda, wave, D, lane);
   __syncthreads();
-  if (wave < QT) {
+  if (a.q_given) {  // the caller's projected query
+    if (lane < DH) qbuf[wave * DH + lane] = a.q_given[(size_t)bc * D + h * DH + lane];
+  } else if (wave < QT) {
     v4i acc[1] = {v4i{0, 0, 0, 0}};
     bfrag_mma<PF, 1>(bq, A_lds, lda, KS, 0, lr, lg, acc);
     const int col = (h * QT + wave) * 16 + lr;
@@ -509,6 +511,15 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
   // c_h = canonical row sum of q_d * pbK[d] over the head's columns (one per lane; lanes past the head hold +0)
   const float *qrow = qbuf + wave * DH;
   const float ch = wave_sum(lane < DH ? qrow[dc] * a.pbk[h * DH + dc] : 0.0f);
+  const bool lit = a.literal;  // (uniform) the reference's sequence: every cached value dequantised first, k = float(accS) u + pb
+  auto dq4 = [&](float4 v, int i) {
+    if (lit) {
+      const float4 pb4 = *reinterpret_cast<const float4 *>(a.pbk + h * DH + 4 * i);
+      v.x = v.x * a.uk; v.y = v.y * a.uk; v.z = v.z * a.uk; v.w = v.w * a.uk;
+      v.x = v.x + pb4.x; v.y = v.y + pb4.y; v.z = v.z + pb4.z; v.w = v.w + pb4.w;
+    }
+    return v;
+  };
   float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
   for (int i = 0; i < DH / 4; ++i) {
@@ -518,6 +529,7 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
       k4 = k0[i];
     else
       k4 = *reinterpret_cast<const float4 *>(kb + ((size_t)i * S + j0) * 4);
+    k4 = dq4(k4, i);
     s0 = __builtin_fmaf(q4.x, k4.x, s0);
     s0 = __builtin_fmaf(q4.y, k4.y, s0);
     s0 = __builtin_fmaf(q4.z, k4.z, s0);
@@ -527,15 +539,17 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
 #pragma unroll
     for (int i = 0; i < DH / 4; ++i) {
       const float4 q4 = *reinterpret_cast<const float4 *>(qrow + 4 * i);
-      const float4 k4 = *reinterpret_cast<const float4 *>(kb + ((size_t)i * S + j1) * 4);
+      const float4 k4 = dq4(*reinterpret_cast<const float4 *>(kb + ((size_t)i * S + j1) * 4), i);
       s1 = __builtin_fmaf(q4.x, k4.x, s1);
       s1 = __builtin_fmaf(q4.y, k4.y, s1);
       s1 = __builtin_fmaf(q4.z, k4.z, s1);
       s1 = __builtin_fmaf(q4.w, k4.w, s1);
     }
   }
-  s0 = __builtin_fmaf(s0, a.uk, ch);
-  s1 = __builtin_fmaf(s1, a.uk, ch);
+  if (!lit) {
+    s0 = __builtin_fmaf(s0, a.uk, ch);
+    s1 = __builtin_fmaf(s1, a.uk, ch);
+  }
   if (a.alpha != 1.0f) {
     s0 = a.alpha * s0;
     s1 = a.alpha * s1;
@@ -567,12 +581,20 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
     }
   }
   // 5. out[d] = fmaf(w_d, uV, pbV[d] * P_h), w_d = key-ascending fmaf chain of p[j] * float(accV[j][d])
+  const float pbv_d = a.pbv[h * DH + dc];
+  auto dqv = [&](float v) {  // literal: v = float(accS) u + pb per cached value
+    if (lit) {
+      v = v * a.uv;
+      v = v + pbv_d;
+    }
+    return v;
+  };
   float o = 0.0f;
 #pragma unroll
   for (int j = 0; j < VPF; ++j) {
     if (j < S) {
       const float pj = __shfl(p0, j, 64);
-      o = __builtin_fmaf(pj, v0[j], o);
+      o = __builtin_fmaf(pj, dqv(v0[j]), o);
     }
   }
   if constexpr (VPF < 16) {
@@ -583,7 +605,7 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
     for (int j = VPF; j < 16; ++j) {
       if (j < S) {
         const float pj = __shfl(p0, j, 64);
-        o = __builtin_fmaf(pj, vv[j - VPF], o);
+        o = __builtin_fmaf(pj, dqv(vv[j - VPF]), o);
       }
     }
   }
@@ -596,11 +618,11 @@ __global__ __launch_bounds__(1024) void dqattn_kernel(DQAttnArgs a) {
       const int jj = jb + j;
       if (jj < S) {
         const float pj = __shfl(jj < 64 ? p0 : p1, jj & 63, 64);
-        o = __builtin_fmaf(pj, vv[j], o);
+        o = __builtin_fmaf(pj, dqv(vv[j]), o);
       }
     }
   }
-  o = __builtin_fmaf(o, a.uv, a.pbv[h * DH + dc] * P);
+  if (!lit) o = __builtin_fmaf(o, a.uv, pbv_d * P);
   if (lane < DH) {
     if (a.out_i8)
       a.out_i8[(size_t)b * D + h * DH + lane] = (int8_t)quantize1(o, a.a_quant_out);

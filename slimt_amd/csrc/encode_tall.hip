@@ -789,10 +789,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   // The narrow form is tried first; an accumulator that does not fit (seen by its lane while the tile is staged) raises
   // kv_wide_flag, every thread reads it behind the staging barrier, and the layer's K and V are produced again in the
   // 24-bit form over whatever the narrow attempt wrote. Both forms hold the same integers.
-  const bool try_narrow = NKT == 2 && a.kv24 && a.kv_fmt != nullptr;
+  const bool try_narrow = a.kv24 && a.kv_fmt != nullptr;
   for (int l = 0; l < a.Ld; ++l) {
     bool wide = !try_narrow;
-    for (int attempt = 0; attempt < (NKT == 2 ? 2 : 1); ++attempt) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
       bool redo = false;
       for (int p = 0; p < 2; ++p) {
         SLIMT_TPHASE_LANE;
@@ -946,9 +946,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       if (!redo) break;
       wide = true;
     }
-    if constexpr (NKT == 2) {  // (33..64-token sentences: always the 24-bit form, nothing recorded)
-      if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
-    }
+    if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
   }
   if (gen_here) {
     // the shortlist of this launch: wait for its publisher (running since before this workgroup started, and

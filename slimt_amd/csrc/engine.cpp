@@ -46,6 +46,10 @@ static std::atomic<bool> g_hip_called{false};
     if (rc_) return rc_;   \
   } while (0)
 
+// The persistent decoder runs the hoisted cross-attention order over a cache of accumulators; the reference's literal
+// sequence (K/V cache format 3) exists in the stage-wise attention kernel only (decode_kernels.hip, DQAttnArgs::literal)
+static bool fused_decoder_allowed(const slimt_hip_ctx *c) { return c->decode_mode != 1 && c->model->kv_format != 3; }
+
 hipError_t DevBuf::reserve(size_t n) {
   if (n <= bytes && p) return hipSuccess;
   g_hip_called.store(true, std::memory_order_relaxed);
@@ -729,9 +733,49 @@ extern "C" int slimt_hip_model_set_adaptive_decoder_rows(slimt_hip_model *model,
 
 extern "C" int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int format) {
   if (!model) return fail(-1, "model is NULL");
-  if (format < 0 || format > 2) return fail(-1, "K/V cache format %d not in 0..2", format);
+  if (format < 0 || format > 3) return fail(-1, "K/V cache format %d not in 0..3", format);
   std::lock_guard<std::mutex> lock(model->gate_mu);
   model->kv_format = format;
+  return 0;
+}
+
+extern "C" int slimt_hip_debug_cross_attention(slimt_hip_ctx *ctx, int layer, int literal, const float *yq, float *joined,
+                                               float *attn) {
+  if (!ctx || !yq || !joined) return fail(-1, "null argument");
+  const slimt_hip_model *m = ctx->model;
+  if (layer < 0 || layer >= m->Ld) return fail(-1, "decoder layer %d not in 0..%d", layer, m->Ld - 1);
+  if (!ctx->decode_ready || !ctx->kv_ready)
+    return fail(-1, "no f32 K/V cache: call slimt_hip_decode_begin (or _begin_from) for the batch first");
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t st = ctx->stream;
+  const int B = ctx->B, S = ctx->S, D = m->D, M = B * S;
+  const DecLayerW &L = m->dec[(size_t)layer];
+  HIPCHK(ctx->dout.reserve((size_t)B * D * 4));
+  HIPCHK(ctx->dh.reserve((size_t)B * D * 4));
+  HIPCHK(ctx->attn_dbg.reserve((size_t)B * m->H * S * 4));
+  HIPCHK(hipMemcpyAsync(ctx->dh.p, yq, (size_t)B * D * 4, hipMemcpyHostToDevice, st));
+  DQAttnArgs a;
+  a.B = B; a.D = D; a.H = m->H; a.S = S;
+  a.x.x = ctx->dh.as<float>();  // (unused rows: the queries are given)
+  a.wq = L.attn.q.w;
+  a.q_given = ctx->dh.as<float>();
+  a.literal = literal != 0;
+  const float *kv = ctx->kv.as<float>();
+  a.k = kv + (size_t)(2 * layer) * M * D;
+  a.v = kv + (size_t)(2 * layer + 1) * M * D;
+  a.ldv = D;
+  a.uk = L.attn.k.w.u;
+  a.uv = L.attn.v.w.u;
+  a.pbk = L.attn.k.w.pb;
+  a.pbv = L.attn.v.w.pb;
+  a.lengths = ctx->lengths.as<uint32_t>();
+  a.alpha = 1.0f / std::sqrt(static_cast<float>(D / m->H));
+  a.out_f32 = ctx->dout.as<float>();
+  a.attn = ctx->attn_dbg.as<float>();
+  HIPCHK(launch_dqattn(a, st));
+  HIPCHK(hipMemcpyAsync(joined, ctx->dout.p, (size_t)B * D * 4, hipMemcpyDeviceToHost, st));
+  if (attn) HIPCHK(hipMemcpyAsync(attn, ctx->attn_dbg.p, (size_t)B * m->H * S * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
   return 0;
 }
 
@@ -998,7 +1042,7 @@ extern "C" int slimt_hip_ctx_plan(const slimt_hip_ctx *ctx, size_t S, int *encod
                                   int *decoder_fused) {
   if (!ctx) return fail(-1, "ctx is NULL");
   const slimt_hip_model *m = ctx->model;
-  const bool fused = ctx->decode_mode != 1;
+  const bool fused = fused_decoder_allowed(ctx);
   if (encoder_fused)
     *encoder_fused = fused && (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                                long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
@@ -1213,7 +1257,8 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     if (kv24 && (size_t)M * D * 3 >= (1u << 31)) return fail(-1, "packed K/V cache: %d rows exceed a 2 GB plane", M);
     // the narrow (20-bit) form where the writer and the reader have it -- D = 256 or 512, S <= 32 -- and where a
     // sentence's V block (groups of eight keys) fits the slot of its 24-bit form (groups of four): not S = 1..4, 9..12
-    c->kv_fmt_valid = kv24 && m->kv_format == 0 && (D == 256 || D == 512) && S <= 32 &&
+    // (... and S = 33..64 at D = 256: the 64-row encoder with one sentence per workgroup, attention_row20_mid)
+    c->kv_fmt_valid = kv24 && m->kv_format == 0 && ((D == 256 && S <= 64) || (D == 512 && S <= 32)) &&
                       ((S + 7) / 8) * 5120 <= ((S + 3) / 4) * 3072;
 #ifdef SLIMT_EXP_NO_KV20  // A/B builds (decode_fused.hip)
     c->kv_fmt_valid = false;
@@ -1474,6 +1519,7 @@ int decoder_layers(slimt_hip_ctx *c, float *d_align, int Tmax, const uint32_t *d
     a.pbv = L.attn.v.w.pb;
     a.lengths = c->lengths.as<uint32_t>();
     a.alpha = 1.0f / std::sqrt(static_cast<float>(D / m->H));
+    a.literal = m->kv_format == 3;
     a.out_i8 = c->datt8.as<int8_t>();
     a.a_quant_out = L.attn.o.w.a_quant;
     if (l + 1 == m->Ld) {  // alignment = last layer (Transformer.cc:165-174)
@@ -1555,7 +1601,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   // Model.cc:144-161: the first step is unconditional (one token is always recorded), the
   // loop then runs while i < (size_t)(limit_factor * S): at least one output column
   const size_t Tmax = std::max<size_t>(1, (size_t)(limit_factor * (float)S));
-  const bool fused_dec = c->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld);
+  const bool fused_dec = fused_decoder_allowed(c) && fused_decode_supported(m->D, m->F, m->H, m->Ld);
   const bool lean = fused_dec && (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                                   long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
   // packed 24-bit K/V cache: fused encoder -> fused decoder, D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32
@@ -1629,7 +1675,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   const AffineW &out = output_layer(c);
   ds.pb0 = out.w.pb;
   ds.u_out = out.w.u;
-  if (c->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld)) {
+  if (fused_decoder_allowed(c) && fused_decode_supported(m->D, m->F, m->H, m->Ld)) {
     // the whole greedy loop in one persistent launch (decode_fused.hip)
     FusedDecodeArgs f;
     f.B = (int)B; f.S = (int)S; f.Ld = m->Ld;
@@ -1952,7 +1998,7 @@ int translate_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const uint3
   const size_t n_hint = *hint;
   void *hint_dev = nullptr;
   if (hipHostGetDevicePointer(&hint_dev, hint, 0) == hipSuccess) a.n_out_host = static_cast<uint32_t *>(hint_dev);
-  const bool lean = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
+  const bool lean = fused_decoder_allowed(ctx) && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
                     (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                      long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
   // With the 64-row encoder the generator runs INSIDE the encoder launch, by the workgroup that starts first
@@ -2024,7 +2070,7 @@ int translate_host(slimt_hip_ctx *ctx, const uint32_t *src_ids, const uint32_t *
   // -- no copy on either side. Copies are what a host pipeline stalls on: an asynchronous copy
   // of stream A sits in a DMA queue behind copies that wait for stream B's kernels (measured with the
   // Service: 12 contexts of equal batches ran strictly one after the other, 3.7 M tok/s).
-  const bool persistent = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
+  const bool persistent = fused_decoder_allowed(ctx) && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
                           (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                            long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
   hclk.lap(0);
@@ -2505,7 +2551,7 @@ int translate_host_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const 
   HIPCHK(hipSetDevice(m->device));
   hipStream_t st = ctx->stream;
   const size_t Tmax = std::max<size_t>(1, (size_t)(limit_factor * (float)S));
-  const bool persistent = ctx->decode_mode != 1 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
+  const bool persistent = fused_decoder_allowed(ctx) && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
                           (fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S) ||
                            long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S));
   if (!wait && persistent) {  // pinned buffers: the kernels read and write host memory themselves (translate_host)

@@ -245,6 +245,12 @@ struct DQAttnArgs {
   const float *pbk = nullptr, *pbv = nullptr;
   const uint32_t *lengths = nullptr;
   float alpha = 0.f, eps = 1e-6f;
+  // q_given (nullable [B][D]): the projected queries themselves -- the LayerNorm and the Q projection are skipped
+  // (slimt_hip_debug_cross_attention: the attention proper on a caller's query, against the checker's)
+  const float *q_given = nullptr;
+  // literal: the reference's own float sequence (Modules.cc:24-86 on K, V dequantised element by element,
+  // Intgemm.inl.cc:146-153: k = float(accS) u + pb) instead of the hoisted order -- same cache, u and pb applied per value
+  bool literal = false;
   int8_t *out_i8 = nullptr;  // joined heads, quantised for the O projection
   float a_quant_out = 0.f;
   float *out_f32 = nullptr;  // optional f32 copy

@@ -166,7 +166,12 @@ class _Hip:
     def __init__(self):
         import ctypes as C
         self.C = C
-        self.rt = C.CDLL("libamdhip64.so")
+        # the runtime this process has mapped already (the product library's): asking the loader for "libamdhip64.so" by
+        # name would map ROCm's copy NEXT to a PyTorch-bundled one
+        from slimt_amd import capi
+        capi.lib()
+        mapped = capi.mapped_hip_runtimes()
+        self.rt = C.CDLL(mapped[0] if mapped else "libamdhip64.so")
         self.rt.hipMalloc.argtypes = [C.c_void_p, C.c_size_t]
         self.rt.hipFree.argtypes = [C.c_void_p]
         self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -222,3 +227,38 @@ def test_gpu_translate_with_generated_shortlist_on_device(hip, oracle, synth_mod
         for b in range(B):
             assert np.array_equal(out[b, : ln[b]], w_out[b, : w_ln[b]]), b
     dev.free(); gen.close(); ctx.close(); gm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,rows", [("tiny11", 64), ("tiny11", 32), ("base", 0)])
+def test_gpu_shortlist_never_published_fails_the_batch(hip, oracle, synth_models, preset, rows):
+    """a workgroup that waits for the shortlist generated inside its encoder launch used to give up after its
+    bounded poll and pack the output layer from ids and a count nobody had published -- translations from a stale or
+    partial shortlist, silently. Now a waiter that gives up packs nothing and raises the context's error word: the call
+    FAILS. Reached here with a publication the waiters cannot see (slimt_hip_debug_break_shortlist_handoff) and a short
+    poll limit, in each of the three encoders; afterwards the same context translates correctly again."""
+    m = synth_models(preset, 6.0)
+    blob = synth.make_lexical_shortlist(m.V, m.V, frequent=64, best=8, seed=21)
+    B, S = 40, 12
+    ids, lens = synth.make_batch(m.V, B, S, seed=33, ragged=True)
+    gen = hip.ShortlistGenerator(blob, m.V, m.V)
+    want_sl = oracle.OracleShortlist(blob, m.V, m.V).generate(ids, lens)
+    oracle.set_mode(oracle.PORTABLE)
+    w_out, w_ln, _, _ = oracle.OracleModel(m).translate(ids, lens, want_sl, 1.5, 0)
+    oracle.set_mode(oracle.FAITHFUL)
+    gm = hip.Model(m)
+    ctx = hip.Context(gm, B, S)
+    try:
+        if rows:
+            ctx.set_encode_rows(rows)
+        out, ln, _ = ctx.translate_generated(gen, ids, lens)
+        assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out)
+        ctx.debug_break_shortlist_handoff(True, 1 << 10)
+        with pytest.raises(hip.SlimtHipError, match="never published"):
+            ctx.translate_generated(gen, ids, lens)
+        ctx.debug_break_shortlist_handoff(False)
+        for _ in range(2):  # the error does not stick, and the context is usable
+            out, ln, _ = ctx.translate_generated(gen, ids, lens)
+            assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out)
+    finally:
+        ctx.close(); gm.close(); gen.close()

@@ -21,8 +21,11 @@ exe = B.build_host()
 with tempfile.TemporaryDirectory() as d:
     mb, cb, ob = (os.path.join(d, n) for n in ("model.bin", "case.bin", "out.bin"))
     open(mb, "wb").write(synth.write_bin(m))
-    lo = int(os.environ.get("SLIMT_SERVICE_MIN_LEN", "8"))  # sentence lengths uniform in [lo, 32]
-    lens = r.integers(lo, 33, size=n_sent)
+    # sentence lengths uniform in [lo, hi]: 8..32 by default; SLIMT_SERVICE_MAX_LEN=64 = SURVEY 8(d)'s SECONDARY workload
+    # (lengths ~ U{8..64}; the Service's queue cuts them into batches by the reference's rule, Batcher.cc:95-120: sentences by
+    # ascending length while (rows + 1) * longest <= max_words, every row padded to the batch's longest)
+    lo, hi = int(os.environ.get("SLIMT_SERVICE_MIN_LEN", "8")), int(os.environ.get("SLIMT_SERVICE_MAX_LEN", "32"))
+    lens = r.integers(lo, hi + 1, size=n_sent)
     per_req = int(os.environ.get("SLIMT_SERVICE_REQUEST", "512"))  # sentences per translate() call
     with open(cb, "wb") as f:
         f.write(struct.pack("<7If", m.enc_layers, m.dec_layers, m.H, max_words, 128, workers, -(-n_sent // per_req), 1.5))
@@ -51,7 +54,7 @@ with tempfile.TemporaryDirectory() as d:
     ms = float(re.search(r"async-warm: .* translated in ([0-9.]+) ms", res.stderr).group(1))
     toks = int(re.search(r"async-warm-tokens: (\d+)", res.stderr).group(1))  # the warm, timed pass: clients x rounds
 print(json.dumps({"workload": f"Service, tiny11 {'lexical shortlist generated per batch on the device' if lexical else 'shortlist ' + str(n_sl) if n_sl else 'full vocabulary'}, {n_sent} ragged "
-                              f"sentences (8..32 tokens), max_words={max_words}, workers={workers} x 2 contexts, "
+                              f"sentences ({lo}..{hi} tokens), max_words={max_words}, workers={workers} x 2 contexts, "
                               f"pinned host buffers{' + alignments' if align else ''}{' (one block per sentence)' if flat else ''}",
                   "target_tokens_per_s": toks / ms * 1e3,
                   "ms": ms, "ms_first_pass_with_worker_startup": ms_cold, "target_tokens": toks,

@@ -53,7 +53,8 @@ fi
     "--forward-steps 0 --batch 512 --workers 12" "--forward-steps 0 --batch 128 --src-len 64" "--forward-steps 0 --batch 64 --src-len 96" \
     "--forward-steps 0 --batch 64 --src-len 128" "--forward-steps 0 --ragged" "--forward-steps 0 --preset base" \
     "--total-sentences 4096 --batch 512 --steps 10" "--total-sentences 4096 --batch 256 --steps 10" \
-    "--forward-steps 0 --batch 4096 --workers 1 --sustained-steps 0"
+    "--forward-steps 0 --batch 4096 --workers 1 --sustained-steps 0" \
+    "--forward-steps 0 --kv-format 2" "--forward-steps 0 --preset base --kv-format 2" "--forward-steps 0 --batch 512 --shortlist 0 --decode-mode 6"
 } > gpurun_out/${TAG}_configs.txt 2>&1
 cat gpurun_out/${TAG}_configs.txt
 SLIMT_BENCH_REHEARSAL=1 timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 2 --workers 8 --no-cpu-baseline --sustained-steps 0 --forward-steps 0 > gpurun_out/${TAG}_rehearsal_2ranks_on_1gpu.json 2> gpurun_out/${TAG}_rehearsal.err
@@ -63,6 +64,10 @@ for cfg in "10 32768 4096 0" "10 32768 4096 1" "10 32768 4096 flat" "10 32768 le
   timeout -k 10 200 python tools/async_bench.py $cfg >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err || { echo "service bench $cfg failed"; exit 1; }
 done
 SLIMT_SERVICE_REPLICAS=2 timeout -k 10 200 python tools/async_bench.py 5 32768 4096 1 >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err
+# SURVEY 8(d)'s secondary workload: lengths ~ U{8..64}, cut into batches by the reference's batcher rule (the Service's queue)
+for cfg in "10 32768 4096 0" "10 32768 4096 1"; do
+  SLIMT_SERVICE_MAX_LEN=64 timeout -k 10 250 python tools/async_bench.py $cfg >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err || { echo "secondary workload $cfg failed"; exit 1; }
+done
 python - gpurun_out/${TAG}_service_bench.jsonl <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
