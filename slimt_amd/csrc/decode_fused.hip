@@ -1543,6 +1543,163 @@ __device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_pt
       pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
 }
 
+// attention_row24_long out of line (see attention_row24_cold): the fallback of the narrow form for 65..128-token sentences.
+template <int KV_AUX>
+__device__ __noinline__ void attention_row24_long_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256, float uv256) {
+  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
+  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
+  attention_row24_long<KV_AUX>(r, lane, pbk, pbv, uk256, uv256);
+}
+
+// attention_row24_long over the narrow form (65..128-token sentences, written by encode_long16_kernel): the layouts of
+// attention_row20, the passes of the 24-bit long form -- lane L holds keys L and L + 64, two K buffers a half pass
+// ahead, the canonical 128-column softmax, V as whole rows in groups of eight keys, groups past the sentence skipped.
+template <int KV_AUX>
+__device__ __forceinline__ void attention_row20_long(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096,
+                                                     float uv4096) {
+  constexpr int D = 256, DH = 32, H = D / DH;
+  const int S = __builtin_amdgcn_readfirstlane(r.S), len = __builtin_amdgcn_readfirstlane(r.len);
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int j0 = lane, j1 = lane + 64;
+  const float mask0 = (1.0f - (j0 < len ? 1.0f : 0.0f)) * minus_inf;
+  const float mask1 = (1.0f - (j1 < len ? 1.0f : 0.0f)) * minus_inf;
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 640));
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((lenf + 7) >> 3) * 5120));
+  const int koff0 = j0 < lenf ? j0 * 16 : kPastDescriptor;  // [head][plane 0..4][S][16 B]
+  const int koff1 = j1 < lenf ? j1 * 16 : kPastDescriptor;
+  const int voff = lane * 16;                               // [S/8][plane 0..4][D/4][16 B]
+  v4i ka[5], kb[5];
+  auto load_k = [&](v4i(&kq)[5], int h, int koff) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((5 * h + i) * S) * 16, KV_AUX));
+  };
+  auto score = [&](const v4i(&kq)[5], int h) -> float {  // this lane's key against head h: the ascending-column fmaf chain t_j
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d0 = h * DH + 8 * i;
+      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
+      const int lo[4] = {kq[4].x, kq[4].y, kq[4].z, kq[4].w};
+      const Lo20 e = expand20(lo[i]);
+      t = __builtin_fmaf(qa.x, unpack20<0>(kq[i], e), t);
+      t = __builtin_fmaf(qa.y, unpack20<1>(kq[i], e), t);
+      t = __builtin_fmaf(qa.z, unpack20<2>(kq[i], e), t);
+      t = __builtin_fmaf(qa.w, unpack20<3>(kq[i], e), t);
+      t = __builtin_fmaf(qb.x, unpack20<4>(kq[i], e), t);
+      t = __builtin_fmaf(qb.y, unpack20<5>(kq[i], e), t);
+      t = __builtin_fmaf(qb.z, unpack20<6>(kq[i], e), t);
+      t = __builtin_fmaf(qb.w, unpack20<7>(kq[i], e), t);
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    return t;
+  };
+  load_k(ka, 0, koff0);
+  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
+    float ck[4];
+    head_constants32(r.qrow, pbk, lane, ck);
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ck[i];
+    }
+  }
+  auto head = [&](int h, bool last) {
+    load_k(kb, h, koff1);
+    __builtin_amdgcn_sched_barrier(0);
+    float s0 = score(ka, h);
+    if (!last) load_k(ka, h + 1, koff0);  // (the last head requests nothing it would have to wait out again)
+    __builtin_amdgcn_sched_barrier(0);
+    float s1 = score(kb, h);
+    const float ch = r.hsum[8 + h];
+    s0 = __builtin_fmaf(s0, uk4096, ch);
+    s1 = __builtin_fmaf(s1, uk4096, ch);
+    if (r.alpha != 1.0f) {
+      s0 = r.alpha * s0;
+      s1 = r.alpha * s1;
+    }
+    s0 = s0 + mask0;
+    s1 = s1 + mask1;
+    if (j0 >= S) s0 = lowest;
+    if (j1 >= S) s1 = lowest;
+    const float m = wave_max(fmaxf(s0, s1));
+    const float e0 = j0 < S ? exp_p(s0 - m) : 0.0f;
+    const float e1 = j1 < S ? exp_p(s1 - m) : 0.0f;
+    const float sum = wave_sum(e0 + e1);
+    const float p0 = e0 / sum, p1 = e1 / sum;  // keys >= S: exactly 0
+    r.pbuf[h * 128 + j0] = p0;
+    r.pbuf[h * 128 + j1] = p1;
+    const float ps = wave_sum(p0 + p1);  // P_h: lane L adds keys L and L + 64, then the butterfly
+    if (lane == 0) r.hsum[h] = ps;
+  };
+#pragma unroll 1
+  for (int h = 0; h < H - 1; ++h) head(h, false);
+  head(H - 1, true);
+  constexpr int NV = 3;  // V key groups (eight rows, five planes each) in flight
+  v4i vq[NV][5];
+  auto load_v = [&](v4i(&vv)[5], int g) {  // rows 8 g .. 8 g + 7 (past the descriptor: zeros)
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (5 * g + i) * 1024, KV_AUX));
+  };
+  if (r.align) {  // head 0 over the sentence's own keys (update_alignment, Model.cc:84-108)
+    if (j0 < len) r.align[j0] = r.pbuf[j0];
+    if (j1 < len) r.align[j1] = r.pbuf[j1];
+  }
+  if (r.attn) {
+    for (int h = 0; h < H; ++h) {
+      if (j0 < S) r.attn[(size_t)h * S + j0] = r.pbuf[h * 128 + j0];
+      if (j1 < S) r.attn[(size_t)h * S + j1] = r.pbuf[h * 128 + j1];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    load_v(vq[k], k);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
+  const int ph = (lane >> 3) * 128;
+  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  const float P = r.hsum[lane >> 3];
+  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
+  const int ng = (lenf + 7) >> 3;  // key groups that hold a key with a non-zero weight
+  const int nkey = 8 * ng;         // (a group's tail past the sentence, inside the head's 128 slots: p == 0 there only up to S)
+  auto group = [&](const v4i(&cur)[5], int g) {
+    if (g >= ng) return;  // (uniform) past the sentence: pbuf holds the next head's probabilities there
+    const int lo[4] = {cur[4].x, cur[4].y, cur[4].z, cur[4].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
+      const Lo20 e = expand20(lo[c]);
+      // keys past the head's 128 probability slots (S = 121..128 never reach them: 8 g + 7 <= 127)
+      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
+      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
+      const f2 va0 = {unpack20<0>(cur[c], e), unpack20<1>(cur[c], e)}, vb0 = {unpack20<2>(cur[c], e), unpack20<3>(cur[c], e)};
+      const f2 va1 = {unpack20<4>(cur[c], e), unpack20<5>(cur[c], e)}, vb1 = {unpack20<6>(cur[c], e), unpack20<7>(cur[c], e)};
+      oa = __builtin_elementwise_fma(p0, va0, oa);
+      ob = __builtin_elementwise_fma(p0, vb0, ob);
+      oa = __builtin_elementwise_fma(p1, va1, oa);
+      ob = __builtin_elementwise_fma(p1, vb1, ob);
+    }
+    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
+  };
+  (void)nkey;
+#pragma unroll 1
+  for (int g = 0; g < ng; g += NV) {  // (groups past ng inside the last round are skipped; their rows: zeros)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      group(vq[k], g + k);
+      load_v(vq[k], g + k + NV);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const float o0 = __builtin_fmaf(oa.x, uv4096, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv4096, pv4.y * P);
+  const float o2 = __builtin_fmaf(ob.x, uv4096, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv4096, pv4.w * P);
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
+}
+
 // The same for D = 512, d_head 64 ("base"). At K = 512 the shifted accumulator needs 25 bits, so
 // the cache holds the SIGNED one (|acc| <= 127 * 128 * 512 < 2^23) and the column's 127 colsum term
 // comes back here: c127 = float(127 colsum * 256) is exact, and so is float(acc * 256) + c127
@@ -1957,7 +2114,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     kv_wide[rr] = ~0u;
-    if constexpr (KV24 && MID != 2) {
+    if constexpr (KV24) {
       if (a.kv_fmt && live[rr]) {
         unsigned w = 0;
         for (int l = 0; l < Ld; ++l) w |= (unsigned)(a.kv_fmt[(size_t)l * B + bq[rr]] != 0) << l;
@@ -2186,10 +2343,23 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #endif
           } else if constexpr (MID == 2) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
+#ifdef SLIMT_EXP_NO_KV20
             if (NT && kv_streams)
               attention_row24_long<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_long<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+#else
+            const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
+            if (!wide) {
+              if (NT && kv_streams)
+                attention_row20_long<2>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+              else
+                attention_row20_long<0>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+            } else if (NT && kv_streams)
+              attention_row24_long_cold<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+            else
+              attention_row24_long_cold<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
+#endif
           } else if constexpr (MID == 1) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
 #ifdef SLIMT_EXP_NO_KV20

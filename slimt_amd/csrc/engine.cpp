@@ -1341,6 +1341,17 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     f.alpha = 1.0f / std::sqrt(static_cast<float>(m->D / m->H));
     f.kv = c->kv.as<float>();
     f.kv24 = kv24;
+    // (the narrow form of the packed cache: the first path above has the note; here every S up to 128)
+    c->kv_fmt_valid = kv24 && m->kv_format == 0 && D == 256 && ((S + 7) / 8) * 5120 <= ((S + 3) / 4) * 3072;
+#ifdef SLIMT_EXP_NO_KV20
+    c->kv_fmt_valid = false;
+#endif
+    if (c->kv_fmt_valid) {
+      HIPCHK(c->kv_fmt.reserve((size_t)m->Ld * c->max_B));
+      f.kv_fmt = c->kv_fmt.as<unsigned char>();
+      f.kv_narrow_limit = std::min(m->kv_narrow_limit, 1 << 19);
+      c->kv_fmt_B = B;
+    }
     f.enc_out = c->x0.as<float>();
     if (pack) {
       f.pack = *pack;

@@ -62,6 +62,15 @@ Model::Model(const Config &config, const void *model_bin, size_t size, const voi
 }
 
 Model::~Model() {
+  {  // the contexts threads still keep for this model (host/Transformer.cc): gone before the weights they point into
+    std::lock_guard<std::mutex> lock(thread_contexts_->mutex);
+    for (ThreadContexts::Entry *e : thread_contexts_->entries) {
+      slimt_hip_ctx_destroy(e->ctx);
+      e->ctx = nullptr;
+    }
+    thread_contexts_->entries.clear();
+    thread_contexts_->model_alive = false;
+  }
   for (Lease &l : idle_) slimt_hip_ctx_destroy(l.ctx);
   if (generator_) slimt_hip_shortlist_destroy(generator_);
   if (owned_) slimt_hip_model_destroy(model_);

@@ -61,6 +61,20 @@ class Input {
   Words words_;
 };
 
+// Device contexts that threads keep for a Model between calls (the class-level mirror: Encoder::forward / Decoder::step
+// have no "end of sequence" call, so the workspace of a sequence lives with the thread: host/Transformer.cc). A context
+// points into the model, so the model and those threads share this registry: whichever goes first -- the Model or a
+// thread -- destroys the context, under the registry's lock, and the other finds it gone. Keyed by the registry itself,
+// never by a Model's address (a later Model at the same address is another registry).
+struct ThreadContexts {
+  struct Entry {
+    slimt_hip_ctx *ctx = nullptr;
+  };
+  std::mutex mutex;
+  bool model_alive = true;
+  std::vector<Entry *> entries;  // every thread's entry for this model (owned by the thread)
+};
+
 class Model {
  public:
   struct Config {  // slimt/Model.hh:33-51 (tiny preset defaults, Model.cc:206-231)
@@ -97,6 +111,8 @@ class Model {
   Histories forward(const Input &input) const;
   // contexts forward() has built so far (at most the largest number of concurrent callers)
   size_t contexts_built() const;
+  // the per-thread contexts of the class-level mirror (host/Transformer.cc); destroyed with the Model at the latest
+  const std::shared_ptr<ThreadContexts> &thread_contexts() const { return thread_contexts_; }
 
  private:
   struct Lease {  // a pooled context and the batch sizes its workspace holds
@@ -110,6 +126,7 @@ class Model {
   mutable std::mutex pool_mu_;
   mutable std::vector<Lease> idle_;
   mutable size_t built_ = 0;
+  std::shared_ptr<ThreadContexts> thread_contexts_ = std::make_shared<ThreadContexts>();
 };
 
 class Worker {

@@ -1,7 +1,10 @@
 #include "Transformer.hh"
 
+#include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <memory>
+#include <mutex>
 #include <cstring>
 #include <stdexcept>
 
@@ -15,28 +18,53 @@ namespace {
   throw std::runtime_error(std::string(what) + ": " + slimt_hip_last_error());
 }
 
-// The calling thread's device workspace for one model: created on first use, regrown
-// when a larger batch arrives. Remembers which encoder output its K/V cache belongs to.
+// The calling thread's device workspace for one model: created on first use, regrown when a larger batch arrives.
+// Remembers which encoder output its K/V cache belongs to. Its context points into the model, so it is registered
+// with the model (Model.hh, ThreadContexts): the Model destroys it when it goes first, the thread when it exits first --
+// a thread that outlives its Model used to destroy a context of freed weights, and a new Model at the same address
+// would have inherited the old one's workspace (the same flaw as the engine hooks' per-thread cache).
 struct Workspace {
-  const Model *model = nullptr;
-  slimt_hip_ctx *ctx = nullptr;
+  std::shared_ptr<ThreadContexts> registry;  // identifies the model (never its address)
+  ThreadContexts::Entry entry;               // .ctx: guarded by registry->mutex against the Model's destructor
   size_t max_B = 0, max_S = 0;
   const void *kv_of = nullptr;  // encoder_out.data() of the sequence being decoded
   size_t kv_B = 0, kv_S = 0, kv_n_shortlist = 0;
-  ~Workspace() { slimt_hip_ctx_destroy(ctx); }
+  slimt_hip_ctx *&ctx = entry.ctx;
+  ~Workspace() {
+    if (!registry) return;
+    std::lock_guard<std::mutex> lock(registry->mutex);
+    if (registry->model_alive) {  // (else the Model has destroyed the context already)
+      auto &v = registry->entries;
+      v.erase(std::remove(v.begin(), v.end(), &entry), v.end());
+      slimt_hip_ctx_destroy(entry.ctx);
+    }
+    entry.ctx = nullptr;
+  }
 };
 
 Workspace &workspace(const Model &model, size_t B, size_t S) {
   thread_local std::vector<std::unique_ptr<Workspace>> all;
+  const std::shared_ptr<ThreadContexts> &registry = model.thread_contexts();
   Workspace *w = nullptr;
-  for (auto &p : all)
-    if (p->model == &model) w = p.get();
+  for (size_t i = 0; i < all.size();) {
+    if (all[i]->registry == registry) {
+      w = all[i].get();
+      ++i;
+    } else if (!all[i]->registry->model_alive) {  // (a plain read: set once, under the lock, never cleared)
+      all.erase(all.begin() + static_cast<std::ptrdiff_t>(i));  // that model is gone: drop its (empty) workspace
+    } else {
+      ++i;
+    }
+  }
   if (!w) {
     all.push_back(std::make_unique<Workspace>());
     w = all.back().get();
-    w->model = &model;
+    w->registry = registry;
+    std::lock_guard<std::mutex> lock(registry->mutex);
+    registry->entries.push_back(&w->entry);
   }
   if (!w->ctx || B > w->max_B || S > w->max_S) {
+    std::lock_guard<std::mutex> lock(registry->mutex);  // (the Model is alive: this is a call on it)
     slimt_hip_ctx_destroy(w->ctx);
     w->ctx = nullptr;
     w->max_B = std::max(B, w->max_B);

@@ -47,6 +47,7 @@ def expected_forms(acc, limit, group):
                                               ("tiny11", 23, 21, 32), ("tiny11", 50, 7, 64), ("tiny11", 19, 29, 64),
                                               ("tiny11", 9, 8, 32), ("tiny11", 30, 13, 64),
                                               ("tiny11", 17, 40, 64), ("tiny11", 9, 64, 64), ("tiny11", 20, 33, 64), ("tiny11", 11, 57, 64),
+                                              ("tiny11", 9, 128, 0), ("tiny11", 7, 65, 0), ("tiny11", 5, 100, 0), ("tiny11", 6, 121, 0),
                                               ("base", 21, 32, 32), ("base", 19, 16, 32), ("base", 26, 7, 32), ("base", 7, 25, 32)])
 def test_forms_follow_the_accumulators_and_results_do_not(hip, oracle, synth_models, preset, B, S, rows):
     """tiny11: both encoders (64- and 32-row tiles) write the narrow form of the shifted accumulator -- sentences of 33..64
@@ -66,7 +67,7 @@ def test_forms_follow_the_accumulators_and_results_do_not(hip, oracle, synth_mod
         peak = np.abs(acc.astype(np.int64)).max(axis=(1, 3, 4))  # [Ld][B]
         assert peak.max() < 2 ** 19  # the synthetic model: every sentence fits the narrow form
         ctx.set_encode_rows(rows)
-        group = rows // S
+        group = max(1, rows // S)  # (sentences of more than 32 tokens: one per workgroup, whichever encoder takes them)
         # limits: the real one, and three that split this batch's sentences (the median peak, its neighbours)
         order = np.sort(peak.ravel())
         limits = [2 ** 19, int(order[len(order) // 2]), int(order[len(order) // 4]) + 1, int(order[-1]), int(order[-1]) + 1, 1]
