@@ -434,6 +434,13 @@ int slimt_hip_debug_break_shortlist_handoff(slimt_hip_ctx *ctx, int broken, unsi
  * 0 = 20-bit, 1 = 24-bit; *batch = B, or 0 when the batch's caches are all in one form (f32 or
  * 24-bit: formats 1 / 2, or a shape without the narrow form). Waits for ctx's stream. */
 int slimt_hip_debug_kv_formats(slimt_hip_ctx *ctx, uint8_t *out, size_t n, size_t *batch);
+/* Diagnostic: format 0's watch. The library counts the sentence-layers it cached (submitted) and those
+ * that needed the 24-bit form (wide; updated by the device, a few batches behind); once more than one
+ * in 32 did (after 1024 were submitted) the model caches every batch in the 24-bit form from then on
+ * (*switched_to_24_bit = 1): a model whose accumulators do not fit 20 bits then runs at the 24-bit
+ * form's own speed instead of through its per-sentence fallback. slimt_hip_model_set_kv_cache_format
+ * and slimt_hip_debug_kv_narrow_limit start the watch afresh. Any pointer may be NULL. */
+int slimt_hip_debug_kv_watch(slimt_hip_model *model, int *switched_to_24_bit, uint64_t *wide, uint64_t *submitted);
 /* Diagnostic: accumulators must lie in [-limit, limit) for the 20-bit form (default and
  * maximum 2^19, what 20 bits hold). Tests lower it so that some sentences of a batch take the
  * 24-bit form next to narrow ones. Results do not depend on it. */

@@ -27,7 +27,7 @@ SYMBOLS = [
     "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_ctx_set_encode_rows", "slimt_hip_ctx_plan", "slimt_hip_translate", "slimt_hip_translate_device",
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
-    "slimt_hip_debug_decode_stamps", "slimt_hip_debug_kv_formats", "slimt_hip_debug_kv_narrow_limit", "slimt_hip_debug_break_shortlist_handoff", "slimt_hip_debug_cross_attention",
+    "slimt_hip_debug_decode_stamps", "slimt_hip_debug_kv_formats", "slimt_hip_debug_kv_narrow_limit", "slimt_hip_debug_kv_watch", "slimt_hip_debug_break_shortlist_handoff", "slimt_hip_debug_cross_attention",
     "slimt_hip_debug_occupancy_trace", "slimt_hip_model_set_decoder_budget",
     "slimt_hip_model_set_kv_cache_policy",
     "slimt_hip_model_set_xcd_affinity", "slimt_hip_model_device",
@@ -196,6 +196,7 @@ def lib():
     L.slimt_hip_debug_occupancy_trace.argtypes = [vp, sz]
     L.slimt_hip_debug_kv_formats.argtypes = [vp, vp, sz, vp]
     L.slimt_hip_debug_kv_narrow_limit.argtypes = [vp, i32]
+    L.slimt_hip_debug_kv_watch.argtypes = [vp, vp, vp, vp]
     L.slimt_hip_debug_break_shortlist_handoff.argtypes = [vp, i32, u32]
     L.slimt_hip_debug_cross_attention.argtypes = [vp, i32, i32, vp, vp, vp]
     L.slimt_hip_model_set_decoder_budget.argtypes = [vp, i32]
@@ -402,6 +403,12 @@ class Model:
         (default); 1 = always f32; 2 = packed, always 24 bits; 3 = f32 and the reference's literal dequantise-then-attend
         sequence (stage-wise decoder: for checking)."""
         _chk(lib().slimt_hip_model_set_kv_cache_format(self.h, fmt))
+
+    def debug_kv_watch(self):
+        """(switched to the 24-bit form for good, sentence-layers that needed it so far, sentence-layers cached so far)."""
+        sw, w, t = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+        _chk(lib().slimt_hip_debug_kv_watch(self.h, C.byref(sw), C.byref(w), C.byref(t)))
+        return bool(sw.value), int(w.value), int(t.value)
 
     def debug_kv_narrow_limit(self, limit: int):
         """Accumulators must lie in [-limit, limit) for the 20-bit cache form (default and maximum 2**19)."""

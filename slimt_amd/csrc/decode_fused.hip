@@ -1990,7 +1990,11 @@ __device__ __forceinline__ void attention_row20_64(AttnRow r, int lane, lcf_ptr 
 // sentence's owner then takes the first maximum over the members' candidates -- columns ascend with the member index, so it
 // is the reference's scan (Transformer.cc:287-298) whatever the split. The members wait for each other: the engine uses
 // clusters only under the decoder admission (every admitted workgroup gets a CU without waiting for another decoder).
-template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0, int SPW = 16, int CL = 1>
+// KV20 (packed-cache variants): true = the narrow 20-bit form inlined, the 24-bit form as the rare sentence's out-of-line
+// fallback; false = the 24-bit form inlined and nothing else (launches whose caches are all 24-bit: K/V cache format 2,
+// or a model the engine found mostly too wide for 20 bits -- there the out-of-line call would cost every sentence).
+template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0, int SPW = 16, int CL = 1,
+          bool KV20 = true>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   static_assert(CL == 1 || (CL <= 4 && RT == 1 && SPW == 16 && MID == 0 && !LONG), "cluster logits: the 16-sentence tilings");
   static_assert(SPW == 16 || ((SPW == 8 || SPW == 4) && RT == 1 && KV24), "fewer sentences per workgroup: the packed-cache, 16-row variants");
@@ -2114,7 +2118,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     kv_wide[rr] = ~0u;
-    if constexpr (KV24) {
+    if constexpr (KV24 && KV20) {
       if (a.kv_fmt && live[rr]) {
         unsigned w = 0;
         for (int l = 0; l < Ld; ++l) w |= (unsigned)(a.kv_fmt[(size_t)l * B + bq[rr]] != 0) << l;
@@ -2324,12 +2328,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + no) * S) : (gf_ptr) nullptr;
           if constexpr (KV24 && KVC == 4) {
             const lcf_ptr kc = (lcf_ptr)(kvpb + (4 * l) * D);
-#ifdef SLIMT_EXP_NO_KV20
+            if constexpr (!KV20) {
             if (NT && kv_streams)
               attention_row24_64<2>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_64<0>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
-#else
+            } else {
             const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
             if (!wide) {
               if (NT && kv_streams)
@@ -2340,15 +2344,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
               attention_row24_64_cold<2>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_64_cold<0>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
-#endif
+            }
           } else if constexpr (MID == 2) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
-#ifdef SLIMT_EXP_NO_KV20
+            if constexpr (!KV20) {
             if (NT && kv_streams)
               attention_row24_long<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_long<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-#else
+            } else {
             const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
             if (!wide) {
               if (NT && kv_streams)
@@ -2359,15 +2363,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
               attention_row24_long_cold<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_long_cold<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-#endif
+            }
           } else if constexpr (MID == 1) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
-#ifdef SLIMT_EXP_NO_KV20
+            if constexpr (!KV20) {
             if (NT && kv_streams)
               attention_row24_mid<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_mid<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-#else
+            } else {
             const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
             if (!wide) {
               if (NT && kv_streams)
@@ -2378,15 +2382,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
               attention_row24_mid_cold<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_mid_cold<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-#endif
+            }
           } else if constexpr (KV24) {
             const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
-#ifdef SLIMT_EXP_NO_KV20  // A/B builds: the kernel as it was before the narrow form (engine.cpp then never records forms)
+            if constexpr (!KV20) {
             if (NT && kv_streams)
               attention_row24<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-#else
+            } else {
             const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
             if (!wide) {
               if (NT && kv_streams)
@@ -2397,7 +2401,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
               attention_row24_cold<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             else
               attention_row24_cold<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-#endif
+            }
           } else if (NT && kv_streams)
             attention_row<D, DH, LONG, 2>(ar, lane);
           else
@@ -2900,16 +2904,24 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
                           : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_, 8>)               \
                : (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_>                    \
                           : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_>))
+  // every cache of this launch in the 24-bit form (a.kv_fmt == nullptr): the 16-sentence tilings have an instantiation
+  // with that form inlined (KV20 = false); the 8- / 4-sentence ones reach it through the fallback call
+#define SLIMT_KV24_ONLY(KSD_, KSF_, DH_, MID_)                                                        \
+  (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_, 16, 1, false>          \
+           : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_, 16, 1, false>)
+  const bool only24 = kv24 && !a.kv_fmt && rows == 16 && a.cluster <= 1;
   if (mid) {
     if (rows > 16 || F != 1536) return hipErrorInvalidValue;
     const size_t ldsm = fused_decode_lds_bytes(D, F, a.Ld, 16, true, mid);
     if (ldsm > 160 * 1024) return hipErrorInvalidValue;
+    if (only24) return go(mid == 2 ? SLIMT_KV24_ONLY(4, 24, 32, 2) : SLIMT_KV24_ONLY(4, 24, 32, 1), ldsm);
     return go(mid == 2 ? SLIMT_KV24_PICK(4, 24, 32, 2) : SLIMT_KV24_PICK(4, 24, 32, 1), ldsm);
   }
   const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows <= 16 ? 16 : rows, kv24, 0, &a.ln_in_lds);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (kv24 && D == 512) {
     if (F != 2048) return hipErrorInvalidValue;
+    if (only24) return go(SLIMT_KV24_ONLY(8, 32, 64, 0), lds);
     return go(SLIMT_KV24_PICK(8, 32, 64, 0), lds);
   }
   if (a.cluster > 1) {  // cluster logits: the 16-sentence tiling of the D = 256 packed-cache shape
@@ -2917,8 +2929,10 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
     return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 0, 16, 4>
                       : decode_fused_kernel<4, 24, 32, false, false, 1, true, 0, 16, 4>, lds);
   }
+  if (only24) return go(SLIMT_KV24_ONLY(4, 24, 32, 0), lds);
   if (kv24 && rows <= 16) return go(SLIMT_KV24_PICK(4, 24, 32, 0), lds);
 #undef SLIMT_KV24_PICK
+#undef SLIMT_KV24_ONLY
   if (rows == 32) {
     auto k = kv24 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true> : decode_fused_kernel<4, 24, 32, false, false, 2, true>)
                   : (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 2>);

@@ -662,7 +662,10 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       // per value, when every K and V accumulator of its valid rows lies in [-limit, limit) -- both tiles are staged, so
       // the choice is made before anything is written --, else 24 bits. The same integers either way.
       const bool wide = !a.kv_fmt || kv_wide_flag != 0;
-      if (a.kv_fmt && tid < spw && s0 + tid < B) a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
+      if (a.kv_fmt && tid < spw && s0 + tid < B) {
+        a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
+        if (wide && a.kv_wide_count) __hip_atomic_fetch_add(a.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       if (!wide) {
         // decode_fused.hip, attention_row20: one thread = 32 values = four quads of hi halves + one quad of lo nibbles
         //   K [sentence][head][plane 0..4][key][16 B],  V [sentence][key / 8][plane 0..4][column / 4][16 B]
@@ -1354,7 +1357,10 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
     if (!redo) break;
     wide = true;
    }
-    if (f.kv_fmt && f.kv24 && tid == 0) f.kv_fmt[(size_t)l * f.B + b] = wide ? 1 : 0;
+    if (f.kv_fmt && f.kv24 && tid == 0) {
+      f.kv_fmt[(size_t)l * f.B + b] = wide ? 1 : 0;
+      if (wide && f.kv_wide_count) __hip_atomic_fetch_add(f.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 

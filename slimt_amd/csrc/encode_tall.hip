@@ -946,7 +946,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       if (!redo) break;
       wide = true;
     }
-    if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
+    if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) {
+      a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
+      if (wide && a.kv_wide_count) __hip_atomic_fetch_add(a.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   if (gen_here) {
     // the shortlist of this launch: wait for its publisher (running since before this workgroup started, and

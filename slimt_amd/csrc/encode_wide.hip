@@ -770,7 +770,10 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         load_w(bw[0], a.dec_k[l], wave, lane);
       }
     }
-    if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
+    if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) {
+      a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
+      if (wide && a.kv_wide_count) __hip_atomic_fetch_add(a.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   if (gen_here) {
     if (shortlist_await_in_launch(a.gen_flag, a.gen_epoch ^ a.gen_wait_xor, tid, a.dev_error, a.gen_spin_limit))  // (never published: nothing to pack from)

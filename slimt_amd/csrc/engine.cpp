@@ -50,6 +50,36 @@ static std::atomic<bool> g_hip_called{false};
 // sequence (K/V cache format 3) exists in the stage-wise attention kernel only (decode_kernels.hip, DQAttnArgs::literal)
 static bool fused_decoder_allowed(const slimt_hip_ctx *c) { return c->decode_mode != 1 && c->model->kv_format != 3; }
 
+// The narrow K/V form for this model's next batch (engine.h, kv_auto_wide): format 0, and the sentences so far mostly fit.
+// Called under the model's submit / gate discipline by encode_device; the counter lags the device by a few batches.
+static bool kv_narrow_wanted(slimt_hip_model *m, unsigned long long **count_dev) {
+  *count_dev = nullptr;
+  if (m->kv_format != 0 || m->kv_auto_wide.load(std::memory_order_relaxed)) return false;
+  {
+    std::lock_guard<std::mutex> lock(m->gate_mu);
+    if (!m->kv_wide_count) {
+      void *p = nullptr;
+      if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;  // (no counter: narrow without the watch)
+      }
+      std::memset(p, 0, 64);
+      m->kv_wide_count = static_cast<unsigned long long *>(p);
+    }
+  }
+  const unsigned long long wide = *static_cast<volatile unsigned long long *>(m->kv_wide_count);
+  const unsigned long long total = m->kv_layers_submitted.load(std::memory_order_relaxed);
+  // one sentence-layer in 32 is enough to make most 16-sentence workgroups wait for a fallback call every step
+  if (total >= 1024 && wide * 32 > total) {
+    m->kv_auto_wide.store(true, std::memory_order_relaxed);
+    return false;
+  }
+  void *dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, m->kv_wide_count, 0) == hipSuccess) *count_dev = static_cast<unsigned long long *>(dev);
+  else (void)hipGetLastError();
+  return true;
+}
+
 hipError_t DevBuf::reserve(size_t n) {
   if (n <= bytes && p) return hipSuccess;
   g_hip_called.store(true, std::memory_order_relaxed);
@@ -696,6 +726,7 @@ extern "C" int slimt_hip_model_destroy(slimt_hip_model *model) {
   timing_report();
   (void)hipSetDevice(model->device);
   model_free(model);
+  if (model->kv_wide_count) (void)hipHostFree(model->kv_wide_count);
   delete model;
   return 0;
 }
@@ -736,6 +767,18 @@ extern "C" int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int f
   if (format < 0 || format > 3) return fail(-1, "K/V cache format %d not in 0..3", format);
   std::lock_guard<std::mutex> lock(model->gate_mu);
   model->kv_format = format;
+  // choosing a format starts format 0's watch afresh (engine.h, kv_auto_wide)
+  model->kv_auto_wide.store(false, std::memory_order_relaxed);
+  model->kv_layers_submitted.store(0, std::memory_order_relaxed);
+  if (model->kv_wide_count) *static_cast<volatile unsigned long long *>(model->kv_wide_count) = 0;
+  return 0;
+}
+
+extern "C" int slimt_hip_debug_kv_watch(slimt_hip_model *model, int *switched_to_24_bit, uint64_t *wide, uint64_t *submitted) {
+  if (!model) return fail(-1, "model is NULL");
+  if (switched_to_24_bit) *switched_to_24_bit = model->kv_auto_wide.load(std::memory_order_relaxed) ? 1 : 0;
+  if (wide) *wide = model->kv_wide_count ? *static_cast<volatile unsigned long long *>(model->kv_wide_count) : 0;
+  if (submitted) *submitted = model->kv_layers_submitted.load(std::memory_order_relaxed);
   return 0;
 }
 
@@ -792,6 +835,9 @@ extern "C" int slimt_hip_debug_kv_narrow_limit(slimt_hip_model *model, int limit
   if (limit < 1 || limit > (1 << 19)) return fail(-1, "narrow-form limit %d not in 1..2^19 (20 bits hold [-2^19, 2^19))", limit);
   std::lock_guard<std::mutex> lock(model->gate_mu);
   model->kv_narrow_limit = limit;
+  model->kv_auto_wide.store(false, std::memory_order_relaxed);  // (a new limit: the watch starts afresh)
+  model->kv_layers_submitted.store(0, std::memory_order_relaxed);
+  if (model->kv_wide_count) *static_cast<volatile unsigned long long *>(model->kv_wide_count) = 0;
   return 0;
 }
 
@@ -1258,9 +1304,9 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     // the narrow (20-bit) form where the writer and the reader have it -- D = 256 or 512, S <= 32 -- and where a
     // sentence's V block (groups of eight keys) fits the slot of its 24-bit form (groups of four): not S = 1..4, 9..12
     // (... and S = 33..64 at D = 256: the 64-row encoder with one sentence per workgroup, attention_row20_mid)
-    c->kv_fmt_valid = kv24 && m->kv_format == 0 && ((D == 256 && S <= 64) || (D == 512 && S <= 32)) &&
-                      ((S + 7) / 8) * 5120 <= ((S + 3) / 4) * 3072;
-#ifdef SLIMT_EXP_NO_KV20  // A/B builds (decode_fused.hip)
+    c->kv_fmt_valid = kv24 && ((D == 256 && S <= 64) || (D == 512 && S <= 32)) &&
+                      ((S + 7) / 8) * 5120 <= ((S + 3) / 4) * 3072 && kv_narrow_wanted(c->model, &f.kv_wide_count);
+#ifdef SLIMT_EXP_NO_KV20  // A/B builds: the 24-bit form only
     c->kv_fmt_valid = false;
 #endif
     if (c->kv_fmt_valid) {
@@ -1268,6 +1314,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.kv_fmt = c->kv_fmt.as<unsigned char>();
       f.kv_narrow_limit = std::min(m->kv_narrow_limit, 1 << 19);
       c->kv_fmt_B = B;
+      c->model->kv_layers_submitted.fetch_add((unsigned long long)B * m->Ld, std::memory_order_relaxed);
     }
     f.enc_out = keep_out ? c->x0.as<float>() : nullptr;
     if (pack) {
@@ -1342,7 +1389,8 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     f.kv = c->kv.as<float>();
     f.kv24 = kv24;
     // (the narrow form of the packed cache: the first path above has the note; here every S up to 128)
-    c->kv_fmt_valid = kv24 && m->kv_format == 0 && D == 256 && ((S + 7) / 8) * 5120 <= ((S + 3) / 4) * 3072;
+    c->kv_fmt_valid = kv24 && D == 256 && ((S + 7) / 8) * 5120 <= ((S + 3) / 4) * 3072 &&
+                      kv_narrow_wanted(c->model, &f.kv_wide_count);
 #ifdef SLIMT_EXP_NO_KV20
     c->kv_fmt_valid = false;
 #endif
@@ -1351,6 +1399,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.kv_fmt = c->kv_fmt.as<unsigned char>();
       f.kv_narrow_limit = std::min(m->kv_narrow_limit, 1 << 19);
       c->kv_fmt_B = B;
+      c->model->kv_layers_submitted.fetch_add((unsigned long long)B * m->Ld, std::memory_order_relaxed);
     }
     f.enc_out = c->x0.as<float>();
     if (pack) {
@@ -1624,7 +1673,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   // ... and for 65..128-token sentences of that shape (the per-sentence encoder, attention_row24_long)
   const bool kv24_long = S > 64 && S <= 128 && c->decode_mode != 3 && fused_decode_long24_supported(m->D, m->F, m->H, m->Ld) &&
                          long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
-  const bool kv24 = lean && m->kv_format == 0 &&
+  const bool kv24 = lean && (m->kv_format == 0 || m->kv_format == 2) &&
                     ((m->D == 256 && m->D / m->H == 32) || (m->D == 512 && m->D / m->H == 64 && m->F == 2048)) &&
                     ((S <= 32 && ((S + 3) & ~(size_t)3) * 3 <= S * 4 &&
                       fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S)) || kv24_mid || kv24_long);

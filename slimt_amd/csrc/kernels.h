@@ -414,6 +414,9 @@ struct FusedEncodeArgs {
   // some sentences of a batch (never above 2^19)
   unsigned char *kv_fmt = nullptr;
   int kv_narrow_limit = 1 << 19;
+  // nullable, pinned host memory: + 1 per sentence-layer that took the 24-bit form (the engine watches the share: a model
+  // whose accumulators mostly do not fit 20 bits is switched to the 24-bit form altogether, engine.cpp)
+  unsigned long long *kv_wide_count = nullptr;
   PackArgs pack;               // the batch's shortlisted output layer, packed by the
   int pack_tiles = 0;          // encoder's workgroups on the side (0 = nothing to pack)
   // ShortlistGenerator::generate inside this launch (the S <= 64 encoders; gen.w2o != nullptr): the workgroup

@@ -190,3 +190,53 @@ def test_lengths_whose_narrow_v_block_would_not_fit_keep_the_24_bit_form(hip, or
     finally:
         ctx.close()
         gm.close()
+
+
+@pytest.mark.parametrize("preset", ["tiny11", "base"])
+def test_a_model_that_mostly_needs_24_bits_is_switched_to_them(hip, oracle, synth_models, preset):
+    """Format 0 watches its own fallback: a sentence in the 24-bit form is read through an out-of-line call that its whole
+    decoder workgroup waits for, so a model whose accumulators mostly do not fit 20 bits (here: every sentence, by a
+    narrow-form limit of 1) is switched to the 24-bit form for every batch once 1024 sentence-layers have shown it
+    (include/slimt_hip.h, slimt_hip_debug_kv_watch). Results never change; a model that fits stays narrow."""
+    from slimt_amd import synth
+    m = synth_models(preset, 6.0)
+    gm, om = hip.Model(m), oracle.OracleModel(m)
+    B, S = 48, 24
+    ctx = hip.Context(gm, B, S)
+    try:
+        ids, lens = synth.make_batch(m.V, B, S, seed=808, ragged=True)
+        sl = synth.make_shortlist(m.V, 640)
+        oracle.set_mode(oracle.PORTABLE)
+        want = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+        oracle.set_mode(oracle.FAITHFUL)
+        # a model that fits: stays narrow however long it runs
+        for _ in range(14):
+            got = ctx.translate(ids, lens, sl, want_align=True)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        switched, wide, total = gm.debug_kv_watch()
+        assert not switched and wide == 0 and total == 14 * B * m.dec_layers
+        assert ctx.debug_kv_formats(m.dec_layers, B) is not None
+        # nothing fits: the watch trips after 1024 sentence-layers (the device's count lags a batch or two)
+        gm.debug_kv_narrow_limit(1)
+        n = 0
+        while not gm.debug_kv_watch()[0]:
+            got = ctx.translate(ids, lens, sl, want_align=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), n
+            n += 1
+            assert n <= 40, gm.debug_kv_watch()
+        assert n * B * m.dec_layers >= 1024
+        switched, wide, total = gm.debug_kv_watch()
+        assert switched and wide * 32 > total
+        for _ in range(3):  # from now on every batch is cached in the 24-bit form, nothing is recorded
+            got = ctx.translate(ids, lens, sl, want_align=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want))
+            assert ctx.debug_kv_formats(m.dec_layers, B) is None
+        # choosing a format (or a limit) starts the watch afresh
+        gm.set_kv_cache_format(0)
+        gm.debug_kv_narrow_limit(2 ** 19)
+        got = ctx.translate(ids, lens, sl, want_align=True)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        assert not gm.debug_kv_watch()[0] and ctx.debug_kv_formats(m.dec_layers, B) is not None
+    finally:
+        ctx.close()
+        gm.close()
