@@ -75,6 +75,8 @@ def parse(argv=None):
     ap.add_argument("--kv-format", type=int, default=0,
                     help="decoder K/V cache: 0 = packed 24-bit accumulators where the shape has that form (default), 1 = f32 "
                          "(slimt_hip_model_set_kv_cache_format; same results, tuning)")
+    ap.add_argument("--kv-narrow-limit", type=int, default=0,
+                    help="diagnostic: accumulators must lie in [-limit, limit) for the 20-bit K/V form (1 = every sentence falls back)")
     ap.add_argument("--kv-policy", type=int, default=0,
                     help="decoder K/V cache loads: 0 = chosen per launch (default), 1 = temporal, 2 = non-temporal")
     ap.add_argument("--xcd-affinity", type=int, default=-1,
@@ -351,6 +353,8 @@ def main():
             gm.set_kv_cache_policy(args.kv_policy)
         if args.kv_format:
             gm.set_kv_cache_format(args.kv_format)
+        if args.kv_narrow_limit:
+            gm.debug_kv_narrow_limit(args.kv_narrow_limit)
         if args.xcd_affinity >= 0:
             gm.set_xcd_affinity(args.xcd_affinity)
         if args.adaptive_rows >= 0:

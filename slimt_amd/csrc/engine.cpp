@@ -70,7 +70,9 @@ static bool kv_narrow_wanted(slimt_hip_model *m, unsigned long long **count_dev)
   const unsigned long long wide = *static_cast<volatile unsigned long long *>(m->kv_wide_count);
   const unsigned long long total = m->kv_layers_submitted.load(std::memory_order_relaxed);
   // one sentence-layer in 32 is enough to make most 16-sentence workgroups wait for a fallback call every step
-  if (total >= 1024 && wide * 32 > total) {
+  // (SLIMT_KV_WATCH=0: never switch -- measurements of the fallback itself)
+  static const bool watch = !(std::getenv("SLIMT_KV_WATCH") && std::getenv("SLIMT_KV_WATCH")[0] == '0');
+  if (watch && total >= 1024 && wide * 32 > total) {
     m->kv_auto_wide.store(true, std::memory_order_relaxed);
     return false;
   }

@@ -102,9 +102,10 @@ struct slimt_hip_model {
   int kv_narrow_limit = 1 << 19;  // accumulators in [-limit, limit) take the narrow form (slimt_hip_debug_kv_narrow_limit)
   // Format 0 watches how its sentences fare: the encoders add 1 to *kv_wide_count (pinned host memory, allocated on first
   // use) per sentence-layer that had to take the 24-bit form, the engine counts the sentence-layers it submitted. A
-  // sentence in the 24-bit form is read through an out-of-line call that makes its whole workgroup wait (the decoder's
-  // 24-bit launches run at half the rate through it: 4.1 against 8.5 M tok/s at S = 128), so a model whose accumulators
-  // mostly do not fit 20 bits is switched, once, to the 24-bit form for every batch (kv_auto_wide): what round 4 ran.
+  // sentence in the 24-bit form is read through an out-of-line call that makes its whole workgroup wait (every sentence
+  // through it: 28.8 against 34.5 M tok/s with the 24-bit form inlined, base 10.7 against 12.0;
+  // profiles/r05_kv_fallback_call_vs_inlined.txt), so a model whose accumulators mostly do not fit 20 bits is switched,
+  // once, to the 24-bit form for every batch (kv_auto_wide): the kernels round 4 ran.
   unsigned long long *kv_wide_count = nullptr;
   std::atomic<unsigned long long> kv_layers_submitted{0};
   std::atomic<bool> kv_auto_wide{false};
