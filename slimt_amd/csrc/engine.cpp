@@ -981,7 +981,7 @@ double gemm_bytes(const PreparedWeight &w) { return (double)w.K * w.n_tiles * 16
 
 // Contexts alive per device in this process. Every context is a stream, and past ~22 of them the device's
 // hardware queues are time-sliced whatever GPU_MAX_HW_QUEUES says: 21 / 22 workers 32.5 / 32.1 M tok/s, 24 workers
-// 23.8 M, 32 workers 20.4 M (profiles/r04_v1_budget_workers_sweep.txt). Said once, on stderr, when it happens
+// 23.8 M, 32 workers 20.4 M (profiles/archive/r04_v1_budget_workers_sweep.txt). Said once, on stderr, when it happens
 // (SLIMT_HIP_QUIET=1: not said); slimt_hip_contexts_on_device reports the count.
 static constexpr int kMaxDevices = 64;
 static constexpr int kContextCliff = 22;
@@ -1906,7 +1906,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       // cached and one streamed attention per step; keeping BOTH layers of k of every 8 launches (by admission order)
       // and streaming both layers of the others holds the same bytes but lets the kept decoders run their whole step
       // at the cached speed (and finish together, so no CU idles inside a launch): 32.35 -> 33.05-33.26 M tok/s at
-      // k = 6, 32.5-32.9 at k = 5, 32.3-32.6 at k = 7, 31.7 all temporal (profiles/r04_v3_kv_by_launch.txt).
+      // k = 6, 32.5-32.9 at k = 5, 32.3-32.6 at k = 7, 31.7 all temporal (profiles/archive/r04_v3_kv_by_launch.txt).
       // k = as many eighths of the pending decoders as SLIMT_KV_LAUNCH_BUDGET_MB covers (round 4: 270, the 24-bit form;
       // round 5: 300 -- with the narrow form the headline's decoders hold 232 MB, k = 6 / 7 / 8 measure the same
       // (35.8 / 35.7 / 35.6 M tok/s, profiles/r05_kv_keep_sweep.txt), and every launch then runs the kept instantiation);
