@@ -2934,6 +2934,9 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
 #undef SLIMT_KV24_PICK
 #undef SLIMT_KV24_ONLY
   if (rows == 32) {
+    if (kv24 && !a.kv_fmt)  // every cache in the 24-bit form: that form inlined (KV20 = false), as for the 16-sentence tilings
+      return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true, 0, 16, 1, false>
+                        : decode_fused_kernel<4, 24, 32, false, false, 2, true, 0, 16, 1, false>, lds);
     auto k = kv24 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true> : decode_fused_kernel<4, 24, 32, false, false, 2, true>)
                   : (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 2>);
     return go(k, lds);
