@@ -2598,14 +2598,23 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           const float qnan = __int_as_float(0x7fc00000);
           const f2 pb01 = {left > 0 ? x.pb.x : qnan, left > 1 ? x.pb.y : qnan}, pb23 = {left > 2 ? x.pb.z : qnan, left > 3 ? x.pb.w : qnan};
           const f2 uu = {a.out.u, a.out.u};
+          // the CL sentence tiles' accumulator chains run INTERLEAVED (k-step outside, sentence tile inside): one tile after
+          // the other, a wave sat out an LDS round trip + four dependent MFMAs per sentence tile (a member's quarter took
+          // 27-41 us for 2 MB of weights and 500 logits per lane)
+          v4i accs[CL];
+#pragma unroll
+          for (int st = 0; st < CL; ++st) accs[st] = sh;
+#pragma unroll
+          for (int ks = 0; ks < KSD; ++ks) {
+            v4i af[CL];
+#pragma unroll
+            for (int st = 0; st < CL; ++st) af[st] = *reinterpret_cast<const v4i *>(CA + (16 * st + lr) * LDA + ks * 64 + lg * 16);
+#pragma unroll
+            for (int st = 0; st < CL; ++st) accs[st] = __builtin_amdgcn_mfma_i32_16x16x64_i8(x.f[ks], af[st], accs[st], 0, 0, 0);
+          }
 #pragma unroll
           for (int st = 0; st < CL; ++st) {
-            v4i acc = sh;
-#pragma unroll
-            for (int ks = 0; ks < KSD; ++ks) {
-              const v4i af = *reinterpret_cast<const v4i *>(CA + (16 * st + lr) * LDA + ks * 64 + lg * 16);
-              acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(x.f[ks], af, acc, 0, 0, 0);
-            }
+            const v4i acc = accs[st];
             // y = float(acc + 127 colsum) * u + pb (Intgemm.inl.cc:146-153): dequant4's operations
             f2 lo = {(float)acc[0], (float)acc[1]}, hi = {(float)acc[2], (float)acc[3]};
             lo = lo * uu;
