@@ -77,6 +77,8 @@ def parse(argv=None):
                          "(slimt_hip_model_set_kv_cache_format; same results, tuning)")
     ap.add_argument("--kv-narrow-limit", type=int, default=0,
                     help="diagnostic: accumulators must lie in [-limit, limit) for the 20-bit K/V form (1 = every sentence falls back)")
+    ap.add_argument("--kv-tight-limit", type=int, default=-1,
+                    help="diagnostic: signed accumulators must lie in [-limit, limit) for the 16-bit K/V form (-1 = library default 2^15, 0 = never tried)")
     ap.add_argument("--kv-policy", type=int, default=0,
                     help="decoder K/V cache loads: 0 = chosen per launch (default), 1 = temporal, 2 = non-temporal")
     ap.add_argument("--xcd-affinity", type=int, default=-1,
@@ -355,6 +357,8 @@ def main():
             gm.set_kv_cache_format(args.kv_format)
         if args.kv_narrow_limit:
             gm.debug_kv_narrow_limit(args.kv_narrow_limit)
+        if args.kv_tight_limit >= 0:
+            gm.debug_kv_tight_limit(args.kv_tight_limit)
         if args.xcd_affinity >= 0:
             gm.set_xcd_affinity(args.xcd_affinity)
         if args.adaptive_rows >= 0:

@@ -431,7 +431,7 @@ int slimt_hip_debug_cross_attention(slimt_hip_ctx *ctx, int layer, int literal, 
  * not to be used. Tests use it to reach that path. */
 int slimt_hip_debug_break_shortlist_handoff(slimt_hip_ctx *ctx, int broken, unsigned poll_limit);
 /* Diagnostic: which form each sentence-layer of ctx's last batch was cached in -- out[l * B + b],
- * 0 = 20-bit, 1 = 24-bit; *batch = B, or 0 when the batch's caches are all in one form (f32 or
+ * 0 = 20-bit, 1 = 24-bit, 2 = 16-bit (the tight form); *batch = B, or 0 when the batch's caches are all in one form (f32 or
  * 24-bit: formats 1 / 2, or a shape without the narrow form). Waits for ctx's stream. */
 int slimt_hip_debug_kv_formats(slimt_hip_ctx *ctx, uint8_t *out, size_t n, size_t *batch);
 /* Diagnostic: format 0's watch. The library counts the sentence-layers it cached (submitted) and those
@@ -445,6 +445,17 @@ int slimt_hip_debug_kv_watch(slimt_hip_model *model, int *switched_to_24_bit, ui
  * maximum 2^19, what 20 bits hold). Tests lower it so that some sentences of a batch take the
  * 24-bit form next to narrow ones. Results do not depend on it. */
 int slimt_hip_debug_kv_narrow_limit(slimt_hip_model *model, int limit);
+/* Diagnostic: the tight (16-bit) form below the 20-bit one. Where the decoder has a reader for it (D = 256 /
+ * F = 1536, sentences of at most 32 tokens, the tilings of 16 / 8 / 4 sentences) format 0 caches a
+ * sentence-layer whose SIGNED K and V accumulators all lie in [-limit, limit) as plain int16 (default
+ * and maximum 2^15; 0 = never tried; tests lower it so that a batch mixes all three forms). Results do
+ * not depend on it. Starts the watches afresh. */
+int slimt_hip_debug_kv_tight_limit(slimt_hip_model *model, int limit);
+/* Diagnostic: the tight form's watch, per decoder layer l < 4: submitted[l] sentences were allowed to
+ * try it, missed[l] of them did not fit (updated by the device, a few batches behind); once more than
+ * half of a layer's sentences missed (after 1024 were submitted) that layer stops trying (bit l of
+ * *layers_off). Any pointer may be NULL; the arrays hold 4 entries. */
+int slimt_hip_debug_kv_tight_watch(slimt_hip_model *model, unsigned *layers_off, uint64_t *missed, uint64_t *submitted);
 /* Diagnostic (process-wide): while device_buf != NULL, thread 0 of every
  * workgroup of the persistent encoder / decoder appends a begin and an end
  * event to it: device_buf[0] = event counter (zero it first), then 3 uint64

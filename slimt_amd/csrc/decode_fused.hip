@@ -1163,6 +1163,131 @@ __device__ __forceinline__ void attention_row20(AttnRow r, int lane, lcf_ptr pbk
       pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
 }
 
+// ---- the tight form of the packed cache: 16 bits per value (kernels.h, FusedDecodeArgs::kv_fmt == 2) ------------------
+// A sentence-layer whose SIGNED K and V accumulators (acc = accS - 127 colsum, what the MFMA itself produces) all lie in
+// [-2^15, 2^15) is cached as plain int16: 2 instead of 2.5 bytes per value, 4 instead of 5 loads per 32 values, and the
+// cheapest unpack of the three forms -- the conversion reads its half of the register itself (v_cvt_f32_i32 with an SDWA
+// word select: no extract at all), and float(accS) = float(acc) + float(127 colsum) is one EXACT addition (both floats are
+// integers, their sum is accS, |accS| < 2^24), half a packed add per value: 1.5 instructions per value where the 20-bit
+// form spends 2.4 and the 24-bit one 2. The column terms c127[d] = float(127 colsum[d]) live in LDS next to the prepared
+// biases. The chains then run over float(accS) itself (no power of two to take out: plain u). Timing-only bound, every
+// sentence in this form: 35.9 -> 38.8 M tok/s (profiles/r05_kv16_bound_timing_only.txt). Whether a model's accumulators are
+// that small depends on its multipliers (sigma(acc) = sqrt(K) sigma(q) sigma(W)); the encoders try this form only while
+// the engine's watch says most sentences take it, and the 20-bit form is inlined next to it.
+//   K [head][plane 0..3][S][16 B]            plane p: the head's columns 8 p .. 8 p + 7 of one key (eight int16)
+//   V [ceil(S / 8)][plane 0..3][D/4][16 B]   plane p: keys 8 g + 2 p, 8 g + 2 p + 1 x 4 consecutive columns (key-major)
+// ck / cv: c127 of the K / V projection [D] in LDS.
+struct C127Lds {  // float(127 colsum[d]) prepared in LDS (the kernels with this form inlined)
+  lcf_ptr p;
+  __device__ __forceinline__ f4 at4(int d) const { return *(lcf4_ptr)(p + d); }
+};
+template <int KV_AUX, typename C127>
+__device__ __forceinline__ void attention_row16(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, C127 ck, C127 cv) {
+  constexpr int D = 256, DH = 32, H = D / DH;
+  const int S = r.S, len = r.len;
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int hh = lane >> 5, j = lane & 31;
+  const int jc = j < S ? j : S - 1;
+  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+  v4i kq[4];     // this lane's key, its head's 32 columns
+  v4i vq[2][4];  // V rows in flight: two groups of eight rows
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 512));
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 4096));
+  // (masked keys are not fetched: zeros past the descriptors -- a score the mask overrides, a value weighted by exactly 0)
+  const int koff = j < lenf ? (hh * 4 * S + jc) * 16 : kPastDescriptor;
+  const int voff = lane * 16;
+  auto load_k = [&](int hp) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((8 * hp + i) * S) * 16, KV_AUX));
+  };
+  auto load_v = [&](v4i(&vv)[4], int g) {  // rows 8 g .. 8 g + 7
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (4 * g + i) * 1024, KV_AUX));
+  };
+  // two int16 of one register -> float(accS) of the two columns / keys: conversion in place + the exact column term
+  auto pair16 = [](int d, f2 c) -> f2 {
+    const f2 v = {(float)(short)(d & 0xffff), (float)(d >> 16)};
+    return v + c;
+  };
+  load_k(0);
+  load_v(vq[0], 0);
+  __builtin_amdgcn_sched_barrier(0);
+  float ckh[4];  // c_h of this lane's head in pass hp (under the first loads' round trip)
+  head_constants32(r.qrow, pbk, lane, ckh);
+#pragma unroll
+  for (int hp = 0; hp < H / 2; ++hp) {
+    const int h = 2 * hp + hh;
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d0 = h * DH + 8 * i;
+      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
+      const f4 ca = ck.at4(d0), cb = ck.at4(d0 + 4);
+      const f2 k01 = pair16(kq[i].x, f2{ca.x, ca.y}), k23 = pair16(kq[i].y, f2{ca.z, ca.w});
+      const f2 k45 = pair16(kq[i].z, f2{cb.x, cb.y}), k67 = pair16(kq[i].w, f2{cb.z, cb.w});
+      t = __builtin_fmaf(qa.x, k01.x, t);
+      t = __builtin_fmaf(qa.y, k01.y, t);
+      t = __builtin_fmaf(qa.z, k23.x, t);
+      t = __builtin_fmaf(qa.w, k23.y, t);
+      t = __builtin_fmaf(qb.x, k45.x, t);
+      t = __builtin_fmaf(qb.y, k45.y, t);
+      t = __builtin_fmaf(qb.z, k67.x, t);
+      t = __builtin_fmaf(qb.w, k67.y, t);
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);  // at most sixteen q / c values from LDS in flight
+    }
+    if (hp + 1 < H / 2) {
+      load_k(hp + 1);
+    } else {  // the K registers are free: the second group of V rows
+      load_v(vq[1], 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float s = __builtin_fmaf(t, r.uk, ckh[hp]);
+    if (r.alpha != 1.0f) s = r.alpha * s;
+    s = s + mask;
+    if (j >= S) s = lowest;
+    const float m = half_max(s);
+    const float e = j < S ? exp_p(s - m) : 0.0f;
+    const float sum = half_sum(e);
+    const float p = e / sum;  // keys >= S: exactly 0
+    const float ps = half_sum(p);  // P_h
+    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
+    if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
+    r.pbuf[h * 32 + j] = p;
+    if (j == 0) r.hsum[h] = ps;
+  }
+  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
+  const int ph = (lane >> 3) * 32;
+  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  const f4 cv4 = cv.at4(4 * lane);
+  const f2 c01 = {cv4.x, cv4.y}, c23 = {cv4.z, cv4.w};
+  const float P = r.hsum[lane >> 3];
+  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};  // columns (0, 1) and (2, 3): v_pk_fma_f32 is one fma per column
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    v4i(&cur)[4] = vq[g & 1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
+      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
+      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
+      oa = __builtin_elementwise_fma(p0, pair16(cur[c].x, c01), oa);
+      ob = __builtin_elementwise_fma(p0, pair16(cur[c].y, c23), ob);
+      oa = __builtin_elementwise_fma(p1, pair16(cur[c].z, c01), oa);
+      ob = __builtin_elementwise_fma(p1, pair16(cur[c].w, c23), ob);
+    }
+    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
+    if (g + 2 < 4) load_v(vq[g & 1], g + 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float o0 = __builtin_fmaf(oa.x, r.uv, pv4.x * P), o1 = __builtin_fmaf(oa.y, r.uv, pv4.y * P);
+  const float o2 = __builtin_fmaf(ob.x, r.uv, pv4.z * P), o3 = __builtin_fmaf(ob.y, r.uv, pv4.w * P);
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
+}
+
 // Sentences of 33..64 tokens over the packed cache (written by encode_tall_kernel<., 4>): lane =
 // key, one head per score pass (8 passes of 6 K loads), the 64-column softmax in the canonical
 // order (one element per lane, the 64-lane butterfly), all heads' probabilities in LDS
@@ -1990,12 +2115,16 @@ __device__ __forceinline__ void attention_row20_64(AttnRow r, int lane, lcf_ptr 
 // sentence's owner then takes the first maximum over the members' candidates -- columns ascend with the member index, so it
 // is the reference's scan (Transformer.cc:287-298) whatever the split. The members wait for each other: the engine uses
 // clusters only under the decoder admission (every admitted workgroup gets a CU without waiting for another decoder).
-// KV20 (packed-cache variants): true = the narrow 20-bit form inlined, the 24-bit form as the rare sentence's out-of-line
-// fallback; false = the 24-bit form inlined and nothing else (launches whose caches are all 24-bit: K/V cache format 2,
+// KVI (packed-cache variants), the forms inlined: 20 = the narrow 20-bit form, the 24-bit form as the rare sentence's out-of-line
+// fallback; 24 = the 24-bit form inlined and nothing else (launches whose caches are all 24-bit: K/V cache format 2,
 // or a model the engine found mostly too wide for 20 bits -- there the out-of-line call would cost every sentence).
+// KVI = 16: additionally the tight 16-bit form inlined (D = 256, S <= 32, RT = 1; kv_fmt == 2), for models whose sentences
+// mostly take it (engine.cpp, kv_try16); its column terms take 2 KB of LDS per layer.
 template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0, int SPW = 16, int CL = 1,
-          bool KV20 = true>
+          int KVI = 20>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
+  constexpr bool KV20 = KVI != 24;
+  static_assert(KVI == 24 || KVI == 20 || (KVI == 16 && KV24 && KSD == 4 && MID == 0 && RT == 1 && CL == 1), "16-bit form: the D = 256 short-sentence tilings");
   static_assert(CL == 1 || (CL <= 4 && RT == 1 && SPW == 16 && MID == 0 && !LONG), "cluster logits: the 16-sentence tilings");
   static_assert(SPW == 16 || ((SPW == 8 || SPW == 4) && RT == 1 && KV24), "fewer sentences per workgroup: the packed-cache, 16-row variants");
   static_assert(!KV24 || (((KSD == 4 && DH == 32) || (KSD == 8 && DH == 64)) && !LONG),
@@ -2049,6 +2178,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr bool LN_LDS = KSD == 4 && RT == 1 && MID == 0;  // (MID: the LDS goes to the wider attention scratch)
   float *lnc = kvpb + (KV24 ? Ld * KVC * D : 0);
   const bool ln_lds = LN_LDS && a.ln_in_lds;  // (the launcher: only where the 160 KiB allow it)
+  float *kvc127 = lnc + (ln_lds ? Ld * 6 * D : 0);  // KVI == 16: [Ld][K, V][D] float(127 colsum) (attention_row16)
 
   // Which R sentences? With a ticket counter the grid is over-subscribed and the first
   // workgroups to START claim the tiles; the rest leave at once. A workgroup needs a whole
@@ -2113,15 +2243,19 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     n_out[rr] = 0;
   }
   const int valid_rows = (B - m0) < RS ? (B - m0) : RS;
-  // the form of this wave's sentences' caches, one bit per layer: 1 = 24-bit, 0 = narrow (kernels.h, kv_fmt)
+  // the form of this wave's sentences' caches: bit l = 24-bit, bit 8 + l = the tight 16-bit form, neither = 20-bit
+  // (kernels.h, kv_fmt: 1 / 2 / 0)
   unsigned kv_wide[RT];
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
-    kv_wide[rr] = ~0u;
+    kv_wide[rr] = 0xffu;
     if constexpr (KV24 && KV20) {
       if (a.kv_fmt && live[rr]) {
         unsigned w = 0;
-        for (int l = 0; l < Ld; ++l) w |= (unsigned)(a.kv_fmt[(size_t)l * B + bq[rr]] != 0) << l;
+        for (int l = 0; l < Ld; ++l) {
+          const unsigned f = a.kv_fmt[(size_t)l * B + bq[rr]];
+          w |= (unsigned)(f == 1) << l | (unsigned)(f == 2) << (8 + l);
+        }
         kv_wide[rr] = __builtin_amdgcn_readfirstlane(w);
       }
     }
@@ -2146,6 +2280,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
                          : v == 4 ? Lw.ffn_ln_s : Lw.ffn_ln_b;
       lnc[i] = src[d];
     }
+  }
+  if constexpr (KVI == 16) {
+    for (int i = tid; i < Ld * 2 * D; i += 1024) kvc127[i] = (float)__mul24(127, a.kv_cs[i / (2 * D)][(i / D) & 1][i % D]);
   }
   if constexpr (KV24) {
     if constexpr (KVC == 2) {
@@ -2391,8 +2528,18 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             else
               attention_row24<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             } else {
-            const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
-            if (!wide) {
+            const unsigned forms = rr ? kv_wide[RT - 1] : kv_wide[0];
+            const bool wide = (forms >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
+            const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
+            if (tight) {
+              if constexpr (KVI == 16) {
+                const C127Lds ck = {(lcf_ptr)(kvc127 + (2 * l) * D)}, cv = {(lcf_ptr)(kvc127 + (2 * l + 1) * D)};
+                if (NT && kv_streams)
+                  attention_row16<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, ck, cv);
+                else
+                  attention_row16<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, ck, cv);
+              }  // (the other kernels never meet the form: the launcher refuses a tight batch, the engine never sends one)
+            } else if (!wide) {
               if (NT && kv_streams)
                 attention_row20<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
               else
@@ -2840,19 +2987,27 @@ int fused_decode_grid(int B, bool tickets, int rows) {
 
 // ln_in_lds (out, nullable): whether the LayerNorm constants of all layers (LN_LDS in the kernel: the
 // D = 256, 16-row, non-MID variants) still fit the 160 KiB; the returned size includes them then.
+// tight: the kernels with the 16-bit cache form inlined (KVI = 16) keep its column terms [Ld][K, V][D] behind everything else.
 size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false, int mid = 0,
-                              bool *ln_in_lds = nullptr) {
+                              bool *ln_in_lds = nullptr, bool tight = false) {
   // D * rows > 256 * 16: two f32 row buffers, SSRU cells in global memory (see the kernel)
   const size_t R = (size_t)rows;
   const bool lean = (size_t)D * R > 256 * 16;
   const size_t cells = (lean || mid == 2) ? 0 : (size_t)Ld * R * D * 4;
   const size_t f32rows = (lean ? 2 : 3) * R * (D + 4) * 4 + cells;
   const size_t base = f32rows + 2 * R * (size_t)(D + 32) + R * (size_t)(F + 32) + 2 * NW * R * 4 + 64 +
-                      NW * (mid == 2 ? 1024 : mid == 1 ? 512 : 256) * 4 + (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0);
+                      NW * (mid == 2 ? 1024 : mid == 1 ? 512 : 256) * 4 + (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0) +
+                      (tight ? (size_t)Ld * 2 * D * 4 : 0);
   const size_t ln = (D == 256 && rows == 16 && !mid) ? (size_t)Ld * 6 * D * 4 : 0;
   const bool fits = ln > 0 && base + ln <= 160 * 1024;
   if (ln_in_lds) *ln_in_lds = fits;
   return fits ? base + ln : base;
+}
+
+// the tight (16-bit) cache form: the D = 256 / F = 1536 short-sentence tilings of 16 / 8 / 4 sentences (decode_fused_kernel<..., KVI = 16>)
+bool fused_decode_tight_supported(int D, int F, int H, int Ld) {
+  if (Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
+  return D == 256 && F == 1536 && D / H == 32 && fused_decode_lds_bytes(D, F, Ld, 16, true, 0, nullptr, true) <= 160 * 1024;
 }
 
 // sentences of 33..64 tokens over the packed cache (decode_fused_kernel<..., MID>)
@@ -2899,6 +3054,8 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   const int mid = (kv24 && D == 256 && a.S > 32) ? (a.S > 64 ? 2 : 1) : 0;  // 33..64 / 65..128-token sentences
   if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= (D == 256 ? 128 : 32))) return hipErrorInvalidValue;
   if (a.home_mask && rows != 16) return hipErrorInvalidValue;  // the XCD-affine claim counts 16-sentence tiles
+  // a batch with sentence-layers in the tight form: only the kernels with its reader (engine.cpp, kv_tight_wanted)
+  if (a.kv_tight && !(kv24 && a.kv_fmt && rows <= 16 && a.cluster <= 1 && D == 256 && F == 1536 && a.S <= 32)) return hipErrorInvalidValue;
   auto go = [&](void (*k)(FusedDecodeArgs), size_t lds) -> hipError_t {
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
     if (e != hipSuccess) return e;
@@ -2916,8 +3073,8 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   // every cache of this launch in the 24-bit form (a.kv_fmt == nullptr): the 16-sentence tilings have an instantiation
   // with that form inlined (KV20 = false); the 8- / 4-sentence ones reach it through the fallback call
 #define SLIMT_KV24_ONLY(KSD_, KSF_, DH_, MID_)                                                        \
-  (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_, 16, 1, false>          \
-           : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_, 16, 1, false>)
+  (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_, 16, 1, 24>          \
+           : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_, 16, 1, 24>)
   const bool only24 = kv24 && !a.kv_fmt && rows == 16 && a.cluster <= 1;
   if (mid) {
     if (rows > 16 || F != 1536) return hipErrorInvalidValue;
@@ -2926,7 +3083,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
     if (only24) return go(mid == 2 ? SLIMT_KV24_ONLY(4, 24, 32, 2) : SLIMT_KV24_ONLY(4, 24, 32, 1), ldsm);
     return go(mid == 2 ? SLIMT_KV24_PICK(4, 24, 32, 2) : SLIMT_KV24_PICK(4, 24, 32, 1), ldsm);
   }
-  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows <= 16 ? 16 : rows, kv24, 0, &a.ln_in_lds);
+  const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows <= 16 ? 16 : rows, kv24, 0, &a.ln_in_lds, a.kv_tight);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (kv24 && D == 512) {
     if (F != 2048) return hipErrorInvalidValue;
@@ -2939,13 +3096,20 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
                       : decode_fused_kernel<4, 24, 32, false, false, 1, true, 0, 16, 4>, lds);
   }
   if (only24) return go(SLIMT_KV24_ONLY(4, 24, 32, 0), lds);
+  if (kv24 && rows <= 16 && a.kv_tight) {  // sentences may be in the tight 16-bit form: the kernels with it (and the 20-bit one) inlined
+#define SLIMT_KV16_PICK(SPW_)                                                                      \
+  (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 0, SPW_, 1, 16>                  \
+           : decode_fused_kernel<4, 24, 32, false, false, 1, true, 0, SPW_, 1, 16>)
+    return go(rows == 4 ? SLIMT_KV16_PICK(4) : rows == 8 ? SLIMT_KV16_PICK(8) : SLIMT_KV16_PICK(16), lds);
+#undef SLIMT_KV16_PICK
+  }
   if (kv24 && rows <= 16) return go(SLIMT_KV24_PICK(4, 24, 32, 0), lds);
 #undef SLIMT_KV24_PICK
 #undef SLIMT_KV24_ONLY
   if (rows == 32) {
     if (kv24 && !a.kv_fmt)  // every cache in the 24-bit form: that form inlined (KV20 = false), as for the 16-sentence tilings
-      return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true, 0, 16, 1, false>
-                        : decode_fused_kernel<4, 24, 32, false, false, 2, true, 0, 16, 1, false>, lds);
+      return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true, 0, 16, 1, 24>
+                        : decode_fused_kernel<4, 24, 32, false, false, 2, true, 0, 16, 1, 24>, lds);
     auto k = kv24 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true> : decode_fused_kernel<4, 24, 32, false, false, 2, true>)
                   : (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 2>);
     return go(k, lds);

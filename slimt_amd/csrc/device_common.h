@@ -48,6 +48,11 @@ __device__ __forceinline__ Packed20 pack20(const v4i &a, const v4i &b) {
   o.hi = v4i{h[0], h[1], h[2], h[3]};
   return o;
 }
+// The tight form (kernels.h, FusedDecodeArgs::kv_tight): eight SIGNED accumulators, each in [-2^15, 2^15), as one quad of
+// int16 (value c in the low / high half of dword c / 2).
+__device__ __forceinline__ v4i pack16(const v4i &a, const v4i &b) {
+  return v4i{(a.x & 0xffff) | (a.y << 16), (a.z & 0xffff) | (a.w << 16), (b.x & 0xffff) | (b.y << 16), (b.z & 0xffff) | (b.w << 16)};
+}
 // does x fit the narrow form?
 __device__ __forceinline__ bool fits20(int x) { return (unsigned)(x + (1 << 19)) < (1u << 20); }
 constexpr int kKvNarrowMin = -(1 << 19), kKvNarrowMax = (1 << 19) - 1;

@@ -784,15 +784,20 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       }
     }
   }
-  // The packed cache takes one of two forms per workgroup and layer (kernels.h, FusedDecodeArgs::kv_fmt): the narrow one,
-  // 20 bits per value, when every K and V accumulator of this workgroup's rows lies in [-limit, limit), else 24 bits.
-  // The narrow form is tried first; an accumulator that does not fit (seen by its lane while the tile is staged) raises
-  // kv_wide_flag, every thread reads it behind the staging barrier, and the layer's K and V are produced again in the
-  // 24-bit form over whatever the narrow attempt wrote. Both forms hold the same integers.
+  // The packed cache takes one of three forms per workgroup and layer (kernels.h, FusedDecodeArgs::kv_fmt): the tight one,
+  // the SIGNED accumulators as int16, when every K and V accumulator of this workgroup's rows lies in [-2^15, 2^15) (tried
+  // only where the decoder has a reader for it and the engine's watch says sentences mostly take it: kv_tight_limit > 0);
+  // the narrow one, 20 bits per value, when every shifted accumulator lies in [-limit, limit); else 24 bits. The smallest
+  // form allowed is tried first; an accumulator that does not fit (seen by its lane while the tile is staged) raises its
+  // bit of kv_wide_flag (1: not tight, 2: not narrow), every thread reads the flag behind the staging barrier, and the
+  // layer's K and V are produced again in the smallest form that holds them, over whatever the attempt wrote. All forms
+  // hold the same integers.
   const bool try_narrow = a.kv24 && a.kv_fmt != nullptr;
   for (int l = 0; l < a.Ld; ++l) {
-    bool wide = !try_narrow;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool try_tight = NKT == 2 && try_narrow && a.kv_tight_limit > 0 && ((a.kv_tight_layers >> l) & 1u);
+    int form = !try_narrow ? 1 : try_tight ? 2 : 0;  // kv_fmt's codes
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      const bool wide = form == 1;
       bool redo = false;
       for (int p = 0; p < 2; ++p) {
         SLIMT_TPHASE_LANE;
@@ -805,25 +810,35 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         // the packing loop of the projection before, or of FFN1's; the staging tile is not written until the barrier below)
         if (!a.kv24) lds_barrier();  // the A buffer and the region are free
         quantise_x(0, w.a_quant, tq_base(lane));
-        // (the flag is raised behind the barrier below only; it can still be 1 from the layer before, whose narrow attempt
-        // was then followed by a whole 24-bit one: every thread has read it long ago)
+        // (the flag is raised behind the barrier below only; it can still be set from the layer before, whose attempt
+        // was then followed by a whole wider one: every thread has read it long ago)
         if (!wide && p == 0 && tid == 0) kv_wide_flag = 0;
         lds_barrier();
         const int col = wave * 16 + lg * 4;
         const AFrag af = a_frag(Aq, lane);
         const v4i skv = tshift(e);
-        int *stg = reinterpret_cast<int *>(region);  // packed cache: [TR][LDY] shifted accumulators
-        unsigned outside = 0;  // narrow attempt: an accumulator of a valid row outside [-limit, limit)
-        const unsigned lim = (unsigned)a.kv_narrow_limit;
+        int *stg = reinterpret_cast<int *>(region);  // packed cache: [TR][LDY] shifted accumulators (tight: the signed ones)
+        unsigned outside = 0;  // an accumulator of a valid row outside the form's range
+        const unsigned lim = (unsigned)a.kv_narrow_limit, lim16 = (unsigned)a.kv_tight_limit;
 #pragma unroll
         for (int rt = 0; rt < TRT; ++rt) {
           const v4i c = mma_rt(wf, rt, af, skv);
           const int rrow = 16 * rt + lr;
           if (a.kv24) {
-            *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = c;
-            if (!wide && row_valid(rrow)) {
+            if (NKT == 2 && form == 2) {
+              const v4i sg = c - skv;  // acc itself
+              *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = sg;
+              if (row_valid(rrow)) {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) outside |= (unsigned)((unsigned)c[i] + lim >= 2u * lim);
+                for (int i = 0; i < 4; ++i)
+                  outside |= (unsigned)((unsigned)sg[i] + lim16 >= 2u * lim16) | (unsigned)((unsigned)c[i] + lim >= 2u * lim) << 1;
+              }
+            } else {
+              *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = c;
+              if (!wide && row_valid(rrow)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) outside |= (unsigned)((unsigned)c[i] + lim >= 2u * lim) << 1;
+              }
             }
           } else if (row_valid(rrow)) {
             // c is the shifted accumulator accS: the cache holds float(accS), exact (kernels.h, kv24)
@@ -837,13 +852,53 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           }
         }
         if (!a.kv24) continue;
-        if (outside) kv_wide_flag = 1;
+        if (outside) __hip_atomic_fetch_or(&kv_wide_flag, (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lds_barrier();
-        if (!wide && kv_wide_flag) {  // uniform: read by every thread behind the barrier
+        // (uniform: read by every thread behind the barrier. A tight attempt looks at both ranges at once to know where
+        // to go if it fails; when it holds, the shifted accumulators' range does not matter)
+        if (!wide && (kv_wide_flag & (form == 2 ? 1 : 2))) {
           redo = true;
+          form = (kv_wide_flag & 2) ? 1 : 0;
           break;
         }
         const int Sp = (S + 3) & ~3;
+        if (NKT == 2 && form == 2) {
+          // the tight form (decode_fused.hip, attention_row16): one thread = 32 values = four quads of int16
+          if (p == 0) {  // K [sentence][head][plane 0..3][key][16 B]: consecutive lanes = consecutive keys
+            const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * S * D * 3));
+            for (int it = tid; it < TR * (D / 32); it += 1024) {
+              const int r = it % TR, h = it / TR;
+              if (!row_valid(r)) continue;
+              const int off = row_sentence(r) * S * D * 3 + (h * 4 * S + r % S) * 16;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const v4i pk = pack16(*reinterpret_cast<const v4i *>(stg + r * LDY + 32 * h + 8 * q),
+                                      *reinterpret_cast<const v4i *>(stg + r * LDY + 32 * h + 8 * q + 4));
+                if (a.kv_store_nt) __builtin_amdgcn_raw_buffer_store_b128(pk, ro, off + q * S * 16, 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(pk, ro, off + q * S * 16, 0, 0);
+              }
+            }
+          } else {  // V [sentence][key / 8][plane 0..3][column / 4][16 B]: key pairs x 4 columns, key-major
+            const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * Sp * D * 3));
+            const int G = (S + 7) >> 3;
+            for (int it = tid; it < spw * G * 64; it += 1024) {
+              const int cl = it & 63, g = (it >> 6) % G, si = (it >> 6) / G;
+              if (s0 + si >= B) continue;
+              const int off = (s0 + si) * Sp * D * 3 + (g * 4 * 64 + cl) * 16;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {  // keys past the sentence: acc = -127 colsum, accS = 0 (finite, weight 0)
+                const int k0 = 8 * g + 2 * q, k1 = k0 + 1;
+                const v4i z = {0, 0, 0, 0};
+                const v4i x0 = *reinterpret_cast<const v4i *>(stg + (si * S + (k0 < S ? k0 : 0)) * LDY + 4 * cl);
+                const v4i x1 = *reinterpret_cast<const v4i *>(stg + (si * S + (k1 < S ? k1 : 0)) * LDY + 4 * cl);
+                const v4i pk = pack16(k0 < S ? x0 : z, k1 < S ? x1 : z);
+                if (a.kv_store_nt) __builtin_amdgcn_raw_buffer_store_b128(pk, ro, off + q * 1024, 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(pk, ro, off + q * 1024, 0, 0);
+              }
+            }
+          }
+          continue;
+        }
         if (!wide) {
           // the narrow form (decode_fused.hip, attention_row20): one thread = 32 values = four quads of hi halves + one
           // quad of lo nibbles
@@ -944,11 +999,12 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         }
       }
       if (!redo) break;
-      wide = true;
     }
     if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) {
-      a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
-      if (wide && a.kv_wide_count) __hip_atomic_fetch_add(a.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      a.kv_fmt[(size_t)l * B + s0 + tid] = (unsigned char)form;
+      if (form == 1 && a.kv_wide_count) __hip_atomic_fetch_add(a.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (try_tight && form != 2 && a.kv_not16_count)
+        __hip_atomic_fetch_add(a.kv_not16_count + l, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   if (gen_here) {

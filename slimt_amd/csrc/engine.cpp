@@ -82,6 +82,48 @@ static bool kv_narrow_wanted(slimt_hip_model *m, unsigned long long **count_dev)
   return true;
 }
 
+// The tight form for this batch's decoder layers (engine.h, kv_tight_off): a mask of the layers that try it. Only where the
+// decoder launch that follows will be one with the reader inlined: the D = 256 / F = 1536 tilings of 16 / 8 / 4 sentences
+// (not the 32-sentence tiling a large output layer takes, not clusters), S <= 32, written by the 64-row encoder.
+static unsigned kv_tight_wanted(slimt_hip_ctx *c, int S, bool tall, unsigned long long **count_dev) {
+  slimt_hip_model *m = c->model;
+  *count_dev = nullptr;
+  static const bool enabled = !(std::getenv("SLIMT_KV_TIGHT") && std::getenv("SLIMT_KV_TIGHT")[0] == '0');
+  if (!enabled || !tall || S > 32 || m->kv_tight_limit <= 0 || !m->kv_wide_count) return 0;
+  // (mode 0 takes the 32-sentence tiling for a large output layer: known at the decoder launch only -- what this context's
+  // last one saw stands in for it; a wrong guess costs that one batch the 16-sentence tiling)
+  if (!((c->decode_mode == 0 && !c->expect_large_output) || c->decode_mode == 2 || c->decode_mode == 4 || c->decode_mode == 5)) return 0;
+  if (!fused_decode_tight_supported(m->D, m->F, m->H, m->Ld)) return 0;
+  static const bool watch = !(std::getenv("SLIMT_KV_WATCH") && std::getenv("SLIMT_KV_WATCH")[0] == '0');
+  unsigned off = m->kv_tight_off.load(std::memory_order_relaxed);
+  for (int l = 0; l < m->Ld && watch; ++l) {
+    const unsigned long long missed = static_cast<volatile unsigned long long *>(m->kv_wide_count)[1 + l];
+    const unsigned long long total = m->kv_tight_submitted[l].load(std::memory_order_relaxed);
+    if (!((off >> l) & 1u) && total >= 1024 && missed * 2 > total) {
+      off |= 1u << l;
+      m->kv_tight_off.fetch_or(1u << l, std::memory_order_relaxed);
+    }
+  }
+  const unsigned layers = ((1u << m->Ld) - 1u) & ~off;
+  if (!layers) return 0;
+  void *dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, m->kv_wide_count, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  *count_dev = static_cast<unsigned long long *>(dev) + 1;
+  return layers;
+}
+
+static void kv_watch_restart(slimt_hip_model *model) {
+  model->kv_auto_wide.store(false, std::memory_order_relaxed);
+  model->kv_layers_submitted.store(0, std::memory_order_relaxed);
+  model->kv_tight_off.store(0, std::memory_order_relaxed);
+  for (auto &n : model->kv_tight_submitted) n.store(0, std::memory_order_relaxed);
+  if (model->kv_wide_count)
+    for (int i = 0; i < 8; ++i) static_cast<volatile unsigned long long *>(model->kv_wide_count)[i] = 0;
+}
+
 hipError_t DevBuf::reserve(size_t n) {
   if (n <= bytes && p) return hipSuccess;
   g_hip_called.store(true, std::memory_order_relaxed);
@@ -769,10 +811,7 @@ extern "C" int slimt_hip_model_set_kv_cache_format(slimt_hip_model *model, int f
   if (format < 0 || format > 3) return fail(-1, "K/V cache format %d not in 0..3", format);
   std::lock_guard<std::mutex> lock(model->gate_mu);
   model->kv_format = format;
-  // choosing a format starts format 0's watch afresh (engine.h, kv_auto_wide)
-  model->kv_auto_wide.store(false, std::memory_order_relaxed);
-  model->kv_layers_submitted.store(0, std::memory_order_relaxed);
-  if (model->kv_wide_count) *static_cast<volatile unsigned long long *>(model->kv_wide_count) = 0;
+  kv_watch_restart(model);  // choosing a format starts format 0's watches afresh (engine.h, kv_auto_wide)
   return 0;
 }
 
@@ -837,9 +876,26 @@ extern "C" int slimt_hip_debug_kv_narrow_limit(slimt_hip_model *model, int limit
   if (limit < 1 || limit > (1 << 19)) return fail(-1, "narrow-form limit %d not in 1..2^19 (20 bits hold [-2^19, 2^19))", limit);
   std::lock_guard<std::mutex> lock(model->gate_mu);
   model->kv_narrow_limit = limit;
-  model->kv_auto_wide.store(false, std::memory_order_relaxed);  // (a new limit: the watch starts afresh)
-  model->kv_layers_submitted.store(0, std::memory_order_relaxed);
-  if (model->kv_wide_count) *static_cast<volatile unsigned long long *>(model->kv_wide_count) = 0;
+  kv_watch_restart(model);  // (a new limit: the watch starts afresh)
+  return 0;
+}
+
+extern "C" int slimt_hip_debug_kv_tight_limit(slimt_hip_model *model, int limit) {
+  if (!model) return fail(-1, "model is NULL");
+  if (limit < 0 || limit > (1 << 15)) return fail(-1, "tight-form limit %d not in 0..2^15 (int16 holds [-2^15, 2^15); 0 = never tried)", limit);
+  std::lock_guard<std::mutex> lock(model->gate_mu);
+  model->kv_tight_limit = limit;
+  kv_watch_restart(model);
+  return 0;
+}
+
+extern "C" int slimt_hip_debug_kv_tight_watch(slimt_hip_model *model, unsigned *layers_off, uint64_t *missed, uint64_t *submitted) {
+  if (!model) return fail(-1, "model is NULL");
+  if (layers_off) *layers_off = model->kv_tight_off.load(std::memory_order_relaxed);
+  for (int l = 0; l < 4; ++l) {
+    if (missed) missed[l] = model->kv_wide_count ? static_cast<volatile unsigned long long *>(model->kv_wide_count)[1 + l] : 0;
+    if (submitted) submitted[l] = model->kv_tight_submitted[l].load(std::memory_order_relaxed);
+  }
   return 0;
 }
 
@@ -1271,6 +1327,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
   const int M = B * S, D = m->D;
   const size_t nbytes = (size_t)M * D * 4;
   c->kv_fmt_valid = false;  // set below by the one path that records the forms of a packed cache
+  c->kv_tight = false;
   c->B = B;
   c->S = S;
   c->have_encoder_out = false;
@@ -1317,6 +1374,13 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.kv_narrow_limit = std::min(m->kv_narrow_limit, 1 << 19);
       c->kv_fmt_B = B;
       c->model->kv_layers_submitted.fetch_add((unsigned long long)B * m->Ld, std::memory_order_relaxed);
+      f.kv_tight_layers = kv_tight_wanted(c, S, tall_encoder_chosen(c, B, S), &f.kv_not16_count);
+      if (f.kv_tight_layers) {
+        f.kv_tight_limit = std::min(m->kv_tight_limit, 1 << 15);
+        c->kv_tight = true;
+        for (int l = 0; l < m->Ld; ++l)
+          if ((f.kv_tight_layers >> l) & 1u) c->model->kv_tight_submitted[l].fetch_add((unsigned long long)B, std::memory_order_relaxed);
+      }
     }
     f.enc_out = keep_out ? c->x0.as<float>() : nullptr;
     if (pack) {
@@ -1760,9 +1824,16 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     // skew between its waves + 6 us of hand-overs where the whole layer took 70, but the 32-sentence tiling's per-sentence
     // cost is lower still: the phase is bound by the arg-max epilogue's issue slots and the address path's load
     // instructions (six per column tile here, four and a half there), not by the bytes the split saves. So: on request only.
-    const bool clusters = cluster_ok && c->decode_mode == 6;
+    // a batch whose encoder was allowed the tight cache form: the tilings with its reader, whatever is asked for now (the
+    // encoder is only allowed it when this context's decoders take those: kv_tight_wanted; a mode changed between the two
+    // calls, or a first large output layer, ends up here)
+    const bool tight = kv24 && c->kv_tight && c->kv_fmt_valid && c->kv_fmt_B == (int)B;
+    const bool clusters = cluster_ok && c->decode_mode == 6 && !tight;
+    c->expect_large_output = n_expected > 16384;
+    f.kv_tight = tight;
     f.rows_per_wg = clusters ? 16 : c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : c->decode_mode == 4 ? 8 : c->decode_mode == 5 ? 4
                     : (n_expected > 16384 ? 32 : 0);
+    if (tight && f.rows_per_wg == 32) f.rows_per_wg = 16;
     int rows = fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, f.rows_per_wg, kv24);
     if (clusters) {
       const size_t tiles = (B + 15) / 16, n_clusters = (tiles + 3) / 4;
@@ -1854,7 +1925,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       // under this lock made every launch O(contexts) runtime calls, and with a dozen worker threads
       // the launches queued behind each other (Service, 16 workers: 9.9 ms per launch call).
       // (the narrow form is what the model's sentences are expected to take where the kernels have it: 2.5 bytes per value)
-      const double kv_bytes = (double)m->Ld * 2.0 * (double)B * (double)S * m->D * (f.kv_fmt ? 2.5 : kv24 ? 3.0 : 4.0);
+      const double kv_bytes = (double)m->Ld * 2.0 * (double)B * (double)S * m->D * (f.kv_tight ? 2.0 : f.kv_fmt ? 2.5 : kv24 ? 3.0 : 4.0);
       const auto now = std::chrono::steady_clock::now();
       double pending = kv_bytes;
       size_t contexts = 1;

@@ -109,6 +109,13 @@ struct slimt_hip_model {
   unsigned long long *kv_wide_count = nullptr;
   std::atomic<unsigned long long> kv_layers_submitted{0};
   std::atomic<bool> kv_auto_wide{false};
+  // The tight (16-bit) form below the narrow one (kernels.h, FusedDecodeArgs::kv_tight), per decoder layer: a sentence that
+  // tries it and does not fit costs its encoder workgroup a second K/V pass and its decoder wave the slower reader, so a
+  // layer whose sentences mostly do not fit stops trying (bit l of kv_tight_off; counters kv_wide_count[1 + l] on the
+  // device side, kv_tight_submitted[l] sentences on this one). kv_tight_limit: 2^15 (int16); tests lower it, 0 = never.
+  int kv_tight_limit = 1 << 15;
+  std::atomic<unsigned long long> kv_tight_submitted[4] = {};
+  std::atomic<unsigned> kv_tight_off{0};
 };
 
 struct slimt_hip_ctx {
@@ -148,6 +155,8 @@ struct slimt_hip_ctx {
   slimt_hip::DevBuf kv_fmt;  // [Ld][B] bytes: the form of each sentence-layer's packed cache (kernels.h, FusedDecodeArgs::kv_fmt)
   bool kv_fmt_valid = false;  // the encoder of the current batch recorded kv_fmt (else every cache is in the 24-bit form)
   int kv_fmt_B = 0;           // the batch size kv_fmt was recorded for
+  bool kv_tight = false;      // ... and some of its sentence-layers may be in the tight form: the decoder with its reader
+  bool expect_large_output = false;  // the last decoder launch of this context had an output layer of > 16384 columns (mode 0: the 32-sentence tiling, no tight reader)
   // decoder workspace
   slimt_hip::DevBuf dx, dx_pre, dh, datt8, dout, df8, state;
   slimt_hip::DevBuf part_val, part_idx;

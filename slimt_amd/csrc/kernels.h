@@ -331,6 +331,10 @@ struct FusedDecodeArgs {
   // encoder that filled the cache, FusedEncodeArgs::kv_fmt) says which: 0 = narrow, 1 = 24-bit; nullptr = all 24-bit.
   // Both forms give back the same integers, so results do not depend on it: 17 % fewer K/V bytes per step.
   const unsigned char *kv_fmt = nullptr;
+  // kv_fmt may hold 2 = the TIGHT form (D = 256, S <= 32): the SIGNED accumulator acc = accS - 127 colsum as plain int16
+  // (decode_fused.hip, attention_row16), for sentence-layers whose K and V all lie in [-2^15, 2^15). Set by the engine
+  // when this batch's encoder was allowed to write it: the launch then uses the kernels with that form inlined.
+  bool kv_tight = false;
   float kv_u4096[4][2] = {};      // [layer][K, V]: u / 4096 (narrow form: the integers come back as accS * 4096)
   const float *kv_pb[4][2] = {};  // [layer][K, V]: the projections' prepared biases [D] (both forms)
   const int *kv_cs[4][2] = {};    // [layer][K, V]: their column sums [D] (D = 512: the cache holds the signed accumulator)
@@ -362,6 +366,7 @@ int fused_decode_grid(int B, bool tickets, int rows);
 int fused_encode_grid(int B, int S, bool tickets);
 bool fused_decode_supported(int D, int F, int H, int Ld);
 bool fused_decode_mid_supported(int D, int F, int H, int Ld);
+bool fused_decode_tight_supported(int D, int F, int H, int Ld);
 bool fused_decode_long24_supported(int D, int F, int H, int Ld);
 int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced, bool kv24);
 hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st);
@@ -414,6 +419,11 @@ struct FusedEncodeArgs {
   // some sentences of a batch (never above 2^19)
   unsigned char *kv_fmt = nullptr;
   int kv_narrow_limit = 1 << 19;
+  // the tight 16-bit form (FusedDecodeArgs::kv_tight) is tried first in the decoder layers of kv_tight_layers (bit l):
+  // signed accumulators must lie in [-kv_tight_limit, kv_tight_limit) (2^15, what int16 holds; tests lower it); recorded as 2
+  int kv_tight_limit = 0;
+  unsigned kv_tight_layers = 0;
+  unsigned long long *kv_not16_count = nullptr;  // [Ld], like kv_wide_count: + 1 per sentence of layer l that tried and did not take the tight form
   // nullable, pinned host memory: + 1 per sentence-layer that took the 24-bit form (the engine watches the share: a model
   // whose accumulators mostly do not fit 20 bits is switched to the 24-bit form altogether, engine.cpp)
   unsigned long long *kv_wide_count = nullptr;

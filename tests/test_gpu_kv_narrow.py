@@ -32,14 +32,30 @@ def kv_accumulators(oracle, m, om, ids, lens):
     return acc
 
 
-def expected_forms(acc, limit, group):
+def signed_accumulators(m, acc):
+    """acc = accS - 127 colsum: what the tight (16-bit) form holds (kernels.h, FusedDecodeArgs::kv_tight)."""
+    out = acc.astype(np.int64)
+    for l in range(m.dec_layers):
+        for t, name in enumerate("kv"):
+            W = np.ascontiguousarray(m.params[f"decoder_l{l + 1}_context_W{name}"].data).reshape(m.D, m.D)  # payload [N][K]
+            out[l, t] -= 127 * W.astype(np.int64).sum(axis=1)[None, None, :]
+    return out
+
+
+def expected_forms(acc, limit, group, signed=None, tight_limit=0):
     """1 = 24-bit: some accumulator of the workgroup's sentences (`group` consecutive ones; every row, padding included)
-    outside [-limit, limit)."""
+    outside [-limit, limit); 2 = 16-bit, where the tight form is tried (tight_limit > 0): every SIGNED accumulator of
+    them in [-tight_limit, tight_limit); else 0 = 20-bit."""
     Ld, _, B = acc.shape[:3]
     outside = ((acc < -limit) | (acc >= limit)).any(axis=(1, 3, 4))  # [Ld][B]
     want = np.zeros((Ld, B), dtype=np.uint8)
     for s0 in range(0, B, group):
         want[:, s0:s0 + group] = outside[:, s0:s0 + group].any(axis=1, keepdims=True)
+    if tight_limit > 0:
+        out16 = ((signed < -tight_limit) | (signed >= tight_limit)).any(axis=(1, 3, 4))
+        for s0 in range(0, B, group):
+            fits = ~out16[:, s0:s0 + group].any(axis=1)
+            want[fits, s0:s0 + group] = 2
     return want
 
 
@@ -71,16 +87,27 @@ def test_forms_follow_the_accumulators_and_results_do_not(hip, oracle, synth_mod
         # limits: the real one, and three that split this batch's sentences (the median peak, its neighbours)
         order = np.sort(peak.ravel())
         limits = [2 ** 19, int(order[len(order) // 2]), int(order[len(order) // 4]) + 1, int(order[-1]), int(order[-1]) + 1, 1]
-        for limit in limits:
+        # the tight (16-bit) form: written by the 64-row encoder for sentences of up to 32 tokens, read by the tilings of
+        # 16 / 8 / 4 sentences (modes 0, 2, 4, 5); its limits likewise: int16's, two that split the batch, none
+        signed = signed_accumulators(m, acc)
+        tight_here = preset == "tiny11" and S <= 32 and rows == 64
+        order16 = np.sort(np.abs(signed).max(axis=(1, 3, 4)).ravel())
+        tights = [2 ** 15, int(order16[len(order16) // 2]), int(order16[len(order16) // 4]) + 1, int(order16[-1]) + 1, 0, 1]
+        tights = [min(t, 2 ** 15) for t in tights]
+        seen_forms = set()
+        for limit, tight in zip(limits, tights):
             gm.debug_kv_narrow_limit(limit)
-            forms = expected_forms(acc, limit, group)
+            gm.debug_kv_tight_limit(tight)
             # 16 / 32 / 8 / 4 sentences per decoder workgroup (32: tiny11's sentences of up to 32 tokens only)
-            for mode in ((2, 3, 4, 5) if preset == "tiny11" and S <= 32 else (2, 4, 5)):
+            for mode in ((2, 3, 4, 5, 0) if preset == "tiny11" and S <= 32 else (2, 4, 5)):
+                forms = expected_forms(acc, limit, group, signed, tight if tight_here and mode != 3 else 0)
                 ctx.set_decode_mode(mode)
                 got = ctx.translate(ids, lens, sl, want_align=True)
-                assert all(np.array_equal(a, b) for a, b in zip(got, want)), (limit, mode)
+                assert all(np.array_equal(a, b) for a, b in zip(got, want)), (limit, tight, mode)
                 seen = ctx.debug_kv_formats(m.dec_layers, B)
-                assert seen is not None and np.array_equal(seen, forms), (limit, mode, seen, forms)
+                assert seen is not None and np.array_equal(seen, forms), (limit, tight, mode, seen, forms)
+                seen_forms |= set(np.unique(seen).tolist())
+        assert seen_forms == ({0, 1, 2} if tight_here else {0, 1}), seen_forms
         assert expected_forms(acc, limits[1], group).any() and not expected_forms(acc, 2 ** 19, group).any()
         # the other cache formats record nothing and give the same results
         for fmt in (2, 1):
@@ -138,6 +165,11 @@ def test_an_accumulator_past_2_19_sends_its_sentences_to_the_24_bit_form(hip, or
         assert np.array_equal(acc[:, :, :, :, 1:], base[:, :, :, :, 1:])  # only column 0 moved
         forms = expected_forms(acc, 2 ** 19, group)
         assert forms.any() and not forms.all(), picked
+        # Where the tight form is tried (64-row encoder, not the 32-sentence tiling) it holds the SIGNED accumulator: a
+        # sentence whose shifted accumulator passes 2^19 through 127 colsum alone still fits int16 -- the 24-bit form is then
+        # only for those whose data-dependent part is large too
+        forms16 = expected_forms(acc, 2 ** 19, group, signed_accumulators(m, acc), 2 ** 15)
+        assert (forms16[forms == 0] != 1).all()
         assert np.abs(acc.astype(np.int64)).max() < 2 ** 23
         sl = synth.make_shortlist(m.V, 640)
         oracle.set_mode(oracle.PORTABLE)
@@ -150,7 +182,7 @@ def test_an_accumulator_past_2_19_sends_its_sentences_to_the_24_bit_form(hip, or
                 gm.set_kv_cache_policy(policy)
                 got = ctx.translate(ids, lens, sl, want_align=True)
                 assert all(np.array_equal(a, b) for a, b in zip(got, want)), (mode, policy)
-                assert np.array_equal(ctx.debug_kv_formats(m.dec_layers, B), forms), (mode, policy)
+                assert np.array_equal(ctx.debug_kv_formats(m.dec_layers, B), forms16 if rows == 64 and mode != 3 else forms), (mode, policy)
     finally:
         ctx.close()
         gm.close()
@@ -164,6 +196,11 @@ def test_narrow_limit_is_bounded(hip, synth_models):
             with pytest.raises(hip.SlimtHipError):
                 gm.debug_kv_narrow_limit(bad)
         gm.debug_kv_narrow_limit(2 ** 19)
+        for bad in (-1, 2 ** 15 + 1):
+            with pytest.raises(hip.SlimtHipError):
+                gm.debug_kv_tight_limit(bad)
+        gm.debug_kv_tight_limit(0)
+        gm.debug_kv_tight_limit(2 ** 15)
     finally:
         gm.close()
 
@@ -237,6 +274,50 @@ def test_a_model_that_mostly_needs_24_bits_is_switched_to_them(hip, oracle, synt
         got = ctx.translate(ids, lens, sl, want_align=True)
         assert all(np.array_equal(a, b) for a, b in zip(got, want))
         assert not gm.debug_kv_watch()[0] and ctx.debug_kv_formats(m.dec_layers, B) is not None
+    finally:
+        ctx.close()
+        gm.close()
+
+
+def test_a_layer_whose_sentences_mostly_miss_the_tight_form_stops_trying(hip, oracle, synth_models):
+    """The tight form has its own watch, per decoder layer (include/slimt_hip.h, slimt_hip_debug_kv_tight_watch): a sentence
+    that tries it and misses costs its encoder workgroup a second pass over the layer's K and V, so a layer where more than
+    half of 1024 sentences missed (here: all of them, by a tight limit of 1) goes back to starting with the 20-bit form.
+    Results never change; the synthetic model at the real limit keeps trying."""
+    from slimt_amd import synth
+    m = synth_models("tiny11", 6.0)
+    gm, om = hip.Model(m), oracle.OracleModel(m)
+    B, S = 64, 32  # (the 64-row encoder: 32 workgroups)
+    ctx = hip.Context(gm, B, S)
+    try:
+        ids, lens = synth.make_batch(m.V, B, S, seed=909, ragged=True)
+        sl = synth.make_shortlist(m.V, 640)
+        oracle.set_mode(oracle.PORTABLE)
+        want = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
+        oracle.set_mode(oracle.FAITHFUL)
+        acc = kv_accumulators(oracle, m, om, ids, lens)
+        forms = expected_forms(acc, 2 ** 19, 2, signed_accumulators(m, acc), 2 ** 15)
+        assert (forms == 2).mean() > 0.5  # the synthetic model: most sentence-layers are this small
+        for _ in range(20):
+            got = ctx.translate(ids, lens, sl, want_align=True)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        off, missed, tried = gm.debug_kv_tight_watch()
+        assert off == 0 and tried[:2] == [20 * B, 20 * B] and missed[:2] == [20 * int((forms[l] != 2).sum()) for l in range(2)]
+        assert np.array_equal(ctx.debug_kv_formats(m.dec_layers, B), forms)
+        gm.debug_kv_tight_limit(1)
+        n = 0
+        while gm.debug_kv_tight_watch()[0] != 3:
+            got = ctx.translate(ids, lens, sl, want_align=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), n
+            n += 1
+            assert n <= 40, gm.debug_kv_tight_watch()
+        assert n * B >= 1024
+        for _ in range(2):
+            got = ctx.translate(ids, lens, sl, want_align=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want))
+            assert not ctx.debug_kv_formats(m.dec_layers, B).any()  # every sentence-layer in the 20-bit form, first try
+        _, missed, tried = gm.debug_kv_tight_watch()
+        assert missed[:2] == tried[:2]  # (nobody tried any more)
     finally:
         ctx.close()
         gm.close()
