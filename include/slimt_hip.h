@@ -447,14 +447,27 @@ int slimt_hip_debug_kv_watch(slimt_hip_model *model, int *switched_to_24_bit, ui
 int slimt_hip_debug_kv_narrow_limit(slimt_hip_model *model, int limit);
 /* Diagnostic: the tight (16-bit) form below the 20-bit one. Where the decoder has a reader for it (D = 256 /
  * F = 1536, sentences of at most 32 tokens, the tilings of 16 / 8 / 4 sentences) format 0 caches a
- * sentence-layer whose SIGNED K and V accumulators all lie in [-limit, limit) as plain int16 (default
- * and maximum 2^15; 0 = never tried; tests lower it so that a batch mixes all three forms). Results do
- * not depend on it. Starts the watches afresh. */
+ * sentence-layer whose K and V accumulators, less their columns' centres (slimt_hip_model_set_kv_centres),
+ * all lie in [-limit, limit) as plain int16 (default and maximum 2^15; 0 = never tried; tests lower it so
+ * that a batch mixes all three forms). Results do not depend on it. Starts the watches afresh. */
 int slimt_hip_debug_kv_tight_limit(slimt_hip_model *model, int limit);
+/* The tight form's per-column centres, [Ld][K, V][D] int32 (n = Ld * 2 * D, each within (-2^23, 2^23)):
+ * the 16-bit form caches accumulator - centre, the decoder adds the centre back (exact), so the centres
+ * decide which sentences fit the form and nothing else -- every result is the same for any centres.
+ * Without this call the library calibrates them itself: the first batch of at least 2048 rows that could
+ * take the form is cached as f32, its column means (floor(sum / rows + 1/2), integer arithmetic) become
+ * the centres, and the form is tried from the first batch submitted after that reduction has finished.
+ * Call it before the first translate, or with no batch of this model in flight; it fails while a
+ * calibration batch is in flight. A deployment that wants the same form for the same sentence on
+ * every run sets centres it has stored (slimt_hip_debug_kv_centres reads the calibrated ones). */
+int slimt_hip_model_set_kv_centres(slimt_hip_model *model, const int32_t *centres, size_t n);
+/* Diagnostic: *ready = 1 and out[0 .. Ld * 2 * D) = the centres once they exist (set, or calibrated and
+ * the reduction finished), else *ready = 0. out may be NULL (state only). */
+int slimt_hip_debug_kv_centres(slimt_hip_model *model, int32_t *out, size_t n, int *ready);
 /* Diagnostic: the tight form's watch, per decoder layer l < 4: submitted[l] sentences were allowed to
  * try it, missed[l] of them did not fit (updated by the device, a few batches behind); once more than
- * half of a layer's sentences missed (after 1024 were submitted) that layer stops trying (bit l of
- * *layers_off). Any pointer may be NULL; the arrays hold 4 entries. */
+ * one in 32 of a layer's sentences missed (after 1024 were submitted) that layer stops trying (bit l of
+ * *layers_off): the 20-bit form is an out-of-line fallback in the kernels with the tight reader. Any pointer may be NULL; the arrays hold 4 entries. */
 int slimt_hip_debug_kv_tight_watch(slimt_hip_model *model, unsigned *layers_off, uint64_t *missed, uint64_t *submitted);
 /* Diagnostic (process-wide): while device_buf != NULL, thread 0 of every
  * workgroup of the persistent encoder / decoder appends a begin and an end

@@ -27,7 +27,7 @@ SYMBOLS = [
     "slimt_hip_ctx_synchronize", "slimt_hip_ctx_set_decode_mode", "slimt_hip_ctx_set_encode_rows", "slimt_hip_ctx_plan", "slimt_hip_translate", "slimt_hip_translate_device",
     "slimt_hip_encode", "slimt_hip_decode_begin", "slimt_hip_decode_step",
     "slimt_hip_profile_enable", "slimt_hip_profile_read", "slimt_hip_profile_reset",
-    "slimt_hip_debug_decode_stamps", "slimt_hip_debug_kv_formats", "slimt_hip_debug_kv_narrow_limit", "slimt_hip_debug_kv_tight_limit", "slimt_hip_debug_kv_tight_watch", "slimt_hip_debug_kv_watch", "slimt_hip_debug_break_shortlist_handoff", "slimt_hip_debug_cross_attention",
+    "slimt_hip_debug_decode_stamps", "slimt_hip_debug_kv_formats", "slimt_hip_debug_kv_narrow_limit", "slimt_hip_debug_kv_tight_limit", "slimt_hip_debug_kv_tight_watch", "slimt_hip_debug_kv_centres", "slimt_hip_model_set_kv_centres", "slimt_hip_debug_kv_watch", "slimt_hip_debug_break_shortlist_handoff", "slimt_hip_debug_cross_attention",
     "slimt_hip_debug_occupancy_trace", "slimt_hip_model_set_decoder_budget",
     "slimt_hip_model_set_kv_cache_policy",
     "slimt_hip_model_set_xcd_affinity", "slimt_hip_model_device",
@@ -199,6 +199,8 @@ def lib():
     L.slimt_hip_debug_kv_watch.argtypes = [vp, vp, vp, vp]
     L.slimt_hip_debug_kv_tight_limit.argtypes = [vp, i32]
     L.slimt_hip_debug_kv_tight_watch.argtypes = [vp, vp, vp, vp]
+    L.slimt_hip_debug_kv_centres.argtypes = [vp, vp, sz, vp]
+    L.slimt_hip_model_set_kv_centres.argtypes = [vp, vp, sz]
     L.slimt_hip_debug_break_shortlist_handoff.argtypes = [vp, i32, u32]
     L.slimt_hip_debug_cross_attention.argtypes = [vp, i32, i32, vp, vp, vp]
     L.slimt_hip_model_set_decoder_budget.argtypes = [vp, i32]
@@ -419,6 +421,17 @@ class Model:
     def debug_kv_tight_limit(self, limit: int):
         """Signed accumulators must lie in [-limit, limit) for the 16-bit cache form (default and maximum 2**15; 0 = never tried)."""
         _chk(lib().slimt_hip_debug_kv_tight_limit(self.h, int(limit)))
+
+    def set_kv_centres(self, centres):
+        """The 16-bit cache form's per-column centres, int32 [Ld][2][D] (else calibrated from the first large batch)."""
+        c = np.ascontiguousarray(centres, dtype=np.int32)
+        _chk(lib().slimt_hip_model_set_kv_centres(self.h, c.ctypes.data_as(C.c_void_p), c.size))
+
+    def debug_kv_centres(self, Ld: int, D: int):
+        """The centres [Ld][2][D] once they exist, else None."""
+        out, ready = np.zeros((Ld, 2, D), dtype=np.int32), C.c_int(0)
+        _chk(lib().slimt_hip_debug_kv_centres(self.h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(ready)))
+        return out if ready.value else None
 
     def debug_kv_tight_watch(self):
         """(mask of decoder layers that stopped trying the 16-bit form, missed[4], submitted[4])."""

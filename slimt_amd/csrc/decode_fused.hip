@@ -1163,26 +1163,36 @@ __device__ __forceinline__ void attention_row20(AttnRow r, int lane, lcf_ptr pbk
       pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
 }
 
+// attention_row20 out of line (see attention_row24_cold): the fallback of the tight form (the KVI = 16 kernels).
+template <int KV_AUX>
+__device__ __noinline__ void attention_row20_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096, float uv4096) {
+  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
+  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
+  r.S = __builtin_amdgcn_readfirstlane(r.S);
+  r.len = __builtin_amdgcn_readfirstlane(r.len);
+  attention_row20<KV_AUX>(r, lane, pbk, pbv, uk4096, uv4096);
+}
+
 // ---- the tight form of the packed cache: 16 bits per value (kernels.h, FusedDecodeArgs::kv_fmt == 2) ------------------
-// A sentence-layer whose SIGNED K and V accumulators (acc = accS - 127 colsum, what the MFMA itself produces) all lie in
-// [-2^15, 2^15) is cached as plain int16: 2 instead of 2.5 bytes per value, 4 instead of 5 loads per 32 values, and the
-// cheapest unpack of the three forms -- the conversion reads its half of the register itself (v_cvt_f32_i32 with an SDWA
-// word select: no extract at all), and float(accS) = float(acc) + float(127 colsum) is one EXACT addition (both floats are
-// integers, their sum is accS, |accS| < 2^24), half a packed add per value: 1.5 instructions per value where the 20-bit
-// form spends 2.4 and the 24-bit one 2. The column terms c127[d] = float(127 colsum[d]) live in LDS next to the prepared
-// biases. The chains then run over float(accS) itself (no power of two to take out: plain u). Timing-only bound, every
-// sentence in this form: 35.9 -> 38.8 M tok/s (profiles/r05_kv16_bound_timing_only.txt). Whether a model's accumulators are
-// that small depends on its multipliers (sigma(acc) = sqrt(K) sigma(q) sigma(W)); the encoders try this form only while
-// the engine's watch says most sentences take it, and the 20-bit form is inlined next to it.
+// A sentence-layer whose K and V accumulators, less their columns' centres (r = accS - centre[d]; kernels.h,
+// FusedDecodeArgs::kv_centre: the column means of a calibration batch), all lie in [-2^15, 2^15) is cached as plain
+// int16: 2 instead of 2.5 bytes per value, 4 instead of 5 loads per 32 values, and the cheapest unpack of the three
+// forms -- the conversion reads its half of the register itself (v_cvt_f32_i32 with an SDWA word select: no extract at
+// all), and float(accS) = float(r) + float(centre) is one EXACT addition (both floats are integers, their sum is accS,
+// everything below 2^24), half a packed add per value: 1.5 instructions per value where the 20-bit form spends 2.4 and
+// the 24-bit one 2. The centres live in LDS as floats next to the prepared biases (their reads cost nothing measurable:
+// profiles/r05_kv16_variants.txt). The chains then run over float(accS) itself (no power of two to take out: plain u).
+// This is the ONE form inlined in its kernels (KVI = 16); the 20- and the 24-bit ones are out-of-line fallbacks there:
+// a second inlined body costs the register allocator 11..26 spilled registers and a third of the form's gain (same file).
 //   K [head][plane 0..3][S][16 B]            plane p: the head's columns 8 p .. 8 p + 7 of one key (eight int16)
 //   V [ceil(S / 8)][plane 0..3][D/4][16 B]   plane p: keys 8 g + 2 p, 8 g + 2 p + 1 x 4 consecutive columns (key-major)
-// ck / cv: c127 of the K / V projection [D] in LDS.
-struct C127Lds {  // float(127 colsum[d]) prepared in LDS (the kernels with this form inlined)
+// ck / cv: the centres of the K / V projection [D] in LDS, as floats.
+struct CentreLds {
   lcf_ptr p;
   __device__ __forceinline__ f4 at4(int d) const { return *(lcf4_ptr)(p + d); }
 };
-template <int KV_AUX, typename C127>
-__device__ __forceinline__ void attention_row16(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, C127 ck, C127 cv) {
+template <int KV_AUX, typename Centres>
+__device__ __forceinline__ void attention_row16(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, Centres ck, Centres cv) {
   constexpr int D = 256, DH = 32, H = D / DH;
   const int S = r.S, len = r.len;
   const int lenf = len > 0 ? len : S;
@@ -1208,7 +1218,7 @@ __device__ __forceinline__ void attention_row16(AttnRow r, int lane, lcf_ptr pbk
     for (int i = 0; i < 4; ++i)
       vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (4 * g + i) * 1024, KV_AUX));
   };
-  // two int16 of one register -> float(accS) of the two columns / keys: conversion in place + the exact column term
+  // two int16 of one register -> float(accS) of the two columns / keys: conversion in place + the column's centre (exact)
   auto pair16 = [](int d, f2 c) -> f2 {
     const f2 v = {(float)(short)(d & 0xffff), (float)(d >> 16)};
     return v + c;
@@ -1226,7 +1236,11 @@ __device__ __forceinline__ void attention_row16(AttnRow r, int lane, lcf_ptr pbk
     for (int i = 0; i < 4; ++i) {
       const int d0 = h * DH + 8 * i;
       const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
+#ifdef SLIMT_EXP_C127_CONST  // timing only (wrong results): the K pass without its column terms' LDS reads
+      const f4 ca = {1024.0f, 2048.0f, 1024.0f, 2048.0f}, cb = ca;
+#else
       const f4 ca = ck.at4(d0), cb = ck.at4(d0 + 4);
+#endif
       const f2 k01 = pair16(kq[i].x, f2{ca.x, ca.y}), k23 = pair16(kq[i].y, f2{ca.z, ca.w});
       const f2 k45 = pair16(kq[i].z, f2{cb.x, cb.y}), k67 = pair16(kq[i].w, f2{cb.z, cb.w});
       t = __builtin_fmaf(qa.x, k01.x, t);
@@ -2178,7 +2192,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr bool LN_LDS = KSD == 4 && RT == 1 && MID == 0;  // (MID: the LDS goes to the wider attention scratch)
   float *lnc = kvpb + (KV24 ? Ld * KVC * D : 0);
   const bool ln_lds = LN_LDS && a.ln_in_lds;  // (the launcher: only where the 160 KiB allow it)
-  float *kvc127 = lnc + (ln_lds ? Ld * 6 * D : 0);  // KVI == 16: [Ld][K, V][D] float(127 colsum) (attention_row16)
+  float *kvc127 = lnc + (ln_lds ? Ld * 6 * D : 0);  // KVI == 16: [Ld][K, V][D] float(centre) (attention_row16)
 
   // Which R sentences? With a ticket counter the grid is over-subscribed and the first
   // workgroups to START claim the tiles; the rest leave at once. A workgroup needs a whole
@@ -2282,7 +2296,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     }
   }
   if constexpr (KVI == 16) {
-    for (int i = tid; i < Ld * 2 * D; i += 1024) kvc127[i] = (float)__mul24(127, a.kv_cs[i / (2 * D)][(i / D) & 1][i % D]);
+    for (int i = tid; i < Ld * 2 * D; i += 1024) kvc127[i] = (float)a.kv_centre[i / (2 * D)][(i / D) & 1][i % D];
   }
   if constexpr (KV24) {
     if constexpr (KVC == 2) {
@@ -2530,17 +2544,26 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             } else {
             const unsigned forms = rr ? kv_wide[RT - 1] : kv_wide[0];
             const bool wide = (forms >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
+#ifdef SLIMT_EXP_TIGHT_ONLY  // timing only (wrong results unless every sentence-layer is tight): no other form in the KVI = 16 kernels
+            const bool tight = KVI == 16;
+#else
             const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
+#endif
             if (tight) {
               if constexpr (KVI == 16) {
-                const C127Lds ck = {(lcf_ptr)(kvc127 + (2 * l) * D)}, cv = {(lcf_ptr)(kvc127 + (2 * l + 1) * D)};
+                const CentreLds ck = {(lcf_ptr)(kvc127 + (2 * l) * D)}, cv = {(lcf_ptr)(kvc127 + (2 * l + 1) * D)};
                 if (NT && kv_streams)
                   attention_row16<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, ck, cv);
                 else
                   attention_row16<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, ck, cv);
               }  // (the other kernels never meet the form: the launcher refuses a tight batch, the engine never sends one)
             } else if (!wide) {
-              if (NT && kv_streams)
+              if constexpr (KVI == 16) {  // (the rare sentence-layer past the calibrated centres' int16)
+                if (NT && kv_streams)
+                  attention_row20_cold<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+                else
+                  attention_row20_cold<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+              } else if (NT && kv_streams)
                 attention_row20<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
               else
                 attention_row20<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);

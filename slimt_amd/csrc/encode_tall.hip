@@ -826,12 +826,15 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           const int rrow = 16 * rt + lr;
           if (a.kv24) {
             if (NKT == 2 && form == 2) {
-              const v4i sg = c - skv;  // acc itself
+              const v4i sg = c - *reinterpret_cast<const v4i *>(a.kv_centre[l][p] + col);  // less the columns' centres
               *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = sg;
               if (row_valid(rrow)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                   outside |= (unsigned)((unsigned)sg[i] + lim16 >= 2u * lim16) | (unsigned)((unsigned)c[i] + lim >= 2u * lim) << 1;
+#ifdef SLIMT_EXP_TIGHT_ALL  // timing only (wrong results): every sentence-layer takes the tight form
+                outside &= 2u;
+#endif
               }
             } else {
               *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = c;

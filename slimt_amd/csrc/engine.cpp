@@ -82,24 +82,46 @@ static bool kv_narrow_wanted(slimt_hip_model *m, unsigned long long **count_dev)
   return true;
 }
 
+static bool kv_tight_enabled() {
+  static const bool enabled = !(std::getenv("SLIMT_KV_TIGHT") && std::getenv("SLIMT_KV_TIGHT")[0] == '0');
+  return enabled;
+}
+
+// Where the tight form has a writer and a reader: the D = 256 / F = 1536 tilings of 16 / 8 / 4 sentences (not the 32-sentence
+// tiling a large output layer takes, not clusters), S <= 32, the 64-row encoder.
+static bool kv_tight_shape(const slimt_hip_ctx *c, int S, bool tall) {
+  const slimt_hip_model *m = c->model;
+  if (!kv_tight_enabled() || !tall || S > 32 || m->kv_tight_limit <= 0 || m->kv_format != 0) return false;
+  // (mode 0 takes the 32-sentence tiling for a large output layer: known at the decoder launch only -- what this context's
+  // last one saw stands in for it; a wrong guess costs that one batch the 16-sentence tiling)
+  if (!((c->decode_mode == 0 && !c->expect_large_output) || c->decode_mode == 2 || c->decode_mode == 4 || c->decode_mode == 5)) return false;
+  return fused_decode_tight_supported(m->D, m->F, m->H, m->Ld);
+}
+
+static bool kv_centres_ready(slimt_hip_model *m) {
+  const int state = m->kv_centre_state.load(std::memory_order_acquire);
+  if (state == 2) return true;
+  if (state == 1 && hipEventQuery(m->kv_centre_ev) == hipSuccess) {
+    m->kv_centre_state.store(2, std::memory_order_release);
+    return true;
+  }
+  (void)hipGetLastError();  // (hipErrorNotReady)
+  return false;
+}
+
 // The tight form for this batch's decoder layers (engine.h, kv_tight_off): a mask of the layers that try it. Only where the
-// decoder launch that follows will be one with the reader inlined: the D = 256 / F = 1536 tilings of 16 / 8 / 4 sentences
-// (not the 32-sentence tiling a large output layer takes, not clusters), S <= 32, written by the 64-row encoder.
+// decoder launch that follows will be one with the reader inlined (kv_tight_shape), and once the centres are there.
 static unsigned kv_tight_wanted(slimt_hip_ctx *c, int S, bool tall, unsigned long long **count_dev) {
   slimt_hip_model *m = c->model;
   *count_dev = nullptr;
-  static const bool enabled = !(std::getenv("SLIMT_KV_TIGHT") && std::getenv("SLIMT_KV_TIGHT")[0] == '0');
-  if (!enabled || !tall || S > 32 || m->kv_tight_limit <= 0 || !m->kv_wide_count) return 0;
-  // (mode 0 takes the 32-sentence tiling for a large output layer: known at the decoder launch only -- what this context's
-  // last one saw stands in for it; a wrong guess costs that one batch the 16-sentence tiling)
-  if (!((c->decode_mode == 0 && !c->expect_large_output) || c->decode_mode == 2 || c->decode_mode == 4 || c->decode_mode == 5)) return 0;
-  if (!fused_decode_tight_supported(m->D, m->F, m->H, m->Ld)) return 0;
+  if (!kv_tight_shape(c, S, tall) || !m->kv_wide_count || !kv_centres_ready(m)) return 0;
   static const bool watch = !(std::getenv("SLIMT_KV_WATCH") && std::getenv("SLIMT_KV_WATCH")[0] == '0');
   unsigned off = m->kv_tight_off.load(std::memory_order_relaxed);
   for (int l = 0; l < m->Ld && watch; ++l) {
     const unsigned long long missed = static_cast<volatile unsigned long long *>(m->kv_wide_count)[1 + l];
     const unsigned long long total = m->kv_tight_submitted[l].load(std::memory_order_relaxed);
-    if (!((off >> l) & 1u) && total >= 1024 && missed * 2 > total) {
+    // (as for the narrow form: the fallback is an out-of-line call its whole workgroup waits for)
+    if (!((off >> l) & 1u) && total >= 1024 && missed * 32 > total) {
       off |= 1u << l;
       m->kv_tight_off.fetch_or(1u << l, std::memory_order_relaxed);
     }
@@ -771,6 +793,9 @@ extern "C" int slimt_hip_model_destroy(slimt_hip_model *model) {
   (void)hipSetDevice(model->device);
   model_free(model);
   if (model->kv_wide_count) (void)hipHostFree(model->kv_wide_count);
+  model->kv_centre.release();
+  model->kv_centre_sums.release();
+  if (model->kv_centre_ev) (void)hipEventDestroy(model->kv_centre_ev);
   delete model;
   return 0;
 }
@@ -886,6 +911,34 @@ extern "C" int slimt_hip_debug_kv_tight_limit(slimt_hip_model *model, int limit)
   std::lock_guard<std::mutex> lock(model->gate_mu);
   model->kv_tight_limit = limit;
   kv_watch_restart(model);
+  return 0;
+}
+
+extern "C" int slimt_hip_debug_kv_centres(slimt_hip_model *model, int32_t *out, size_t n, int *ready) {
+  if (!model || !ready) return fail(-1, "null argument");
+  HIPCHK(hipSetDevice(model->device));
+  *ready = kv_centres_ready(model) ? 1 : 0;
+  if (!*ready || !out) return 0;
+  const size_t have = (size_t)model->Ld * 2 * (size_t)model->D;
+  if (n < have) return fail(-1, "kv centres: room for %zu values, the model has %zu", n, have);
+  HIPCHK(hipMemcpy(out, model->kv_centre.p, have * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int slimt_hip_model_set_kv_centres(slimt_hip_model *model, const int32_t *centres, size_t n) {
+  if (!model || !centres) return fail(-1, "null argument");
+  const size_t have = (size_t)model->Ld * 2 * (size_t)model->D;
+  if (n != have) return fail(-1, "kv centres: %zu values given, the model takes Ld * 2 * D = %zu", n, have);
+  for (size_t i = 0; i < n; ++i)
+    if (centres[i] <= -(1 << 23) || centres[i] >= (1 << 23)) return fail(-1, "kv centre %zu = %d not within (-2^23, 2^23)", i, centres[i]);
+  HIPCHK(hipSetDevice(model->device));
+  if (model->kv_centre_claimed.exchange(true, std::memory_order_acq_rel) && model->kv_centre_state.load(std::memory_order_acquire) != 2 &&
+      !kv_centres_ready(model))
+    return fail(-1, "kv centres: a calibration batch is in flight");
+  HIPCHK(model->kv_centre.reserve(have * 4));
+  HIPCHK(hipDeviceSynchronize());  // (the caller promises no batch in flight; make the copy safe against a finished one's tail)
+  HIPCHK(hipMemcpy(model->kv_centre.p, centres, have * 4, hipMemcpyHostToDevice));
+  model->kv_centre_state.store(2, std::memory_order_release);
   return 0;
 }
 
@@ -1377,6 +1430,8 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.kv_tight_layers = kv_tight_wanted(c, S, tall_encoder_chosen(c, B, S), &f.kv_not16_count);
       if (f.kv_tight_layers) {
         f.kv_tight_limit = std::min(m->kv_tight_limit, 1 << 15);
+        for (int l = 0; l < m->Ld; ++l)
+          for (int p = 0; p < 2; ++p) f.kv_centre[l][p] = m->kv_centre.as<int>() + (size_t)(2 * l + p) * D;
         c->kv_tight = true;
         for (int l = 0; l < m->Ld; ++l)
           if ((f.kv_tight_layers >> l) & 1u) c->model->kv_tight_submitted[l].fetch_add((unsigned long long)B, std::memory_order_relaxed);
@@ -1739,10 +1794,18 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   // ... and for 65..128-token sentences of that shape (the per-sentence encoder, attention_row24_long)
   const bool kv24_long = S > 64 && S <= 128 && c->decode_mode != 3 && fused_decode_long24_supported(m->D, m->F, m->H, m->Ld) &&
                          long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
-  const bool kv24 = lean && (m->kv_format == 0 || m->kv_format == 2) &&
+  const bool kv_packed = lean && (m->kv_format == 0 || m->kv_format == 2) &&
                     ((m->D == 256 && m->D / m->H == 32) || (m->D == 512 && m->D / m->H == 64 && m->F == 2048)) &&
                     ((S <= 32 && ((S + 3) & ~(size_t)3) * 3 <= S * 4 &&
                       fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S)) || kv24_mid || kv24_long);
+  // The tight form's centres (engine.h, kv_centre): the first batch of enough rows that could take the form is cached as
+  // f32 instead, and its column means become the centres (behind the encoder, on this stream).
+  bool calibrate = false;
+  if (kv_packed && c->model->kv_centre_state.load(std::memory_order_acquire) == 0 && B * S >= 2048 &&
+      kv_tight_shape(c, (int)S, tall_encoder_chosen(c, (int)B, (int)S)) &&
+      !c->model->kv_centre_claimed.exchange(true, std::memory_order_acq_rel))
+    calibrate = true;
+  const bool kv24 = kv_packed && !calibrate;
   // One thread at a time queues a persistent translate (a few runtime calls, ~50 us): the runtime
   // serialises launches internally anyway, and a dozen worker threads contending inside it take
   // far longer per call than the same calls made one after the other (Service, 10 workers: 2.1 ms
@@ -1777,6 +1840,21 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr, false, false,
                         kv24, gen, store_nt && kv24 && call_k < 8 && (int)(call_slot % 8) >= call_k));
     c->n_sl = (int)n_sl;
+    if (calibrate) {
+      slimt_hip_model *gm = c->model;
+      int rc = 0;
+      if (gm->kv_centre.reserve((size_t)m->Ld * 2 * m->D * 4) != hipSuccess || gm->kv_centre_sums.reserve((size_t)m->Ld * 2 * m->D * 8) != hipSuccess ||
+          (!gm->kv_centre_ev && hipEventCreateWithFlags(&gm->kv_centre_ev, hipEventDisableTiming) != hipSuccess) ||
+          launch_kv_centres(c->kv.as<float>(), m->Ld, (int)B, (int)S, m->D, gm->kv_centre_sums.as<unsigned long long>(), gm->kv_centre.as<int>(), st) != hipSuccess ||
+          hipEventRecord(gm->kv_centre_ev, st) != hipSuccess)
+        rc = 1;
+      if (rc) {  // (no centres: the next suitable batch tries again; this one goes on with its f32 cache)
+        (void)hipGetLastError();
+        gm->kv_centre_claimed.store(false, std::memory_order_release);
+      } else {
+        gm->kv_centre_state.store(1, std::memory_order_release);
+      }
+    }
     clk.lap(1);
   } else {
     if (d_ids != c->ids.as<uint32_t>())
@@ -1873,6 +1951,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       f.kv_u[l][1] = wv.w.u;
       f.kv_u256[l][0] = wk.w.u * (1.0f / 256.0f);  // exact scalings: the packed integers come back
       f.kv_u256[l][1] = wv.w.u * (1.0f / 256.0f);  // as accS * 256 (decode_fused.hip, unpack24f)
+      f.kv_centre[l][0] = m->kv_centre.as<int>() + (size_t)(2 * l) * m->D;  // (the tight form; null until calibrated, not read then)
+      f.kv_centre[l][1] = m->kv_centre.as<int>() + (size_t)(2 * l + 1) * m->D;
       f.kv_u4096[l][0] = wk.w.u * (1.0f / 4096.0f);  // ... as accS * 4096 from the narrow form (unpack20)
       f.kv_u4096[l][1] = wv.w.u * (1.0f / 4096.0f);
     }

@@ -116,6 +116,15 @@ struct slimt_hip_model {
   int kv_tight_limit = 1 << 15;
   std::atomic<unsigned long long> kv_tight_submitted[4] = {};
   std::atomic<unsigned> kv_tight_off{0};
+  // The tight form's per-column centres [Ld][K, V][D] (kernels.h, FusedDecodeArgs::kv_centre): the column means of the
+  // first batch of at least 2048 rows that could have taken the form -- that batch is cached as f32 (its decoder reads
+  // that form), a reduction behind its encoder writes the centres, and the form is tried from the first batch submitted
+  // after the reduction's event has completed. Written once (or set by the caller before any batch), never changed after:
+  // a batch's encoder and decoder read the same numbers.
+  slimt_hip::DevBuf kv_centre, kv_centre_sums;
+  hipEvent_t kv_centre_ev = nullptr;
+  std::atomic<int> kv_centre_state{0};  // 0 = none, 1 = a calibration batch is in flight, 2 = ready
+  std::atomic<bool> kv_centre_claimed{false};
 };
 
 struct slimt_hip_ctx {

@@ -331,10 +331,16 @@ struct FusedDecodeArgs {
   // encoder that filled the cache, FusedEncodeArgs::kv_fmt) says which: 0 = narrow, 1 = 24-bit; nullptr = all 24-bit.
   // Both forms give back the same integers, so results do not depend on it: 17 % fewer K/V bytes per step.
   const unsigned char *kv_fmt = nullptr;
-  // kv_fmt may hold 2 = the TIGHT form (D = 256, S <= 32): the SIGNED accumulator acc = accS - 127 colsum as plain int16
-  // (decode_fused.hip, attention_row16), for sentence-layers whose K and V all lie in [-2^15, 2^15). Set by the engine
+  // kv_fmt may hold 2 = the TIGHT form (D = 256, S <= 32): the accumulator less its column's centre as plain int16
+  // (decode_fused.hip, attention_row16), for sentence-layers whose K and V all lie in [-2^15, 2^15) then. Set by the engine
   // when this batch's encoder was allowed to write it: the launch then uses the kernels with that form inlined.
   bool kv_tight = false;
+  // ... held relative to a per-column CENTRE: the cache has r = accS - kv_centre[l][K, V][d], the reader adds float(centre)
+  // back (exact: integers below 2^24). The accumulators of a column scatter around a mean that depends on the column (the
+  // encoder output's per-feature mean times the weights: on the synthetic tiny11 the column means' spread is 7.5 k, the
+  // scatter around them 3.2 k), so the centres -- the column means of one calibration batch (engine.cpp, kv_calibrate) --
+  // are what makes the form fit practically every sentence. Any integers would give the same results.
+  const int *kv_centre[4][2] = {};
   float kv_u4096[4][2] = {};      // [layer][K, V]: u / 4096 (narrow form: the integers come back as accS * 4096)
   const float *kv_pb[4][2] = {};  // [layer][K, V]: the projections' prepared biases [D] (both forms)
   const int *kv_cs[4][2] = {};    // [layer][K, V]: their column sums [D] (D = 512: the cache holds the signed accumulator)
@@ -420,9 +426,10 @@ struct FusedEncodeArgs {
   unsigned char *kv_fmt = nullptr;
   int kv_narrow_limit = 1 << 19;
   // the tight 16-bit form (FusedDecodeArgs::kv_tight) is tried first in the decoder layers of kv_tight_layers (bit l):
-  // signed accumulators must lie in [-kv_tight_limit, kv_tight_limit) (2^15, what int16 holds; tests lower it); recorded as 2
+  // centred accumulators must lie in [-kv_tight_limit, kv_tight_limit) (2^15, what int16 holds; tests lower it); recorded as 2
   int kv_tight_limit = 0;
   unsigned kv_tight_layers = 0;
+  const int *kv_centre[4][2] = {};  // [layer][K, V][D]: the tight form holds accS - centre (FusedDecodeArgs::kv_centre)
   unsigned long long *kv_not16_count = nullptr;  // [Ld], like kv_wide_count: + 1 per sentence of layer l that tried and did not take the tight form
   // nullable, pinned host memory: + 1 per sentence-layer that took the 24-bit form (the engine watches the share: a model
   // whose accumulators mostly do not fit 20 bits is switched to the 24-bit form altogether, engine.cpp)
@@ -487,5 +494,7 @@ struct LongEncodeArgs {
 };
 bool long_encode_supported(int D, int F, int H, int Le, int Ld, int S);
 hipError_t launch_encode_long(const LongEncodeArgs &a, hipStream_t st);
+// the column means (rounded) of an f32 K/V cache [Ld][K, V][B * S][D]: centre[(2 l + p) * D + d] (FusedDecodeArgs::kv_centre)
+hipError_t launch_kv_centres(const float *kv, int Ld, int B, int S, int D, unsigned long long *sums, int *centre, hipStream_t st);
 
 }  // namespace slimt_hip

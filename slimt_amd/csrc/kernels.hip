@@ -1027,4 +1027,38 @@ hipError_t launch_transpose_heads(const float *in, int B, int d2, int d1, int d0
   return hipGetLastError();
 }
 
+// ---- centres of the tight K/V cache form (kernels.h, FusedDecodeArgs::kv_centre) ----------------------------------------
+// One calibration batch is cached in the f32 form (float(accS), exact): K [sentence][D/4][key][4], V [sentence][key][D]
+// per layer and projection. Column sums over all its rows as 64-bit integers (exact, order-free), then
+// centre = floor(sum / rows + 1/2) in integer arithmetic: the same numbers on every run.
+__global__ __launch_bounds__(256) void kv_centre_sum_kernel(const float *kv, int B, int S, int D, unsigned long long *sums) {
+  const int lp = blockIdx.x, d = threadIdx.x + 256 * blockIdx.z;  // lp = 2 * layer + (0: K, 1: V)
+  if (d >= D) return;
+  const float *base = kv + (size_t)lp * B * S * D;
+  long long acc = 0;
+  for (int r = blockIdx.y; r < B * S; r += gridDim.y) {
+    const int b = r / S, key = r - b * S;
+    const float v = (lp & 1) ? base[(size_t)r * D + d] : base[(((size_t)b * (D / 4) + (d >> 2)) * S + key) * 4 + (d & 3)];
+    acc += (long long)v;
+  }
+  atomicAdd(sums + (size_t)lp * D + d, (unsigned long long)acc);
+}
+
+__global__ void kv_centre_finish_kernel(const unsigned long long *sums, long long rows, int n, int *centre) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long num = 2 * (long long)sums[i] + rows, den = 2 * rows;
+  long long q = num / den;
+  if (num % den < 0) q -= 1;  // floor
+  centre[i] = (int)q;
+}
+
+hipError_t launch_kv_centres(const float *kv, int Ld, int B, int S, int D, unsigned long long *sums, int *centre, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(sums, 0, (size_t)Ld * 2 * D * 8, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kv_centre_sum_kernel, dim3(Ld * 2, 64, (D + 255) / 256), dim3(256), 0, st, kv, B, S, D, sums);
+  hipLaunchKernelGGL(kv_centre_finish_kernel, dim3((Ld * 2 * D + 255) / 256), dim3(256), 0, st, sums, (long long)B * S, Ld * 2 * D, centre);
+  return hipGetLastError();
+}
+
 }  // namespace slimt_hip

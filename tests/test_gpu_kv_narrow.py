@@ -32,14 +32,23 @@ def kv_accumulators(oracle, m, om, ids, lens):
     return acc
 
 
-def signed_accumulators(m, acc):
-    """acc = accS - 127 colsum: what the tight (16-bit) form holds (kernels.h, FusedDecodeArgs::kv_tight)."""
-    out = acc.astype(np.int64)
+def colsum_centres(m, jitter_seed=None):
+    """Centres for the tight (16-bit) form (include/slimt_hip.h, slimt_hip_model_set_kv_centres), int32 [Ld][2][D]: 127 colsum
+    -- the form then holds the signed accumulator -- plus, for tests of the arithmetic, arbitrary offsets: any integers
+    must give the same results."""
+    out = np.zeros((m.dec_layers, 2, m.D), dtype=np.int64)
     for l in range(m.dec_layers):
         for t, name in enumerate("kv"):
             W = np.ascontiguousarray(m.params[f"decoder_l{l + 1}_context_W{name}"].data).reshape(m.D, m.D)  # payload [N][K]
-            out[l, t] -= 127 * W.astype(np.int64).sum(axis=1)[None, None, :]
-    return out
+            out[l, t] = 127 * W.astype(np.int64).sum(axis=1)
+    if jitter_seed is not None:
+        out += np.random.Generator(np.random.PCG64(jitter_seed)).integers(-6000, 6001, size=out.shape)
+    return out.astype(np.int32)
+
+
+def centred(acc, centres):
+    """accS - centre: what the tight form holds (kernels.h, FusedDecodeArgs::kv_centre)."""
+    return acc.astype(np.int64) - centres.astype(np.int64)[:, :, None, None, :]
 
 
 def expected_forms(acc, limit, group, signed=None, tight_limit=0):
@@ -89,8 +98,12 @@ def test_forms_follow_the_accumulators_and_results_do_not(hip, oracle, synth_mod
         limits = [2 ** 19, int(order[len(order) // 2]), int(order[len(order) // 4]) + 1, int(order[-1]), int(order[-1]) + 1, 1]
         # the tight (16-bit) form: written by the 64-row encoder for sentences of up to 32 tokens, read by the tilings of
         # 16 / 8 / 4 sentences (modes 0, 2, 4, 5); its limits likewise: int16's, two that split the batch, none
-        signed = signed_accumulators(m, acc)
         tight_here = preset == "tiny11" and S <= 32 and rows == 64
+        centres = colsum_centres(m, jitter_seed=B * 100 + S)
+        if tight_here:
+            gm.set_kv_centres(centres)
+            assert np.array_equal(gm.debug_kv_centres(m.dec_layers, m.D), centres)
+        signed = centred(acc, centres)
         order16 = np.sort(np.abs(signed).max(axis=(1, 3, 4)).ravel())
         tights = [2 ** 15, int(order16[len(order16) // 2]), int(order16[len(order16) // 4]) + 1, int(order16[-1]) + 1, 0, 1]
         tights = [min(t, 2 ** 15) for t in tights]
@@ -165,10 +178,12 @@ def test_an_accumulator_past_2_19_sends_its_sentences_to_the_24_bit_form(hip, or
         assert np.array_equal(acc[:, :, :, :, 1:], base[:, :, :, :, 1:])  # only column 0 moved
         forms = expected_forms(acc, 2 ** 19, group)
         assert forms.any() and not forms.all(), picked
-        # Where the tight form is tried (64-row encoder, not the 32-sentence tiling) it holds the SIGNED accumulator: a
-        # sentence whose shifted accumulator passes 2^19 through 127 colsum alone still fits int16 -- the 24-bit form is then
-        # only for those whose data-dependent part is large too
-        forms16 = expected_forms(acc, 2 ** 19, group, signed_accumulators(m, acc), 2 ** 15)
+        # Where the tight form is tried (64-row encoder, not the 32-sentence tiling) it holds the accumulator less its column's
+        # centre -- here 127 colsum, i.e. the SIGNED accumulator: a sentence whose shifted accumulator passes 2^19 through
+        # 127 colsum alone still fits int16 -- the 24-bit form is then only for those whose data-dependent part is large too
+        centres = colsum_centres(m)
+        gm.set_kv_centres(centres)
+        forms16 = expected_forms(acc, 2 ** 19, group, centred(acc, centres), 2 ** 15)
         assert (forms16[forms == 0] != 1).all()
         assert np.abs(acc.astype(np.int64)).max() < 2 ** 23
         sl = synth.make_shortlist(m.V, 640)
@@ -279,15 +294,18 @@ def test_a_model_that_mostly_needs_24_bits_is_switched_to_them(hip, oracle, synt
         gm.close()
 
 
-def test_a_layer_whose_sentences_mostly_miss_the_tight_form_stops_trying(hip, oracle, synth_models):
-    """The tight form has its own watch, per decoder layer (include/slimt_hip.h, slimt_hip_debug_kv_tight_watch): a sentence
-    that tries it and misses costs its encoder workgroup a second pass over the layer's K and V, so a layer where more than
-    half of 1024 sentences missed (here: all of them, by a tight limit of 1) goes back to starting with the 20-bit form.
-    Results never change; the synthetic model at the real limit keeps trying."""
+def test_centres_are_calibrated_from_the_first_large_batch_and_a_layer_that_mostly_misses_stops_trying(hip, oracle, synth_models):
+    """Without centres from the caller the library calibrates them (include/slimt_hip.h, slimt_hip_model_set_kv_centres): the
+    first batch of >= 2048 rows that could take the tight form is cached as f32 and its column means -- floor(sum / rows +
+    1/2) over every row of the batch, in integers -- become the centres. On the synthetic model the column means carry most
+    of the accumulators' spread (7.5 k against 3.2 k around them), so every sentence fits int16 afterwards.
+    The tight form has its own watch, per decoder layer (slimt_hip_debug_kv_tight_watch): a sentence that misses is read
+    through an out-of-line call, so a layer where more than one in 32 of 1024 sentences missed (here: all of them, by a tight
+    limit of 1) goes back to starting with the 20-bit form. Results never change."""
     from slimt_amd import synth
     m = synth_models("tiny11", 6.0)
     gm, om = hip.Model(m), oracle.OracleModel(m)
-    B, S = 64, 32  # (the 64-row encoder: 32 workgroups)
+    B, S = 64, 32  # (2048 rows; the 64-row encoder: 32 workgroups)
     ctx = hip.Context(gm, B, S)
     try:
         ids, lens = synth.make_batch(m.V, B, S, seed=909, ragged=True)
@@ -296,14 +314,24 @@ def test_a_layer_whose_sentences_mostly_miss_the_tight_form_stops_trying(hip, or
         want = om.translate(ids, lens, sl, 1.5, 0, want_align=True)[:3]
         oracle.set_mode(oracle.FAITHFUL)
         acc = kv_accumulators(oracle, m, om, ids, lens)
-        forms = expected_forms(acc, 2 ** 19, 2, signed_accumulators(m, acc), 2 ** 15)
-        assert (forms == 2).mean() > 0.5  # the synthetic model: most sentence-layers are this small
-        for _ in range(20):
+        assert gm.debug_kv_centres(m.dec_layers, m.D) is None
+        got = ctx.translate(ids, lens, sl, want_align=True)  # the calibration batch: an f32 cache
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        assert ctx.debug_kv_formats(m.dec_layers, B) is None
+        centres = gm.debug_kv_centres(m.dec_layers, m.D)
+        sums = acc.astype(np.int64).sum(axis=(2, 3))  # [Ld][2][D]
+        assert centres is not None and np.array_equal(centres, (2 * sums + B * S) // (2 * B * S))
+        forms = expected_forms(acc, 2 ** 19, 2, centred(acc, centres), 2 ** 15)
+        assert (forms == 2).all()  # the synthetic model around its column means
+        assert (expected_forms(acc, 2 ** 19, 2, centred(acc, colsum_centres(m)), 2 ** 15) != 2).any()  # ... not around 127 colsum
+        for _ in range(19):
             got = ctx.translate(ids, lens, sl, want_align=True)
         assert all(np.array_equal(a, b) for a, b in zip(got, want))
         off, missed, tried = gm.debug_kv_tight_watch()
-        assert off == 0 and tried[:2] == [20 * B, 20 * B] and missed[:2] == [20 * int((forms[l] != 2).sum()) for l in range(2)]
+        assert off == 0 and tried[:2] == [19 * B, 19 * B] and missed[:2] == [0, 0]
         assert np.array_equal(ctx.debug_kv_formats(m.dec_layers, B), forms)
+        with pytest.raises(hip.SlimtHipError):
+            gm.set_kv_centres(np.zeros(5, dtype=np.int32))
         gm.debug_kv_tight_limit(1)
         n = 0
         while gm.debug_kv_tight_watch()[0] != 3:
