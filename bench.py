@@ -431,7 +431,12 @@ def main():
         step(i)
     barrier()
     dt = time.perf_counter() - t0
+    kv_forms = None
     if not dry:
+        # which form the last batch's K/V caches took, per sentence and decoder layer (slimt_hip_debug_kv_formats)
+        seen = ctxs[0].debug_kv_formats(Ld, B)
+        if seen is not None:
+            kv_forms = {"int16": float((seen == 2).mean()), "int20": float((seen == 0).mean()), "int24": float((seen == 1).mean())}
         prof = {"launches": 0, "total_ms": 0.0, "int8_macs": 0.0, "weight_bytes": 0.0}
         for c in ctxs:
             r = c.profile_read()
@@ -598,6 +603,9 @@ def main():
             kv20 = (kv24 and args.kv_format == 0 and ((D == 256 and S <= 64) or (D == 512 and S <= 32)) and
                     ((S + 7) // 8) * 5120 <= ((S + 3) // 4) * 3072)
             kv_impl = kv_once * (0.625 if kv20 else 0.75 if kv24 else 1.0)
+            # ... 16 bits where the tight form has a reader (this launch's last batch says which sentences took which form)
+            if kv20 and kv_forms:
+                kv_impl = kv_once * (0.5 * kv_forms["int16"] + 0.625 * kv_forms["int20"] + 0.75 * kv_forms["int24"])
             w_once = float(Ld * (4 * D * D + 2 * D * F) + D * N_out)
             io_bytes = float(B) * T * (D + 4)
             alg_bytes = w_once + io_bytes + kv_once
@@ -610,7 +618,10 @@ def main():
                 "implementation_bytes_per_launch": impl_bytes,
                 "implementation_over_algorithmic": impl_bytes / alg_bytes,
                 "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
-                "kv_cache_format": ("int20 accumulators (2.5 bytes per value; 24-bit fallback per sentence and layer)" if kv20
+                "kv_cache_forms_last_batch": kv_forms,
+                "kv_cache_format": ("int16 accumulators less per-column centres (2 bytes per value; 20- and 24-bit fallbacks per sentence and layer)"
+                                    if kv20 and kv_forms and kv_forms["int16"] > 0.5
+                                    else "int20 accumulators (2.5 bytes per value; 24-bit fallback per sentence and layer)" if kv20
                                     else "int24 accumulators (3 bytes per value)" if kv24 else "f32"),
                 "bytes_model": {"kv_cache_once": kv_once, "kv_cache_reread_every_step": kv_reread,
                                 "weights_once": w_once, "weights_once_per_step": w_once * T,

@@ -2089,6 +2089,128 @@ __device__ __forceinline__ void attention_row20_64(AttnRow r, int lane, lcf_ptr 
   *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) = packed[1];
 }
 
+// attention_row20_64 out of line (see attention_row24_cold): the fallback of the tight form at D = 512.
+template <int KV_AUX>
+__device__ __noinline__ void attention_row20_64_cold(AttnRow r, int lane, lcf_ptr kc, float uk4096, float uv4096) {
+  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
+  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
+  r.S = __builtin_amdgcn_readfirstlane(r.S);
+  r.len = __builtin_amdgcn_readfirstlane(r.len);
+  attention_row20_64<KV_AUX>(r, lane, kc, uk4096, uv4096);
+}
+
+// attention_row20_64 over the tight form (attention_row16 has the arithmetic: int16 less the column's centre, one SDWA
+// conversion per value + half a packed add): the passes and the order of every float operation are attention_row20_64's.
+//   K [head][plane 0..7][S][16 B]             plane p: the head's columns 8 p .. 8 p + 7 of one key (eight int16)
+//   V [ceil(S / 8)][plane 0..3][D/4][16 B]    plane p: keys 8 g + 2 p, 8 g + 2 p + 1 x 4 consecutive columns (key-major)
+// kc: LDS constants of this layer, [K pb | K c127 | V pb | V c127][D]; ck / cv: the centres of K / V [D] in LDS, as floats
+template <int KV_AUX>
+__device__ __forceinline__ void attention_row16_64(AttnRow r, int lane, lcf_ptr kc, CentreLds ck, CentreLds cv) {
+  constexpr int D = 512, DH = 64, H = D / DH;
+  const int S = r.S, len = r.len;
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int hh = lane >> 5, j = lane & 31;
+  const int jc = j < S ? j : S - 1;
+  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 1024));
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 8192));
+  const int koff = j < lenf ? (hh * 8 * S + jc) * 16 : kPastDescriptor;
+  const lcf_ptr kpb = kc, vpb = kc + 2 * D;
+  auto pair16 = [](int d, f2 c) -> f2 {
+    const f2 v = {(float)(short)(d & 0xffff), (float)(d >> 16)};
+    return v + c;
+  };
+#pragma unroll 1
+  for (int hp = 0; hp < H / 2; ++hp) {
+    const int h = 2 * hp + hh;
+    v4i kq[8];  // this lane's key, its head's 64 columns
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((16 * hp + i) * S) * 16, KV_AUX));
+    // c_h = row sum of q_d * pbK[d] over the 64 columns of this lane's head (attention_row20_64)
+    const float c0 = wave_sum(r.qrow[(2 * hp) * DH + lane] * kpb[(2 * hp) * DH + lane]);
+    const float c1 = wave_sum(r.qrow[(2 * hp + 1) * DH + lane] * kpb[(2 * hp + 1) * DH + lane]);
+    const float ch = hh ? c1 : c0;
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d0 = h * DH + 8 * i;
+      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
+      const f4 ca = ck.at4(d0), cb = ck.at4(d0 + 4);
+      const f2 k01 = pair16(kq[i].x, f2{ca.x, ca.y}), k23 = pair16(kq[i].y, f2{ca.z, ca.w});
+      const f2 k45 = pair16(kq[i].z, f2{cb.x, cb.y}), k67 = pair16(kq[i].w, f2{cb.z, cb.w});
+      t = __builtin_fmaf(qa.x, k01.x, t);
+      t = __builtin_fmaf(qa.y, k01.y, t);
+      t = __builtin_fmaf(qa.z, k23.x, t);
+      t = __builtin_fmaf(qa.w, k23.y, t);
+      t = __builtin_fmaf(qb.x, k45.x, t);
+      t = __builtin_fmaf(qb.y, k45.y, t);
+      t = __builtin_fmaf(qb.z, k67.x, t);
+      t = __builtin_fmaf(qb.w, k67.y, t);
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);  // at most sixteen q / centre values from LDS in flight
+    }
+    float s = __builtin_fmaf(t, r.uk, ch);
+    if (r.alpha != 1.0f) s = r.alpha * s;
+    s = s + mask;
+    if (j >= S) s = lowest;
+    const float m = half_max(s);
+    const float e = j < S ? exp_p(s - m) : 0.0f;
+    const float sum = half_sum(e);
+    const float p = e / sum;  // keys >= S: exactly 0
+    const float ps = half_sum(p);  // P_h
+    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
+    if (r.align && h == 0 && j < len) r.align[j] = p;
+    r.pbuf[h * 32 + j] = p;
+    if (j == 0) r.hsum[h] = ps;
+  }
+  // V: a lane owns column quads `lane` (head lane / 16) and 64 + lane (head 4 + lane / 16): two independent passes over
+  // the keys, each with two groups of eight rows in flight
+  int packed[2];
+#pragma unroll
+  for (int slot = 0; slot < 2; ++slot) {
+    const int voff = (slot * 64 + lane) * 16;
+    v4i vq[2][4];
+    auto load_v = [&](v4i(&vv)[4], int g) {  // rows 8 g .. 8 g + 7
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (4 * g + i) * 2048, KV_AUX));
+    };
+    load_v(vq[0], 0);
+    load_v(vq[1], 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int head = 4 * slot + (lane >> 4);
+    const int ph = head * 32;
+    const f4 pv4 = *(lcf4_ptr)(vpb + slot * (D / 2) + 4 * lane);
+    const f4 cv4 = cv.at4(slot * (D / 2) + 4 * lane);
+    const f2 c01 = {cv4.x, cv4.y}, c23 = {cv4.z, cv4.w};
+    const float P = r.hsum[head];
+    f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      v4i(&cur)[4] = vq[g & 1];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
+        const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
+        const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
+        oa = __builtin_elementwise_fma(p0, pair16(cur[c].x, c01), oa);
+        ob = __builtin_elementwise_fma(p0, pair16(cur[c].y, c23), ob);
+        oa = __builtin_elementwise_fma(p1, pair16(cur[c].z, c01), oa);
+        ob = __builtin_elementwise_fma(p1, pair16(cur[c].w, c23), ob);
+      }
+      asm volatile("" : "+v"(oa), "+v"(ob));  // (attention_row24: keeps a group's work next to its loads)
+      if (g + 2 < 4) load_v(vq[g & 1], g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float o0 = __builtin_fmaf(oa.x, r.uv, pv4.x * P), o1 = __builtin_fmaf(oa.y, r.uv, pv4.y * P);
+    const float o2 = __builtin_fmaf(ob.x, r.uv, pv4.z * P), o3 = __builtin_fmaf(ob.y, r.uv, pv4.w * P);
+    packed[slot] = pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
+  }
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) = packed[0];
+  *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) = packed[1];
+}
+
 }  // namespace
 
 // Diagnostic phase stamps (100 MHz wall clock) of workgroup 0 at one chosen
@@ -2132,13 +2254,13 @@ __device__ __forceinline__ void attention_row20_64(AttnRow r, int lane, lcf_ptr 
 // KVI (packed-cache variants), the forms inlined: 20 = the narrow 20-bit form, the 24-bit form as the rare sentence's out-of-line
 // fallback; 24 = the 24-bit form inlined and nothing else (launches whose caches are all 24-bit: K/V cache format 2,
 // or a model the engine found mostly too wide for 20 bits -- there the out-of-line call would cost every sentence).
-// KVI = 16: additionally the tight 16-bit form inlined (D = 256, S <= 32, RT = 1; kv_fmt == 2), for models whose sentences
-// mostly take it (engine.cpp, kv_try16); its column terms take 2 KB of LDS per layer.
+// KVI = 16: the tight 16-bit form inlined instead (S <= 32, RT = 1; kv_fmt == 2; the others out of line), for batches whose
+// encoder was allowed it (engine.cpp, kv_tight_wanted); its centres take 2 D floats of LDS per layer.
 template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0, int SPW = 16, int CL = 1,
           int KVI = 20>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr bool KV20 = KVI != 24;
-  static_assert(KVI == 24 || KVI == 20 || (KVI == 16 && KV24 && KSD == 4 && MID == 0 && RT == 1 && CL == 1), "16-bit form: the D = 256 short-sentence tilings");
+  static_assert(KVI == 24 || KVI == 20 || (KVI == 16 && KV24 && (KSD == 4 || KSD == 8) && MID == 0 && RT == 1 && CL == 1), "16-bit form: the short-sentence tilings of D = 256 and D = 512");
   static_assert(CL == 1 || (CL <= 4 && RT == 1 && SPW == 16 && MID == 0 && !LONG), "cluster logits: the 16-sentence tilings");
   static_assert(SPW == 16 || ((SPW == 8 || SPW == 4) && RT == 1 && KV24), "fewer sentences per workgroup: the packed-cache, 16-row variants");
   static_assert(!KV24 || (((KSD == 4 && DH == 32) || (KSD == 8 && DH == 64)) && !LONG),
@@ -2485,9 +2607,24 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             else
               attention_row24_64<0>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
             } else {
-            const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
-            if (!wide) {
-              if (NT && kv_streams)
+            const unsigned forms = rr ? kv_wide[RT - 1] : kv_wide[0];
+            const bool wide = (forms >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
+            const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
+            if (tight) {
+              if constexpr (KVI == 16) {
+                const CentreLds ck = {(lcf_ptr)(kvc127 + (2 * l) * D)}, cv = {(lcf_ptr)(kvc127 + (2 * l + 1) * D)};
+                if (NT && kv_streams)
+                  attention_row16_64<2>(ar, lane, kc, ck, cv);
+                else
+                  attention_row16_64<0>(ar, lane, kc, ck, cv);
+              }
+            } else if (!wide) {
+              if constexpr (KVI == 16) {  // (the rare sentence-layer past the centres' int16)
+                if (NT && kv_streams)
+                  attention_row20_64_cold<2>(ar, lane, kc, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+                else
+                  attention_row20_64_cold<0>(ar, lane, kc, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+              } else if (NT && kv_streams)
                 attention_row20_64<2>(ar, lane, kc, a.kv_u4096[l][0], a.kv_u4096[l][1]);
               else
                 attention_row20_64<0>(ar, lane, kc, a.kv_u4096[l][0], a.kv_u4096[l][1]);
@@ -3027,10 +3164,12 @@ size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false,
   return fits ? base + ln : base;
 }
 
-// the tight (16-bit) cache form: the D = 256 / F = 1536 short-sentence tilings of 16 / 8 / 4 sentences (decode_fused_kernel<..., KVI = 16>)
+// the tight (16-bit) cache form: the short-sentence tilings of 16 / 8 / 4 sentences, D = 256 / F = 1536 and D = 512 / F = 2048
+// (decode_fused_kernel<..., KVI = 16>)
 bool fused_decode_tight_supported(int D, int F, int H, int Ld) {
   if (Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
-  return D == 256 && F == 1536 && D / H == 32 && fused_decode_lds_bytes(D, F, Ld, 16, true, 0, nullptr, true) <= 160 * 1024;
+  return ((D == 256 && F == 1536 && D / H == 32) || (D == 512 && F == 2048 && D / H == 64)) &&
+         fused_decode_lds_bytes(D, F, Ld, 16, true, 0, nullptr, true) <= 160 * 1024;
 }
 
 // sentences of 33..64 tokens over the packed cache (decode_fused_kernel<..., MID>)
@@ -3078,7 +3217,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= (D == 256 ? 128 : 32))) return hipErrorInvalidValue;
   if (a.home_mask && rows != 16) return hipErrorInvalidValue;  // the XCD-affine claim counts 16-sentence tiles
   // a batch with sentence-layers in the tight form: only the kernels with its reader (engine.cpp, kv_tight_wanted)
-  if (a.kv_tight && !(kv24 && a.kv_fmt && rows <= 16 && a.cluster <= 1 && D == 256 && F == 1536 && a.S <= 32)) return hipErrorInvalidValue;
+  if (a.kv_tight && !(kv24 && a.kv_fmt && rows <= 16 && a.cluster <= 1 && fused_decode_tight_supported(D, F, H, a.Ld) && a.S <= 32)) return hipErrorInvalidValue;
   auto go = [&](void (*k)(FusedDecodeArgs), size_t lds) -> hipError_t {
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
     if (e != hipSuccess) return e;
@@ -3110,6 +3249,13 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (kv24 && D == 512) {
     if (F != 2048) return hipErrorInvalidValue;
+    if (a.kv_tight) {
+#define SLIMT_KV16_PICK(SPW_)                                                                      \
+  (a.kv_nt ? decode_fused_kernel<8, 32, 64, false, true, 1, true, 0, SPW_, 1, 16>                  \
+           : decode_fused_kernel<8, 32, 64, false, false, 1, true, 0, SPW_, 1, 16>)
+      return go(rows == 4 ? SLIMT_KV16_PICK(4) : rows == 8 ? SLIMT_KV16_PICK(8) : SLIMT_KV16_PICK(16), lds);
+#undef SLIMT_KV16_PICK
+    }
     if (only24) return go(SLIMT_KV24_ONLY(8, 32, 64, 0), lds);
     return go(SLIMT_KV24_PICK(8, 32, 64, 0), lds);
   }

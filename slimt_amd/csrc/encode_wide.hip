@@ -603,14 +603,18 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       }
     }
   }
-  // The packed cache takes one of two forms per workgroup and layer (kernels.h, FusedDecodeArgs::kv_fmt; encode_tall.hip
-  // has the same scheme): the narrow one -- 20 bits per value, the SHIFTED accumulator accS = acc + 127 colsum -- when every
-  // accS of this workgroup's rows lies in [-limit, limit), else 24 bits holding the signed accumulator (accS needs 25 bits
-  // at K = 512). Narrow first; an accumulator that does not fit raises kv_wide_flag and the layer is done again.
+  // The packed cache takes one of three forms per workgroup and layer (kernels.h, FusedDecodeArgs::kv_fmt; encode_tall.hip
+  // has the same scheme): the tight one -- int16, the SHIFTED accumulator accS = acc + 127 colsum less its column's centre --
+  // where the engine allows it (kv_tight_layers) and every such value of this workgroup's rows lies in [-2^15, 2^15); the
+  // narrow one -- 20 bits, accS itself -- when every accS lies in [-limit, limit); else 24 bits holding the signed
+  // accumulator (accS needs 25 bits at K = 512). The smallest allowed form first; an accumulator that does not fit raises
+  // its bit of kv_wide_flag (1: not tight, 2: not narrow) and the layer is done again in the smallest form that holds it.
   const bool try_narrow = a.kv24 && a.kv_fmt != nullptr;
   for (int l = 0; l < a.Ld; ++l) {
-    bool wide = !try_narrow;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool try_tight = try_narrow && a.kv_tight_limit > 0 && ((a.kv_tight_layers >> l) & 1u);
+    int form = !try_narrow ? 1 : try_tight ? 2 : 0;  // kv_fmt's codes
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      const bool wide = form == 1;
       bool redo = false;
       for (int p = 0; p < 2; ++p) {
         SLIMT_WPHASE_LANE;
@@ -621,8 +625,8 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         quantise_x(Abuf, w.a_quant, lane);
         if (!wide && p == 0 && tid == 0) kv_wide_flag = 0;  // (raised behind the barrier below only; encode_tall.hip)
         lds_barrier();
-        unsigned outside = 0;  // narrow attempt: an accS of a valid row outside [-limit, limit)
-        const unsigned lim = (unsigned)a.kv_narrow_limit;
+        unsigned outside = 0;  // an accumulator of a valid row outside the form's range
+        const unsigned lim = (unsigned)a.kv_narrow_limit, lim16 = (unsigned)a.kv_tight_limit;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
           const int ct = wave + WNW * t2;
@@ -638,15 +642,25 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
             __builtin_amdgcn_sched_barrier(0);
           }
           const int col = ct * 16 + lg * 4;
-          if (a.kv24) {  // staged: the signed accumulators (24-bit form), or accS (narrow form)
+          if (a.kv24) {  // staged: the signed accumulators (24-bit form), accS (narrow form), or accS - centre (tight form)
             int *stg = reinterpret_cast<int *>(region);  // [WR][LDY] int32
             if (!wide) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 c0[i] += __mul24(127, e.cs[i]);
                 c1[i] += __mul24(127, e.cs[i]);
-                if (row_valid(lr)) outside |= (unsigned)((unsigned)c0[i] + lim >= 2u * lim);
-                if (row_valid(16 + lr)) outside |= (unsigned)((unsigned)c1[i] + lim >= 2u * lim);
+                if (row_valid(lr)) outside |= (unsigned)((unsigned)c0[i] + lim >= 2u * lim) << 1;
+                if (row_valid(16 + lr)) outside |= (unsigned)((unsigned)c1[i] + lim >= 2u * lim) << 1;
+              }
+              if (form == 2) {
+                const v4i ctr = *reinterpret_cast<const v4i *>(a.kv_centre[l][p] + col);
+                c0 -= ctr;
+                c1 -= ctr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  if (row_valid(lr)) outside |= (unsigned)((unsigned)c0[i] + lim16 >= 2u * lim16);
+                  if (row_valid(16 + lr)) outside |= (unsigned)((unsigned)c1[i] + lim16 >= 2u * lim16);
+                }
               }
             }
             *reinterpret_cast<v4i *>(stg + lr * LDY + col) = c0;
@@ -671,14 +685,52 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           }
         }
         if (!a.kv24) continue;
-        if (outside) kv_wide_flag = 1;
+        if (outside) __hip_atomic_fetch_or(&kv_wide_flag, (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lds_barrier();
-        if (!wide && kv_wide_flag) {  // uniform: read by every thread behind the barrier
+        // (uniform: read by every thread behind the barrier; a tight attempt that holds does not care about accS's range)
+        if (!wide && (kv_wide_flag & (form == 2 ? 1 : 2))) {
           redo = true;
+          form = (kv_wide_flag & 2) ? 1 : 0;
           break;
         }
         const int *stg = reinterpret_cast<const int *>(region);
         const int Sp = (S + 3) & ~3;
+        if (form == 2) {
+          // the tight form (decode_fused.hip, attention_row16_64): one thread = 32 values = four quads of int16
+          if (p == 0) {  // K [sentence][head][plane 0..7][key][16 B]
+            const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * S * D * 3));
+            for (int it = tid; it < WR * (D / 32); it += 1024) {
+              const int r = it % WR, hf = it / WR;  // hf: half a head (32 columns)
+              if (!row_valid(r)) continue;
+              const int h = hf >> 1, half = hf & 1;
+              const int off = row_sentence(r) * S * D * 3 + (h * 8 * S + r % S) * 16;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const v4i pk = pack16(*reinterpret_cast<const v4i *>(stg + r * LDY + 32 * hf + 8 * q),
+                                      *reinterpret_cast<const v4i *>(stg + r * LDY + 32 * hf + 8 * q + 4));
+                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, off + (4 * half + q) * S * 16, 0, 0);
+              }
+            }
+          } else {  // V [sentence][key / 8][plane 0..3][column / 4][16 B]
+            const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * Sp * D * 3));
+            const int G = (S + 7) >> 3;
+            for (int it = tid; it < spw * G * (D / 4); it += 1024) {
+              const int cl = it % (D / 4), g = (it / (D / 4)) % G, si = (it / (D / 4)) / G;
+              if (s0 + si >= B) continue;
+              const int off = (s0 + si) * Sp * D * 3 + (g * 4 * (D / 4) + cl) * 16;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {  // keys past the sentence: zeros (finite once unpacked, weight 0)
+                const int k0 = 8 * g + 2 * q, k1 = k0 + 1;
+                const v4i z = {0, 0, 0, 0};
+                const v4i x0 = *reinterpret_cast<const v4i *>(stg + (si * S + (k0 < S ? k0 : 0)) * LDY + 4 * cl);
+                const v4i x1 = *reinterpret_cast<const v4i *>(stg + (si * S + (k1 < S ? k1 : 0)) * LDY + 4 * cl);
+                const v4i pk = pack16(k0 < S ? x0 : z, k1 < S ? x1 : z);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, off + q * (D / 4) * 16, 0, 0);
+              }
+            }
+          }
+          continue;
+        }
         if (!wide) {
           // the narrow form (decode_fused.hip, attention_row20_64): one thread = 32 values = four quads of hi halves +
           // one quad of lo nibbles
@@ -764,15 +816,16 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         }
       }
       if (!redo) break;
-      wide = true;
       {  // bw[0] holds the tile of whatever came next: back to this layer's K
         SLIMT_WPHASE_LANE;
         load_w(bw[0], a.dec_k[l], wave, lane);
       }
     }
     if (a.kv_fmt && a.kv24 && tid < spw && s0 + tid < B) {
-      a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
-      if (wide && a.kv_wide_count) __hip_atomic_fetch_add(a.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      a.kv_fmt[(size_t)l * B + s0 + tid] = (unsigned char)form;
+      if (form == 1 && a.kv_wide_count) __hip_atomic_fetch_add(a.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (try_tight && form != 2 && a.kv_not16_count)
+        __hip_atomic_fetch_add(a.kv_not16_count + l, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   if (gen_here) {

@@ -87,14 +87,15 @@ static bool kv_tight_enabled() {
   return enabled;
 }
 
-// Where the tight form has a writer and a reader: the D = 256 / F = 1536 tilings of 16 / 8 / 4 sentences (not the 32-sentence
-// tiling a large output layer takes, not clusters), S <= 32, the 64-row encoder.
+// Where the tight form has a writer and a reader: the tilings of 16 / 8 / 4 sentences of D = 256 / F = 1536 and D = 512 /
+// F = 2048 (not the 32-sentence tiling a large output layer takes, not clusters), S <= 32, the 64-row encoder (`tall`) or
+// the D = 512 one.
 static bool kv_tight_shape(const slimt_hip_ctx *c, int S, bool tall) {
   const slimt_hip_model *m = c->model;
   if (!kv_tight_enabled() || !tall || S > 32 || m->kv_tight_limit <= 0 || m->kv_format != 0) return false;
   // (mode 0 takes the 32-sentence tiling for a large output layer: known at the decoder launch only -- what this context's
   // last one saw stands in for it; a wrong guess costs that one batch the 16-sentence tiling)
-  if (!((c->decode_mode == 0 && !c->expect_large_output) || c->decode_mode == 2 || c->decode_mode == 4 || c->decode_mode == 5)) return false;
+  if (!((c->decode_mode == 0 && (!c->expect_large_output || m->D != 256)) || c->decode_mode == 2 || c->decode_mode == 4 || c->decode_mode == 5)) return false;
   return fused_decode_tight_supported(m->D, m->F, m->H, m->Ld);
 }
 
@@ -1427,7 +1428,8 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.kv_narrow_limit = std::min(m->kv_narrow_limit, 1 << 19);
       c->kv_fmt_B = B;
       c->model->kv_layers_submitted.fetch_add((unsigned long long)B * m->Ld, std::memory_order_relaxed);
-      f.kv_tight_layers = kv_tight_wanted(c, S, tall_encoder_chosen(c, B, S), &f.kv_not16_count);
+      // (the encoders with a writer for it: the 64-row one at D = 256, the D = 512 one)
+      f.kv_tight_layers = kv_tight_wanted(c, S, tall_encoder_chosen(c, B, S) || D == 512, &f.kv_not16_count);
       if (f.kv_tight_layers) {
         f.kv_tight_limit = std::min(m->kv_tight_limit, 1 << 15);
         for (int l = 0; l < m->Ld; ++l)
@@ -1802,7 +1804,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   // f32 instead, and its column means become the centres (behind the encoder, on this stream).
   bool calibrate = false;
   if (kv_packed && c->model->kv_centre_state.load(std::memory_order_acquire) == 0 && B * S >= 2048 &&
-      kv_tight_shape(c, (int)S, tall_encoder_chosen(c, (int)B, (int)S)) &&
+      kv_tight_shape(c, (int)S, tall_encoder_chosen(c, (int)B, (int)S) || m->D == 512) &&
       !c->model->kv_centre_claimed.exchange(true, std::memory_order_acq_rel))
     calibrate = true;
   const bool kv24 = kv_packed && !calibrate;
