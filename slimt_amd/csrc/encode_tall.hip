@@ -794,7 +794,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   // hold the same integers.
   const bool try_narrow = a.kv24 && a.kv_fmt != nullptr;
   for (int l = 0; l < a.Ld; ++l) {
-    const bool try_tight = NKT == 2 && try_narrow && a.kv_tight_limit > 0 && ((a.kv_tight_layers >> l) & 1u);
+    const bool try_tight = try_narrow && a.kv_tight_limit > 0 && ((a.kv_tight_layers >> l) & 1u);
     int form = !try_narrow ? 1 : try_tight ? 2 : 0;  // kv_fmt's codes
     for (int attempt = 0; attempt < 3; ++attempt) {
       const bool wide = form == 1;
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           const v4i c = mma_rt(wf, rt, af, skv);
           const int rrow = 16 * rt + lr;
           if (a.kv24) {
-            if (NKT == 2 && form == 2) {
+            if (form == 2) {
               const v4i sg = c - *reinterpret_cast<const v4i *>(a.kv_centre[l][p] + col);  // less the columns' centres
               *reinterpret_cast<v4i *>(stg + rrow * LDY + col) = sg;
               if (row_valid(rrow)) {
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           break;
         }
         const int Sp = (S + 3) & ~3;
-        if (NKT == 2 && form == 2) {
+        if (form == 2) {
           // the tight form (decode_fused.hip, attention_row16): one thread = 32 values = four quads of int16
           if (p == 0) {  // K [sentence][head][plane 0..3][key][16 B]: consecutive lanes = consecutive keys
             const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * S * D * 3));

@@ -88,11 +88,14 @@ static bool kv_tight_enabled() {
 }
 
 // Where the tight form has a writer and a reader: the tilings of 16 / 8 / 4 sentences of D = 256 / F = 1536 and D = 512 /
-// F = 2048 (not the 32-sentence tiling a large output layer takes, not clusters), S <= 32, the 64-row encoder (`tall`) or
-// the D = 512 one.
+// F = 2048 (not the 32-sentence tiling a large output layer takes, not clusters), S <= 32 -- S <= 64 at D = 256 --, the
+// 64-row encoder (`tall`) or the D = 512 one.
 static bool kv_tight_shape(const slimt_hip_ctx *c, int S, bool tall) {
   const slimt_hip_model *m = c->model;
-  if (!kv_tight_enabled() || !tall || S > 32 || m->kv_tight_limit <= 0 || m->kv_format != 0) return false;
+  if (!kv_tight_enabled() || !tall || m->kv_tight_limit <= 0 || m->kv_format != 0) return false;
+  if (S > 32)  // sentences of 33..64 tokens: D = 256 only (`tall`: one per 64-row workgroup)
+    return S <= 64 && m->D == 256 && c->decode_mode != 3 && c->decode_mode != 6 && c->decode_mode != 1 &&
+           fused_decode_tight_mid_supported(m->D, m->F, m->H, m->Ld);
   // (mode 0 takes the 32-sentence tiling for a large output layer: known at the decoder launch only -- what this context's
   // last one saw stands in for it; a wrong guess costs that one batch the 16-sentence tiling)
   if (!((c->decode_mode == 0 && (!c->expect_large_output || m->D != 256)) || c->decode_mode == 2 || c->decode_mode == 4 || c->decode_mode == 5)) return false;
