@@ -1960,6 +1960,163 @@ __device__ __forceinline__ void attention_row20_long(AttnRow r, int lane, lcf_pt
       pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
 }
 
+// attention_row20_long out of line (see attention_row24_cold): the fallback of the tight form for 65..128-token sentences.
+template <int KV_AUX>
+__device__ __noinline__ void attention_row20_long_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096, float uv4096) {
+  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
+  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
+  attention_row20_long<KV_AUX>(r, lane, pbk, pbv, uk4096, uv4096);
+}
+
+// attention_row20_long over the tight form (65..128-token sentences, written by encode_long16_kernel): the layouts and the
+// arithmetic of attention_row16 (four int16 planes, less the column's centre), the passes of the long forms -- lane L holds
+// keys L and L + 64, two K buffers a half pass ahead, the canonical 128-column softmax, V as whole rows in groups of eight
+// keys, groups past the sentence skipped.
+template <int KV_AUX>
+__device__ __forceinline__ void attention_row16_long(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, CentreLds ck, CentreLds cv) {
+  constexpr int D = 256, DH = 32, H = D / DH;
+  const int S = __builtin_amdgcn_readfirstlane(r.S), len = __builtin_amdgcn_readfirstlane(r.len);
+  const int lenf = len > 0 ? len : S;
+  const float minus_inf = -99999999.0f;  // Input.cc:56-61
+  const float lowest = -3.402823466e+38f;
+  const int j0 = lane, j1 = lane + 64;
+  const float mask0 = (1.0f - (j0 < len ? 1.0f : 0.0f)) * minus_inf;
+  const float mask1 = (1.0f - (j1 < len ? 1.0f : 0.0f)) * minus_inf;
+  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 512));
+  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((lenf + 7) >> 3) * 4096));
+  const int koff0 = j0 < lenf ? j0 * 16 : kPastDescriptor;  // [head][plane 0..3][S][16 B]
+  const int koff1 = j1 < lenf ? j1 * 16 : kPastDescriptor;
+  const int voff = lane * 16;                               // [S/8][plane 0..3][D/4][16 B]
+  auto pair16 = [](int d, f2 c) -> f2 {
+    const f2 v = {(float)(short)(d & 0xffff), (float)(d >> 16)};
+    return v + c;
+  };
+  v4i ka[4], kb[4];
+  auto load_k = [&](v4i(&kq)[4], int h, int koff) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((4 * h + i) * S) * 16, KV_AUX));
+  };
+  auto score = [&](const v4i(&kq)[4], int h) -> float {  // this lane's key against head h: the ascending-column fmaf chain t_j
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d0 = h * DH + 8 * i;
+      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
+      const f4 ca = ck.at4(d0), cb = ck.at4(d0 + 4);
+      const f2 k01 = pair16(kq[i].x, f2{ca.x, ca.y}), k23 = pair16(kq[i].y, f2{ca.z, ca.w});
+      const f2 k45 = pair16(kq[i].z, f2{cb.x, cb.y}), k67 = pair16(kq[i].w, f2{cb.z, cb.w});
+      t = __builtin_fmaf(qa.x, k01.x, t);
+      t = __builtin_fmaf(qa.y, k01.y, t);
+      t = __builtin_fmaf(qa.z, k23.x, t);
+      t = __builtin_fmaf(qa.w, k23.y, t);
+      t = __builtin_fmaf(qb.x, k45.x, t);
+      t = __builtin_fmaf(qb.y, k45.y, t);
+      t = __builtin_fmaf(qb.z, k67.x, t);
+      t = __builtin_fmaf(qb.w, k67.y, t);
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    return t;
+  };
+  load_k(ka, 0, koff0);
+  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
+    float ckh[4];
+    head_constants32(r.qrow, pbk, lane, ckh);
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ckh[i];
+    }
+  }
+  auto head = [&](int h, bool last) {
+    load_k(kb, h, koff1);
+    __builtin_amdgcn_sched_barrier(0);
+    float s0 = score(ka, h);
+    if (!last) load_k(ka, h + 1, koff0);  // (the last head requests nothing it would have to wait out again)
+    __builtin_amdgcn_sched_barrier(0);
+    float s1 = score(kb, h);
+    const float ch = r.hsum[8 + h];
+    s0 = __builtin_fmaf(s0, r.uk, ch);
+    s1 = __builtin_fmaf(s1, r.uk, ch);
+    if (r.alpha != 1.0f) {
+      s0 = r.alpha * s0;
+      s1 = r.alpha * s1;
+    }
+    s0 = s0 + mask0;
+    s1 = s1 + mask1;
+    if (j0 >= S) s0 = lowest;
+    if (j1 >= S) s1 = lowest;
+    const float m = wave_max(fmaxf(s0, s1));
+    const float e0 = j0 < S ? exp_p(s0 - m) : 0.0f;
+    const float e1 = j1 < S ? exp_p(s1 - m) : 0.0f;
+    const float sum = wave_sum(e0 + e1);
+    const float p0 = e0 / sum, p1 = e1 / sum;  // keys >= S: exactly 0
+    r.pbuf[h * 128 + j0] = p0;
+    r.pbuf[h * 128 + j1] = p1;
+    const float ps = wave_sum(p0 + p1);  // P_h: lane L adds keys L and L + 64, then the butterfly
+    if (lane == 0) r.hsum[h] = ps;
+  };
+#pragma unroll 1
+  for (int h = 0; h < H - 1; ++h) head(h, false);
+  head(H - 1, true);
+  constexpr int NV = 3;  // V key groups (eight rows, four planes each) in flight
+  v4i vq[NV][4];
+  auto load_v = [&](v4i(&vv)[4], int g) {  // rows 8 g .. 8 g + 7 (past the descriptor: zeros)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (4 * g + i) * 1024, KV_AUX));
+  };
+  if (r.align) {  // head 0 over the sentence's own keys (update_alignment, Model.cc:84-108)
+    if (j0 < len) r.align[j0] = r.pbuf[j0];
+    if (j1 < len) r.align[j1] = r.pbuf[j1];
+  }
+  if (r.attn) {
+    for (int h = 0; h < H; ++h) {
+      if (j0 < S) r.attn[(size_t)h * S + j0] = r.pbuf[h * 128 + j0];
+      if (j1 < S) r.attn[(size_t)h * S + j1] = r.pbuf[h * 128 + j1];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    load_v(vq[k], k);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
+  const int ph = (lane >> 3) * 128;
+  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
+  const f4 cv4 = cv.at4(4 * lane);
+  const f2 c01 = {cv4.x, cv4.y}, c23 = {cv4.z, cv4.w};
+  const float P = r.hsum[lane >> 3];
+  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
+  const int ng = (lenf + 7) >> 3;  // key groups that hold a key with a non-zero weight
+  auto group = [&](const v4i(&cur)[4], int g) {
+    if (g >= ng) return;  // (uniform) past the sentence: pbuf holds the next head's probabilities there
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
+      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
+      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
+      oa = __builtin_elementwise_fma(p0, pair16(cur[c].x, c01), oa);
+      ob = __builtin_elementwise_fma(p0, pair16(cur[c].y, c23), ob);
+      oa = __builtin_elementwise_fma(p1, pair16(cur[c].z, c01), oa);
+      ob = __builtin_elementwise_fma(p1, pair16(cur[c].w, c23), ob);
+    }
+    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
+  };
+#pragma unroll 1
+  for (int g = 0; g < ng; g += NV) {  // (groups past ng inside the last round are skipped; their rows: zeros)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      group(vq[k], g + k);
+      load_v(vq[k], g + k + NV);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const float o0 = __builtin_fmaf(oa.x, r.uv, pv4.x * P), o1 = __builtin_fmaf(oa.y, r.uv, pv4.y * P);
+  const float o2 = __builtin_fmaf(ob.x, r.uv, pv4.z * P), o3 = __builtin_fmaf(ob.y, r.uv, pv4.w * P);
+  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
+      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
+}
+
 // The same for D = 512, d_head 64 ("base"). At K = 512 the shifted accumulator needs 25 bits, so
 // the cache holds the SIGNED one (|acc| <= 127 * 128 * 512 < 2^23) and the column's 127 colsum term
 // comes back here: c127 = float(127 colsum * 256) is exact, and so is float(acc * 256) + c127
@@ -2381,7 +2538,7 @@ template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = 
           int KVI = 20>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr bool KV20 = KVI != 24;
-  static_assert(KVI == 24 || KVI == 20 || (KVI == 16 && KV24 && (KSD == 4 || KSD == 8) && MID <= 1 && RT == 1 && CL == 1), "16-bit form: sentences of up to 64 tokens at D = 256, up to 32 at D = 512");
+  static_assert(KVI == 24 || KVI == 20 || (KVI == 16 && KV24 && (KSD == 4 || KSD == 8) && RT == 1 && CL == 1), "16-bit form: sentences of up to 128 tokens at D = 256, up to 32 at D = 512");
   static_assert(CL == 1 || (CL <= 4 && RT == 1 && SPW == 16 && MID == 0 && !LONG), "cluster logits: the 16-sentence tilings");
   static_assert(SPW == 16 || ((SPW == 8 || SPW == 4) && RT == 1 && KV24), "fewer sentences per workgroup: the packed-cache, 16-row variants");
   static_assert(!KV24 || (((KSD == 4 && DH == 32) || (KSD == 8 && DH == 64)) && !LONG),
@@ -2762,9 +2919,24 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             else
               attention_row24_long<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
             } else {
-            const bool wide = ((rr ? kv_wide[RT - 1] : kv_wide[0]) >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
-            if (!wide) {
-              if (NT && kv_streams)
+            const unsigned forms = rr ? kv_wide[RT - 1] : kv_wide[0];
+            const bool wide = (forms >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
+            const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
+            if (tight) {
+              if constexpr (KVI == 16) {
+                const CentreLds ck = {(lcf_ptr)(kvc127 + (2 * l) * D)}, cv = {(lcf_ptr)(kvc127 + (2 * l + 1) * D)};
+                if (NT && kv_streams)
+                  attention_row16_long<2>(ar, lane, pbk, pbv, ck, cv);
+                else
+                  attention_row16_long<0>(ar, lane, pbk, pbv, ck, cv);
+              }
+            } else if (!wide) {
+              if constexpr (KVI == 16) {  // (the rare sentence-layer past the centres' int16)
+                if (NT && kv_streams)
+                  attention_row20_long_cold<2>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+                else
+                  attention_row20_long_cold<0>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
+              } else if (NT && kv_streams)
                 attention_row20_long<2>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
               else
                 attention_row20_long<0>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
@@ -3308,10 +3480,10 @@ bool fused_decode_tight_supported(int D, int F, int H, int Ld) {
          fused_decode_lds_bytes(D, F, Ld, 16, true, 0, nullptr, true) <= 160 * 1024;
 }
 
-// ... and for sentences of 33..64 tokens (D = 256; decode_fused_kernel<..., MID = 1, ..., KVI = 16>)
-bool fused_decode_tight_mid_supported(int D, int F, int H, int Ld) {
+// ... and for sentences of 33..128 tokens (D = 256; decode_fused_kernel<..., MID = 1 / 2, ..., KVI = 16>)
+bool fused_decode_tight_mid_supported(int D, int F, int H, int Ld, int mid) {  // mid: 1 = 33..64 tokens, 2 = 65..128
   if (Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
-  return D == 256 && F == 1536 && D / H == 32 && fused_decode_lds_bytes(D, F, Ld, 16, true, 1, nullptr, true) <= 160 * 1024;
+  return D == 256 && F == 1536 && D / H == 32 && fused_decode_lds_bytes(D, F, Ld, 16, true, mid, nullptr, true) <= 160 * 1024;
 }
 
 // sentences of 33..64 tokens over the packed cache (decode_fused_kernel<..., MID>)
@@ -3360,7 +3532,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   if (a.home_mask && rows != 16) return hipErrorInvalidValue;  // the XCD-affine claim counts 16-sentence tiles
   // a batch with sentence-layers in the tight form: only the kernels with its reader (engine.cpp, kv_tight_wanted)
   if (a.kv_tight && !(kv24 && a.kv_fmt && rows <= 16 && a.cluster <= 1 &&
-                      (a.S <= 32 ? fused_decode_tight_supported(D, F, H, a.Ld) : a.S <= 64 && fused_decode_tight_mid_supported(D, F, H, a.Ld))))
+                      (a.S <= 32 ? fused_decode_tight_supported(D, F, H, a.Ld) : a.S <= 128 && fused_decode_tight_mid_supported(D, F, H, a.Ld, mid))))
     return hipErrorInvalidValue;
   auto go = [&](void (*k)(FusedDecodeArgs), size_t lds) -> hipError_t {
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
@@ -3386,11 +3558,12 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
     if (rows > 16 || F != 1536) return hipErrorInvalidValue;
     const size_t ldsm = fused_decode_lds_bytes(D, F, a.Ld, 16, true, mid, nullptr, a.kv_tight);
     if (ldsm > 160 * 1024) return hipErrorInvalidValue;
-    if (a.kv_tight) {  // (mid == 1: checked above)
-#define SLIMT_KV16_PICK(SPW_)                                                                      \
-  (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 1, SPW_, 1, 16>                  \
-           : decode_fused_kernel<4, 24, 32, false, false, 1, true, 1, SPW_, 1, 16>)
-      return go(rows == 4 ? SLIMT_KV16_PICK(4) : rows == 8 ? SLIMT_KV16_PICK(8) : SLIMT_KV16_PICK(16), ldsm);
+    if (a.kv_tight) {
+#define SLIMT_KV16_PICK(MID_, SPW_)                                                                \
+  (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, MID_, SPW_, 1, 16>               \
+           : decode_fused_kernel<4, 24, 32, false, false, 1, true, MID_, SPW_, 1, 16>)
+      if (mid == 1) return go(rows == 4 ? SLIMT_KV16_PICK(1, 4) : rows == 8 ? SLIMT_KV16_PICK(1, 8) : SLIMT_KV16_PICK(1, 16), ldsm);
+      return go(rows == 4 ? SLIMT_KV16_PICK(2, 4) : rows == 8 ? SLIMT_KV16_PICK(2, 8) : SLIMT_KV16_PICK(2, 16), ldsm);
 #undef SLIMT_KV16_PICK
     }
     if (only24) return go(mid == 2 ? SLIMT_KV24_ONLY(4, 24, 32, 2) : SLIMT_KV24_ONLY(4, 24, 32, 1), ldsm);

@@ -1205,16 +1205,19 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
 #pragma unroll
       for (int i = 0; i < KSD; ++i) f.enc_out[((size_t)row0 + r) * D + lane + 64 * i] = X[(size_t)r * D + lane + 64 * i];
   const size_t M = (size_t)f.B * S;
-  // The packed cache of this sentence takes one of two forms per layer (kernels.h, FusedDecodeArgs::kv_fmt; encode_tall.hip
-  // has the same scheme): narrow first, and when an accumulator of K or V does not fit 20 bits the layer is done again in
-  // the 24-bit form.
+  // The packed cache of this sentence takes one of three forms per layer (kernels.h, FusedDecodeArgs::kv_fmt; encode_tall.hip
+  // has the same scheme): the smallest allowed first -- tight (int16 less the column's centre) where the engine allows it,
+  // else narrow --, and when an accumulator of K or V does not fit, the layer is done again in the smallest form that
+  // holds it (kv_wide_flag: 1 = not tight, 2 = not narrow).
   __shared__ int kv_wide_flag;
   const bool try_narrow = f.kv24 && f.kv_fmt != nullptr;
   for (int l = 0; l < f.Ld; ++l) {
     SLIMT_PHASE_LANE;
     const int col = wave * 16 + lr;
-    bool wide = !try_narrow;
-   for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool try_tight = try_narrow && f.kv_tight_limit > 0 && ((f.kv_tight_layers >> l) & 1u);
+    int form = !try_narrow ? 1 : try_tight ? 2 : 0;  // kv_fmt's codes
+   for (int attempt = 0; attempt < 3; ++attempt) {
+    const bool wide = form == 1;
     bool redo = false;
     for (int which = 0; which < 2; ++which) {
       const PreparedWeight &W = which == 0 ? f.dec_k[l] : f.dec_v[l];
@@ -1244,25 +1247,66 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
         // so that a thread holds 16 columns of one key (K) or 4 keys x 4 columns (V).
         __syncthreads();  // every wave has read its A fragments
         int *stg = reinterpret_cast<int *>(smem);
-        unsigned outside = 0;  // narrow attempt: an accumulator of one of the sentence's rows outside [-limit, limit)
-        const unsigned lim = (unsigned)f.kv_narrow_limit;
+        unsigned outside = 0;  // an accumulator of one of the sentence's rows outside the form's range
+        const unsigned lim = (unsigned)f.kv_narrow_limit, lim16 = (unsigned)f.kv_tight_limit;
+        const int ctr = form == 2 ? f.kv_centre[l][which][col] : 0;  // tight: staged less the column's centre
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
           if (rt < nrt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int v = acc[rt][r] + __mul24(127, cs);
-              stg[(16 * rt + lg * 4 + r) * D + col] = v;
-              if (!wide && 16 * rt + lg * 4 + r < S) outside |= (unsigned)((unsigned)v + lim >= 2u * lim);
+              stg[(16 * rt + lg * 4 + r) * D + col] = v - ctr;
+              if (!wide && 16 * rt + lg * 4 + r < S) {
+                outside |= (unsigned)((unsigned)v + lim >= 2u * lim) << 1;
+                if (form == 2) outside |= (unsigned)((unsigned)(v - ctr) + lim16 >= 2u * lim16);
+              }
             }
           }
-        if (outside) kv_wide_flag = 1;
+        if (outside) __hip_atomic_fetch_or(&kv_wide_flag, (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
-        if (!wide && kv_wide_flag) {  // uniform: read by every thread behind the barrier
+        // (uniform: read by every thread behind the barrier; a tight attempt that holds does not care about accS's range)
+        if (!wide && (kv_wide_flag & (form == 2 ? 1 : 2))) {
           redo = true;
+          form = (kv_wide_flag & 2) ? 1 : 0;
           break;
         }
         const int Sp = (S + 3) & ~3;
+        if (form == 2) {
+          // the tight form (decode_fused.hip, attention_row16_long): one thread = 32 values = four quads of int16;
+          // K [head][plane 0..3][key][16 B], V [key / 8][plane 0..3][column / 4][16 B]
+          if (which == 0) {
+            const rsrc_t rp = make_rsrc(reinterpret_cast<const char *>(out) + (size_t)b * S * D * 3, (unsigned)(S * D * 3));
+            for (int it = tid; it < S * (D / 32); it += 1024) {
+              const int r = it % S, h = it / S;
+              const int off = (h * 4 * S + r) * 16;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const v4i pk = pack16(*reinterpret_cast<const v4i *>(stg + r * D + 32 * h + 8 * q),
+                                      *reinterpret_cast<const v4i *>(stg + r * D + 32 * h + 8 * q + 4));
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rp, off + q * S * 16, 0, 0);
+              }
+            }
+          } else {
+            const rsrc_t rp = make_rsrc(reinterpret_cast<const char *>(out) + (size_t)b * Sp * D * 3, (unsigned)(Sp * D * 3));
+            const int G = (S + 7) >> 3;
+            for (int it = tid; it < G * 64; it += 1024) {
+              const int cl = it & 63, g = it >> 6;
+              const int off = (g * 4 * 64 + cl) * 16;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {  // keys past the sentence: zeros (finite once unpacked, weight 0)
+                const int k0 = 8 * g + 2 * q, k1 = k0 + 1;
+                const v4i z = {0, 0, 0, 0};
+                const v4i x0 = *reinterpret_cast<const v4i *>(stg + (k0 < S ? k0 : 0) * D + 4 * cl);
+                const v4i x1 = *reinterpret_cast<const v4i *>(stg + (k1 < S ? k1 : 0) * D + 4 * cl);
+                const v4i pk = pack16(k0 < S ? x0 : z, k1 < S ? x1 : z);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rp, off + q * 1024, 0, 0);
+              }
+            }
+          }
+          __syncthreads();
+          continue;
+        }
         if (!wide) {
           // the narrow form (decode_fused.hip, attention_row20_long): one thread = 32 values = four quads of hi halves +
           // one quad of lo nibbles; K [head][plane 0..4][key][16 B], V [key / 8][plane 0..4][column / 4][16 B]
@@ -1355,11 +1399,12 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
       __syncthreads();
     }
     if (!redo) break;
-    wide = true;
    }
     if (f.kv_fmt && f.kv24 && tid == 0) {
-      f.kv_fmt[(size_t)l * f.B + b] = wide ? 1 : 0;
-      if (wide && f.kv_wide_count) __hip_atomic_fetch_add(f.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      f.kv_fmt[(size_t)l * f.B + b] = (unsigned char)form;
+      if (form == 1 && f.kv_wide_count) __hip_atomic_fetch_add(f.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (try_tight && form != 2 && f.kv_not16_count)
+        __hip_atomic_fetch_add(f.kv_not16_count + l, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

@@ -88,14 +88,14 @@ static bool kv_tight_enabled() {
 }
 
 // Where the tight form has a writer and a reader: the tilings of 16 / 8 / 4 sentences of D = 256 / F = 1536 and D = 512 /
-// F = 2048 (not the 32-sentence tiling a large output layer takes, not clusters), S <= 32 -- S <= 64 at D = 256 --, the
-// 64-row encoder (`tall`) or the D = 512 one.
+// F = 2048 (not the 32-sentence tiling a large output layer takes, not clusters), S <= 32 -- S <= 128 at D = 256 --, and
+// an encoder with a writer for it (`tall`: kv_tight_writer).
 static bool kv_tight_shape(const slimt_hip_ctx *c, int S, bool tall) {
   const slimt_hip_model *m = c->model;
   if (!kv_tight_enabled() || !tall || m->kv_tight_limit <= 0 || m->kv_format != 0) return false;
-  if (S > 32)  // sentences of 33..64 tokens: D = 256 only (`tall`: one per 64-row workgroup)
-    return S <= 64 && m->D == 256 && c->decode_mode != 3 && c->decode_mode != 6 && c->decode_mode != 1 &&
-           fused_decode_tight_mid_supported(m->D, m->F, m->H, m->Ld);
+  if (S > 32)  // longer sentences: D = 256 only (33..64 tokens: one per 64-row workgroup; 65..128: the per-sentence encoder)
+    return S <= 128 && m->D == 256 && c->decode_mode != 3 && c->decode_mode != 6 && c->decode_mode != 1 &&
+           fused_decode_tight_mid_supported(m->D, m->F, m->H, m->Ld, S > 64 ? 2 : 1);
   // (mode 0 takes the 32-sentence tiling for a large output layer: known at the decoder launch only -- what this context's
   // last one saw stands in for it; a wrong guess costs that one batch the 16-sentence tiling)
   if (!((c->decode_mode == 0 && (!c->expect_large_output || m->D != 256)) || c->decode_mode == 2 || c->decode_mode == 4 || c->decode_mode == 5)) return false;
@@ -1361,6 +1361,14 @@ bool tall_encoder_chosen(const slimt_hip_ctx *c, int B, int S) {
                       (c->encode_rows == 64 || (c->encode_rows == 0 && tall_encode_grid(B, S, false) >= 32)));
 }
 
+// the encoders with a writer for the tight K/V form: the 64-row one (D = 256, S <= 64), the D = 512 one, and the
+// per-sentence one for 65..128 tokens
+static bool kv_tight_writer(const slimt_hip_ctx *c, int B, int S) {
+  const slimt_hip_model *m = c->model;
+  if (S > 64) return c->decode_mode != 1 && long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S);
+  return tall_encoder_chosen(c, B, S) || (m->D == 512 && S <= 32);
+}
+
 // embedding + every encoder layer + the decoder's K/V cache in one launch of encode_tall / encode_fused / encode_wide
 bool fused_encoder_chosen(const slimt_hip_ctx *c, int B, int S) {
   (void)B;
@@ -1431,8 +1439,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.kv_narrow_limit = std::min(m->kv_narrow_limit, 1 << 19);
       c->kv_fmt_B = B;
       c->model->kv_layers_submitted.fetch_add((unsigned long long)B * m->Ld, std::memory_order_relaxed);
-      // (the encoders with a writer for it: the 64-row one at D = 256, the D = 512 one)
-      f.kv_tight_layers = kv_tight_wanted(c, S, tall_encoder_chosen(c, B, S) || D == 512, &f.kv_not16_count);
+      f.kv_tight_layers = kv_tight_wanted(c, S, kv_tight_writer(c, B, S), &f.kv_not16_count);
       if (f.kv_tight_layers) {
         f.kv_tight_limit = std::min(m->kv_tight_limit, 1 << 15);
         for (int l = 0; l < m->Ld; ++l)
@@ -1526,6 +1533,15 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.kv_narrow_limit = std::min(m->kv_narrow_limit, 1 << 19);
       c->kv_fmt_B = B;
       c->model->kv_layers_submitted.fetch_add((unsigned long long)B * m->Ld, std::memory_order_relaxed);
+      f.kv_tight_layers = kv_tight_wanted(c, S, kv_tight_writer(c, B, S), &f.kv_not16_count);
+      if (f.kv_tight_layers) {
+        f.kv_tight_limit = std::min(m->kv_tight_limit, 1 << 15);
+        for (int l = 0; l < m->Ld; ++l)
+          for (int p = 0; p < 2; ++p) f.kv_centre[l][p] = m->kv_centre.as<int>() + (size_t)(2 * l + p) * D;
+        c->kv_tight = true;
+        for (int l = 0; l < m->Ld; ++l)
+          if ((f.kv_tight_layers >> l) & 1u) c->model->kv_tight_submitted[l].fetch_add((unsigned long long)B, std::memory_order_relaxed);
+      }
     }
     f.enc_out = c->x0.as<float>();
     if (pack) {
@@ -1807,7 +1823,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   // f32 instead, and its column means become the centres (behind the encoder, on this stream).
   bool calibrate = false;
   if (kv_packed && c->model->kv_centre_state.load(std::memory_order_acquire) == 0 && B * S >= 2048 &&
-      kv_tight_shape(c, (int)S, tall_encoder_chosen(c, (int)B, (int)S) || m->D == 512) &&
+      kv_tight_shape(c, (int)S, kv_tight_writer(c, (int)B, (int)S)) &&
       !c->model->kv_centre_claimed.exchange(true, std::memory_order_acq_rel))
     calibrate = true;
   const bool kv24 = kv_packed && !calibrate;

@@ -96,10 +96,10 @@ def test_forms_follow_the_accumulators_and_results_do_not(hip, oracle, synth_mod
         # limits: the real one, and three that split this batch's sentences (the median peak, its neighbours)
         order = np.sort(peak.ravel())
         limits = [2 ** 19, int(order[len(order) // 2]), int(order[len(order) // 4]) + 1, int(order[-1]), int(order[-1]) + 1, 1]
-        # the tight (16-bit) form: written by the 64-row encoder (tiny11: sentences of up to 64 tokens) and the D = 512 one
-        # (base: up to 32), read by the tilings of 16 / 8 / 4 sentences (modes 0, 2, 4, 5); its limits likewise: int16's,
-        # two that split the batch, none
-        tight_here = (preset == "tiny11" and S <= 64 and rows == 64) or preset == "base"
+        # the tight (16-bit) form: written by the 64-row encoder (tiny11: sentences of up to 64 tokens), the per-sentence one
+        # (65..128) and the D = 512 one (base: up to 32), read by the tilings of 16 / 8 / 4 sentences (modes 0, 2, 4, 5);
+        # its limits likewise: int16's, two that split the batch, none
+        tight_here = (preset == "tiny11" and (rows == 64 or S > 64)) or preset == "base"
         centres = colsum_centres(m, jitter_seed=B * 100 + S)
         if tight_here:
             gm.set_kv_centres(centres)
