@@ -3326,6 +3326,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = l4v.v[r];
+#ifdef SLIMT_EXP_LOGITS_MAXONLY  // timing only (wrong tokens): the epilogue without its index bookkeeping -- what a two-stage arg-max could save
+            bv[rt][r] = fmaxf(bv[rt][r], v);
+            bi[rt][r] = col;
+            (void)in_range;
+            continue;
+#endif
             // a lane's columns only grow, so strict > keeps its first maximum
             const bool better = in_range && v > bv[rt][r];
             bv[rt][r] = better ? v : bv[rt][r];
