@@ -54,7 +54,8 @@ fi
     "--forward-steps 0 --batch 64 --src-len 128" "--forward-steps 0 --ragged" "--forward-steps 0 --preset base" \
     "--total-sentences 4096 --batch 512 --steps 10" "--total-sentences 4096 --batch 256 --steps 10" \
     "--forward-steps 0 --batch 4096 --workers 1 --sustained-steps 0" \
-    "--forward-steps 0 --kv-format 2" "--forward-steps 0 --preset base --kv-format 2" "--forward-steps 0 --batch 512 --shortlist 0 --decode-mode 6"
+    "--forward-steps 0 --kv-format 2" "--forward-steps 0 --preset base --kv-format 2" "--forward-steps 0 --batch 512 --shortlist 0 --decode-mode 6" \
+    "--forward-steps 0 --kv-tight-limit 0" "--forward-steps 0 --preset base --kv-tight-limit 0"
 } > gpurun_out/${TAG}_configs.txt 2>&1
 cat gpurun_out/${TAG}_configs.txt
 SLIMT_BENCH_REHEARSAL=1 timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 2 --workers 8 --no-cpu-baseline --sustained-steps 0 --forward-steps 0 > gpurun_out/${TAG}_rehearsal_2ranks_on_1gpu.json 2> gpurun_out/${TAG}_rehearsal.err
