@@ -387,6 +387,16 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     TEpi e1_next;
 #pragma unroll
     for (int hr = 0; hr < NR; ++hr) {
+#ifdef SLIMT_EXP_QKV_STAMPS  // diagnosis only: every wave's clock at four points of round SLIMT_EXP_QKV_STAMPS (slots wave * 3 + i, i < 3;
+                             // 48 + 11 + wave is taken: the fourth goes without)
+#define SLIMT_WSTAMP(i)                                                                                             \
+  do {                                                                                                              \
+    if (a.stamps && s0 == 0 && (tid & 63) == 0 && l == a.stamp_layer && hr == SLIMT_EXP_QKV_STAMPS)                 \
+      (a.stamps - 48)[wave * 3 + (i)] = wall_clock64();                                                             \
+  } while (0)
+#else
+#define SLIMT_WSTAMP(i)
+#endif
       const int ctl = wave & 7;
       const int ct = hr * (RC / 16) + ctl;
       {  // Q, K, V projections of this round's heads
@@ -414,14 +424,18 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         // here: the A buffers were last read by FFN1 (two barriers ago), and nothing below touches the region -- still the
         // exchange tile the LayerNorm before read -- until the barrier behind the quantisation. (Layer 0: the in-launch
         // shortlist generation used this memory.)
+        SLIMT_WSTAMP(0);
         if (hr > 0 || l == 0) lds_barrier();
+        SLIMT_WSTAMP(1);
         if (hr == 0) {  // x quantised with the three projections' multipliers, once per layer
           const lds_bptr qb0 = tq_base(lane);
           quantise_x(0, L.q.a_quant, qb0);
           quantise_x(TR * LDA, L.k.a_quant, qb0);
           quantise_x(2 * TR * LDA, L.v.a_quant, qb0);
+          SLIMT_WSTAMP(1);
           lds_barrier();
         }
+        SLIMT_WSTAMP(2);
         const char *A1 = qv ? Aq : Ak;
         float *dst1 = qv ? qb : kb;
         const AFrag af = a_frag(A1, lane);
