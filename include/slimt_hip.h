@@ -451,7 +451,7 @@ int slimt_hip_debug_kv_narrow_limit(slimt_hip_model *model, int limit);
  * all lie in [-limit, limit) as plain int16 (default and maximum 2^15; 0 = never tried; tests lower it so
  * that a batch mixes all three forms). Results do not depend on it. Starts the watches afresh. */
 int slimt_hip_debug_kv_tight_limit(slimt_hip_model *model, int limit);
-/* The tight form's per-column centres, [Ld][K, V][D] int32 (n = Ld * 2 * D, each within (-2^23, 2^23)):
+/* The tight form's per-column centres, [Ld][K, V][D] int32 (n = Ld * 2 * D, each within (-2^24, 2^24): a float holds it exactly):
  * the 16-bit form caches accumulator - centre, the decoder adds the centre back (exact), so the centres
  * decide which sentences fit the form and nothing else -- every result is the same for any centres.
  * Without this call the library calibrates them itself: the first batch of at least 2048 rows that could

@@ -934,7 +934,7 @@ extern "C" int slimt_hip_model_set_kv_centres(slimt_hip_model *model, const int3
   const size_t have = (size_t)model->Ld * 2 * (size_t)model->D;
   if (n != have) return fail(-1, "kv centres: %zu values given, the model takes Ld * 2 * D = %zu", n, have);
   for (size_t i = 0; i < n; ++i)
-    if (centres[i] <= -(1 << 23) || centres[i] >= (1 << 23)) return fail(-1, "kv centre %zu = %d not within (-2^23, 2^23)", i, centres[i]);
+    if (centres[i] <= -(1 << 24) || centres[i] >= (1 << 24)) return fail(-1, "kv centre %zu = %d not within (-2^24, 2^24)", i, centres[i]);
   HIPCHK(hipSetDevice(model->device));
   if (model->kv_centre_claimed.exchange(true, std::memory_order_acq_rel) && model->kv_centre_state.load(std::memory_order_acquire) != 2 &&
       !kv_centres_ready(model))

@@ -217,6 +217,13 @@ def test_narrow_limit_is_bounded(hip, synth_models):
                 gm.debug_kv_tight_limit(bad)
         gm.debug_kv_tight_limit(0)
         gm.debug_kv_tight_limit(2 ** 15)
+        n = m.dec_layers * 2 * m.D
+        for bad in (np.full(n, 2 ** 24, dtype=np.int32), np.full(n, -2 ** 24, dtype=np.int32), np.zeros(n - 1, dtype=np.int32)):
+            with pytest.raises(hip.SlimtHipError):
+                gm.set_kv_centres(bad)
+        assert gm.debug_kv_centres(m.dec_layers, m.D) is None
+        gm.set_kv_centres(np.full(n, 2 ** 24 - 1, dtype=np.int32))
+        assert (gm.debug_kv_centres(m.dec_layers, m.D) == 2 ** 24 - 1).all()
     finally:
         gm.close()
 
