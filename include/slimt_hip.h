@@ -172,9 +172,11 @@ int slimt_hip_model_set_xcd_affinity(slimt_hip_model *model, int xcds);
  * roundings, <= 2.5e-5 apart; every format gives the same floats as every other):
  *   0 (default) = packed integers where the kernels support it (emb 256 / head dim 32 with
  *       sources of up to 128 tokens, emb 512 / head dim 64 up to 32), f32 elsewhere. Packed
- *       means 24 bits per value, or -- emb 256, sources of up to 32 tokens -- 20 bits for
- *       every sentence and layer whose accumulators all lie in [-2^19, 2^19), decided by the
- *       encoder per batch (the 24-bit form holds any accumulator and is the fallback);
+ *       means, per sentence and decoder layer and decided by the encoder: 16 bits per value
+ *       where every accumulator less its column's centre lies in [-2^15, 2^15)
+ *       (slimt_hip_model_set_kv_centres; the first batch of >= 2048 rows is cached as f32
+ *       to calibrate the centres when none were set), else 20 bits where every accumulator
+ *       lies in [-2^19, 2^19), else 24 bits (holds any accumulator);
  *   1 = always f32 (float(acc), exact);
  *   2 = packed, always 24 bits;
  *   3 = f32, and the attention in the reference's LITERAL sequence: every cached value
@@ -431,7 +433,8 @@ int slimt_hip_debug_cross_attention(slimt_hip_ctx *ctx, int layer, int literal, 
  * not to be used. Tests use it to reach that path. */
 int slimt_hip_debug_break_shortlist_handoff(slimt_hip_ctx *ctx, int broken, unsigned poll_limit);
 /* Diagnostic: which form each sentence-layer of ctx's last batch was cached in -- out[l * B + b],
- * 0 = 20-bit, 1 = 24-bit, 2 = 16-bit (the tight form); *batch = B, or 0 when the batch's caches are all in one form (f32 or
+ * 0 = 20-bit, 1 = 24-bit, 2 = 16-bit (the tight form); *batch = B, or 0 when the batch's caches
+ * are all in one form (f32 or
  * 24-bit: formats 1 / 2, or a shape without the narrow form). Waits for ctx's stream. */
 int slimt_hip_debug_kv_formats(slimt_hip_ctx *ctx, uint8_t *out, size_t n, size_t *batch);
 /* Diagnostic: format 0's watch. The library counts the sentence-layers it cached (submitted) and those

@@ -89,10 +89,10 @@ static bool kv_tight_enabled() {
 
 // Where the tight form has a writer and a reader: the tilings of 16 / 8 / 4 sentences of D = 256 / F = 1536 and D = 512 /
 // F = 2048 (not the 32-sentence tiling a large output layer takes, not clusters), S <= 32 -- S <= 128 at D = 256 --, and
-// an encoder with a writer for it (`tall`: kv_tight_writer).
-static bool kv_tight_shape(const slimt_hip_ctx *c, int S, bool tall) {
+// an encoder with a writer for it (`writer`: kv_tight_writer).
+static bool kv_tight_shape(const slimt_hip_ctx *c, int S, bool writer) {
   const slimt_hip_model *m = c->model;
-  if (!kv_tight_enabled() || !tall || m->kv_tight_limit <= 0 || m->kv_format != 0) return false;
+  if (!kv_tight_enabled() || !writer || m->kv_tight_limit <= 0 || m->kv_format != 0) return false;
   if (S > 32)  // longer sentences: D = 256 only (33..64 tokens: one per 64-row workgroup; 65..128: the per-sentence encoder)
     return S <= 128 && m->D == 256 && c->decode_mode != 3 && c->decode_mode != 6 && c->decode_mode != 1 &&
            fused_decode_tight_mid_supported(m->D, m->F, m->H, m->Ld, S > 64 ? 2 : 1);
@@ -115,10 +115,10 @@ static bool kv_centres_ready(slimt_hip_model *m) {
 
 // The tight form for this batch's decoder layers (engine.h, kv_tight_off): a mask of the layers that try it. Only where the
 // decoder launch that follows will be one with the reader inlined (kv_tight_shape), and once the centres are there.
-static unsigned kv_tight_wanted(slimt_hip_ctx *c, int S, bool tall, unsigned long long **count_dev) {
+static unsigned kv_tight_wanted(slimt_hip_ctx *c, int S, bool writer, unsigned long long **count_dev) {
   slimt_hip_model *m = c->model;
   *count_dev = nullptr;
-  if (!kv_tight_shape(c, S, tall) || !m->kv_wide_count || !kv_centres_ready(m)) return 0;
+  if (!kv_tight_shape(c, S, writer) || !m->kv_wide_count || !kv_centres_ready(m)) return 0;
   static const bool watch = !(std::getenv("SLIMT_KV_WATCH") && std::getenv("SLIMT_KV_WATCH")[0] == '0');
   unsigned off = m->kv_tight_off.load(std::memory_order_relaxed);
   for (int l = 0; l < m->Ld && watch; ++l) {
