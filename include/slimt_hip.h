@@ -434,8 +434,8 @@ int slimt_hip_debug_cross_attention(slimt_hip_ctx *ctx, int layer, int literal, 
 int slimt_hip_debug_break_shortlist_handoff(slimt_hip_ctx *ctx, int broken, unsigned poll_limit);
 /* Diagnostic: which form each sentence-layer of ctx's last batch was cached in -- out[l * B + b],
  * 0 = 20-bit, 1 = 24-bit, 2 = 16-bit (the tight form); *batch = B, or 0 when the batch's caches
- * are all in one form (f32 or
- * 24-bit: formats 1 / 2, or a shape without the narrow form). Waits for ctx's stream. */
+ * are all in one form (f32 or 24-bit: formats 1 / 2, a shape without the narrow form, or the
+ * centres' calibration batch). Waits for ctx's stream. */
 int slimt_hip_debug_kv_formats(slimt_hip_ctx *ctx, uint8_t *out, size_t n, size_t *batch);
 /* Diagnostic: format 0's watch. The library counts the sentence-layers it cached (submitted) and those
  * that needed the 24-bit form (wide; updated by the device, a few batches behind); once more than one
