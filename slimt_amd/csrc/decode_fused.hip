@@ -2532,7 +2532,7 @@ __device__ __forceinline__ void attention_row16_64(AttnRow r, int lane, lcf_ptr 
 // KVI (packed-cache variants), the forms inlined: 20 = the narrow 20-bit form, the 24-bit form as the rare sentence's out-of-line
 // fallback; 24 = the 24-bit form inlined and nothing else (launches whose caches are all 24-bit: K/V cache format 2,
 // or a model the engine found mostly too wide for 20 bits -- there the out-of-line call would cost every sentence).
-// KVI = 16: the tight 16-bit form inlined instead (S <= 32, RT = 1; kv_fmt == 2; the others out of line), for batches whose
+// KVI = 16: the tight 16-bit form inlined instead (RT = 1; kv_fmt == 2; the 20- and 24-bit ones out of line), for batches whose
 // encoder was allowed it (engine.cpp, kv_tight_wanted); its centres take 2 D floats of LDS per layer.
 template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0, int SPW = 16, int CL = 1,
           int KVI = 20>
@@ -3555,7 +3555,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
                : (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_>                    \
                           : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_>))
   // every cache of this launch in the 24-bit form (a.kv_fmt == nullptr): the 16-sentence tilings have an instantiation
-  // with that form inlined (KV20 = false); the 8- / 4-sentence ones reach it through the fallback call
+  // with that form inlined (KVI = 24); the 8- / 4-sentence ones reach it through the fallback call
 #define SLIMT_KV24_ONLY(KSD_, KSF_, DH_, MID_)                                                        \
   (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_, 16, 1, 24>          \
            : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_, 16, 1, 24>)
@@ -3606,7 +3606,7 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
 #undef SLIMT_KV24_PICK
 #undef SLIMT_KV24_ONLY
   if (rows == 32) {
-    if (kv24 && !a.kv_fmt)  // every cache in the 24-bit form: that form inlined (KV20 = false), as for the 16-sentence tilings
+    if (kv24 && !a.kv_fmt)  // every cache in the 24-bit form: that form inlined (KVI = 24), as for the 16-sentence tilings
       return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true, 0, 16, 1, 24>
                         : decode_fused_kernel<4, 24, 32, false, false, 2, true, 0, 16, 1, 24>, lds);
     auto k = kv24 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true> : decode_fused_kernel<4, 24, 32, false, false, 2, true>)
