@@ -1826,6 +1826,14 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       kv_tight_shape(c, (int)S, kv_tight_writer(c, (int)B, (int)S)) &&
       !c->model->kv_centre_claimed.exchange(true, std::memory_order_acq_rel))
     calibrate = true;
+  // (a call that claimed the calibration and leaves before its reduction is queued -- an error on the way -- gives the claim back)
+  struct ClaimGuard {
+    slimt_hip_model *m;
+    bool armed;
+    ~ClaimGuard() {
+      if (armed && m->kv_centre_state.load(std::memory_order_acquire) == 0) m->kv_centre_claimed.store(false, std::memory_order_release);
+    }
+  } claim_guard{c->model, calibrate};
   const bool kv24 = kv_packed && !calibrate;
   // One thread at a time queues a persistent translate (a few runtime calls, ~50 us): the runtime
   // serialises launches internally anyway, and a dozen worker threads contending inside it take
@@ -1869,12 +1877,10 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
           launch_kv_centres(c->kv.as<float>(), m->Ld, (int)B, (int)S, m->D, gm->kv_centre_sums.as<unsigned long long>(), gm->kv_centre.as<int>(), st) != hipSuccess ||
           hipEventRecord(gm->kv_centre_ev, st) != hipSuccess)
         rc = 1;
-      if (rc) {  // (no centres: the next suitable batch tries again; this one goes on with its f32 cache)
+      if (rc)  // (no centres: the next suitable batch tries again -- claim_guard --; this one goes on with its f32 cache)
         (void)hipGetLastError();
-        gm->kv_centre_claimed.store(false, std::memory_order_release);
-      } else {
+      else
         gm->kv_centre_state.store(1, std::memory_order_release);
-      }
     }
     clk.lap(1);
   } else {
