@@ -449,7 +449,7 @@ int slimt_hip_debug_kv_watch(slimt_hip_model *model, int *switched_to_24_bit, ui
  * 24-bit form next to narrow ones. Results do not depend on it. */
 int slimt_hip_debug_kv_narrow_limit(slimt_hip_model *model, int limit);
 /* Diagnostic: the tight (16-bit) form below the 20-bit one. Where the decoder has a reader for it (D = 256 /
- * F = 1536, sentences of at most 32 tokens, the tilings of 16 / 8 / 4 sentences) format 0 caches a
+ * F = 1536 with sentences of up to 128 tokens, D = 512 / F = 2048 up to 32) format 0 caches a
  * sentence-layer whose K and V accumulators, less their columns' centres (slimt_hip_model_set_kv_centres),
  * all lie in [-limit, limit) as plain int16 (default and maximum 2^15; 0 = never tried; tests lower it so
  * that a batch mixes all three forms). Results do not depend on it. Starts the watches afresh. */

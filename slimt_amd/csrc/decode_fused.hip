@@ -1191,8 +1191,15 @@ struct CentreLds {
   lcf_ptr p;
   __device__ __forceinline__ f4 at4(int d) const { return *(lcf4_ptr)(p + d); }
 };
-template <int KV_AUX, typename Centres>
-__device__ __forceinline__ void attention_row16(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, Centres ck, Centres cv) {
+struct CentreGlobal {  // the V pass reads its four once per row: where LDS is short (the 32-sentence tiling) they stay in global memory
+  const int *p;
+  __device__ __forceinline__ f4 at4(int d) const {
+    const v4i c = *reinterpret_cast<const v4i *>(p + d);
+    return f4{(float)c.x, (float)c.y, (float)c.z, (float)c.w};
+  }
+};
+template <int KV_AUX, typename CentresK, typename CentresV>
+__device__ __forceinline__ void attention_row16(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, CentresK ck, CentresV cv) {
   constexpr int D = 256, DH = 32, H = D / DH;
   const int S = r.S, len = r.len;
   const int lenf = len > 0 ? len : S;
@@ -2538,7 +2545,8 @@ template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = 
           int KVI = 20>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr bool KV20 = KVI != 24;
-  static_assert(KVI == 24 || KVI == 20 || (KVI == 16 && KV24 && (KSD == 4 || KSD == 8) && RT == 1 && CL == 1), "16-bit form: sentences of up to 128 tokens at D = 256, up to 32 at D = 512");
+  static_assert(KVI == 24 || KVI == 20 || (KVI == 16 && KV24 && (KSD == 4 || KSD == 8) && (RT == 1 || (KSD == 4 && MID == 0)) && CL == 1),
+                "16-bit form: sentences of up to 128 tokens at D = 256 (the 32-sentence tiling: up to 32), up to 32 at D = 512");
   static_assert(CL == 1 || (CL <= 4 && RT == 1 && SPW == 16 && MID == 0 && !LONG), "cluster logits: the 16-sentence tilings");
   static_assert(SPW == 16 || ((SPW == 8 || SPW == 4) && RT == 1 && KV24), "fewer sentences per workgroup: the packed-cache, 16-row variants");
   static_assert(!KV24 || (((KSD == 4 && DH == 32) || (KSD == 8 && DH == 64)) && !LONG),
@@ -2696,7 +2704,11 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     }
   }
   if constexpr (KVI == 16) {
-    for (int i = tid; i < Ld * 2 * D; i += 1024) kvc127[i] = (float)a.kv_centre[i / (2 * D)][(i / D) & 1][i % D];
+    if constexpr (RT == 1) {
+      for (int i = tid; i < Ld * 2 * D; i += 1024) kvc127[i] = (float)a.kv_centre[i / (2 * D)][(i / D) & 1][i % D];
+    } else {  // (the K centres only: attention_row16's V pass reads its own from global memory)
+      for (int i = tid; i < Ld * D; i += 1024) kvc127[i] = (float)a.kv_centre[i / D][0][i % D];
+    }
   }
   if constexpr (KV24) {
     if constexpr (KVC == 2) {
@@ -2995,8 +3007,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
             const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
 #endif
             if (tight) {
-              if constexpr (KVI == 16) {
+              if constexpr (KVI == 16 && RT == 1) {
                 const CentreLds ck = {(lcf_ptr)(kvc127 + (2 * l) * D)}, cv = {(lcf_ptr)(kvc127 + (2 * l + 1) * D)};
+                if (NT && kv_streams)
+                  attention_row16<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, ck, cv);
+                else
+                  attention_row16<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, ck, cv);
+              } else if constexpr (KVI == 16) {  // 32 sentences: LDS holds the K centres only ([Ld][D])
+                const CentreLds ck = {(lcf_ptr)(kvc127 + l * D)};
+                const CentreGlobal cv = {a.kv_centre[l][1]};
                 if (NT && kv_streams)
                   attention_row16<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, ck, cv);
                 else
@@ -3471,7 +3490,7 @@ size_t fused_decode_lds_bytes(int D, int F, int Ld, int rows, bool kv24 = false,
   const size_t f32rows = (lean ? 2 : 3) * R * (D + 4) * 4 + cells;
   const size_t base = f32rows + 2 * R * (size_t)(D + 32) + R * (size_t)(F + 32) + 2 * NW * R * 4 + 64 +
                       NW * (mid == 2 ? 1024 : mid == 1 ? 512 : 256) * 4 + (kv24 ? (size_t)Ld * (D == 512 ? 4 : 2) * D * 4 : 0) +
-                      (tight ? (size_t)Ld * 2 * D * 4 : 0);
+                      (tight ? (size_t)Ld * (rows > 16 ? 1 : 2) * D * 4 : 0);  // (32 sentences: the K centres only)
   const size_t ln = (D == 256 && rows == 16 && !mid) ? (size_t)Ld * 6 * D * 4 : 0;
   const bool fits = ln > 0 && base + ln <= 160 * 1024;
   if (ln_in_lds) *ln_in_lds = fits;
@@ -3484,6 +3503,12 @@ bool fused_decode_tight_supported(int D, int F, int H, int Ld) {
   if (Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
   return ((D == 256 && F == 1536 && D / H == 32) || (D == 512 && F == 2048 && D / H == 64)) &&
          fused_decode_lds_bytes(D, F, Ld, 16, true, 0, nullptr, true) <= 160 * 1024;
+}
+
+// ... in the 32-sentence tiling (D = 256, S <= 32; decode_fused_kernel<..., RT = 2, ..., KVI = 16>)
+bool fused_decode_tight_rows32_supported(int D, int F, int H, int Ld) {
+  if (Ld < 1 || Ld > 4 || H <= 0 || D % H) return false;
+  return D == 256 && F == 1536 && D / H == 32 && fused_decode_lds_bytes(D, F, Ld, 32, true, 0, nullptr, true) <= 160 * 1024;
 }
 
 // ... and for sentences of 33..128 tokens (D = 256; decode_fused_kernel<..., MID = 1 / 2, ..., KVI = 16>)
@@ -3537,8 +3562,10 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   if (kv24 && !(((D == 256 && D / H == 32) || (D == 512 && D / H == 64)) && a.S <= (D == 256 ? 128 : 32))) return hipErrorInvalidValue;
   if (a.home_mask && rows != 16) return hipErrorInvalidValue;  // the XCD-affine claim counts 16-sentence tiles
   // a batch with sentence-layers in the tight form: only the kernels with its reader (engine.cpp, kv_tight_wanted)
-  if (a.kv_tight && !(kv24 && a.kv_fmt && rows <= 16 && a.cluster <= 1 &&
-                      (a.S <= 32 ? fused_decode_tight_supported(D, F, H, a.Ld) : a.S <= 128 && fused_decode_tight_mid_supported(D, F, H, a.Ld, mid))))
+  if (a.kv_tight && !(kv24 && a.kv_fmt && a.cluster <= 1 &&
+                      (rows == 32 ? a.S <= 32 && fused_decode_tight_rows32_supported(D, F, H, a.Ld)
+                       : a.S <= 32 ? fused_decode_tight_supported(D, F, H, a.Ld)
+                                   : a.S <= 128 && fused_decode_tight_mid_supported(D, F, H, a.Ld, mid))))
     return hipErrorInvalidValue;
   auto go = [&](void (*k)(FusedDecodeArgs), size_t lds) -> hipError_t {
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);
@@ -3606,6 +3633,9 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
 #undef SLIMT_KV24_PICK
 #undef SLIMT_KV24_ONLY
   if (rows == 32) {
+    if (kv24 && a.kv_tight)
+      return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true, 0, 16, 1, 16>
+                        : decode_fused_kernel<4, 24, 32, false, false, 2, true, 0, 16, 1, 16>, lds);
     if (kv24 && !a.kv_fmt)  // every cache in the 24-bit form: that form inlined (KVI = 24), as for the 16-sentence tilings
       return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true, 0, 16, 1, 24>
                         : decode_fused_kernel<4, 24, 32, false, false, 2, true, 0, 16, 1, 24>, lds);

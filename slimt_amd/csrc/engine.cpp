@@ -96,9 +96,12 @@ static bool kv_tight_shape(const slimt_hip_ctx *c, int S, bool writer) {
   if (S > 32)  // longer sentences: D = 256 only (33..64 tokens: one per 64-row workgroup; 65..128: the per-sentence encoder)
     return S <= 128 && m->D == 256 && c->decode_mode != 3 && c->decode_mode != 6 && c->decode_mode != 1 &&
            fused_decode_tight_mid_supported(m->D, m->F, m->H, m->Ld, S > 64 ? 2 : 1);
-  // (mode 0 takes the 32-sentence tiling for a large output layer: known at the decoder launch only -- what this context's
-  // last one saw stands in for it; a wrong guess costs that one batch the 16-sentence tiling)
-  if (!((c->decode_mode == 0 && (!c->expect_large_output || m->D != 256)) || c->decode_mode == 2 || c->decode_mode == 4 || c->decode_mode == 5)) return false;
+  // (the 32-sentence tiling -- mode 3, or mode 0 with a large output layer, which only the decoder launch knows: what this
+  // context's last one saw stands in for it -- has the reader too where its LDS allows; else a batch that meets it is
+  // decoded by the 16-sentence tiling)
+  const bool rows32 = c->decode_mode == 3 || (c->decode_mode == 0 && c->expect_large_output && m->D == 256);
+  if (rows32) return fused_decode_tight_rows32_supported(m->D, m->F, m->H, m->Ld);
+  if (!(c->decode_mode == 0 || c->decode_mode == 2 || c->decode_mode == 4 || c->decode_mode == 5)) return false;
   return fused_decode_tight_supported(m->D, m->F, m->H, m->Ld);
 }
 
@@ -1938,7 +1941,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.kv_tight = tight;
     f.rows_per_wg = clusters ? 16 : c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : c->decode_mode == 4 ? 8 : c->decode_mode == 5 ? 4
                     : (n_expected > 16384 ? 32 : 0);
-    if (tight && f.rows_per_wg == 32) f.rows_per_wg = 16;
+    if (tight && f.rows_per_wg == 32 && !(S <= 32 && fused_decode_tight_rows32_supported(m->D, m->F, m->H, m->Ld))) f.rows_per_wg = 16;
     int rows = fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, f.rows_per_wg, kv24);
     if (clusters) {
       const size_t tiles = (B + 15) / 16, n_clusters = (tiles + 3) / 4;

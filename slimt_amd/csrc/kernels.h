@@ -373,6 +373,7 @@ int fused_encode_grid(int B, int S, bool tickets);
 bool fused_decode_supported(int D, int F, int H, int Ld);
 bool fused_decode_mid_supported(int D, int F, int H, int Ld);
 bool fused_decode_tight_supported(int D, int F, int H, int Ld);
+bool fused_decode_tight_rows32_supported(int D, int F, int H, int Ld);
 bool fused_decode_tight_mid_supported(int D, int F, int H, int Ld, int mid);
 bool fused_decode_long24_supported(int D, int F, int H, int Ld);
 int fused_decode_rows(int D, int F, int H, int Ld, int S, int B, int forced, bool kv24);

@@ -97,7 +97,7 @@ def test_forms_follow_the_accumulators_and_results_do_not(hip, oracle, synth_mod
         order = np.sort(peak.ravel())
         limits = [2 ** 19, int(order[len(order) // 2]), int(order[len(order) // 4]) + 1, int(order[-1]), int(order[-1]) + 1, 1]
         # the tight (16-bit) form: written by the 64-row encoder (tiny11: sentences of up to 64 tokens), the per-sentence one
-        # (65..128) and the D = 512 one (base: up to 32), read by the tilings of 16 / 8 / 4 sentences (modes 0, 2, 4, 5);
+        # (65..128) and the D = 512 one (base: up to 32), read by the tilings of 16 / 8 / 4 sentences and, up to 32 tokens, of 32 (mode 3);
         # its limits likewise: int16's, two that split the batch, none
         tight_here = (preset == "tiny11" and (rows == 64 or S > 64)) or preset == "base"
         centres = colsum_centres(m, jitter_seed=B * 100 + S)
@@ -114,7 +114,7 @@ def test_forms_follow_the_accumulators_and_results_do_not(hip, oracle, synth_mod
             gm.debug_kv_tight_limit(tight)
             # 16 / 32 / 8 / 4 sentences per decoder workgroup (32: tiny11's sentences of up to 32 tokens only)
             for mode in ((2, 3, 4, 5, 0) if preset == "tiny11" and S <= 32 else (2, 4, 5)):
-                forms = expected_forms(acc, limit, group, signed, tight if tight_here and mode != 3 else 0)
+                forms = expected_forms(acc, limit, group, signed, tight if tight_here else 0)
                 ctx.set_decode_mode(mode)
                 got = ctx.translate(ids, lens, sl, want_align=True)
                 assert all(np.array_equal(a, b) for a, b in zip(got, want)), (limit, tight, mode)
@@ -179,7 +179,7 @@ def test_an_accumulator_past_2_19_sends_its_sentences_to_the_24_bit_form(hip, or
         assert np.array_equal(acc[:, :, :, :, 1:], base[:, :, :, :, 1:])  # only column 0 moved
         forms = expected_forms(acc, 2 ** 19, group)
         assert forms.any() and not forms.all(), picked
-        # Where the tight form is tried (64-row encoder, not the 32-sentence tiling) it holds the accumulator less its column's
+        # Where the tight form is tried (64-row encoder) it holds the accumulator less its column's
         # centre -- here 127 colsum, i.e. the SIGNED accumulator: a sentence whose shifted accumulator passes 2^19 through
         # 127 colsum alone still fits int16 -- the 24-bit form is then only for those whose data-dependent part is large too
         centres = colsum_centres(m)
@@ -198,7 +198,7 @@ def test_an_accumulator_past_2_19_sends_its_sentences_to_the_24_bit_form(hip, or
                 gm.set_kv_cache_policy(policy)
                 got = ctx.translate(ids, lens, sl, want_align=True)
                 assert all(np.array_equal(a, b) for a, b in zip(got, want)), (mode, policy)
-                assert np.array_equal(ctx.debug_kv_formats(m.dec_layers, B), forms16 if rows == 64 and mode != 3 else forms), (mode, policy)
+                assert np.array_equal(ctx.debug_kv_formats(m.dec_layers, B), forms16 if rows == 64 else forms), (mode, policy)
     finally:
         ctx.close()
         gm.close()
