@@ -8,6 +8,9 @@ run python tools/stress_vs_oracle.py tiny11 24 4 32 20
 run python tools/stress_vs_oracle.py tiny11 12 4 9 100
 run python tools/stress_vs_oracle.py tiny11 12 4 17 50
 run python tools/stress_vs_oracle.py base 12 4 32 20
+run env SLIMT_STRESS_CENTRES=7 python tools/stress_vs_oracle.py tiny11 8 4 64 32
+run env SLIMT_STRESS_CENTRES=8 python tools/stress_vs_oracle.py tiny11 8 4 40 60
+run python tools/stress_vs_oracle.py base 8 4 64 32  # (calibrates its centres on the first batch)
 run python tools/stress_determinism.py
 run python tools/leak_check.py
 run python tools/stress_generated.py 6 4

@@ -14,6 +14,16 @@ gm = capi.Model(m)
 om = O.OracleModel(m)
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 32
 S = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+# SLIMT_STRESS_CENTRES=<seed>: the tight K/V cache form in play -- arbitrary centres (127 colsum + noise) set up front, so that
+# batches too small to calibrate them take it too (with batches of >= 32 workgroups of the 64-row encoder: B * S >= 2048 at S = 32)
+if os.environ.get("SLIMT_STRESS_CENTRES"):
+    rng = np.random.Generator(np.random.PCG64(int(os.environ["SLIMT_STRESS_CENTRES"])))
+    centres = np.zeros((m.dec_layers, 2, m.D), dtype=np.int64)
+    for l in range(m.dec_layers):
+        for t, name in enumerate("kv"):
+            W_ = np.ascontiguousarray(m.params[f"decoder_l{l + 1}_context_W{name}"].data).reshape(m.D, m.D)
+            centres[l, t] = 127 * W_.astype(np.int64).sum(axis=1)
+    gm.set_kv_centres((centres + rng.integers(-6000, 6001, size=centres.shape)).astype(np.int32))
 sl = synth.make_shortlist(m.V, 1024)
 jobs = [synth.make_batch(m.V, B, S, seed=5000 + i, ragged=True) for i in range(n_jobs)]
 O.set_mode(O.PORTABLE)
@@ -34,6 +44,8 @@ def work(w):
 ts = [threading.Thread(target=work, args=(w,)) for w in range(W)]
 [t.start() for t in ts]
 [t.join() for t in ts]
-print(f"{preset}: {len(bad)} mismatches vs oracle in {3 * n_jobs} translates on {W} concurrent contexts")
+forms = ctxs[0].debug_kv_formats(m.dec_layers, B)
+seen = "" if forms is None else f"; last batch's cache forms: {int((forms == 2).sum())} x 16-bit, {int((forms == 0).sum())} x 20-bit, {int((forms == 1).sum())} x 24-bit"
+print(f"{preset}: {len(bad)} mismatches vs oracle in {3 * n_jobs} translates on {W} concurrent contexts{seen}")
 for b in bad[:10]:
     print("  ", b)
