@@ -174,7 +174,7 @@ int slimt_hip_model_set_xcd_affinity(slimt_hip_model *model, int xcds);
  *       sources of up to 128 tokens, emb 512 / head dim 64 up to 32), f32 elsewhere. Packed
  *       means, per sentence and decoder layer and decided by the encoder: 16 bits per value
  *       where every accumulator less its column's centre lies in [-2^15, 2^15)
- *       (slimt_hip_model_set_kv_centres; the first batch of >= 2048 rows is cached as f32
+ *       (slimt_hip_model_set_kv_centres; the first batch of >= 1024 rows is cached as f32
  *       to calibrate the centres when none were set), else 20 bits where every accumulator
  *       lies in [-2^19, 2^19), else 24 bits (holds any accumulator);
  *   1 = always f32 (float(acc), exact);
@@ -457,7 +457,7 @@ int slimt_hip_debug_kv_tight_limit(slimt_hip_model *model, int limit);
 /* The tight form's per-column centres, [Ld][K, V][D] int32 (n = Ld * 2 * D, each within (-2^24, 2^24): a float holds it exactly):
  * the 16-bit form caches accumulator - centre, the decoder adds the centre back (exact), so the centres
  * decide which sentences fit the form and nothing else -- every result is the same for any centres.
- * Without this call the library calibrates them itself: the first batch of at least 2048 rows that could
+ * Without this call the library calibrates them itself: the first batch of at least 1024 rows that could
  * take the form is cached as f32, its column means (floor(sum / rows + 1/2), integer arithmetic) become
  * the centres, and the form is tried from the first batch submitted after that reduction has finished.
  * Call it before the first translate, or with no batch of this model in flight; it fails while a

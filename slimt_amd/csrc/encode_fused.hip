@@ -622,8 +622,10 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
       // through the (dead) q / k buffers.
       int *stk = reinterpret_cast<int *>(qb), *stv = reinterpret_cast<int *>(kb);
       static_assert(LDQQ == LDK, "both staging tiles use the q row stride");
-      unsigned outside = 0;  // an accumulator of a valid row outside the narrow form's [-limit, limit)
+      unsigned outside = 0;  // an accumulator of a valid row outside a form's range: bit 0 the tight one's, bit 1 the narrow one's
       const unsigned lim = a.kv_fmt ? (unsigned)a.kv_narrow_limit : 0x40000000u;
+      const bool try_tight = a.kv_fmt && a.kv_tight_limit > 0 && ((a.kv_tight_layers >> l) & 1u);
+      const unsigned lim16 = try_tight ? (unsigned)a.kv_tight_limit : 0x40000000u;
       {
         v4i c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
         tile_mma2<KSD>(Ak, LDA, bk, lr, lg, c0, c1);
@@ -631,13 +633,16 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         float pb;
         load_epi(wk, wave, lr, cs, pb);
         (void)pb;
+        const int ctr = try_tight ? a.kv_centre[l][0][col] : 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int s0v = c0[r] + __mul24(127, cs), s1v = c1[r] + __mul24(127, cs);
           stk[(lg * 4 + r) * LDQQ + col] = s0v;
           stk[(16 + lg * 4 + r) * LDQQ + col] = s1v;
-          if (row_valid(lg * 4 + r)) outside |= (unsigned)((unsigned)s0v + lim >= 2u * lim);
-          if (row_valid(16 + lg * 4 + r)) outside |= (unsigned)((unsigned)s1v + lim >= 2u * lim);
+          if (row_valid(lg * 4 + r))
+            outside |= (unsigned)((unsigned)s0v + lim >= 2u * lim) << 1 | (unsigned)((unsigned)(s0v - ctr) + lim16 >= 2u * lim16);
+          if (row_valid(16 + lg * 4 + r))
+            outside |= (unsigned)((unsigned)s1v + lim >= 2u * lim) << 1 | (unsigned)((unsigned)(s1v - ctr) + lim16 >= 2u * lim16);
         }
       }
       {
@@ -647,24 +652,67 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         float pb;
         load_epi(wv, wave, lr, cs, pb);
         (void)pb;
+        const int ctr = try_tight ? a.kv_centre[l][1][col] : 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int s0v = c0[r] + __mul24(127, cs), s1v = c1[r] + __mul24(127, cs);
           stv[(lg * 4 + r) * LDQQ + col] = s0v;
           stv[(16 + lg * 4 + r) * LDQQ + col] = s1v;
-          if (row_valid(lg * 4 + r)) outside |= (unsigned)((unsigned)s0v + lim >= 2u * lim);
-          if (row_valid(16 + lg * 4 + r)) outside |= (unsigned)((unsigned)s1v + lim >= 2u * lim);
+          if (row_valid(lg * 4 + r))
+            outside |= (unsigned)((unsigned)s0v + lim >= 2u * lim) << 1 | (unsigned)((unsigned)(s0v - ctr) + lim16 >= 2u * lim16);
+          if (row_valid(16 + lg * 4 + r))
+            outside |= (unsigned)((unsigned)s1v + lim >= 2u * lim) << 1 | (unsigned)((unsigned)(s1v - ctr) + lim16 >= 2u * lim16);
         }
       }
-      if (outside) kv_wide_flag = 1;
+      if (outside) __hip_atomic_fetch_or(&kv_wide_flag, (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       lds_barrier();
-      // The form of this workgroup's caches of this layer (kernels.h, FusedDecodeArgs::kv_fmt): the narrow one, 20 bits
-      // per value, when every K and V accumulator of its valid rows lies in [-limit, limit) -- both tiles are staged, so
-      // the choice is made before anything is written --, else 24 bits. The same integers either way.
-      const bool wide = !a.kv_fmt || kv_wide_flag != 0;
+      // The form of this workgroup's caches of this layer (kernels.h, FusedDecodeArgs::kv_fmt): the tight one (int16 less the
+      // columns' centres) where the engine allows it and every such value of its valid rows lies in [-2^15, 2^15); else the
+      // narrow one, 20 bits per value, when every K and V accumulator lies in [-limit, limit); else 24 bits -- both tiles are
+      // staged (as accS), so the choice is made before anything is written. The same integers either way.
+      const int form = !a.kv_fmt ? 1 : (try_tight && !(kv_wide_flag & 1)) ? 2 : (kv_wide_flag & 2) ? 1 : 0;  // kv_fmt's codes
+      const bool wide = form == 1;
       if (a.kv_fmt && tid < spw && s0 + tid < B) {
-        a.kv_fmt[(size_t)l * B + s0 + tid] = wide ? 1 : 0;
+        a.kv_fmt[(size_t)l * B + s0 + tid] = (unsigned char)form;
         if (wide && a.kv_wide_count) __hip_atomic_fetch_add(a.kv_wide_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (try_tight && form != 2 && a.kv_not16_count)
+          __hip_atomic_fetch_add(a.kv_not16_count + l, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (form == 2) {
+        // decode_fused.hip, attention_row16: one thread = 32 values = four quads of int16 (accS - centre)
+        //   K [sentence][head][plane 0..3][key][16 B],  V [sentence][key / 8][plane 0..3][column / 4][16 B]
+        const int Sp = (S + 3) & ~3, G = (S + 7) >> 3;
+        const rsrc_t rko = make_rsrc(kout, (unsigned)((size_t)B * S * D * 3));
+        const rsrc_t rvo = make_rsrc(vout, (unsigned)((size_t)B * Sp * D * 3));
+        for (int it = tid; it < ER * (D / 32); it += 1024) {
+          const int r = it % ER, h = it / ER;
+          if (!row_valid(r)) continue;
+          const int off = row_sentence(r) * S * D * 3 + (h * 4 * S + r % S) * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4i ca = *reinterpret_cast<const v4i *>(a.kv_centre[l][0] + 32 * h + 8 * q), cb = *reinterpret_cast<const v4i *>(a.kv_centre[l][0] + 32 * h + 8 * q + 4);
+            const v4i pk = pack16(*reinterpret_cast<const v4i *>(stk + r * LDQQ + 32 * h + 8 * q) - ca,
+                                  *reinterpret_cast<const v4i *>(stk + r * LDQQ + 32 * h + 8 * q + 4) - cb);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rko, off + q * S * 16, 0, 0);
+          }
+        }
+        for (int it = tid; it < spw * G * 64; it += 1024) {
+          const int cl = it & 63, g = (it >> 6) % G, si = (it >> 6) / G;
+          if (s0 + si >= B) continue;
+          const int off = (s0 + si) * Sp * D * 3 + (g * 4 * 64 + cl) * 16;
+          const v4i cc = *reinterpret_cast<const v4i *>(a.kv_centre[l][1] + 4 * cl);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {  // keys past the sentence: zeros (finite once unpacked, weight 0)
+            const int k0 = 8 * g + 2 * q, k1 = k0 + 1;
+            const v4i z = {0, 0, 0, 0};
+            const v4i x0 = *reinterpret_cast<const v4i *>(stv + (si * S + (k0 < S ? k0 : 0)) * LDQQ + 4 * cl) - cc;
+            const v4i x1 = *reinterpret_cast<const v4i *>(stv + (si * S + (k1 < S ? k1 : 0)) * LDQQ + 4 * cl) - cc;
+            const v4i pk = pack16(k0 < S ? x0 : z, k1 < S ? x1 : z);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rvo, off + q * 1024, 0, 0);
+          }
+        }
+        lds_barrier();
+        continue;
       }
       if (!wide) {
         // decode_fused.hip, attention_row20: one thread = 32 values = four quads of hi halves + one quad of lo nibbles

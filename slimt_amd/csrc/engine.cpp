@@ -1364,12 +1364,13 @@ bool tall_encoder_chosen(const slimt_hip_ctx *c, int B, int S) {
                       (c->encode_rows == 64 || (c->encode_rows == 0 && tall_encode_grid(B, S, false) >= 32)));
 }
 
-// the encoders with a writer for the tight K/V form: the 64-row one (D = 256, S <= 64), the D = 512 one, and the
-// per-sentence one for 65..128 tokens
+// the encoders with a writer for the tight K/V form: every fused one for S <= 32 (64- and 32-row tiles at D = 256, the D = 512
+// one), the 64-row one with a sentence of 33..64 tokens per workgroup, the per-sentence one for 65..128 tokens
 static bool kv_tight_writer(const slimt_hip_ctx *c, int B, int S) {
   const slimt_hip_model *m = c->model;
   if (S > 64) return c->decode_mode != 1 && long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S);
-  return tall_encoder_chosen(c, B, S) || (m->D == 512 && S <= 32);
+  if (S > 32) return tall_encoder_chosen(c, B, S);
+  return c->decode_mode != 1 && fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S);
 }
 
 // embedding + every encoder layer + the decoder's K/V cache in one launch of encode_tall / encode_fused / encode_wide
@@ -1825,7 +1826,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   // The tight form's centres (engine.h, kv_centre): the first batch of enough rows that could take the form is cached as
   // f32 instead, and its column means become the centres (behind the encoder, on this stream).
   bool calibrate = false;
-  if (kv_packed && c->model->kv_centre_state.load(std::memory_order_acquire) == 0 && B * S >= 2048 &&
+  if (kv_packed && c->model->kv_centre_state.load(std::memory_order_acquire) == 0 && B * S >= 1024 &&
       kv_tight_shape(c, (int)S, kv_tight_writer(c, (int)B, (int)S)) &&
       !c->model->kv_centre_claimed.exchange(true, std::memory_order_acq_rel))
     calibrate = true;

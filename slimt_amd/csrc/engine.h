@@ -117,7 +117,7 @@ struct slimt_hip_model {
   std::atomic<unsigned long long> kv_tight_submitted[4] = {};
   std::atomic<unsigned> kv_tight_off{0};
   // The tight form's per-column centres [Ld][K, V][D] (kernels.h, FusedDecodeArgs::kv_centre): the column means of the
-  // first batch of at least 2048 rows that could have taken the form -- that batch is cached as f32 (its decoder reads
+  // first batch of at least 1024 rows that could have taken the form -- that batch is cached as f32 (its decoder reads
   // that form), a reduction behind its encoder writes the centres, and the form is tried from the first batch submitted
   // after the reduction's event has completed. Written once (or set by the caller before any batch), never changed after:
   // a batch's encoder and decoder read the same numbers.

@@ -99,7 +99,7 @@ def test_forms_follow_the_accumulators_and_results_do_not(hip, oracle, synth_mod
         # the tight (16-bit) form: written by the 64-row encoder (tiny11: sentences of up to 64 tokens), the per-sentence one
         # (65..128) and the D = 512 one (base: up to 32), read by the tilings of 16 / 8 / 4 sentences and, up to 32 tokens, of 32 (mode 3);
         # its limits likewise: int16's, two that split the batch, none
-        tight_here = (preset == "tiny11" and (rows == 64 or S > 64)) or preset == "base"
+        tight_here = True  # (every encoder writes the tight form: 64- and 32-row tiles, one sentence per workgroup, D = 512)
         centres = colsum_centres(m, jitter_seed=B * 100 + S)
         if tight_here:
             gm.set_kv_centres(centres)
@@ -198,7 +198,7 @@ def test_an_accumulator_past_2_19_sends_its_sentences_to_the_24_bit_form(hip, or
                 gm.set_kv_cache_policy(policy)
                 got = ctx.translate(ids, lens, sl, want_align=True)
                 assert all(np.array_equal(a, b) for a, b in zip(got, want)), (mode, policy)
-                assert np.array_equal(ctx.debug_kv_formats(m.dec_layers, B), forms16 if rows == 64 else forms), (mode, policy)
+                assert np.array_equal(ctx.debug_kv_formats(m.dec_layers, B), forms16), (mode, policy)
     finally:
         ctx.close()
         gm.close()
@@ -264,6 +264,7 @@ def test_a_model_that_mostly_needs_24_bits_is_switched_to_them(hip, oracle, synt
     B, S = 48, 24
     ctx = hip.Context(gm, B, S)
     try:
+        gm.debug_kv_tight_limit(0)  # (this test is about the 20- / 24-bit pair: no tight form, no calibration batch)
         ids, lens = synth.make_batch(m.V, B, S, seed=808, ragged=True)
         sl = synth.make_shortlist(m.V, 640)
         oracle.set_mode(oracle.PORTABLE)
@@ -304,7 +305,7 @@ def test_a_model_that_mostly_needs_24_bits_is_switched_to_them(hip, oracle, synt
 
 def test_centres_are_calibrated_from_the_first_large_batch_and_a_layer_that_mostly_misses_stops_trying(hip, oracle, synth_models):
     """Without centres from the caller the library calibrates them (include/slimt_hip.h, slimt_hip_model_set_kv_centres): the
-    first batch of >= 2048 rows that could take the tight form is cached as f32 and its column means -- floor(sum / rows +
+    first batch of >= 1024 rows that could take the tight form is cached as f32 and its column means -- floor(sum / rows +
     1/2) over every row of the batch, in integers -- become the centres. On the synthetic model the column means carry most
     of the accumulators' spread (7.5 k against 3.2 k around them), so every sentence fits int16 afterwards.
     The tight form has its own watch, per decoder layer (slimt_hip_debug_kv_tight_watch): a sentence that misses is read
