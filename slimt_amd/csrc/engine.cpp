@@ -87,9 +87,8 @@ static bool kv_tight_enabled() {
   return enabled;
 }
 
-// Where the tight form has a writer and a reader: the tilings of 16 / 8 / 4 sentences of D = 256 / F = 1536 and D = 512 /
-// F = 2048 (not the 32-sentence tiling a large output layer takes, not clusters), S <= 32 -- S <= 128 at D = 256 --, and
-// an encoder with a writer for it (`writer`: kv_tight_writer).
+// Where the tight form has a writer and a reader: D = 256 / F = 1536 (S <= 128; the 32-sentence tiling: S <= 32) and D = 512 /
+// F = 2048 (S <= 32), not clusters, and an encoder with a writer for it (`writer`: kv_tight_writer).
 static bool kv_tight_shape(const slimt_hip_ctx *c, int S, bool writer) {
   const slimt_hip_model *m = c->model;
   if (!kv_tight_enabled() || !writer || m->kv_tight_limit <= 0 || m->kv_format != 0) return false;
@@ -99,9 +98,9 @@ static bool kv_tight_shape(const slimt_hip_ctx *c, int S, bool writer) {
   // (the 32-sentence tiling -- mode 3, or mode 0 with a large output layer, which only the decoder launch knows: what this
   // context's last one saw stands in for it -- has the reader too where its LDS allows; else a batch that meets it is
   // decoded by the 16-sentence tiling)
-  const bool rows32 = c->decode_mode == 3 || (c->decode_mode == 0 && c->expect_large_output && m->D == 256);
+  const bool rows32 = m->D == 256 && (c->decode_mode == 3 || (c->decode_mode == 0 && c->expect_large_output));
   if (rows32) return fused_decode_tight_rows32_supported(m->D, m->F, m->H, m->Ld);
-  if (!(c->decode_mode == 0 || c->decode_mode == 2 || c->decode_mode == 4 || c->decode_mode == 5)) return false;
+  if (!(c->decode_mode == 0 || c->decode_mode == 2 || c->decode_mode == 3 || c->decode_mode == 4 || c->decode_mode == 5)) return false;
   return fused_decode_tight_supported(m->D, m->F, m->H, m->Ld);
 }
 

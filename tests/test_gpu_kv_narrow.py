@@ -113,7 +113,7 @@ def test_forms_follow_the_accumulators_and_results_do_not(hip, oracle, synth_mod
             gm.debug_kv_narrow_limit(limit)
             gm.debug_kv_tight_limit(tight)
             # 16 / 32 / 8 / 4 sentences per decoder workgroup (32: tiny11's sentences of up to 32 tokens only)
-            for mode in ((2, 3, 4, 5, 0) if preset == "tiny11" and S <= 32 else (2, 4, 5)):
+            for mode in ((2, 3, 4, 5, 0) if preset == "tiny11" and S <= 32 else (2, 3, 4, 5) if preset == "base" else (2, 4, 5)):
                 forms = expected_forms(acc, limit, group, signed, tight if tight_here else 0)
                 ctx.set_decode_mode(mode)
                 got = ctx.translate(ids, lens, sl, want_align=True)
