@@ -65,6 +65,9 @@ def parse(argv=None):
     ap.add_argument("--workers", type=int, default=20,
                     help="translate contexts (HIP streams) per GPU, like slimt::Async workers "
                          "(Frontend.cc:212-226): independent batches in flight on one device")
+    ap.add_argument("--merge", type=int, default=1,
+                    help="batches of --batch sentences per translate call (slimt_hip_translate_many_device: ONE encoder and ONE "
+                         "decoder launch for all of them, each batch with its own arrays); 1 = slimt_hip_translate_device")
     ap.add_argument("--ragged", action="store_true",
                     help="sentence lengths uniform in [S/4, S] instead of all S (not the headline config)")
     ap.add_argument("--decoder-budget", type=int, default=-1,
@@ -317,6 +320,7 @@ def main():
     B, S = args.batch, args.src_len
     T = int(np.float32(1.5) * np.float32(S))
     W = max(1, args.workers)
+    MG = max(1, min(8, args.merge))  # batches per translate call
     n_sl = args.shortlist
     D, F, H, Le, Ld, V = synth.PRESETS[args.preset]
     N_out = n_sl if n_sl else V
@@ -325,8 +329,8 @@ def main():
         my_batches = plan_shards(args.total_sentences, B, world)[rank]  # [(start, count)]
         batches_per_step = len(my_batches)
     else:
-        my_batches = [(0, B)] * W
-        batches_per_step = W
+        my_batches = [(0, B)] * (W * MG)
+        batches_per_step = W * MG
 
     if dry:
         def step(i):
@@ -363,7 +367,8 @@ def main():
             gm.set_xcd_affinity(args.xcd_affinity)
         if args.adaptive_rows >= 0:
             gm.set_adaptive_decoder_rows(bool(args.adaptive_rows))
-        ctxs = [capi.Context(gm, B, S) for _ in range(W)]
+        rows_ctx = capi.translate_many_rows([B] * MG) if MG > 1 else B  # sentences a context's launches hold
+        ctxs = [capi.Context(gm, rows_ctx, S) for _ in range(W)]
         for c in ctxs:
             c.set_decode_mode(args.decode_mode)
             if args.encode_rows:
@@ -380,17 +385,29 @@ def main():
             batches = [(to_dev(ids_all[s: s + c]), to_dev(lens_all[s: s + c]), c) for s, c in my_batches]
         else:
             batches = []
-            for i in range(4):
+            for i in range(4 * MG):
                 ids, lens = synth.make_batch(model.V, B, S, seed=4321 + 97 * rank + i, ragged=args.ragged)
                 batches.append((to_dev(ids), to_dev(lens), B))
         d_sl = to_dev(sl) if sl is not None else None
-        n_slots = max(W, 1)
+        n_slots = max(W, 1) * MG
         d_outs = [torch.zeros((B, T), dtype=torch.int32, device=dev) for _ in range(n_slots)]
         d_lens_out = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(n_slots)]
+
+        def step_merged(i):
+            # MG batches per worker and call, each with its own input and output arrays, one launch pair for all
+            for w in range(W):
+                call = []
+                for q in range(MG):
+                    d_ids, d_lens, nb = batches[((i * W + w) * MG + q) % len(batches)]
+                    call.append((d_ids.data_ptr(), d_lens.data_ptr(), nb, d_sl.data_ptr() if d_sl is not None else 0, n_sl,
+                                 d_outs[w * MG + q].data_ptr(), d_lens_out[w * MG + q].data_ptr(), 0))
+                ctxs[w].translate_many_device(call, S, 1.5, 0, steps_hint=T)
 
         def step(i):
             # one batch on every worker (weak) / every batch of this rank's shard, dealt to
             # the workers round-robin (strong); the calls are asynchronous (fixed step count)
+            if MG > 1 and not strong:
+                return step_merged(i)
             for j in range(batches_per_step):
                 w = j % W
                 d_ids, d_lens, nb = batches[j] if strong else batches[(i * W + j) % len(batches)]
@@ -434,7 +451,7 @@ def main():
     kv_forms = None
     if not dry:
         # which form the last batch's K/V caches took, per sentence and decoder layer (slimt_hip_debug_kv_formats)
-        seen = ctxs[0].debug_kv_formats(Ld, B)
+        seen = ctxs[0].debug_kv_formats(Ld, rows_ctx)
         if seen is not None:
             kv_forms = {"int16": float((seen == 2).mean()), "int20": float((seen == 0).mean()), "int24": float((seen == 1).mean())}
         prof = {"launches": 0, "total_ms": 0.0, "int8_macs": 0.0, "weight_bytes": 0.0}
@@ -465,7 +482,45 @@ def main():
                      "value": total_tokens_per_step * args.sustained_steps / dts, "seconds": dts}
 
     forward = None
-    if args.forward_steps > 0 and not dry and not strong:
+    if args.forward_steps > 0 and not dry and not strong and MG > 1:
+        # Model::forward on host buffers, merged: MG pinned batches per worker through slimt_hip_translate_many_async
+        from slimt_amd import capi as _capi
+        K = args.forward_steps
+        fb, pins = [], []
+        for w in range(W):
+            group = []
+            for q in range(MG):
+                ids_h, lens_h = synth.make_batch(model.V, B, S, seed=8000 + 97 * rank + w * MG + q, ragged=args.ragged)
+                ps = [_capi._Pinned() for _ in range(5)]
+                bufs = (ps[0].array(np.uint32, (B, S)), ps[1].array(np.uint32, (B,)), ps[2].array(np.uint32, (B, T)),
+                        ps[3].array(np.uint32, (B,)), ps[4].array(np.float32, (B, T, S)))
+                bufs[0][...] = ids_h
+                bufs[1][...] = lens_h
+                pins.append(ps)
+                group.append(bufs)
+            fb.append(group)
+
+        def fstep():
+            for w in range(W):
+                ctxs[w].translate_many_async(fb[w], sl)
+        for _ in range(2):
+            fstep()
+        barrier()
+        t = time.perf_counter()
+        for _ in range(K):
+            fstep()
+        barrier()
+        d, _ = reduce_timing(dist, cpu, time.perf_counter() - t, tokens_per_step)
+        got = int(sum(int(b[3].sum()) for g in fb for b in g))
+        if got != W * MG * B * T:
+            raise SystemExit(f"bench: merged model_forward produced {got} tokens, expected {W * MG * B * T}")
+        forward = {"model_forward": {"value": total_tokens_per_step * K / d, "ms_per_step": 1e3 * d / K, "steps": K, "alignments": True,
+                                     "io": f"{MG} pinned batches per call (slimt_hip_translate_many_async): ids + lengths read from, "
+                                           "tokens + lengths + alignment rows written to pinned host memory by the two launches"}}
+        for ps in pins:
+            for p_ in ps:
+                p_.free()
+    elif args.forward_steps > 0 and not dry and not strong:
         # Model::forward as the reference's workers call it (Model.cc:111-204): ids and lengths in
         # (pinned) HOST memory, tokens, lengths and the alignment rows of every step (Model.cc:84-108)
         # back in host memory -- slimt_hip_translate_async[_generated] on the same 20 x 256 workload.
@@ -558,7 +613,7 @@ def main():
         # the committed counters are of the default workload of each preset: no figure for others
         profiled = (args.preset in ("tiny11", "base") and B == 256 and S == 32 and n_sl == 4096 and not args.ragged)
         traffic, traffic_src = pmc_traffic(prof_name, args.preset) if profiled else (None, None)
-        cus = -(-B // 16) if prof_name == "decode_fused" else 256
+        cus = -(-(B * MG) // 16) if prof_name == "decode_fused" else 256
         in_flight = prof["total_ms"] / (1e3 * dt) if dt > 0 else 0.0  # launches of this kernel running at once (this rank)
         # the path is a dense int8 contraction, so the bound is the int8 MFMA
         # roofline. `achieved` = algorithmic int8 OPs of one launch of the dominant kernel /
@@ -595,7 +650,7 @@ def main():
             # The cache the decoder re-reads is the packed 24-bit form where the kernels have it
             # (tiny11, S <= 32, not S = 1, 2, 5: slimt_hip_model_set_kv_cache_format), f32 elsewhere;
             # SURVEY's algorithmic K/V stays the f32 tensor it names.
-            kv_once = float(B) * Ld * 2 * S * D * 4
+            kv_once = float(B * MG) * Ld * 2 * S * D * 4
             kv24 = (dec_fused and enc_fused and args.kv_format in (0, 2) and ((S + 3) // 4 * 4) * 3 <= S * 4 and
                     ((D == 256 and D // H == 32 and S <= 128) or (D == 512 and D // H == 64 and S <= 32)))
             # ... 20 bits per value where the kernels have the narrow form and the accumulators fit it (every sentence of
@@ -607,7 +662,7 @@ def main():
             if kv20 and kv_forms:
                 kv_impl = kv_once * (0.5 * kv_forms["int16"] + 0.625 * kv_forms["int20"] + 0.75 * kv_forms["int24"])
             w_once = float(Ld * (4 * D * D + 2 * D * F) + D * N_out)
-            io_bytes = float(B) * T * (D + 4)
+            io_bytes = float(B * MG) * T * (D + 4)
             alg_bytes = w_once + io_bytes + kv_once
             kv_reread = kv_impl * T
             impl_bytes = kv_reread + w_once * T + io_bytes
@@ -641,14 +696,16 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int8", "data": "dry-run: no device work (SLIMT_BENCH_DRY)" if dry else "synthetic",
             "config": {
-                "workload": (f"en-de {args.preset} int8 greedy decode, batch={B} sentences per translate call, "
+                "workload": (f"en-de {args.preset} int8 greedy decode, "
+                             + (f"{MG} batches of {B} sentences per translate call (one launch pair, own arrays each), " if MG > 1 else
+                                f"batch={B} sentences per translate call, ") +
                              f"S={S} source tokens, T={T} decode steps, "
                              f"{'shortlist ' + str(n_sl) if n_sl else 'full 32k vocabulary'}; "
                              + (f"one step = the same {args.total_sentences} sentences cut into batches of {B} "
                                 f"and dealt to {world} GPU(s)" if strong else
-                                f"one step = one batch on each of the {W} workers of every GPU "
-                                f"({W * B} sentences per GPU and step)")),
-                "preset": args.preset, "batch": B, "src_len": S, "decode_steps": T,
+                                f"one step = one translate call on each of the {W} workers of every GPU "
+                                f"({W * MG * B} sentences per GPU and step)")),
+                "preset": args.preset, "batch": B, "merged_batches_per_call": MG, "src_len": S, "decode_steps": T,
                 "shortlist": n_sl, "parallelism": f"dp{world} (replicated weights, no collective, no RCCL)",
                 "workers_per_gpu": W, "batches_per_step_per_gpu": batches_per_step,
                 "sentences_per_step_all_gpus": sentences_per_step,

@@ -287,6 +287,48 @@ int slimt_hip_translate_device(slimt_hip_ctx *ctx, const uint32_t *d_src_ids,
                                uint32_t *d_out_ids, uint32_t *d_out_len,
                                float *d_align, int steps_hint);
 
+/* ---- several batches in one launch pair -----------------------------------
+ * What `workers` concurrent Model::forward calls are in the reference (Async,
+ * slimt/Frontend.cc:207-227, each worker translating the batch the Batcher hands
+ * it, Batcher.cc:95-120): n batches of ONE padded source length S, each with its
+ * own arrays, its own shortlist and its own outputs, translated by ONE encoder
+ * and ONE decoder launch on ctx's stream. The reference's default batch is 1024
+ * padded tokens (Frontend.hh:21-39: 32 sentences of 32 tokens) -- one such batch
+ * per launch pair occupies 2 of 256 CUs in the decoder; merged, k of them fill
+ * what one batch of k x B would. Every sentence's arithmetic is independent of
+ * its neighbours, so each batch's outputs equal those of its own
+ * slimt_hip_translate* call bit for bit (tests/test_gpu_translate_many.py).
+ *
+ * The launch works on sum_j roundup(B_j, 32) "global" sentences (_rows below):
+ * ctx must hold that many (max_batch) and that many times S padded tokens.
+ * Limits: n <= 8; the persistent kernels for sources of up to 64 tokens. Whatever
+ * cannot be merged (more batches, longer sources, decode modes 1 / 6, K/V cache
+ * format 3) is translated batch by batch, in order, on the same stream: same
+ * results, same asynchrony. Batches that give the SAME shortlist pointer and
+ * size share one packed output layer. */
+typedef struct slimt_hip_batch {
+  const uint32_t *src_ids;   /* [B][S] */
+  const uint32_t *lengths;   /* [B] */
+  size_t B;
+  const uint32_t *shortlist; /* sorted unique target ids, or NULL with n_shortlist == 0: full vocabulary */
+  size_t n_shortlist;
+  uint32_t *out_ids;         /* [B][Tmax], Tmax = max(1, (size_t)(limit_factor * S)) */
+  uint32_t *out_len;         /* [B] */
+  float *align;              /* nullable [B][Tmax][S] */
+} slimt_hip_batch;
+
+/* global sentences a merged launch of these batch sizes occupies in its context */
+size_t slimt_hip_translate_many_rows(const size_t *B, size_t n_batches);
+/* every array (shortlists included) resident in device memory; steps_hint as for _translate_device */
+int slimt_hip_translate_many_device(slimt_hip_ctx *ctx, const slimt_hip_batch *batches, size_t n_batches,
+                                    size_t S, float limit_factor, uint32_t eos_id, int steps_hint);
+/* host arrays, asynchronous like _translate_async (slimt_hip_ctx_synchronize waits): ids, lengths and
+ * outputs should be pinned (slimt_hip_host_alloc) -- the kernels then read and write them in place;
+ * batches whose arrays are not are translated one by one through _translate_async. The shortlists
+ * are host arrays; the merged path needs them to be ONE array (or none) for all batches. */
+int slimt_hip_translate_many_async(slimt_hip_ctx *ctx, const slimt_hip_batch *batches, size_t n_batches,
+                                   size_t S, float limit_factor, uint32_t eos_id);
+
 /* Step-wise mirrors for parity tests ------------------------------------- */
 /* Model.cc:195-201: embed + Encoder::forward (Transformer.cc:57-69). Keeps
  * the encoder output in the ctx for slimt_hip_decode_*. enc_out nullable

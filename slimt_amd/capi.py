@@ -37,6 +37,7 @@ SYMBOLS = [
     "slimt_hip_translate_device_generated", "slimt_hip_translate_generated", "slimt_hip_translate_async_generated",
     "slimt_hip_translate_async", "slimt_hip_host_alloc", "slimt_hip_host_free",
     "slimt_hip_encode_embedded", "slimt_hip_decode_begin_from", "slimt_hip_decode_step_states",
+    "slimt_hip_translate_many_rows", "slimt_hip_translate_many_device", "slimt_hip_translate_many_async",
 ]
 
 K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED, K_ENCODE_FUSED = range(9)
@@ -51,6 +52,12 @@ class SlimtHipError(RuntimeError):
 class _Param(C.Structure):
     _fields_ = [("name", C.c_char_p), ("type", C.c_int32), ("rows", C.c_int32),
                 ("cols", C.c_int32), ("data", C.c_void_p), ("bytes", C.c_uint64)]
+
+
+class _Batch(C.Structure):
+    """slimt_hip_batch (include/slimt_hip.h): one batch of a merged launch."""
+    _fields_ = [("src_ids", C.c_void_p), ("lengths", C.c_void_p), ("B", C.c_size_t), ("shortlist", C.c_void_p),
+                ("n_shortlist", C.c_size_t), ("out_ids", C.c_void_p), ("out_len", C.c_void_p), ("align", C.c_void_p)]
 
 
 class _Dims(C.Structure):
@@ -217,12 +224,22 @@ def lib():
     L.slimt_hip_translate_device_generated.argtypes = [vp, vp, vp, vp, sz, sz, f32, u32, vp, vp, vp, i32]
     L.slimt_hip_translate_generated.argtypes = [vp, vp, vp, vp, sz, sz, f32, u32, vp, vp, vp]
     L.slimt_hip_translate_async_generated.argtypes = [vp, vp, vp, vp, sz, sz, f32, u32, vp, vp, vp]
+    L.slimt_hip_translate_many_rows.argtypes = [vp, sz]
+    L.slimt_hip_translate_many_rows.restype = sz
+    L.slimt_hip_translate_many_device.argtypes = [vp, vp, sz, sz, f32, u32, i32]
+    L.slimt_hip_translate_many_async.argtypes = [vp, vp, sz, sz, f32, u32]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("slimt_hip_abi_version",):
             fn.restype = C.c_int
     _lib = L
     return L
+
+
+def translate_many_rows(sizes) -> int:
+    """Global sentences a merged launch of these batch sizes occupies in its context (max_batch)."""
+    a = (C.c_size_t * len(sizes))(*[int(x) for x in sizes])
+    return int(lib().slimt_hip_translate_many_rows(a, len(sizes)))
 
 
 def contexts_on_device(device: int = 0) -> int:
@@ -617,6 +634,28 @@ class Context:
             self.h, vp(d_ids), vp(d_lengths), B, S, vp(d_shortlist) if n_shortlist else None,
             n_shortlist, limit_factor, eos_id, vp(d_out_ids), vp(d_out_len),
             vp(d_align) if d_align else None, steps_hint))
+
+    def translate_many_device(self, batches, S: int, limit_factor: float, eos_id: int, steps_hint: int = 0):
+        """slimt_hip_translate_many_device: `batches` = [(d_ids, d_lengths, B, d_shortlist, n_shortlist, d_out_ids,
+        d_out_len, d_align)] of device pointers (ints; 0 = none) -- ONE encoder and ONE decoder launch for all of them."""
+        arr = (_Batch * len(batches))()
+        for j, (d_ids, d_len, B, d_sl, n_sl, d_out, d_ol, d_al) in enumerate(batches):
+            arr[j] = _Batch(d_ids, d_len, B, d_sl if n_sl else None, n_sl, d_out, d_ol, d_al or None)
+        _chk(lib().slimt_hip_translate_many_device(self.h, arr, len(batches), S, limit_factor, eos_id, steps_hint))
+
+    def translate_many_async(self, bufs_list, shortlist=None, limit_factor: float = 1.5, eos_id: int = 0):
+        """slimt_hip_translate_many_async on a list of pinned buffer tuples (ids, lengths, out_ids, out_len, align|None),
+        one shortlist (host array) or none for all; synchronize() before reading the outputs."""
+        sl = None if shortlist is None else np.ascontiguousarray(shortlist, dtype=np.uint32)
+        arr = (_Batch * len(bufs_list))()
+        S = bufs_list[0][0].shape[1]
+        for j, (p_ids, p_len, p_out, p_ol, p_al) in enumerate(bufs_list):
+            assert p_ids.shape[1] == S
+            arr[j] = _Batch(p_ids.ctypes.data, p_len.ctypes.data, p_ids.shape[0], None if sl is None else sl.ctypes.data,
+                            0 if sl is None else sl.size, p_out.ctypes.data, p_ol.ctypes.data,
+                            None if p_al is None else p_al.ctypes.data)
+        self._many_keep = (arr, sl)
+        _chk(lib().slimt_hip_translate_many_async(self.h, arr, len(bufs_list), S, limit_factor, eos_id))
 
     def translate_device_generated(self, gen: "ShortlistGenerator", d_ids: int, d_lengths: int, B: int,
                                    S: int, limit_factor: float, eos_id: int, d_out_ids: int,

@@ -2644,6 +2644,13 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     if ((unsigned)tile >= (unsigned)((B + RS - 1) / RS)) return;
   }
   const int m0 = tile * RS;
+  // merged launch (kernels.h, MergeOut): this tile lies inside sub-batch sj, whose sentences are the global ones
+  // sj_first .. Bv - 1 (the global ones up to the next sub-batch are holes: a tile of nothing but holes leaves); the caller's
+  // arrays are the sub-batch's, the workspace (K/V cache, its form bytes, SSRU cells) is indexed by the global sentence
+  const int sj = a.n_sub ? __builtin_amdgcn_readfirstlane(merge_find(a.sub, a.n_sub, m0)) : 0;
+  const int sj_first = a.n_sub ? a.sub[sj].first : 0;
+  const int Bv = a.n_sub ? sj_first + a.sub[sj].n : B;
+  if (m0 >= Bv) return;
   if (tid == 0) occ_trace_event(a.trace, 1, 0);
   // my cluster (CL > 1): tiles cl_first .. cl_first + cl_n - 1 (the last cluster of a batch may be short), me = member cl_m
   const int n_tiles_b = (B + RS - 1) / RS;
@@ -2659,12 +2666,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     bq[rr] = m0 + 16 * rr + wave;
-    live[rr] = row_wave && bq[rr] < B;
-    len[rr] = live[rr] ? checked_length(a.lengths[bq[rr]], S) : 0;
+    live[rr] = row_wave && bq[rr] < Bv;
+    len[rr] = live[rr] ? checked_length(a.n_sub ? a.sub[sj].lengths[bq[rr] - sj_first] : a.lengths[bq[rr]], S) : 0;
     finished[rr] = !live[rr];
     n_out[rr] = 0;
   }
-  const int valid_rows = (B - m0) < RS ? (B - m0) : RS;
+  const int valid_rows = (Bv - m0) < RS ? (Bv - m0) : RS;
   // the form of this wave's sentences' caches: bit l = 24-bit, bit 8 + l = the tight 16-bit form, neither = 20-bit
   // (kernels.h, kv_fmt: 1 / 2 / 0)
   unsigned kv_wide[RT];
@@ -2723,9 +2730,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     if (live[rr]) {  // outputs past a sentence's length read as zero (no memset launches)
-      for (int i = lane; i < a.Tmax; i += 64) a.out_ids[(size_t)bq[rr] * a.Tmax + i] = 0;
-      if (a.align && !a.align_out)
-        for (int i = lane; i < a.Tmax * S; i += 64) a.align[(size_t)bq[rr] * a.Tmax * S + i] = 0.0f;
+      uint32_t *oi = a.n_sub ? a.sub[sj].out_ids : a.out_ids;
+      float *al = a.n_sub ? a.sub[sj].align : a.align;
+      const bool staged = (a.n_sub ? a.sub[sj].align_out : a.align_out) != nullptr;
+      for (int i = lane; i < a.Tmax; i += 64) oi[(size_t)(bq[rr] - sj_first) * a.Tmax + i] = 0;
+      if (al && !staged)
+        for (int i = lane; i < a.Tmax * S; i += 64) al[(size_t)(bq[rr] - sj_first) * a.Tmax * S + i] = 0.0f;
     }
     // step-0 embedding: zeros * sqrt(D) + pos(0)  (Transformer.cc:138-144,160)
 #pragma unroll
@@ -2738,7 +2748,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 
   // the output layer's column count may live on the device (a shortlist generated there)
   PreparedWeight outw = a.out;
-  if (a.out_n_dev) {
+  if (a.n_sub) {  // this sub-batch's packed output layer: job strides behind the first (same K, multipliers, a_quant)
+    const int job = a.sub[sj].job;
+    outw.Wp = reinterpret_cast<const char *>(a.out.Wp) + (size_t)job * a.out_stride_wp;
+    outw.colsum = reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.out.colsum) + (size_t)job * a.out_stride_cs);
+    outw.cp4 = outw.colsum + epi_pair_offset_ints(a.sub[sj].N);
+    outw.pb = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.out.pb) + (size_t)job * a.out_stride_pb);
+    outw.N = a.sub[sj].N;
+    outw.n_tiles = (outw.N + 15) / 16;
+  } else if (a.out_n_dev) {
     outw.N = (int)*a.out_n_dev;
     outw.n_tiles = (outw.N + 15) / 16;
   }
@@ -2887,8 +2905,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           ar.alpha = a.alpha;
           ar.aq_o = L.o.a_quant;
           ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
-          const bool want_align = a.align && (l + 1 == Ld) && !fin && (no < a.Tmax);
-          ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + no) * S) : (gf_ptr) nullptr;
+          float *al = a.n_sub ? a.sub[sj].align : a.align;
+          const bool want_align = al && (l + 1 == Ld) && !fin && (no < a.Tmax);
+          ar.align = want_align ? (gf_ptr)(al + ((size_t)(b - sj_first) * a.Tmax + no) * S) : (gf_ptr) nullptr;
           if constexpr (KV24 && KVC == 4) {
             const lcf_ptr kc = (lcf_ptr)(kvpb + (4 * l) * D);
             if constexpr (!KV20) {
@@ -3391,10 +3410,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         // no column beat the start value (every logit NaN or -inf): class 0, where the reference's scan
         // starts and stays (Transformer.cc:287-298) -- and never an index past the shortlist
         ix = (ix == 0x7fffffff || nan0) ? 0 : ix;
-        if (live[rr]) tok = a.shortlist ? a.shortlist[ix] : (uint32_t)ix;
+        const uint32_t *sl = a.n_sub ? a.sub[sj].shortlist : a.shortlist;
+        if (live[rr]) tok = sl ? sl[ix] : (uint32_t)ix;
       }
       if (live[rr] && !finished[rr]) {  // record(), Model.cc:127-137
-        if (lane == 0 && (int)n_out[rr] < a.Tmax) a.out_ids[(size_t)bq[rr] * a.Tmax + n_out[rr]] = tok;
+        if (lane == 0 && (int)n_out[rr] < a.Tmax)
+          (a.n_sub ? a.sub[sj].out_ids : a.out_ids)[(size_t)(bq[rr] - sj_first) * a.Tmax + n_out[rr]] = tok;
         n_out[rr] += 1;
         if (tok == a.eos) {
           finished[rr] = true;
@@ -3421,20 +3442,22 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   }
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr)
-    if (live[rr] && lane == 0) a.out_len[bq[rr]] = n_out[rr];
-  if (a.align && a.align_out) {
+    if (live[rr] && lane == 0) (a.n_sub ? a.sub[sj].out_len : a.out_len)[bq[rr] - sj_first] = n_out[rr];
+  const float *al_src = a.n_sub ? a.sub[sj].align : a.align;
+  float *al_dst = a.n_sub ? a.sub[sj].align_out : a.align_out;
+  if (al_src && al_dst) {
     // staged alignment rows -> their destination (kernels.h, align_out). This wave wrote the rows it
     // reads (rows 0 .. n_out - 1, columns 0 .. len - 1); everything else is zero.
 #pragma unroll 1
     for (int rr = 0; rr < RT; ++rr) {
       if (!live[rr]) continue;
-      const size_t base = (size_t)bq[rr] * a.Tmax * S;
+      const size_t base = (size_t)(bq[rr] - sj_first) * a.Tmax * S;
       const int rows_set = (int)n_out[rr] < a.Tmax ? (int)n_out[rr] : a.Tmax;
       const int n = a.Tmax * S, ln = len[rr];
-      if (((base | (size_t)S) & 3) == 0 && (reinterpret_cast<size_t>(a.align_out) & 15) == 0 &&
-          (reinterpret_cast<size_t>(a.align) & 15) == 0) {  // 16-byte pieces: four columns of one row
-        const f4 *src = reinterpret_cast<const f4 *>(a.align + base);
-        f4 *dst = reinterpret_cast<f4 *>(a.align_out + base);
+      if (((base | (size_t)S) & 3) == 0 && (reinterpret_cast<size_t>(al_dst) & 15) == 0 &&
+          (reinterpret_cast<size_t>(al_src) & 15) == 0) {  // 16-byte pieces: four columns of one row
+        const f4 *src = reinterpret_cast<const f4 *>(al_src + base);
+        f4 *dst = reinterpret_cast<f4 *>(al_dst + base);
         for (int i = lane; i < n / 4; i += 64) {
           const int row = (4 * i) / S, col = (4 * i) % S;
           f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -3449,7 +3472,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       } else {
         for (int i = lane; i < n; i += 64) {
           const int row = i / S, col = i % S;
-          a.align_out[base + i] = (row < rows_set && col < ln) ? a.align[base + i] : 0.0f;
+          al_dst[base + i] = (row < rows_set && col < ln) ? al_src[base + i] : 0.0f;
         }
       }
     }

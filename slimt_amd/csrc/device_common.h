@@ -400,4 +400,35 @@ __device__ __forceinline__ void pack_weight_tile(const PackArgs &a, int ntile, i
   }
 }
 
+// ---- merged launches (kernels.h, MergeIn / MergePack) ------------------------------------------------------------
+// global sentence g of an encoder launch: its length (a hole: 0) ...
+__device__ __forceinline__ int sentence_length(const FusedEncodeArgs &a, int g, int S) {
+  if (a.n_sub == 0) return checked_length(a.lengths[g], S);
+  const int j = merge_find(a.sub, a.n_sub, g), i = g - a.sub[j].first;
+  return i < a.sub[j].n ? checked_length(a.sub[j].lengths[i], S) : 0;
+}
+// ... and its S token ids (a hole: nullptr -- the caller embeds token 0 at every position, which nobody reads)
+__device__ __forceinline__ const uint32_t *sentence_ids(const FusedEncodeArgs &a, int g, int S) {
+  if (a.n_sub == 0) return a.ids + (size_t)g * S;
+  const int j = merge_find(a.sub, a.n_sub, g), i = g - a.sub[j].first;
+  return i < a.sub[j].n ? a.sub[j].ids + (size_t)i * S : nullptr;
+}
+// this workgroup's share (tiles first, first + step, ...) of the launch's packing jobs
+__device__ __forceinline__ void pack_weight_share(const FusedEncodeArgs &a, int first, int step, int tid, int nthreads) {
+  if (a.n_pack <= 1) {
+    for (int pt = first; pt < a.pack_tiles; pt += step) pack_weight_tile(a.pack, pt, tid, nthreads);
+    return;
+  }
+  for (int pt = first; pt < a.pack_tiles * a.n_pack; pt += step) {
+    const int job = pt / a.pack_tiles, t = pt - job * a.pack_tiles;
+    PackArgs pj = a.pack;
+    pj.idx = a.pjob[job].idx;
+    pj.N = a.pjob[job].N;
+    pj.Wp = reinterpret_cast<char *>(a.pack.Wp) + (size_t)job * a.pack_stride_wp;
+    pj.colsum = reinterpret_cast<int *>(reinterpret_cast<char *>(a.pack.colsum) + (size_t)job * a.pack_stride_cs);
+    pj.pb = reinterpret_cast<float *>(reinterpret_cast<char *>(a.pack.pb) + (size_t)job * a.pack_stride_pb);
+    pack_weight_tile(pj, t, tid, nthreads);
+  }
+}
+
 }  // namespace slimt_hip

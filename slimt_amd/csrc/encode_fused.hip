@@ -194,8 +194,10 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
   // this workgroup's sentence lengths: read once (they may live in pinned host memory)
   __shared__ int slens[ER];
-  __shared__ int kv_wide_flag;  // the narrow cache form does not hold this workgroup's accumulators (kernels.h, kv_fmt)
-  if (tid < spw) slens[tid] = s0 + tid < B ? checked_length(a.lengths[s0 + tid], S) : 0;
+  // the narrow cache form does not hold this workgroup's accumulators (kernels.h, kv_fmt); two words used in turn, so that a
+  // layer's clearing never meets a lagging wave's read of the layer before (encode_tall.hip)
+  __shared__ int kv_wide_flag[2];
+  if (tid < spw) slens[tid] = s0 + tid < B ? sentence_length(a, s0 + tid, S) : 0;
 
   float *xs = reinterpret_cast<float *>(smem);
   char *Aq = reinterpret_cast<char *>(xs + ER * LDX);
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   // launch that follows this one in the stream; independent of the encoder) ----
   const bool gen_here = a.gen.w2o != nullptr;  // the batch's shortlist is generated in this launch (encode_tall.hip): packed at the end
   if (!gen_here) {
-    for (int pt = tile; pt < a.pack_tiles; pt += n_tiles) pack_weight_tile(a.pack, pt, tid, 1024);
+    pack_weight_share(a, tile, n_tiles, tid, 1024);
   } else if (tile == 0) {
     shortlist_publish_in_launch(a.gen, reinterpret_cast<uint32_t *>(smem), a.gen_flag, a.gen_epoch, tid);
   }
@@ -245,7 +247,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   for (int r = wave; r < ER; r += ENW) {
     const bool ok = row_valid(r);
     const int sb = row_sentence(r), pos = r % S;
-    const uint32_t tok = ok ? embed_row(a.emb, a.ids[(size_t)sb * S + pos]) : 0;
+    const uint32_t *sids = ok ? sentence_ids(a, sb, S) : nullptr;
+      const uint32_t tok = sids ? embed_row(a.emb, sids[pos]) : 0;
 #pragma unroll
     for (int i = 0; i < KSD; ++i) {
       float v = 0.0f;
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         Av[r * LDA + lane + 64 * i] = (char)quantize1_byte(v, wv.a_quant);
       }
     }
-    if (tid == 0) kv_wide_flag = 0;  // (raised behind this barrier, read behind the staging barrier, by every thread)
+    if (tid == 0) kv_wide_flag[l & 1] = 0;  // (raised behind this barrier, read ONCE behind the staging barrier, by every thread)
     lds_barrier();
     v4i bk[KSD], bv[KSD];
     load_frags<KSD>(bk, wk, wave, 0, lane);
@@ -664,13 +667,14 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
             outside |= (unsigned)((unsigned)s1v + lim >= 2u * lim) << 1 | (unsigned)((unsigned)(s1v - ctr) + lim16 >= 2u * lim16);
         }
       }
-      if (outside) __hip_atomic_fetch_or(&kv_wide_flag, (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (outside) __hip_atomic_fetch_or(&kv_wide_flag[l & 1], (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       lds_barrier();
+      const int raised = kv_wide_flag[l & 1];
       // The form of this workgroup's caches of this layer (kernels.h, FusedDecodeArgs::kv_fmt): the tight one (int16 less the
       // columns' centres) where the engine allows it and every such value of its valid rows lies in [-2^15, 2^15); else the
       // narrow one, 20 bits per value, when every K and V accumulator lies in [-limit, limit); else 24 bits -- both tiles are
       // staged (as accS), so the choice is made before anything is written. The same integers either way.
-      const int form = !a.kv_fmt ? 1 : (try_tight && !(kv_wide_flag & 1)) ? 2 : (kv_wide_flag & 2) ? 1 : 0;  // kv_fmt's codes
+      const int form = !a.kv_fmt ? 1 : (try_tight && !(raised & 1)) ? 2 : (raised & 2) ? 1 : 0;  // kv_fmt's codes
       const bool wide = form == 1;
       if (a.kv_fmt && tid < spw && s0 + tid < B) {
         a.kv_fmt[(size_t)l * B + s0 + tid] = (unsigned char)form;
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   }
   if (gen_here) {
     if (shortlist_await_in_launch(a.gen_flag, a.gen_epoch ^ a.gen_wait_xor, tid, a.dev_error, a.gen_spin_limit))  // (never published: nothing to pack from)
-      for (int pt = tile; pt < a.pack_tiles; pt += n_tiles) pack_weight_tile(a.pack, pt, tid, 1024);
+      pack_weight_share(a, tile, n_tiles, tid, 1024);
   }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);
 }
@@ -1256,8 +1260,9 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
   // The packed cache of this sentence takes one of three forms per layer (kernels.h, FusedDecodeArgs::kv_fmt; encode_tall.hip
   // has the same scheme): the smallest allowed first -- tight (int16 less the column's centre) where the engine allows it,
   // else narrow --, and when an accumulator of K or V does not fit, the layer is done again in the smallest form that
-  // holds it (kv_wide_flag: 1 = not tight, 2 = not narrow).
-  __shared__ int kv_wide_flag;
+  // holds it (kv_wide_flag: 1 = not tight, 2 = not narrow; two words used in turn, encode_tall.hip).
+  __shared__ int kv_wide_flag[2];
+  int kvf = 0;
   const bool try_narrow = f.kv24 && f.kv_fmt != nullptr;
   for (int l = 0; l < f.Ld; ++l) {
     SLIMT_PHASE_LANE;
@@ -1276,7 +1281,10 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
       float pb;
       load_epi(W, wave, lr, cs, pb);
       quantise_rows(X, W.a_quant);
-      if (!wide && which == 0 && tid == 0) kv_wide_flag = 0;  // (raised behind the staging only; encode_tall.hip)
+      if (!wide && which == 0) {  // (raised behind the staging only; encode_tall.hip)
+        kvf ^= 1;
+        if (tid == 0) kv_wide_flag[kvf] = 0;
+      }
       __syncthreads();
       v4i acc[NRT];
       zero_acc(acc);
@@ -1311,12 +1319,13 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
               }
             }
           }
-        if (outside) __hip_atomic_fetch_or(&kv_wide_flag, (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (outside) __hip_atomic_fetch_or(&kv_wide_flag[kvf], (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
-        // (uniform: read by every thread behind the barrier; a tight attempt that holds does not care about accS's range)
-        if (!wide && (kv_wide_flag & (form == 2 ? 1 : 2))) {
+        // (uniform: ONE read by every thread behind the barrier; a tight attempt that holds does not care about accS's range)
+        const int raised = wide ? 0 : kv_wide_flag[kvf];
+        if (raised & (form == 2 ? 1 : 2)) {
           redo = true;
-          form = (kv_wide_flag & 2) ? 1 : 0;
+          form = (raised & 2) ? 1 : 0;
           break;
         }
         const int Sp = (S + 3) & ~3;

@@ -218,8 +218,12 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   // this workgroup's sentence lengths: read once (they may live in pinned host memory, and every
   // attention job needs its sentence's; ordered by the first barrier below)
   __shared__ int slens[TR];
-  __shared__ int kv_wide_flag;  // the narrow cache form does not hold this workgroup's accumulators (the K/V phase at the end)
-  if (tid < spw) slens[tid] = s0 + tid < B ? checked_length(a.lengths[s0 + tid], S) : 0;
+  // the narrow cache form does not hold this workgroup's accumulators (the K/V phase at the end). TWO words, used in turn
+  // (kvf): an attempt's flag is cleared in front of its first barrier while a lagging wave may still be reading the flag of
+  // the attempt before -- a different word, whose next clearing lies behind two barriers every reader has passed by then.
+  __shared__ int kv_wide_flag[2];
+  int kvf = 0;
+  if (tid < spw) slens[tid] = s0 + tid < B ? sentence_length(a, s0 + tid, S) : 0;
 
   char *Aq = smem;                       // x quantised for Q | round 1's attention output | for FFN1 | for the decoder's K / V
   char *Ak = Aq + TR * LDA;              // x quantised for K
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   // side job: the batch's shortlisted output layer (used by the decoder launch behind this one)
   const bool gen_here = a.gen.w2o != nullptr;  // ... of a shortlist this launch generates itself: packed at the end
   if (!gen_here) {
-    for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+    pack_weight_share(a, tile, n_wg, tid, 1024);
   } else if (tile == 0) {
     // ShortlistGenerator::generate (Shortlist.cc:115-175; Model.cc:117-120) by the workgroup that started first,
     // in the still unused LDS, then published for the others (shortlist_device.h)
@@ -275,7 +279,8 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       const int r = 4 * wave + rr;
       const bool ok = row_valid(r);
       const int sb = row_sentence(r), pos = r % S;
-      const uint32_t tok = ok ? embed_row(a.emb, a.ids[(size_t)sb * S + pos]) : 0;
+      const uint32_t *sids = ok ? sentence_ids(a, sb, S) : nullptr;
+      const uint32_t tok = sids ? embed_row(a.emb, sids[pos]) : 0;
 #pragma unroll
       for (int i = 0; i < KSD; ++i) {
         float v = 0.0f;
@@ -824,9 +829,11 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         // the packing loop of the projection before, or of FFN1's; the staging tile is not written until the barrier below)
         if (!a.kv24) lds_barrier();  // the A buffer and the region are free
         quantise_x(0, w.a_quant, tq_base(lane));
-        // (the flag is raised behind the barrier below only; it can still be set from the layer before, whose attempt
-        // was then followed by a whole wider one: every thread has read it long ago)
-        if (!wide && p == 0 && tid == 0) kv_wide_flag = 0;
+        // (the flag is raised behind the barrier below only)
+        if (!wide && p == 0) {
+          kvf ^= 1;
+          if (tid == 0) kv_wide_flag[kvf] = 0;
+        }
         lds_barrier();
         const int col = wave * 16 + lg * 4;
         const AFrag af = a_frag(Aq, lane);
@@ -869,13 +876,14 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           }
         }
         if (!a.kv24) continue;
-        if (outside) __hip_atomic_fetch_or(&kv_wide_flag, (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (outside) __hip_atomic_fetch_or(&kv_wide_flag[kvf], (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lds_barrier();
-        // (uniform: read by every thread behind the barrier. A tight attempt looks at both ranges at once to know where
+        // (uniform: ONE read by every thread behind the barrier. A tight attempt looks at both ranges at once to know where
         // to go if it fails; when it holds, the shifted accumulators' range does not matter)
-        if (!wide && (kv_wide_flag & (form == 2 ? 1 : 2))) {
+        const int raised = wide ? 0 : kv_wide_flag[kvf];
+        if (raised & (form == 2 ? 1 : 2)) {
           redo = true;
-          form = (kv_wide_flag & 2) ? 1 : 0;
+          form = (raised & 2) ? 1 : 0;
           break;
         }
         const int Sp = (S + 3) & ~3;
@@ -1028,7 +1036,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     // the shortlist of this launch: wait for its publisher (running since before this workgroup started, and
     // waiting for nobody: ~40 us of work against this workgroup's ~250); then this workgroup's share of the output layer
     if (shortlist_await_in_launch(a.gen_flag, a.gen_epoch ^ a.gen_wait_xor, tid, a.dev_error, a.gen_spin_limit))  // (never published: nothing to pack from)
-      for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+      pack_weight_share(a, tile, n_wg, tid, 1024);
   }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);
 }

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   // this workgroup's sentence lengths: read once (they may live in pinned host memory)
   __shared__ int slens[WR];
   __shared__ int kv_wide_flag;  // the narrow cache form does not hold this workgroup's accumulators (the K/V phase at the end)
-  if (tid < spw) slens[tid] = s0 + tid < B ? checked_length(a.lengths[s0 + tid], S) : 0;
+  if (tid < spw) slens[tid] = s0 + tid < B ? sentence_length(a, s0 + tid, S) : 0;
 
   char *Abuf = smem;                 // x quantised for Q | round 1's attention output | FFN1 / decoder K/V input
   char *Akb = Abuf + WR * LDA;       // x quantised for K
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   // side job: the batch's shortlisted output layer (used by the decoder launch behind this one)
   const bool gen_here = a.gen.w2o != nullptr;  // the batch's shortlist is generated in this launch (encode_tall.hip): packed at the end
   if (!gen_here) {
-    for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+    pack_weight_share(a, tile, n_wg, tid, 1024);
   } else if (tile == 0) {
     shortlist_publish_in_launch(a.gen, reinterpret_cast<uint32_t *>(smem), a.gen_flag, a.gen_epoch, tid);
   }
@@ -236,7 +236,8 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       const int r = 2 * wave + rr;
       const bool ok = row_valid(r);
       const int sb = row_sentence(r), pos = r % S;
-      const uint32_t tok = ok ? embed_row(a.emb, a.ids[(size_t)sb * S + pos]) : 0;
+      const uint32_t *sids = ok ? sentence_ids(a, sb, S) : nullptr;
+      const uint32_t tok = sids ? embed_row(a.emb, sids[pos]) : 0;
 #pragma unroll
       for (int i = 0; i < KSD; ++i) {
         float v = 0.0f;
@@ -623,7 +624,8 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         load_w(bw[1], w, wave + WNW, lane);
         lds_barrier();
         quantise_x(Abuf, w.a_quant, lane);
-        if (!wide && p == 0 && tid == 0) kv_wide_flag = 0;  // (raised behind the barrier below only; encode_tall.hip)
+        // (cleared behind the barrier above, which every thread reaches after its read of the attempt before; raised behind the one below)
+        if (!wide && p == 0 && tid == 0) kv_wide_flag = 0;
         lds_barrier();
         unsigned outside = 0;  // an accumulator of a valid row outside the form's range
         const unsigned lim = (unsigned)a.kv_narrow_limit, lim16 = (unsigned)a.kv_tight_limit;
@@ -687,10 +689,11 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         if (!a.kv24) continue;
         if (outside) __hip_atomic_fetch_or(&kv_wide_flag, (int)outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lds_barrier();
-        // (uniform: read by every thread behind the barrier; a tight attempt that holds does not care about accS's range)
-        if (!wide && (kv_wide_flag & (form == 2 ? 1 : 2))) {
+        // (uniform: ONE read by every thread behind the barrier; a tight attempt that holds does not care about accS's range)
+        const int raised = wide ? 0 : kv_wide_flag;
+        if (raised & (form == 2 ? 1 : 2)) {
           redo = true;
-          form = (kv_wide_flag & 2) ? 1 : 0;
+          form = (raised & 2) ? 1 : 0;
           break;
         }
         const int *stg = reinterpret_cast<const int *>(region);
@@ -830,7 +833,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   }
   if (gen_here) {
     if (shortlist_await_in_launch(a.gen_flag, a.gen_epoch ^ a.gen_wait_xor, tid, a.dev_error, a.gen_spin_limit))  // (never published: nothing to pack from)
-      for (int pt = tile; pt < a.pack_tiles; pt += n_wg) pack_weight_tile(a.pack, pt, tid, 1024);
+      pack_weight_share(a, tile, n_wg, tid, 1024);
   }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);
 }

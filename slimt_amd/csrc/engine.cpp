@@ -1380,12 +1380,25 @@ bool fused_encoder_chosen(const slimt_hip_ctx *c, int B, int S) {
   return c->decode_mode != 1 && (tall_mid || fused_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S));
 }
 
+// One merged launch pair (kernels.h, MergeIn / MergeOut / MergePack): the sub-batches' tables as the kernels take them, and
+// the packing jobs of the launch -- one per distinct shortlist, their buffers job strides apart in ctx->out_sl.
+struct MergePlan {
+  int n = 0;
+  MergeIn in[kMaxMerge];
+  MergeOut out[kMaxMerge];
+  int n_jobs = 0;
+  MergePack jobs[kMaxMerge];
+  int max_N = 0;  // columns of the widest job
+  size_t stride_wp = 0, stride_cs = 0, stride_pb = 0;
+};
+
 // gen (nullable; only where fused_encoder_chosen): the batch's shortlist is generated inside the encoder launch
 // (kernels.h, FusedEncodeArgs::gen) -- its ids / count are pack->idx / pack->n_dev.
 int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layers,
                   const uint32_t *d_ids = nullptr, const uint32_t *d_lengths = nullptr,
                   const PackArgs *pack = nullptr, bool embedded = false, bool keep_out = true,
-                  bool kv24 = false, const ShortlistArgs *gen = nullptr, bool kv_store_nt = false) {
+                  bool kv24 = false, const ShortlistArgs *gen = nullptr, bool kv_store_nt = false,
+                  const MergePlan *mp = nullptr) {
   // kv24 (translate_device only: the caller decodes with the persistent kernel's packed-cache
   // variant right behind this launch): the fused encoder leaves the 24-bit K/V cache
   // keep_out = false (the translate path): the persistent encoder leaves the decoder its K/V
@@ -1457,6 +1470,18 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       f.pack = *pack;
       f.pack_tiles = (pack->N + 15) / 16;
     }
+    if (mp) {  // a merged launch: the sub-batches' inputs, and one packing job per distinct shortlist
+      f.n_sub = mp->n;
+      for (int j = 0; j < mp->n; ++j) f.sub[j] = mp->in[j];
+      if (pack) {
+        f.n_pack = mp->n_jobs;
+        for (int j = 0; j < mp->n_jobs; ++j) f.pjob[j] = mp->jobs[j];
+        f.pack_tiles = (mp->max_N + 15) / 16;
+        f.pack_stride_wp = mp->stride_wp;
+        f.pack_stride_cs = mp->stride_cs;
+        f.pack_stride_pb = mp->stride_pb;
+      }
+    }
     if (h_embed) {
       HIPCHK(c->dbg_embed.reserve(nbytes));
       f.embed_out = c->dbg_embed.as<float>();
@@ -1501,6 +1526,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     c->kv_ready = !kv24;  // the step-wise decoder reads the f32 form only
     return 0;
   }
+  if (mp) return fail(-1, "merged launch: no persistent encoder for this shape");
   if (!embedded && c->decode_mode != 1 && long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, S)) {
     // 32 < S <= 128: one persistent workgroup per sentence (kernels.hip, encode_long_kernel)
     LongEncodeArgs a;
@@ -1792,7 +1818,10 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
                      const uint32_t *d_shortlist, size_t B, size_t S, size_t n_sl,
                      float limit_factor, uint32_t eos_id, uint32_t *d_out_ids, uint32_t *d_out_len,
                      float *d_align, int steps_hint, const uint32_t *d_n_sl = nullptr,
-                     float *align_out = nullptr, size_t n_sl_hint = 0, const ShortlistArgs *gen = nullptr) {
+                     float *align_out = nullptr, size_t n_sl_hint = 0, const ShortlistArgs *gen = nullptr,
+                     MergePlan *mp = nullptr) {
+  // mp (merged launch; lean path only, checked by the caller): B = the launch's global sentences, n_sl = the widest job's
+  // columns (0 = full vocabulary for every sub-batch); d_ids / d_lengths / d_shortlist / d_out_* / d_align are not used
   // gen (with d_n_sl, lean path, 64-row encoder): the shortlist is generated inside the encoder launch
   // n_sl_hint (with d_n_sl): what the host expects the device-side shortlist size to be (the size of
   // this context's previous generated shortlist): tuning decisions only
@@ -1860,9 +1889,20 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   ds.eos = eos_id;
   if (lean) {
     PackArgs job;
-    if (n_sl)
+    if (n_sl && mp) {
+      // one allocation for the launch's jobs, job j at j strides (a stride holds the widest job)
+      mp->stride_wp = (packed_weight_bytes(m->D, (int)n_sl) + 255) / 256 * 256;
+      mp->stride_cs = (colsum_alloc_bytes((int)n_sl) + 255) / 256 * 256;
+      mp->stride_pb = (((size_t)n_sl + 15) / 16 * 16 * sizeof(float) + 255) / 256 * 256;
+      HIPCHK(c->out_sl.Wp.reserve(mp->stride_wp * mp->n_jobs));
+      HIPCHK(c->out_sl.colsum.reserve(mp->stride_cs * mp->n_jobs));
+      HIPCHK(c->out_sl.pb.reserve(mp->stride_pb * mp->n_jobs));
+      RCCHK(prepare_affine_meta(c->out_sl, m->out_raw.as<int8_t>(), m->D, mp->jobs[0].N, mp->jobs[0].idx,
+                                m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, job, m->V));
+    } else if (n_sl) {
       RCCHK(prepare_affine_meta(c->out_sl, m->out_raw.as<int8_t>(), m->D, (int)n_sl, d_shortlist,
                                 m->out_bias.as<float>(), m->out_a_quant, m->wemb_mult, job, m->V));
+    }
     job.n_dev = d_n_sl;
     // the decoder's cache policy of THIS call (decided further down, under the admission lock, from the same two
     // numbers): will its caches be kept in the Infinity Cache, or streamed? Streamed ones are also WRITTEN past it
@@ -1870,7 +1910,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     call_k = c->model->kv_k_last.load(std::memory_order_relaxed);
     static const bool store_nt = std::getenv("SLIMT_KV_STORE_NT") && std::getenv("SLIMT_KV_STORE_NT")[0] == '1';
     RCCHK(encode_device(c, (int)B, (int)S, nullptr, nullptr, d_ids, d_lengths, n_sl ? &job : nullptr, false, false,
-                        kv24, gen, store_nt && kv24 && call_k < 8 && (int)(call_slot % 8) >= call_k));
+                        kv24, gen, store_nt && kv24 && call_k < 8 && (int)(call_slot % 8) >= call_k, mp));
     c->n_sl = (int)n_sl;
     if (calibrate) {
       slimt_hip_model *gm = c->model;
@@ -1919,7 +1959,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     // weights a step streams: with the full 32k vocabulary it is 8 of 10 MB per workgroup and step, and
     // halving it per sentence beats the longer attention chain (B = 512, full vocabulary: 20.4 -> 23-24 M
     // tok/s; at 16k columns the two are level, below that 16 rows win)
-    const size_t n_expected = d_n_sl && n_sl_hint ? n_sl_hint : (size_t)out.w.N;
+    const size_t n_expected = mp ? (size_t)(n_sl ? mp->max_N : m->V) : d_n_sl && n_sl_hint ? n_sl_hint : (size_t)out.w.N;
     // ... and 8 or 4 (decode_fused.hip, SPW) when the decoders in flight would leave most of the chip idle:
     // decided below, under the admission lock, from the contexts that have a decoder pending
     // Round 5: where the kernel has it, output layers that wide are SHARED by clusters of four 16-sentence workgroups
@@ -1936,7 +1976,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     // encoder is only allowed it when this context's decoders take those: kv_tight_wanted; a mode changed between the two
     // calls, or a first large output layer, ends up here)
     const bool tight = kv24 && c->kv_tight && c->kv_fmt_valid && c->kv_fmt_B == (int)B;
-    const bool clusters = cluster_ok && c->decode_mode == 6 && !tight;
+    const bool clusters = cluster_ok && c->decode_mode == 6 && !tight && !mp;
     c->expect_large_output = n_expected > 16384;
     f.kv_tight = tight;
     f.rows_per_wg = clusters ? 16 : c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : c->decode_mode == 4 ? 8 : c->decode_mode == 5 ? 4
@@ -1985,6 +2025,14 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       f.kv_centre[l][1] = m->kv_centre.as<int>() + (size_t)(2 * l + 1) * m->D;
       f.kv_u4096[l][0] = wk.w.u * (1.0f / 4096.0f);  // ... as accS * 4096 from the narrow form (unpack20)
       f.kv_u4096[l][1] = wv.w.u * (1.0f / 4096.0f);
+    }
+    if (mp) {
+      f.n_sub = mp->n;
+      for (int j = 0; j < mp->n; ++j) f.sub[j] = mp->out[j];
+      f.out_stride_wp = mp->stride_wp;
+      f.out_stride_cs = mp->stride_cs;
+      f.out_stride_pb = mp->stride_pb;
+      f.shortlist = nullptr;
     }
     f.cells = c->state.as<float>();
     f.lengths = d_lengths;
@@ -2368,6 +2416,157 @@ extern "C" int slimt_hip_translate_async(slimt_hip_ctx *ctx, const uint32_t *src
                                          uint32_t *out_len, float *align) {
   return translate_host(ctx, src_ids, lengths, B, S, shortlist, n_shortlist, limit_factor, eos_id,
                         out_ids, out_len, align, false);
+}
+
+// ---- several batches in one launch pair (include/slimt_hip.h, slimt_hip_translate_many*) ----------------------------
+namespace {
+constexpr size_t kMergeAlign = 32;  // a sub-batch starts at a multiple of the widest decoder tile (kernels.h, MergeOut)
+
+bool merge_supported(const slimt_hip_ctx *c, size_t rows, size_t S) {
+  const slimt_hip_model *m = c->model;
+  return fused_decoder_allowed(c) && c->decode_mode != 6 && fused_decode_supported(m->D, m->F, m->H, m->Ld) &&
+         fused_encoder_chosen(c, (int)rows, (int)S);
+}
+
+// the sub-batches' tables. align_staging (nullable): the alignment rows are staged there (global sentence order) and
+// each batch's `align` (a device view of the caller's pinned array) is where they go when a sentence ends
+int build_merge_plan(const slimt_hip_ctx *c, const slimt_hip_batch *b, size_t n, size_t S, size_t Tmax, float *align_staging,
+                     MergePlan &mp, size_t &rows) {
+  mp.n = (int)n;
+  rows = 0;
+  for (size_t j = 0; j < n; ++j) {
+    if (!b[j].src_ids || !b[j].lengths || !b[j].out_ids || !b[j].out_len) return fail(-1, "batch %zu: null array", j);
+    if (b[j].B == 0) return fail(-1, "batch %zu is empty", j);
+    if (b[j].n_shortlist > (size_t)c->model->V) return fail(-1, "batch %zu: shortlist larger than the vocabulary", j);
+    if (b[j].n_shortlist && !b[j].shortlist) return fail(-1, "batch %zu: shortlist is NULL", j);
+    if ((b[j].n_shortlist != 0) != (b[0].n_shortlist != 0))
+      return fail(-1, "merged batches: all with a shortlist or all with the full vocabulary");
+    MergeIn &in = mp.in[j];
+    MergeOut &o = mp.out[j];
+    in.ids = b[j].src_ids;
+    in.lengths = b[j].lengths;
+    in.first = (int)rows;
+    in.n = (int)b[j].B;
+    o.lengths = b[j].lengths;
+    o.out_ids = b[j].out_ids;
+    o.out_len = b[j].out_len;
+    if (b[j].align && align_staging) {
+      o.align = align_staging + rows * Tmax * S;
+      o.align_out = b[j].align;
+    } else {
+      o.align = b[j].align;
+      o.align_out = nullptr;
+    }
+    o.shortlist = b[j].n_shortlist ? b[j].shortlist : nullptr;
+    o.first = (int)rows;
+    o.n = (int)b[j].B;
+    o.N = b[j].n_shortlist ? (int)b[j].n_shortlist : c->model->V;
+    o.job = 0;
+    if (b[j].n_shortlist) {  // one packing job per distinct (pointer, size)
+      int job = -1;
+      for (int q = 0; q < mp.n_jobs; ++q)
+        if (mp.jobs[q].idx == b[j].shortlist && mp.jobs[q].N == (int)b[j].n_shortlist) job = q;
+      if (job < 0) {
+        job = mp.n_jobs++;
+        mp.jobs[job].idx = b[j].shortlist;
+        mp.jobs[job].N = (int)b[j].n_shortlist;
+        mp.max_N = std::max(mp.max_N, (int)b[j].n_shortlist);
+      }
+      o.job = job;
+    }
+    rows += (b[j].B + kMergeAlign - 1) / kMergeAlign * kMergeAlign;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" size_t slimt_hip_translate_many_rows(const size_t *B, size_t n_batches) {
+  size_t rows = 0;
+  for (size_t j = 0; B && j < n_batches; ++j) rows += (B[j] + kMergeAlign - 1) / kMergeAlign * kMergeAlign;
+  return rows;
+}
+
+extern "C" int slimt_hip_translate_many_device(slimt_hip_ctx *ctx, const slimt_hip_batch *batches, size_t n_batches, size_t S,
+                                               float limit_factor, uint32_t eos_id, int steps_hint) {
+  if (!ctx || !batches || n_batches == 0) return fail(-1, "null argument");
+  HIPCHK(hipSetDevice(ctx->model->device));
+  const size_t Tmax = std::max<size_t>(1, (size_t)(limit_factor * (float)S));
+  MergePlan mp;
+  size_t rows = 0;
+  const bool mergeable = n_batches > 1 && n_batches <= (size_t)kMaxMerge;
+  if (mergeable) RCCHK(build_merge_plan(ctx, batches, n_batches, S, Tmax, nullptr, mp, rows));
+  if (mergeable && rows <= ctx->max_B && rows * S <= ctx->max_M && S <= ctx->max_S && merge_supported(ctx, rows, S))
+    return translate_device(ctx, batches[0].src_ids, batches[0].lengths, batches[0].shortlist, rows, S, (size_t)mp.max_N,
+                            limit_factor, eos_id, batches[0].out_ids, batches[0].out_len, batches[0].align, steps_hint, nullptr,
+                            nullptr, 0, nullptr, &mp);
+  for (size_t j = 0; j < n_batches; ++j) {  // batch by batch, in order, on the same stream
+    const slimt_hip_batch &b = batches[j];
+    RCCHK(slimt_hip_translate_device(ctx, b.src_ids, b.lengths, b.B, S, b.shortlist, b.n_shortlist, limit_factor, eos_id,
+                                     b.out_ids, b.out_len, b.align, steps_hint));
+  }
+  return 0;
+}
+
+extern "C" int slimt_hip_translate_many_async(slimt_hip_ctx *ctx, const slimt_hip_batch *batches, size_t n_batches, size_t S,
+                                              float limit_factor, uint32_t eos_id) {
+  if (!ctx || !batches || n_batches == 0) return fail(-1, "null argument");
+  const slimt_hip_model *m = ctx->model;
+  HIPCHK(hipSetDevice(m->device));
+  const size_t Tmax = std::max<size_t>(1, (size_t)(limit_factor * (float)S));
+  bool merged = n_batches > 1 && n_batches <= (size_t)kMaxMerge && S <= ctx->max_S;
+  slimt_hip_batch dev[kMaxMerge];
+  bool any_align = false;
+  size_t rows = 0;
+  for (size_t j = 0; merged && j < n_batches; ++j) {
+    const slimt_hip_batch &b = batches[j];
+    if (!b.src_ids || !b.lengths || !b.out_ids || !b.out_len || b.B == 0) return fail(-1, "batch %zu: null array or empty", j);
+    if (b.shortlist != batches[0].shortlist || b.n_shortlist != batches[0].n_shortlist) merged = false;  // one host shortlist
+    for (size_t i = 0; merged && i < b.B * S; ++i)
+      if (b.src_ids[i] >= (uint32_t)m->V) return fail(-1, "batch %zu: token id %u out of range", j, b.src_ids[i]);
+    for (size_t i = 0; merged && i < b.B; ++i)
+      if (b.lengths[i] > S) return fail(-1, "batch %zu: length %u > S", j, b.lengths[i]);
+    dev[j] = b;
+    dev[j].src_ids = static_cast<const uint32_t *>(host_device_view(b.src_ids));
+    dev[j].lengths = static_cast<const uint32_t *>(host_device_view(b.lengths));
+    dev[j].out_ids = static_cast<uint32_t *>(host_device_view(b.out_ids));
+    dev[j].out_len = static_cast<uint32_t *>(host_device_view(b.out_len));
+    dev[j].align = b.align ? static_cast<float *>(host_device_view(b.align)) : nullptr;
+    if (!dev[j].src_ids || !dev[j].lengths || !dev[j].out_ids || !dev[j].out_len || (b.align && !dev[j].align)) merged = false;
+    any_align = any_align || b.align != nullptr;
+    rows += (b.B + kMergeAlign - 1) / kMergeAlign * kMergeAlign;
+  }
+  merged = merged && rows <= ctx->max_B && rows * S <= ctx->max_M && merge_supported(ctx, rows, S);
+  if (!merged) {
+    for (size_t j = 0; j < n_batches; ++j) {
+      const slimt_hip_batch &b = batches[j];
+      RCCHK(translate_host(ctx, b.src_ids, b.lengths, b.B, S, b.shortlist, b.n_shortlist, limit_factor, eos_id, b.out_ids,
+                           b.out_len, b.align, false));
+    }
+    return 0;
+  }
+  const size_t n_sl = batches[0].n_shortlist;
+  const uint32_t *shortlist = batches[0].shortlist;
+  if (n_sl > (size_t)m->V) return fail(-1, "shortlist larger than the vocabulary");
+  if (n_sl && !shortlist) return fail(-1, "shortlist is NULL");
+  for (size_t i = 0; i < n_sl; ++i)
+    if (shortlist[i] >= (uint32_t)m->V) return fail(-1, "shortlist id %u out of range", shortlist[i]);
+  hipStream_t st = ctx->stream;
+  if (n_sl && (ctx->sl_host.size() != n_sl || std::memcmp(ctx->sl_host.data(), shortlist, n_sl * 4) != 0)) {
+    ctx->sl_host.clear();  // (translate_host: uploaded when it changes)
+    HIPCHK(hipMemcpyAsync(ctx->shortlist.p, shortlist, n_sl * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ctx->sl_host.assign(shortlist, shortlist + n_sl);
+  }
+  if (any_align) HIPCHK(ctx->align.reserve(align_staging_bytes(ctx, rows, S, Tmax, limit_factor)));
+  for (size_t j = 0; j < n_batches; ++j) {
+    dev[j].shortlist = n_sl ? ctx->shortlist.as<uint32_t>() : nullptr;
+    dev[j].n_shortlist = n_sl;
+  }
+  MergePlan mp;
+  RCCHK(build_merge_plan(ctx, dev, n_batches, S, Tmax, any_align ? ctx->align.as<float>() : nullptr, mp, rows));
+  return translate_device(ctx, dev[0].src_ids, dev[0].lengths, dev[0].shortlist, rows, S, (size_t)mp.max_N, limit_factor, eos_id,
+                          dev[0].out_ids, dev[0].out_len, any_align ? ctx->align.as<float>() : nullptr, (int)Tmax, nullptr,
+                          any_align ? dev[0].align : nullptr, 0, nullptr, &mp);
 }
 
 extern "C" int slimt_hip_host_alloc(size_t bytes, void **out) {

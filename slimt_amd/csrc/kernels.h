@@ -262,6 +262,46 @@ struct DQAttnArgs {
 };
 hipError_t launch_dqattn(const DQAttnArgs &a, hipStream_t st);
 
+// ---- merged launches (slimt_hip_translate_many*) -------------------------------
+// Several batches of ONE padded source length share an encoder and a decoder launch: what k concurrent Model::forward
+// calls of k workers are in the reference (Frontend.cc:207-227; its default batches are 1024 padded tokens,
+// Frontend.hh:21-39 -- 32 sentences at S = 32 --, far too few to fill 256 CUs one batch per launch pair). The launch sees
+// ONE batch of `B` global sentences; sub-batch j owns the global sentences first[j] .. first[j] + n[j] - 1, first[j] a
+// multiple of 32 (so every decoder tile of 4 / 8 / 16 / 32 sentences lies inside one sub-batch: a tile has ONE output
+// layer and ONE set of output arrays), and the global sentences in between are HOLES: the encoder runs them as empty
+// sentences of pad tokens (their cache slots exist; nothing of the caller's is read), the decoder never owns them.
+// The K/V cache, its form bytes and every other per-sentence workspace are indexed by the global sentence; only the
+// caller's arrays go through these tables, which travel in the kernel arguments (no copy, no helper launch).
+// A sentence's arithmetic never depends on its neighbours, so each sub-batch's results are those of its own call.
+constexpr int kMaxMerge = 8;
+struct MergeIn {  // encoder side, one per sub-batch
+  const uint32_t *ids = nullptr;      // [n][S]
+  const uint32_t *lengths = nullptr;  // [n]
+  int first = 0, n = 0;
+};
+struct MergeOut {  // decoder side, one per sub-batch
+  const uint32_t *lengths = nullptr;    // [n]
+  uint32_t *out_ids = nullptr;          // [n][Tmax]
+  uint32_t *out_len = nullptr;          // [n]
+  float *align = nullptr;               // nullable [n][Tmax][S] (a staging block when align_out is set)
+  float *align_out = nullptr;           // nullable (FusedDecodeArgs::align_out)
+  const uint32_t *shortlist = nullptr;  // nullable: this sub-batch's column -> vocabulary id
+  int first = 0, n = 0;
+  int job = 0;    // which of the launch's packed output layers (sub-batches with one shortlist share one)
+  int N = 0;      // its columns
+};
+struct MergePack {  // one packing job per DISTINCT shortlist of the launch; job j's buffers lie j strides behind job 0's
+  const uint32_t *idx = nullptr;
+  int N = 0, pad = 0;
+};
+// which sub-batch owns global sentence g (first[] ascends; holes belong to the sub-batch in front of them)
+template <class T>
+__host__ __device__ inline int merge_find(const T *sub, int n_sub, int g) {
+  int j = n_sub - 1;
+  while (j > 0 && g < sub[j].first) --j;
+  return j;
+}
+
 // ---- persistent fused decoder (decode_fused.hip) ------------------------------
 struct FusedLayerW {
   PreparedWeight rnn_f, rnn_w, q, o, ffn1, ffn2;
@@ -356,6 +396,12 @@ struct FusedDecodeArgs {
   int *cl_part = nullptr;
   unsigned *cl_sync = nullptr;
   unsigned *dev_error = nullptr;
+  // merged launch (MergeOut above): n_sub > 0 -- lengths / out_ids / out_len / align / align_out / shortlist / out above are
+  // then NOT used (each tile takes its sub-batch's); the packed output layer of job j: Wp, colsum (+ pair constants), pb of
+  // `out` moved by j strides (bytes)
+  int n_sub = 0;
+  MergeOut sub[kMaxMerge];
+  size_t out_stride_wp = 0, out_stride_cs = 0, out_stride_pb = 0;
   bool ln_in_lds = false;  // set by the launcher: the LayerNorm constants of all layers fit LDS beside the rest
   bool kv_nt = false;  // non-temporal K/V cache loads (d_head 32 / 64 shapes; see decode_fused.hip)
   // with kv_nt: which caches are still read temporally, in eighths of a layer: sentence b's cache of
@@ -438,6 +484,13 @@ struct FusedEncodeArgs {
   unsigned long long *kv_wide_count = nullptr;
   PackArgs pack;               // the batch's shortlisted output layer, packed by the
   int pack_tiles = 0;          // encoder's workgroups on the side (0 = nothing to pack)
+  // merged launch (MergeIn above): n_sub > 0 -- ids / lengths above are not used. n_pack > 1: `pack` describes job 0 and
+  // job j differs by its idx / N and by j strides (bytes) on Wp / colsum / pb; pack_tiles = tiles of the LARGEST job
+  int n_sub = 0;
+  MergeIn sub[kMaxMerge];
+  int n_pack = 0;
+  MergePack pjob[kMaxMerge];
+  size_t pack_stride_wp = 0, pack_stride_cs = 0, pack_stride_pb = 0;
   // ShortlistGenerator::generate inside this launch (the S <= 64 encoders; gen.w2o != nullptr): the workgroup
   // that claims tile 0 generates the batch's shortlist (gen.out / gen.n_out = pack.idx / pack.n_dev) before its
   // encoder work and publishes *gen_flag = gen_epoch; every workgroup packs its share of the output layer at
