@@ -290,17 +290,21 @@ int slimt_hip_translate_device(slimt_hip_ctx *ctx, const uint32_t *d_src_ids,
 /* ---- several batches in one launch pair -----------------------------------
  * What `workers` concurrent Model::forward calls are in the reference (Async,
  * slimt/Frontend.cc:207-227, each worker translating the batch the Batcher hands
- * it, Batcher.cc:95-120): n batches of ONE padded source length S, each with its
- * own arrays, its own shortlist and its own outputs, translated by ONE encoder
- * and ONE decoder launch on ctx's stream. The reference's default batch is 1024
+ * it, Batcher.cc:95-120): n batches, each with its own padded source length (at
+ * most S, the launch's), its own arrays, its own shortlist and its own outputs,
+ * translated by ONE encoder and ONE decoder launch on ctx's stream. A batch padded
+ * to fewer tokens than the launch keeps ITS length's step limit and alignment
+ * width (Model.cc:159-161, 84-108); the extra positions are padding like any
+ * other (masked keys of weight exactly 0, Input.cc:49-63). The reference's default batch is 1024
  * padded tokens (Frontend.hh:21-39: 32 sentences of 32 tokens) -- one such batch
  * per launch pair occupies 2 of 256 CUs in the decoder; merged, k of them fill
  * what one batch of k x B would. Every sentence's arithmetic is independent of
  * its neighbours, so each batch's outputs equal those of its own
  * slimt_hip_translate* call bit for bit (tests/test_gpu_translate_many.py).
  *
- * The launch works on sum_j roundup(B_j, 32) "global" sentences (_rows below):
- * ctx must hold that many (max_batch) and that many times S padded tokens.
+ * The launch works on sum_j roundup(B_j, 32) "global" sentences (_rows below),
+ * every one padded to the call's S: ctx must hold that many (max_batch) and that
+ * many times S padded tokens.
  * Limits: n <= 8; the persistent kernels for sources of up to 64 tokens. Whatever
  * cannot be merged (more batches, longer sources, decode modes 1 / 6, K/V cache
  * format 3) is translated batch by batch, in order, on the same stream: same
@@ -310,9 +314,10 @@ typedef struct slimt_hip_batch {
   const uint32_t *src_ids;   /* [B][S] */
   const uint32_t *lengths;   /* [B] */
   size_t B;
+  size_t S;                  /* this batch's padded length, <= the call's S; 0 = the call's S */
   const uint32_t *shortlist; /* sorted unique target ids, or NULL with n_shortlist == 0: full vocabulary */
   size_t n_shortlist;
-  uint32_t *out_ids;         /* [B][Tmax], Tmax = max(1, (size_t)(limit_factor * S)) */
+  uint32_t *out_ids;         /* [B][Tmax], Tmax = max(1, (size_t)(limit_factor * S)), S = this batch's */
   uint32_t *out_len;         /* [B] */
   float *align;              /* nullable [B][Tmax][S] */
 } slimt_hip_batch;

@@ -38,6 +38,11 @@ typedef struct slimt_hip_service_config {
   int32_t shortlist_shared_vocab, shortlist_check;
   const uint32_t *shortlist;
   uint64_t n_shortlist;
+  /* merged launches (slimt_hip_translate_many_async; host/Service.hh, ServiceConfig::merge_batches): a worker takes up
+   * to merge_batches consecutive batches of one padded length -- each formed under max_words, each with its own results --
+   * into one launch pair while their rows x length stay within merge_words. 0 = the defaults (8 batches, 8192 words);
+   * merge_batches = 1: never. Not used with a lexical shortlist. */
+  uint64_t merge_batches, merge_words;
 } slimt_hip_service_config;
 
 const char *slimt_hip_service_last_error(void); /* thread-local, never NULL */

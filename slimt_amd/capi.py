@@ -56,7 +56,7 @@ class _Param(C.Structure):
 
 class _Batch(C.Structure):
     """slimt_hip_batch (include/slimt_hip.h): one batch of a merged launch."""
-    _fields_ = [("src_ids", C.c_void_p), ("lengths", C.c_void_p), ("B", C.c_size_t), ("shortlist", C.c_void_p),
+    _fields_ = [("src_ids", C.c_void_p), ("lengths", C.c_void_p), ("B", C.c_size_t), ("S", C.c_size_t), ("shortlist", C.c_void_p),
                 ("n_shortlist", C.c_size_t), ("out_ids", C.c_void_p), ("out_len", C.c_void_p), ("align", C.c_void_p)]
 
 
@@ -637,10 +637,12 @@ class Context:
 
     def translate_many_device(self, batches, S: int, limit_factor: float, eos_id: int, steps_hint: int = 0):
         """slimt_hip_translate_many_device: `batches` = [(d_ids, d_lengths, B, d_shortlist, n_shortlist, d_out_ids,
-        d_out_len, d_align)] of device pointers (ints; 0 = none) -- ONE encoder and ONE decoder launch for all of them."""
+        d_out_len, d_align[, S_j])] of device pointers (ints; 0 = none) -- ONE encoder and ONE decoder launch for all of them;
+        S_j: that batch's own padded length (<= S; default S)."""
         arr = (_Batch * len(batches))()
-        for j, (d_ids, d_len, B, d_sl, n_sl, d_out, d_ol, d_al) in enumerate(batches):
-            arr[j] = _Batch(d_ids, d_len, B, d_sl if n_sl else None, n_sl, d_out, d_ol, d_al or None)
+        for j, b in enumerate(batches):
+            d_ids, d_len, B, d_sl, n_sl, d_out, d_ol, d_al = b[:8]
+            arr[j] = _Batch(d_ids, d_len, B, b[8] if len(b) > 8 else 0, d_sl if n_sl else None, n_sl, d_out, d_ol, d_al or None)
         _chk(lib().slimt_hip_translate_many_device(self.h, arr, len(batches), S, limit_factor, eos_id, steps_hint))
 
     def translate_many_async(self, bufs_list, shortlist=None, limit_factor: float = 1.5, eos_id: int = 0):
@@ -648,10 +650,9 @@ class Context:
         one shortlist (host array) or none for all; synchronize() before reading the outputs."""
         sl = None if shortlist is None else np.ascontiguousarray(shortlist, dtype=np.uint32)
         arr = (_Batch * len(bufs_list))()
-        S = bufs_list[0][0].shape[1]
+        S = max(b[0].shape[1] for b in bufs_list)  # the launch's padded length; a batch may be padded to fewer tokens
         for j, (p_ids, p_len, p_out, p_ol, p_al) in enumerate(bufs_list):
-            assert p_ids.shape[1] == S
-            arr[j] = _Batch(p_ids.ctypes.data, p_len.ctypes.data, p_ids.shape[0], None if sl is None else sl.ctypes.data,
+            arr[j] = _Batch(p_ids.ctypes.data, p_len.ctypes.data, p_ids.shape[0], p_ids.shape[1], None if sl is None else sl.ctypes.data,
                             0 if sl is None else sl.size, p_out.ctypes.data, p_ol.ctypes.data,
                             None if p_al is None else p_al.ctypes.data)
         self._many_keep = (arr, sl)
@@ -807,7 +808,8 @@ class _ServiceConfig(C.Structure):
                 ("workers_per_device", C.c_uint32), ("pad_id", C.c_uint32), ("eos_id", C.c_uint32),
                 ("alignments", C.c_int32), ("lexical_shortlist", C.c_void_p), ("lexical_shortlist_bytes", C.c_uint64),
                 ("source_vocab", C.c_uint64), ("target_vocab", C.c_uint64), ("shortlist_shared_vocab", C.c_int32),
-                ("shortlist_check", C.c_int32), ("shortlist", C.c_void_p), ("n_shortlist", C.c_uint64)]
+                ("shortlist_check", C.c_int32), ("shortlist", C.c_void_p), ("n_shortlist", C.c_uint64),
+                ("merge_batches", C.c_uint64), ("merge_words", C.c_uint64)]
 
 
 class ServiceResult:
@@ -864,11 +866,13 @@ class BatchService:
     def __init__(self, models, max_words: int = 8192, wrap_length: int = 128, limit_factor: float = 1.5,
                  workers_per_device: int = 6, pad_id: int = 0, eos_id: int = 0, alignments: bool = True,
                  lexical_shortlist: bytes = b"", source_vocab: int = 0, target_vocab: int = 0,
-                 shared_vocab: bool = False, check: bool = False, shortlist=None):
+                 shared_vocab: bool = False, check: bool = False, shortlist=None, merge_batches: int = 0, merge_words: int = 0):
+        """merge_batches / merge_words: merged launches (0 = the library's defaults: up to 8 consecutive batches of one padded
+        length per launch pair within 8192 words; merge_batches = 1: never)."""
         self._keep = []
         cfg = _ServiceConfig(max_words, wrap_length, limit_factor, workers_per_device, pad_id, eos_id,
                              1 if alignments else 0, None, 0, source_vocab, target_vocab,
-                             1 if shared_vocab else 0, 1 if check else 0, None, 0)
+                             1 if shared_vocab else 0, 1 if check else 0, None, 0, merge_batches, merge_words)
         if lexical_shortlist:
             buf = C.create_string_buffer(bytes(lexical_shortlist), len(lexical_shortlist))
             self._keep.append(buf)

@@ -2651,6 +2651,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   const int sj_first = a.n_sub ? a.sub[sj].first : 0;
   const int Bv = a.n_sub ? sj_first + a.sub[sj].n : B;
   if (m0 >= Bv) return;
+  // ... and a sub-batch has its own padded length: the row length of its outputs, the width of its alignment rows, its step limit
+  const int Tmx = a.n_sub ? a.sub[sj].Tmax : a.Tmax;
+  const int Sal = a.n_sub ? a.sub[sj].S : S;
   if (tid == 0) occ_trace_event(a.trace, 1, 0);
   // my cluster (CL > 1): tiles cl_first .. cl_first + cl_n - 1 (the last cluster of a batch may be short), me = member cl_m
   const int n_tiles_b = (B + RS - 1) / RS;
@@ -2733,9 +2736,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       uint32_t *oi = a.n_sub ? a.sub[sj].out_ids : a.out_ids;
       float *al = a.n_sub ? a.sub[sj].align : a.align;
       const bool staged = (a.n_sub ? a.sub[sj].align_out : a.align_out) != nullptr;
-      for (int i = lane; i < a.Tmax; i += 64) oi[(size_t)(bq[rr] - sj_first) * a.Tmax + i] = 0;
+      for (int i = lane; i < Tmx; i += 64) oi[(size_t)(bq[rr] - sj_first) * Tmx + i] = 0;
       if (al && !staged)
-        for (int i = lane; i < a.Tmax * S; i += 64) al[(size_t)(bq[rr] - sj_first) * a.Tmax * S + i] = 0.0f;
+        for (int i = lane; i < Tmx * Sal; i += 64) al[(size_t)(bq[rr] - sj_first) * Tmx * Sal + i] = 0.0f;
     }
     // step-0 embedding: zeros * sqrt(D) + pos(0)  (Transformer.cc:138-144,160)
 #pragma unroll
@@ -2764,7 +2767,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   // from logits[0] and only moves on `value > max`, so it stays at class 0 (Transformer.cc:287-298); the arg-max
   // below skips NaNs, so the rule is applied where the token is taken
   const bool nan0 = outw.pb[0] != outw.pb[0] || a.out.u != a.out.u;
-  const int max_steps = a.max_steps;
+  const int max_steps = a.n_sub ? a.sub[sj].max_steps : a.max_steps;
   bool all_done = false;
   for (int t = 0; t < max_steps; ++t) {
     SLIMT_STAMP(0);
@@ -2906,8 +2909,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           ar.aq_o = L.o.a_quant;
           ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
           float *al = a.n_sub ? a.sub[sj].align : a.align;
-          const bool want_align = al && (l + 1 == Ld) && !fin && (no < a.Tmax);
-          ar.align = want_align ? (gf_ptr)(al + ((size_t)(b - sj_first) * a.Tmax + no) * S) : (gf_ptr) nullptr;
+          const bool want_align = al && (l + 1 == Ld) && !fin && (no < Tmx);
+          ar.align = want_align ? (gf_ptr)(al + ((size_t)(b - sj_first) * Tmx + no) * Sal) : (gf_ptr) nullptr;
           if constexpr (KV24 && KVC == 4) {
             const lcf_ptr kc = (lcf_ptr)(kvpb + (4 * l) * D);
             if constexpr (!KV20) {
@@ -3414,8 +3417,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         if (live[rr]) tok = sl ? sl[ix] : (uint32_t)ix;
       }
       if (live[rr] && !finished[rr]) {  // record(), Model.cc:127-137
-        if (lane == 0 && (int)n_out[rr] < a.Tmax)
-          (a.n_sub ? a.sub[sj].out_ids : a.out_ids)[(size_t)(bq[rr] - sj_first) * a.Tmax + n_out[rr]] = tok;
+        if (lane == 0 && (int)n_out[rr] < Tmx)
+          (a.n_sub ? a.sub[sj].out_ids : a.out_ids)[(size_t)(bq[rr] - sj_first) * Tmx + n_out[rr]] = tok;
         n_out[rr] += 1;
         if (tok == a.eos) {
           finished[rr] = true;
@@ -3451,15 +3454,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll 1
     for (int rr = 0; rr < RT; ++rr) {
       if (!live[rr]) continue;
-      const size_t base = (size_t)(bq[rr] - sj_first) * a.Tmax * S;
-      const int rows_set = (int)n_out[rr] < a.Tmax ? (int)n_out[rr] : a.Tmax;
-      const int n = a.Tmax * S, ln = len[rr];
-      if (((base | (size_t)S) & 3) == 0 && (reinterpret_cast<size_t>(al_dst) & 15) == 0 &&
+      const size_t base = (size_t)(bq[rr] - sj_first) * Tmx * Sal;
+      const int rows_set = (int)n_out[rr] < Tmx ? (int)n_out[rr] : Tmx;
+      const int n = Tmx * Sal, ln = len[rr];
+      if (((base | (size_t)Sal) & 3) == 0 && (reinterpret_cast<size_t>(al_dst) & 15) == 0 &&
           (reinterpret_cast<size_t>(al_src) & 15) == 0) {  // 16-byte pieces: four columns of one row
         const f4 *src = reinterpret_cast<const f4 *>(al_src + base);
         f4 *dst = reinterpret_cast<f4 *>(al_dst + base);
         for (int i = lane; i < n / 4; i += 64) {
-          const int row = (4 * i) / S, col = (4 * i) % S;
+          const int row = (4 * i) / Sal, col = (4 * i) % Sal;
           f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
           if (row < rows_set && col < ln) {
             v = src[i];
@@ -3471,7 +3474,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         }
       } else {
         for (int i = lane; i < n; i += 64) {
-          const int row = i / S, col = i % S;
+          const int row = i / Sal, col = i % Sal;
           al_dst[base + i] = (row < rows_set && col < ln) ? al_src[base + i] : 0.0f;
         }
       }

@@ -407,11 +407,17 @@ __device__ __forceinline__ int sentence_length(const FusedEncodeArgs &a, int g, 
   const int j = merge_find(a.sub, a.n_sub, g), i = g - a.sub[j].first;
   return i < a.sub[j].n ? checked_length(a.sub[j].lengths[i], S) : 0;
 }
-// ... and its S token ids (a hole: nullptr -- the caller embeds token 0 at every position, which nobody reads)
-__device__ __forceinline__ const uint32_t *sentence_ids(const FusedEncodeArgs &a, int g, int S) {
-  if (a.n_sub == 0) return a.ids + (size_t)g * S;
+// ... and its token ids: n of them (a hole: none; a sub-batch padded to fewer tokens than the launch: its own S). The
+// caller embeds token 0 at the positions behind them -- padding, which nobody reads.
+struct SentenceIds {
+  const uint32_t *p;
+  int n;
+};
+__device__ __forceinline__ SentenceIds sentence_ids(const FusedEncodeArgs &a, int g, int S) {
+  if (a.n_sub == 0) return {a.ids + (size_t)g * S, S};
   const int j = merge_find(a.sub, a.n_sub, g), i = g - a.sub[j].first;
-  return i < a.sub[j].n ? a.sub[j].ids + (size_t)i * S : nullptr;
+  if (i >= a.sub[j].n) return {nullptr, 0};
+  return {a.sub[j].ids + (size_t)i * a.sub[j].S, a.sub[j].S};
 }
 // this workgroup's share (tiles first, first + step, ...) of the launch's packing jobs
 __device__ __forceinline__ void pack_weight_share(const FusedEncodeArgs &a, int first, int step, int tid, int nthreads) {

@@ -247,8 +247,8 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   for (int r = wave; r < ER; r += ENW) {
     const bool ok = row_valid(r);
     const int sb = row_sentence(r), pos = r % S;
-    const uint32_t *sids = ok ? sentence_ids(a, sb, S) : nullptr;
-      const uint32_t tok = sids ? embed_row(a.emb, sids[pos]) : 0;
+    const SentenceIds sids = ok ? sentence_ids(a, sb, S) : SentenceIds{nullptr, 0};
+      const uint32_t tok = pos < sids.n ? embed_row(a.emb, sids.p[pos]) : 0;
 #pragma unroll
     for (int i = 0; i < KSD; ++i) {
       float v = 0.0f;

@@ -2430,11 +2430,14 @@ bool merge_supported(const slimt_hip_ctx *c, size_t rows, size_t S) {
 
 // the sub-batches' tables. align_staging (nullable): the alignment rows are staged there (global sentence order) and
 // each batch's `align` (a device view of the caller's pinned array) is where they go when a sentence ends
-int build_merge_plan(const slimt_hip_ctx *c, const slimt_hip_batch *b, size_t n, size_t S, size_t Tmax, float *align_staging,
-                     MergePlan &mp, size_t &rows) {
+int build_merge_plan(const slimt_hip_ctx *c, const slimt_hip_batch *b, size_t n, size_t S, size_t Tmax, float limit_factor,
+                     int steps_hint, float *align_staging, MergePlan &mp, size_t &rows) {
   mp.n = (int)n;
   rows = 0;
   for (size_t j = 0; j < n; ++j) {
+    const size_t Sj = b[j].S ? b[j].S : S;
+    if (Sj > S) return fail(-1, "batch %zu is padded to %zu tokens, the launch to %zu", j, Sj, S);
+    const size_t Tj = std::max<size_t>(1, (size_t)(limit_factor * (float)Sj));  // Model.cc:159-161 on this batch's length
     if (!b[j].src_ids || !b[j].lengths || !b[j].out_ids || !b[j].out_len) return fail(-1, "batch %zu: null array", j);
     if (b[j].B == 0) return fail(-1, "batch %zu is empty", j);
     if (b[j].n_shortlist > (size_t)c->model->V) return fail(-1, "batch %zu: shortlist larger than the vocabulary", j);
@@ -2447,6 +2450,7 @@ int build_merge_plan(const slimt_hip_ctx *c, const slimt_hip_batch *b, size_t n,
     in.lengths = b[j].lengths;
     in.first = (int)rows;
     in.n = (int)b[j].B;
+    in.S = (int)Sj;
     o.lengths = b[j].lengths;
     o.out_ids = b[j].out_ids;
     o.out_len = b[j].out_len;
@@ -2462,6 +2466,9 @@ int build_merge_plan(const slimt_hip_ctx *c, const slimt_hip_batch *b, size_t n,
     o.n = (int)b[j].B;
     o.N = b[j].n_shortlist ? (int)b[j].n_shortlist : c->model->V;
     o.job = 0;
+    o.S = (int)Sj;
+    o.Tmax = (int)Tj;
+    o.max_steps = steps_hint > 0 ? std::min(steps_hint, (int)Tj) : (int)Tj;
     if (b[j].n_shortlist) {  // one packing job per distinct (pointer, size)
       int job = -1;
       for (int q = 0; q < mp.n_jobs; ++q)
@@ -2494,15 +2501,15 @@ extern "C" int slimt_hip_translate_many_device(slimt_hip_ctx *ctx, const slimt_h
   MergePlan mp;
   size_t rows = 0;
   const bool mergeable = n_batches > 1 && n_batches <= (size_t)kMaxMerge;
-  if (mergeable) RCCHK(build_merge_plan(ctx, batches, n_batches, S, Tmax, nullptr, mp, rows));
+  if (mergeable) RCCHK(build_merge_plan(ctx, batches, n_batches, S, Tmax, limit_factor, steps_hint, nullptr, mp, rows));
   if (mergeable && rows <= ctx->max_B && rows * S <= ctx->max_M && S <= ctx->max_S && merge_supported(ctx, rows, S))
     return translate_device(ctx, batches[0].src_ids, batches[0].lengths, batches[0].shortlist, rows, S, (size_t)mp.max_N,
                             limit_factor, eos_id, batches[0].out_ids, batches[0].out_len, batches[0].align, steps_hint, nullptr,
                             nullptr, 0, nullptr, &mp);
   for (size_t j = 0; j < n_batches; ++j) {  // batch by batch, in order, on the same stream
     const slimt_hip_batch &b = batches[j];
-    RCCHK(slimt_hip_translate_device(ctx, b.src_ids, b.lengths, b.B, S, b.shortlist, b.n_shortlist, limit_factor, eos_id,
-                                     b.out_ids, b.out_len, b.align, steps_hint));
+    RCCHK(slimt_hip_translate_device(ctx, b.src_ids, b.lengths, b.B, b.S ? b.S : S, b.shortlist, b.n_shortlist, limit_factor,
+                                     eos_id, b.out_ids, b.out_len, b.align, steps_hint));
   }
   return 0;
 }
@@ -2521,10 +2528,12 @@ extern "C" int slimt_hip_translate_many_async(slimt_hip_ctx *ctx, const slimt_hi
     const slimt_hip_batch &b = batches[j];
     if (!b.src_ids || !b.lengths || !b.out_ids || !b.out_len || b.B == 0) return fail(-1, "batch %zu: null array or empty", j);
     if (b.shortlist != batches[0].shortlist || b.n_shortlist != batches[0].n_shortlist) merged = false;  // one host shortlist
-    for (size_t i = 0; merged && i < b.B * S; ++i)
+    const size_t Sj = b.S ? b.S : S;
+    if (Sj > S) return fail(-1, "batch %zu is padded to %zu tokens, the launch to %zu", j, Sj, S);
+    for (size_t i = 0; merged && i < b.B * Sj; ++i)
       if (b.src_ids[i] >= (uint32_t)m->V) return fail(-1, "batch %zu: token id %u out of range", j, b.src_ids[i]);
     for (size_t i = 0; merged && i < b.B; ++i)
-      if (b.lengths[i] > S) return fail(-1, "batch %zu: length %u > S", j, b.lengths[i]);
+      if (b.lengths[i] > Sj) return fail(-1, "batch %zu: length %u > S", j, b.lengths[i]);
     dev[j] = b;
     dev[j].src_ids = static_cast<const uint32_t *>(host_device_view(b.src_ids));
     dev[j].lengths = static_cast<const uint32_t *>(host_device_view(b.lengths));
@@ -2539,8 +2548,8 @@ extern "C" int slimt_hip_translate_many_async(slimt_hip_ctx *ctx, const slimt_hi
   if (!merged) {
     for (size_t j = 0; j < n_batches; ++j) {
       const slimt_hip_batch &b = batches[j];
-      RCCHK(translate_host(ctx, b.src_ids, b.lengths, b.B, S, b.shortlist, b.n_shortlist, limit_factor, eos_id, b.out_ids,
-                           b.out_len, b.align, false));
+      RCCHK(translate_host(ctx, b.src_ids, b.lengths, b.B, b.S ? b.S : S, b.shortlist, b.n_shortlist, limit_factor, eos_id,
+                           b.out_ids, b.out_len, b.align, false));
     }
     return 0;
   }
@@ -2563,7 +2572,7 @@ extern "C" int slimt_hip_translate_many_async(slimt_hip_ctx *ctx, const slimt_hi
     dev[j].n_shortlist = n_sl;
   }
   MergePlan mp;
-  RCCHK(build_merge_plan(ctx, dev, n_batches, S, Tmax, any_align ? ctx->align.as<float>() : nullptr, mp, rows));
+  RCCHK(build_merge_plan(ctx, dev, n_batches, S, Tmax, limit_factor, 0, any_align ? ctx->align.as<float>() : nullptr, mp, rows));
   return translate_device(ctx, dev[0].src_ids, dev[0].lengths, dev[0].shortlist, rows, S, (size_t)mp.max_N, limit_factor, eos_id,
                           dev[0].out_ids, dev[0].out_len, any_align ? ctx->align.as<float>() : nullptr, (int)Tmax, nullptr,
                           any_align ? dev[0].align : nullptr, 0, nullptr, &mp);

@@ -273,11 +273,16 @@ hipError_t launch_dqattn(const DQAttnArgs &a, hipStream_t st);
 // The K/V cache, its form bytes and every other per-sentence workspace are indexed by the global sentence; only the
 // caller's arrays go through these tables, which travel in the kernel arguments (no copy, no helper launch).
 // A sentence's arithmetic never depends on its neighbours, so each sub-batch's results are those of its own call.
+// A sub-batch may be padded to FEWER tokens than the launch (S_j <= S): its arrays have rows of S_j, its decode loop the
+// limit and its alignment rows the width of ITS length (Model.cc:159-161,84-108: both follow the batch's padded length),
+// and the positions S_j .. S - 1 of its sentences are padding like any other -- masked keys whose weight is exactly 0
+// (Input.cc:49-63), query rows nobody reads.
 constexpr int kMaxMerge = 8;
 struct MergeIn {  // encoder side, one per sub-batch
-  const uint32_t *ids = nullptr;      // [n][S]
+  const uint32_t *ids = nullptr;      // [n][S]: rows of S (this sub-batch's own padded length) ids
   const uint32_t *lengths = nullptr;  // [n]
   int first = 0, n = 0;
+  int S = 0, pad = 0;
 };
 struct MergeOut {  // decoder side, one per sub-batch
   const uint32_t *lengths = nullptr;    // [n]
@@ -289,6 +294,10 @@ struct MergeOut {  // decoder side, one per sub-batch
   int first = 0, n = 0;
   int job = 0;    // which of the launch's packed output layers (sub-batches with one shortlist share one)
   int N = 0;      // its columns
+  int S = 0;          // this sub-batch's own padded length: the width of its alignment rows
+  int Tmax = 0;       // ... its row length of out_ids / align: max(1, (size_t)(limit_factor * S))
+  int max_steps = 0;  // ... and the decode steps its tiles run at most
+  int pad = 0;
 };
 struct MergePack {  // one packing job per DISTINCT shortlist of the launch; job j's buffers lie j strides behind job 0's
   const uint32_t *idx = nullptr;

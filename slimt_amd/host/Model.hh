@@ -152,6 +152,10 @@ class Worker {
   void forward_async_generated(slimt_hip_shortlist *generator, const uint32_t *ids, const uint32_t *lengths,
                                size_t B, size_t S, float limit_factor, uint32_t *out_ids, uint32_t *out_len,
                                float *align);
+  // Several batches of one padded length S in ONE launch pair (slimt_hip_translate_many_async): what `n` workers'
+  // concurrent forward calls are in the reference (Frontend.cc:207-227). Each batch keeps its own arrays, its own
+  // shortlist and its own results; the workspace must hold slimt_hip_translate_many_rows() sentences.
+  void forward_many_async(const slimt_hip_batch *batches, size_t n, size_t S, float limit_factor);
   void wait();
 
  private:

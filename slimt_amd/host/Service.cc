@@ -77,6 +77,22 @@ done:
   return batch;
 }
 
+size_t LengthQueue::peek_length() const {
+  if (waiting_ == 0) return 0;
+  size_t count = 0, last = 0;
+  for (size_t len = low_; len <= high_; ++len) {
+    const size_t have = fifos_[len].size();
+    if (have == 0) continue;
+    // (count + 1) * len <= max_words for every sentence added: at most max_words / len sentences in all
+    const size_t room = len ? max_words_ / len : have;
+    if (room <= count) break;
+    last = len;
+    if (count + have > room) break;
+    count += have;
+  }
+  return last;
+}
+
 // ---- Service -------------------------------------------------------------------
 
 namespace {
@@ -128,8 +144,15 @@ struct Service::Slot {
   Pinned<uint32_t> ids, lengths, out_ids, out_len, shortlist;
   Pinned<float> align;
   std::vector<Unit> batch;  // non-empty while a translate is in flight on this slot
-  size_t B = 0, S = 0, T = 0;
   uint64_t serial = 0;
+  // `batch` is the concatenation of the launch's batches (one, or several merged: ServiceConfig::merge_batches), each with
+  // its own padded length and its own arrays, one part behind the other in the slot's staging; part j's Hypothesis::batch
+  // is serial + j
+  struct Part {
+    size_t first = 0, B = 0, S = 0, T = 0;         // its sentences in `batch`, its padded length, its row length of tokens
+    size_t ids_at = 0, out_at = 0, align_at = 0;  // its arrays in ids / out_ids / align (lengths, out_len: at `first`)
+  };
+  std::vector<Part> parts;
 };
 
 Service::Service(const ServiceConfig &config, std::vector<const Model *> replicas)
@@ -207,6 +230,9 @@ Service::~Service() {
                  "launch %.3f, waiting for the GPU %.3f, collect %.3f, deliver %.3f\n",
                  n, threads_.size(), ms * ns_idle_ / n, ms * ns_launch_ / n, ms * ns_wait_ / n, ms * ns_collect_ / n,
                  ms * ns_deliver_ / n);
+    std::fprintf(stderr, "service-stats: merged launches: %llu of %llu launches, %.0f batches\n",
+                 static_cast<unsigned long long>(merged_launches_.load() - merged_base_),
+                 static_cast<unsigned long long>(launches_.load() - launches_base_), n);
   }
 }
 
@@ -255,16 +281,43 @@ std::future<Histories> Service::translate(std::vector<Words> sentences) {
 }
 
 // The next batch, or an empty one: nothing waits (may_block false) / the service closes.
-std::vector<Unit> Service::next_batch(bool may_block) {
+// parts (nullable): merge -- the batches behind the first are taken as well (see ServiceConfig::merge_batches) while the
+// launch stays within merge_words and no batch is padded by more than a quarter; their sizes, in order, when more than
+// one was taken. Each part keeps the padded length the reference's rule gave it: that of its own last sentence.
+std::vector<Unit> Service::next_batch(bool may_block, std::vector<size_t> *parts) {
   Lap lap;
   std::unique_lock<std::mutex> lock(mutex_);
   if (may_block) wake_.wait(lock, [this]() { return queue_.waiting() > 0 || closing_; });
   std::vector<Unit> batch = queue_.take();
+  if (parts) parts->clear();
+  if (parts && !batch.empty() && config_.merge_batches > 1) {
+    auto rows_of = [](size_t n) { return (n + 31) / 32 * 32; };  // slimt_hip_translate_many_rows
+    size_t lo = batch.back().length, hi = lo;  // shortest / longest padded length of the launch
+    size_t rows = rows_of(batch.size()), n = 1;
+    std::vector<size_t> sizes{batch.size()};
+    while (n < config_.merge_batches) {
+      const size_t S = queue_.peek_length();
+      if (S == 0) break;
+      const size_t lo2 = std::min(lo, S), hi2 = std::max(hi, S);
+      if (4 * hi2 > 5 * lo2) break;  // the shortest batch would run padded by more than a quarter (encoder rows nobody needs)
+      // (the next batch holds at most max_words / S sentences: does the launch still fit with all of them?)
+      if ((rows + rows_of(config_.max_words / S)) * hi2 > config_.merge_words) break;
+      std::vector<Unit> more = queue_.take();
+      if (more.empty()) break;
+      lo = std::min<size_t>(lo, more.back().length);
+      hi = std::max<size_t>(hi, more.back().length);
+      rows += rows_of(more.size());
+      sizes.push_back(more.size());
+      batch.insert(batch.end(), std::make_move_iterator(more.begin()), std::make_move_iterator(more.end()));
+      ++n;
+    }
+    if (n > 1) *parts = std::move(sizes);
+  }
   lap.to(ns_idle_);
   return batch;
 }
 
-void Service::launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *generator) {
+void Service::launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *generator, std::vector<size_t> &parts) {
   Lap lap;
   struct Done {
     Lap &lap;
@@ -274,25 +327,48 @@ void Service::launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *
   // the slot owns the batch from here on: whatever throws below, the caller fails slot.batch
   slot.batch = std::move(batch);
   batch.clear();
-  const size_t B = slot.batch.size();
-  const size_t S = slot.batch.back().length;  // lengths ascend inside a batch
-  const size_t T = std::max<size_t>(1, static_cast<size_t>(config_.tgt_length_limit_factor * static_cast<float>(S)));
-  slot.B = B;
-  slot.S = S;
-  slot.T = T;
-  slot.serial = batches_.fetch_add(1, std::memory_order_relaxed);
-  uint32_t *ids = slot.ids.ensure(B * S);
-  uint32_t *lengths = slot.lengths.ensure(B);
-  std::fill(ids, ids + B * S, config_.pad_id);
-  for (size_t b = 0; b < B; ++b) {
-    const Words &w = slot.batch[b].owner->sentence(slot.batch[b].index);
-    std::copy(w.begin(), w.end(), ids + b * S);
-    lengths[b] = static_cast<uint32_t>(w.size());
+  if (parts.empty()) parts.push_back(slot.batch.size());
+  // every part's arrays, one part behind the other in the slot's staging: [B][S] ids, [B] lengths, [B][T] tokens,
+  // [B][T][S] alignment rows with the part's OWN padded length S = that of its last sentence (lengths ascend inside a batch)
+  slot.parts.clear();
+  size_t first = 0, n_ids = 0, n_out = 0, n_align = 0, launch_S = 0;
+  for (size_t count : parts) {
+    Slot::Part p;
+    p.first = first;
+    p.B = count;
+    p.S = slot.batch[first + count - 1].length;
+    p.T = std::max<size_t>(1, static_cast<size_t>(config_.tgt_length_limit_factor * static_cast<float>(p.S)));
+    p.ids_at = n_ids;
+    p.out_at = n_out;
+    p.align_at = n_align;
+    n_ids += p.B * p.S;
+    n_out += p.B * p.T;
+    n_align += p.B * p.T * p.S;
+    n_align = (n_align + 3) / 4 * 4;  // 16-byte aligned blocks: the decoder writes a sentence's rows as whole quads
+    launch_S = std::max(launch_S, p.S);
+    first += count;
+    slot.parts.push_back(p);
   }
-  uint32_t *out_ids = slot.out_ids.ensure(B * T), *out_len = slot.out_len.ensure(B);
-  float *align = config_.alignments ? slot.align.ensure(B * T * S) : nullptr;
-  if (generator) {  // the batch's own lexical shortlist, generated on the worker's stream (Model.cc:117-120)
-    slot.worker->forward_async_generated(generator, ids, lengths, B, S, config_.tgt_length_limit_factor, out_ids,
+  parts.clear();
+  const size_t B = slot.batch.size();
+  slot.serial = batches_.fetch_add(slot.parts.size(), std::memory_order_relaxed);
+  launches_.fetch_add(1, std::memory_order_relaxed);
+  if (slot.parts.size() > 1) merged_launches_.fetch_add(1, std::memory_order_relaxed);
+  uint32_t *ids = slot.ids.ensure(n_ids);
+  uint32_t *lengths = slot.lengths.ensure(B);
+  std::fill(ids, ids + n_ids, config_.pad_id);
+  for (const Slot::Part &p : slot.parts)
+    for (size_t b = 0; b < p.B; ++b) {
+      const Unit &u = slot.batch[p.first + b];
+      const Words &w = u.owner->sentence(u.index);
+      std::copy(w.begin(), w.end(), ids + p.ids_at + b * p.S);
+      lengths[p.first + b] = static_cast<uint32_t>(w.size());
+    }
+  uint32_t *out_ids = slot.out_ids.ensure(n_out), *out_len = slot.out_len.ensure(B);
+  float *align = config_.alignments ? slot.align.ensure(n_align) : nullptr;
+  const Slot::Part &p0 = slot.parts[0];
+  if (generator) {  // the batch's own lexical shortlist, generated on the worker's stream (Model.cc:117-120); never merged
+    slot.worker->forward_async_generated(generator, ids, lengths, B, p0.S, config_.tgt_length_limit_factor, out_ids,
                                          out_len, align);
     return;
   }
@@ -302,7 +378,25 @@ void Service::launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *
     n_sl = config_.shortlist->size();
     sl = slot.shortlist.get();
   }
-  slot.worker->forward_async(ids, lengths, B, S, sl, n_sl, config_.tgt_length_limit_factor, out_ids, out_len, align);
+  if (slot.parts.size() > 1) {  // one launch pair for all parts, each with its own arrays
+    std::vector<slimt_hip_batch> calls(slot.parts.size());
+    for (size_t j = 0; j < slot.parts.size(); ++j) {
+      const Slot::Part &p = slot.parts[j];
+      slimt_hip_batch &c = calls[j];
+      c.src_ids = ids + p.ids_at;
+      c.lengths = lengths + p.first;
+      c.B = p.B;
+      c.S = p.S;
+      c.shortlist = sl;
+      c.n_shortlist = n_sl;
+      c.out_ids = out_ids + p.out_at;
+      c.out_len = out_len + p.first;
+      c.align = align ? align + p.align_at : nullptr;
+    }
+    slot.worker->forward_many_async(calls.data(), calls.size(), launch_S, config_.tgt_length_limit_factor);
+    return;
+  }
+  slot.worker->forward_async(ids, lengths, B, p0.S, sl, n_sl, config_.tgt_length_limit_factor, out_ids, out_len, align);
 }
 
 void Service::finish(Slot &slot) {
@@ -311,16 +405,23 @@ void Service::finish(Slot &slot) {
   Lap lap;
   slot.worker->wait();
   lap.to(ns_wait_);
-  Histories histories = collect(slot.out_ids.get(), slot.out_len.get(),
-                                config_.alignments ? slot.align.get() : nullptr, slot.lengths.get(), slot.B,
-                                slot.S, slot.T, /*flat=*/true);  // (cut into rows by the collecting thread: translate())
+  std::vector<Histories> histories;
+  histories.reserve(slot.parts.size());
+  for (const Slot::Part &p : slot.parts)  // (rows cut by the collecting thread: translate())
+    histories.push_back(collect(slot.out_ids.get() + p.out_at, slot.out_len.get() + p.first,
+                                config_.alignments ? slot.align.get() + p.align_at : nullptr, slot.lengths.get() + p.first, p.B,
+                                p.S, p.T, /*flat=*/true));
   lap.to(ns_collect_);
   std::vector<Unit> batch = std::move(slot.batch);
   slot.batch.clear();
-  for (size_t b = 0; b < batch.size(); ++b) {
-    histories[b]->batch = slot.serial;
-    batch[b].owner->deliver(batch[b].index, std::move(histories[b]));
+  for (size_t j = 0; j < slot.parts.size(); ++j) {
+    const Slot::Part &p = slot.parts[j];
+    for (size_t b = 0; b < p.B; ++b) {
+      histories[j][b]->batch = slot.serial + j;
+      batch[p.first + b].owner->deliver(batch[p.first + b].index, std::move(histories[j][b]));
+    }
   }
+  slot.parts.clear();
   lap.to(ns_deliver_);
 }
 
@@ -348,11 +449,14 @@ void Service::work(const Model *model, slimt_hip_shortlist *generator) {
   try {
     if (config_.fail_worker_setup) config_.fail_worker_setup(model);  // tests: a worker that cannot be built
     for (Slot &s : slots) {
-      // (B + 1) * S <= max_words: at most max_words - 1 rows, at most max_words padded tokens
-      s.worker = std::make_unique<Worker>(*model, config_.max_words, longest_, config_.max_words);
+      // (B + 1) * S <= max_words: at most max_words - 1 rows, at most max_words padded tokens; a merged launch: up to
+      // merge_words of its 32-aligned rows x length (next_batch)
+      const bool merging = config_.merge_batches > 1 && !generator && config_.merge_words > config_.max_words;
+      const size_t words = merging ? config_.merge_words : config_.max_words;
+      s.worker = std::make_unique<Worker>(*model, words, longest_, words);
       // every staging array at its largest, once: growing one later frees and allocates pinned
       // memory, and hipHostFree waits for the whole device (B S <= max_words, T <= factor S + 1)
-      const size_t rows = config_.max_words;
+      const size_t rows = words;
       const size_t out_tokens = static_cast<size_t>(config_.tgt_length_limit_factor * static_cast<float>(rows)) + rows + 1;
       s.ids.ensure(rows);
       s.lengths.ensure(rows);
@@ -371,7 +475,9 @@ void Service::work(const Model *model, slimt_hip_shortlist *generator) {
   for (;;) {
     Slot &mine = slots[cur], &other = slots[cur ^ 1];
     // with a batch in flight on the other slot, only take work that is already there
-    std::vector<Unit> batch = next_batch(other.batch.empty());
+    const bool merging = config_.merge_batches > 1 && !generator && config_.merge_words > config_.max_words;
+    std::vector<size_t> parts;
+    std::vector<Unit> batch = next_batch(other.batch.empty(), merging ? &parts : nullptr);
     if (batch.empty()) {
       if (other.batch.empty()) break;  // closing and drained
       try {
@@ -382,7 +488,7 @@ void Service::work(const Model *model, slimt_hip_shortlist *generator) {
       continue;
     }
     try {
-      launch(mine, batch, generator);
+      launch(mine, batch, generator, parts);
     } catch (...) {
       const std::exception_ptr error = std::current_exception();
       fail_batch(batch, error);

@@ -77,6 +77,8 @@ class LengthQueue {
   // ascending, arrival order within a length, stop at the first sentence that
   // would push (count + 1) * its length over the budget. Empty when nothing waits.
   std::vector<Unit> take();
+  // the padded length of the batch take() would return now (the length of its last sentence); 0 when nothing waits
+  size_t peek_length() const;
   size_t waiting() const { return waiting_; }
   size_t longest() const { return fifos_.size() - 1; }
 
@@ -95,6 +97,15 @@ struct ServiceConfig {
   size_t wrap_length = 128;  // longest sentence (slimt wraps there, Frontend.hh:27)
   float tgt_length_limit_factor = 1.5F;
   size_t workers_per_device = 10;  // x 2 contexts each: about 20 batches in flight per GPU
+  // Merged launches (slimt_hip_translate_many_async): a worker that has taken a batch keeps taking the batches that
+  // follow it in the queue -- each formed by the reference's rule under max_words, each with its own padded length,
+  // arrays and results -- up to merge_batches of them, while the launch's rows x its longest length stay within
+  // merge_words and no batch runs padded by more than a quarter; all of them run as ONE encoder and ONE decoder launch.
+  // The reference's default batch is 1024 padded words (Frontend.hh:21-39): 32 sentences of 32 tokens fill 2 of 256 CUs
+  // in the decoder; eight of them per launch pair fill what one batch of 8192 words does. 1 = never merge. (Not with a
+  // lexical shortlist: a batch's shortlist is generated inside ITS encoder launch.)
+  size_t merge_batches = 8;
+  size_t merge_words = 8192;
   uint32_t pad_id = 0;
   // one line on stderr when started with > 2 workers per device and < 8 hardware queues, or with more than
   // kContextsPerDeviceCliff contexts (2 per worker) on one device
@@ -131,14 +142,16 @@ class Service {
   // restart the SLIMT_SERVICE_STATS counters (benchmarks: after the warm-up pass)
   void stats_reset() {
     stats_base_ = batches_.load();
+    launches_base_ = launches_.load();
+    merged_base_ = merged_launches_.load();
     for (auto *c : {&ns_idle_, &ns_launch_, &ns_wait_, &ns_collect_, &ns_deliver_}) c->store(0);
   }
 
  private:
   struct Slot;
   void work(const Model *model, slimt_hip_shortlist *generator);
-  std::vector<Unit> next_batch(bool may_block);
-  void launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *generator);
+  std::vector<Unit> next_batch(bool may_block, std::vector<size_t> *parts = nullptr);
+  void launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *generator, std::vector<size_t> &parts);
   void finish(Slot &slot);
   void retire(const std::exception_ptr &error);
 
@@ -148,7 +161,8 @@ class Service {
   std::vector<std::unique_ptr<ShortlistGenerator>> generators_;  // one per device in use (lexical shortlist)
   uint64_t sequence_ = 0;
   std::atomic<uint64_t> batches_{0};  // batches launched so far (Hypothesis::batch)
-  uint64_t stats_base_ = 0;
+  std::atomic<uint64_t> launches_{0}, merged_launches_{0};  // launch pairs so far, and those that carried more than one batch
+  uint64_t stats_base_ = 0, launches_base_ = 0, merged_base_ = 0;
   // where the workers' time goes, in nanoseconds (printed by the destructor when SLIMT_SERVICE_STATS is set)
   std::atomic<uint64_t> ns_idle_{0}, ns_launch_{0}, ns_wait_{0}, ns_collect_{0}, ns_deliver_{0};
   bool closing_ = false;

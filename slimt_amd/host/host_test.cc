@@ -105,8 +105,15 @@ static int batching_main(int argc, char **argv) {
           queue.push(std::move(u));
         }
       }
-      for (std::vector<Unit> b = queue.take(); !b.empty(); b = queue.take()) {
+      // (peek_length -- what a worker asks before it merges the NEXT batch into its launch -- must name the padded length
+      // of exactly the batch take() then forms)
+      size_t peeked = queue.peek_length();
+      for (std::vector<Unit> b = queue.take(); !b.empty(); peeked = queue.peek_length(), b = queue.take()) {
         const uint32_t n = static_cast<uint32_t>(b.size()), ml = b.back().length;
+        if (peeked != ml) {
+          std::fprintf(stderr, "peek_length said %zu, take() formed a batch padded to %u\n", peeked, ml);
+          return 1;
+        }
         put(out, &n, 1);
         put(out, &ml, 1);
         for (const Unit &u : b) {
@@ -114,6 +121,10 @@ static int batching_main(int argc, char **argv) {
           put(out, &rid, 1);
           put(out, &idx, 1);
         }
+      }
+      if (peeked != 0) {
+        std::fprintf(stderr, "peek_length said %zu on an empty queue\n", peeked);
+        return 1;
       }
       return 0;
     }
@@ -133,6 +144,8 @@ static int batching_main(int argc, char **argv) {
       if (n_sl) sc.shortlist = c.vec<uint32_t>(n_sl);
     }
     if (const char *e = std::getenv("SLIMT_SERVICE_NO_ALIGN")) sc.alignments = e[0] != '1';
+    if (const char *e = std::getenv("SLIMT_SERVICE_MERGE")) sc.merge_batches = static_cast<size_t>(std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("SLIMT_SERVICE_MERGE_WORDS")) sc.merge_words = static_cast<size_t>(std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("SLIMT_SERVICE_FLAT_ALIGN")) sc.flat_alignments = e[0] == '1';
     // SLIMT_SERVICE_LEXICAL=<binary shortlist file>: every batch gets its own lexical shortlist,
     // generated on the device (ServiceConfig::lexical_shortlist); the vocabulary sizes are the model's

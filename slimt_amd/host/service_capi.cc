@@ -55,6 +55,8 @@ extern "C" int slimt_hip_service_create(const slimt_hip_service_config *config, 
     sc.tgt_length_limit_factor = config->limit_factor;
     sc.workers_per_device = config->workers_per_device;
     sc.pad_id = config->pad_id;
+    if (config->merge_batches) sc.merge_batches = config->merge_batches;
+    if (config->merge_words) sc.merge_words = config->merge_words;
     sc.alignments = config->alignments != 0;
     sc.flat_alignments = true;  // arrays out: one block per sentence
     if (config->lexical_shortlist && config->lexical_shortlist_bytes) {

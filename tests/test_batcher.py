@@ -206,6 +206,40 @@ def test_service_generates_a_lexical_shortlist_per_batch(hip, oracle, synth_mode
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("preset,workers,merge,n_sl,max_len", [("micro", 2, "8", 128, 20), ("micro", 3, "3", None, 20),
+                                                               ("tiny11", 2, "8", 1024, 12), ("micro", 2, "1", 128, 20)])
+def test_service_merges_batches_of_one_length_into_one_launch(hip, oracle, synth_models, preset, workers, merge, n_sl, max_len):
+    """ServiceConfig::merge_batches: a worker takes up to k consecutive batches of ONE padded length -- each formed by the
+    reference's rule under max_words (Batcher.cc:95-120), each with its own arrays, results and serial number -- into one
+    encoder + one decoder launch (slimt_hip_translate_many_async). Many sentences of few lengths, a small word budget: most
+    launches are merged ones (the Service says how many). Every rebuilt batch == the oracle on that batch, alignment
+    rows included; staggered EOS; the short last batch of a length travels with the others."""
+    m = synth_models(preset, 3.0 if preset == "micro" else 6.0)
+    r = np.random.Generator(np.random.PCG64(5 + workers))
+    reqs = []
+    for _ in range(10):  # ten requests of 40 sentences, lengths drawn from four values: long runs of one padded length
+        segs = []
+        for _ in range(40):
+            n = int(r.choice([3, max_len // 2, max_len - 1, max_len]))
+            segs.append(np.concatenate([r.integers(2, m.V, size=n - 1), [0]]).astype(np.uint32))
+        reqs.append(segs)
+    sl = None if n_sl is None else synth.make_shortlist(m.V, n_sl, frequent=16)
+    res, raw = _run_async(m, reqs, workers, max_words=6 * max_len, wrap=max_len + 4, sl=sl,
+                          env_extra={"SLIMT_SERVICE_MERGE": merge, "SLIMT_SERVICE_REPEAT": "1", "SLIMT_SERVICE_STATS": "1"})
+    rows = _parse_full(raw, reqs)
+    n_batches = _check_batches(oracle, oracle.OracleModel(m), rows, lambda ids, lens: sl)
+    assert n_batches >= 40  # 400 sentences, at most 5..11 per batch
+    import re
+    mm = re.findall(r"merged launches: (\d+) of (\d+) launches, (\d+) batches", res.stderr)
+    assert mm, res.stderr
+    merged, launches, batches = (int(x) for x in mm[-1])
+    if merge == "1":
+        assert merged == 0 and launches == batches
+    else:
+        assert merged >= 5 and batches > launches
+
+
+@pytest.mark.gpu
 def test_service_two_replicas_on_one_device(hip, oracle, synth_models):
     """Two Model replicas (both on device 0), three workers each: the replica / worker assignment of
     Service (slimt/Frontend.cc:207-227's workers, one set per GPU) runs before an 8-GPU node does."""

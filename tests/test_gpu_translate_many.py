@@ -39,8 +39,9 @@ def _dev(a):
 
 
 def _run_many_device(hip, gm, batches, S, sls, mode=0, enc_rows=0, want_align=True, max_rows=None):
-    """batches: [(ids, lens)], sls: per batch a shortlist array or None. Returns per batch (out, len, align)."""
-    T = max(int(np.float32(1.5) * np.float32(S)), 1)
+    """batches: [(ids, lens)] -- each padded to its own length <= S --, sls: per batch a shortlist array or None.
+    Returns per batch (out, len, align)."""
+    T_launch = max(int(np.float32(1.5) * np.float32(S)), 1)
     rows = hip.translate_many_rows([b[0].shape[0] for b in batches])
     ctx = hip.Context(gm, max_rows or rows, S)
     ctx.set_decode_mode(mode)
@@ -49,19 +50,20 @@ def _run_many_device(hip, gm, batches, S, sls, mode=0, enc_rows=0, want_align=Tr
     keep, args, outs = [], [], []
     sl_dev = {}
     for (ids, lens), sl in zip(batches, sls):
-        B = ids.shape[0]
+        B, Sj = ids.shape
+        T = max(int(np.float32(1.5) * np.float32(Sj)), 1)
         d_ids, d_len = _dev(ids), _dev(lens)
         if sl is not None and id(sl) not in sl_dev:
             sl_dev[id(sl)] = _dev(sl)
         d_sl = sl_dev.get(id(sl))
         d_out = torch.full((B, T), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
         d_ol = torch.full((B,), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
-        d_al = torch.full((B, T, S), 7.25, dtype=torch.float32, device="cuda") if want_align else None
+        d_al = torch.full((B, T, Sj), 7.25, dtype=torch.float32, device="cuda") if want_align else None
         keep.append((d_ids, d_len, d_sl))
         outs.append((d_out, d_ol, d_al))
         args.append((d_ids.data_ptr(), d_len.data_ptr(), B, d_sl.data_ptr() if d_sl is not None else 0,
-                     0 if sl is None else sl.size, d_out.data_ptr(), d_ol.data_ptr(), d_al.data_ptr() if want_align else 0))
-    ctx.translate_many_device(args, S, 1.5, 0, steps_hint=T)
+                     0 if sl is None else sl.size, d_out.data_ptr(), d_ol.data_ptr(), d_al.data_ptr() if want_align else 0, Sj))
+    ctx.translate_many_device(args, S, 1.5, 0, steps_hint=T_launch)
     ctx.synchronize()
     res = [(o.cpu().numpy().view(np.uint32), l.cpu().numpy().view(np.uint32), None if a is None else a.cpu().numpy())
            for o, l, a in outs]
@@ -109,6 +111,31 @@ def test_merged_batches_equal_their_own_calls_and_the_oracle(hip, oracle, engine
     ctx.close()
 
 
+@pytest.mark.parametrize("preset,S,shapes,n_sl,mode", [
+    ("tiny11", 32, [(40, 32), (33, 27), (64, 26), (9, 32)], 1024, 0),   # padded to fewer tokens than the launch
+    ("tiny11", 24, [(20, 19), (50, 24), (31, 22)], 1024, 2),
+    ("tiny11", 16, [(64, 13), (64, 16)], 0, 0),
+    ("tiny11", 48, [(5, 40), (7, 48), (4, 35)], 512, 0),               # 33..64 tokens
+    ("base", 32, [(19, 32), (12, 25)], 512, 0),
+])
+def test_merged_batches_with_their_own_padded_lengths(hip, oracle, engines, preset, S, shapes, n_sl, mode):
+    """A batch padded to fewer tokens than the launch keeps the step limit and the alignment width of ITS length
+    (Model.cc:159-161, 84-108): outputs == the oracle on that batch at its own padded length, and == its own call."""
+    from slimt_amd import synth
+    m, gm, om = engines(preset, 6.0)
+    sl = synth.make_shortlist(m.V, n_sl) if n_sl else None
+    batches = [synth.make_batch(m.V, B, Sj, seed=400 + 13 * j + B, ragged=True) for j, (B, Sj) in enumerate(shapes)]
+    sls = [sl] * len(shapes)
+    res = _run_many_device(hip, gm, batches, S, sls, mode)
+    _check(oracle, om, batches, sls, res)
+    ctx = hip.Context(gm, max(b for b, _ in shapes), S)
+    ctx.set_decode_mode(mode)
+    for (ids, lens), (out, ln, al) in zip(batches, res):
+        o1, l1, a1 = ctx.translate(ids, lens, sl, want_align=True)
+        assert np.array_equal(o1, out) and np.array_equal(l1, ln) and np.array_equal(a1, al)
+    ctx.close()
+
+
 def test_merged_batches_with_their_own_shortlists(hip, oracle, engines):
     """Model.cc:117-120: a batch's shortlist is ITS shortlist -- three batches, three lists of different sizes (two batches
     share one: one packed output layer for both)."""
@@ -142,22 +169,23 @@ def test_merged_launch_falls_back_batch_by_batch(hip, oracle, engines):
 
 
 @pytest.mark.parametrize("preset,S,sizes,n_sl", [("tiny11", 32, [64, 40, 64], 2048), ("tiny11", 13, [7, 33], None),
-                                                   ("base", 32, [19, 19], 1024)])
+                                                   ("base", 32, [19, 19], 1024), ("tiny11", 30, [(20, 26), (33, 30), (8, 25)], 1024)])
 def test_merged_pinned_async(hip, oracle, engines, preset, S, sizes, n_sl):
     """slimt_hip_translate_many_async: pinned host arrays per batch, read and written in place by the two launches;
     alignment rows staged in device memory and copied out per sentence (Model.cc:84-108)."""
     from slimt_amd import synth
     m, gm, om = engines(preset, 6.0)
     sl = None if n_sl is None else synth.make_shortlist(m.V, n_sl)
-    T = max(int(np.float32(1.5) * np.float32(S)), 1)
-    batches = [synth.make_batch(m.V, B, S, seed=300 + 11 * j + B, ragged=True) for j, B in enumerate(sizes)]
-    ctx = hip.Context(gm, hip.translate_many_rows(sizes), S)
+    sizes = [x if isinstance(x, tuple) else (x, S) for x in sizes]  # (B, this batch's own padded length)
+    batches = [synth.make_batch(m.V, B, Sj, seed=300 + 11 * j + B, ragged=True) for j, (B, Sj) in enumerate(sizes)]
+    ctx = hip.Context(gm, hip.translate_many_rows([b for b, _ in sizes]), S)
     pins, bufs = [], []
     for ids, lens in batches:
-        B = ids.shape[0]
+        B, Sj = ids.shape
+        T = max(int(np.float32(1.5) * np.float32(Sj)), 1)
         ps = [hip._Pinned() for _ in range(5)]
-        b = (ps[0].array(np.uint32, (B, S)), ps[1].array(np.uint32, (B,)), ps[2].array(np.uint32, (B, T)),
-             ps[3].array(np.uint32, (B,)), ps[4].array(np.float32, (B, T, S)))
+        b = (ps[0].array(np.uint32, (B, Sj)), ps[1].array(np.uint32, (B,)), ps[2].array(np.uint32, (B, T)),
+             ps[3].array(np.uint32, (B,)), ps[4].array(np.float32, (B, T, Sj)))
         b[0][...] = ids
         b[1][...] = lens
         pins.append(ps)

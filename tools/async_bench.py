@@ -14,7 +14,9 @@ lexical = len(sys.argv) > 3 and sys.argv[3] == "lex"
 n_sl = 0 if lexical or len(sys.argv) <= 3 else int(sys.argv[3])
 align = (sys.argv[4] if len(sys.argv) > 4 else "1") in ("1", "flat")
 flat = len(sys.argv) > 4 and sys.argv[4] == "flat"  # one [T][len] block per sentence instead of T small vectors
-max_words = 8192 + 32  # 256 sentences of 32 tokens: (B + 1) * S <= max_words
+# 256 sentences of 32 tokens: (B + 1) * S <= max_words; SLIMT_SERVICE_MAX_WORDS=1024 = the reference's default (Frontend.hh:21-39),
+# with SLIMT_SERVICE_MERGE=k (default 8; 1 = off) consecutive batches of one padded length per launch pair (ServiceConfig::merge_batches)
+max_words = int(os.environ.get("SLIMT_SERVICE_MAX_WORDS", str(8192 + 32)))
 m = synth.make_model("tiny11", eos_bias=-100.0)  # nobody emits EOS: floor(1.5 * S) tokens per sentence
 r = np.random.Generator(np.random.PCG64(5))
 exe = B.build_host()
@@ -49,15 +51,16 @@ with tempfile.TemporaryDirectory() as d:
     res = subprocess.run([exe, "--async", mb, cb, ob], capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, res.stderr
     stats = re.search(r"service-stats: (.*)", res.stderr)
+    merged = re.findall(r"service-stats: merged launches: (.*)", res.stderr)
     host_timing = re.findall(r"host-timing: (.*)", res.stderr)
     ms_cold = float(re.search(r"async: .* translated in ([0-9.]+) ms", res.stderr).group(1))
     ms = float(re.search(r"async-warm: .* translated in ([0-9.]+) ms", res.stderr).group(1))
     toks = int(re.search(r"async-warm-tokens: (\d+)", res.stderr).group(1))  # the warm, timed pass: clients x rounds
 print(json.dumps({"workload": f"Service, tiny11 {'lexical shortlist generated per batch on the device' if lexical else 'shortlist ' + str(n_sl) if n_sl else 'full vocabulary'}, {n_sent} ragged "
-                              f"sentences ({lo}..{hi} tokens), max_words={max_words}, workers={workers} x 2 contexts, "
+                              f"sentences ({lo}..{hi} tokens), max_words={max_words}, merge={os.environ.get('SLIMT_SERVICE_MERGE', '8 (default)')}, workers={workers} x 2 contexts, "
                               f"pinned host buffers{' + alignments' if align else ''}{' (one block per sentence)' if flat else ''}",
                   "target_tokens_per_s": toks / ms * 1e3,
                   "ms": ms, "ms_first_pass_with_worker_startup": ms_cold, "target_tokens": toks,
-                  "service_stats": stats.group(1) if stats else None,
+                  "service_stats": stats.group(1) if stats else None, "merged_launches": merged[-1] if merged else None,
                   "host_timing": host_timing[-1] if host_timing else None,
                   "client": (re.findall(r"client 0: (.*)", res.stderr) or [None])[-1]}))
