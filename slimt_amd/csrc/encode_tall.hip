@@ -24,6 +24,8 @@
 // Arithmetic is bit-identical to encode_fused.hip, the layer-by-layer kernels and the oracle's
 // portable order. Reference: Model.cc:195-201, Transformer.cc:57-69, Modules.cc:287-334,
 // TensorOps.cc:542-580.
+#include <cstdlib>
+
 #include "device_common.h"
 #include "shortlist_device.h"
 #include "kernels.h"
@@ -167,8 +169,11 @@ __device__ __forceinline__ v3i tpack24(v4i x) {
 // NKT = key tiles of 16 per sentence: 2 (S <= 32, floor(64 / S) sentences per workgroup) or 4
 // (33 <= S <= 64: one sentence per workgroup -- what encode_long16_kernel does through global
 // scratch tensors stays in LDS here).
-template <int KSF, int NKT = 2>
+// NRT = row tiles of 16 the workgroup's sentences occupy: 4, or 3 when they end within 48 rows (two sentences of 22..24
+// tokens, one of 33..48) -- the fourth tile's MFMAs, epilogues, LayerNorm rows and quantisations would be padding only.
+template <int KSF, int NKT = 2, int NRT = TRT>
 __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
+  static_assert(NRT == TRT || NRT == TRT - 1, "all four row tiles, or the first three");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KSD = 4, D = 256, DH = 32, F = 64 * KSF;
   constexpr int HR = 4;        // heads per round
@@ -214,6 +219,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   }
   const int s0 = tile * spw;  // first sentence
   const int rows_used = spw * S;
+  // this wave owns rows 4 wave .. 4 wave + 3 in the row-wise phases (embedding, LayerNorm, quantisation): with NRT = 3 the
+  // last four waves' rows are beyond every sentence, and what they would read there (the fourth row tile of the exchange
+  // tile) is never written
+  const bool owner = NRT == TRT || wave < 4 * NRT;
   if (tid == 0) occ_trace_event(a.trace, 2, 0);
   // this workgroup's sentence lengths: read once (they may live in pinned host memory, and every
   // attention job needs its sentence's; ordered by the first barrier below)
@@ -369,11 +378,11 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KSD; ++ks) A[ks] = *(lds_v4i)(o.p[ks]);
 #pragma unroll
-    for (int rt = 0; rt < TRT; ++rt) {
+    for (int rt = 0; rt < NRT; ++rt) {
       v4i c = init;
 #pragma unroll
       for (int ks = 0; ks < KSD; ++ks) c = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], A[ks], c, 0, 0, 0);
-      if (rt + 1 < TRT) {
+      if (rt + 1 < NRT) {
 #pragma unroll
         for (int ks = 0; ks < KSD; ++ks) A[ks] = *(lds_v4i)(o.p[ks] + 16 * (rt + 1) * LDA);
       }
@@ -434,9 +443,11 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         SLIMT_WSTAMP(1);
         if (hr == 0) {  // x quantised with the three projections' multipliers, once per layer
           const lds_bptr qb0 = tq_base(lane);
-          quantise_x(0, L.q.a_quant, qb0);
-          quantise_x(TR * LDA, L.k.a_quant, qb0);
-          quantise_x(2 * TR * LDA, L.v.a_quant, qb0);
+          if (owner) {
+            quantise_x(0, L.q.a_quant, qb0);
+            quantise_x(TR * LDA, L.k.a_quant, qb0);
+            quantise_x(2 * TR * LDA, L.v.a_quant, qb0);
+          }
           SLIMT_WSTAMP(1);
           lds_barrier();
         }
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       SLIMT_TSTAMP(4);
       const v4i so = tshift(eo);
 #pragma unroll
-      for (int rt = 0; rt < TRT; ++rt) {
+      for (int rt = 0; rt < NRT; ++rt) {
         v4i c = so;
 #pragma unroll
         for (int ks = 0; ks < KSD; ++ks) {  // k-steps 0, 1: round 0's heads; 2, 3: round 1's
@@ -649,13 +660,15 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       lds_barrier();
       SLIMT_TSTAMP(5);
       // x = LN(x + O(...)); quantised for FFN1
+      if (owner) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
+        for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
-        for (int i = 0; i < KSD; ++i) x[rr][i] = x[rr][i] + Yb[(4 * wave + rr) * LDY + lane + 64 * i];
-        tln_regs(x[rr], lsc, lbi, a.eps);
+          for (int i = 0; i < KSD; ++i) x[rr][i] = x[rr][i] + Yb[(4 * wave + rr) * LDY + lane + 64 * i];
+          tln_regs(x[rr], lsc, lbi, a.eps);
+        }
+        quantise_x(0, L.ffn1.a_quant, tq_base(lane));
       }
-      quantise_x(0, L.ffn1.a_quant, tq_base(lane));
 #pragma unroll
       for (int i = 0; i < EPT; ++i)
         if (tid + 1024 * i < F) {
@@ -698,14 +711,14 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         e.pb = __builtin_bit_cast(float4, *(lds_v4i)((lds_cptr)(epb + t * 16 + lg * 4)));
         const v4i sh = tshift(e);
 #pragma unroll
-        for (int rt = 0; rt < TRT; ++rt) {
+        for (int rt = 0; rt < NRT; ++rt) {
           v4i c = sh;
 #pragma unroll
           for (int ks = 0; ks < KSD; ++ks) c = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[buf][ks], A[ks], c, 0, 0, 0);
           // the next row tile's fragments (the next column tile starts over at row tile 0)
-          if (rt + 1 < TRT || i + 1 < NT1) {
+          if (rt + 1 < NRT || i + 1 < NT1) {
 #pragma unroll
-            for (int ks = 0; ks < KSD; ++ks) A[ks] = *(lds_v4i)(af.p[ks] + 16 * ((rt + 1) % TRT) * LDA);
+            for (int ks = 0; ks < KSD; ++ks) A[ks] = *(lds_v4i)(af.p[ks] + 16 * ((rt + 1) % NRT) * LDA);
           }
           __builtin_amdgcn_sched_barrier(0);
           *reinterpret_cast<int *>(Hb + (16 * rt + lr) * LDH + t * 16 + lg * 4) = trelu_quant4(c, e, L.ffn1.u, L.ffn2.a_quant);
@@ -726,11 +739,11 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
     {  // FFN2: this wave's column tile over K = F, chunks of 4 k-steps, three in flight
       SLIMT_TPHASE_LANE;
       const TEpi e2 = tload_epi(L.ffn2, wave, lg);  // its shift starts the accumulators
-      v4i f[TRT];
+      v4i f[NRT];
       {
         const v4i s2 = tshift(e2);
 #pragma unroll
-        for (int rt = 0; rt < TRT; ++rt) f[rt] = s2;
+        for (int rt = 0; rt < NRT; ++rt) f[rt] = s2;
       }
       // A k-step's four hidden-layer fragments (one per row tile) are requested together, the next k-step's right behind this
       // one's four MFMAs (independent accumulators: they issue back to back). The plain loop compiled to read -> wait -> MFMA
@@ -738,19 +751,19 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       typedef const __attribute__((address_space(3))) v4i *lds_v4i;
       typedef const __attribute__((address_space(3))) char *lds_c;
       const lds_c hrow = (lds_c)(Hb + lr * LDH + lg * 16);
-      v4i H[TRT];
+      v4i H[NRT];
 #pragma unroll
-      for (int rt = 0; rt < TRT; ++rt) H[rt] = *(lds_v4i)(hrow + 16 * rt * LDH);
+      for (int rt = 0; rt < NRT; ++rt) H[rt] = *(lds_v4i)(hrow + 16 * rt * LDH);
 #pragma unroll
       for (int c = 0; c < NC2; ++c) {
         const int buf = c % 3;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-          for (int rt = 0; rt < TRT; ++rt) f[rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[buf][ks], H[rt], f[rt], 0, 0, 0);
+          for (int rt = 0; rt < NRT; ++rt) f[rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2[buf][ks], H[rt], f[rt], 0, 0, 0);
           if (c * 4 + ks + 1 < KSF) {
 #pragma unroll
-            for (int rt = 0; rt < TRT; ++rt) H[rt] = *(lds_v4i)(hrow + 16 * rt * LDH + (c * 4 + ks + 1) * 64);
+            for (int rt = 0; rt < NRT; ++rt) H[rt] = *(lds_v4i)(hrow + 16 * rt * LDH + (c * 4 + ks + 1) * 64);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -764,7 +777,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       lds_barrier();  // every wave has read the hidden layer: the region becomes the exchange tile
       SLIMT_TSTAMP(8);
 #pragma unroll
-      for (int rt = 0; rt < TRT; ++rt)
+      for (int rt = 0; rt < NRT; ++rt)
         *reinterpret_cast<float4 *>(Yb + (16 * rt + lr) * LDY + wave * 16 + lg * 4) = tdequant4(f[rt], e2, L.ffn2.u);
     }
     {  // x = LN(FFN2(...) + x)
@@ -775,6 +788,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
       SLIMT_TSTAMP(9);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
+        if (!owner) break;
         const int r = 4 * wave + rr;
 #pragma unroll
         for (int i = 0; i < KSD; ++i) x[rr][i] = Yb[r * LDY + lane + 64 * i] + x[rr][i];
@@ -828,7 +842,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         // (packed cache: no barrier here -- every wave's reads of the A buffer lie in front of the barrier between the products and
         // the packing loop of the projection before, or of FFN1's; the staging tile is not written until the barrier below)
         if (!a.kv24) lds_barrier();  // the A buffer and the region are free
-        quantise_x(0, w.a_quant, tq_base(lane));
+        if (owner) quantise_x(0, w.a_quant, tq_base(lane));
         // (the flag is raised behind the barrier below only)
         if (!wide && p == 0) {
           kvf ^= 1;
@@ -842,7 +856,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         unsigned outside = 0;  // an accumulator of a valid row outside the form's range
         const unsigned lim = (unsigned)a.kv_narrow_limit, lim16 = (unsigned)a.kv_tight_limit;
 #pragma unroll
-        for (int rt = 0; rt < TRT; ++rt) {
+        for (int rt = 0; rt < NRT; ++rt) {
           const v4i c = mma_rt(wf, rt, af, skv);
           const int rrow = 16 * rt + lr;
           if (a.kv24) {
@@ -1073,9 +1087,13 @@ hipError_t launch_encode_tall(const FusedEncodeArgs &a, int F, hipStream_t st) {
   const dim3 grid(tall_encode_grid(a.B, a.S, a.ticket != nullptr));
   const size_t lds = tall_encode_lds_bytes(F);
   hipError_t e = hipSuccess;
+  static const bool no_row_tile_skip = std::getenv("SLIMT_ENC_ROW_TILES") && std::getenv("SLIMT_ENC_ROW_TILES")[0] == '4';  // A/B
 #define SLIMT_TALL_CASE(KSF_)                                                                  \
   if (F == 64 * KSF_) {                                                                        \
-    auto k = a.S > 32 ? encode_tall_kernel<KSF_, 4> : encode_tall_kernel<KSF_, 2>;             \
+    /* three row tiles where the workgroup's sentences end within 48 rows (S = 22..24, 33..48) */ \
+    const bool three = (64 / a.S) * a.S <= 48 && !no_row_tile_skip;                             \
+    auto k = a.S > 32 ? (three ? encode_tall_kernel<KSF_, 4, 3> : encode_tall_kernel<KSF_, 4>)  \
+                      : (three ? encode_tall_kernel<KSF_, 2, 3> : encode_tall_kernel<KSF_, 2>); \
     e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds);             \
     if (e != hipSuccess) return e;                                                             \
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);                                       \
