@@ -65,6 +65,10 @@ def parse(argv=None):
     ap.add_argument("--workers", type=int, default=20,
                     help="translate contexts (HIP streams) per GPU, like slimt::Async workers "
                          "(Frontend.cc:212-226): independent batches in flight on one device")
+    ap.add_argument("--rounds", type=int, default=4,
+                    help="translate calls per worker and step (weak scaling): a step is `rounds` passes of the hot path over "
+                         "one batch on every worker, so that the driver's 20 timed steps are >= 0.5 s of GPU time (one pass "
+                         "is 6.6 ms; VERDICT r05: a 0.13 s timed region is the size of the box-to-box noise)")
     ap.add_argument("--merge", type=int, default=1,
                     help="batches of --batch sentences per translate call (slimt_hip_translate_many_device: ONE encoder and ONE "
                          "decoder launch for all of them, each batch with its own arrays); 1 = slimt_hip_translate_device")
@@ -321,6 +325,7 @@ def main():
     T = int(np.float32(1.5) * np.float32(S))
     W = max(1, args.workers)
     MG = max(1, min(8, args.merge))  # batches per translate call
+    RD = 1 if args.total_sentences > 0 else max(1, args.rounds)  # translate calls per worker and step
     n_sl = args.shortlist
     D, F, H, Le, Ld, V = synth.PRESETS[args.preset]
     N_out = n_sl if n_sl else V
@@ -329,8 +334,8 @@ def main():
         my_batches = plan_shards(args.total_sentences, B, world)[rank]  # [(start, count)]
         batches_per_step = len(my_batches)
     else:
-        my_batches = [(0, B)] * (W * MG)
-        batches_per_step = W * MG
+        my_batches = [(0, B)] * (W * MG * RD)
+        batches_per_step = W * MG * RD
 
     if dry:
         def step(i):
@@ -404,10 +409,12 @@ def main():
                 ctxs[w].translate_many_device(call, S, 1.5, 0, steps_hint=T)
 
         def step(i):
-            # one batch on every worker (weak) / every batch of this rank's shard, dealt to
+            # `rounds` x one batch on every worker (weak) / every batch of this rank's shard, dealt to
             # the workers round-robin (strong); the calls are asynchronous (fixed step count)
             if MG > 1 and not strong:
-                return step_merged(i)
+                for r in range(RD):
+                    step_merged(i * RD + r)
+                return
             for j in range(batches_per_step):
                 w = j % W
                 d_ids, d_lens, nb = batches[j] if strong else batches[(i * W + j) % len(batches)]
@@ -470,6 +477,7 @@ def main():
         who.update({"device": None, "pci_bus_id": None, "numa_node": None} if dry else device_identity(local_rank))
         print("bench-rank " + json.dumps(who), file=sys.stderr, flush=True)
 
+    tokens_per_pass_all = total_tokens_per_step // RD  # one translate call on every worker of every GPU (the forward regions' step)
     sustained = None
     if args.sustained_steps > 0 and not dry:
         barrier()
@@ -510,11 +518,11 @@ def main():
         for _ in range(K):
             fstep()
         barrier()
-        d, _ = reduce_timing(dist, cpu, time.perf_counter() - t, tokens_per_step)
+        d, _ = reduce_timing(dist, cpu, time.perf_counter() - t, tokens_per_step // RD)
         got = int(sum(int(b[3].sum()) for g in fb for b in g))
         if got != W * MG * B * T:
             raise SystemExit(f"bench: merged model_forward produced {got} tokens, expected {W * MG * B * T}")
-        forward = {"model_forward": {"value": total_tokens_per_step * K / d, "ms_per_step": 1e3 * d / K, "steps": K, "alignments": True,
+        forward = {"model_forward": {"value": tokens_per_pass_all * K / d, "ms_per_step": 1e3 * d / K, "steps": K, "alignments": True,
                                      "io": f"{MG} pinned batches per call (slimt_hip_translate_many_async): ids + lengths read from, "
                                            "tokens + lengths + alignment rows written to pinned host memory by the two launches"}}
         for ps in pins:
@@ -548,11 +556,11 @@ def main():
             for _ in range(K):
                 fstep()
             barrier()
-            d, _ = reduce_timing(dist, cpu, time.perf_counter() - t, tokens_per_step)
+            d, _ = reduce_timing(dist, cpu, time.perf_counter() - t, tokens_per_step // RD)
             got = int(sum(int(fb[w][3].sum()) for w in range(W)))
             if got != W * B * T:
                 raise SystemExit(f"bench: model_forward produced {got} tokens, expected {W * B * T}")
-            return {"value": total_tokens_per_step * K / d, "ms_per_step": 1e3 * d / K, "steps": K}
+            return {"value": tokens_per_pass_all * K / d, "ms_per_step": 1e3 * d / K, "steps": K}
 
         io = ("ids + lengths read from pinned host memory, tokens + lengths + alignment rows [B,T,S] written to "
               "pinned host memory by the persistent kernels (no copy queued)")
@@ -703,11 +711,11 @@ def main():
                              f"{'shortlist ' + str(n_sl) if n_sl else 'full 32k vocabulary'}; "
                              + (f"one step = the same {args.total_sentences} sentences cut into batches of {B} "
                                 f"and dealt to {world} GPU(s)" if strong else
-                                f"one step = one translate call on each of the {W} workers of every GPU "
-                                f"({W * MG * B} sentences per GPU and step)")),
+                                f"one step = {RD} translate call(s) on each of the {W} workers of every GPU "
+                                f"({W * MG * RD * B} sentences per GPU and step)")),
                 "preset": args.preset, "batch": B, "merged_batches_per_call": MG, "src_len": S, "decode_steps": T,
                 "shortlist": n_sl, "parallelism": f"dp{world} (replicated weights, no collective, no RCCL)",
-                "workers_per_gpu": W, "batches_per_step_per_gpu": batches_per_step,
+                "workers_per_gpu": W, "rounds_per_step": RD, "batches_per_step_per_gpu": batches_per_step,
                 "sentences_per_step_all_gpus": sentences_per_step,
                 "decode": "fused-persistent" if dec_fused else "step-wise",
                 "encode": "fused-persistent" if enc_fused else "layer-by-layer",
