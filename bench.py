@@ -65,6 +65,14 @@ def parse(argv=None):
     ap.add_argument("--workers", type=int, default=20,
                     help="translate contexts (HIP streams) per GPU, like slimt::Async workers "
                          "(Frontend.cc:212-226): independent batches in flight on one device")
+    ap.add_argument("--family", default="default",
+                    help="synthetic model family (slimt_amd.synth.FAMILIES): weight spread / tails, activation multiplier range, "
+                         "LayerNorm scale spread -- what the K/V cache forms' hit rates depend on")
+    ap.add_argument("--eos-bias", type=float, default=-100.0,
+                    help="added to the EOS logit's bias: -100 (default) = nobody emits EOS, every sentence runs T steps (the "
+                         "headline); about 6 = sentences end at different steps (Model.cc:127-137 counts what they emit: "
+                         "the line's tokens are then the recorded ones, and `decoder_tile_live_fraction` says how full a "
+                         "16-sentence decoder tile is on average while it runs)")
     ap.add_argument("--rounds", type=int, default=4,
                     help="translate calls per worker and step (weak scaling): a step is `rounds` passes of the hot path over "
                          "one batch on every worker, so that the driver's 20 timed steps are >= 0.5 s of GPU time (one pass "
@@ -355,7 +363,7 @@ def main():
         if not torch.cuda.is_available() or capi.device_count() <= 0:
             raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
         torch.cuda.set_device(local_rank)
-        model = synth.make_model(args.preset, seed=1234, eos_bias=-100.0)  # nobody emits EOS
+        model = synth.make_model(args.preset, seed=1234, eos_bias=args.eos_bias, family=args.family)  # -100: nobody emits EOS
         sl = synth.make_shortlist(model.V, n_sl) if n_sl else None
         gm = capi.Model(model, device=local_rank)
         if args.decoder_budget >= 0:
@@ -429,7 +437,29 @@ def main():
             step(i)
         sync()
         tokens_per_step = sum(c for _, c in my_batches) * T  # nobody emits EOS: T tokens per sentence
-        if not strong:
+        live_fraction = None
+        if args.eos_bias > -50.0:
+            # sentences end when they emit EOS (Model.cc:127-137): count what every distinct batch records, once, and
+            # how full the decoder's 16-sentence tiles run (a tile lives until its longest sentence ends)
+            per_batch, live_num, live_den = [], 0, 0
+            for d_ids, d_lens, nb in batches:
+                ctxs[0].translate_device(d_ids.data_ptr(), d_lens.data_ptr(), nb, S, d_sl.data_ptr() if d_sl is not None else 0,
+                                         n_sl, 1.5, 0, d_outs[0].data_ptr(), d_lens_out[0].data_ptr(), 0, steps_hint=T)
+                sync()
+                ol = d_lens_out[0][:nb].cpu().numpy().astype(np.int64)
+                per_batch.append(int(ol.sum()))
+                for t0 in range(0, nb, 16):
+                    tile = ol[t0:t0 + 16]
+                    live_num += int(tile.sum())
+                    live_den += 16 * int(tile.max())
+            live_fraction = live_num / max(1, live_den)
+            if strong:
+                tokens_per_step = sum(per_batch)
+            else:  # the step cycles through the distinct batches evenly (W * rounds * merge calls over len(batches) batches)
+                calls = batches_per_step
+                tokens_per_step = sum(per_batch[(0 * W + j) % len(batches)] for j in range(calls)) if MG == 1 else \
+                    sum(per_batch[q % len(batches)] for q in range(calls))
+        elif not strong:
             check = int(d_lens_out[0].sum().item())
             if check != B * T:
                 raise SystemExit(f"bench: expected {B * T} tokens from one batch, got {check}")
@@ -455,12 +485,18 @@ def main():
         step(i)
     barrier()
     dt = time.perf_counter() - t0
-    kv_forms = None
+    kv_forms = kv_watch = None
     if not dry:
         # which form the last batch's K/V caches took, per sentence and decoder layer (slimt_hip_debug_kv_formats)
         seen = ctxs[0].debug_kv_formats(Ld, rows_ctx)
         if seen is not None:
             kv_forms = {"int16": float((seen == 2).mean()), "int20": float((seen == 0).mean()), "int24": float((seen == 1).mean())}
+        # the cache forms' watches (engine.cpp): did a layer stop trying the 16-bit form, did the model switch to 24 bits?
+        t_off, t_missed, t_sub = gm.debug_kv_tight_watch()
+        sw24, w24, sub24 = gm.debug_kv_watch()
+        kv_watch = {"tight_layers_off": t_off, "tight_missed": t_missed[:Ld], "tight_submitted": t_sub[:Ld],
+                    "switched_to_24_bit": sw24, "needed_24_bit": w24, "sentence_layers": sub24,
+                    "recalibrations": gm.debug_kv_recalibrations()}
         prof = {"launches": 0, "total_ms": 0.0, "int8_macs": 0.0, "weight_bytes": 0.0}
         for c in ctxs:
             r = c.profile_read()
@@ -490,6 +526,8 @@ def main():
                      "value": total_tokens_per_step * args.sustained_steps / dts, "seconds": dts}
 
     forward = None
+    if args.eos_bias > -50.0:
+        args.forward_steps = 0  # (the host-buffer regions check T tokens per sentence)
     if args.forward_steps > 0 and not dry and not strong and MG > 1:
         # Model::forward on host buffers, merged: MG pinned batches per worker through slimt_hip_translate_many_async
         from slimt_amd import capi as _capi
@@ -612,7 +650,7 @@ def main():
     if rank == 0:
         value = total_tokens_per_step * args.steps / dt_max
         macs_sentence = algorithmic_macs_per_sentence(D, F, Le, Ld, S, T, N_out)
-        sentences_per_step = total_tokens_per_step // T
+        sentences_per_step = args.total_sentences if strong else world * sum(c for _, c in my_batches)
         whole_job_tops = 2.0 * macs_sentence * sentences_per_step * args.steps / dt_max / 1e12
         avg_ms = prof["total_ms"] / max(1, prof["launches"])
         ops = 2.0 * prof["int8_macs"] / max(1, prof["launches"])       # algorithmic int8 OPs / launch
@@ -725,6 +763,15 @@ def main():
             },
             "roofline": roofline,
         }
+        if not dry and args.family != "default":
+            out["config"]["family"] = {"name": args.family, **synth.FAMILIES[args.family]}
+        if not dry and args.eos_bias > -50.0:
+            out["config"]["eos_bias"] = args.eos_bias
+            out["decoder_tile_live_fraction"] = live_fraction
+            out["config"]["workload"] += (f"; EOS bias {args.eos_bias}: sentences end at different steps, tokens counted as recorded "
+                                          f"(Model.cc:127-137), mean {tokens_per_step / max(1, sum(c for _, c in my_batches)):.1f} per sentence")
+        if kv_watch is not None:
+            out["kv_watch"] = kv_watch
         if sustained is not None:
             out["sustained"] = sustained
         if forward is not None:

@@ -276,7 +276,14 @@ int slimt_hip_host_free(void *p);
 /* Same with every buffer already resident in device memory; asynchronous on
  * the ctx stream when `steps_hint` > 0 (runs exactly that many decode steps,
  * no early-exit read-back), otherwise syncs every few steps to stop as soon
- * as every sentence has emitted EOS. */
+ * as every sentence has emitted EOS.
+ * Wait for an asynchronous call with slimt_hip_ctx_synchronize(ctx), not on the
+ * stream yourself: a bounded wait INSIDE the launches (the in-launch shortlist
+ * hand-over, the cluster logits' hand-overs) that ran out is reported through a
+ * word only that function reads and clears -- it then fails with the reason, and
+ * the batch's outputs must be discarded. A caller that waits on the stream alone
+ * sees rc 0 for such a batch and the error on the NEXT call that does synchronise
+ * through the library. */
 /* Device arrays cannot be checked by the host: a token or shortlist id >= the vocabulary reads the table's last
  * row instead of faulting -- that sentence's result is undefined (as in the reference, which does not check
  * either), the other sentences' results are not affected. */
@@ -519,6 +526,14 @@ int slimt_hip_debug_kv_centres(slimt_hip_model *model, int32_t *out, size_t n, i
  * one in 32 of a layer's sentences missed (after 1024 were submitted) that layer stops trying (bit l of
  * *layers_off): the 20-bit form is an out-of-line fallback in the kernels with the tight reader. Any pointer may be NULL; the arrays hold 4 entries. */
 int slimt_hip_debug_kv_tight_watch(slimt_hip_model *model, unsigned *layers_off, uint64_t *missed, uint64_t *submitted);
+/* Re-calibration of the centres (round 6): the first calibration batch need not look like the traffic behind
+ * it, so the first `max_recalibrations` times a layer's watch trips (above) the engine starts a new GENERATION
+ * of centres instead of switching the layer off: the next batch of >= 1024 rows is cached as f32 and calibrates
+ * them (into a buffer of its own: batches in flight keep the generation they were encoded with), and the form
+ * is tried again. Only a trip past that limit switches a layer off for good. Default 2, at most 3;
+ * max_recalibrations < 0 leaves the limit alone. *generations_started (nullable): 0 until the first trip.
+ * The counters of _kv_tight_watch are those of the current generation. Results never depend on any of this. */
+int slimt_hip_debug_kv_recalibrations(slimt_hip_model *model, int *generations_started, int max_recalibrations);
 /* Diagnostic (process-wide): while device_buf != NULL, thread 0 of every
  * workgroup of the persistent encoder / decoder appends a begin and an end
  * event to it: device_buf[0] = event counter (zero it first), then 3 uint64

@@ -38,6 +38,7 @@ SYMBOLS = [
     "slimt_hip_translate_async", "slimt_hip_host_alloc", "slimt_hip_host_free",
     "slimt_hip_encode_embedded", "slimt_hip_decode_begin_from", "slimt_hip_decode_step_states",
     "slimt_hip_translate_many_rows", "slimt_hip_translate_many_device", "slimt_hip_translate_many_async",
+    "slimt_hip_debug_kv_recalibrations",
 ]
 
 K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED, K_ENCODE_FUSED = range(9)
@@ -206,6 +207,7 @@ def lib():
     L.slimt_hip_debug_kv_watch.argtypes = [vp, vp, vp, vp]
     L.slimt_hip_debug_kv_tight_limit.argtypes = [vp, i32]
     L.slimt_hip_debug_kv_tight_watch.argtypes = [vp, vp, vp, vp]
+    L.slimt_hip_debug_kv_recalibrations.argtypes = [vp, vp, i32]
     L.slimt_hip_debug_kv_centres.argtypes = [vp, vp, sz, vp]
     L.slimt_hip_model_set_kv_centres.argtypes = [vp, vp, sz]
     L.slimt_hip_debug_break_shortlist_handoff.argtypes = [vp, i32, u32]
@@ -455,6 +457,13 @@ class Model:
         off, missed, sub = C.c_uint(0), (C.c_uint64 * 4)(), (C.c_uint64 * 4)()
         _chk(lib().slimt_hip_debug_kv_tight_watch(self.h, C.byref(off), missed, sub))
         return int(off.value), [int(x) for x in missed], [int(x) for x in sub]
+
+    def debug_kv_recalibrations(self, max_recalibrations: int = -1) -> int:
+        """Generations of K/V centres started after the first (a layer's watch tripped and the engine re-calibrated instead
+        of switching it off); max_recalibrations >= 0 sets how many it may start (default 2)."""
+        g = C.c_int(0)
+        _chk(lib().slimt_hip_debug_kv_recalibrations(self.h, C.byref(g), max_recalibrations))
+        return int(g.value)
 
     def set_adaptive_decoder_rows(self, on: bool):
         """Decode mode 0: 8 or 4 sentences per decoder workgroup while CUs would idle (default on)."""

@@ -2660,7 +2660,10 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   const int cl_first = tile / CL * CL;
   const int cl_n = CL == 1 ? 1 : (n_tiles_b - cl_first < CL ? n_tiles_b - cl_first : CL);
   const int cl_m = tile - cl_first;
-  if (CL > 1 && tid == 0) flags[2] = 0;  // every member of my cluster has finished all its sentences
+  if (CL > 1 && tid == 0) {
+    flags[2] = 0;  // every member of my cluster has finished all its sentences
+    flags[3] = 0;  // a cluster wait of this launch has timed out
+  }
 
   // per-sentence state of rows wave + 16 rr, owned by wave `wave` (uniform within the wave)
   int bq[RT], len[RT];
@@ -3173,9 +3176,12 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
           __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           unsigned spin = 0;
-          while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          // (flags[3]: a wait of this launch has run out already -- the batch has failed, dev_error says so; the waits
+          // behind it do not spin their two seconds again: ADVICE r05)
+          while (!flags[3] && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if (++spin > (1u << 22)) {  // ~2 s: a member never arrived (it cannot under the admission the engine asks for)
               if (a.dev_error) __hip_atomic_store(a.dev_error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              flags[3] = 1;
               break;
             }
             __builtin_amdgcn_s_sleep(4);

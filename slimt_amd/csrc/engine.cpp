@@ -59,11 +59,11 @@ static bool kv_narrow_wanted(slimt_hip_model *m, unsigned long long **count_dev)
     std::lock_guard<std::mutex> lock(m->gate_mu);
     if (!m->kv_wide_count) {
       void *p = nullptr;
-      if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) {
+      if (hipHostMalloc(&p, 256, hipHostMallocDefault) != hipSuccess) {  // [0] 24-bit, [1 + 4 gen + layer] not-16-bit (engine.h)
         (void)hipGetLastError();
         return true;  // (no counter: narrow without the watch)
       }
-      std::memset(p, 0, 64);
+      std::memset(p, 0, 256);
       m->kv_wide_count = static_cast<unsigned long long *>(p);
     }
   }
@@ -123,14 +123,26 @@ static unsigned kv_tight_wanted(slimt_hip_ctx *c, int S, bool writer, unsigned l
   if (!kv_tight_shape(c, S, writer) || !m->kv_wide_count || !kv_centres_ready(m)) return 0;
   static const bool watch = !(std::getenv("SLIMT_KV_WATCH") && std::getenv("SLIMT_KV_WATCH")[0] == '0');
   unsigned off = m->kv_tight_off.load(std::memory_order_relaxed);
+  const int gen = m->kv_gen.load(std::memory_order_relaxed);
+  unsigned tripped = 0;
   for (int l = 0; l < m->Ld && watch; ++l) {
-    const unsigned long long missed = static_cast<volatile unsigned long long *>(m->kv_wide_count)[1 + l];
+    const unsigned long long missed = static_cast<volatile unsigned long long *>(m->kv_wide_count)[1 + 4 * gen + l];
     const unsigned long long total = m->kv_tight_submitted[l].load(std::memory_order_relaxed);
     // (as for the narrow form: the fallback is an out-of-line call its whole workgroup waits for)
-    if (!((off >> l) & 1u) && total >= 1024 && missed * 32 > total) {
-      off |= 1u << l;
-      m->kv_tight_off.fetch_or(1u << l, std::memory_order_relaxed);
+    if (!((off >> l) & 1u) && total >= 1024 && missed * 32 > total) tripped |= 1u << l;
+  }
+  if (tripped) {
+    if (gen < m->kv_recal_max && gen + 1 < slimt_hip_model::kKvGens) {
+      // these centres do not fit the traffic: a new generation, calibrated from the next suitable batch (translate_device);
+      // until it is ready nobody tries the form, and this generation's buffer stays as it is for the batches in flight
+      for (auto &n : m->kv_tight_submitted) n.store(0, std::memory_order_relaxed);
+      m->kv_gen.store(gen + 1, std::memory_order_relaxed);
+      m->kv_centre_state.store(0, std::memory_order_release);
+      m->kv_centre_claimed.store(false, std::memory_order_release);
+      return 0;
     }
+    off |= tripped;
+    m->kv_tight_off.fetch_or(tripped, std::memory_order_relaxed);
   }
   const unsigned layers = ((1u << m->Ld) - 1u) & ~off;
   if (!layers) return 0;
@@ -139,7 +151,8 @@ static unsigned kv_tight_wanted(slimt_hip_ctx *c, int S, bool writer, unsigned l
     (void)hipGetLastError();
     return 0;
   }
-  *count_dev = static_cast<unsigned long long *>(dev) + 1;
+  *count_dev = static_cast<unsigned long long *>(dev) + 1 + 4 * gen;
+  c->kv_gen = gen;
   return layers;
 }
 
@@ -149,7 +162,7 @@ static void kv_watch_restart(slimt_hip_model *model) {
   model->kv_tight_off.store(0, std::memory_order_relaxed);
   for (auto &n : model->kv_tight_submitted) n.store(0, std::memory_order_relaxed);
   if (model->kv_wide_count)
-    for (int i = 0; i < 8; ++i) static_cast<volatile unsigned long long *>(model->kv_wide_count)[i] = 0;
+    for (int i = 0; i < 32; ++i) static_cast<volatile unsigned long long *>(model->kv_wide_count)[i] = 0;
 }
 
 hipError_t DevBuf::reserve(size_t n) {
@@ -799,7 +812,7 @@ extern "C" int slimt_hip_model_destroy(slimt_hip_model *model) {
   (void)hipSetDevice(model->device);
   model_free(model);
   if (model->kv_wide_count) (void)hipHostFree(model->kv_wide_count);
-  model->kv_centre.release();
+  for (auto &b : model->kv_centre) b.release();
   model->kv_centre_sums.release();
   if (model->kv_centre_ev) (void)hipEventDestroy(model->kv_centre_ev);
   delete model;
@@ -927,7 +940,14 @@ extern "C" int slimt_hip_debug_kv_centres(slimt_hip_model *model, int32_t *out, 
   if (!*ready || !out) return 0;
   const size_t have = (size_t)model->Ld * 2 * (size_t)model->D;
   if (n < have) return fail(-1, "kv centres: room for %zu values, the model has %zu", n, have);
-  HIPCHK(hipMemcpy(out, model->kv_centre.p, have * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, model->kv_centre[model->kv_gen.load(std::memory_order_relaxed)].p, have * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int slimt_hip_debug_kv_recalibrations(slimt_hip_model *model, int *generations_started, int max_recalibrations) {
+  if (!model) return fail(-1, "model is NULL");
+  if (max_recalibrations >= 0) model->kv_recal_max = std::min(max_recalibrations, slimt_hip_model::kKvGens - 1);
+  if (generations_started) *generations_started = model->kv_gen.load(std::memory_order_relaxed);
   return 0;
 }
 
@@ -938,13 +958,33 @@ extern "C" int slimt_hip_model_set_kv_centres(slimt_hip_model *model, const int3
   for (size_t i = 0; i < n; ++i)
     if (centres[i] <= -(1 << 24) || centres[i] >= (1 << 24)) return fail(-1, "kv centre %zu = %d not within (-2^24, 2^24)", i, centres[i]);
   HIPCHK(hipSetDevice(model->device));
-  if (model->kv_centre_claimed.exchange(true, std::memory_order_acq_rel) && model->kv_centre_state.load(std::memory_order_acquire) != 2 &&
-      !kv_centres_ready(model))
+  //  serialised against translate calls: they read the generation, its state and its buffer under these locks
+  std::lock_guard<std::mutex> submit(model->submit_mu);
+  std::lock_guard<std::mutex> gate(model->gate_mu);
+  const int gen = model->kv_gen.load(std::memory_order_relaxed);
+  const bool was_claimed = model->kv_centre_claimed.exchange(true, std::memory_order_acq_rel);
+  if (was_claimed && model->kv_centre_state.load(std::memory_order_acquire) != 2 && !kv_centres_ready(model))
     return fail(-1, "kv centres: a calibration batch is in flight");
-  HIPCHK(model->kv_centre.reserve(have * 4));
-  HIPCHK(hipDeviceSynchronize());  // (the caller promises no batch in flight; make the copy safe against a finished one's tail)
-  HIPCHK(hipMemcpy(model->kv_centre.p, centres, have * 4, hipMemcpyHostToDevice));
+  // whatever fails below gives the claim back (a claim without centres would keep every batch from calibrating: the form
+  // would silently never be used)
+  struct Unclaim {
+    slimt_hip_model *m;
+    bool armed;
+    ~Unclaim() {
+      if (armed) m->kv_centre_claimed.store(false, std::memory_order_release);
+    }
+  } unclaim{model, !was_claimed};
+  hipError_t e = model->kv_centre[gen].reserve(have * 4);
+  if (e == hipSuccess) e = hipDeviceSynchronize();  // (the caller promises no batch in flight; make the copy safe against a finished one's tail)
+  if (e == hipSuccess) e = hipMemcpy(model->kv_centre[gen].p, centres, have * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail((int)e, "kv centres: %s", hipGetErrorString(e));
+  unclaim.armed = false;
   model->kv_centre_state.store(2, std::memory_order_release);
+  // layers switched off under the centres before, and the counters they were judged by, start over with these
+  model->kv_tight_off.store(0, std::memory_order_relaxed);
+  for (auto &c : model->kv_tight_submitted) c.store(0, std::memory_order_relaxed);
+  if (model->kv_wide_count)
+    for (int l = 0; l < 4; ++l) static_cast<volatile unsigned long long *>(model->kv_wide_count)[1 + 4 * gen + l] = 0;
   return 0;
 }
 
@@ -952,7 +992,9 @@ extern "C" int slimt_hip_debug_kv_tight_watch(slimt_hip_model *model, unsigned *
   if (!model) return fail(-1, "model is NULL");
   if (layers_off) *layers_off = model->kv_tight_off.load(std::memory_order_relaxed);
   for (int l = 0; l < 4; ++l) {
-    if (missed) missed[l] = model->kv_wide_count ? static_cast<volatile unsigned long long *>(model->kv_wide_count)[1 + l] : 0;
+    if (missed)
+      missed[l] = model->kv_wide_count ? static_cast<volatile unsigned long long *>(
+                                              model->kv_wide_count)[1 + 4 * model->kv_gen.load(std::memory_order_relaxed) + l] : 0;
     if (submitted) submitted[l] = model->kv_tight_submitted[l].load(std::memory_order_relaxed);
   }
   return 0;
@@ -1459,7 +1501,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       if (f.kv_tight_layers) {
         f.kv_tight_limit = std::min(m->kv_tight_limit, 1 << 15);
         for (int l = 0; l < m->Ld; ++l)
-          for (int p = 0; p < 2; ++p) f.kv_centre[l][p] = m->kv_centre.as<int>() + (size_t)(2 * l + p) * D;
+          for (int p = 0; p < 2; ++p) f.kv_centre[l][p] = m->kv_centre_of(c->kv_gen, l, p);
         c->kv_tight = true;
         for (int l = 0; l < m->Ld; ++l)
           if ((f.kv_tight_layers >> l) & 1u) c->model->kv_tight_submitted[l].fetch_add((unsigned long long)B, std::memory_order_relaxed);
@@ -1566,7 +1608,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
       if (f.kv_tight_layers) {
         f.kv_tight_limit = std::min(m->kv_tight_limit, 1 << 15);
         for (int l = 0; l < m->Ld; ++l)
-          for (int p = 0; p < 2; ++p) f.kv_centre[l][p] = m->kv_centre.as<int>() + (size_t)(2 * l + p) * D;
+          for (int p = 0; p < 2; ++p) f.kv_centre[l][p] = m->kv_centre_of(c->kv_gen, l, p);
         c->kv_tight = true;
         for (int l = 0; l < m->Ld; ++l)
           if ((f.kv_tight_layers >> l) & 1u) c->model->kv_tight_submitted[l].fetch_add((unsigned long long)B, std::memory_order_relaxed);
@@ -1915,9 +1957,10 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     if (calibrate) {
       slimt_hip_model *gm = c->model;
       int rc = 0;
-      if (gm->kv_centre.reserve((size_t)m->Ld * 2 * m->D * 4) != hipSuccess || gm->kv_centre_sums.reserve((size_t)m->Ld * 2 * m->D * 8) != hipSuccess ||
+      DevBuf &centres = gm->kv_centre[gm->kv_gen.load(std::memory_order_relaxed)];  // this generation's own buffer
+      if (centres.reserve((size_t)m->Ld * 2 * m->D * 4) != hipSuccess || gm->kv_centre_sums.reserve((size_t)m->Ld * 2 * m->D * 8) != hipSuccess ||
           (!gm->kv_centre_ev && hipEventCreateWithFlags(&gm->kv_centre_ev, hipEventDisableTiming) != hipSuccess) ||
-          launch_kv_centres(c->kv.as<float>(), m->Ld, (int)B, (int)S, m->D, gm->kv_centre_sums.as<unsigned long long>(), gm->kv_centre.as<int>(), st) != hipSuccess ||
+          launch_kv_centres(c->kv.as<float>(), m->Ld, (int)B, (int)S, m->D, gm->kv_centre_sums.as<unsigned long long>(), centres.as<int>(), st) != hipSuccess ||
           hipEventRecord(gm->kv_centre_ev, st) != hipSuccess)
         rc = 1;
       if (rc)  // (no centres: the next suitable batch tries again -- claim_guard --; this one goes on with its f32 cache)
@@ -2021,8 +2064,8 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
       f.kv_u[l][1] = wv.w.u;
       f.kv_u256[l][0] = wk.w.u * (1.0f / 256.0f);  // exact scalings: the packed integers come back
       f.kv_u256[l][1] = wv.w.u * (1.0f / 256.0f);  // as accS * 256 (decode_fused.hip, unpack24f)
-      f.kv_centre[l][0] = m->kv_centre.as<int>() + (size_t)(2 * l) * m->D;  // (the tight form; null until calibrated, not read then)
-      f.kv_centre[l][1] = m->kv_centre.as<int>() + (size_t)(2 * l + 1) * m->D;
+      f.kv_centre[l][0] = m->kv_centre_of(c->kv_gen, l, 0);  // (the tight form, the generation this batch's encoder wrote
+      f.kv_centre[l][1] = m->kv_centre_of(c->kv_gen, l, 1);  //  it against; null until calibrated, not read then)
       f.kv_u4096[l][0] = wk.w.u * (1.0f / 4096.0f);  // ... as accS * 4096 from the narrow form (unpack20)
       f.kv_u4096[l][1] = wv.w.u * (1.0f / 4096.0f);
     }

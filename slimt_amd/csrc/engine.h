@@ -121,10 +121,23 @@ struct slimt_hip_model {
   // that form), a reduction behind its encoder writes the centres, and the form is tried from the first batch submitted
   // after the reduction's event has completed. Written once (or set by the caller before any batch), never changed after:
   // a batch's encoder and decoder read the same numbers.
-  slimt_hip::DevBuf kv_centre, kv_centre_sums;
+  // Round 6: centres come in GENERATIONS. A layer whose sentences mostly miss the form under the current centres (the watch
+  // above) used to stop trying for good -- but the first batch of >= 1024 rows need not look like the traffic behind it.
+  // Now the first kv_recal_max trips start a new generation instead: the next suitable batch is cached as f32 and
+  // calibrates fresh centres into ITS OWN buffer (batches in flight keep reading the generation they were encoded with:
+  // a context remembers it, slimt_hip_ctx::kv_gen), the form is tried again with them, and only a generation past the
+  // limit switches a layer off. The miss counters are per generation (kv_wide_count[1 + 4 gen + layer]): stale batches
+  // of the generation before cannot trip the new one.
+  static constexpr int kKvGens = 4;
+  slimt_hip::DevBuf kv_centre[kKvGens], kv_centre_sums;
   hipEvent_t kv_centre_ev = nullptr;
-  std::atomic<int> kv_centre_state{0};  // 0 = none, 1 = a calibration batch is in flight, 2 = ready
+  std::atomic<int> kv_centre_state{0};  // of the CURRENT generation: 0 = none, 1 = a calibration batch is in flight, 2 = ready
   std::atomic<bool> kv_centre_claimed{false};
+  std::atomic<int> kv_gen{0};           // the current generation
+  int kv_recal_max = 2;                 // re-calibrations allowed (at most kKvGens - 1)
+  const int *kv_centre_of(int gen, int layer, int kv) const {
+    return kv_centre[gen].as<int>() + (size_t)(2 * layer + kv) * (size_t)D;
+  }
 };
 
 struct slimt_hip_ctx {
@@ -165,6 +178,7 @@ struct slimt_hip_ctx {
   bool kv_fmt_valid = false;  // the encoder of the current batch recorded kv_fmt (else every cache is in the 24-bit form)
   int kv_fmt_B = 0;           // the batch size kv_fmt was recorded for
   bool kv_tight = false;      // ... and some of its sentence-layers may be in the tight form: the decoder with its reader
+  int kv_gen = 0;             // ... relative to the centres of this generation (engine.h, slimt_hip_model::kv_gen)
   bool expect_large_output = false;  // the last decoder launch of this context had an output layer of > 16384 columns (mode 0: the 32-sentence tiling, no tight reader)
   // decoder workspace
   slimt_hip::DevBuf dx, dx_pre, dh, datt8, dout, df8, state;

@@ -63,9 +63,34 @@ class Model:
         return self.params[k]
 
 
-def _ig8(rng, name, K, N, absmax_range=(0.3, 1.0)) -> Param:
+# Synthetic model FAMILIES: the default is what every fixture and benchmark of rounds 1-5 used; the others
+# vary what the K/V cache forms' hit rates depend on -- the spread of the int8 weights (sigma, or a heavy-tailed Student-t
+# draw of the same variance), the range of the activation multipliers (QuantMultA = 127 / absmax_a) and the spread of the
+# LayerNorm scales. Any values are legal models; parity must hold for all of them and the forms must stay exact.
+FAMILIES = {
+    "default": {},
+    "w48": {"weight_sigma": 48.0},
+    "w64": {"weight_sigma": 64.0},
+    "heavy": {"weight_dist": "student3"},
+    "a2_6": {"absmax_a": (2.0, 6.0)},
+    "a8_24": {"absmax_a": (8.0, 24.0)},
+    "ln0.3": {"ln_sigma": 0.3},
+    "w64_heavy_a8_24": {"weight_sigma": 64.0, "weight_dist": "student3", "absmax_a": (8.0, 24.0)},
+}
+_FAMILY = {"weight_sigma": 32.0, "weight_dist": "normal", "absmax_a": (4.0, 12.0), "ln_sigma": 0.05}
+
+
+def _weights(rng, shape, fam):
+    if fam["weight_dist"] == "student3":  # heavy tails, scaled to the same standard deviation (Var t_3 = 3)
+        x = rng.standard_t(3.0, size=shape) * (fam["weight_sigma"] / np.sqrt(3.0))
+    else:
+        x = rng.normal(0.0, fam["weight_sigma"], size=shape)
+    return np.clip(np.rint(x), -127, 127).astype(np.int8)
+
+
+def _ig8(rng, name, K, N, absmax_range=(0.3, 1.0), fam=_FAMILY) -> Param:
     """int8 weight, logical [K, N], payload [N][K]."""
-    q = np.clip(np.rint(rng.normal(0.0, 32.0, size=(N, K))), -127, 127).astype(np.int8)
+    q = _weights(rng, (N, K), fam)
     absmax = rng.uniform(*absmax_range)
     return Param(name, "ig8", K, N, q, float(np.float32(127.0 / absmax)))
 
@@ -77,8 +102,8 @@ def _f32(name, arr) -> Param:
     return Param(name, "f32", arr.shape[0], arr.shape[1], arr)
 
 
-def _quant_a(rng, name) -> Param:
-    absmax = rng.uniform(4.0, 12.0)
+def _quant_a(rng, name, fam=_FAMILY) -> Param:
+    absmax = rng.uniform(*fam["absmax_a"])
     return _f32(name, np.array([[127.0 / absmax]], dtype=np.float32))
 
 
@@ -88,6 +113,7 @@ def make_model(
     eos_id: int = 0,
     eos_bias: float = -100.0,
     dims: Optional[Tuple[int, int, int, int, int, int]] = None,
+    family: str = "default",
 ) -> Model:
     """Seeded random model with realistic quantisation ranges.
 
@@ -96,6 +122,7 @@ def make_model(
     positive => staggered finishing (correctness fixtures).
     """
     D, F, H, Le, Ld, V = dims if dims is not None else PRESETS[preset]
+    fam = dict(_FAMILY, **FAMILIES[family])
     rng = np.random.Generator(np.random.PCG64(seed))
     P: Dict[str, Param] = {}
 
@@ -106,21 +133,21 @@ def make_model(
         # W2 is kept small: relu() has a positive mean, and a large random W2
         # turns that mean into one input-independent direction that dominates
         # the residual stream (every sentence then decodes the same token).
-        add(_ig8(rng, prefix + w, K, N, (0.05, 0.15) if w == "W2" else (0.3, 1.0)))
+        add(_ig8(rng, prefix + w, K, N, (0.05, 0.15) if w == "W2" else (0.3, 1.0), fam))
         add(_f32(prefix + b, rng.normal(0.0, 0.05, size=(1, N))))
-        add(_quant_a(rng, prefix + w + "_QuantMultA"))
+        add(_quant_a(rng, prefix + w + "_QuantMultA", fam))
 
     def ln(prefix):
-        add(_f32(prefix + "_ln_scale", 1.0 + rng.normal(0.0, 0.05, size=(1, D))))
+        add(_f32(prefix + "_ln_scale", 1.0 + rng.normal(0.0, fam["ln_sigma"], size=(1, D))))
         add(_f32(prefix + "_ln_bias", rng.normal(0.0, 0.05, size=(1, D))))
 
     # Wemb: payload [V][D] (B^T of the output layer's [D, V]); Io.cc:182-224
-    q = np.clip(np.rint(rng.normal(0.0, 32.0, size=(V, D))), -127, 127).astype(np.int8)
+    q = _weights(rng, (V, D), fam)
     # small embedding range: with tied embeddings a large E makes the random
     # decoder collapse onto "repeat the previous token"; keeping |E|*sqrt(D)
     # below the other residual-stream terms gives varied greedy outputs.
     add(Param("Wemb", "ig8", V, D, q, float(np.float32(127.0 / rng.uniform(0.3, 0.6)))))
-    add(_quant_a(rng, "none_QuantMultA"))  # none_QuantMultA, Transformer.cc:106-112
+    add(_quant_a(rng, "none_QuantMultA", fam))  # none_QuantMultA, Transformer.cc:106-112
     out_b = rng.normal(0.0, 0.05, size=(1, V)).astype(np.float32)
     out_b[0, eos_id] += np.float32(eos_bias)
     add(_f32("decoder_ff_logit_out_b", out_b))
@@ -141,11 +168,11 @@ def make_model(
         affine(L + "_ffn_", "W1", "b1", D, F)
         affine(L + "_ffn_", "W2", "b2", F, D)
         ln(L + "_ffn_ffn")
-        add(_ig8(rng, L + "_rnn_W", D, D))
-        add(_quant_a(rng, L + "_rnn_W_QuantMultA"))
-        add(_ig8(rng, L + "_rnn_Wf", D, D))
+        add(_ig8(rng, L + "_rnn_W", D, D, fam=fam))
+        add(_quant_a(rng, L + "_rnn_W_QuantMultA", fam))
+        add(_ig8(rng, L + "_rnn_Wf", D, D, fam=fam))
         add(_f32(L + "_rnn_bf", rng.normal(0.0, 0.05, size=(1, D))))
-        add(_quant_a(rng, L + "_rnn_Wf_QuantMultA"))
+        add(_quant_a(rng, L + "_rnn_Wf_QuantMultA", fam))
         ln(L + "_rnn_ffn")
     # Tied embeddings + residual stream make a random decoder repeat its own
     # previous token forever. Flipping the sign of the last decoder LayerNorm

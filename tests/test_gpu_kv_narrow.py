@@ -341,7 +341,8 @@ def test_centres_are_calibrated_from_the_first_large_batch_and_a_layer_that_most
         assert np.array_equal(ctx.debug_kv_formats(m.dec_layers, B), forms)
         with pytest.raises(hip.SlimtHipError):
             gm.set_kv_centres(np.zeros(5, dtype=np.int32))
-        gm.debug_kv_tight_limit(1)
+        gm.debug_kv_recalibrations(0)  # (no new generation of centres: the end of the road is what this part is about; the
+        gm.debug_kv_tight_limit(1)     #  re-calibration has its own test below)
         n = 0
         while gm.debug_kv_tight_watch()[0] != 3:
             got = ctx.translate(ids, lens, sl, want_align=True)
@@ -358,3 +359,62 @@ def test_centres_are_calibrated_from_the_first_large_batch_and_a_layer_that_most
     finally:
         ctx.close()
         gm.close()
+
+
+def test_centres_that_do_not_fit_the_traffic_are_replaced_not_fatal(hip, oracle, synth_models):
+    """VERDICT r05 item 4(ii). The tight form's centres are the column means of the FIRST batch of >= 1024 rows (or set by
+    the caller); when they do not fit the traffic behind them -- here the caller sets 127 colsum, under which the form
+    holds the signed accumulator and about one sentence in sixteen misses it -- the layer's watch trips (more than 1 in
+    32 of >= 1024 sentences). Round 5 then switched the layer off for good. Now the first trips start a new GENERATION
+    of centres, calibrated from the next large batch (slimt_hip_debug_kv_recalibrations): the form comes back for
+    (nearly) every sentence, batches in flight keep the generation they were encoded with, results stay the checker's
+    throughout, and only trips past the limit switch a layer off."""
+    from slimt_amd import synth
+    m = synth_models("tiny11", 6.0)
+    om = oracle.OracleModel(m)
+    S, B = 32, 64
+    sl = synth.make_shortlist(m.V, 1024)
+
+    def run(gm, n_batches, check_every):
+        ctx = hip.Context(gm, B, S)
+        shares, gens = [], []
+        oracle.set_mode(oracle.PORTABLE)
+        for i in range(n_batches):
+            ids, lens = synth.make_batch(m.V, B, S, seed=9000 + i, ragged=True)
+            out, ln, al = ctx.translate(ids, lens, sl, want_align=True)
+            if check_every and (i % check_every == 0 or i >= n_batches - 3):
+                w_out, w_ln, w_al, _ = om.translate(ids, lens, sl, 1.5, 0, want_align=True)
+                assert np.array_equal(ln, w_ln) and np.array_equal(out, w_out) and np.array_equal(al, w_al), i
+            f = ctx.debug_kv_formats(m.dec_layers, B)
+            shares.append(0.0 if f is None else float((f == 2).mean()))
+            gens.append(gm.debug_kv_recalibrations())
+        oracle.set_mode(oracle.FAITHFUL)
+        ctx.close()
+        return shares, gens
+
+    gm = hip.Model(m)
+    try:
+        gm.set_kv_centres(colsum_centres(m))
+        assert gm.debug_kv_recalibrations() == 0
+        shares, gens = run(gm, 44, 8)
+        off, missed, sub = gm.debug_kv_tight_watch()
+        assert gens[-1] == 1, (gens, shares)               # noticed once, replaced once
+        first = gens.index(1)
+        assert 16 <= first <= 26, gens                     # 1024 sentences = 16 batches of 64 (+ the device counters' lag)
+        assert 0.3 < np.mean(shares[:first]) < 0.97, shares  # under the set centres a good share of the workgroups missed
+        assert off == 0 and np.mean(shares[-8:]) > 0.97, (off, shares, gens)  # calibrated from the traffic: the form is back
+        got = gm.debug_kv_centres(m.dec_layers, m.D)
+        assert got is not None and not np.array_equal(got, colsum_centres(m))
+    finally:
+        gm.close()
+    # a model that may not re-calibrate switches the layers off instead (round 5's behaviour: still the end of the road)
+    gm2 = hip.Model(m)
+    try:
+        gm2.set_kv_centres(colsum_centres(m))
+        gm2.debug_kv_recalibrations(0)
+        shares2, gens2 = run(gm2, 30, 0)
+        off2, _, _ = gm2.debug_kv_tight_watch()
+        # (per layer: a layer whose sentences mostly fit under these centres goes on trying)
+        assert off2 != 0 and gens2[-1] == 0 and shares2[-1] <= 0.5
+    finally:
+        gm2.close()
