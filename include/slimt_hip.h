@@ -444,6 +444,17 @@ int slimt_hip_translate_async_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist 
                                         size_t S, float limit_factor, uint32_t eos_id,
                                         uint32_t *out_ids, uint32_t *out_len, float *align);
 
+/* Several batches in one launch pair (slimt_hip_translate_many_* above) with every batch's OWN lexical shortlist, generated from its source words inside the encoder launch
+ * (Model.cc:117-120 per batch; slimt_hip_translate_*_generated below): the first n workgroups to start each
+ * generate one batch's list and publish it, every workgroup packs its share of the n output layers at the end of
+ * its encoder work. batches[].shortlist / n_shortlist are ignored. Falls back batch by batch like the others
+ * (also when the generator's bitmaps do not fit the encoder's LDS). */
+int slimt_hip_translate_many_device_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const slimt_hip_batch *batches,
+                                              size_t n_batches, size_t S, float limit_factor, uint32_t eos_id, int steps_hint);
+int slimt_hip_translate_many_async_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const slimt_hip_batch *batches,
+                                             size_t n_batches, size_t S, float limit_factor, uint32_t eos_id);
+
+
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, HIP events bracket every launch of kernel family `kernel_id`
  * on the ctx stream; slimt_hip_profile_read returns the number of launches

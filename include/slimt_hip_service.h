@@ -41,7 +41,7 @@ typedef struct slimt_hip_service_config {
   /* merged launches (slimt_hip_translate_many_async; host/Service.hh, ServiceConfig::merge_batches): a worker takes up
    * to merge_batches consecutive batches of one padded length -- each formed under max_words, each with its own results --
    * into one launch pair while their rows x length stay within merge_words. 0 = the defaults (8 batches, 8192 words);
-   * merge_batches = 1: never. Not used with a lexical shortlist. */
+   * merge_batches = 1: never. With a lexical shortlist every merged batch still gets its own list. */
   uint64_t merge_batches, merge_words;
 } slimt_hip_service_config;
 

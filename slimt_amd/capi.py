@@ -38,7 +38,7 @@ SYMBOLS = [
     "slimt_hip_translate_async", "slimt_hip_host_alloc", "slimt_hip_host_free",
     "slimt_hip_encode_embedded", "slimt_hip_decode_begin_from", "slimt_hip_decode_step_states",
     "slimt_hip_translate_many_rows", "slimt_hip_translate_many_device", "slimt_hip_translate_many_async",
-    "slimt_hip_debug_kv_recalibrations",
+    "slimt_hip_debug_kv_recalibrations", "slimt_hip_translate_many_device_generated", "slimt_hip_translate_many_async_generated",
 ]
 
 K_NONE, K_GEMM_ENC, K_GEMM_DEC, K_LOGITS, K_ATTN_ENC, K_ATTN_DEC, K_SSRU, K_DECODE_FUSED, K_ENCODE_FUSED = range(9)
@@ -230,6 +230,8 @@ def lib():
     L.slimt_hip_translate_many_rows.restype = sz
     L.slimt_hip_translate_many_device.argtypes = [vp, vp, sz, sz, f32, u32, i32]
     L.slimt_hip_translate_many_async.argtypes = [vp, vp, sz, sz, f32, u32]
+    L.slimt_hip_translate_many_device_generated.argtypes = [vp, vp, vp, sz, sz, f32, u32, i32]
+    L.slimt_hip_translate_many_async_generated.argtypes = [vp, vp, vp, sz, sz, f32, u32]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("slimt_hip_abi_version",):
@@ -644,7 +646,7 @@ class Context:
             n_shortlist, limit_factor, eos_id, vp(d_out_ids), vp(d_out_len),
             vp(d_align) if d_align else None, steps_hint))
 
-    def translate_many_device(self, batches, S: int, limit_factor: float, eos_id: int, steps_hint: int = 0):
+    def translate_many_device(self, batches, S: int, limit_factor: float, eos_id: int, steps_hint: int = 0, generator=None):
         """slimt_hip_translate_many_device: `batches` = [(d_ids, d_lengths, B, d_shortlist, n_shortlist, d_out_ids,
         d_out_len, d_align[, S_j])] of device pointers (ints; 0 = none) -- ONE encoder and ONE decoder launch for all of them;
         S_j: that batch's own padded length (<= S; default S)."""
@@ -652,9 +654,12 @@ class Context:
         for j, b in enumerate(batches):
             d_ids, d_len, B, d_sl, n_sl, d_out, d_ol, d_al = b[:8]
             arr[j] = _Batch(d_ids, d_len, B, b[8] if len(b) > 8 else 0, d_sl if n_sl else None, n_sl, d_out, d_ol, d_al or None)
+        if generator is not None:
+            _chk(lib().slimt_hip_translate_many_device_generated(self.h, generator.h, arr, len(batches), S, limit_factor, eos_id, steps_hint))
+            return
         _chk(lib().slimt_hip_translate_many_device(self.h, arr, len(batches), S, limit_factor, eos_id, steps_hint))
 
-    def translate_many_async(self, bufs_list, shortlist=None, limit_factor: float = 1.5, eos_id: int = 0):
+    def translate_many_async(self, bufs_list, shortlist=None, limit_factor: float = 1.5, eos_id: int = 0, generator=None):
         """slimt_hip_translate_many_async on a list of pinned buffer tuples (ids, lengths, out_ids, out_len, align|None),
         one shortlist (host array) or none for all; synchronize() before reading the outputs."""
         sl = None if shortlist is None else np.ascontiguousarray(shortlist, dtype=np.uint32)
@@ -665,6 +670,9 @@ class Context:
                             0 if sl is None else sl.size, p_out.ctypes.data, p_ol.ctypes.data,
                             None if p_al is None else p_al.ctypes.data)
         self._many_keep = (arr, sl)
+        if generator is not None:  # every batch's own lexical shortlist, generated inside the encoder launch
+            _chk(lib().slimt_hip_translate_many_async_generated(self.h, generator.h, arr, len(bufs_list), S, limit_factor, eos_id))
+            return
         _chk(lib().slimt_hip_translate_many_async(self.h, arr, len(bufs_list), S, limit_factor, eos_id))
 
     def translate_device_generated(self, gen: "ShortlistGenerator", d_ids: int, d_lengths: int, B: int,

@@ -2760,7 +2760,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     outw.colsum = reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.out.colsum) + (size_t)job * a.out_stride_cs);
     outw.cp4 = outw.colsum + epi_pair_offset_ints(a.sub[sj].N);
     outw.pb = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.out.pb) + (size_t)job * a.out_stride_pb);
-    outw.N = a.sub[sj].N;
+    outw.N = a.out_n_dev ? (int)a.out_n_dev[job] : a.sub[sj].N;  // (a shortlist generated on the device: job j's count)
     outw.n_tiles = (outw.N + 15) / 16;
   } else if (a.out_n_dev) {
     outw.N = (int)*a.out_n_dev;

@@ -430,6 +430,7 @@ __device__ __forceinline__ void pack_weight_share(const FusedEncodeArgs &a, int 
     PackArgs pj = a.pack;
     pj.idx = a.pjob[job].idx;
     pj.N = a.pjob[job].N;
+    pj.n_dev = a.pack.n_dev ? a.pack.n_dev + job : nullptr;  // (shortlists generated in this launch: job j's count is n_dev[j])
     pj.Wp = reinterpret_cast<char *>(a.pack.Wp) + (size_t)job * a.pack_stride_wp;
     pj.colsum = reinterpret_cast<int *>(reinterpret_cast<char *>(a.pack.colsum) + (size_t)job * a.pack_stride_cs);
     pj.pb = reinterpret_cast<float *>(reinterpret_cast<char *>(a.pack.pb) + (size_t)job * a.pack_stride_pb);

@@ -239,8 +239,10 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
   const bool gen_here = a.gen.w2o != nullptr;  // the batch's shortlist is generated in this launch (encode_tall.hip): packed at the end
   if (!gen_here) {
     pack_weight_share(a, tile, n_tiles, tid, 1024);
-  } else if (tile == 0) {
-    shortlist_publish_in_launch(a.gen, reinterpret_cast<uint32_t *>(smem), a.gen_flag, a.gen_epoch, tid);
+  } else {
+    // ShortlistGenerator::generate (Shortlist.cc:115-175; Model.cc:117-120) by the workgroup that started first (a merged
+    // launch: by the first n, one shortlist per sub-batch), in the still unused LDS, then published for the others (shortlist_device.h)
+    shortlists_publish_in_launch(a, reinterpret_cast<uint32_t *>(smem), tile, n_tiles, tid);
   }
 
   // ---- embedding (Model.cc:195-197) ----------------------------------------
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
     lds_barrier();
   }
   if (gen_here) {
-    if (shortlist_await_in_launch(a.gen_flag, a.gen_epoch ^ a.gen_wait_xor, tid, a.dev_error, a.gen_spin_limit))  // (never published: nothing to pack from)
+    if (shortlists_await_in_launch(a, tid))  // (never published: nothing to pack from)
       pack_weight_share(a, tile, n_tiles, tid, 1024);
   }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);

@@ -256,10 +256,10 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   const bool gen_here = a.gen.w2o != nullptr;  // ... of a shortlist this launch generates itself: packed at the end
   if (!gen_here) {
     pack_weight_share(a, tile, n_wg, tid, 1024);
-  } else if (tile == 0) {
-    // ShortlistGenerator::generate (Shortlist.cc:115-175; Model.cc:117-120) by the workgroup that started first,
-    // in the still unused LDS, then published for the others (shortlist_device.h)
-    shortlist_publish_in_launch(a.gen, reinterpret_cast<uint32_t *>(smem), a.gen_flag, a.gen_epoch, tid);
+  } else {
+    // ShortlistGenerator::generate (Shortlist.cc:115-175; Model.cc:117-120) by the workgroup that started first (a merged
+    // launch: by the first n, one shortlist per sub-batch), in the still unused LDS, then published for the others (shortlist_device.h)
+    shortlists_publish_in_launch(a, reinterpret_cast<uint32_t *>(smem), tile, n_wg, tid);
   }
 
   // A round's projections are 3 x 8 column tiles (Q, K, V of four heads) x 4 row tiles on 16 waves:
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
   if (gen_here) {
     // the shortlist of this launch: wait for its publisher (running since before this workgroup started, and
     // waiting for nobody: ~40 us of work against this workgroup's ~250); then this workgroup's share of the output layer
-    if (shortlist_await_in_launch(a.gen_flag, a.gen_epoch ^ a.gen_wait_xor, tid, a.dev_error, a.gen_spin_limit))  // (never published: nothing to pack from)
+    if (shortlists_await_in_launch(a, tid))  // (never published: nothing to pack from)
       pack_weight_share(a, tile, n_wg, tid, 1024);
   }
   if (tid == 0) occ_trace_event(a.trace, 2, 1);

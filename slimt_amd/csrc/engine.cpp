@@ -2002,7 +2002,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     // weights a step streams: with the full 32k vocabulary it is 8 of 10 MB per workgroup and step, and
     // halving it per sentence beats the longer attention chain (B = 512, full vocabulary: 20.4 -> 23-24 M
     // tok/s; at 16k columns the two are level, below that 16 rows win)
-    const size_t n_expected = mp ? (size_t)(n_sl ? mp->max_N : m->V) : d_n_sl && n_sl_hint ? n_sl_hint : (size_t)out.w.N;
+    const size_t n_expected = d_n_sl && n_sl_hint ? n_sl_hint : mp ? (size_t)(n_sl ? mp->max_N : m->V) : (size_t)out.w.N;
     // ... and 8 or 4 (decode_fused.hip, SPW) when the decoders in flight would leave most of the chip idle:
     // decided below, under the admission lock, from the contexts that have a decoder pending
     // Round 5: where the kernel has it, output layers that wide are SHARED by clusters of four 16-sentence workgroups
@@ -3073,6 +3073,137 @@ int translate_host_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const 
   return 0;
 }
 }  // namespace
+
+// ---- merged launches whose batches each get THEIR lexical shortlist, generated inside the encoder launch ---------------
+namespace {
+// dev: the batches with arrays the device can read (device memory, or the device views of pinned arrays); the merged launch
+// when it is possible, else batch by batch through translate_generated
+int translate_many_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const slimt_hip_batch *dev, size_t n, size_t S,
+                             float limit_factor, uint32_t eos_id, int steps_hint, bool stage_align,
+                             const slimt_hip_batch *host = nullptr) {
+  // host (the asynchronous entry point): the same batches with the caller's HOST pointers -- what the batch-by-batch
+  // fallback hands to translate_host_generated, which knows when the kernels can use pinned arrays in place
+  const slimt_hip_model *m = ctx->model;
+  const size_t Tmax = std::max<size_t>(1, (size_t)(limit_factor * (float)S));
+  const size_t V = (size_t)m->V;
+  size_t rows = 0;
+  bool any_align = false;
+  for (size_t j = 0; j < n; ++j) {
+    rows += (dev[j].B + kMergeAlign - 1) / kMergeAlign * kMergeAlign;
+    any_align = any_align || dev[j].align != nullptr;
+  }
+  static const bool fold = !(std::getenv("SLIMT_SHORTLIST_FOLD") && std::getenv("SLIMT_SHORTLIST_FOLD")[0] == '0');
+  const bool merged = n > 1 && n <= (size_t)kMaxMerge && S <= ctx->max_S && rows <= ctx->max_B && rows * S <= ctx->max_M &&
+                      merge_supported(ctx, rows, S) && fold &&
+                      shortlist_in_launch_lds_bytes((int)sl->source_vocab, (int)sl->target_vocab) <= 64 * 1024;
+  if (!merged && host) {
+    for (size_t j = 0; j < n; ++j) {
+      const slimt_hip_batch &b = host[j];
+      RCCHK(translate_host_generated(ctx, sl, b.src_ids, b.lengths, b.B, b.S ? b.S : S, limit_factor, eos_id, b.out_ids, b.out_len,
+                                     b.align, false));
+    }
+    return 0;
+  }
+  if (!merged) {
+    for (size_t j = 0; j < n; ++j) {
+      const slimt_hip_batch &b = dev[j];
+      const size_t Sj = b.S ? b.S : S, Tj = std::max<size_t>(1, (size_t)(limit_factor * (float)Sj));
+      float *staging = nullptr;
+      if (b.align && stage_align) {
+        HIPCHK(ctx->align.reserve(align_staging_bytes(ctx, b.B, Sj, Tj, limit_factor)));
+        staging = ctx->align.as<float>();
+      }
+      RCCHK(check_batch(ctx, b.B, Sj));
+      RCCHK(translate_generated(ctx, sl, b.src_ids, b.lengths, b.B, Sj, limit_factor, eos_id, b.out_ids, b.out_len,
+                                staging ? staging : b.align, steps_hint > 0 ? std::min(steps_hint, (int)Tj) : (stage_align ? (int)Tj : 0),
+                                staging ? b.align : nullptr));
+    }
+    return 0;
+  }
+  hipStream_t st = ctx->stream;
+  ctx->sl_host.clear();  // ctx->shortlist no longer holds what translate_host uploaded last
+  HIPCHK(ctx->shortlist.reserve(n * V * 4));  // job j's ids at j * V, its count at n_sl_dev[j]
+  HIPCHK(ctx->n_sl_dev.reserve(4 * (size_t)kMaxMerge));
+  slimt_hip_batch plan[kMaxMerge];
+  for (size_t j = 0; j < n; ++j) {
+    plan[j] = dev[j];
+    plan[j].shortlist = ctx->shortlist.as<uint32_t>() + j * V;
+    plan[j].n_shortlist = V;  // the capacity; the kernels read the count
+  }
+  if (any_align && stage_align) HIPCHK(ctx->align.reserve(align_staging_bytes(ctx, rows, S, Tmax, limit_factor)));
+  MergePlan mp;
+  RCCHK(build_merge_plan(ctx, plan, n, S, Tmax, limit_factor, steps_hint, any_align && stage_align ? ctx->align.as<float>() : nullptr, mp, rows));
+  ShortlistArgs a;
+  shortlist_args(sl, plan[0].src_ids, plan[0].lengths, plan[0].B, S, ctx->shortlist.as<uint32_t>(), ctx->n_sl_dev.as<uint32_t>(), a);
+  uint32_t *hint = reinterpret_cast<uint32_t *>(ctx->n_finished_host) + 1;  // (translate_generated: the previous shortlist's size)
+  const size_t n_hint = *hint;
+  void *hint_dev = nullptr;
+  if (hipHostGetDevicePointer(&hint_dev, hint, 0) == hipSuccess) a.n_out_host = static_cast<uint32_t *>(hint_dev);
+  (void)st;
+  return translate_device(ctx, plan[0].src_ids, plan[0].lengths, ctx->shortlist.as<uint32_t>(), rows, S, V, limit_factor, eos_id,
+                          plan[0].out_ids, plan[0].out_len, any_align ? (stage_align ? ctx->align.as<float>() : plan[0].align) : nullptr,
+                          steps_hint > 0 ? steps_hint : (int)Tmax, ctx->n_sl_dev.as<uint32_t>(),
+                          any_align && stage_align ? plan[0].align : nullptr, n_hint, &a, &mp);
+}
+
+int check_generator(const slimt_hip_ctx *ctx, const slimt_hip_shortlist *sl) {
+  const slimt_hip_model *m = ctx->model;
+  if (sl->device != m->device) return fail(-1, "shortlist and context are on different devices");
+  if (sl->target_vocab != (size_t)m->V)
+    return fail(-1, "shortlist target vocabulary %zu != model vocabulary %d", sl->target_vocab, m->V);
+  return 0;
+}
+}  // namespace
+
+extern "C" int slimt_hip_translate_many_device_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const slimt_hip_batch *batches,
+                                                         size_t n_batches, size_t S, float limit_factor, uint32_t eos_id,
+                                                         int steps_hint) {
+  if (!ctx || !sl || !batches || n_batches == 0) return fail(-1, "null argument");
+  RCCHK(check_generator(ctx, sl));
+  for (size_t j = 0; j < n_batches; ++j) {
+    const slimt_hip_batch &b = batches[j];
+    if (!b.src_ids || !b.lengths || !b.out_ids || !b.out_len || b.B == 0) return fail(-1, "batch %zu: null array or empty", j);
+    if ((b.S ? b.S : S) > S) return fail(-1, "batch %zu is padded to %zu tokens, the launch to %zu", j, b.S, S);
+  }
+  HIPCHK(hipSetDevice(ctx->model->device));
+  return translate_many_generated(ctx, sl, batches, n_batches, S, limit_factor, eos_id, steps_hint, false);
+}
+
+extern "C" int slimt_hip_translate_many_async_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const slimt_hip_batch *batches,
+                                                        size_t n_batches, size_t S, float limit_factor, uint32_t eos_id) {
+  if (!ctx || !sl || !batches || n_batches == 0) return fail(-1, "null argument");
+  RCCHK(check_generator(ctx, sl));
+  const slimt_hip_model *m = ctx->model;
+  HIPCHK(hipSetDevice(m->device));
+  const uint32_t vmax = (uint32_t)std::min((size_t)m->V, sl->source_vocab);
+  slimt_hip_batch dev[kMaxMerge];
+  bool pinned = n_batches <= (size_t)kMaxMerge;
+  for (size_t j = 0; j < n_batches; ++j) {
+    const slimt_hip_batch &b = batches[j];
+    if (!b.src_ids || !b.lengths || !b.out_ids || !b.out_len || b.B == 0) return fail(-1, "batch %zu: null array or empty", j);
+    const size_t Sj = b.S ? b.S : S;
+    if (Sj > S) return fail(-1, "batch %zu is padded to %zu tokens, the launch to %zu", j, Sj, S);
+    for (size_t i = 0; i < b.B * Sj; ++i)
+      if (b.src_ids[i] >= vmax) return fail(-1, "batch %zu: token id %u out of range", j, b.src_ids[i]);
+    for (size_t i = 0; i < b.B; ++i)
+      if (b.lengths[i] > Sj) return fail(-1, "batch %zu: length %u > S", j, b.lengths[i]);
+    if (!pinned) continue;
+    dev[j] = b;
+    dev[j].src_ids = static_cast<const uint32_t *>(host_device_view(b.src_ids));
+    dev[j].lengths = static_cast<const uint32_t *>(host_device_view(b.lengths));
+    dev[j].out_ids = static_cast<uint32_t *>(host_device_view(b.out_ids));
+    dev[j].out_len = static_cast<uint32_t *>(host_device_view(b.out_len));
+    dev[j].align = b.align ? static_cast<float *>(host_device_view(b.align)) : nullptr;
+    if (!dev[j].src_ids || !dev[j].lengths || !dev[j].out_ids || !dev[j].out_len || (b.align && !dev[j].align)) pinned = false;
+  }
+  if (pinned) return translate_many_generated(ctx, sl, dev, n_batches, S, limit_factor, eos_id, 0, true, batches);
+  for (size_t j = 0; j < n_batches; ++j) {  // pageable arrays, or too many batches: one by one through the copying path
+    const slimt_hip_batch &b = batches[j];
+    RCCHK(translate_host_generated(ctx, sl, b.src_ids, b.lengths, b.B, b.S ? b.S : S, limit_factor, eos_id, b.out_ids, b.out_len,
+                                   b.align, false));
+  }
+  return 0;
+}
 
 extern "C" int slimt_hip_translate_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const uint32_t *src_ids,
                                              const uint32_t *lengths, size_t B, size_t S, float limit_factor,

@@ -214,4 +214,54 @@ __device__ __forceinline__ bool shortlist_await_in_launch(unsigned *flag, unsign
   return published != 0;
 }
 
+// ---- a merged launch (kernels.h, MergeIn): every sub-batch has ITS shortlist (Model.cc:117-120) -----------------------
+// Sub-batch j's generator arguments: the launch's (tables, vocabularies, `frequent`) with j's own sentences; its ids go
+// to out + j * tgt_vocab, its count to n_out[j], its flag is flag[j].
+__device__ __forceinline__ ShortlistArgs shortlist_args_of(const FusedEncodeArgs &a, int j) {
+  ShortlistArgs g = a.gen;
+  if (a.n_sub == 0) return g;
+  g.ids = a.sub[j].ids;
+  g.lengths = a.sub[j].lengths;
+  g.B = a.sub[j].n;
+  g.S = a.sub[j].S;
+  g.out = a.gen.out + (size_t)j * a.gen.tgt_vocab;
+  g.n_out = a.gen.n_out + j;
+  g.n_out_host = j == 0 ? a.gen.n_out_host : nullptr;
+  return g;
+}
+// The publishers: the workgroups that claimed tiles 0 .. n - 1 -- the first n to START, each running before any waiter
+// that could wait for it exists and waiting for nobody while it generates (tile t also takes t + n_wg, ... when a launch
+// has fewer tiles than shortlists: sentences of one or two tokens).
+__device__ __forceinline__ void shortlists_publish_in_launch(const FusedEncodeArgs &a, uint32_t *lds, int tile, int n_wg, int tid) {
+  const int n = a.n_sub ? a.n_sub : 1;
+  for (int j = tile; j < n; j += n_wg)
+    shortlist_publish_in_launch(shortlist_args_of(a, j), lds, a.gen_flag + j, a.gen_epoch, tid);
+}
+// ... and the waiters: one lane polls the flags one after the other, ONE acquire behind the last (see shortlist_await_in_launch)
+__device__ __forceinline__ bool shortlists_await_in_launch(const FusedEncodeArgs &a, int tid) {
+  const int n = a.n_sub ? a.n_sub : 1;
+  if (n == 1) return shortlist_await_in_launch(a.gen_flag, a.gen_epoch ^ a.gen_wait_xor, tid, a.dev_error, a.gen_spin_limit);
+  __shared__ int published_all;
+  if (tid == 0) {
+    bool ok = true;
+    const unsigned epoch = a.gen_epoch ^ a.gen_wait_xor;
+    for (int j = 0; j < n && ok; ++j) {
+      unsigned spin = 0;
+      while (__hip_atomic_load(a.gen_flag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        if (++spin >= a.gen_spin_limit) {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    if (!ok && a.dev_error) __hip_atomic_store(a.dev_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    published_all = ok ? 1 : 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  return published_all != 0;
+}
+
 }  // namespace slimt_hip

@@ -178,6 +178,12 @@ void Worker::forward_many_async(const slimt_hip_batch *batches, size_t n, size_t
     raise("slimt_hip_translate_many_async");
 }
 
+void Worker::forward_many_async_generated(slimt_hip_shortlist *generator, const slimt_hip_batch *batches, size_t n, size_t S,
+                                          float limit_factor) {
+  if (slimt_hip_translate_many_async_generated(ctx_, generator, batches, n, S, limit_factor, model_.config().eos_id))
+    raise("slimt_hip_translate_many_async_generated");
+}
+
 void Worker::wait() {
   if (slimt_hip_ctx_synchronize(ctx_)) raise("slimt_hip_ctx_synchronize");
 }

@@ -156,6 +156,9 @@ class Worker {
   // concurrent forward calls are in the reference (Frontend.cc:207-227). Each batch keeps its own arrays, its own
   // shortlist and its own results; the workspace must hold slimt_hip_translate_many_rows() sentences.
   void forward_many_async(const slimt_hip_batch *batches, size_t n, size_t S, float limit_factor);
+  // ... each batch with its own lexical shortlist, generated inside the encoder launch (slimt_hip_translate_many_async_generated)
+  void forward_many_async_generated(slimt_hip_shortlist *generator, const slimt_hip_batch *batches, size_t n, size_t S,
+                                    float limit_factor);
   void wait();
 
  private:

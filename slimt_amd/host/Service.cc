@@ -367,7 +367,7 @@ void Service::launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *
   uint32_t *out_ids = slot.out_ids.ensure(n_out), *out_len = slot.out_len.ensure(B);
   float *align = config_.alignments ? slot.align.ensure(n_align) : nullptr;
   const Slot::Part &p0 = slot.parts[0];
-  if (generator) {  // the batch's own lexical shortlist, generated on the worker's stream (Model.cc:117-120); never merged
+  if (generator && slot.parts.size() == 1) {  // the batch's own lexical shortlist, generated on the worker's stream (Model.cc:117-120)
     slot.worker->forward_async_generated(generator, ids, lengths, B, p0.S, config_.tgt_length_limit_factor, out_ids,
                                          out_len, align);
     return;
@@ -393,7 +393,10 @@ void Service::launch(Slot &slot, std::vector<Unit> &batch, slimt_hip_shortlist *
       c.out_len = out_len + p.first;
       c.align = align ? align + p.align_at : nullptr;
     }
-    slot.worker->forward_many_async(calls.data(), calls.size(), launch_S, config_.tgt_length_limit_factor);
+    if (generator)  // every part's own shortlist, generated inside the one encoder launch
+      slot.worker->forward_many_async_generated(generator, calls.data(), calls.size(), launch_S, config_.tgt_length_limit_factor);
+    else
+      slot.worker->forward_many_async(calls.data(), calls.size(), launch_S, config_.tgt_length_limit_factor);
     return;
   }
   slot.worker->forward_async(ids, lengths, B, p0.S, sl, n_sl, config_.tgt_length_limit_factor, out_ids, out_len, align);
@@ -451,7 +454,7 @@ void Service::work(const Model *model, slimt_hip_shortlist *generator) {
     for (Slot &s : slots) {
       // (B + 1) * S <= max_words: at most max_words - 1 rows, at most max_words padded tokens; a merged launch: up to
       // merge_words of its 32-aligned rows x length (next_batch)
-      const bool merging = config_.merge_batches > 1 && !generator && config_.merge_words > config_.max_words;
+      const bool merging = config_.merge_batches > 1 && config_.merge_words > config_.max_words;
       const size_t words = merging ? config_.merge_words : config_.max_words;
       s.worker = std::make_unique<Worker>(*model, words, longest_, words);
       // every staging array at its largest, once: growing one later frees and allocates pinned
@@ -475,7 +478,7 @@ void Service::work(const Model *model, slimt_hip_shortlist *generator) {
   for (;;) {
     Slot &mine = slots[cur], &other = slots[cur ^ 1];
     // with a batch in flight on the other slot, only take work that is already there
-    const bool merging = config_.merge_batches > 1 && !generator && config_.merge_words > config_.max_words;
+    const bool merging = config_.merge_batches > 1 && config_.merge_words > config_.max_words;
     std::vector<size_t> parts;
     std::vector<Unit> batch = next_batch(other.batch.empty(), merging ? &parts : nullptr);
     if (batch.empty()) {

@@ -102,8 +102,8 @@ struct ServiceConfig {
   // arrays and results -- up to merge_batches of them, while the launch's rows x its longest length stay within
   // merge_words and no batch runs padded by more than a quarter; all of them run as ONE encoder and ONE decoder launch.
   // The reference's default batch is 1024 padded words (Frontend.hh:21-39): 32 sentences of 32 tokens fill 2 of 256 CUs
-  // in the decoder; eight of them per launch pair fill what one batch of 8192 words does. 1 = never merge. (Not with a
-  // lexical shortlist: a batch's shortlist is generated inside ITS encoder launch.)
+  // in the decoder; eight of them per launch pair fill what one batch of 8192 words does. 1 = never merge. With a lexical
+  // shortlist every merged batch still gets ITS OWN list (Model.cc:117-120), generated inside the one encoder launch.
   size_t merge_batches = 8;
   size_t merge_words = 8192;
   uint32_t pad_id = 0;

@@ -221,3 +221,44 @@ def test_merged_headline_shape_full_size(hip, oracle, engines):
         ctx.close()
         if eos_bias > 0:
             _check(oracle, om, batches[:1], [sl], res[:1])
+
+
+@pytest.mark.parametrize("preset,S,shapes,mode", [
+    ("tiny11", 24, [(33, 24), (20, 20), (47, 24), (5, 19)], 0),
+    ("tiny11", 16, [(64, 16), (64, 16), (10, 13)], 2),
+    ("base", 32, [(19, 32), (12, 27)], 0),
+    ("tiny11", 2, [(3, 2)] * 8, 0),   # eight shortlists, one encoder tile: the workgroup of tile 0 generates all of them
+])
+def test_merged_batches_generate_their_own_lexical_shortlists(hip, oracle, engines, preset, S, shapes, mode):
+    """Model.cc:117-120 per batch, merged: every batch's output vocabulary is ShortlistGenerator::generate of ITS source
+    words, produced by one of the first workgroups of the ONE encoder launch; tokens, lengths and alignment rows == the
+    checker's on that batch with the checker's own shortlist for it -- and the lists really differ between the batches."""
+    from slimt_amd import synth
+    m, gm, om = engines(preset, 6.0)
+    blob = synth.make_lexical_shortlist(m.V, m.V, 100, 2, seed=21, empty_fraction=0.3, min_count=1)
+    osl = oracle.OracleShortlist(blob, m.V, m.V)
+    gen = hip.ShortlistGenerator(blob, m.V, m.V)
+    batches = [synth.make_batch(m.V, B, Sj, seed=700 + 17 * j + B, ragged=True) for j, (B, Sj) in enumerate(shapes)]
+    sls = [osl.generate(ids, lens) for ids, lens in batches]
+    assert len({tuple(s_) for s_ in sls}) > 1
+    rows = hip.translate_many_rows([b for b, _ in shapes])
+    ctx = hip.Context(gm, rows, S)
+    ctx.set_decode_mode(mode)
+    keep, args, outs = [], [], []
+    for ids, lens in batches:
+        B, Sj = ids.shape
+        T = max(int(np.float32(1.5) * np.float32(Sj)), 1)
+        d_ids, d_len = _dev(ids), _dev(lens)
+        d_out = torch.full((B, T), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
+        d_ol = torch.full((B,), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
+        d_al = torch.full((B, T, Sj), 7.25, dtype=torch.float32, device="cuda")
+        keep.append((d_ids, d_len))
+        outs.append((d_out, d_ol, d_al))
+        args.append((d_ids.data_ptr(), d_len.data_ptr(), B, 0, 0, d_out.data_ptr(), d_ol.data_ptr(), d_al.data_ptr(), Sj))
+    for rep in range(2):
+        ctx.translate_many_device(args, S, 1.5, 0, steps_hint=max(int(np.float32(1.5) * np.float32(S)), 1), generator=gen)
+        ctx.synchronize()
+        res = [(o.cpu().numpy().view(np.uint32), l.cpu().numpy().view(np.uint32), a.cpu().numpy()) for o, l, a in outs]
+        _check(oracle, om, batches, sls, res)
+    ctx.close()
+    gen.close()
