@@ -2644,16 +2644,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     if ((unsigned)tile >= (unsigned)((B + RS - 1) / RS)) return;
   }
   const int m0 = tile * RS;
-  // merged launch (kernels.h, MergeOut): this tile lies inside sub-batch sj, whose sentences are the global ones
-  // sj_first .. Bv - 1 (the global ones up to the next sub-batch are holes: a tile of nothing but holes leaves); the caller's
-  // arrays are the sub-batch's, the workspace (K/V cache, its form bytes, SSRU cells) is indexed by the global sentence
+  // merged launch (kernels.h, MergeOut). Aligned (every sub-batch starts at a multiple of the tile: each has its own output
+  // layer): this tile lies inside sub-batch sj, whose sentences are the global ones first .. Bv - 1, the global ones up to
+  // the next sub-batch are holes, and a tile of nothing but holes leaves. Dense (one output layer for all: sub-batches
+  // follow each other without holes, a tile may hold sentences of several): Bv = B. Either way every SENTENCE finds its
+  // own sub-batch below (the caller's arrays, its padded length); the workspace (K/V cache, its form bytes, SSRU cells)
+  // is indexed by the global sentence.
   const int sj = a.n_sub ? __builtin_amdgcn_readfirstlane(merge_find(a.sub, a.n_sub, m0)) : 0;
-  const int sj_first = a.n_sub ? a.sub[sj].first : 0;
-  const int Bv = a.n_sub ? sj_first + a.sub[sj].n : B;
+  const int Bv = a.n_sub && !a.sub_dense ? a.sub[sj].first + a.sub[sj].n : B;
   if (m0 >= Bv) return;
-  // ... and a sub-batch has its own padded length: the row length of its outputs, the width of its alignment rows, its step limit
-  const int Tmx = a.n_sub ? a.sub[sj].Tmax : a.Tmax;
-  const int Sal = a.n_sub ? a.sub[sj].S : S;
   if (tid == 0) occ_trace_event(a.trace, 1, 0);
   // my cluster (CL > 1): tiles cl_first .. cl_first + cl_n - 1 (the last cluster of a batch may be short), me = member cl_m
   const int n_tiles_b = (B + RS - 1) / RS;
@@ -2667,13 +2666,23 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 
   // per-sentence state of rows wave + 16 rr, owned by wave `wave` (uniform within the wave)
   int bq[RT], len[RT];
+  int sw[RT];  // this wave's sentences' sub-batches (merged launches); what follows from them is re-read where it is needed --
+  // once per step at most -- instead of living in scalar registers across the loop (five more per sentence spilled 11
+  // vector registers in the headline's instantiation)
+#define SLIMT_SW(rr) sw[rr]
+#define SLIMT_SUB_FIRST(rr) (a.n_sub ? a.sub[SLIMT_SW(rr)].first : 0)
+#define SLIMT_SUB_TMAX(rr) (a.n_sub ? a.sub[SLIMT_SW(rr)].Tmax : a.Tmax)
+#define SLIMT_SUB_S(rr) (a.n_sub ? a.sub[SLIMT_SW(rr)].S : S)
   bool live[RT], finished[RT];
   uint32_t n_out[RT];
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     bq[rr] = m0 + 16 * rr + wave;
     live[rr] = row_wave && bq[rr] < Bv;
-    len[rr] = live[rr] ? checked_length(a.n_sub ? a.sub[sj].lengths[bq[rr] - sj_first] : a.lengths[bq[rr]], S) : 0;
+    // this sentence's sub-batch: its first global sentence, the row length of its outputs (its own padded length's
+    // limit, Model.cc:159-161), the width of its alignment rows, the steps it runs at most
+    sw[rr] = a.n_sub && live[rr] ? __builtin_amdgcn_readfirstlane(merge_find(a.sub, a.n_sub, bq[rr])) : 0;
+    len[rr] = live[rr] ? checked_length(a.n_sub ? a.sub[sw[rr]].lengths[bq[rr] - SLIMT_SUB_FIRST(rr)] : a.lengths[bq[rr]], S) : 0;
     finished[rr] = !live[rr];
     n_out[rr] = 0;
   }
@@ -2736,12 +2745,13 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     if (live[rr]) {  // outputs past a sentence's length read as zero (no memset launches)
-      uint32_t *oi = a.n_sub ? a.sub[sj].out_ids : a.out_ids;
-      float *al = a.n_sub ? a.sub[sj].align : a.align;
-      const bool staged = (a.n_sub ? a.sub[sj].align_out : a.align_out) != nullptr;
-      for (int i = lane; i < Tmx; i += 64) oi[(size_t)(bq[rr] - sj_first) * Tmx + i] = 0;
+      uint32_t *oi = a.n_sub ? a.sub[sw[rr]].out_ids : a.out_ids;
+      float *al = a.n_sub ? a.sub[sw[rr]].align : a.align;
+      const bool staged = (a.n_sub ? a.sub[sw[rr]].align_out : a.align_out) != nullptr;
+      const int Tr = SLIMT_SUB_TMAX(rr), Sr = SLIMT_SUB_S(rr), fr = SLIMT_SUB_FIRST(rr);
+      for (int i = lane; i < Tr; i += 64) oi[(size_t)(bq[rr] - fr) * Tr + i] = 0;
       if (al && !staged)
-        for (int i = lane; i < Tmx * Sal; i += 64) al[(size_t)(bq[rr] - sj_first) * Tmx * Sal + i] = 0.0f;
+        for (int i = lane; i < Tr * Sr; i += 64) al[(size_t)(bq[rr] - fr) * Tr * Sr + i] = 0.0f;
     }
     // step-0 embedding: zeros * sqrt(D) + pos(0)  (Transformer.cc:138-144,160)
 #pragma unroll
@@ -2770,7 +2780,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   // from logits[0] and only moves on `value > max`, so it stays at class 0 (Transformer.cc:287-298); the arg-max
   // below skips NaNs, so the rule is applied where the token is taken
   const bool nan0 = outw.pb[0] != outw.pb[0] || a.out.u != a.out.u;
-  const int max_steps = a.n_sub ? a.sub[sj].max_steps : a.max_steps;
+  // (a dense tile runs while any of its sentences does: each ends at its own limit below; an aligned one has one limit)
+  const int max_steps = a.n_sub && !a.sub_dense ? a.sub[sj].max_steps : a.max_steps;
   bool all_done = false;
   for (int t = 0; t < max_steps; ++t) {
     SLIMT_STAMP(0);
@@ -2911,9 +2922,11 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           ar.alpha = a.alpha;
           ar.aq_o = L.o.a_quant;
           ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
-          float *al = a.n_sub ? a.sub[sj].align : a.align;
-          const bool want_align = al && (l + 1 == Ld) && !fin && (no < Tmx);
-          ar.align = want_align ? (gf_ptr)(al + ((size_t)(b - sj_first) * Tmx + no) * Sal) : (gf_ptr) nullptr;
+          const int swr = rr ? sw[RT - 1] : sw[0];
+          const int fwr = a.n_sub ? a.sub[swr].first : 0, Tr = a.n_sub ? a.sub[swr].Tmax : a.Tmax, Sr = a.n_sub ? a.sub[swr].S : S;
+          float *al = a.n_sub ? a.sub[swr].align : a.align;
+          const bool want_align = al && (l + 1 == Ld) && !fin && (no < Tr);
+          ar.align = want_align ? (gf_ptr)(al + ((size_t)(b - fwr) * Tr + no) * Sr) : (gf_ptr) nullptr;
           if constexpr (KV24 && KVC == 4) {
             const lcf_ptr kc = (lcf_ptr)(kvpb + (4 * l) * D);
             if constexpr (!KV20) {
@@ -3419,14 +3432,16 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         // no column beat the start value (every logit NaN or -inf): class 0, where the reference's scan
         // starts and stays (Transformer.cc:287-298) -- and never an index past the shortlist
         ix = (ix == 0x7fffffff || nan0) ? 0 : ix;
-        const uint32_t *sl = a.n_sub ? a.sub[sj].shortlist : a.shortlist;
+        const uint32_t *sl = a.n_sub ? a.sub[sj].shortlist : a.shortlist;  // (one output layer per tile: the tile's sub-batch's list)
         if (live[rr]) tok = sl ? sl[ix] : (uint32_t)ix;
       }
       if (live[rr] && !finished[rr]) {  // record(), Model.cc:127-137
-        if (lane == 0 && (int)n_out[rr] < Tmx)
-          (a.n_sub ? a.sub[sj].out_ids : a.out_ids)[(size_t)(bq[rr] - sj_first) * Tmx + n_out[rr]] = tok;
+        const int Tr = SLIMT_SUB_TMAX(rr);
+        if (lane == 0 && (int)n_out[rr] < Tr)
+          (a.n_sub ? a.sub[SLIMT_SW(rr)].out_ids : a.out_ids)[(size_t)(bq[rr] - SLIMT_SUB_FIRST(rr)) * Tr + n_out[rr]] = tok;
         n_out[rr] += 1;
-        if (tok == a.eos) {
+        // (merged launches: a sentence also ends at its own sub-batch's step limit -- a tile may go on for the others)
+        if (tok == a.eos || (a.n_sub && (int)n_out[rr] >= a.sub[SLIMT_SW(rr)].max_steps)) {
           finished[rr] = true;
           if (lane == 0) atomicAdd(&flags[0], 1);
         }
@@ -3451,24 +3466,26 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   }
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr)
-    if (live[rr] && lane == 0) (a.n_sub ? a.sub[sj].out_len : a.out_len)[bq[rr] - sj_first] = n_out[rr];
-  const float *al_src = a.n_sub ? a.sub[sj].align : a.align;
-  float *al_dst = a.n_sub ? a.sub[sj].align_out : a.align_out;
-  if (al_src && al_dst) {
+    if (live[rr] && lane == 0) (a.n_sub ? a.sub[sw[rr]].out_len : a.out_len)[bq[rr] - SLIMT_SUB_FIRST(rr)] = n_out[rr];
+  {
     // staged alignment rows -> their destination (kernels.h, align_out). This wave wrote the rows it
     // reads (rows 0 .. n_out - 1, columns 0 .. len - 1); everything else is zero.
 #pragma unroll 1
     for (int rr = 0; rr < RT; ++rr) {
       if (!live[rr]) continue;
-      const size_t base = (size_t)(bq[rr] - sj_first) * Tmx * Sal;
-      const int rows_set = (int)n_out[rr] < Tmx ? (int)n_out[rr] : Tmx;
-      const int n = Tmx * Sal, ln = len[rr];
-      if (((base | (size_t)Sal) & 3) == 0 && (reinterpret_cast<size_t>(al_dst) & 15) == 0 &&
+      const float *al_src = a.n_sub ? a.sub[sw[rr]].align : a.align;
+      float *al_dst = a.n_sub ? a.sub[sw[rr]].align_out : a.align_out;
+      if (!al_src || !al_dst) continue;
+      const int Tr = SLIMT_SUB_TMAX(rr), Sr = SLIMT_SUB_S(rr);
+      const size_t base = (size_t)(bq[rr] - SLIMT_SUB_FIRST(rr)) * Tr * Sr;
+      const int rows_set = (int)n_out[rr] < Tr ? (int)n_out[rr] : Tr;
+      const int n = Tr * Sr, ln = len[rr];
+      if (((base | (size_t)Sr) & 3) == 0 && (reinterpret_cast<size_t>(al_dst) & 15) == 0 &&
           (reinterpret_cast<size_t>(al_src) & 15) == 0) {  // 16-byte pieces: four columns of one row
         const f4 *src = reinterpret_cast<const f4 *>(al_src + base);
         f4 *dst = reinterpret_cast<f4 *>(al_dst + base);
         for (int i = lane; i < n / 4; i += 64) {
-          const int row = (4 * i) / Sal, col = (4 * i) % Sal;
+          const int row = (4 * i) / Sr, col = (4 * i) % Sr;
           f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
           if (row < rows_set && col < ln) {
             v = src[i];
@@ -3480,7 +3497,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         }
       } else {
         for (int i = lane; i < n; i += 64) {
-          const int row = i / Sal, col = i % Sal;
+          const int row = i / Sr, col = i % Sr;
           al_dst[base + i] = (row < rows_set && col < ln) ? al_src[base + i] : 0.0f;
         }
       }

@@ -1432,6 +1432,7 @@ struct MergePlan {
   MergePack jobs[kMaxMerge];
   int max_N = 0;  // columns of the widest job
   size_t stride_wp = 0, stride_cs = 0, stride_pb = 0;
+  bool dense = false;  // one output layer for all sub-batches: no holes between them (kernels.h, FusedDecodeArgs::sub_dense)
 };
 
 // gen (nullable; only where fused_encoder_chosen): the batch's shortlist is generated inside the encoder launch
@@ -2071,6 +2072,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     }
     if (mp) {
       f.n_sub = mp->n;
+      f.sub_dense = mp->dense ? 1 : 0;
       for (int j = 0; j < mp->n; ++j) f.sub[j] = mp->out[j];
       f.out_stride_wp = mp->stride_wp;
       f.out_stride_cs = mp->stride_cs;
@@ -2473,10 +2475,20 @@ bool merge_supported(const slimt_hip_ctx *c, size_t rows, size_t S) {
 
 // the sub-batches' tables. align_staging (nullable): the alignment rows are staged there (global sentence order) and
 // each batch's `align` (a device view of the caller's pinned array) is where they go when a sentence ends
+// align: sub-batches start at multiples of it -- the decoder's tile where every sub-batch has its own output layer; with
+// ONE layer for all of them (one shortlist pointer and size, or the full vocabulary) they follow each other densely
+// whatever it says
 int build_merge_plan(const slimt_hip_ctx *c, const slimt_hip_batch *b, size_t n, size_t S, size_t Tmax, float limit_factor,
-                     int steps_hint, float *align_staging, MergePlan &mp, size_t &rows) {
+                     int steps_hint, float *align_staging, MergePlan &mp, size_t &rows, size_t align = kMergeAlign) {
   mp.n = (int)n;
   rows = 0;
+  mp.dense = true;
+  for (size_t j = 1; j < n; ++j)
+    if (b[j].shortlist != b[0].shortlist || b[j].n_shortlist != b[0].n_shortlist) mp.dense = false;
+  static const bool no_dense = std::getenv("SLIMT_MERGE_DENSE") && std::getenv("SLIMT_MERGE_DENSE")[0] == '0';  // A/B
+  if (no_dense) mp.dense = false;
+  if (mp.dense) align = 1;
+  size_t stage_at = 0;  // floats of alignment staging handed out so far (16-byte pieces: the decoder copies whole quads)
   for (size_t j = 0; j < n; ++j) {
     const size_t Sj = b[j].S ? b[j].S : S;
     if (Sj > S) return fail(-1, "batch %zu is padded to %zu tokens, the launch to %zu", j, Sj, S);
@@ -2498,8 +2510,9 @@ int build_merge_plan(const slimt_hip_ctx *c, const slimt_hip_batch *b, size_t n,
     o.out_ids = b[j].out_ids;
     o.out_len = b[j].out_len;
     if (b[j].align && align_staging) {
-      o.align = align_staging + rows * Tmax * S;
+      o.align = align_staging + stage_at;
       o.align_out = b[j].align;
+      stage_at += (b[j].B * Tj * Sj + 3) / 4 * 4;
     } else {
       o.align = b[j].align;
       o.align_out = nullptr;
@@ -2524,9 +2537,15 @@ int build_merge_plan(const slimt_hip_ctx *c, const slimt_hip_batch *b, size_t n,
       }
       o.job = job;
     }
-    rows += (b[j].B + kMergeAlign - 1) / kMergeAlign * kMergeAlign;
+    rows += (b[j].B + align - 1) / align * align;
   }
   return 0;
+}
+
+// the decoder tile a merged launch of this context will run at most: 32 sentences where the 32-sentence tiling may be
+// chosen (decode mode 3, or mode 0 with an output layer of more than 16k columns -- translate_device), else 16
+size_t merge_tile(const slimt_hip_ctx *c, size_t n_columns) {
+  return (c->decode_mode == 3 || (c->decode_mode == 0 && n_columns > 16384)) ? 32 : 16;
 }
 }  // namespace
 
@@ -2544,7 +2563,10 @@ extern "C" int slimt_hip_translate_many_device(slimt_hip_ctx *ctx, const slimt_h
   MergePlan mp;
   size_t rows = 0;
   const bool mergeable = n_batches > 1 && n_batches <= (size_t)kMaxMerge;
-  if (mergeable) RCCHK(build_merge_plan(ctx, batches, n_batches, S, Tmax, limit_factor, steps_hint, nullptr, mp, rows));
+  size_t n_cols = 0;  // the widest output layer of the launch
+  for (size_t j = 0; j < n_batches; ++j) n_cols = std::max(n_cols, batches[j].n_shortlist ? batches[j].n_shortlist : (size_t)ctx->model->V);
+  if (mergeable)
+    RCCHK(build_merge_plan(ctx, batches, n_batches, S, Tmax, limit_factor, steps_hint, nullptr, mp, rows, merge_tile(ctx, n_cols)));
   if (mergeable && rows <= ctx->max_B && rows * S <= ctx->max_M && S <= ctx->max_S && merge_supported(ctx, rows, S))
     return translate_device(ctx, batches[0].src_ids, batches[0].lengths, batches[0].shortlist, rows, S, (size_t)mp.max_N,
                             limit_factor, eos_id, batches[0].out_ids, batches[0].out_len, batches[0].align, steps_hint, nullptr,
@@ -2585,7 +2607,7 @@ extern "C" int slimt_hip_translate_many_async(slimt_hip_ctx *ctx, const slimt_hi
     dev[j].align = b.align ? static_cast<float *>(host_device_view(b.align)) : nullptr;
     if (!dev[j].src_ids || !dev[j].lengths || !dev[j].out_ids || !dev[j].out_len || (b.align && !dev[j].align)) merged = false;
     any_align = any_align || b.align != nullptr;
-    rows += (b.B + kMergeAlign - 1) / kMergeAlign * kMergeAlign;
+    rows += b.B;  // (one shortlist for all: the sub-batches follow each other densely)
   }
   merged = merged && rows <= ctx->max_B && rows * S <= ctx->max_M && merge_supported(ctx, rows, S);
   if (!merged) {
@@ -3088,8 +3110,11 @@ int translate_many_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const 
   const size_t V = (size_t)m->V;
   size_t rows = 0;
   bool any_align = false;
+  uint32_t *hint = reinterpret_cast<uint32_t *>(ctx->n_finished_host) + 1;  // (translate_generated: the previous shortlist's size)
+  const size_t n_hint = *hint;
+  const size_t tile = merge_tile(ctx, n_hint ? n_hint : V);  // (translate_device picks the decoder tiling from the same number)
   for (size_t j = 0; j < n; ++j) {
-    rows += (dev[j].B + kMergeAlign - 1) / kMergeAlign * kMergeAlign;
+    rows += (dev[j].B + tile - 1) / tile * tile;
     any_align = any_align || dev[j].align != nullptr;
   }
   static const bool fold = !(std::getenv("SLIMT_SHORTLIST_FOLD") && std::getenv("SLIMT_SHORTLIST_FOLD")[0] == '0');
@@ -3132,11 +3157,9 @@ int translate_many_generated(slimt_hip_ctx *ctx, slimt_hip_shortlist *sl, const 
   }
   if (any_align && stage_align) HIPCHK(ctx->align.reserve(align_staging_bytes(ctx, rows, S, Tmax, limit_factor)));
   MergePlan mp;
-  RCCHK(build_merge_plan(ctx, plan, n, S, Tmax, limit_factor, steps_hint, any_align && stage_align ? ctx->align.as<float>() : nullptr, mp, rows));
+  RCCHK(build_merge_plan(ctx, plan, n, S, Tmax, limit_factor, steps_hint, any_align && stage_align ? ctx->align.as<float>() : nullptr, mp, rows, tile));
   ShortlistArgs a;
   shortlist_args(sl, plan[0].src_ids, plan[0].lengths, plan[0].B, S, ctx->shortlist.as<uint32_t>(), ctx->n_sl_dev.as<uint32_t>(), a);
-  uint32_t *hint = reinterpret_cast<uint32_t *>(ctx->n_finished_host) + 1;  // (translate_generated: the previous shortlist's size)
-  const size_t n_hint = *hint;
   void *hint_dev = nullptr;
   if (hipHostGetDevicePointer(&hint_dev, hint, 0) == hipSuccess) a.n_out_host = static_cast<uint32_t *>(hint_dev);
   (void)st;

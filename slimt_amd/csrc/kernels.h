@@ -266,10 +266,11 @@ hipError_t launch_dqattn(const DQAttnArgs &a, hipStream_t st);
 // Several batches of ONE padded source length share an encoder and a decoder launch: what k concurrent Model::forward
 // calls of k workers are in the reference (Frontend.cc:207-227; its default batches are 1024 padded tokens,
 // Frontend.hh:21-39 -- 32 sentences at S = 32 --, far too few to fill 256 CUs one batch per launch pair). The launch sees
-// ONE batch of `B` global sentences; sub-batch j owns the global sentences first[j] .. first[j] + n[j] - 1, first[j] a
-// multiple of 32 (so every decoder tile of 4 / 8 / 16 / 32 sentences lies inside one sub-batch: a tile has ONE output
-// layer and ONE set of output arrays), and the global sentences in between are HOLES: the encoder runs them as empty
-// sentences of pad tokens (their cache slots exist; nothing of the caller's is read), the decoder never owns them.
+// ONE batch of `B` global sentences; sub-batch j owns the global sentences first[j] .. first[j] + n[j] - 1. When the
+// sub-batches have output layers of their own (different shortlists), first[j] is a multiple of the decoder's tile (16,
+// or 32 where the 32-sentence tiling may run) -- a tile has ONE output layer --, and the global sentences in between are
+// HOLES: the encoder runs them as empty sentences of pad tokens (their cache slots exist; nothing of the caller's is
+// read), the decoder never owns them. When all share one layer they follow each other densely (FusedDecodeArgs::sub_dense).
 // The K/V cache, its form bytes and every other per-sentence workspace are indexed by the global sentence; only the
 // caller's arrays go through these tables, which travel in the kernel arguments (no copy, no helper launch).
 // A sentence's arithmetic never depends on its neighbours, so each sub-batch's results are those of its own call.
@@ -409,6 +410,10 @@ struct FusedDecodeArgs {
   // then NOT used (each tile takes its sub-batch's); the packed output layer of job j: Wp, colsum (+ pair constants), pb of
   // `out` moved by j strides (bytes)
   int n_sub = 0;
+  // sub_dense: the sub-batches share ONE output layer (one shortlist for all, or the full vocabulary) and follow each other
+  // without holes -- a tile may then hold sentences of several (each wave finds its sentence's own); else every sub-batch
+  // starts at a multiple of the tile (a tile has one output layer) and the sentences in between are holes
+  int sub_dense = 0;
   MergeOut sub[kMaxMerge];
   size_t out_stride_wp = 0, out_stride_cs = 0, out_stride_pb = 0;
   bool ln_in_lds = false;  // set by the launcher: the LayerNorm constants of all layers fit LDS beside the rest
