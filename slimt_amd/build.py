@@ -20,7 +20,8 @@ LIB_PATH = os.environ.get("SLIMT_HIP_LIB") or os.path.join(LIB_DIR, "libslimt_hi
 
 SOURCES = ["kernels.hip", "gemm_tile.hip", "decode_kernels.hip", "decode_fused.hip", "encode_fused.hip", "encode_wide.hip", "encode_tall.hip", "shortlist.hip",
            "engine.cpp"]
-HEADERS = ["kernels.h", "engine.h", "device_common.h", "shortlist_device.h", os.path.join(ROOT, "include", "slimt_hip.h")]
+HEADERS = ["kernels.h", "engine.h", "device_common.h", "shortlist_device.h", "decode_attention_packed.inl.h",
+           os.path.join(ROOT, "include", "slimt_hip.h")]
 
 # -ffp-contract=off: the float epilogues are written operation by operation
 # (separate mul/add like intgemm's callbacks); fused ops are explicit fmaf.

@@ -858,1643 +858,8 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
   }
 }
 
-// ---- packed K/V cache (FusedDecodeArgs::kv24): D = 256, d_head 32, S <= 32 -----------------
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef int v2i __attribute__((ext_vector_type(2)));
-
-// The cached cross-attention in the hoisted (PORTABLE) order -- the CPU checker under oracle/ restates it as cross_attention_portable:
-// the projections' unquantisation multiplier u and prepared bias pb are per-column constants, so they are
-// applied AFTER the sums instead of to every cached value in every step:
-//   t_j = fmaf chain over the head's columns of q_d * float(accK[j][d]);  c_h = row sum of q_d * pbK[d]
-//   s_j = alpha * fmaf(t_j, uK, c_h) + mask_j;   p = softmax(s);   P_h = row sum of p
-//   w_d = fmaf chain over the keys of p_j * float(accV[j][d]);            o_d = fmaf(w_d, uV, pbV[d] * P_h)
-// (the reference dequantises first, Intgemm.inl.cc:146-153 / Modules.cc:24-86: same reals, other roundings;
-// per value the unpack was extract + convert + half a packed multiply + half a packed add, now extract + convert).
-//
-// 12 bytes = four 24-bit accumulators accS -> float(accS * 256). A 24-bit field moved into the HIGH three bytes
-// of a register is accS * 256 as a signed integer: one v_perm / shift per value instead of extract + sign-extend,
-// and its conversion is exact (24 significant bits). The fmaf chains over 256 accS are 256 times those over accS
-// (a power of two scales every partial sum exactly), and u / 256 takes the factor out again.
-__device__ __forceinline__ f4 unpack24f(int d0, int d1, int d2) {
-  const int y0 = d0 << 8;
-  const int y1 = (int)__builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x0504030cu);
-  const int y2 = (int)__builtin_amdgcn_perm((unsigned)d2, (unsigned)d1, 0x0403020cu);
-  const int y3 = d2 & (int)0xffffff00;
-  const f4 o = {(float)y0, (float)y1, (float)y2, (float)y3};
-  return o;
-}
-
-// c_h = row sum (canonical order) of q_d * pbK[d] over head h's DH columns, for the heads this lane meets in the
-// score passes. DH = 32, D = 256: lane l holds column l + 64 i of head 2 i + (l >> 5) -- the head of pass i in
-// the two-heads-per-pass forms, whose lanes of half hh score head 2 i + hh: no shuffle at all.
-__device__ __forceinline__ void head_constants32(lcf_ptr q, lcf_ptr pbk, int lane, float (&c)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) c[i] = half_sum(q[lane + 64 * i] * pbk[lane + 64 * i]);
-}
-
-// attention_row's S <= 32, d_head 32 form over the packed cache (layout: kernels.h, kv24): same
-// passes, same order of every float operation; 16 cached values arrive as three 16-byte loads
-// (one per plane), i.e. 6 instead of 8 K loads per score pass and 3 instead of 4 V loads per
-// four keys. pbk / pbv: the K / V projections' prepared biases [D] in LDS.
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row24(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256,
-                                                float uv256) {
-  constexpr int D = 256, DH = 32, H = D / DH;
-  const int S = r.S, len = r.len;
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int hh = lane >> 5, j = lane & 31;
-  const int jc = j < S ? j : S - 1;
-  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-  v4i kq[6];     // this lane's key, its head's 32 columns: two chunks of three planes
-  v4i vq[3][3];  // V rows in flight: three groups of four rows (three planes each)
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 3u);
-  // masked keys are not fetched: past the descriptors a load returns zeros -- a score that the mask
-  // overrides, a value weighted by a probability that is exactly 0
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 3) >> 2) * 3072));
-  const int koff = j < lenf ? (hh * 6 * S + jc) * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
-  const int voff = lane * 16;                                            // [S/4][plane][D/4][16 B]
-  auto load_k = [&](int hp) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-#ifdef SLIMT_EXP_KV56  // bandwidth experiment only (wrong results): 5 of 6 quads, the bytes of a 20-bit cache
-      if (i == 5) { kq[5] = kq[4]; continue; }
-#endif
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((12 * hp + i) * S) * 16, KV_AUX));
-    }
-  };
-  auto load_v = [&](v4i(&vv)[3], int g) {  // rows 4 g .. 4 g + 3
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#ifdef SLIMT_EXP_KV56
-      if (i == 2 && (g & 1)) { vv[2] = vv[1]; continue; }
-#endif
-      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + i) * 1024, KV_AUX));
-    }
-  };
-  // group g (12 bytes = 4 values) of the 48-byte item in planes p0, p1, p2
-  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g) -> f4 {
-    const int w[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-    return unpack24f(w[3 * g], w[3 * g + 1], w[3 * g + 2]);
-  };
-  load_k(0);
-  load_v(vq[0], 0);
-  __builtin_amdgcn_sched_barrier(0);
-  float ck[4];  // c_h of this lane's head in pass hp (under the first loads' round trip)
-  head_constants32(r.qrow, pbk, lane, ck);
-#pragma unroll
-  for (int hp = 0; hp < H / 2; ++hp) {
-    const int h = 2 * hp + hh;
-    float t = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = h * DH + 16 * c + 4 * g;
-        const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
-        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g);
-        t = __builtin_fmaf(q4.x, kk.x, t);
-        t = __builtin_fmaf(q4.y, kk.y, t);
-        t = __builtin_fmaf(q4.z, kk.z, t);
-        t = __builtin_fmaf(q4.w, kk.w, t);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // at most one chunk's q reads from LDS in flight
-    }
-    if (hp + 1 < H / 2) {
-      load_k(hp + 1);
-    } else {  // the K registers are free: two more groups of V rows
-      load_v(vq[1], 1);
-      load_v(vq[2], 2);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float s = __builtin_fmaf(t, uk256, ck[hp]);
-    if (r.alpha != 1.0f) s = r.alpha * s;
-    s = s + mask;
-    if (j >= S) s = lowest;
-    const float m = half_max(s);
-    const float e = j < S ? exp_p(s - m) : 0.0f;
-    const float sum = half_sum(e);
-    const float p = e / sum;  // keys >= S: exactly 0
-    const float ps = half_sum(p);  // P_h
-    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
-    if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
-    r.pbuf[h * 32 + j] = p;
-    if (j == 0) r.hsum[h] = ps;
-  }
-  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
-  const int ph = (lane >> 3) * 32;
-  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
-  const float P = r.hsum[lane >> 3];
-  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};  // columns (0, 1) and (2, 3): v_pk_fma_f32 is one fma per column
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    v4i(&cur)[3] = vq[g % 3];
-    const f4 p4 = *(lcf4_ptr)(r.pbuf + ph + 4 * g);
-    const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
-      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c);
-      const f2 pp = {pj[c], pj[c]}, va = {v4.x, v4.y}, vb = {v4.z, v4.w};
-      oa = __builtin_elementwise_fma(pp, va, oa);
-      ob = __builtin_elementwise_fma(pp, vb, ob);
-    }
-    // pin this group's sums here: the unpack + fma chains are pure arithmetic, and without a use
-    // the optimiser sinks all eight groups' work below the last load -- 96 registers of packed
-    // rows live at once (seen as 134 spilled VGPRs)
-    asm volatile("" : "+v"(oa), "+v"(ob));
-    if (g + 3 < 8) load_v(vq[g % 3], g + 3);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const float o0 = __builtin_fmaf(oa.x, uv256, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv256, pv4.y * P);
-  const float o2 = __builtin_fmaf(ob.x, uv256, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv256, pv4.w * P);
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-}
-
-// attention_row24 out of line: where the narrow form below is the expected one, the 24-bit form is the fallback of the
-// rare sentence-layer with an accumulator past 2^19 -- as a second inlined copy of the attention it costs every
-// sentence registers (the kernel's allocation is the maximum over both paths); as a call it costs the rare one a few
-// saved registers.
-template <int KV_AUX>
-__device__ __noinline__ void attention_row24_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256, float uv256) {
-  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
-  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
-  r.S = __builtin_amdgcn_readfirstlane(r.S);
-  r.len = __builtin_amdgcn_readfirstlane(r.len);
-  attention_row24<KV_AUX>(r, lane, pbk, pbv, uk256, uv256);
-}
-
-// ---- the narrow form of the packed cache: 20 bits per value (kernels.h, FusedDecodeArgs::kv_fmt) -------------------
-// A sentence-layer whose K and V accumulators all lie in [-2^19, 2^19) is cached as hi = accS >> 4 (16 bits) and
-// lo = accS & 15 (4 bits): 2.5 instead of 3 bytes per value, 5 instead of 6 sixteen-byte loads per 32 values -- the
-// K/V stream is what a loaded decoder step waits for (timing-only build with 5 of 6 quads: + 5 % tokens/s). Eight
-// values = one quad of hi halves + one dword of lo nibbles (device_common.h, pack20). Three bit operations per EIGHT
-// values move the nibbles into the high halves of bytes (f0: even values, f1: odd ones); then one v_perm per value
-// builds {hi byte 1, hi byte 0, lo << 4, 0} = accS << 12, whose conversion is exact (20 significant bits) -- the
-// 24-bit form's one extract per value, + 3/8 of an instruction. The chains run 4096 times the accumulators' (exact,
-// a power of two), and u / 4096 takes the factor out: the same floats as from the 24-bit and the f32 form.
-struct Lo20 {
-  unsigned f0, f1;
-};
-__device__ __forceinline__ Lo20 expand20(int lo) {
-  Lo20 e;
-  e.f1 = (unsigned)lo & 0xf0f0f0f0u;
-  e.f0 = ((unsigned)lo << 4) & 0xf0f0f0f0u;
-  return e;
-}
-template <int C>  // value C (0..7) of a quad
-__device__ __forceinline__ float unpack20(const v4i &hi, const Lo20 &e) {
-  constexpr int k = C >> 1, n = C & 1;
-  const unsigned hw = (unsigned)(k == 0 ? hi.x : k == 1 ? hi.y : k == 2 ? hi.z : hi.w);
-  constexpr unsigned sel = ((4u + 2 * n + 1) << 24) | ((4u + 2 * n) << 16) | ((unsigned)k << 8) | 0x0cu;
-  return (float)(int)__builtin_amdgcn_perm(hw, n ? e.f1 : e.f0, sel);
-}
-
-// attention_row24 over the narrow form (S <= 32, d_head 32, D = 256): the same passes and the same order of every
-// float operation. Layouts (per sentence, in the slot the 24-bit form would take):
-//   K [head][plane 0..4][S][16 B]         planes 0..3: hi halves of the head's columns 8 p .. 8 p + 7 of one key,
-//                                          plane 4: the lo nibbles of all 32 (dword p belongs to plane p)
-//   V [ceil(S / 8)][plane 0..4][D/4][16 B] planes 0..3: keys 8 g + 2 p, 8 g + 2 p + 1 x 4 consecutive columns
-//                                          (key-major), plane 4: their lo nibbles (dword p belongs to plane p)
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row20(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096,
-                                                float uv4096) {
-  constexpr int D = 256, DH = 32, H = D / DH;
-  const int S = r.S, len = r.len;
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int hh = lane >> 5, j = lane & 31;
-  const int jc = j < S ? j : S - 1;
-  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-  v4i kq[5];     // this lane's key, its head's 32 columns
-  v4i vq[2][5];  // V rows in flight: two groups of eight rows
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 640));
-  // masked keys are not fetched: past the descriptors a load returns zeros -- a score that the mask
-  // overrides, a value weighted by a probability that is exactly 0
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 5120));
-  const int koff = j < lenf ? (hh * 5 * S + jc) * 16 : kPastDescriptor;
-  const int voff = lane * 16;
-  auto load_k = [&](int hp) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((10 * hp + i) * S) * 16, KV_AUX));
-  };
-  auto load_v = [&](v4i(&vv)[5], int g) {  // rows 8 g .. 8 g + 7
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (5 * g + i) * 1024, KV_AUX));
-  };
-  load_k(0);
-  load_v(vq[0], 0);
-  __builtin_amdgcn_sched_barrier(0);
-  float ck[4];  // c_h of this lane's head in pass hp (under the first loads' round trip)
-  head_constants32(r.qrow, pbk, lane, ck);
-#pragma unroll
-  for (int hp = 0; hp < H / 2; ++hp) {
-    const int h = 2 * hp + hh;
-    float t = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d0 = h * DH + 8 * i;
-      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
-      const int lo[4] = {kq[4].x, kq[4].y, kq[4].z, kq[4].w};
-      const Lo20 e = expand20(lo[i]);
-      t = __builtin_fmaf(qa.x, unpack20<0>(kq[i], e), t);
-      t = __builtin_fmaf(qa.y, unpack20<1>(kq[i], e), t);
-      t = __builtin_fmaf(qa.z, unpack20<2>(kq[i], e), t);
-      t = __builtin_fmaf(qa.w, unpack20<3>(kq[i], e), t);
-      t = __builtin_fmaf(qb.x, unpack20<4>(kq[i], e), t);
-      t = __builtin_fmaf(qb.y, unpack20<5>(kq[i], e), t);
-      t = __builtin_fmaf(qb.z, unpack20<6>(kq[i], e), t);
-      t = __builtin_fmaf(qb.w, unpack20<7>(kq[i], e), t);
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);  // at most sixteen q values from LDS in flight
-    }
-    if (hp + 1 < H / 2) {
-      load_k(hp + 1);
-    } else {  // the K registers are free: the second group of V rows
-      load_v(vq[1], 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float s = __builtin_fmaf(t, uk4096, ck[hp]);
-    if (r.alpha != 1.0f) s = r.alpha * s;
-    s = s + mask;
-    if (j >= S) s = lowest;
-    const float m = half_max(s);
-    const float e = j < S ? exp_p(s - m) : 0.0f;
-    const float sum = half_sum(e);
-    const float p = e / sum;  // keys >= S: exactly 0
-    const float ps = half_sum(p);  // P_h
-    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
-    if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
-    r.pbuf[h * 32 + j] = p;
-    if (j == 0) r.hsum[h] = ps;
-  }
-  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
-  const int ph = (lane >> 3) * 32;
-  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
-  const float P = r.hsum[lane >> 3];
-  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};  // columns (0, 1) and (2, 3): v_pk_fma_f32 is one fma per column
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    v4i(&cur)[5] = vq[g & 1];
-    const int lo[4] = {cur[4].x, cur[4].y, cur[4].z, cur[4].w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
-      const Lo20 e = expand20(lo[c]);
-      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);  // (two at a time: eight would be eight registers)
-      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
-      const f2 va0 = {unpack20<0>(cur[c], e), unpack20<1>(cur[c], e)}, vb0 = {unpack20<2>(cur[c], e), unpack20<3>(cur[c], e)};
-      const f2 va1 = {unpack20<4>(cur[c], e), unpack20<5>(cur[c], e)}, vb1 = {unpack20<6>(cur[c], e), unpack20<7>(cur[c], e)};
-      oa = __builtin_elementwise_fma(p0, va0, oa);
-      ob = __builtin_elementwise_fma(p0, vb0, ob);
-      oa = __builtin_elementwise_fma(p1, va1, oa);
-      ob = __builtin_elementwise_fma(p1, vb1, ob);
-    }
-    // pin this group's sums here (attention_row24: without a use the optimiser sinks every group's work below the last load)
-    asm volatile("" : "+v"(oa), "+v"(ob));
-    if (g + 2 < 4) load_v(vq[g & 1], g + 2);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const float o0 = __builtin_fmaf(oa.x, uv4096, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv4096, pv4.y * P);
-  const float o2 = __builtin_fmaf(ob.x, uv4096, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv4096, pv4.w * P);
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-}
-
-// attention_row20 out of line (see attention_row24_cold): the fallback of the tight form (the KVI = 16 kernels).
-template <int KV_AUX>
-__device__ __noinline__ void attention_row20_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096, float uv4096) {
-  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
-  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
-  r.S = __builtin_amdgcn_readfirstlane(r.S);
-  r.len = __builtin_amdgcn_readfirstlane(r.len);
-  attention_row20<KV_AUX>(r, lane, pbk, pbv, uk4096, uv4096);
-}
-
-// ---- the tight form of the packed cache: 16 bits per value (kernels.h, FusedDecodeArgs::kv_fmt == 2) ------------------
-// A sentence-layer whose K and V accumulators, less their columns' centres (r = accS - centre[d]; kernels.h,
-// FusedDecodeArgs::kv_centre: the column means of a calibration batch), all lie in [-2^15, 2^15) is cached as plain
-// int16: 2 instead of 2.5 bytes per value, 4 instead of 5 loads per 32 values, and the cheapest unpack of the three
-// forms -- the conversion reads its half of the register itself (v_cvt_f32_i32 with an SDWA word select: no extract at
-// all), and float(accS) = float(r) + float(centre) is one EXACT addition (both floats are integers, their sum is accS,
-// everything below 2^24), half a packed add per value: 1.5 instructions per value where the 20-bit form spends 2.4 and
-// the 24-bit one 2. The centres live in LDS as floats next to the prepared biases (their reads cost nothing measurable:
-// profiles/r05_kv16_variants.txt). The chains then run over float(accS) itself (no power of two to take out: plain u).
-// This is the ONE form inlined in its kernels (KVI = 16); the 20- and the 24-bit ones are out-of-line fallbacks there:
-// a second inlined body costs the register allocator 11..26 spilled registers and a third of the form's gain (same file).
-//   K [head][plane 0..3][S][16 B]            plane p: the head's columns 8 p .. 8 p + 7 of one key (eight int16)
-//   V [ceil(S / 8)][plane 0..3][D/4][16 B]   plane p: keys 8 g + 2 p, 8 g + 2 p + 1 x 4 consecutive columns (key-major)
-// ck / cv: the centres of the K / V projection [D] in LDS, as floats.
-struct CentreLds {
-  lcf_ptr p;
-  __device__ __forceinline__ f4 at4(int d) const { return *(lcf4_ptr)(p + d); }
-};
-struct CentreGlobal {  // the V pass reads its four once per row: where LDS is short (the 32-sentence tiling) they stay in global memory
-  const int *p;
-  __device__ __forceinline__ f4 at4(int d) const {
-    const v4i c = *reinterpret_cast<const v4i *>(p + d);
-    return f4{(float)c.x, (float)c.y, (float)c.z, (float)c.w};
-  }
-};
-template <int KV_AUX, typename CentresK, typename CentresV>
-__device__ __forceinline__ void attention_row16(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, CentresK ck, CentresV cv) {
-  constexpr int D = 256, DH = 32, H = D / DH;
-  const int S = r.S, len = r.len;
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int hh = lane >> 5, j = lane & 31;
-  const int jc = j < S ? j : S - 1;
-  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-  v4i kq[4];     // this lane's key, its head's 32 columns
-  v4i vq[2][4];  // V rows in flight: two groups of eight rows
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 512));
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 4096));
-  // (masked keys are not fetched: zeros past the descriptors -- a score the mask overrides, a value weighted by exactly 0)
-  const int koff = j < lenf ? (hh * 4 * S + jc) * 16 : kPastDescriptor;
-  const int voff = lane * 16;
-  auto load_k = [&](int hp) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((8 * hp + i) * S) * 16, KV_AUX));
-  };
-  auto load_v = [&](v4i(&vv)[4], int g) {  // rows 8 g .. 8 g + 7
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (4 * g + i) * 1024, KV_AUX));
-  };
-  // two int16 of one register -> float(accS) of the two columns / keys: conversion in place + the column's centre (exact)
-  auto pair16 = [](int d, f2 c) -> f2 {
-    const f2 v = {(float)(short)(d & 0xffff), (float)(d >> 16)};
-    return v + c;
-  };
-  load_k(0);
-  load_v(vq[0], 0);
-  __builtin_amdgcn_sched_barrier(0);
-  float ckh[4];  // c_h of this lane's head in pass hp (under the first loads' round trip)
-  head_constants32(r.qrow, pbk, lane, ckh);
-#pragma unroll
-  for (int hp = 0; hp < H / 2; ++hp) {
-    const int h = 2 * hp + hh;
-    float t = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d0 = h * DH + 8 * i;
-      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
-#ifdef SLIMT_EXP_C127_CONST  // timing only (wrong results): the K pass without its column terms' LDS reads
-      const f4 ca = {1024.0f, 2048.0f, 1024.0f, 2048.0f}, cb = ca;
-#else
-      const f4 ca = ck.at4(d0), cb = ck.at4(d0 + 4);
-#endif
-      const f2 k01 = pair16(kq[i].x, f2{ca.x, ca.y}), k23 = pair16(kq[i].y, f2{ca.z, ca.w});
-      const f2 k45 = pair16(kq[i].z, f2{cb.x, cb.y}), k67 = pair16(kq[i].w, f2{cb.z, cb.w});
-      t = __builtin_fmaf(qa.x, k01.x, t);
-      t = __builtin_fmaf(qa.y, k01.y, t);
-      t = __builtin_fmaf(qa.z, k23.x, t);
-      t = __builtin_fmaf(qa.w, k23.y, t);
-      t = __builtin_fmaf(qb.x, k45.x, t);
-      t = __builtin_fmaf(qb.y, k45.y, t);
-      t = __builtin_fmaf(qb.z, k67.x, t);
-      t = __builtin_fmaf(qb.w, k67.y, t);
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);  // at most sixteen q / c values from LDS in flight
-    }
-    if (hp + 1 < H / 2) {
-      load_k(hp + 1);
-    } else {  // the K registers are free: the second group of V rows
-      load_v(vq[1], 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float s = __builtin_fmaf(t, r.uk, ckh[hp]);
-    if (r.alpha != 1.0f) s = r.alpha * s;
-    s = s + mask;
-    if (j >= S) s = lowest;
-    const float m = half_max(s);
-    const float e = j < S ? exp_p(s - m) : 0.0f;
-    const float sum = half_sum(e);
-    const float p = e / sum;  // keys >= S: exactly 0
-    const float ps = half_sum(p);  // P_h
-    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
-    if (r.align && hp == 0 && hh == 0 && j < len) r.align[j] = p;
-    r.pbuf[h * 32 + j] = p;
-    if (j == 0) r.hsum[h] = ps;
-  }
-  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
-  const int ph = (lane >> 3) * 32;
-  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
-  const f4 cv4 = cv.at4(4 * lane);
-  const f2 c01 = {cv4.x, cv4.y}, c23 = {cv4.z, cv4.w};
-  const float P = r.hsum[lane >> 3];
-  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};  // columns (0, 1) and (2, 3): v_pk_fma_f32 is one fma per column
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    v4i(&cur)[4] = vq[g & 1];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
-      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
-      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
-      oa = __builtin_elementwise_fma(p0, pair16(cur[c].x, c01), oa);
-      ob = __builtin_elementwise_fma(p0, pair16(cur[c].y, c23), ob);
-      oa = __builtin_elementwise_fma(p1, pair16(cur[c].z, c01), oa);
-      ob = __builtin_elementwise_fma(p1, pair16(cur[c].w, c23), ob);
-    }
-    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
-    if (g + 2 < 4) load_v(vq[g & 1], g + 2);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const float o0 = __builtin_fmaf(oa.x, r.uv, pv4.x * P), o1 = __builtin_fmaf(oa.y, r.uv, pv4.y * P);
-  const float o2 = __builtin_fmaf(ob.x, r.uv, pv4.z * P), o3 = __builtin_fmaf(ob.y, r.uv, pv4.w * P);
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-}
-
-// Sentences of 33..64 tokens over the packed cache (written by encode_tall_kernel<., 4>): lane =
-// key, one head per score pass (8 passes of 6 K loads), the 64-column softmax in the canonical
-// order (one element per lane, the 64-lane butterfly), all heads' probabilities in LDS
-// (pbuf: [H][64]), then V as whole rows, 4 keys per three loads, like the S <= 32 form.
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row24_mid(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256,
-                                                    float uv256) {
-  constexpr int D = 256, DH = 32, H = D / DH;
-  const int S = r.S, len = r.len;
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int j = lane;
-  const int jc = j < S ? j : S - 1;
-  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 3u);
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 3) >> 2) * 3072));
-  const int koff = j < lenf ? jc * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
-  const int voff = lane * 16;                             // [S/4][plane][D/4][16 B]
-  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g) -> f4 {
-    const int w[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-    return unpack24f(w[3 * g], w[3 * g + 1], w[3 * g + 2]);
-  };
-  v4i kq[6];
-  auto load_k = [&](int h) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((6 * h + i) * S) * 16, KV_AUX));
-  };
-  load_k(0);
-  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
-    float ck[4];
-    head_constants32(r.qrow, pbk, lane, ck);
-    if ((lane & 31) == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ck[i];
-    }
-  }
-#pragma unroll 1
-  for (int h = 0; h < H; ++h) {
-    float t = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = h * DH + 16 * c + 4 * g;
-        const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
-        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g);
-        t = __builtin_fmaf(q4.x, kk.x, t);
-        t = __builtin_fmaf(q4.y, kk.y, t);
-        t = __builtin_fmaf(q4.z, kk.z, t);
-        t = __builtin_fmaf(q4.w, kk.w, t);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    load_k(h + 1 < H ? h + 1 : h);  // the next head's keys travel under this head's softmax
-    __builtin_amdgcn_sched_barrier(0);
-    float s = __builtin_fmaf(t, uk256, r.hsum[8 + h]);
-    if (r.alpha != 1.0f) s = r.alpha * s;
-    s = s + mask;
-    if (j >= S) s = lowest;
-    const float m = wave_max(s);
-    const float e = j < S ? exp_p(s - m) : 0.0f;
-    const float sum = wave_sum(e);
-    const float p = e / sum;  // keys >= S: exactly 0
-    const float ps = wave_sum(p);  // P_h
-    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
-    if (r.align && h == 0 && j < len) r.align[j] = p;
-    r.pbuf[h * 64 + j] = p;
-    if (lane == 0) r.hsum[h] = ps;
-  }
-  v4i vq[3][3];  // V rows in flight: three groups of four rows (three planes each)
-  auto load_v = [&](v4i(&vv)[3], int g) {  // rows 4 g .. 4 g + 3
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + i) * 1024, KV_AUX));
-  };
-  load_v(vq[0], 0);
-  load_v(vq[1], 1);
-  load_v(vq[2], 2);
-  __builtin_amdgcn_sched_barrier(0);
-  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
-  const int ph = (lane >> 3) * 64;
-  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
-  const float P = r.hsum[lane >> 3];
-  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    v4i(&cur)[3] = vq[g % 3];
-    const f4 p4 = *(lcf4_ptr)(r.pbuf + ph + 4 * g);
-    const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
-      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c);
-      const f2 pp = {pj[c], pj[c]}, va = {v4.x, v4.y}, vb = {v4.z, v4.w};
-      oa = __builtin_elementwise_fma(pp, va, oa);
-      ob = __builtin_elementwise_fma(pp, vb, ob);
-    }
-    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
-    if (g + 3 < 16) load_v(vq[g % 3], g + 3);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const float o0 = __builtin_fmaf(oa.x, uv256, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv256, pv4.y * P);
-  const float o2 = __builtin_fmaf(ob.x, uv256, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv256, pv4.w * P);
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-}
-
-// attention_row24_mid out of line (see attention_row24_cold): the fallback of the narrow form for 33..64-token sentences.
-template <int KV_AUX>
-__device__ __noinline__ void attention_row24_mid_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256, float uv256) {
-  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
-  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
-  r.S = __builtin_amdgcn_readfirstlane(r.S);
-  r.len = __builtin_amdgcn_readfirstlane(r.len);
-  attention_row24_mid<KV_AUX>(r, lane, pbk, pbv, uk256, uv256);
-}
-
-// attention_row24_mid over the narrow form (33..64-token sentences, written by encode_tall_kernel<., 4>): the layouts of
-// attention_row20 (K [head][plane 0..4][S][16 B], V [ceil(S / 8)][plane 0..4][D/4][16 B]), the passes of the 24-bit
-// mid form: lane = key, one head per score pass, the 64-column softmax in the canonical order, V as whole rows.
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row20_mid(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096,
-                                                    float uv4096) {
-  constexpr int D = 256, DH = 32, H = D / DH;
-  const int S = r.S, len = r.len;
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int j = lane;
-  const int jc = j < S ? j : S - 1;
-  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 640));
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 5120));
-  const int koff = j < lenf ? jc * 16 : kPastDescriptor;
-  const int voff = lane * 16;
-  v4i kq[5];
-  auto load_k = [&](int h) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((5 * h + i) * S) * 16, KV_AUX));
-  };
-  load_k(0);
-  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
-    float ck[4];
-    head_constants32(r.qrow, pbk, lane, ck);
-    if ((lane & 31) == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ck[i];
-    }
-  }
-#pragma unroll 1
-  for (int h = 0; h < H; ++h) {
-    float t = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d0 = h * DH + 8 * i;
-      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
-      const int lo[4] = {kq[4].x, kq[4].y, kq[4].z, kq[4].w};
-      const Lo20 e = expand20(lo[i]);
-      t = __builtin_fmaf(qa.x, unpack20<0>(kq[i], e), t);
-      t = __builtin_fmaf(qa.y, unpack20<1>(kq[i], e), t);
-      t = __builtin_fmaf(qa.z, unpack20<2>(kq[i], e), t);
-      t = __builtin_fmaf(qa.w, unpack20<3>(kq[i], e), t);
-      t = __builtin_fmaf(qb.x, unpack20<4>(kq[i], e), t);
-      t = __builtin_fmaf(qb.y, unpack20<5>(kq[i], e), t);
-      t = __builtin_fmaf(qb.z, unpack20<6>(kq[i], e), t);
-      t = __builtin_fmaf(qb.w, unpack20<7>(kq[i], e), t);
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    load_k(h + 1 < H ? h + 1 : h);  // the next head's keys travel under this head's softmax
-    __builtin_amdgcn_sched_barrier(0);
-    float s = __builtin_fmaf(t, uk4096, r.hsum[8 + h]);
-    if (r.alpha != 1.0f) s = r.alpha * s;
-    s = s + mask;
-    if (j >= S) s = lowest;
-    const float m = wave_max(s);
-    const float e = j < S ? exp_p(s - m) : 0.0f;
-    const float sum = wave_sum(e);
-    const float p = e / sum;  // keys >= S: exactly 0
-    const float ps = wave_sum(p);  // P_h
-    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
-    if (r.align && h == 0 && j < len) r.align[j] = p;
-    r.pbuf[h * 64 + j] = p;
-    if (lane == 0) r.hsum[h] = ps;
-  }
-  v4i vq[2][5];  // V rows in flight: two groups of eight rows
-  auto load_v = [&](v4i(&vv)[5], int g) {  // rows 8 g .. 8 g + 7
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (5 * g + i) * 1024, KV_AUX));
-  };
-  load_v(vq[0], 0);
-  load_v(vq[1], 1);
-  __builtin_amdgcn_sched_barrier(0);
-  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
-  const int ph = (lane >> 3) * 64;
-  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
-  const float P = r.hsum[lane >> 3];
-  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    v4i(&cur)[5] = vq[g & 1];
-    const int lo[4] = {cur[4].x, cur[4].y, cur[4].z, cur[4].w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
-      const Lo20 e = expand20(lo[c]);
-      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
-      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
-      const f2 va0 = {unpack20<0>(cur[c], e), unpack20<1>(cur[c], e)}, vb0 = {unpack20<2>(cur[c], e), unpack20<3>(cur[c], e)};
-      const f2 va1 = {unpack20<4>(cur[c], e), unpack20<5>(cur[c], e)}, vb1 = {unpack20<6>(cur[c], e), unpack20<7>(cur[c], e)};
-      oa = __builtin_elementwise_fma(p0, va0, oa);
-      ob = __builtin_elementwise_fma(p0, vb0, ob);
-      oa = __builtin_elementwise_fma(p1, va1, oa);
-      ob = __builtin_elementwise_fma(p1, vb1, ob);
-    }
-    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
-    if (g + 2 < 8) load_v(vq[g & 1], g + 2);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const float o0 = __builtin_fmaf(oa.x, uv4096, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv4096, pv4.y * P);
-  const float o2 = __builtin_fmaf(ob.x, uv4096, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv4096, pv4.w * P);
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-}
-
-// attention_row20_mid out of line (see attention_row24_cold): the fallback of the tight form for 33..64-token sentences.
-template <int KV_AUX>
-__device__ __noinline__ void attention_row20_mid_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096, float uv4096) {
-  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
-  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
-  r.S = __builtin_amdgcn_readfirstlane(r.S);
-  r.len = __builtin_amdgcn_readfirstlane(r.len);
-  attention_row20_mid<KV_AUX>(r, lane, pbk, pbv, uk4096, uv4096);
-}
-
-// attention_row20_mid over the tight form (33..64-token sentences, written by encode_tall_kernel<., 4>): the layouts and the
-// arithmetic of attention_row16 (K [head][plane 0..3][S][16 B], V [ceil(S / 8)][plane 0..3][D/4][16 B]; int16 less the
-// column's centre), the passes of the mid forms: lane = key, one head per score pass, the 64-column softmax in the
-// canonical order, V as whole rows.
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row16_mid(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, CentreLds ck, CentreLds cv) {
-  constexpr int D = 256, DH = 32, H = D / DH;
-  const int S = r.S, len = r.len;
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int j = lane;
-  const int jc = j < S ? j : S - 1;
-  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 512));
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 4096));
-  const int koff = j < lenf ? jc * 16 : kPastDescriptor;
-  const int voff = lane * 16;
-  auto pair16 = [](int d, f2 c) -> f2 {
-    const f2 v = {(float)(short)(d & 0xffff), (float)(d >> 16)};
-    return v + c;
-  };
-  v4i kq[4];
-  auto load_k = [&](int h) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((4 * h + i) * S) * 16, KV_AUX));
-  };
-  load_k(0);
-  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
-    float ckh[4];
-    head_constants32(r.qrow, pbk, lane, ckh);
-    if ((lane & 31) == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ckh[i];
-    }
-  }
-#pragma unroll 1
-  for (int h = 0; h < H; ++h) {
-    float t = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d0 = h * DH + 8 * i;
-      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
-      const f4 ca = ck.at4(d0), cb = ck.at4(d0 + 4);
-      const f2 k01 = pair16(kq[i].x, f2{ca.x, ca.y}), k23 = pair16(kq[i].y, f2{ca.z, ca.w});
-      const f2 k45 = pair16(kq[i].z, f2{cb.x, cb.y}), k67 = pair16(kq[i].w, f2{cb.z, cb.w});
-      t = __builtin_fmaf(qa.x, k01.x, t);
-      t = __builtin_fmaf(qa.y, k01.y, t);
-      t = __builtin_fmaf(qa.z, k23.x, t);
-      t = __builtin_fmaf(qa.w, k23.y, t);
-      t = __builtin_fmaf(qb.x, k45.x, t);
-      t = __builtin_fmaf(qb.y, k45.y, t);
-      t = __builtin_fmaf(qb.z, k67.x, t);
-      t = __builtin_fmaf(qb.w, k67.y, t);
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    load_k(h + 1 < H ? h + 1 : h);  // the next head's keys travel under this head's softmax
-    __builtin_amdgcn_sched_barrier(0);
-    float s = __builtin_fmaf(t, r.uk, r.hsum[8 + h]);
-    if (r.alpha != 1.0f) s = r.alpha * s;
-    s = s + mask;
-    if (j >= S) s = lowest;
-    const float m = wave_max(s);
-    const float e = j < S ? exp_p(s - m) : 0.0f;
-    const float sum = wave_sum(e);
-    const float p = e / sum;  // keys >= S: exactly 0
-    const float ps = wave_sum(p);  // P_h
-    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
-    if (r.align && h == 0 && j < len) r.align[j] = p;
-    r.pbuf[h * 64 + j] = p;
-    if (lane == 0) r.hsum[h] = ps;
-  }
-  v4i vq[2][4];  // V rows in flight: two groups of eight rows
-  auto load_v = [&](v4i(&vv)[4], int g) {  // rows 8 g .. 8 g + 7
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (4 * g + i) * 1024, KV_AUX));
-  };
-  load_v(vq[0], 0);
-  load_v(vq[1], 1);
-  __builtin_amdgcn_sched_barrier(0);
-  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
-  const int ph = (lane >> 3) * 64;
-  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
-  const f4 cv4 = cv.at4(4 * lane);
-  const f2 c01 = {cv4.x, cv4.y}, c23 = {cv4.z, cv4.w};
-  const float P = r.hsum[lane >> 3];
-  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    v4i(&cur)[4] = vq[g & 1];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
-      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
-      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
-      oa = __builtin_elementwise_fma(p0, pair16(cur[c].x, c01), oa);
-      ob = __builtin_elementwise_fma(p0, pair16(cur[c].y, c23), ob);
-      oa = __builtin_elementwise_fma(p1, pair16(cur[c].z, c01), oa);
-      ob = __builtin_elementwise_fma(p1, pair16(cur[c].w, c23), ob);
-    }
-    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
-    if (g + 2 < 8) load_v(vq[g & 1], g + 2);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const float o0 = __builtin_fmaf(oa.x, r.uv, pv4.x * P), o1 = __builtin_fmaf(oa.y, r.uv, pv4.y * P);
-  const float o2 = __builtin_fmaf(ob.x, r.uv, pv4.z * P), o3 = __builtin_fmaf(ob.y, r.uv, pv4.w * P);
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-}
-
-// Sentences of 65..128 tokens over the packed cache (written by encode_long16_kernel): lane L holds
-// keys L and L + 64 -- one head per score pass, in two half passes of 6 K loads each --, the
-// 128-column softmax in the canonical order (lane L first adds keys L and L + 64, then the 64-lane
-// butterfly, as attention_row_long and the generic form do), all heads' probabilities in LDS
-// (pbuf: [H][128]), then V as whole rows, 4 keys per three loads, key groups past the sentence skipped.
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row24_long(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256,
-                                                     float uv256) {
-  constexpr int D = 256, DH = 32, H = D / DH;
-  const int S = __builtin_amdgcn_readfirstlane(r.S), len = __builtin_amdgcn_readfirstlane(r.len);
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int j0 = lane, j1 = lane + 64;
-  const float mask0 = (1.0f - (j0 < len ? 1.0f : 0.0f)) * minus_inf;
-  const float mask1 = (1.0f - (j1 < len ? 1.0f : 0.0f)) * minus_inf;
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 3u);
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((lenf + 3) >> 2) * 3072));
-  // masked keys are not fetched (zeros past the descriptor: the value pb, weighted by exactly 0)
-  const int koff0 = j0 < lenf ? j0 * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
-  const int koff1 = j1 < lenf ? j1 * 16 : kPastDescriptor;
-  const int voff = lane * 16;                               // [S/4][plane][D/4][16 B]
-  auto unpack_group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g) -> f4 {
-    const int w[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-    return unpack24f(w[3 * g], w[3 * g + 1], w[3 * g + 2]);
-  };
-  // Two K buffers: a half pass's keys are requested one half pass ahead (keys L + 64 of head h before
-  // keys L are scored, keys L of head h + 1 before keys L + 64 are), so that a round trip to the cache
-  // runs under 64 values' worth of unpacking instead of in front of it. No store inside the loop (the
-  // probabilities leave through LDS): loads and stores share one counter, and a conditional store
-  // would make the compiler drain every load in flight at the loop head.
-  v4i ka[6], kb[6];
-  auto load_k = [&](v4i(&kq)[6], int h, int koff) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((6 * h + i) * S) * 16, KV_AUX));
-  };
-  auto score = [&](const v4i(&kq)[6], int h) -> float {  // this lane's key against head h: the ascending-column fmaf chain t_j
-    float s = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = h * DH + 16 * c + 4 * g;
-        const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
-        const f4 kk = unpack_group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g);
-        s = __builtin_fmaf(q4.x, kk.x, s);
-        s = __builtin_fmaf(q4.y, kk.y, s);
-        s = __builtin_fmaf(q4.z, kk.z, s);
-        s = __builtin_fmaf(q4.w, kk.w, s);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    return s;
-  };
-  load_k(ka, 0, koff0);
-  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
-    float ck[4];
-    head_constants32(r.qrow, pbk, lane, ck);
-    if ((lane & 31) == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ck[i];
-    }
-  }
-  auto head = [&](int h, bool last) {
-    load_k(kb, h, koff1);
-    __builtin_amdgcn_sched_barrier(0);
-    float s0 = score(ka, h);
-    if (!last) load_k(ka, h + 1, koff0);  // (the last head requests nothing it would have to wait out again)
-    __builtin_amdgcn_sched_barrier(0);
-    float s1 = score(kb, h);
-    const float ch = r.hsum[8 + h];
-    s0 = __builtin_fmaf(s0, uk256, ch);
-    s1 = __builtin_fmaf(s1, uk256, ch);
-    if (r.alpha != 1.0f) {
-      s0 = r.alpha * s0;
-      s1 = r.alpha * s1;
-    }
-    s0 = s0 + mask0;
-    s1 = s1 + mask1;
-    if (j0 >= S) s0 = lowest;
-    if (j1 >= S) s1 = lowest;
-    const float m = wave_max(fmaxf(s0, s1));
-    const float e0 = j0 < S ? exp_p(s0 - m) : 0.0f;
-    const float e1 = j1 < S ? exp_p(s1 - m) : 0.0f;
-    const float sum = wave_sum(e0 + e1);
-    const float p0 = e0 / sum, p1 = e1 / sum;  // keys >= S: exactly 0
-    r.pbuf[h * 128 + j0] = p0;
-    r.pbuf[h * 128 + j1] = p1;
-    const float ps = wave_sum(p0 + p1);  // P_h: lane L adds keys L and L + 64, then the butterfly
-    if (lane == 0) r.hsum[h] = ps;
-  };
-#pragma unroll 1
-  for (int h = 0; h < H - 1; ++h) head(h, false);
-  head(H - 1, true);
-  constexpr int NV = 5;  // V key groups (four rows, three planes each) in flight
-  v4i vq[NV][3];
-  auto load_v = [&](v4i(&vv)[3], int g) {  // rows 4 g .. 4 g + 3 (past the descriptor: zeros)
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + i) * 1024, KV_AUX));
-  };
-  if (r.align) {  // head 0 over the sentence's own keys (update_alignment, Model.cc:84-108)
-    if (j0 < len) r.align[j0] = r.pbuf[j0];
-    if (j1 < len) r.align[j1] = r.pbuf[j1];
-  }
-  if (r.attn) {
-    for (int h = 0; h < H; ++h) {
-      if (j0 < S) r.attn[(size_t)h * S + j0] = r.pbuf[h * 128 + j0];
-      if (j1 < S) r.attn[(size_t)h * S + j1] = r.pbuf[h * 128 + j1];
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // the groups are requested in the order the loop re-requests them, nothing else behind them: the
-  // pending-load order at the loop head is then the same from both of its entries (exact waits)
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    load_v(vq[k], k);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
-  const int ph = (lane >> 3) * 128;
-  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
-  const float P = r.hsum[lane >> 3];
-  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
-  const int ng = (lenf + 3) >> 2;  // key groups that hold a key with a non-zero weight
-  auto group = [&](const v4i(&cur)[3], int g) {
-    if (g >= ng) return;  // (uniform) past the sentence: pbuf holds the next head's probabilities there
-    const f4 p4 = *(lcf4_ptr)(r.pbuf + ph + 4 * g);
-    const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
-      const f4 v4 = unpack_group(cur[0], cur[1], cur[2], c);
-      const f2 pp = {pj[c], pj[c]}, va = {v4.x, v4.y}, vb = {v4.z, v4.w};
-      oa = __builtin_elementwise_fma(pp, va, oa);
-      ob = __builtin_elementwise_fma(pp, vb, ob);
-    }
-    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
-  };
-#pragma unroll 1
-  for (int g = 0; g < ng; g += NV) {  // (groups past ng inside the last round are skipped; their rows: zeros)
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      group(vq[k], g + k);
-      load_v(vq[k], g + k + NV);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  const float o0 = __builtin_fmaf(oa.x, uv256, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv256, pv4.y * P);
-  const float o2 = __builtin_fmaf(ob.x, uv256, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv256, pv4.w * P);
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-}
-
-// attention_row24_long out of line (see attention_row24_cold): the fallback of the narrow form for 65..128-token sentences.
-template <int KV_AUX>
-__device__ __noinline__ void attention_row24_long_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk256, float uv256) {
-  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
-  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
-  attention_row24_long<KV_AUX>(r, lane, pbk, pbv, uk256, uv256);
-}
-
-// attention_row24_long over the narrow form (65..128-token sentences, written by encode_long16_kernel): the layouts of
-// attention_row20, the passes of the 24-bit long form -- lane L holds keys L and L + 64, two K buffers a half pass
-// ahead, the canonical 128-column softmax, V as whole rows in groups of eight keys, groups past the sentence skipped.
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row20_long(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096,
-                                                     float uv4096) {
-  constexpr int D = 256, DH = 32, H = D / DH;
-  const int S = __builtin_amdgcn_readfirstlane(r.S), len = __builtin_amdgcn_readfirstlane(r.len);
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int j0 = lane, j1 = lane + 64;
-  const float mask0 = (1.0f - (j0 < len ? 1.0f : 0.0f)) * minus_inf;
-  const float mask1 = (1.0f - (j1 < len ? 1.0f : 0.0f)) * minus_inf;
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 640));
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((lenf + 7) >> 3) * 5120));
-  const int koff0 = j0 < lenf ? j0 * 16 : kPastDescriptor;  // [head][plane 0..4][S][16 B]
-  const int koff1 = j1 < lenf ? j1 * 16 : kPastDescriptor;
-  const int voff = lane * 16;                               // [S/8][plane 0..4][D/4][16 B]
-  v4i ka[5], kb[5];
-  auto load_k = [&](v4i(&kq)[5], int h, int koff) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((5 * h + i) * S) * 16, KV_AUX));
-  };
-  auto score = [&](const v4i(&kq)[5], int h) -> float {  // this lane's key against head h: the ascending-column fmaf chain t_j
-    float t = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d0 = h * DH + 8 * i;
-      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
-      const int lo[4] = {kq[4].x, kq[4].y, kq[4].z, kq[4].w};
-      const Lo20 e = expand20(lo[i]);
-      t = __builtin_fmaf(qa.x, unpack20<0>(kq[i], e), t);
-      t = __builtin_fmaf(qa.y, unpack20<1>(kq[i], e), t);
-      t = __builtin_fmaf(qa.z, unpack20<2>(kq[i], e), t);
-      t = __builtin_fmaf(qa.w, unpack20<3>(kq[i], e), t);
-      t = __builtin_fmaf(qb.x, unpack20<4>(kq[i], e), t);
-      t = __builtin_fmaf(qb.y, unpack20<5>(kq[i], e), t);
-      t = __builtin_fmaf(qb.z, unpack20<6>(kq[i], e), t);
-      t = __builtin_fmaf(qb.w, unpack20<7>(kq[i], e), t);
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    return t;
-  };
-  load_k(ka, 0, koff0);
-  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
-    float ck[4];
-    head_constants32(r.qrow, pbk, lane, ck);
-    if ((lane & 31) == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ck[i];
-    }
-  }
-  auto head = [&](int h, bool last) {
-    load_k(kb, h, koff1);
-    __builtin_amdgcn_sched_barrier(0);
-    float s0 = score(ka, h);
-    if (!last) load_k(ka, h + 1, koff0);  // (the last head requests nothing it would have to wait out again)
-    __builtin_amdgcn_sched_barrier(0);
-    float s1 = score(kb, h);
-    const float ch = r.hsum[8 + h];
-    s0 = __builtin_fmaf(s0, uk4096, ch);
-    s1 = __builtin_fmaf(s1, uk4096, ch);
-    if (r.alpha != 1.0f) {
-      s0 = r.alpha * s0;
-      s1 = r.alpha * s1;
-    }
-    s0 = s0 + mask0;
-    s1 = s1 + mask1;
-    if (j0 >= S) s0 = lowest;
-    if (j1 >= S) s1 = lowest;
-    const float m = wave_max(fmaxf(s0, s1));
-    const float e0 = j0 < S ? exp_p(s0 - m) : 0.0f;
-    const float e1 = j1 < S ? exp_p(s1 - m) : 0.0f;
-    const float sum = wave_sum(e0 + e1);
-    const float p0 = e0 / sum, p1 = e1 / sum;  // keys >= S: exactly 0
-    r.pbuf[h * 128 + j0] = p0;
-    r.pbuf[h * 128 + j1] = p1;
-    const float ps = wave_sum(p0 + p1);  // P_h: lane L adds keys L and L + 64, then the butterfly
-    if (lane == 0) r.hsum[h] = ps;
-  };
-#pragma unroll 1
-  for (int h = 0; h < H - 1; ++h) head(h, false);
-  head(H - 1, true);
-  constexpr int NV = 3;  // V key groups (eight rows, five planes each) in flight
-  v4i vq[NV][5];
-  auto load_v = [&](v4i(&vv)[5], int g) {  // rows 8 g .. 8 g + 7 (past the descriptor: zeros)
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (5 * g + i) * 1024, KV_AUX));
-  };
-  if (r.align) {  // head 0 over the sentence's own keys (update_alignment, Model.cc:84-108)
-    if (j0 < len) r.align[j0] = r.pbuf[j0];
-    if (j1 < len) r.align[j1] = r.pbuf[j1];
-  }
-  if (r.attn) {
-    for (int h = 0; h < H; ++h) {
-      if (j0 < S) r.attn[(size_t)h * S + j0] = r.pbuf[h * 128 + j0];
-      if (j1 < S) r.attn[(size_t)h * S + j1] = r.pbuf[h * 128 + j1];
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    load_v(vq[k], k);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
-  const int ph = (lane >> 3) * 128;
-  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
-  const float P = r.hsum[lane >> 3];
-  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
-  const int ng = (lenf + 7) >> 3;  // key groups that hold a key with a non-zero weight
-  const int nkey = 8 * ng;         // (a group's tail past the sentence, inside the head's 128 slots: p == 0 there only up to S)
-  auto group = [&](const v4i(&cur)[5], int g) {
-    if (g >= ng) return;  // (uniform) past the sentence: pbuf holds the next head's probabilities there
-    const int lo[4] = {cur[4].x, cur[4].y, cur[4].z, cur[4].w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
-      const Lo20 e = expand20(lo[c]);
-      // keys past the head's 128 probability slots (S = 121..128 never reach them: 8 g + 7 <= 127)
-      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
-      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
-      const f2 va0 = {unpack20<0>(cur[c], e), unpack20<1>(cur[c], e)}, vb0 = {unpack20<2>(cur[c], e), unpack20<3>(cur[c], e)};
-      const f2 va1 = {unpack20<4>(cur[c], e), unpack20<5>(cur[c], e)}, vb1 = {unpack20<6>(cur[c], e), unpack20<7>(cur[c], e)};
-      oa = __builtin_elementwise_fma(p0, va0, oa);
-      ob = __builtin_elementwise_fma(p0, vb0, ob);
-      oa = __builtin_elementwise_fma(p1, va1, oa);
-      ob = __builtin_elementwise_fma(p1, vb1, ob);
-    }
-    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
-  };
-  (void)nkey;
-#pragma unroll 1
-  for (int g = 0; g < ng; g += NV) {  // (groups past ng inside the last round are skipped; their rows: zeros)
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      group(vq[k], g + k);
-      load_v(vq[k], g + k + NV);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  const float o0 = __builtin_fmaf(oa.x, uv4096, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv4096, pv4.y * P);
-  const float o2 = __builtin_fmaf(ob.x, uv4096, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv4096, pv4.w * P);
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-}
-
-// attention_row20_long out of line (see attention_row24_cold): the fallback of the tight form for 65..128-token sentences.
-template <int KV_AUX>
-__device__ __noinline__ void attention_row20_long_cold(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, float uk4096, float uv4096) {
-  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
-  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
-  attention_row20_long<KV_AUX>(r, lane, pbk, pbv, uk4096, uv4096);
-}
-
-// attention_row20_long over the tight form (65..128-token sentences, written by encode_long16_kernel): the layouts and the
-// arithmetic of attention_row16 (four int16 planes, less the column's centre), the passes of the long forms -- lane L holds
-// keys L and L + 64, two K buffers a half pass ahead, the canonical 128-column softmax, V as whole rows in groups of eight
-// keys, groups past the sentence skipped.
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row16_long(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, CentreLds ck, CentreLds cv) {
-  constexpr int D = 256, DH = 32, H = D / DH;
-  const int S = __builtin_amdgcn_readfirstlane(r.S), len = __builtin_amdgcn_readfirstlane(r.len);
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int j0 = lane, j1 = lane + 64;
-  const float mask0 = (1.0f - (j0 < len ? 1.0f : 0.0f)) * minus_inf;
-  const float mask1 = (1.0f - (j1 < len ? 1.0f : 0.0f)) * minus_inf;
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 512));
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((lenf + 7) >> 3) * 4096));
-  const int koff0 = j0 < lenf ? j0 * 16 : kPastDescriptor;  // [head][plane 0..3][S][16 B]
-  const int koff1 = j1 < lenf ? j1 * 16 : kPastDescriptor;
-  const int voff = lane * 16;                               // [S/8][plane 0..3][D/4][16 B]
-  auto pair16 = [](int d, f2 c) -> f2 {
-    const f2 v = {(float)(short)(d & 0xffff), (float)(d >> 16)};
-    return v + c;
-  };
-  v4i ka[4], kb[4];
-  auto load_k = [&](v4i(&kq)[4], int h, int koff) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((4 * h + i) * S) * 16, KV_AUX));
-  };
-  auto score = [&](const v4i(&kq)[4], int h) -> float {  // this lane's key against head h: the ascending-column fmaf chain t_j
-    float t = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d0 = h * DH + 8 * i;
-      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
-      const f4 ca = ck.at4(d0), cb = ck.at4(d0 + 4);
-      const f2 k01 = pair16(kq[i].x, f2{ca.x, ca.y}), k23 = pair16(kq[i].y, f2{ca.z, ca.w});
-      const f2 k45 = pair16(kq[i].z, f2{cb.x, cb.y}), k67 = pair16(kq[i].w, f2{cb.z, cb.w});
-      t = __builtin_fmaf(qa.x, k01.x, t);
-      t = __builtin_fmaf(qa.y, k01.y, t);
-      t = __builtin_fmaf(qa.z, k23.x, t);
-      t = __builtin_fmaf(qa.w, k23.y, t);
-      t = __builtin_fmaf(qb.x, k45.x, t);
-      t = __builtin_fmaf(qb.y, k45.y, t);
-      t = __builtin_fmaf(qb.z, k67.x, t);
-      t = __builtin_fmaf(qb.w, k67.y, t);
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    return t;
-  };
-  load_k(ka, 0, koff0);
-  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
-    float ckh[4];
-    head_constants32(r.qrow, pbk, lane, ckh);
-    if ((lane & 31) == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) r.hsum[8 + 2 * i + (lane >> 5)] = ckh[i];
-    }
-  }
-  auto head = [&](int h, bool last) {
-    load_k(kb, h, koff1);
-    __builtin_amdgcn_sched_barrier(0);
-    float s0 = score(ka, h);
-    if (!last) load_k(ka, h + 1, koff0);  // (the last head requests nothing it would have to wait out again)
-    __builtin_amdgcn_sched_barrier(0);
-    float s1 = score(kb, h);
-    const float ch = r.hsum[8 + h];
-    s0 = __builtin_fmaf(s0, r.uk, ch);
-    s1 = __builtin_fmaf(s1, r.uk, ch);
-    if (r.alpha != 1.0f) {
-      s0 = r.alpha * s0;
-      s1 = r.alpha * s1;
-    }
-    s0 = s0 + mask0;
-    s1 = s1 + mask1;
-    if (j0 >= S) s0 = lowest;
-    if (j1 >= S) s1 = lowest;
-    const float m = wave_max(fmaxf(s0, s1));
-    const float e0 = j0 < S ? exp_p(s0 - m) : 0.0f;
-    const float e1 = j1 < S ? exp_p(s1 - m) : 0.0f;
-    const float sum = wave_sum(e0 + e1);
-    const float p0 = e0 / sum, p1 = e1 / sum;  // keys >= S: exactly 0
-    r.pbuf[h * 128 + j0] = p0;
-    r.pbuf[h * 128 + j1] = p1;
-    const float ps = wave_sum(p0 + p1);  // P_h: lane L adds keys L and L + 64, then the butterfly
-    if (lane == 0) r.hsum[h] = ps;
-  };
-#pragma unroll 1
-  for (int h = 0; h < H - 1; ++h) head(h, false);
-  head(H - 1, true);
-  constexpr int NV = 3;  // V key groups (eight rows, four planes each) in flight
-  v4i vq[NV][4];
-  auto load_v = [&](v4i(&vv)[4], int g) {  // rows 8 g .. 8 g + 7 (past the descriptor: zeros)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (4 * g + i) * 1024, KV_AUX));
-  };
-  if (r.align) {  // head 0 over the sentence's own keys (update_alignment, Model.cc:84-108)
-    if (j0 < len) r.align[j0] = r.pbuf[j0];
-    if (j1 < len) r.align[j1] = r.pbuf[j1];
-  }
-  if (r.attn) {
-    for (int h = 0; h < H; ++h) {
-      if (j0 < S) r.attn[(size_t)h * S + j0] = r.pbuf[h * 128 + j0];
-      if (j1 < S) r.attn[(size_t)h * S + j1] = r.pbuf[h * 128 + j1];
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    load_v(vq[k], k);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // lane l: head l / 8, columns 4 l .. 4 l + 3; keys ascending
-  const int ph = (lane >> 3) * 128;
-  const f4 pv4 = *(lcf4_ptr)(pbv + 4 * lane);
-  const f4 cv4 = cv.at4(4 * lane);
-  const f2 c01 = {cv4.x, cv4.y}, c23 = {cv4.z, cv4.w};
-  const float P = r.hsum[lane >> 3];
-  f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
-  const int ng = (lenf + 7) >> 3;  // key groups that hold a key with a non-zero weight
-  auto group = [&](const v4i(&cur)[4], int g) {
-    if (g >= ng) return;  // (uniform) past the sentence: pbuf holds the next head's probabilities there
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
-      const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
-      const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
-      oa = __builtin_elementwise_fma(p0, pair16(cur[c].x, c01), oa);
-      ob = __builtin_elementwise_fma(p0, pair16(cur[c].y, c23), ob);
-      oa = __builtin_elementwise_fma(p1, pair16(cur[c].z, c01), oa);
-      ob = __builtin_elementwise_fma(p1, pair16(cur[c].w, c23), ob);
-    }
-    asm volatile("" : "+v"(oa), "+v"(ob));  // pin this group's sums here (see attention_row24)
-  };
-#pragma unroll 1
-  for (int g = 0; g < ng; g += NV) {  // (groups past ng inside the last round are skipped; their rows: zeros)
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      group(vq[k], g + k);
-      load_v(vq[k], g + k + NV);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  const float o0 = __builtin_fmaf(oa.x, r.uv, pv4.x * P), o1 = __builtin_fmaf(oa.y, r.uv, pv4.y * P);
-  const float o2 = __builtin_fmaf(ob.x, r.uv, pv4.z * P), o3 = __builtin_fmaf(ob.y, r.uv, pv4.w * P);
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-}
-
-// The same for D = 512, d_head 64 ("base"). At K = 512 the shifted accumulator needs 25 bits, so
-// the cache holds the SIGNED one (|acc| <= 127 * 128 * 512 < 2^23) and the column's 127 colsum term
-// comes back here: c127 = float(127 colsum * 256) is exact, and so is float(acc * 256) + c127
-// (= 256 accS, |accS| < 2^24): float(accS * 256) as unpack24f gives it, at one exact add per value.
-__device__ __forceinline__ f4 unpack24cf(int d0, int d1, int d2, f4 c127) {
-  const int y0 = d0 << 8;
-  const int y1 = (int)__builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x0504030cu);
-  const int y2 = (int)__builtin_amdgcn_perm((unsigned)d2, (unsigned)d1, 0x0403020cu);
-  const int y3 = d2 & (int)0xffffff00;
-  f2 a = {(float)y0, (float)y1}, b = {(float)y2, (float)y3};
-  const f2 ca = {c127.x, c127.y}, cb = {c127.z, c127.w};
-  a = a + ca;
-  b = b + cb;
-  const f4 o = {a.x, a.y, b.x, b.y};
-  return o;
-}
-
-// kc: LDS constants of this layer, [K pb | K c127 | V pb | V c127][D]
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr kc, float uk256, float uv256) {
-  constexpr int D = 512, DH = 64, H = D / DH;
-  const int S = r.S, len = r.len;
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int j = lane & 31;
-  const int jc = j < S ? j : S - 1;
-  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * D) * 3u);
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 3) >> 2) * (3 * (D / 4) * 16)));
-  const int koff = j < lenf ? jc * 16 : kPastDescriptor;  // [D/16][plane][S][16 B]
-  const int voff = lane * 16;                             // [S/4][plane][D/4][16 B]: slots lane and 64 + lane
-  auto group = [](const v4i &p0, const v4i &p1, const v4i &p2, int g, int w) -> int {
-    const int d[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-    return d[3 * g + w];
-  };
-  const lcf_ptr kpb = kc, kcs = kc + D, vpb = kc + 2 * D, vcs = kc + 3 * D;
-#pragma unroll 1
-  for (int h = 0; h < H; ++h) {
-    v4i kq[12];  // this lane's key, the head's 64 columns: four chunks of three planes
-#pragma unroll
-    for (int i = 0; i < 12; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((12 * h + i) * S) * 16, KV_AUX));
-    // c_h = row sum of q_d * pbK[d] over the head's 64 columns (one per lane, the canonical 64-lane butterfly)
-    const float ch = wave_sum(r.qrow[h * DH + lane] * kpb[h * DH + lane]);
-    float t = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = h * DH + 16 * c + 4 * g;
-        const f4 q4 = *(lcf4_ptr)(r.qrow + d0);
-        const f4 kk = unpack24cf(group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 0), group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 1),
-                                 group(kq[3 * c], kq[3 * c + 1], kq[3 * c + 2], g, 2), *(lcf4_ptr)(kcs + d0));
-        t = __builtin_fmaf(q4.x, kk.x, t);
-        t = __builtin_fmaf(q4.y, kk.y, t);
-        t = __builtin_fmaf(q4.z, kk.z, t);
-        t = __builtin_fmaf(q4.w, kk.w, t);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // one chunk's q / constant reads from LDS in flight
-    }
-    float s = __builtin_fmaf(t, uk256, ch);
-    if (r.alpha != 1.0f) s = r.alpha * s;
-    s = s + mask;
-    if (j >= S) s = lowest;
-    const float m = half_max(s);
-    const float e = j < S ? exp_p(s - m) : 0.0f;
-    const float sum = half_sum(e);
-    const float p = e / sum;  // keys >= S: exactly 0
-    const float ps = half_sum(p);  // P_h
-    if (lane < 32) {
-      if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
-      if (r.align && h == 0 && j < len) r.align[j] = p;
-      r.pbuf[h * 32 + j] = p;
-      if (lane == 0) r.hsum[h] = ps;
-    }
-  }
-  v4i vq[2][6];  // V rows in flight: two groups of four rows, two column slots of three planes each
-  auto load_v = [&](v4i(&vv)[6], int g) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      vv[p] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + p) * (D / 4) * 16, KV_AUX));
-      vv[3 + p] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (3 * g + p) * (D / 4) * 16 + 1024, KV_AUX));
-    }
-  };
-  load_v(vq[0], 0);
-  load_v(vq[1], 1);
-  __builtin_amdgcn_sched_barrier(0);
-  const int ph0 = (lane >> 4) * 32, ph1 = (4 + (lane >> 4)) * 32;
-  const f4 pv0 = *(lcf4_ptr)(vpb + 4 * lane), pv1 = *(lcf4_ptr)(vpb + D / 2 + 4 * lane);
-  const f4 cv0 = *(lcf4_ptr)(vcs + 4 * lane), cv1 = *(lcf4_ptr)(vcs + D / 2 + 4 * lane);
-  const float P0 = r.hsum[lane >> 4], P1 = r.hsum[4 + (lane >> 4)];
-  f2 o0a = {0.0f, 0.0f}, o0b = {0.0f, 0.0f}, o1a = {0.0f, 0.0f}, o1b = {0.0f, 0.0f};  // column pairs: one v_pk_fma_f32 each
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    v4i(&cur)[6] = vq[g % 2];
-    const f4 pa4 = *(lcf4_ptr)(r.pbuf + ph0 + 4 * g), pb4 = *(lcf4_ptr)(r.pbuf + ph1 + 4 * g);
-    const float pa[4] = {pa4.x, pa4.y, pa4.z, pa4.w}, pb_[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {  // keys >= len: p == 0, fma(0, v, o) == o
-      const f4 v0 = unpack24cf(group(cur[0], cur[1], cur[2], c, 0), group(cur[0], cur[1], cur[2], c, 1),
-                               group(cur[0], cur[1], cur[2], c, 2), cv0);
-      const f4 v1 = unpack24cf(group(cur[3], cur[4], cur[5], c, 0), group(cur[3], cur[4], cur[5], c, 1),
-                               group(cur[3], cur[4], cur[5], c, 2), cv1);
-      const f2 ppa = {pa[c], pa[c]}, ppb = {pb_[c], pb_[c]};
-      o0a = __builtin_elementwise_fma(ppa, f2{v0.x, v0.y}, o0a);
-      o0b = __builtin_elementwise_fma(ppa, f2{v0.z, v0.w}, o0b);
-      o1a = __builtin_elementwise_fma(ppb, f2{v1.x, v1.y}, o1a);
-      o1b = __builtin_elementwise_fma(ppb, f2{v1.z, v1.w}, o1b);
-    }
-    // pin this group's sums here (see attention_row24)
-    asm volatile("" : "+v"(o0a), "+v"(o0b), "+v"(o1a), "+v"(o1b));
-    if (g + 2 < 8) load_v(vq[g % 2], g + 2);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const float a0 = __builtin_fmaf(o0a.x, uv256, pv0.x * P0), a1 = __builtin_fmaf(o0a.y, uv256, pv0.y * P0);
-  const float a2 = __builtin_fmaf(o0b.x, uv256, pv0.z * P0), a3 = __builtin_fmaf(o0b.y, uv256, pv0.w * P0);
-  const float b0 = __builtin_fmaf(o1a.x, uv256, pv1.x * P1), b1 = __builtin_fmaf(o1a.y, uv256, pv1.y * P1);
-  const float b2 = __builtin_fmaf(o1b.x, uv256, pv1.z * P1), b3 = __builtin_fmaf(o1b.y, uv256, pv1.w * P1);
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) =
-      pack4(quantize1_byte(a0, r.aq_o), quantize1_byte(a1, r.aq_o), quantize1_byte(a2, r.aq_o), quantize1_byte(a3, r.aq_o));
-  *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) =
-      pack4(quantize1_byte(b0, r.aq_o), quantize1_byte(b1, r.aq_o), quantize1_byte(b2, r.aq_o), quantize1_byte(b3, r.aq_o));
-}
-
-// attention_row24_64 out of line (see attention_row24_cold): the fallback of the narrow form at D = 512.
-template <int KV_AUX>
-__device__ __noinline__ void attention_row24_64_cold(AttnRow r, int lane, lcf_ptr kc, float uk256, float uv256) {
-  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
-  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
-  r.S = __builtin_amdgcn_readfirstlane(r.S);
-  r.len = __builtin_amdgcn_readfirstlane(r.len);
-  attention_row24_64<KV_AUX>(r, lane, kc, uk256, uv256);
-}
-
-// The narrow form at D = 512 / d_head 64 (S <= 32). Unlike the 24-bit form of this shape it caches the SHIFTED
-// accumulator accS = acc + 127 colsum -- 20 bits hold it where they hold anything (|accS| < 2^19), and the attention then
-// needs no per-value column term: one v_perm + one conversion per value (+ 3/8 for the nibbles) instead of extract +
-// conversion + half a packed add, from 17 % fewer bytes. Two heads per score pass (lanes 0..31 / 32..63: the 24-bit form
-// of this shape scores one head on both halves). Same floats: float(accS) is what every form multiplies.
-//   K [head][plane 0..9][S][16 B]            planes 0..7: hi halves of the head's columns 8 p .. 8 p + 7 of one key,
-//                                             planes 8, 9: the lo nibbles of columns 0..31 / 32..63 (dword i <-> plane i / 4 + i)
-//   V [ceil(S / 8)][plane 0..4][D/4][16 B]    as at D = 256, 128 column quads per plane (a lane owns quads lane, 64 + lane)
-// kc: LDS constants of this layer, [K pb | K c127 | V pb | V c127][D] (the c127 vectors serve the 24-bit form only)
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row20_64(AttnRow r, int lane, lcf_ptr kc, float uk4096, float uv4096) {
-  constexpr int D = 512, DH = 64, H = D / DH;
-  const int S = r.S, len = r.len;
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int hh = lane >> 5, j = lane & 31;
-  const int jc = j < S ? j : S - 1;
-  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 1280));
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 10240));
-  const int koff = j < lenf ? (hh * 10 * S + jc) * 16 : kPastDescriptor;
-  const lcf_ptr kpb = kc, vpb = kc + 2 * D;
-#pragma unroll 1
-  for (int hp = 0; hp < H / 2; ++hp) {
-    const int h = 2 * hp + hh;
-    v4i kq[10];  // this lane's key, its head's 64 columns
-#pragma unroll
-    for (int i = 0; i < 10; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((20 * hp + i) * S) * 16, KV_AUX));
-    // c_h = row sum of q_d * pbK[d] over the 64 columns of this lane's head (one per lane, the canonical 64-lane
-    // butterfly; both heads of the pass, under the loads' round trip)
-    const float c0 = wave_sum(r.qrow[(2 * hp) * DH + lane] * kpb[(2 * hp) * DH + lane]);
-    const float c1 = wave_sum(r.qrow[(2 * hp + 1) * DH + lane] * kpb[(2 * hp + 1) * DH + lane]);
-    const float ch = hh ? c1 : c0;
-    float t = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int d0 = h * DH + 8 * i;
-      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
-      const v4i &lq = kq[8 + (i >> 2)];
-      const int lo[4] = {lq.x, lq.y, lq.z, lq.w};
-      const Lo20 e = expand20(lo[i & 3]);
-      t = __builtin_fmaf(qa.x, unpack20<0>(kq[i], e), t);
-      t = __builtin_fmaf(qa.y, unpack20<1>(kq[i], e), t);
-      t = __builtin_fmaf(qa.z, unpack20<2>(kq[i], e), t);
-      t = __builtin_fmaf(qa.w, unpack20<3>(kq[i], e), t);
-      t = __builtin_fmaf(qb.x, unpack20<4>(kq[i], e), t);
-      t = __builtin_fmaf(qb.y, unpack20<5>(kq[i], e), t);
-      t = __builtin_fmaf(qb.z, unpack20<6>(kq[i], e), t);
-      t = __builtin_fmaf(qb.w, unpack20<7>(kq[i], e), t);
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);  // at most sixteen q values from LDS in flight
-    }
-    float s = __builtin_fmaf(t, uk4096, ch);
-    if (r.alpha != 1.0f) s = r.alpha * s;
-    s = s + mask;
-    if (j >= S) s = lowest;
-    const float m = half_max(s);
-    const float e = j < S ? exp_p(s - m) : 0.0f;
-    const float sum = half_sum(e);
-    const float p = e / sum;  // keys >= S: exactly 0
-    const float ps = half_sum(p);  // P_h
-    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
-    if (r.align && h == 0 && j < len) r.align[j] = p;
-    r.pbuf[h * 32 + j] = p;
-    if (j == 0) r.hsum[h] = ps;
-  }
-  // V: a lane owns column quads `lane` (head lane / 16) and 64 + lane (head 4 + lane / 16): two independent passes over
-  // the keys, each with two groups of eight rows in flight
-  int packed[2];
-#pragma unroll
-  for (int slot = 0; slot < 2; ++slot) {
-    const int voff = (slot * 64 + lane) * 16;
-    v4i vq[2][5];
-    auto load_v = [&](v4i(&vv)[5], int g) {  // rows 8 g .. 8 g + 7
-#pragma unroll
-      for (int i = 0; i < 5; ++i)
-        vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (5 * g + i) * 2048, KV_AUX));
-    };
-    load_v(vq[0], 0);
-    load_v(vq[1], 1);
-    __builtin_amdgcn_sched_barrier(0);
-    const int head = 4 * slot + (lane >> 4);
-    const int ph = head * 32;
-    const f4 pv4 = *(lcf4_ptr)(vpb + slot * (D / 2) + 4 * lane);
-    const float P = r.hsum[head];
-    f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      v4i(&cur)[5] = vq[g & 1];
-      const int lo[4] = {cur[4].x, cur[4].y, cur[4].z, cur[4].w};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
-        const Lo20 e = expand20(lo[c]);
-        const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
-        const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
-        const f2 va0 = {unpack20<0>(cur[c], e), unpack20<1>(cur[c], e)}, vb0 = {unpack20<2>(cur[c], e), unpack20<3>(cur[c], e)};
-        const f2 va1 = {unpack20<4>(cur[c], e), unpack20<5>(cur[c], e)}, vb1 = {unpack20<6>(cur[c], e), unpack20<7>(cur[c], e)};
-        oa = __builtin_elementwise_fma(p0, va0, oa);
-        ob = __builtin_elementwise_fma(p0, vb0, ob);
-        oa = __builtin_elementwise_fma(p1, va1, oa);
-        ob = __builtin_elementwise_fma(p1, vb1, ob);
-      }
-      asm volatile("" : "+v"(oa), "+v"(ob));  // (attention_row24: keeps a group's work next to its loads)
-      if (g + 2 < 4) load_v(vq[g & 1], g + 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const float o0 = __builtin_fmaf(oa.x, uv4096, pv4.x * P), o1 = __builtin_fmaf(oa.y, uv4096, pv4.y * P);
-    const float o2 = __builtin_fmaf(ob.x, uv4096, pv4.z * P), o3 = __builtin_fmaf(ob.y, uv4096, pv4.w * P);
-    packed[slot] = pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-  }
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) = packed[0];
-  *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) = packed[1];
-}
-
-// attention_row20_64 out of line (see attention_row24_cold): the fallback of the tight form at D = 512.
-template <int KV_AUX>
-__device__ __noinline__ void attention_row20_64_cold(AttnRow r, int lane, lcf_ptr kc, float uk4096, float uv4096) {
-  r.kl = (gcf_ptr)uniform_ptr((const float *)r.kl);
-  r.vl = (gcf_ptr)uniform_ptr((const float *)r.vl);
-  r.S = __builtin_amdgcn_readfirstlane(r.S);
-  r.len = __builtin_amdgcn_readfirstlane(r.len);
-  attention_row20_64<KV_AUX>(r, lane, kc, uk4096, uv4096);
-}
-
-// attention_row20_64 over the tight form (attention_row16 has the arithmetic: int16 less the column's centre, one SDWA
-// conversion per value + half a packed add): the passes and the order of every float operation are attention_row20_64's.
-//   K [head][plane 0..7][S][16 B]             plane p: the head's columns 8 p .. 8 p + 7 of one key (eight int16)
-//   V [ceil(S / 8)][plane 0..3][D/4][16 B]    plane p: keys 8 g + 2 p, 8 g + 2 p + 1 x 4 consecutive columns (key-major)
-// kc: LDS constants of this layer, [K pb | K c127 | V pb | V c127][D]; ck / cv: the centres of K / V [D] in LDS, as floats
-template <int KV_AUX>
-__device__ __forceinline__ void attention_row16_64(AttnRow r, int lane, lcf_ptr kc, CentreLds ck, CentreLds cv) {
-  constexpr int D = 512, DH = 64, H = D / DH;
-  const int S = r.S, len = r.len;
-  const int lenf = len > 0 ? len : S;
-  const float minus_inf = -99999999.0f;  // Input.cc:56-61
-  const float lowest = -3.402823466e+38f;
-  const int hh = lane >> 5, j = lane & 31;
-  const int jc = j < S ? j : S - 1;
-  const float mask = (1.0f - (j < len ? 1.0f : 0.0f)) * minus_inf;
-  const rsrc_t rk = make_rsrc((const float *)r.kl, (unsigned)(S * 1024));
-  const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + 7) >> 3) * 8192));
-  const int koff = j < lenf ? (hh * 8 * S + jc) * 16 : kPastDescriptor;
-  const lcf_ptr kpb = kc, vpb = kc + 2 * D;
-  auto pair16 = [](int d, f2 c) -> f2 {
-    const f2 v = {(float)(short)(d & 0xffff), (float)(d >> 16)};
-    return v + c;
-  };
-#pragma unroll 1
-  for (int hp = 0; hp < H / 2; ++hp) {
-    const int h = 2 * hp + hh;
-    v4i kq[8];  // this lane's key, its head's 64 columns
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((16 * hp + i) * S) * 16, KV_AUX));
-    // c_h = row sum of q_d * pbK[d] over the 64 columns of this lane's head (attention_row20_64)
-    const float c0 = wave_sum(r.qrow[(2 * hp) * DH + lane] * kpb[(2 * hp) * DH + lane]);
-    const float c1 = wave_sum(r.qrow[(2 * hp + 1) * DH + lane] * kpb[(2 * hp + 1) * DH + lane]);
-    const float ch = hh ? c1 : c0;
-    float t = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int d0 = h * DH + 8 * i;
-      const f4 qa = *(lcf4_ptr)(r.qrow + d0), qb = *(lcf4_ptr)(r.qrow + d0 + 4);
-      const f4 ca = ck.at4(d0), cb = ck.at4(d0 + 4);
-      const f2 k01 = pair16(kq[i].x, f2{ca.x, ca.y}), k23 = pair16(kq[i].y, f2{ca.z, ca.w});
-      const f2 k45 = pair16(kq[i].z, f2{cb.x, cb.y}), k67 = pair16(kq[i].w, f2{cb.z, cb.w});
-      t = __builtin_fmaf(qa.x, k01.x, t);
-      t = __builtin_fmaf(qa.y, k01.y, t);
-      t = __builtin_fmaf(qa.z, k23.x, t);
-      t = __builtin_fmaf(qa.w, k23.y, t);
-      t = __builtin_fmaf(qb.x, k45.x, t);
-      t = __builtin_fmaf(qb.y, k45.y, t);
-      t = __builtin_fmaf(qb.z, k67.x, t);
-      t = __builtin_fmaf(qb.w, k67.y, t);
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);  // at most sixteen q / centre values from LDS in flight
-    }
-    float s = __builtin_fmaf(t, r.uk, ch);
-    if (r.alpha != 1.0f) s = r.alpha * s;
-    s = s + mask;
-    if (j >= S) s = lowest;
-    const float m = half_max(s);
-    const float e = j < S ? exp_p(s - m) : 0.0f;
-    const float sum = half_sum(e);
-    const float p = e / sum;  // keys >= S: exactly 0
-    const float ps = half_sum(p);  // P_h
-    if (r.attn && j < S) r.attn[(size_t)h * S + j] = p;
-    if (r.align && h == 0 && j < len) r.align[j] = p;
-    r.pbuf[h * 32 + j] = p;
-    if (j == 0) r.hsum[h] = ps;
-  }
-  // V: a lane owns column quads `lane` (head lane / 16) and 64 + lane (head 4 + lane / 16): two independent passes over
-  // the keys, each with two groups of eight rows in flight
-  int packed[2];
-#pragma unroll
-  for (int slot = 0; slot < 2; ++slot) {
-    const int voff = (slot * 64 + lane) * 16;
-    v4i vq[2][4];
-    auto load_v = [&](v4i(&vv)[4], int g) {  // rows 8 g .. 8 g + 7
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (4 * g + i) * 2048, KV_AUX));
-    };
-    load_v(vq[0], 0);
-    load_v(vq[1], 1);
-    __builtin_amdgcn_sched_barrier(0);
-    const int head = 4 * slot + (lane >> 4);
-    const int ph = head * 32;
-    const f4 pv4 = *(lcf4_ptr)(vpb + slot * (D / 2) + 4 * lane);
-    const f4 cv4 = cv.at4(slot * (D / 2) + 4 * lane);
-    const f2 c01 = {cv4.x, cv4.y}, c23 = {cv4.z, cv4.w};
-    const float P = r.hsum[head];
-    f2 oa = {0.0f, 0.0f}, ob = {0.0f, 0.0f};
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      v4i(&cur)[4] = vq[g & 1];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {  // keys 8 g + 2 c, 8 g + 2 c + 1 (keys >= len: p == 0, fma(0, v, o) == o)
-        const f2 pp = *(const SLIMT_LDS f2 *)(r.pbuf + ph + 8 * g + 2 * c);
-        const f2 p0 = {pp.x, pp.x}, p1 = {pp.y, pp.y};
-        oa = __builtin_elementwise_fma(p0, pair16(cur[c].x, c01), oa);
-        ob = __builtin_elementwise_fma(p0, pair16(cur[c].y, c23), ob);
-        oa = __builtin_elementwise_fma(p1, pair16(cur[c].z, c01), oa);
-        ob = __builtin_elementwise_fma(p1, pair16(cur[c].w, c23), ob);
-      }
-      asm volatile("" : "+v"(oa), "+v"(ob));  // (attention_row24: keeps a group's work next to its loads)
-      if (g + 2 < 4) load_v(vq[g & 1], g + 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const float o0 = __builtin_fmaf(oa.x, r.uv, pv4.x * P), o1 = __builtin_fmaf(oa.y, r.uv, pv4.y * P);
-    const float o2 = __builtin_fmaf(ob.x, r.uv, pv4.z * P), o3 = __builtin_fmaf(ob.y, r.uv, pv4.w * P);
-    packed[slot] = pack4(quantize1_byte(o0, r.aq_o), quantize1_byte(o1, r.aq_o), quantize1_byte(o2, r.aq_o), quantize1_byte(o3, r.aq_o));
-  }
-  *(SLIMT_LDS int *)(r.arow + 4 * lane) = packed[0];
-  *(SLIMT_LDS int *)(r.arow + D / 2 + 4 * lane) = packed[1];
-}
+// ---- the packed K/V cache (FusedDecodeArgs::kv24 / kv_fmt): one reader per shape of sentence, one unpack policy per form ----
+#include "decode_attention_packed.inl.h"
 
 }  // namespace
 
@@ -2927,153 +1292,45 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           float *al = a.n_sub ? a.sub[swr].align : a.align;
           const bool want_align = al && (l + 1 == Ld) && !fin && (no < Tr);
           ar.align = want_align ? (gf_ptr)(al + ((size_t)(b - fwr) * Tr + no) * Sr) : (gf_ptr) nullptr;
-          if constexpr (KV24 && KVC == 4) {
-            const lcf_ptr kc = (lcf_ptr)(kvpb + (4 * l) * D);
+          if constexpr (KV24) {
+            // the packed cache (decode_attention_packed.inl.h): one reader per shape of sentence, one unpack policy per form.
+            // This sentence-layer's form is uniform in the wave (kv_wide); the form the kernel was built around (KVI) is
+            // inlined, a wider one is the rare sentence-layer's out-of-line fallback.
+            constexpr int SHAPE = KVC == 4 ? 3 : MID;  // 0: up to 32 tokens, 1: 33..64, 2: 65..128 (D = 256); 3: D = 512
+            const lcf_ptr c0 = (lcf_ptr)(kvpb + (KVC * l) * D), c1 = (lcf_ptr)(kvpb + (KVC * l + 1) * D);
+            const Form24 f24 = {a.kv_u256[l][0], a.kv_u256[l][1]};
+            const Form20 f20 = {a.kv_u4096[l][0], a.kv_u4096[l][1]};
+#define SLIMT_ATTN(FN, FORM)                                                 \
+  do {                                                                       \
+    if (NT && kv_streams)                                                    \
+      FN<SHAPE, SLIMT_KV_AUX_NT>(ar, lane, c0, c1, FORM);                    \
+    else                                                                     \
+      FN<SHAPE, SLIMT_KV_AUX_KEEP>(ar, lane, c0, c1, FORM);                  \
+  } while (0)
             if constexpr (!KV20) {
-            if (NT && kv_streams)
-              attention_row24_64<2>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
-            else
-              attention_row24_64<0>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
+              SLIMT_ATTN(attention_packed, f24);
             } else {
-            const unsigned forms = rr ? kv_wide[RT - 1] : kv_wide[0];
-            const bool wide = (forms >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
-            const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
-            if (tight) {
-              if constexpr (KVI == 16) {
-                const CentreLds ck = {(lcf_ptr)(kvc127 + (2 * l) * D)}, cv = {(lcf_ptr)(kvc127 + (2 * l + 1) * D)};
-                if (NT && kv_streams)
-                  attention_row16_64<2>(ar, lane, kc, ck, cv);
+              const unsigned forms = rr ? kv_wide[RT - 1] : kv_wide[0];
+              const bool wide = (forms >> l) & 1u;
+              const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
+              if (tight) {
+                if constexpr (KVI == 16 && RT == 1) {
+                  const Form16<CentreLds, CentreLds> f16 = {ar.uk, ar.uv, {(lcf_ptr)(kvc127 + (2 * l) * D)}, {(lcf_ptr)(kvc127 + (2 * l + 1) * D)}};
+                  SLIMT_ATTN(attention_packed, f16);
+                } else if constexpr (KVI == 16) {  // 32 sentences: LDS holds the K centres only ([Ld][D])
+                  const Form16<CentreLds, CentreGlobal> f16 = {ar.uk, ar.uv, {(lcf_ptr)(kvc127 + l * D)}, {a.kv_centre[l][1]}};
+                  SLIMT_ATTN(attention_packed, f16);
+                }  // (the other kernels never meet the form: the launcher refuses a tight batch, the engine never sends one)
+              } else if (!wide) {
+                if constexpr (KVI == 16)  // (the rare sentence-layer past the calibrated centres' int16)
+                  SLIMT_ATTN(attention_packed_cold, f20);
                 else
-                  attention_row16_64<0>(ar, lane, kc, ck, cv);
+                  SLIMT_ATTN(attention_packed, f20);
+              } else {
+                SLIMT_ATTN(attention_packed_cold, f24);
               }
-            } else if (!wide) {
-              if constexpr (KVI == 16) {  // (the rare sentence-layer past the centres' int16)
-                if (NT && kv_streams)
-                  attention_row20_64_cold<2>(ar, lane, kc, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-                else
-                  attention_row20_64_cold<0>(ar, lane, kc, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-              } else if (NT && kv_streams)
-                attention_row20_64<2>(ar, lane, kc, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-              else
-                attention_row20_64<0>(ar, lane, kc, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-            } else if (NT && kv_streams)
-              attention_row24_64_cold<2>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
-            else
-              attention_row24_64_cold<0>(ar, lane, kc, a.kv_u256[l][0], a.kv_u256[l][1]);
             }
-          } else if constexpr (MID == 2) {
-            const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
-            if constexpr (!KV20) {
-            if (NT && kv_streams)
-              attention_row24_long<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            else
-              attention_row24_long<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            } else {
-            const unsigned forms = rr ? kv_wide[RT - 1] : kv_wide[0];
-            const bool wide = (forms >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
-            const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
-            if (tight) {
-              if constexpr (KVI == 16) {
-                const CentreLds ck = {(lcf_ptr)(kvc127 + (2 * l) * D)}, cv = {(lcf_ptr)(kvc127 + (2 * l + 1) * D)};
-                if (NT && kv_streams)
-                  attention_row16_long<2>(ar, lane, pbk, pbv, ck, cv);
-                else
-                  attention_row16_long<0>(ar, lane, pbk, pbv, ck, cv);
-              }
-            } else if (!wide) {
-              if constexpr (KVI == 16) {  // (the rare sentence-layer past the centres' int16)
-                if (NT && kv_streams)
-                  attention_row20_long_cold<2>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-                else
-                  attention_row20_long_cold<0>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-              } else if (NT && kv_streams)
-                attention_row20_long<2>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-              else
-                attention_row20_long<0>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-            } else if (NT && kv_streams)
-              attention_row24_long_cold<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            else
-              attention_row24_long_cold<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            }
-          } else if constexpr (MID == 1) {
-            const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
-            if constexpr (!KV20) {
-            if (NT && kv_streams)
-              attention_row24_mid<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            else
-              attention_row24_mid<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            } else {
-            const unsigned forms = rr ? kv_wide[RT - 1] : kv_wide[0];
-            const bool wide = (forms >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
-            const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
-            if (tight) {
-              if constexpr (KVI == 16) {
-                const CentreLds ck = {(lcf_ptr)(kvc127 + (2 * l) * D)}, cv = {(lcf_ptr)(kvc127 + (2 * l + 1) * D)};
-                if (NT && kv_streams)
-                  attention_row16_mid<2>(ar, lane, pbk, pbv, ck, cv);
-                else
-                  attention_row16_mid<0>(ar, lane, pbk, pbv, ck, cv);
-              }
-            } else if (!wide) {
-              if constexpr (KVI == 16) {  // (the rare sentence-layer past the centres' int16)
-                if (NT && kv_streams)
-                  attention_row20_mid_cold<2>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-                else
-                  attention_row20_mid_cold<0>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-              } else if (NT && kv_streams)
-                attention_row20_mid<2>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-              else
-                attention_row20_mid<0>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-            } else if (NT && kv_streams)
-              attention_row24_mid_cold<2>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            else
-              attention_row24_mid_cold<0>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            }
-          } else if constexpr (KV24) {
-            const lcf_ptr pbk = (lcf_ptr)(kvpb + (2 * l) * D), pbv = (lcf_ptr)(kvpb + (2 * l + 1) * D);
-            if constexpr (!KV20) {
-            if (NT && kv_streams)
-              attention_row24<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            else
-              attention_row24<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            } else {
-            const unsigned forms = rr ? kv_wide[RT - 1] : kv_wide[0];
-            const bool wide = (forms >> l) & 1u;  // this sentence-layer's form (uniform in the wave)
-#ifdef SLIMT_EXP_TIGHT_ONLY  // timing only (wrong results unless every sentence-layer is tight): no other form in the KVI = 16 kernels
-            const bool tight = KVI == 16;
-#else
-            const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
-#endif
-            if (tight) {
-              if constexpr (KVI == 16 && RT == 1) {
-                const CentreLds ck = {(lcf_ptr)(kvc127 + (2 * l) * D)}, cv = {(lcf_ptr)(kvc127 + (2 * l + 1) * D)};
-                if (NT && kv_streams)
-                  attention_row16<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, ck, cv);
-                else
-                  attention_row16<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, ck, cv);
-              } else if constexpr (KVI == 16) {  // 32 sentences: LDS holds the K centres only ([Ld][D])
-                const CentreLds ck = {(lcf_ptr)(kvc127 + l * D)};
-                const CentreGlobal cv = {a.kv_centre[l][1]};
-                if (NT && kv_streams)
-                  attention_row16<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, ck, cv);
-                else
-                  attention_row16<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, ck, cv);
-              }  // (the other kernels never meet the form: the launcher refuses a tight batch, the engine never sends one)
-            } else if (!wide) {
-              if constexpr (KVI == 16) {  // (the rare sentence-layer past the calibrated centres' int16)
-                if (NT && kv_streams)
-                  attention_row20_cold<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-                else
-                  attention_row20_cold<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-              } else if (NT && kv_streams)
-                attention_row20<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-              else
-                attention_row20<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u4096[l][0], a.kv_u4096[l][1]);
-            } else if (NT && kv_streams)
-              attention_row24_cold<SLIMT_KV_AUX_NT>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            else
-              attention_row24_cold<SLIMT_KV_AUX_KEEP>(ar, lane, pbk, pbv, a.kv_u256[l][0], a.kv_u256[l][1]);
-            }
+#undef SLIMT_ATTN
           } else if (NT && kv_streams)
             attention_row<D, DH, LONG, 2>(ar, lane);
           else
