@@ -496,7 +496,11 @@ def main():
         sw24, w24, sub24 = gm.debug_kv_watch()
         kv_watch = {"tight_layers_off": t_off, "tight_missed": t_missed[:Ld], "tight_submitted": t_sub[:Ld],
                     "switched_to_24_bit": sw24, "needed_24_bit": w24, "sentence_layers": sub24,
-                    "recalibrations": gm.debug_kv_recalibrations()}
+                    "recalibrations": None}
+        try:  # (an older library loaded through SLIMT_HIP_LIB for an A/B lacks the entry point)
+            kv_watch["recalibrations"] = gm.debug_kv_recalibrations()
+        except capi.SlimtHipError:
+            pass
         prof = {"launches": 0, "total_ms": 0.0, "int8_macs": 0.0, "weight_bytes": 0.0}
         for c in ctxs:
             r = c.profile_read()
@@ -657,7 +661,8 @@ def main():
         wbytes = prof["weight_bytes"] / max(1, prof["launches"])       # weight bytes streamed / launch
         achieved = ops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         # the committed counters are of the default workload of each preset: no figure for others
-        profiled = (args.preset in ("tiny11", "base") and B == 256 and S == 32 and n_sl == 4096 and not args.ragged)
+        profiled = (args.preset in ("tiny11", "base") and B == 256 and S == 32 and n_sl == 4096 and not args.ragged and MG == 1 and
+                    args.family == "default" and args.eos_bias <= -50.0)
         traffic, traffic_src = pmc_traffic(prof_name, args.preset) if profiled else (None, None)
         cus = -(-(B * MG) // 16) if prof_name == "decode_fused" else 256
         in_flight = prof["total_ms"] / (1e3 * dt) if dt > 0 else 0.0  # launches of this kernel running at once (this rank)

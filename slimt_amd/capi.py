@@ -154,6 +154,23 @@ def lib():
             "(there is no CPU fallback)")
     _preload_hip_runtime()
     L = C.CDLL(path)
+    if os.environ.get("SLIMT_HIP_LIB"):
+        # an alternative library (A/B of builds, tools/ab_lib.sh): an OLDER one may lack the newest entry points -- they
+        # then fail when called, not when the library is loaded
+        class _Tolerant:
+            def __init__(self, lib_):
+                object.__setattr__(self, "_l", lib_)
+
+            def __getattr__(self, name):
+                try:
+                    return getattr(self._l, name)
+                except AttributeError:
+                    def missing(*a, **k):
+                        raise SlimtHipError(f"{name} is not exported by {path}")
+                    missing.argtypes = missing.restype = None
+                    object.__setattr__(self, name, missing)
+                    return missing
+        L = _Tolerant(L)
     if len(mapped_hip_runtimes()) > 1:  # (someone mapped another copy by file name before or behind us)
         import warnings
         warnings.warn("two HIP runtimes are mapped in this process (%s): the GPU may be invisible to one of them"

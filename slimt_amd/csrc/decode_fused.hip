@@ -906,9 +906,15 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
 // or a model the engine found mostly too wide for 20 bits -- there the out-of-line call would cost every sentence).
 // KVI = 16: the tight 16-bit form inlined instead (RT = 1; kv_fmt == 2; the 20- and 24-bit ones out of line), for batches whose
 // encoder was allowed it (engine.cpp, kv_tight_wanted); its centres take 2 D floats of LDS per layer.
-template <int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0, int SPW = 16, int CL = 1,
+// MG: the kernel serves merged launches (kernels.h, MergeOut; a.n_sub > 0). A template parameter, not a runtime test: compiled
+// into the ONE set of kernels, the merged paths' scalar loads and selects cost the unmerged launches 1.5-3.5 % (B = 64, base,
+// the f32 and the streamed-cache variants: same-box A/B against round 5's library, profiles/r06_merge_template_ab.txt) --
+// these kernels run at the edge of their 128 registers. The 16-row tilings for sentences of up to 64 tokens have the merged
+// twin; the engine gives a merged launch one of those.
+template <bool MG, int KSD, int KSF, int DH, bool LONG, bool NT, int RT = 1, bool KV24 = false, int MID = 0, int SPW = 16, int CL = 1,
           int KVI = 20>
 __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
+  static_assert(!MG || (RT == 1 && CL == 1 && MID <= 1), "merged launches: the 16-row tilings, sentences of up to 64 tokens");
   constexpr bool KV20 = KVI != 24;
   static_assert(KVI == 24 || KVI == 20 || (KVI == 16 && KV24 && (KSD == 4 || KSD == 8) && (RT == 1 || (KSD == 4 && MID == 0)) && CL == 1),
                 "16-bit form: sentences of up to 128 tokens at D = 256 (the 32-sentence tiling: up to 32), up to 32 at D = 512");
@@ -939,6 +945,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = a.B, S = a.S, H = D / DH, Ld = a.Ld;
+  const int n_sub = MG ? a.n_sub : 0;  // (0 at compile time in the unmerged kernels: every merged path folds away)
   const bool row_wave = SPW == 16 || wave < SPW;  // this wave owns a sentence in the row-wise phases
 
   // 16 rows x 512 ("base") or 32 rows x 256 do not fit the full layout in 160 KiB: the
@@ -1015,8 +1022,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   // follow each other without holes, a tile may hold sentences of several): Bv = B. Either way every SENTENCE finds its
   // own sub-batch below (the caller's arrays, its padded length); the workspace (K/V cache, its form bytes, SSRU cells)
   // is indexed by the global sentence.
-  const int sj = a.n_sub ? __builtin_amdgcn_readfirstlane(merge_find(a.sub, a.n_sub, m0)) : 0;
-  const int Bv = a.n_sub && !a.sub_dense ? a.sub[sj].first + a.sub[sj].n : B;
+  const int sj = n_sub ? __builtin_amdgcn_readfirstlane(merge_find(a.sub, n_sub, m0)) : 0;
+  const int Bv = n_sub && !a.sub_dense ? a.sub[sj].first + a.sub[sj].n : B;
   if (m0 >= Bv) return;
   if (tid == 0) occ_trace_event(a.trace, 1, 0);
   // my cluster (CL > 1): tiles cl_first .. cl_first + cl_n - 1 (the last cluster of a batch may be short), me = member cl_m
@@ -1035,9 +1042,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   // once per step at most -- instead of living in scalar registers across the loop (five more per sentence spilled 11
   // vector registers in the headline's instantiation)
 #define SLIMT_SW(rr) sw[rr]
-#define SLIMT_SUB_FIRST(rr) (a.n_sub ? a.sub[SLIMT_SW(rr)].first : 0)
-#define SLIMT_SUB_TMAX(rr) (a.n_sub ? a.sub[SLIMT_SW(rr)].Tmax : a.Tmax)
-#define SLIMT_SUB_S(rr) (a.n_sub ? a.sub[SLIMT_SW(rr)].S : S)
+#define SLIMT_SUB_FIRST(rr) (n_sub ? a.sub[SLIMT_SW(rr)].first : 0)
+#define SLIMT_SUB_TMAX(rr) (n_sub ? a.sub[SLIMT_SW(rr)].Tmax : a.Tmax)
+#define SLIMT_SUB_S(rr) (n_sub ? a.sub[SLIMT_SW(rr)].S : S)
   bool live[RT], finished[RT];
   uint32_t n_out[RT];
 #pragma unroll
@@ -1046,8 +1053,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
     live[rr] = row_wave && bq[rr] < Bv;
     // this sentence's sub-batch: its first global sentence, the row length of its outputs (its own padded length's
     // limit, Model.cc:159-161), the width of its alignment rows, the steps it runs at most
-    sw[rr] = a.n_sub && live[rr] ? __builtin_amdgcn_readfirstlane(merge_find(a.sub, a.n_sub, bq[rr])) : 0;
-    len[rr] = live[rr] ? checked_length(a.n_sub ? a.sub[sw[rr]].lengths[bq[rr] - SLIMT_SUB_FIRST(rr)] : a.lengths[bq[rr]], S) : 0;
+    sw[rr] = n_sub && live[rr] ? __builtin_amdgcn_readfirstlane(merge_find(a.sub, n_sub, bq[rr])) : 0;
+    len[rr] = live[rr] ? checked_length(n_sub ? a.sub[sw[rr]].lengths[bq[rr] - SLIMT_SUB_FIRST(rr)] : a.lengths[bq[rr]], S) : 0;
     finished[rr] = !live[rr];
     n_out[rr] = 0;
   }
@@ -1110,9 +1117,9 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
     if (live[rr]) {  // outputs past a sentence's length read as zero (no memset launches)
-      uint32_t *oi = a.n_sub ? a.sub[sw[rr]].out_ids : a.out_ids;
-      float *al = a.n_sub ? a.sub[sw[rr]].align : a.align;
-      const bool staged = (a.n_sub ? a.sub[sw[rr]].align_out : a.align_out) != nullptr;
+      uint32_t *oi = n_sub ? a.sub[sw[rr]].out_ids : a.out_ids;
+      float *al = n_sub ? a.sub[sw[rr]].align : a.align;
+      const bool staged = (n_sub ? a.sub[sw[rr]].align_out : a.align_out) != nullptr;
       const int Tr = SLIMT_SUB_TMAX(rr), Sr = SLIMT_SUB_S(rr), fr = SLIMT_SUB_FIRST(rr);
       for (int i = lane; i < Tr; i += 64) oi[(size_t)(bq[rr] - fr) * Tr + i] = 0;
       if (al && !staged)
@@ -1129,7 +1136,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 
   // the output layer's column count may live on the device (a shortlist generated there)
   PreparedWeight outw = a.out;
-  if (a.n_sub) {  // this sub-batch's packed output layer: job strides behind the first (same K, multipliers, a_quant)
+  if (n_sub) {  // this sub-batch's packed output layer: job strides behind the first (same K, multipliers, a_quant)
     const int job = a.sub[sj].job;
     outw.Wp = reinterpret_cast<const char *>(a.out.Wp) + (size_t)job * a.out_stride_wp;
     outw.colsum = reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.out.colsum) + (size_t)job * a.out_stride_cs);
@@ -1146,7 +1153,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   // below skips NaNs, so the rule is applied where the token is taken
   const bool nan0 = outw.pb[0] != outw.pb[0] || a.out.u != a.out.u;
   // (a dense tile runs while any of its sentences does: each ends at its own limit below; an aligned one has one limit)
-  const int max_steps = a.n_sub && !a.sub_dense ? a.sub[sj].max_steps : a.max_steps;
+  const int max_steps = n_sub && !a.sub_dense ? a.sub[sj].max_steps : a.max_steps;
   bool all_done = false;
   for (int t = 0; t < max_steps; ++t) {
     SLIMT_STAMP(0);
@@ -1288,8 +1295,8 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
           ar.aq_o = L.o.a_quant;
           ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
           const int swr = rr ? sw[RT - 1] : sw[0];
-          const int fwr = a.n_sub ? a.sub[swr].first : 0, Tr = a.n_sub ? a.sub[swr].Tmax : a.Tmax, Sr = a.n_sub ? a.sub[swr].S : S;
-          float *al = a.n_sub ? a.sub[swr].align : a.align;
+          const int fwr = n_sub ? a.sub[swr].first : 0, Tr = n_sub ? a.sub[swr].Tmax : a.Tmax, Sr = n_sub ? a.sub[swr].S : S;
+          float *al = n_sub ? a.sub[swr].align : a.align;
           const bool want_align = al && (l + 1 == Ld) && !fin && (no < Tr);
           ar.align = want_align ? (gf_ptr)(al + ((size_t)(b - fwr) * Tr + no) * Sr) : (gf_ptr) nullptr;
           if constexpr (KV24) {
@@ -1689,16 +1696,16 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
         // no column beat the start value (every logit NaN or -inf): class 0, where the reference's scan
         // starts and stays (Transformer.cc:287-298) -- and never an index past the shortlist
         ix = (ix == 0x7fffffff || nan0) ? 0 : ix;
-        const uint32_t *sl = a.n_sub ? a.sub[sj].shortlist : a.shortlist;  // (one output layer per tile: the tile's sub-batch's list)
+        const uint32_t *sl = n_sub ? a.sub[sj].shortlist : a.shortlist;  // (one output layer per tile: the tile's sub-batch's list)
         if (live[rr]) tok = sl ? sl[ix] : (uint32_t)ix;
       }
       if (live[rr] && !finished[rr]) {  // record(), Model.cc:127-137
         const int Tr = SLIMT_SUB_TMAX(rr);
         if (lane == 0 && (int)n_out[rr] < Tr)
-          (a.n_sub ? a.sub[SLIMT_SW(rr)].out_ids : a.out_ids)[(size_t)(bq[rr] - SLIMT_SUB_FIRST(rr)) * Tr + n_out[rr]] = tok;
+          (n_sub ? a.sub[SLIMT_SW(rr)].out_ids : a.out_ids)[(size_t)(bq[rr] - SLIMT_SUB_FIRST(rr)) * Tr + n_out[rr]] = tok;
         n_out[rr] += 1;
         // (merged launches: a sentence also ends at its own sub-batch's step limit -- a tile may go on for the others)
-        if (tok == a.eos || (a.n_sub && (int)n_out[rr] >= a.sub[SLIMT_SW(rr)].max_steps)) {
+        if (tok == a.eos || (n_sub && (int)n_out[rr] >= a.sub[SLIMT_SW(rr)].max_steps)) {
           finished[rr] = true;
           if (lane == 0) atomicAdd(&flags[0], 1);
         }
@@ -1723,15 +1730,15 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   }
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr)
-    if (live[rr] && lane == 0) (a.n_sub ? a.sub[sw[rr]].out_len : a.out_len)[bq[rr] - SLIMT_SUB_FIRST(rr)] = n_out[rr];
-  {
+    if (live[rr] && lane == 0) (n_sub ? a.sub[sw[rr]].out_len : a.out_len)[bq[rr] - SLIMT_SUB_FIRST(rr)] = n_out[rr];
+  if (n_sub || (a.align && a.align_out)) {  // (the uniform test first: without it the f32-cache 32-sentence kernel spilled 75 registers for 37)
     // staged alignment rows -> their destination (kernels.h, align_out). This wave wrote the rows it
     // reads (rows 0 .. n_out - 1, columns 0 .. len - 1); everything else is zero.
 #pragma unroll 1
     for (int rr = 0; rr < RT; ++rr) {
       if (!live[rr]) continue;
-      const float *al_src = a.n_sub ? a.sub[sw[rr]].align : a.align;
-      float *al_dst = a.n_sub ? a.sub[sw[rr]].align_out : a.align_out;
+      const float *al_src = n_sub ? a.sub[sw[rr]].align : a.align;
+      float *al_dst = n_sub ? a.sub[sw[rr]].align_out : a.align_out;
       if (!al_src || !al_dst) continue;
       const int Tr = SLIMT_SUB_TMAX(rr), Sr = SLIMT_SUB_S(rr);
       const size_t base = (size_t)(bq[rr] - SLIMT_SUB_FIRST(rr)) * Tr * Sr;
@@ -1845,20 +1852,21 @@ bool fused_decode_supported(int D, int F, int H, int Ld) {
 
 // the long-sentence instantiation exists for d_head 32 only (attention_row_long), the
 // non-temporal K/V variant for d_head 32 and 64 (the buffer-load paths of attention_row)
-template <int KSD, int KSF, int DH>
+template <bool MG, int KSD, int KSF, int DH>
 static auto decode_fused_pick(bool long_sentences, bool nt) -> void (*)(FusedDecodeArgs) {
   if constexpr (DH == 32) {
-    if (long_sentences) return nt ? decode_fused_kernel<KSD, KSF, DH, true, true> : decode_fused_kernel<KSD, KSF, DH, true, false>;
+    if (long_sentences) return nt ? decode_fused_kernel<MG, KSD, KSF, DH, true, true> : decode_fused_kernel<MG, KSD, KSF, DH, true, false>;
   }
   if constexpr (DH >= 32) {
-    if (nt) return decode_fused_kernel<KSD, KSF, DH, false, true>;
+    if (nt) return decode_fused_kernel<MG, KSD, KSF, DH, false, true>;
   }
   (void)long_sentences;
   (void)nt;
-  return decode_fused_kernel<KSD, KSF, DH, false, false>;
+  return decode_fused_kernel<MG, KSD, KSF, DH, false, false>;
 }
 
-hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H, hipStream_t st) {
+template <bool MG>
+static hipError_t launch_decode_fused_t(const FusedDecodeArgs &a_in, int D, int F, int H, hipStream_t st) {
   FusedDecodeArgs a = a_in;
   if (!fused_decode_supported(D, F, H, a.Ld)) return hipErrorInvalidValue;
   const bool kv24 = a.kv24;
@@ -1881,32 +1889,39 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   };
   // the variants over the packed cache: <KSD, KSF, DH, MID> x non-temporal K/V loads x sentences per workgroup
 #define SLIMT_KV24_PICK(KSD_, KSF_, DH_, MID_)                                                                  \
-  (rows == 4   ? (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_, 4>                 \
-                          : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_, 4>)               \
-   : rows == 8 ? (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_, 8>                 \
-                          : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_, 8>)               \
-               : (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_>                    \
-                          : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_>))
+  (rows == 4   ? (a.kv_nt ? decode_fused_kernel<MG, KSD_, KSF_, DH_, false, true, 1, true, MID_, 4>                 \
+                          : decode_fused_kernel<MG, KSD_, KSF_, DH_, false, false, 1, true, MID_, 4>)               \
+   : rows == 8 ? (a.kv_nt ? decode_fused_kernel<MG, KSD_, KSF_, DH_, false, true, 1, true, MID_, 8>                 \
+                          : decode_fused_kernel<MG, KSD_, KSF_, DH_, false, false, 1, true, MID_, 8>)               \
+               : (a.kv_nt ? decode_fused_kernel<MG, KSD_, KSF_, DH_, false, true, 1, true, MID_>                    \
+                          : decode_fused_kernel<MG, KSD_, KSF_, DH_, false, false, 1, true, MID_>))
   // every cache of this launch in the 24-bit form (a.kv_fmt == nullptr): the 16-sentence tilings have an instantiation
   // with that form inlined (KVI = 24); the 8- / 4-sentence ones reach it through the fallback call
 #define SLIMT_KV24_ONLY(KSD_, KSF_, DH_, MID_)                                                        \
-  (a.kv_nt ? decode_fused_kernel<KSD_, KSF_, DH_, false, true, 1, true, MID_, 16, 1, 24>          \
-           : decode_fused_kernel<KSD_, KSF_, DH_, false, false, 1, true, MID_, 16, 1, 24>)
+  (a.kv_nt ? decode_fused_kernel<MG, KSD_, KSF_, DH_, false, true, 1, true, MID_, 16, 1, 24>          \
+           : decode_fused_kernel<MG, KSD_, KSF_, DH_, false, false, 1, true, MID_, 16, 1, 24>)
   const bool only24 = kv24 && !a.kv_fmt && rows == 16 && a.cluster <= 1;
+  if constexpr (MG) {  // (the merged twins: 16-row tilings, sentences of up to 64 tokens, no clusters)
+    if (rows > 16 || mid == 2 || a.cluster > 1) return hipErrorInvalidValue;
+  }
   if (mid) {
     if (rows > 16 || F != 1536) return hipErrorInvalidValue;
     const size_t ldsm = fused_decode_lds_bytes(D, F, a.Ld, 16, true, mid, nullptr, a.kv_tight);
     if (ldsm > 160 * 1024) return hipErrorInvalidValue;
     if (a.kv_tight) {
 #define SLIMT_KV16_PICK(MID_, SPW_)                                                                \
-  (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, MID_, SPW_, 1, 16>               \
-           : decode_fused_kernel<4, 24, 32, false, false, 1, true, MID_, SPW_, 1, 16>)
+  (a.kv_nt ? decode_fused_kernel<MG, 4, 24, 32, false, true, 1, true, MID_, SPW_, 1, 16>               \
+           : decode_fused_kernel<MG, 4, 24, 32, false, false, 1, true, MID_, SPW_, 1, 16>)
       if (mid == 1) return go(rows == 4 ? SLIMT_KV16_PICK(1, 4) : rows == 8 ? SLIMT_KV16_PICK(1, 8) : SLIMT_KV16_PICK(1, 16), ldsm);
-      return go(rows == 4 ? SLIMT_KV16_PICK(2, 4) : rows == 8 ? SLIMT_KV16_PICK(2, 8) : SLIMT_KV16_PICK(2, 16), ldsm);
+      if constexpr (!MG) return go(rows == 4 ? SLIMT_KV16_PICK(2, 4) : rows == 8 ? SLIMT_KV16_PICK(2, 8) : SLIMT_KV16_PICK(2, 16), ldsm);
 #undef SLIMT_KV16_PICK
     }
-    if (only24) return go(mid == 2 ? SLIMT_KV24_ONLY(4, 24, 32, 2) : SLIMT_KV24_ONLY(4, 24, 32, 1), ldsm);
-    return go(mid == 2 ? SLIMT_KV24_PICK(4, 24, 32, 2) : SLIMT_KV24_PICK(4, 24, 32, 1), ldsm);
+    if constexpr (!MG) {
+      if (only24 && mid == 2) return go(SLIMT_KV24_ONLY(4, 24, 32, 2), ldsm);
+      if (mid == 2) return go(SLIMT_KV24_PICK(4, 24, 32, 2), ldsm);
+    }
+    if (only24) return go(SLIMT_KV24_ONLY(4, 24, 32, 1), ldsm);
+    return go(SLIMT_KV24_PICK(4, 24, 32, 1), ldsm);
   }
   const size_t lds = fused_decode_lds_bytes(D, F, a.Ld, rows <= 16 ? 16 : rows, kv24, 0, &a.ln_in_lds, a.kv_tight);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -1914,44 +1929,48 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
     if (F != 2048) return hipErrorInvalidValue;
     if (a.kv_tight) {
 #define SLIMT_KV16_PICK(SPW_)                                                                      \
-  (a.kv_nt ? decode_fused_kernel<8, 32, 64, false, true, 1, true, 0, SPW_, 1, 16>                  \
-           : decode_fused_kernel<8, 32, 64, false, false, 1, true, 0, SPW_, 1, 16>)
+  (a.kv_nt ? decode_fused_kernel<MG, 8, 32, 64, false, true, 1, true, 0, SPW_, 1, 16>                  \
+           : decode_fused_kernel<MG, 8, 32, 64, false, false, 1, true, 0, SPW_, 1, 16>)
       return go(rows == 4 ? SLIMT_KV16_PICK(4) : rows == 8 ? SLIMT_KV16_PICK(8) : SLIMT_KV16_PICK(16), lds);
 #undef SLIMT_KV16_PICK
     }
     if (only24) return go(SLIMT_KV24_ONLY(8, 32, 64, 0), lds);
     return go(SLIMT_KV24_PICK(8, 32, 64, 0), lds);
   }
+  if constexpr (!MG) {
   if (a.cluster > 1) {  // cluster logits: the 16-sentence tiling of the D = 256 packed-cache shape
     if (!(kv24 && D == 256 && F == 1536 && rows == 16 && a.cluster == 4 && a.cl_act && a.cl_part && a.cl_sync)) return hipErrorInvalidValue;
-    return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 0, 16, 4>
-                      : decode_fused_kernel<4, 24, 32, false, false, 1, true, 0, 16, 4>, lds);
+    return go(a.kv_nt ? decode_fused_kernel<MG, 4, 24, 32, false, true, 1, true, 0, 16, 4>
+                      : decode_fused_kernel<MG, 4, 24, 32, false, false, 1, true, 0, 16, 4>, lds);
+  }
   }
   if (only24) return go(SLIMT_KV24_ONLY(4, 24, 32, 0), lds);
   if (kv24 && rows <= 16 && a.kv_tight) {  // sentences may be in the tight 16-bit form: the kernels with it (and the 20-bit one) inlined
 #define SLIMT_KV16_PICK(SPW_)                                                                      \
-  (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 1, true, 0, SPW_, 1, 16>                  \
-           : decode_fused_kernel<4, 24, 32, false, false, 1, true, 0, SPW_, 1, 16>)
+  (a.kv_nt ? decode_fused_kernel<MG, 4, 24, 32, false, true, 1, true, 0, SPW_, 1, 16>                  \
+           : decode_fused_kernel<MG, 4, 24, 32, false, false, 1, true, 0, SPW_, 1, 16>)
     return go(rows == 4 ? SLIMT_KV16_PICK(4) : rows == 8 ? SLIMT_KV16_PICK(8) : SLIMT_KV16_PICK(16), lds);
 #undef SLIMT_KV16_PICK
   }
   if (kv24 && rows <= 16) return go(SLIMT_KV24_PICK(4, 24, 32, 0), lds);
 #undef SLIMT_KV24_PICK
 #undef SLIMT_KV24_ONLY
+  if constexpr (!MG) {
   if (rows == 32) {
     if (kv24 && a.kv_tight)
-      return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true, 0, 16, 1, 16>
-                        : decode_fused_kernel<4, 24, 32, false, false, 2, true, 0, 16, 1, 16>, lds);
+      return go(a.kv_nt ? decode_fused_kernel<MG, 4, 24, 32, false, true, 2, true, 0, 16, 1, 16>
+                        : decode_fused_kernel<MG, 4, 24, 32, false, false, 2, true, 0, 16, 1, 16>, lds);
     if (kv24 && !a.kv_fmt)  // every cache in the 24-bit form: that form inlined (KVI = 24), as for the 16-sentence tilings
-      return go(a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true, 0, 16, 1, 24>
-                        : decode_fused_kernel<4, 24, 32, false, false, 2, true, 0, 16, 1, 24>, lds);
-    auto k = kv24 ? (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2, true> : decode_fused_kernel<4, 24, 32, false, false, 2, true>)
-                  : (a.kv_nt ? decode_fused_kernel<4, 24, 32, false, true, 2> : decode_fused_kernel<4, 24, 32, false, false, 2>);
+      return go(a.kv_nt ? decode_fused_kernel<MG, 4, 24, 32, false, true, 2, true, 0, 16, 1, 24>
+                        : decode_fused_kernel<MG, 4, 24, 32, false, false, 2, true, 0, 16, 1, 24>, lds);
+    auto k = kv24 ? (a.kv_nt ? decode_fused_kernel<MG, 4, 24, 32, false, true, 2, true> : decode_fused_kernel<MG, 4, 24, 32, false, false, 2, true>)
+                  : (a.kv_nt ? decode_fused_kernel<MG, 4, 24, 32, false, true, 2> : decode_fused_kernel<MG, 4, 24, 32, false, false, 2>);
     return go(k, lds);
+  }
   }
 #define SLIMT_FUSED_CASE(KSD_, KSF_, DH_)                                                   \
   if (D == 64 * KSD_ && F == 64 * KSF_ && D / H == DH_) {                                    \
-    auto k = decode_fused_pick<KSD_, KSF_, DH_>(a.S > 32, a.kv_nt);                           \
+    auto k = decode_fused_pick<MG, KSD_, KSF_, DH_>(a.S > 32, a.kv_nt);                           \
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void *>(k), (int)lds); \
     if (e != hipSuccess) return e;                                                           \
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, st, a);                                     \
@@ -1961,6 +1980,10 @@ hipError_t launch_decode_fused(const FusedDecodeArgs &a_in, int D, int F, int H,
   SLIMT_FUSED_CASE(8, 32, 64)
 #undef SLIMT_FUSED_CASE
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_decode_fused(const FusedDecodeArgs &a, int D, int F, int H, hipStream_t st) {
+  return a.n_sub > 0 ? launch_decode_fused_t<true>(a, D, F, H, st) : launch_decode_fused_t<false>(a, D, F, H, st);
 }
 
 }  // namespace slimt_hip

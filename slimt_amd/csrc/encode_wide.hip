@@ -612,6 +612,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   // narrow one -- 20 bits, accS itself -- when every accS lies in [-limit, limit); else 24 bits holding the signed
   // accumulator (accS needs 25 bits at K = 512). The smallest allowed form first; an accumulator that does not fit raises
   // its bit of kv_wide_flag (1: not tight, 2: not narrow) and the layer is done again in the smallest form that holds it.
+#ifndef SLIMT_EXP_WIDE_NO_KV  // timing only (no K/V cache is written: wrong results): what the phase costs the LAYERS in registers
   const bool try_narrow = a.kv24 && a.kv_fmt != nullptr;
   for (int l = 0; l < a.Ld; ++l) {
     const bool try_tight = try_narrow && a.kv_tight_limit > 0 && ((a.kv_tight_layers >> l) & 1u);
@@ -833,6 +834,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         __hip_atomic_fetch_add(a.kv_not16_count + l, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+#endif
   if (gen_here) {
     if (shortlists_await_in_launch(a, tid))  // (never published: nothing to pack from)
       pack_weight_share(a, tile, n_wg, tid, 1024);

@@ -2026,6 +2026,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
     f.rows_per_wg = clusters ? 16 : c->decode_mode == 2 ? 16 : c->decode_mode == 3 ? 32 : c->decode_mode == 4 ? 8 : c->decode_mode == 5 ? 4
                     : (n_expected > 16384 ? 32 : 0);
     if (tight && f.rows_per_wg == 32 && !(S <= 32 && fused_decode_tight_rows32_supported(m->D, m->F, m->H, m->Ld))) f.rows_per_wg = 16;
+    if (mp && f.rows_per_wg == 32) f.rows_per_wg = 16;  // (merged launches: the 16-row tilings only, decode_fused.hip)
     int rows = fused_decode_rows(m->D, m->F, m->H, m->Ld, (int)S, (int)B, f.rows_per_wg, kv24);
     if (clusters) {
       const size_t tiles = (B + 15) / 16, n_clusters = (tiles + 3) / 4;
@@ -2542,10 +2543,13 @@ int build_merge_plan(const slimt_hip_ctx *c, const slimt_hip_batch *b, size_t n,
   return 0;
 }
 
-// the decoder tile a merged launch of this context will run at most: 32 sentences where the 32-sentence tiling may be
-// chosen (decode mode 3, or mode 0 with an output layer of more than 16k columns -- translate_device), else 16
+// the decoder tile of a merged launch: always 16 sentences -- where an unmerged call would take the 32-sentence tiling (decode
+// mode 3, or mode 0 with an output layer of more than 16k columns) a merged one runs the 16-sentence tiling instead
+// (translate_device; decode_fused.hip compiles the merged paths into the 16-row tilings only)
 size_t merge_tile(const slimt_hip_ctx *c, size_t n_columns) {
-  return (c->decode_mode == 3 || (c->decode_mode == 0 && n_columns > 16384)) ? 32 : 16;
+  (void)c;
+  (void)n_columns;
+  return 16;  // (merged launches never take the 32-sentence tiling: translate_device)
 }
 }  // namespace
 

@@ -18,9 +18,9 @@ for line in out.splitlines():
         cur = {"name": v}; rows.append(cur)
     else:
         cur[k] = v
-print(f"{'kernel':70s} VGPR AGPR SGPR scratch vspill sspill LDS occ")
+print(f"{'kernel':92s} VGPR AGPR SGPR scratch vspill sspill LDS occ")
 for r in rows:
     name = subprocess.run(["c++filt", r["name"]], capture_output=True, text=True).stdout.strip()
     name = re.sub(r"slimt_hip::|\(.*\)|void ", "", name)
-    print(f"{name[:70]:70s} {r.get('VGPRs','?'):>4} {r.get('AGPRs','?'):>4} {r.get('SGPRs','?'):>4} "
+    print(f"{name[:92]:92s} {r.get('VGPRs','?'):>4} {r.get('AGPRs','?'):>4} {r.get('SGPRs','?'):>4} "
           f"{r.get('ScratchSize [bytes/lane]','?'):>7} {r.get('VGPRs Spill','?'):>6} {r.get('SGPRs Spill','?'):>6} {r.get('LDS Size [bytes/block]','?'):>5} {r.get('Occupancy [waves/SIMD]','?'):>3}")

@@ -49,7 +49,8 @@ grep -E "total" gpurun_out/${TAG}_phases_loaded.txt gpurun_out/${TAG}_encoder_ph
 fi
 [ "$STAGE" = "a" ] && exit 0
 {
-  tools/sweep.sh "--forward-steps 0" "--forward-steps 0 --batch 64" "--forward-steps 0 --batch 64 --adaptive-rows 0" "--forward-steps 0 --batch 512 --shortlist 0" \
+  tools/sweep.sh "--forward-steps 0" "--forward-steps 0 --batch 64" "--batch 64 --merge 4" "--forward-steps 0 --batch 64 --adaptive-rows 0" "--forward-steps 0 --batch 512 --shortlist 0" \
+    "--forward-steps 0 --batch 340 --src-len 24" "--forward-steps 0 --batch 128 --src-len 48" "--forward-steps 0 --ragged --eos-bias 8" \
     "--forward-steps 0 --batch 512 --workers 12" "--forward-steps 0 --batch 128 --src-len 64" "--forward-steps 0 --batch 64 --src-len 96" \
     "--forward-steps 0 --batch 64 --src-len 128" "--forward-steps 0 --ragged" "--forward-steps 0 --preset base" \
     "--total-sentences 4096 --batch 512 --steps 10" "--total-sentences 4096 --batch 256 --steps 10" \
@@ -65,6 +66,11 @@ for cfg in "10 32768 4096 0" "10 32768 4096 1" "10 32768 4096 flat" "10 32768 le
   timeout -k 10 200 python tools/async_bench.py $cfg >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err || { echo "service bench $cfg failed"; exit 1; }
 done
 SLIMT_SERVICE_REPLICAS=2 timeout -k 10 200 python tools/async_bench.py 5 32768 4096 1 >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err
+# the reference's default word budget (max_words 1024, Frontend.hh:21-39): merged launches (default, 8 batches) against one batch per launch
+for cfg in "8 4096 0" "1 4096 0" "8 lex 0" "1 lex 0" "8 4096 1"; do
+  set -- $cfg
+  SLIMT_SERVICE_MAX_WORDS=1024 SLIMT_SERVICE_MERGE=$1 SLIMT_SERVICE_WINDOW=16 timeout -k 10 200 python tools/async_bench.py 10 32768 $2 $3 >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err || { echo "service bench max_words 1024 $cfg failed"; exit 1; }
+done
 # SURVEY 8(d)'s secondary workload: lengths ~ U{8..64}, cut into batches by the reference's batcher rule (the Service's queue)
 for cfg in "10 32768 4096 0" "10 32768 4096 1"; do
   SLIMT_SERVICE_MAX_LEN=64 timeout -k 10 250 python tools/async_bench.py $cfg >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err || { echo "secondary workload $cfg failed"; exit 1; }
