@@ -68,31 +68,73 @@ int slimt_hip_host_alloc(size_t bytes, void **out) {
 }
 int slimt_hip_host_free(void *p) { std::free(p); return 0; }
 
-static int run(slimt_hip_ctx *c, const uint32_t *ids, const uint32_t *lengths, size_t B, size_t S, float limit, uint32_t eos,
-               uint32_t *out_ids, uint32_t *out_len, float *align, bool wait) {
+// one batch's "translation": every sentence's tokens reversed (+ EOS), its alignment rows one-hot on the token they came from
+static void fake_translate(const uint32_t *ids, const uint32_t *lengths, size_t B, size_t S, size_t T, uint32_t eos,
+                           uint32_t *out_ids, uint32_t *out_len, float *align) {
+  for (size_t b = 0; b < B; ++b) {
+    const size_t len = lengths[b];
+    size_t n = 0;
+    for (size_t t = 0; t + 1 < len && n + 1 < T; ++t) out_ids[b * T + n++] = ids[b * S + (len - 2 - t)];
+    out_ids[b * T + n++] = eos;
+    for (size_t t = n; t < T; ++t) out_ids[b * T + t] = 0;
+    out_len[b] = (uint32_t)n;
+    if (align) {
+      std::fill(align + b * T * S, align + (b + 1) * T * S, 0.0f);
+      for (size_t t = 0; t < n; ++t) align[(b * T + t) * S + (t + 1 < n && len >= 2 + t ? len - 2 - t : len - 1)] = 1.0f;
+    }
+  }
+}
+
+static int check_one(slimt_hip_ctx *c, const uint32_t *ids, const uint32_t *lengths, size_t B, size_t S, const uint32_t *out_ids,
+                     const uint32_t *out_len) {
   if (!c || !ids || !lengths || !out_ids || !out_len) return fail("null argument");
   if (B == 0 || S == 0 || B > c->max_B || S > c->max_S || B * S > c->max_M) return fail("batch exceeds the context's workspace");
   for (size_t b = 0; b < B; ++b)
     for (size_t j = 0; j < lengths[b]; ++j)
       if (ids[b * S + j] >= 512) return fail("token id out of range");
+  return 0;
+}
+
+static int run(slimt_hip_ctx *c, const uint32_t *ids, const uint32_t *lengths, size_t B, size_t S, float limit, uint32_t eos,
+               uint32_t *out_ids, uint32_t *out_len, float *align, bool wait) {
+  if (int rc = check_one(c, ids, lengths, B, S, out_ids, out_len)) return rc;
   const size_t T = std::max<size_t>(1, (size_t)(limit * (float)S));
   c->pending = std::async(std::launch::async, [=]() {
     std::this_thread::sleep_for(std::chrono::microseconds(200 + 13 * (B % 7)));
-    for (size_t b = 0; b < B; ++b) {
-      const size_t len = lengths[b];
-      size_t n = 0;
-      for (size_t t = 0; t + 1 < len && n + 1 < T; ++t) out_ids[b * T + n++] = ids[b * S + (len - 2 - t)];
-      out_ids[b * T + n++] = eos;
-      for (size_t t = n; t < T; ++t) out_ids[b * T + t] = 0;
-      out_len[b] = (uint32_t)n;
-      if (align) {
-        std::fill(align + b * T * S, align + (b + 1) * T * S, 0.0f);
-        for (size_t t = 0; t < n; ++t) align[(b * T + t) * S + (t + 1 < n && len >= 2 + t ? len - 2 - t : len - 1)] = 1.0f;
-      }
-    }
+    fake_translate(ids, lengths, B, S, T, eos, out_ids, out_len, align);
   });
   if (wait) c->pending.get();
   return 0;
+}
+
+// several batches in one "launch pair" (include/slimt_hip.h, slimt_hip_translate_many_async): each with its own padded
+// length, arrays and results, all of them completed by the one asynchronous task
+static int run_many(slimt_hip_ctx *c, const slimt_hip_batch *batches, size_t n, size_t S, float limit, uint32_t eos) {
+  if (!c || !batches || n == 0) return fail("null argument");
+  std::vector<slimt_hip_batch> copy(batches, batches + n);
+  size_t rows = 0;
+  for (slimt_hip_batch &b : copy) {
+    if (b.S == 0) b.S = S;
+    if (b.S > S) return fail("a batch is padded to more tokens than the launch");
+    if (int rc = check_one(c, b.src_ids, b.lengths, b.B, b.S, b.out_ids, b.out_len)) return rc;
+    rows += b.B;
+  }
+  if (rows > c->max_B || rows * S > c->max_M) return fail("merged batches exceed the context's workspace");
+  c->pending = std::async(std::launch::async, [copy, limit, eos]() {
+    std::this_thread::sleep_for(std::chrono::microseconds(200 + 13 * (copy.size() % 7)));
+    for (const slimt_hip_batch &b : copy)
+      fake_translate(b.src_ids, b.lengths, b.B, b.S, std::max<size_t>(1, (size_t)(limit * (float)b.S)), eos, b.out_ids, b.out_len,
+                     b.align);
+  });
+  return 0;
+}
+int slimt_hip_translate_many_async(slimt_hip_ctx *c, const slimt_hip_batch *batches, size_t n, size_t S, float limit, uint32_t eos) {
+  return run_many(c, batches, n, S, limit, eos);
+}
+int slimt_hip_translate_many_async_generated(slimt_hip_ctx *c, slimt_hip_shortlist *sl, const slimt_hip_batch *batches, size_t n,
+                                             size_t S, float limit, uint32_t eos) {
+  if (!sl) return fail("shortlist is NULL");
+  return run_many(c, batches, n, S, limit, eos);
 }
 int slimt_hip_translate(slimt_hip_ctx *c, const uint32_t *ids, const uint32_t *lengths, size_t B, size_t S, const uint32_t *,
                         size_t, float limit, uint32_t eos, uint32_t *out_ids, uint32_t *out_len, float *align) {
