@@ -152,6 +152,13 @@ __device__ __forceinline__ void load_ln_regs(const float *scale, const float *bi
       a.stamps[(id)] = wall_clock64();                                                \
   } while (0)
 
+// Loop conditions of the phase that runs once per batch (the decoder's K/V cache, behind the layers). The register allocator weighs a
+// value by the STATIC frequency of the blocks that use it -- loop depth, 32 iterations assumed per level --, so the phase's four-deep
+// loops outweighed the encoder layers (depth 1-2) and the layers' values were the ones spilled: 58 spilled registers, 10 scratch
+// stores + 21 loads inside a layer. With its loops marked unlikely the layers keep the 12 they had without the phase (the residual
+// stream parked across the FFN) and the phase takes the spills (profiles/r06_encode_wide_cold_phase.txt).
+#define SLIMT_ONCE_PER_BATCH(c) __builtin_expect(!!(c), 0)
+
 #define SLIMT_WPHASE_LANE                               \
   int lane = lane0;                                     \
   asm volatile("" : "+v"(lane));                        \
@@ -216,8 +223,8 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   float *Yb = reinterpret_cast<float *>(region);
   char *Hb = region;
 
-  auto row_sentence = [&](int r) { return s0 + r / S; };
-  auto row_valid = [&](int r) { return r < rows_used && row_sentence(r) < B; };
+  auto row_sentence = [&](int r) __attribute__((always_inline)) { return s0 + r / S; };
+  auto row_valid = [&](int r) __attribute__((always_inline)) { return r < rows_used && row_sentence(r) < B; };
 
   // side job: the batch's shortlisted output layer (used by the decoder launch behind this one)
   const bool gen_here = a.gen.w2o != nullptr;  // the batch's shortlist is generated in this launch (encode_tall.hip): packed at the end
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
     }
   }
   // the owner's rows, quantised for the next affine, into the A buffer
-  auto quantise_x = [&](char *A, float aq, int lane) {
+  auto quantise_x = [&](char *A, float aq, int lane) __attribute__((always_inline)) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
@@ -269,14 +276,14 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   v4i bw[2][KSD];
   v4i ecs[2];    // FFN1: colsum / prepared bias of the tile in bw[buf], requested with it (loads
   float4 epb[2]; // return in order: constants asked for later would wait behind the next tile)
-  auto load_w = [&](v4i (&f)[KSD], const PreparedWeight &w, int ct, int lane) {
+  auto load_w = [&](v4i (&f)[KSD], const PreparedWeight &w, int ct, int lane) __attribute__((always_inline)) {
     const rsrc_t rw = wrsrc(w.Wp, (unsigned)w.n_tiles * KSD * 1024u);
 #pragma unroll
     for (int ks = 0; ks < KSD; ++ks) f[ks] = wload(rw, lane * 16, (ct * KSD + ks) * 1024);
   };
   // one 16-column tile against the 32 rows of `A`: accumulator lane = rows lr / 16 + lr, columns
   // 4 lg .. 4 lg + 3 of the tile (weights as the MFMA A operand)
-  auto mma = [&](const char *A, const v4i (&f)[KSD], int lane, v4i &c0, v4i &c1) {
+  auto mma = [&](const char *A, const v4i (&f)[KSD], int lane, v4i &c0, v4i &c1) __attribute__((always_inline)) {
     const int lr = lane & 15, lg = lane >> 4;
     c0 = v4i{0, 0, 0, 0};
     c1 = v4i{0, 0, 0, 0};
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
     }
   };
   // the same against the attention output (k-steps 0..3: round 0's heads, 4..7: round 1's; padded rows)
-  auto mma_o = [&](const v4i (&f)[KSD], int lane, v4i &c0, v4i &c1) {
+  auto mma_o = [&](const v4i (&f)[KSD], int lane, v4i &c0, v4i &c1) __attribute__((always_inline)) {
     const int lr = lane & 15, lg = lane >> 4;
     c0 = v4i{0, 0, 0, 0};
     c1 = v4i{0, 0, 0, 0};
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks], a1, c1, 0, 0, 0);
     }
   };
-  auto dequant4 = [&](const v4i &c, const Epi4 &e, float u) { return wdequant4(c, e.cs, u, e.pb); };
+  auto dequant4 = [&](const v4i &c, const Epi4 &e, float u) __attribute__((always_inline)) { return wdequant4(c, e.cs, u, e.pb); };
   {
     SLIMT_WPHASE_LANE;
     load_w(bw[0], a.L[0].q, wave, lane);
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
     const rsrc_t r2[2] = {wrsrc(w2 + (size_t)wave * KSF * 1024, KSF * 1024u),
                           wrsrc(w2 + (size_t)(wave + WNW) * KSF * 1024, KSF * 1024u)};
     // FFN2 chunk c (k-steps 4 c .. 4 c + 3 of both column tiles) into buffer `buf`
-    auto load2 = [&](int buf, int c, int lane) {
+    auto load2 = [&](int buf, int c, int lane) __attribute__((always_inline)) {
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -614,13 +621,13 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
   // its bit of kv_wide_flag (1: not tight, 2: not narrow) and the layer is done again in the smallest form that holds it.
 #ifndef SLIMT_EXP_WIDE_NO_KV  // timing only (no K/V cache is written: wrong results): what the phase costs the LAYERS in registers
   const bool try_narrow = a.kv24 && a.kv_fmt != nullptr;
-  for (int l = 0; l < a.Ld; ++l) {
+  for (int l = 0; SLIMT_ONCE_PER_BATCH(l < a.Ld); ++l) {
     const bool try_tight = try_narrow && a.kv_tight_limit > 0 && ((a.kv_tight_layers >> l) & 1u);
     int form = !try_narrow ? 1 : try_tight ? 2 : 0;  // kv_fmt's codes
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; SLIMT_ONCE_PER_BATCH(attempt < 3); ++attempt) {
       const bool wide = form == 1;
       bool redo = false;
-      for (int p = 0; p < 2; ++p) {
+      for (int p = 0; SLIMT_ONCE_PER_BATCH(p < 2); ++p) {
         SLIMT_WPHASE_LANE;
         const PreparedWeight &w = p == 0 ? a.dec_k[l] : a.dec_v[l];
         float *out = a.kv + (size_t)(2 * l + p) * B * S * D;
@@ -705,7 +712,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           // the tight form (decode_fused.hip, attention_row16_64): one thread = 32 values = four quads of int16
           if (p == 0) {  // K [sentence][head][plane 0..7][key][16 B]
             const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * S * D * 3));
-            for (int it = tid; it < WR * (D / 32); it += 1024) {
+            for (int it = tid; SLIMT_ONCE_PER_BATCH(it < WR * (D / 32)); it += 1024) {
               const int r = it % WR, hf = it / WR;  // hf: half a head (32 columns)
               if (!row_valid(r)) continue;
               const int h = hf >> 1, half = hf & 1;
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           } else {  // V [sentence][key / 8][plane 0..3][column / 4][16 B]
             const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * Sp * D * 3));
             const int G = (S + 7) >> 3;
-            for (int it = tid; it < spw * G * (D / 4); it += 1024) {
+            for (int it = tid; SLIMT_ONCE_PER_BATCH(it < spw * G * (D / 4)); it += 1024) {
               const int cl = it % (D / 4), g = (it / (D / 4)) % G, si = (it / (D / 4)) / G;
               if (s0 + si >= B) continue;
               const int off = (s0 + si) * Sp * D * 3 + (g * 4 * (D / 4) + cl) * 16;
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           // one quad of lo nibbles
           if (p == 0) {  // K [sentence][head][plane 0..9][key][16 B]
             const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * S * D * 3));
-            for (int it = tid; it < WR * (D / 32); it += 1024) {
+            for (int it = tid; SLIMT_ONCE_PER_BATCH(it < WR * (D / 32)); it += 1024) {
               const int r = it % WR, hf = it / WR;  // hf: half a head (32 columns)
               if (!row_valid(r)) continue;
               const int h = hf >> 1, half = hf & 1;
@@ -761,7 +768,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           } else {  // V [sentence][key / 8][plane 0..4][column / 4][16 B]
             const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * Sp * D * 3));
             const int G = (S + 7) >> 3;
-            for (int it = tid; it < spw * G * (D / 4); it += 1024) {
+            for (int it = tid; SLIMT_ONCE_PER_BATCH(it < spw * G * (D / 4)); it += 1024) {
               const int cl = it % (D / 4), g = (it / (D / 4)) % G, si = (it / (D / 4)) / G;
               if (s0 + si >= B) continue;
               const int off = (s0 + si) * Sp * D * 3 + (g * 5 * (D / 4) + cl) * 16;
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         // column's 127 colsum term): one thread = 16 values = 48 bytes = three 16-byte stores
         if (p == 0) {  // K [sentence][column / 16][plane][key][16 B]
           const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * S * D * 3));
-          for (int it = tid; it < WR * (D / 16); it += 1024) {
+          for (int it = tid; SLIMT_ONCE_PER_BATCH(it < WR * (D / 16)); it += 1024) {
             const int r = it % WR, ci = it / WR;
             if (!row_valid(r)) continue;
             wv3i wd[4];
@@ -801,7 +808,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           }
         } else {  // V [sentence][key / 4][plane][column / 4][16 B]: 4 keys x 4 columns, key-major
           const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * Sp * D * 3));
-          for (int it = tid; it < spw * (Sp / 4) * (D / 4); it += 1024) {
+          for (int it = tid; SLIMT_ONCE_PER_BATCH(it < spw * (Sp / 4) * (D / 4)); it += 1024) {
             const int cl = it % (D / 4), g = (it / (D / 4)) % (Sp / 4), si = (it / (D / 4)) / (Sp / 4);
             if (s0 + si >= B) continue;
             wv3i wd[4];
