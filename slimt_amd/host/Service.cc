@@ -226,9 +226,9 @@ Service::~Service() {
   if (std::getenv("SLIMT_SERVICE_STATS")) {
     const double n = static_cast<double>(batches_.load() - stats_base_), ms = 1e-6;
     std::fprintf(stderr,
-                 "service-stats: %.0f batches, %zu workers; worker time per batch (ms): waiting for work %.3f, "
-                 "launch %.3f, waiting for the GPU %.3f, collect %.3f, deliver %.3f\n",
-                 n, threads_.size(), ms * ns_idle_ / n, ms * ns_launch_ / n, ms * ns_wait_ / n, ms * ns_collect_ / n,
+                 "service-stats: %.0f batches, %zu workers; worker time per batch (ms): waiting for work %.3f (the queue's lock %.3f, "
+                 "nothing queued %.3f), launch %.3f, waiting for the GPU %.3f, collect %.3f, deliver %.3f\n",
+                 n, threads_.size(), ms * ns_idle_ / n, ms * ns_lock_ / n, ms * ns_starved_ / n, ms * ns_launch_ / n, ms * ns_wait_ / n, ms * ns_collect_ / n,
                  ms * ns_deliver_ / n);
     std::fprintf(stderr, "service-stats: merged launches: %llu of %llu launches, %.0f batches\n",
                  static_cast<unsigned long long>(merged_launches_.load() - merged_base_),
@@ -285,9 +285,11 @@ std::future<Histories> Service::translate(std::vector<Words> sentences) {
 // launch stays within merge_words and no batch is padded by more than a quarter; their sizes, in order, when more than
 // one was taken. Each part keeps the padded length the reference's rule gave it: that of its own last sentence.
 std::vector<Unit> Service::next_batch(bool may_block, std::vector<size_t> *parts) {
-  Lap lap;
+  Lap lap, part;
   std::unique_lock<std::mutex> lock(mutex_);
+  part.to(ns_lock_);  // (of "waiting for work": the queue's lock ...
   if (may_block) wake_.wait(lock, [this]() { return queue_.waiting() > 0 || closing_; });
+  part.to(ns_starved_);  // ... and an empty queue)
   std::vector<Unit> batch = queue_.take();
   if (parts) parts->clear();
   if (parts && !batch.empty() && config_.merge_batches > 1) {

@@ -144,7 +144,7 @@ class Service {
     stats_base_ = batches_.load();
     launches_base_ = launches_.load();
     merged_base_ = merged_launches_.load();
-    for (auto *c : {&ns_idle_, &ns_launch_, &ns_wait_, &ns_collect_, &ns_deliver_}) c->store(0);
+    for (auto *c : {&ns_idle_, &ns_lock_, &ns_starved_, &ns_launch_, &ns_wait_, &ns_collect_, &ns_deliver_}) c->store(0);
   }
 
  private:
@@ -164,7 +164,7 @@ class Service {
   std::atomic<uint64_t> launches_{0}, merged_launches_{0};  // launch pairs so far, and those that carried more than one batch
   uint64_t stats_base_ = 0, launches_base_ = 0, merged_base_ = 0;
   // where the workers' time goes, in nanoseconds (printed by the destructor when SLIMT_SERVICE_STATS is set)
-  std::atomic<uint64_t> ns_idle_{0}, ns_launch_{0}, ns_wait_{0}, ns_collect_{0}, ns_deliver_{0};
+  std::atomic<uint64_t> ns_idle_{0}, ns_lock_{0}, ns_starved_{0}, ns_launch_{0}, ns_wait_{0}, ns_collect_{0}, ns_deliver_{0};
   bool closing_ = false;
   size_t live_workers_ = 0;          // workers that can take batches
   std::exception_ptr dead_error_;    // set once the last of them has failed: requests fail with it

@@ -62,6 +62,9 @@ cat gpurun_out/${TAG}_configs.txt
 SLIMT_BENCH_REHEARSAL=1 timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 2 --workers 8 --no-cpu-baseline --sustained-steps 0 --forward-steps 0 > gpurun_out/${TAG}_rehearsal_2ranks_on_1gpu.json 2> gpurun_out/${TAG}_rehearsal.err
 cut -c1-200 gpurun_out/${TAG}_rehearsal_2ranks_on_1gpu.json
 rm -f gpurun_out/${TAG}_service_bench.jsonl
+# a timed pass of ~1 s (30 rounds over the requests; 3 rounds = 0.1 s, of which fill and drain are 6 %), 16 requests outstanding per
+# client (profiles/r06_service_steady_state.txt)
+export SLIMT_SERVICE_ROUNDS=30 SLIMT_SERVICE_WINDOW=16
 for cfg in "10 32768 4096 0" "10 32768 4096 1" "10 32768 4096 flat" "10 32768 lex 0" "10 32768 lex 1" "6 32768 4096 1" "10 32768 0 1"; do
   timeout -k 10 200 python tools/async_bench.py $cfg >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err || { echo "service bench $cfg failed"; exit 1; }
 done
@@ -69,7 +72,7 @@ SLIMT_SERVICE_REPLICAS=2 timeout -k 10 200 python tools/async_bench.py 5 32768 4
 # the reference's default word budget (max_words 1024, Frontend.hh:21-39): merged launches (default, 8 batches) against one batch per launch
 for cfg in "8 4096 0" "1 4096 0" "8 lex 0" "1 lex 0" "8 4096 1"; do
   set -- $cfg
-  SLIMT_SERVICE_MAX_WORDS=1024 SLIMT_SERVICE_MERGE=$1 SLIMT_SERVICE_WINDOW=16 timeout -k 10 200 python tools/async_bench.py 10 32768 $2 $3 >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err || { echo "service bench max_words 1024 $cfg failed"; exit 1; }
+  SLIMT_SERVICE_MAX_WORDS=1024 SLIMT_SERVICE_MERGE=$1 timeout -k 10 200 python tools/async_bench.py 10 32768 $2 $3 >> gpurun_out/${TAG}_service_bench.jsonl 2>> gpurun_out/${TAG}_service.err || { echo "service bench max_words 1024 $cfg failed"; exit 1; }
 done
 # SURVEY 8(d)'s secondary workload: lengths ~ U{8..64}, cut into batches by the reference's batcher rule (the Service's queue)
 for cfg in "10 32768 4096 0" "10 32768 4096 1"; do
