@@ -733,7 +733,7 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
       o1a = __builtin_elementwise_fma(ppb, f2{v1.x, v1.y}, o1a);
       o1b = __builtin_elementwise_fma(ppb, f2{v1.z, v1.w}, o1b);
     }
-    // pin this group's sums here (see attention_row24)
+    // pin this group's sums here (see attention_packed32)
     asm volatile("" : "+v"(o0a), "+v"(o0b), "+v"(o1a), "+v"(o1b));
     if (g + 2 < 8) load_v(vq[g % 2], g + 2);
     __builtin_amdgcn_sched_barrier(0);

@@ -884,8 +884,8 @@ __device__ __forceinline__ void attention_row(AttnRow r, int lane) {
 // RT = row tiles per workgroup: 1 (16 sentences) or 2 (32 sentences). Every streamed weight
 // fragment then feeds RT MFMAs (half the weight bytes per sentence and step at RT = 2), wave w
 // owns sentences w and w + 16 in the row-wise phases.
-// MID: 1 = sentences of 33..64 tokens over the packed cache (D = 256; attention_row24_mid), 2 = of 65..128
-// tokens (attention_row24_long; the SSRU cells then live in global memory: their 32 KB of LDS hold the
+// MID: 1 = sentences of 33..64 tokens over the packed cache (D = 256; attention_packed64 with Form24), 2 = of 65..128
+// tokens (attention_packed128 with Form24; the SSRU cells then live in global memory: their 32 KB of LDS hold the
 // [H][128] probabilities of every wave's sentence).
 // SPW: sentences per workgroup, 16 (a full MFMA row tile), 8 or 4 -- for launches that would leave most of the
 // chip idle (one batch of 256 at 16 sentences per workgroup runs on 16 of 256 CUs). The row tile stays 16 rows
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
                 "the packed K/V cache: D = 256 / d_head 32 or D = 512 / d_head 64, S <= 32 (64 / 128 with MID 1 / 2)");
   static_assert(!MID || (KV24 && KSD == 4 && RT == 1), "33..128-token sentences: the D = 256 packed cache, 16 rows");
   constexpr int PBW = MID == 2 ? 1024 : MID == 1 ? 512 : 256;  // floats of attention scratch per wave ([H][S])
-  constexpr int KVC = KSD == 8 ? 4 : 2;  // constant vectors per layer in LDS (see attention_row24 / _64)
+  constexpr int KVC = KSD == 8 ? 4 : 2;  // constant vectors per layer in LDS (decode_attention_packed.inl.h: Form24, attention_row24_64)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 64 * KSD, F = 64 * KSF;
   constexpr int R = 16 * RT;    // rows of the operand tiles per workgroup
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   constexpr bool LN_LDS = KSD == 4 && RT == 1 && MID == 0;  // (MID: the LDS goes to the wider attention scratch)
   float *lnc = kvpb + (KV24 ? Ld * KVC * D : 0);
   const bool ln_lds = LN_LDS && a.ln_in_lds;  // (the launcher: only where the 160 KiB allow it)
-  float *kvc127 = lnc + (ln_lds ? Ld * 6 * D : 0);  // KVI == 16: [Ld][K, V][D] float(centre) (attention_row16)
+  float *kvc127 = lnc + (ln_lds ? Ld * 6 * D : 0);  // KVI == 16: [Ld][K, V][D] float(centre) (attention_packed32 with Form16)
 
   // Which R sentences? With a ticket counter the grid is over-subscribed and the first
   // workgroups to START claim the tiles; the rest leave at once. A workgroup needs a whole
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   if constexpr (KVI == 16) {
     if constexpr (RT == 1) {
       for (int i = tid; i < Ld * 2 * D; i += 1024) kvc127[i] = (float)a.kv_centre[i / (2 * D)][(i / D) & 1][i % D];
-    } else {  // (the K centres only: attention_row16's V pass reads its own from global memory)
+    } else {  // (the K centres only: attention_packed32 with Form16's V pass reads its own from global memory)
       for (int i = tid; i < Ld * D; i += 1024) kvc127[i] = (float)a.kv_centre[i / D][0][i % D];
     }
   }

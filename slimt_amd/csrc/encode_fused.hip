@@ -685,7 +685,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
           __hip_atomic_fetch_add(a.kv_not16_count + l, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       if (form == 2) {
-        // decode_fused.hip, attention_row16: one thread = 32 values = four quads of int16 (accS - centre)
+        // decode_attention_packed.inl.h, attention_packed32 with Form16: one thread = 32 values = four quads of int16 (accS - centre)
         //   K [sentence][head][plane 0..3][key][16 B],  V [sentence][key / 8][plane 0..3][column / 4][16 B]
         const int Sp = (S + 3) & ~3, G = (S + 7) >> 3;
         const rsrc_t rko = make_rsrc(kout, (unsigned)((size_t)B * S * D * 3));
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(1024) void encode_fused_kernel(FusedEncodeArgs a) {
         continue;
       }
       if (!wide) {
-        // decode_fused.hip, attention_row20: one thread = 32 values = four quads of hi halves + one quad of lo nibbles
+        // decode_attention_packed.inl.h, attention_packed32 with Form20: one thread = 32 values = four quads of hi halves + one quad of lo nibbles
         //   K [sentence][head][plane 0..4][key][16 B],  V [sentence][key / 8][plane 0..4][column / 4][16 B]
         const int Sp = (S + 3) & ~3, G = (S + 7) >> 3;
         const rsrc_t rko = make_rsrc(kout, (unsigned)((size_t)B * S * D * 3));
@@ -1332,7 +1332,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
         }
         const int Sp = (S + 3) & ~3;
         if (form == 2) {
-          // the tight form (decode_fused.hip, attention_row16_long): one thread = 32 values = four quads of int16;
+          // the tight form (decode_attention_packed.inl.h, attention_packed128 with Form16): one thread = 32 values = four quads of int16;
           // K [head][plane 0..3][key][16 B], V [key / 8][plane 0..3][column / 4][16 B]
           if (which == 0) {
             const rsrc_t rp = make_rsrc(reinterpret_cast<const char *>(out) + (size_t)b * S * D * 3, (unsigned)(S * D * 3));
@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(1024) void encode_long16_kernel(LongEncodeArgs a) {
           continue;
         }
         if (!wide) {
-          // the narrow form (decode_fused.hip, attention_row20_long): one thread = 32 values = four quads of hi halves +
+          // the narrow form (decode_attention_packed.inl.h, attention_packed128 with Form20): one thread = 32 values = four quads of hi halves +
           // one quad of lo nibbles; K [head][plane 0..4][key][16 B], V [key / 8][plane 0..4][column / 4][16 B]
           if (which == 0) {
             const rsrc_t rp = make_rsrc(reinterpret_cast<const char *>(out) + (size_t)b * S * D * 3, (unsigned)(S * D * 3));

@@ -902,7 +902,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
         }
         const int Sp = (S + 3) & ~3;
         if (form == 2) {
-          // the tight form (decode_fused.hip, attention_row16): one thread = 32 values = four quads of int16
+          // the tight form (decode_attention_packed.inl.h, attention_packed32 with Form16): one thread = 32 values = four quads of int16
           if (p == 0) {  // K [sentence][head][plane 0..3][key][16 B]: consecutive lanes = consecutive keys
             const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * S * D * 3));
             for (int it = tid; it < TR * (D / 32); it += 1024) {
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(1024) void encode_tall_kernel(FusedEncodeArgs a) {
           continue;
         }
         if (!wide) {
-          // the narrow form (decode_fused.hip, attention_row20): one thread = 32 values = four quads of hi halves + one
+          // the narrow form (decode_attention_packed.inl.h, attention_packed32 with Form20): one thread = 32 values = four quads of hi halves + one
           // quad of lo nibbles
           if (p == 0) {  // K [sentence][head][plane 0..4][key][16 B]: consecutive lanes = consecutive keys
             const rsrc_t ro = trsrc(out, (unsigned)((size_t)B * S * D * 3));

@@ -709,7 +709,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         const int *stg = reinterpret_cast<const int *>(region);
         const int Sp = (S + 3) & ~3;
         if (form == 2) {
-          // the tight form (decode_fused.hip, attention_row16_64): one thread = 32 values = four quads of int16
+          // the tight form (decode_attention_packed.inl.h, attention_packed32_d64 with Form16): one thread = 32 values = four quads of int16
           if (p == 0) {  // K [sentence][head][plane 0..7][key][16 B]
             const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * S * D * 3));
             for (int it = tid; SLIMT_ONCE_PER_BATCH(it < WR * (D / 32)); it += 1024) {
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           continue;
         }
         if (!wide) {
-          // the narrow form (decode_fused.hip, attention_row20_64): one thread = 32 values = four quads of hi halves +
+          // the narrow form (decode_attention_packed.inl.h, attention_packed32_d64 with Form20): one thread = 32 values = four quads of hi halves +
           // one quad of lo nibbles
           if (p == 0) {  // K [sentence][head][plane 0..9][key][16 B]
             const rsrc_t ro = wrsrc(out, (unsigned)((size_t)B * S * D * 3));

@@ -1486,7 +1486,7 @@ int encode_device(slimt_hip_ctx *c, int B, int S, float *h_embed, float *h_layer
     if (kv24 && (size_t)M * D * 3 >= (1u << 31)) return fail(-1, "packed K/V cache: %d rows exceed a 2 GB plane", M);
     // the narrow (20-bit) form where the writer and the reader have it -- D = 256 or 512, S <= 32 -- and where a
     // sentence's V block (groups of eight keys) fits the slot of its 24-bit form (groups of four): not S = 1..4, 9..12
-    // (... and S = 33..64 at D = 256: the 64-row encoder with one sentence per workgroup, attention_row20_mid)
+    // (... and S = 33..64 at D = 256: the 64-row encoder with one sentence per workgroup, attention_packed64 with Form20)
     c->kv_fmt_valid = kv24 && ((D == 256 && S <= 64) || (D == 512 && S <= 32)) &&
                       ((S + 7) / 8) * 5120 <= ((S + 3) / 4) * 3072 && kv_narrow_wanted(c->model, &f.kv_wide_count);
 #ifdef SLIMT_EXP_NO_KV20  // A/B builds: the 24-bit form only
@@ -1887,7 +1887,7 @@ int translate_device(slimt_hip_ctx *c, const uint32_t *d_ids, const uint32_t *d_
   const bool kv24_mid = S > 32 && S <= 64 && c->encode_rows != 32 && c->decode_mode != 3 &&
                         fused_decode_mid_supported(m->D, m->F, m->H, m->Ld) &&
                         tall_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
-  // ... and for 65..128-token sentences of that shape (the per-sentence encoder, attention_row24_long)
+  // ... and for 65..128-token sentences of that shape (the per-sentence encoder, attention_packed128 with Form24)
   const bool kv24_long = S > 64 && S <= 128 && c->decode_mode != 3 && fused_decode_long24_supported(m->D, m->F, m->H, m->Ld) &&
                          long_encode_supported(m->D, m->F, m->H, m->Le, m->Ld, (int)S);
   const bool kv_packed = lean && (m->kv_format == 0 || m->kv_format == 2) &&

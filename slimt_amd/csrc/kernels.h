@@ -376,13 +376,13 @@ struct FusedDecodeArgs {
   bool kv24 = false;
   // The NARROW form of the packed cache (D = 256, S <= 32): a sentence-layer whose K and V accumulators all lie in
   // [-2^19, 2^19) is cached in 20 bits per value -- accS >> 4 as a signed 16-bit plane, accS & 15 as a nibble plane
-  // (decode_fused.hip, attention_row20: layouts and the unpack) -- in the slot its 24-bit form would take; any other
+  // (decode_attention_packed.inl.h, attention_packed32 with Form20: layouts and the unpack) -- in the slot its 24-bit form would take; any other
   // keeps the 24-bit form, which holds every accumulator K = 256 can produce. kv_fmt[l * B + b] (written by the
   // encoder that filled the cache, FusedEncodeArgs::kv_fmt) says which: 0 = narrow, 1 = 24-bit; nullptr = all 24-bit.
   // Both forms give back the same integers, so results do not depend on it: 17 % fewer K/V bytes per step.
   const unsigned char *kv_fmt = nullptr;
   // kv_fmt may hold 2 = the TIGHT form (D = 256, S <= 32): the accumulator less its column's centre as plain int16
-  // (decode_fused.hip, attention_row16), for sentence-layers whose K and V all lie in [-2^15, 2^15) then. Set by the engine
+  // (decode_attention_packed.inl.h, attention_packed32 with Form16), for sentence-layers whose K and V all lie in [-2^15, 2^15) then. Set by the engine
   // when this batch's encoder was allowed to write it: the launch then uses the kernels with that form inlined.
   bool kv_tight = false;
   // ... held relative to a per-column CENTRE: the cache has r = accS - kv_centre[l][K, V][d], the reader adds float(centre)
