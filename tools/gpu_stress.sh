@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the stress runs on the final kernels: concurrent translates against the CPU checker (tiny11 S = 20 / 100, base), run-to-run
-# determinism, device memory after create / destroy cycles, generated shortlists under uneven load. usage: tools/gpu_stress.sh <tag>
+# determinism, device memory after create / destroy cycles, generated shortlists under uneven load, merged launches under uneven load. usage: tools/gpu_stress.sh <tag>
 mkdir -p gpurun_out
 TAG=${1:-stress}; OUT=gpurun_out/${TAG}_stress.txt; : > $OUT
 run() { echo "## $*" >> $OUT; timeout -k 10 300 "$@" >> $OUT 2>&1 || { echo "FAILED: $*"; tail -5 $OUT; exit 1; }; }
@@ -15,4 +15,6 @@ run python tools/stress_determinism.py
 run python tools/leak_check.py
 run python tools/stress_generated.py 6 4
 run python tools/stress_generated.py 4 3 base
+run python tools/stress_many.py 6 9
+run python tools/stress_many.py 4 6 base
 grep -v amdgpu.ids $OUT | grep -i "mismatch\|delta\|##"
