@@ -358,11 +358,11 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
       lds_barrier();
       SLIMT_WSTAMP(hr == 0 ? 1 : 3);
       // scaled_dot_product_attention (Modules.cc:24-86) on the f32 matrix cores: one wave per
-      // (sentence, head of the round, 16 queries, half of the head's columns) -- 16 jobs for one
-      // 32-token sentence. v_mfma_f32_16x16x4_f32 chains over ascending k (bit-identical to the
+      // (sentence, head of the round, 16 queries) -- 8 jobs for one 32-token sentence, on waves 0 .. 7 = two per SIMD
+      // (a job per half of the head's columns filled all 16 waves, but the two halves' waves computed the same
+      // scores and the same softmax, four to a SIMD: 6.7 -> 5.1 us per round without the copy). v_mfma_f32_16x16x4_f32 chains over ascending k (bit-identical to the
       // ascending fmaf chain, tools/probe_mfma_f32.py); operand maps, butterfly order and the
-      // lane-group transpose of P as in encode_fused.hip. The two waves that share a (head,
-      // query half) compute the same scores and each take 32 of the 64 output columns.
+      // lane-group transpose of P as in encode_fused.hip.
       {
         SLIMT_WPHASE_LANE;
         typedef float v4f __attribute__((ext_vector_type(4)));
@@ -370,8 +370,8 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
         const float minus_inf = -99999999.0f;  // Input.cc:56-61
         const float lowest = -3.402823466e+38f;
         const int nqh = S > 16 ? 2 : 1;  // 16-query halves of a sentence
-        for (int job = wave; job < spw * HR * nqh * 2; job += WNW) {
-          const int dq = job & 1, qh = (job >> 1) % nqh, hl = ((job >> 1) / nqh) % HR, sl = (job >> 1) / (nqh * HR);
+        for (int job = wave; job < spw * HR * nqh; job += WNW) {
+          const int qh = job % nqh, hl = (job / nqh) % HR, sl = job / (nqh * HR);
           const int sb = s0 + sl;
           if (sb >= B) continue;
           const int base = sl * S;
@@ -379,22 +379,41 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
           const int qr = 16 * qh + n;
           const float *qp = qb + (base + (qr < S ? qr : S - 1)) * LDQ + hl * DH + g;
           float sc[2][4];
+          {
+            // operands first, chains second: fetched where they are used, every pair of MFMAs waited out an LDS round trip
+            // (ds_read2, s_waitcnt lgkmcnt(0), two v_mfma: eight times per key tile), and the two key tiles' chains ran one
+            // after the other. Both tiles' chains are independent: interleaved, one's latency hides behind the other's issue.
+            const float *kp0 = kb + (base + (n < S ? n : S - 1)) * LDQ + hl * DH + g;
+            const float *kp1 = kb + (base + (16 + n < S ? 16 + n : S - 1)) * LDQ + hl * DH + g;
+            v4f st0 = {0.0f, 0.0f, 0.0f, 0.0f}, st1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
-            const int kr = 16 * kt + n;
-            const float *kp = kb + (base + (kr < S ? kr : S - 1)) * LDQ + hl * DH + g;
-            v4f st = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int half = 0; half < 2; ++half) {  // (all 48 operands at once cost the phases around this one 30 spilled registers)
+              float qv[DH / 8], kv0[DH / 8], kv1[DH / 8];
 #pragma unroll
-            for (int k0 = 0; k0 < DH; k0 += 4) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[k0], qp[k0], st, 0, 0, 0);
+              for (int i = 0; i < DH / 8; ++i) {
+                qv[i] = qp[4 * (half * (DH / 8) + i)];
+                kv0[i] = kp0[4 * (half * (DH / 8) + i)];
+                kv1[i] = kp1[4 * (half * (DH / 8) + i)];
+              }
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int m = 16 * kt + 4 * g + r;  // key of this register
-              float v = st[r];
-              v = a.alpha * v;  // (alpha == 1: the product is v, bit for bit)
-              v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
-              if (m >= S) v = lowest;
-              sc[kt][r] = v;
+              for (int i = 0; i < DH / 8; ++i) {
+                st0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kv0[i], qv[i], st0, 0, 0, 0);
+                st1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kv1[i], qv[i], st1, 0, 0, 0);
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int m = 16 * kt + 4 * g + r;  // key of this register
+                float v = kt ? st1[r] : st0[r];
+                v = a.alpha * v;  // (alpha == 1: the product is v, bit for bit)
+                v = v + (1.0f - (m < len ? 1.0f : 0.0f)) * minus_inf;
+                if (m >= S) v = lowest;
+                sc[kt][r] = v;
+              }
           }
           float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
                            fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
@@ -402,7 +421,10 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * g + r) < S ? exp_p_select(sc[kt][r] - mx) : 0.0f;
+            for (int r = 0; r < 4; ++r) {  // (unconditional: a select, not eight exec-mask branches -- encode_tall.hip)
+              const float e = exp_p_select(sc[kt][r] - mx);
+              sc[kt][r] = (16 * kt + 4 * g + r) < S ? e : 0.0f;
+            }
           float t[2];
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt)
@@ -426,19 +448,31 @@ __global__ __launch_bounds__(1024) void encode_wide_kernel(FusedEncodeArgs a) {
             pa[kt][3] = __int_as_float(bd.y);
           }
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            const int dcol = hl * DH + 32 * dq + 16 * nt + n;  // column inside the round
-            v4f o = {0.0f, 0.0f, 0.0f, 0.0f};
+          for (int np = 0; np < DH / 32; ++np) {  // two column tiles at a time: their V operands first, their chains interleaved
+            const int dcol = hl * DH + 32 * np + n;  // column inside the round (+ 16: the second tile)
+            float v0[8], v1[8];
 #pragma unroll
             for (int s4 = 0; s4 < 8; ++s4) {  // keys >= S contribute fma(0, v, o) == o
               const int key = 4 * s4 + g;
-              const float vv = vb[(base + (key < S ? key : S - 1)) * LDV + dcol];
-              o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4 >> 2][s4 & 3], vv, o, 0, 0, 0);
+              const float *vr = vb + (base + (key < S ? key : S - 1)) * LDV + dcol;
+              v0[s4] = vr[0];
+              v1[s4] = vr[16];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            v4f o0 = {0.0f, 0.0f, 0.0f, 0.0f}, o1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+              o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4 >> 2][s4 & 3], v0[s4], o0, 0, 0, 0);
+              o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4 >> 2][s4 & 3], v1[s4], o1, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int q = 16 * qh + 4 * g + r;  // query of this register
-              if (q < S) (hr == 0 ? Ob0 : Ob1)[(base + q) * LDO + dcol] = (char)quantize1_byte(o[r], L.o.a_quant);
+              if (q < S) {
+                char *orow = (hr == 0 ? Ob0 : Ob1) + (base + q) * LDO + dcol;
+                orow[0] = (char)quantize1_byte(o0[r], L.o.a_quant);
+                orow[16] = (char)quantize1_byte(o1[r], L.o.a_quant);
+              }
             }
           }
         }
