@@ -6,7 +6,8 @@ from slimt_amd import capi, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 n_sl = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-m = synth.make_model("tiny11", eos_bias=-100.0)
+preset = os.environ.get("SLIMT_PRESET", "tiny11")  # base: its six decoder layers' stamps collide with the logits' from layer 4 on -- layers 0 and 1 and the step total are shown
+m = synth.make_model(preset, eos_bias=-100.0)
 gm = capi.Model(m); ctx = capi.Context(gm, B, S)
 if os.environ.get("SLIMT_KV_FORMAT"):  # 0 = packed, 20 bits where the accumulators fit (default); 2 = packed 24-bit; 1 = f32
     gm.set_kv_cache_format(int(os.environ["SLIMT_KV_FORMAT"]))
