@@ -428,7 +428,10 @@ __device__ __forceinline__ void attention_packed64(AttnRow r, int lane, lcf_ptr 
 // L of head h + 1 before keys L + 64 are), so that a round trip to the cache runs under 64 values' worth of unpacking
 // instead of in front of it. No store inside the loop (the probabilities leave through LDS): loads and stores share one
 // counter, and a conditional store would make the compiler drain every load in flight at the loop head.
-template <int KV_AUX, class F>
+// PART: 0 = the whole attention by this wave; 1 = the score passes of heads wave / SPW, + 16 / SPW, ... only (probabilities and
+// P_h into r.pbuf / r.hsum: the sentence's owner and the idle waves of an SPW-sentence workgroup share the heads); 2 = the
+// context pass only, from the probabilities all of them left there (a workgroup barrier lies between the two).
+template <int KV_AUX, class F, int PART = 0, int SPW = 16>
 __device__ __forceinline__ void attention_packed128(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, const F f) {
   constexpr int D = 256, DH = 32, H = D / DH;
   constexpr int KQ = F::KQ, VQ = F::VQ, VK = F::VK, NV = F::NVL;
@@ -445,14 +448,18 @@ __device__ __forceinline__ void attention_packed128(AttnRow r, int lane, lcf_ptr
   const int koff0 = j0 < lenf ? j0 * 16 : kPastDescriptor;
   const int koff1 = j1 < lenf ? j1 * 16 : kPastDescriptor;
   const int voff = lane * 16;
+  const int h_first = PART == 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) / SPW : 0;
+  constexpr int h_step = PART == 1 ? 16 / SPW : 1;
+  if constexpr (PART != 2) {
   v4i ka[KQ], kb[KQ];
   auto load_k = [&](v4i(&kq)[KQ], int h, int koff) {
 #pragma unroll
     for (int i = 0; i < KQ; ++i)
       kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((KQ * h + i) * S) * 16, KV_AUX));
   };
-  load_k(ka, 0, koff0);
-  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
+  load_k(ka, h_first, koff0);
+  {  // c_h of every head -> hsum[8 + h] (the sentence's scratch; read back wave-uniformly in pass h -- sharing waves all write
+     // the same eight values)
     float ckh[4];
     head_constants32(r.qrow, pbk, lane, ckh);
     if ((lane & 31) == 0) {
@@ -465,7 +472,7 @@ __device__ __forceinline__ void attention_packed128(AttnRow r, int lane, lcf_ptr
     __builtin_amdgcn_sched_barrier(0);
     float s0 = 0.0f, s1 = 0.0f;  // this lane's two keys against head h: the ascending-column fmaf chains t_j
     f.dot32(ka, r.qrow, h * DH, s0);
-    if (!last) load_k(ka, h + 1, koff0);  // (the last head requests nothing it would have to wait out again)
+    if (!last) load_k(ka, h + h_step, koff0);  // (the last head requests nothing it would have to wait out again)
     __builtin_amdgcn_sched_barrier(0);
     f.dot32(kb, r.qrow, h * DH, s1);
     const float ch = r.hsum[8 + h];
@@ -489,25 +496,30 @@ __device__ __forceinline__ void attention_packed128(AttnRow r, int lane, lcf_ptr
     const float ps = wave_sum(p0 + p1);  // P_h: lane L adds keys L and L + 64, then the butterfly
     if (lane == 0) r.hsum[h] = ps;
   };
+  {
+    int h = h_first;
 #pragma unroll 1
-  for (int h = 0; h < H - 1; ++h) head(h, false);
-  head(H - 1, true);
+    for (; h + h_step < H; h += h_step) head(h, false);
+    head(h, true);
+  }
+  if (r.align) {  // head 0 over the sentence's own keys (update_alignment, Model.cc:84-108)
+    if (j0 < len) r.align[j0] = r.pbuf[j0];
+    if (j1 < len) r.align[j1] = r.pbuf[j1];
+  }
+  if (r.attn) {
+    for (int h = h_first; h < H; h += h_step) {
+      if (j0 < S) r.attn[(size_t)h * S + j0] = r.pbuf[h * 128 + j0];
+      if (j1 < S) r.attn[(size_t)h * S + j1] = r.pbuf[h * 128 + j1];
+    }
+  }
+  }  // PART != 2
+  if constexpr (PART == 1) return;
   v4i vq[NV][VQ];  // V key groups in flight
   auto load_v = [&](v4i(&vv)[VQ], int g) {  // rows VK g .. VK g + VK - 1 (past the descriptor: zeros)
 #pragma unroll
     for (int i = 0; i < VQ; ++i)
       vv[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, (VQ * g + i) * 1024, KV_AUX));
   };
-  if (r.align) {  // head 0 over the sentence's own keys (update_alignment, Model.cc:84-108)
-    if (j0 < len) r.align[j0] = r.pbuf[j0];
-    if (j1 < len) r.align[j1] = r.pbuf[j1];
-  }
-  if (r.attn) {
-    for (int h = 0; h < H; ++h) {
-      if (j0 < S) r.attn[(size_t)h * S + j0] = r.pbuf[h * 128 + j0];
-      if (j1 < S) r.attn[(size_t)h * S + j1] = r.pbuf[h * 128 + j1];
-    }
-  }
   __builtin_amdgcn_sched_barrier(0);
   // the groups are requested in the order the loop re-requests them, nothing else behind them: the pending-load order at
   // the loop head is then the same from both of its entries (exact waits)
@@ -751,14 +763,15 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
 // ---- one entry point per SHAPE: 0 = sentences of up to 32 tokens, 1 = 33..64, 2 = 65..128 (D = 256), 3 = D = 512 (up to 32) --
 // c0 / c1: the layer's constants in LDS -- the K / V projections' prepared biases [D] (SHAPE 3: c0 = [K pb | K c127 | V pb |
 // V c127][D], c1 unused).
-template <int SHAPE, int KV_AUX, class F>
+template <int SHAPE, int KV_AUX, class F, int PART = 0, int SPW = 16>
 __device__ __forceinline__ void attention_packed(AttnRow r, int lane, lcf_ptr c0, lcf_ptr c1, const F f) {
+  static_assert(PART == 0 || SHAPE == 2, "shared heads: the 65..128-token reader");
   if constexpr (SHAPE == 0)
     attention_packed32<KV_AUX>(r, lane, c0, c1, f);
   else if constexpr (SHAPE == 1)
     attention_packed64<KV_AUX>(r, lane, c0, c1, f);
   else if constexpr (SHAPE == 2)
-    attention_packed128<KV_AUX>(r, lane, c0, c1, f);
+    attention_packed128<KV_AUX, F, PART, SPW>(r, lane, c0, c1, f);
   else if constexpr (F::BITS == 24)
     attention_row24_64<KV_AUX>(r, lane, c0, f.uk, f.uv);
   else

@@ -1047,14 +1047,24 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #define SLIMT_SUB_S(rr) (n_sub ? a.sub[SLIMT_SW(rr)].S : S)
   bool live[RT], finished[RT];
   uint32_t n_out[RT];
+  // Sentences of 65..128 tokens in a 4-sentence workgroup: the waves that own no sentence share the score passes of the
+  // sentence in slot wave % 4 with its owner (heads wave / 4 and + 4; attention_packed128<PART>): they know its index, length
+  // and cache forms, and nothing else of it. Four sentences per workgroup is what the engine picks while CUs would idle
+  // (adaptive rows): there the shared passes are worth 9 % (one to four contexts of 64 such sentences: 13.2 -> 12.0 ms per
+  // batch). At 8 per workgroup -- what it picks under the 20-worker load, where these sentences wait for their K/V bytes, not
+  // for their instructions -- sharing cost 2 %: not shared there (profiles/r06_shared_score_passes.txt).
+  constexpr bool SHARE = MID == 2 && SPW == 4;
+  const bool sharer = SHARE && wave >= SPW;
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
-    bq[rr] = m0 + 16 * rr + wave;
+    bq[rr] = m0 + 16 * rr + (sharer ? (wave & (SPW - 1)) : wave);
     live[rr] = row_wave && bq[rr] < Bv;
     // this sentence's sub-batch: its first global sentence, the row length of its outputs (its own padded length's
     // limit, Model.cc:159-161), the width of its alignment rows, the steps it runs at most
     sw[rr] = n_sub && live[rr] ? __builtin_amdgcn_readfirstlane(merge_find(a.sub, n_sub, bq[rr])) : 0;
-    len[rr] = live[rr] ? checked_length(n_sub ? a.sub[sw[rr]].lengths[bq[rr] - SLIMT_SUB_FIRST(rr)] : a.lengths[bq[rr]], S) : 0;
+    len[rr] = live[rr] || (sharer && bq[rr] < Bv)
+                  ? checked_length(n_sub ? a.sub[sw[rr]].lengths[bq[rr] - SLIMT_SUB_FIRST(rr)] : a.lengths[bq[rr]], S)
+                  : 0;
     finished[rr] = !live[rr];
     n_out[rr] = 0;
   }
@@ -1066,7 +1076,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
   for (int rr = 0; rr < RT; ++rr) {
     kv_wide[rr] = 0xffu;
     if constexpr (KV24 && KV20) {
-      if (a.kv_fmt && live[rr]) {
+      if (a.kv_fmt && (live[rr] || (sharer && bq[rr] < Bv))) {
         unsigned w = 0;
         for (int l = 0; l < Ld; ++l) {
           const unsigned f = a.kv_fmt[(size_t)l * B + bq[rr]];
@@ -1261,6 +1271,86 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       lds_barrier();
       SLIMT_STAMP(sb + 3);
       // SDPA over the cached K/V of this wave's sentence(s); output quantised into A1
+      if constexpr (SHARE) {
+        // 65..128 tokens, 4 sentences per workgroup: a sentence's score passes are half of its attention and 12 waves own no
+        // sentence -- the four waves of slot wave % 4 take two heads each (PART 1), a barrier, the owner runs
+        // the context pass (PART 2; per column a chain over all keys in order: nothing to share). The form the kernel is
+        // built around only: a sentence-layer in a wider form is its owner's alone, through the fallback call, as before.
+        const int row = wave & (SPW - 1);
+        const int b = bq[0];
+        const bool mine = live[0], part_of = mine || (sharer && b < Bv);
+        AttnRow ar;
+        bool shared = false;
+        const bool kv_streams = 8 * l + (b & 7) >= a.kv_temporal_eighths;
+        const lcf_ptr c0 = (lcf_ptr)(kvpb + (KVC * l) * D), c1 = (lcf_ptr)(kvpb + (KVC * l + 1) * D);
+        const Form24 f24 = {a.kv_u256[l][0], a.kv_u256[l][1]};
+        const Form20 f20 = {a.kv_u4096[l][0], a.kv_u4096[l][1]};
+        const Form16<CentreLds, CentreLds> f16 = {a.kv_u[l][0], a.kv_u[l][1], {(lcf_ptr)(kvc127 + (2 * l) * D)}, {(lcf_ptr)(kvc127 + (2 * l + 1) * D)}};
+#define SLIMT_ATTN(FN, FORM, PART)                                       \
+  do {                                                                   \
+    if (NT && kv_streams)                                                \
+      FN<2, SLIMT_KV_AUX_NT, decltype(FORM), PART, SPW>(ar, lane, c0, c1, FORM);   \
+    else                                                                 \
+      FN<2, SLIMT_KV_AUX_KEEP, decltype(FORM), PART, SPW>(ar, lane, c0, c1, FORM); \
+  } while (0)
+#define SLIMT_ATTN_COLD(FORM)                                            \
+  do {                                                                   \
+    if (NT && kv_streams)                                                \
+      attention_packed_cold<2, SLIMT_KV_AUX_NT>(ar, lane, c0, c1, FORM); \
+    else                                                                 \
+      attention_packed_cold<2, SLIMT_KV_AUX_KEEP>(ar, lane, c0, c1, FORM); \
+  } while (0)
+        const unsigned forms = kv_wide[0];
+        const bool wide = KV20 && ((forms >> l) & 1u);
+        const bool tight = KVI == 16 && ((forms >> (8 + l)) & 1u);
+        if (part_of) {
+          ar.kl = (gcf_ptr)((const SLIMT_GLOBAL char *)(a.kv + (size_t)(2 * l) * B * S * D) + (size_t)EXP_SENT(b) * S * D * 3);
+          ar.vl = (gcf_ptr)((const SLIMT_GLOBAL char *)(a.kv + (size_t)(2 * l + 1) * B * S * D) + (size_t)EXP_SENT(b) * ((S + 3) & ~3) * D * 3);
+          ar.qrow = (lcf_ptr)(xs + row * LDF);
+          ar.arow = (lc_ptr)(A1 + row * LDA);
+          ar.pbuf = (SLIMT_LDS float *)(pbufs + row * PBW);
+          ar.hsum = (SLIMT_LDS float *)(red_v + row * R);
+          ar.pbk = (gcf_ptr)a.kv_pb[l][0];
+          ar.pbv = (gcf_ptr)a.kv_pb[l][1];
+          ar.uk = a.kv_u[l][0];
+          ar.uv = a.kv_u[l][1];
+          ar.S = S;
+          ar.len = len[0];
+          ar.alpha = a.alpha;
+          ar.aq_o = L.o.a_quant;
+          ar.attn = (a.attn && (l + 1 == Ld)) ? (gf_ptr)(a.attn + (size_t)b * H * S) : (gf_ptr) nullptr;
+          const bool want_align = mine && a.align && (l + 1 == Ld) && !finished[0] && ((int)n_out[0] < a.Tmax);
+          ar.align = want_align ? (gf_ptr)(a.align + ((size_t)b * a.Tmax + n_out[0]) * S) : (gf_ptr) nullptr;
+          shared = KVI == 24 ? true : KVI == 16 ? tight : !wide;  // the inlined form
+          if (shared) {
+            if constexpr (KVI == 24)
+              SLIMT_ATTN(attention_packed, f24, 1);
+            else if constexpr (KVI == 16)
+              SLIMT_ATTN(attention_packed, f16, 1);
+            else
+              SLIMT_ATTN(attention_packed, f20, 1);
+          } else if (mine) {
+            if (!wide)
+              SLIMT_ATTN_COLD(f20);
+            else
+              SLIMT_ATTN_COLD(f24);
+          }
+        } else if (row_wave) {
+#pragma unroll
+          for (int i = 0; i < KSD; ++i) A1[row * LDA + lane + 64 * i] = 0;
+        }
+        lds_barrier();  // every head's probabilities and P_h are in the sentence's scratch
+        if (mine && shared) {
+          if constexpr (KVI == 24)
+            SLIMT_ATTN(attention_packed, f24, 2);
+          else if constexpr (KVI == 16)
+            SLIMT_ATTN(attention_packed, f16, 2);
+          else
+            SLIMT_ATTN(attention_packed, f20, 2);
+        }
+#undef SLIMT_ATTN
+#undef SLIMT_ATTN_COLD
+      } else {
 #pragma unroll 1
       for (int rr = 0; rr < RT; ++rr) {
         const int row = 16 * rr + wave;
@@ -1346,6 +1436,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #pragma unroll
           for (int i = 0; i < KSD; ++i) A1[row * LDA + lane + 64 * i] = 0;
         }
+      }
       }
       Frags fo[1];  // this wave's sentences are done: O's fragments travel under the barrier wait
       stream_prologue<KSD, 1, NT_D>(L.o, wave, lane, fo);
