@@ -346,7 +346,8 @@ __device__ __forceinline__ void attention_packed32(AttnRow r, int lane, lcf_ptr 
 // ---- 33..64 tokens (written by encode_tall_kernel<., 4>) ---------------------------------------------------------------------
 // Lane = key, one head per score pass, the 64-column softmax in the canonical order (one element per lane, the 64-lane
 // butterfly), all heads' probabilities in LDS (pbuf [H][64]), then V as whole rows like the S <= 32 shape.
-template <int KV_AUX, class F>
+// PART / SPW: as for attention_packed128 below (1 = the score passes of heads wave / SPW, + 16 / SPW, ...; 2 = the context pass).
+template <int KV_AUX, class F, int PART = 0, int SPW = 16>
 __device__ __forceinline__ void attention_packed64(AttnRow r, int lane, lcf_ptr pbk, lcf_ptr pbv, const F f) {
   constexpr int D = 256, DH = 32, H = D / DH;
   constexpr int KQ = F::KQ, VQ = F::VQ, VK = F::VK, NVF = F::NVF, NG = 64 / VK;
@@ -361,14 +362,17 @@ __device__ __forceinline__ void attention_packed64(AttnRow r, int lane, lcf_ptr 
   const rsrc_t rv = make_rsrc((const float *)r.vl, (unsigned)(((__builtin_amdgcn_readfirstlane(lenf) + VK - 1) / VK) * (VQ * 1024)));
   const int koff = j < lenf ? jc * 16 : kPastDescriptor;
   const int voff = lane * 16;
+  const int h_first = PART == 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) / SPW : 0;
+  constexpr int h_step = PART == 1 ? 16 / SPW : 1;
+  if constexpr (PART != 2) {
   v4i kq[KQ];
   auto load_k = [&](int h) {
 #pragma unroll
     for (int i = 0; i < KQ; ++i)
       kq[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, ((KQ * h + i) * S) * 16, KV_AUX));
   };
-  load_k(0);
-  {  // c_h of every head -> hsum[8 + h] (this wave's scratch; read back wave-uniformly in pass h)
+  load_k(h_first);
+  {  // c_h of every head -> hsum[8 + h] (the sentence's scratch; read back wave-uniformly in pass h)
     float ckh[4];
     head_constants32(r.qrow, pbk, lane, ckh);
     if ((lane & 31) == 0) {
@@ -377,10 +381,10 @@ __device__ __forceinline__ void attention_packed64(AttnRow r, int lane, lcf_ptr 
     }
   }
 #pragma unroll 1
-  for (int h = 0; h < H; ++h) {
+  for (int h = h_first; h < H; h += h_step) {
     float t = 0.0f;
     f.dot32(kq, r.qrow, h * DH, t);
-    load_k(h + 1 < H ? h + 1 : h);  // the next head's keys travel under this head's softmax
+    load_k(h + h_step < H ? h + h_step : h);  // the next head's keys travel under this head's softmax
     __builtin_amdgcn_sched_barrier(0);
     float s = __builtin_fmaf(t, f.uk, r.hsum[8 + h]);
     if (r.alpha != 1.0f) s = r.alpha * s;
@@ -396,6 +400,8 @@ __device__ __forceinline__ void attention_packed64(AttnRow r, int lane, lcf_ptr 
     r.pbuf[h * 64 + j] = p;
     if (lane == 0) r.hsum[h] = ps;
   }
+  }  // PART != 2
+  if constexpr (PART == 1) return;
   v4i vq[NVF][VQ];  // V rows in flight
   auto load_v = [&](v4i(&vv)[VQ], int g) {  // rows VK g .. VK g + VK - 1
 #pragma unroll
@@ -765,11 +771,11 @@ __device__ __forceinline__ void attention_row24_64(AttnRow r, int lane, lcf_ptr 
 // V c127][D], c1 unused).
 template <int SHAPE, int KV_AUX, class F, int PART = 0, int SPW = 16>
 __device__ __forceinline__ void attention_packed(AttnRow r, int lane, lcf_ptr c0, lcf_ptr c1, const F f) {
-  static_assert(PART == 0 || SHAPE == 2, "shared heads: the 65..128-token reader");
+  static_assert(PART == 0 || SHAPE == 1 || SHAPE == 2, "shared heads: the 33..64- and the 65..128-token reader");
   if constexpr (SHAPE == 0)
     attention_packed32<KV_AUX>(r, lane, c0, c1, f);
   else if constexpr (SHAPE == 1)
-    attention_packed64<KV_AUX>(r, lane, c0, c1, f);
+    attention_packed64<KV_AUX, F, PART, SPW>(r, lane, c0, c1, f);
   else if constexpr (SHAPE == 2)
     attention_packed128<KV_AUX, F, PART, SPW>(r, lane, c0, c1, f);
   else if constexpr (F::BITS == 24)

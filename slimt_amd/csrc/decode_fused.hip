@@ -1047,13 +1047,13 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #define SLIMT_SUB_S(rr) (n_sub ? a.sub[SLIMT_SW(rr)].S : S)
   bool live[RT], finished[RT];
   uint32_t n_out[RT];
-  // Sentences of 65..128 tokens in a 4-sentence workgroup: the waves that own no sentence share the score passes of the
+  // Sentences of 33..128 tokens in a 4-sentence workgroup: the waves that own no sentence share the score passes of the
   // sentence in slot wave % 4 with its owner (heads wave / 4 and + 4; attention_packed128<PART>): they know its index, length
   // and cache forms, and nothing else of it. Four sentences per workgroup is what the engine picks while CUs would idle
   // (adaptive rows): there the shared passes are worth 9 % (one to four contexts of 64 such sentences: 13.2 -> 12.0 ms per
   // batch). At 8 per workgroup -- what it picks under the 20-worker load, where these sentences wait for their K/V bytes, not
   // for their instructions -- sharing cost 2 %: not shared there (profiles/r06_shared_score_passes.txt).
-  constexpr bool SHARE = MID == 2 && SPW == 4;
+  constexpr bool SHARE = !MG && MID >= 1 && SPW == 4;
   const bool sharer = SHARE && wave >= SPW;
 #pragma unroll
   for (int rr = 0; rr < RT; ++rr) {
@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
       SLIMT_STAMP(sb + 3);
       // SDPA over the cached K/V of this wave's sentence(s); output quantised into A1
       if constexpr (SHARE) {
-        // 65..128 tokens, 4 sentences per workgroup: a sentence's score passes are half of its attention and 12 waves own no
+        // 33..128 tokens, 4 sentences per workgroup: a sentence's score passes are half of its attention and 12 waves own no
         // sentence -- the four waves of slot wave % 4 take two heads each (PART 1), a barrier, the owner runs
         // the context pass (PART 2; per column a chain over all keys in order: nothing to share). The form the kernel is
         // built around only: a sentence-layer in a wider form is its owner's alone, through the fallback call, as before.
@@ -1289,16 +1289,16 @@ __global__ __launch_bounds__(1024) void decode_fused_kernel(FusedDecodeArgs a) {
 #define SLIMT_ATTN(FN, FORM, PART)                                       \
   do {                                                                   \
     if (NT && kv_streams)                                                \
-      FN<2, SLIMT_KV_AUX_NT, decltype(FORM), PART, SPW>(ar, lane, c0, c1, FORM);   \
+      FN<MID, SLIMT_KV_AUX_NT, decltype(FORM), PART, SPW>(ar, lane, c0, c1, FORM);   \
     else                                                                 \
-      FN<2, SLIMT_KV_AUX_KEEP, decltype(FORM), PART, SPW>(ar, lane, c0, c1, FORM); \
+      FN<MID, SLIMT_KV_AUX_KEEP, decltype(FORM), PART, SPW>(ar, lane, c0, c1, FORM); \
   } while (0)
 #define SLIMT_ATTN_COLD(FORM)                                            \
   do {                                                                   \
     if (NT && kv_streams)                                                \
-      attention_packed_cold<2, SLIMT_KV_AUX_NT>(ar, lane, c0, c1, FORM); \
+      attention_packed_cold<MID, SLIMT_KV_AUX_NT>(ar, lane, c0, c1, FORM); \
     else                                                                 \
-      attention_packed_cold<2, SLIMT_KV_AUX_KEEP>(ar, lane, c0, c1, FORM); \
+      attention_packed_cold<MID, SLIMT_KV_AUX_KEEP>(ar, lane, c0, c1, FORM); \
   } while (0)
         const unsigned forms = kv_wide[0];
         const bool wide = KV20 && ((forms >> l) & 1u);
